@@ -1,0 +1,263 @@
+"""CompiledModel: flat physics tables + the env's index tables, with (de)serialisation.
+
+``build_model`` = assemble_scene + compile_mjcf + the name->id reference tables
+the env logic needs (ref FurnitureEnv._get_reference furniture.py:2696-2721,
+FurnitureSawyerEnv._get_reference furniture_sawyer.py:157-212,
+FurnitureBaxterEnv._get_reference furniture_baxter.py:167-244).
+
+Two on-disk forms:
+* ``.npz``  -- what ships in ``furniture_amd/assets/compiled`` (generated from the
+  reference's MJCF assets by ``scripts/compile_assets.py``; the GPU box has no
+  /root/reference).
+* blob      -- ``to_blob()``: a self-describing little-endian byte string
+  (name table + raw arrays) that crosses the C-ABI in ``fsim_create``.
+"""
+
+import io
+import json
+import os
+import struct
+
+import numpy as np
+
+from . import assemble as _asm
+from . import compile as _cmp
+
+_COMPILED_DIR = os.path.join(os.path.dirname(os.path.dirname(__file__)), "assets", "compiled")
+
+BLOB_MAGIC = b"FSIMBLOB"
+BLOB_VERSION = 3
+MAX_ANGLES = 8
+
+
+class CompiledModel:
+    def __init__(self, arrays, meta):
+        self.arrays = arrays  # name -> ndarray
+        self.meta = meta      # json-able dict (names, strings)
+        for k, v in arrays.items():
+            setattr(self, k, v)
+        for k in ("nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "neq", "npair", "nM", "nparts"):
+            setattr(self, k, int(arrays["dims"][_DIMS.index(k)]))
+
+    # -- names -------------------------------------------------------------
+    def body_name2id(self, n):
+        return self.meta["body_names"].index(n)
+
+    def geom_name2id(self, n):
+        return self.meta["geom_names"].index(n)
+
+    def site_name2id(self, n):
+        return self.meta["site_names"].index(n)
+
+    def joint_name2id(self, n):
+        return self.meta["joint_names"].index(n)
+
+    # -- io ------------------------------------------------------------------
+    def save(self, path):
+        buf = dict(self.arrays)
+        buf["__meta__"] = np.frombuffer(json.dumps(self.meta).encode(), dtype=np.uint8)
+        np.savez_compressed(path, **buf)
+
+    @staticmethod
+    def load(path):
+        z = np.load(path, allow_pickle=False)
+        arrays = {k: z[k] for k in z.files if k != "__meta__"}
+        meta = json.loads(bytes(z["__meta__"]).decode())
+        return CompiledModel(arrays, meta)
+
+    def to_blob(self):
+        """magic, version, n, then n x {name[48], dtype(i32: 0=f64,1=i32), count(i64), offset(i64)}, data."""
+        names = sorted(self.arrays.keys())
+        head = 8 + 4 + 4 + len(names) * (48 + 4 + 4 + 8 + 8)
+        off = (head + 63) // 64 * 64
+        table, chunks = [], []
+        for n in names:
+            a = self.arrays[n]
+            if a.dtype.kind == "f":
+                a, code = np.ascontiguousarray(a, dtype="<f8"), 0
+            else:
+                a, code = np.ascontiguousarray(a, dtype="<i4"), 1
+            raw = a.tobytes()
+            table.append(struct.pack("<48siiqq", n.encode(), code, 0, a.size, off))
+            pad = (-len(raw)) % 64
+            chunks.append((off, raw + b"\0" * pad))
+            off += len(raw) + pad
+        out = io.BytesIO()
+        out.write(BLOB_MAGIC)
+        out.write(struct.pack("<ii", BLOB_VERSION, len(names)))
+        for t in table:
+            out.write(t)
+        out.write(b"\0" * (chunks[0][0] - out.tell() if chunks else 0))
+        for o, raw in chunks:
+            assert out.tell() == o
+            out.write(raw)
+        return out.getvalue()
+
+
+_DIMS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "neq", "npair", "nM", "nparts",
+         "nrobot_dof", "narm", "nconn", "ndof_action", "agent_code", "nrobot_geom", "npart_geom"]
+_AGENT_CODE = {"Sawyer": 0, "Baxter": 1, "Cursor": 2}
+
+
+def compiled_name(agent, furniture_name, control_type="impedance"):
+    ct = "torque" if control_type == "torque" else "vel"
+    return "%s__%s__%s" % (agent, furniture_name, ct)
+
+
+def load_compiled(agent, furniture_name, control_type="impedance"):
+    """Load the shipped tables; fall back to compiling from MJCF assets if available."""
+    path = os.path.join(_COMPILED_DIR, compiled_name(agent, furniture_name, control_type) + ".npz")
+    if os.path.exists(path):
+        return CompiledModel.load(path)
+    root = _asm.default_assets_root()
+    if root is None:
+        raise FileNotFoundError(
+            "no compiled model %s and no MJCF assets (set FURNITURE_ASSETS_ROOT)" % path)
+    return build_model(agent, furniture_name, control_type=control_type, assets_root=root)
+
+
+def build_model(agent, furniture_name, control_type="impedance", assets_root=None, move_speed=0.1):
+    assets_root = assets_root or _asm.default_assets_root()
+    root, info = _asm.assemble_scene(assets_root, agent, furniture_name, control_type, move_speed)
+    m = _cmp.compile_mjcf(root)
+    A = {}
+    for k, v in m.__dict__.items():
+        if isinstance(v, np.ndarray) and not k.startswith("_"):
+            A[k] = v
+    A["opt"] = np.array([m.timestep, m.gravity[0], m.gravity[1], m.gravity[2], m.impratio])
+
+    parts = info["part_names"]
+    nparts = len(parts)
+    part_body = np.array([m.body_names.index(p) for p in parts], dtype=np.int32)
+    part_jnt = np.array([m.joint_names.index(p) for p in parts], dtype=np.int32)
+    A["part_bodyid"] = part_body
+    A["part_qposadr"] = m.jnt_qposadr[part_jnt].astype(np.int32)
+    A["part_dofadr"] = m.jnt_dofadr[part_jnt].astype(np.int32)
+    A["part_siteid"] = np.array([m.site_names.index(p) for p in parts], dtype=np.int32)
+    body2part = -np.ones(m.nbody, dtype=np.int32)
+    body2part[part_body] = np.arange(nparts)
+    A["body_partid"] = body2part
+    A["part_hradius"] = np.array([info["horizontal_radius"][p] for p in parts])
+    init = np.zeros((nparts, 7))
+    has_init = np.zeros(nparts, dtype=np.int32)
+    for i, p in enumerate(parts):
+        if p in info["part_init_qpos"]:
+            init[i] = info["part_init_qpos"][p]
+            has_init[i] = 1
+        else:
+            init[i] = [0, 0, 0, 1, 0, 0, 0]
+    A["part_initqpos"], A["part_hasinit"] = init, has_init
+
+    # welds in part indices (order = XML order, drives _get_next_subtask furniture.py:2723-2736)
+    A["eq_part1"] = body2part[m.eq_obj1id].astype(np.int32) if m.neq else np.zeros(0, np.int32)
+    A["eq_part2"] = body2part[m.eq_obj2id].astype(np.int32) if m.neq else np.zeros(0, np.int32)
+
+    # geoms the env toggles
+    is_part_geom = np.array([body2part[b] >= 0 for b in m.geom_bodyid])
+    part_col = np.array([bool(is_part_geom[g] and "collision" in m.geom_names[g]) for g in range(m.ngeom)])
+    A["geom_is_partcol"] = part_col.astype(np.int32)
+    robot_names = set(info["contact_geoms"])
+    for g in info["grippers"].values():
+        robot_names.update(g["contact_geoms"])
+    robot_geom = np.array([(not is_part_geom[g]) and (m.geom_names[g] in robot_names) for g in range(m.ngeom)])
+    A["geom_is_robot"] = robot_geom.astype(np.int32)
+    A["floor_geomid"] = np.array([m.geom_names.index("FLOOR")], dtype=np.int32)
+
+    # finger role per geom: bit (2*arm) = left finger set, bit (2*arm+1) = right finger set
+    role = np.zeros(m.ngeom, dtype=np.int32)
+    arms = info["arms"]
+    for ai, arm in enumerate(arms):
+        g = info["grippers"][arm]
+        for n in g["left_finger_geoms"]:
+            role[m.geom_names.index(n)] |= 1 << (2 * ai)
+        for n in g["right_finger_geoms"]:
+            role[m.geom_names.index(n)] |= 1 << (2 * ai + 1)
+    A["geom_fingerrole"] = role
+
+    # robot joints (arm joints in robot order, then gripper joints per arm)
+    jq = lambda names: np.array([m.jnt_qposadr[m.joint_names.index(n)] for n in names], dtype=np.int32)
+    jd = lambda names: np.array([m.jnt_dofadr[m.joint_names.index(n)] for n in names], dtype=np.int32)
+    A["arm_qposadr"], A["arm_dofadr"] = jq(info["joints"]), jd(info["joints"])
+    gj = []
+    ginit = []
+    for arm in arms:
+        gj += info["grippers"][arm]["joints"]
+        ginit += list(info["grippers"][arm]["init_qpos"])
+    A["grip_qposadr"], A["grip_dofadr"] = jq(gj), jd(gj)
+    A["arm_initqpos"] = np.asarray(info["init_qpos"], dtype=np.float64)
+    A["grip_initqpos"] = np.asarray(ginit, dtype=np.float64)
+    if arms:
+        A["eef_siteid"] = np.array([m.site_names.index(info["grippers"][a]["grip_site"]) for a in arms], dtype=np.int32)
+        A["hand_bodyid"] = np.array([m.body_names.index(a + "_hand") for a in arms], dtype=np.int32)
+    else:
+        A["eef_siteid"] = np.zeros(0, np.int32)
+        A["hand_bodyid"] = np.zeros(0, np.int32)
+    if agent == "Cursor":
+        A["cursor_bodyid"] = np.array([m.body_names.index("cursor0"), m.body_names.index("cursor1")], dtype=np.int32)
+        A["cursor_geomid"] = np.array([m.geom_names.index("cursor0"), m.geom_names.index("cursor1")], dtype=np.int32)
+
+    # connector sites (ref furniture.py:955-988, 1065-1067): pair key = name.split(",")[0].split("-")
+    conn = [s for s in range(m.nsite) if "conn_site" in m.site_names[s]]
+    keys = {}
+
+    def key_id(tok):
+        return keys.setdefault(tok, len(keys))
+
+    cs_site, cs_part, cs_a, cs_b, cs_nang, cs_ang = [], [], [], [], [], []
+    for s in conn:
+        nm = m.site_names[s]
+        toks = nm.split(",")[0].split("-")
+        cs_site.append(s)
+        cs_part.append(body2part[m.site_bodyid[s]])
+        # names are "<A>-<B>,..."; anything else can never satisfy pairs1 == pairs2[::-1] with 2 tokens
+        cs_a.append(key_id(toks[0]))
+        cs_b.append(key_id(toks[1]) if len(toks) > 1 else -1)
+        angs = [float(x) for x in nm.split(",")[1:-1] if x]
+        if len(angs) > MAX_ANGLES:
+            raise NotImplementedError("more than %d allowed angles on %s" % (MAX_ANGLES, nm))
+        cs_nang.append(len(angs))
+        cs_ang.append(angs + [0.0] * (MAX_ANGLES - len(angs)))
+    A["conn_siteid"] = np.array(cs_site, dtype=np.int32)
+    A["conn_partid"] = np.array(cs_part, dtype=np.int32)
+    A["conn_keya"] = np.array(cs_a, dtype=np.int32)
+    A["conn_keyb"] = np.array(cs_b, dtype=np.int32)
+    A["conn_nangle"] = np.array(cs_nang, dtype=np.int32)
+    A["conn_angles"] = np.array(cs_ang, dtype=np.float64).reshape(len(conn), MAX_ANGLES)
+
+    # action -> ctrl (ref furniture.py:3359-3367)
+    if m.nu:
+        cr = m.actuator_ctrlrange
+        A["ctrl_bias"] = 0.5 * (cr[:, 1] + cr[:, 0])
+        A["ctrl_weight"] = 0.5 * (cr[:, 1] - cr[:, 0])
+    else:
+        A["ctrl_bias"], A["ctrl_weight"] = np.zeros(0), np.zeros(0)
+
+    ndof_action = {"Sawyer": 9, "Baxter": 17, "Cursor": 15}[agent]
+    dims = dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
+                neq=m.neq, npair=m.npair, nM=m.nM, nparts=nparts,
+                nrobot_dof=len(A["arm_dofadr"]) + len(A["grip_dofadr"]), narm=len(arms), nconn=len(conn),
+                ndof_action=ndof_action, agent_code=_AGENT_CODE[agent],
+                nrobot_geom=int(robot_geom.sum()), npart_geom=int(part_col.sum()))
+    A["dims"] = np.array([dims[k] for k in _DIMS], dtype=np.int32)
+
+    meta = dict(agent=agent, furniture_name=furniture_name, control_type=control_type,
+                part_names=parts, arms=arms, body_names=m.body_names, joint_names=m.joint_names,
+                geom_names=m.geom_names, site_names=m.site_names, actuator_names=m.actuator_names,
+                has_recipe=info["recipe_path"] is not None, move_speed=move_speed,
+                conn_keys=sorted(keys, key=keys.get))
+    if info["recipe_path"] is not None:
+        meta["site_recipe"] = _read_site_recipe(info["recipe_path"])
+    return CompiledModel(A, meta)
+
+
+def _read_site_recipe(path):
+    """site_recipe entries [[site1, site2, angle?], ...] (ref util/__init__.py:54-61 loader)."""
+    import yaml
+
+    class _L(yaml.SafeLoader):
+        pass
+
+    _L.add_constructor("tag:yaml.org,2002:python/tuple", lambda l, n: list(l.construct_sequence(n)))
+    with open(path) as f:
+        rec = yaml.load(f, Loader=_L)
+    return [list(x) for x in rec.get("site_recipe", [])]

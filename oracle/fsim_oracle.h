@@ -1,0 +1,49 @@
+/* fsim_oracle.h -- CPU restatement (double precision, one env) of the physics the
+ * reference reaches through mujoco-py (sim.forward()/sim.step(), furniture/env/furniture.py:2857-2879).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in furniture_amd/ may link or call this;
+ * it is the checker for the HIP path (tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py).
+ *
+ * PARITY UNPINNED: MuJoCo 2.0 (closed binary, un-vendored: README.md:44,
+ * requirements.txt:12) is absent from /root/reference and from this image and the
+ * reference ships no numeric tests for this path.  The pipeline
+ * below restates MuJoCo's *published* computation (kinematics, CRB, RNE, soft
+ * constraint model with solref/solimp impedance, elliptic cones, PGS dual solver,
+ * semi-implicit Euler with implicit joint damping) and is pinned only by analytic
+ * invariants (tests/test_oracle_physics.py) and by the reference's MJCF geometry.
+ */
+#ifndef FSIM_ORACLE_H
+#define FSIM_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct osim osim_t;
+
+osim_t *osim_create(const void *model_blob, size_t nbytes);
+void osim_destroy(osim_t *);
+const char *osim_last_error(void);
+
+/* named views into the simulator's own memory (mujoco_py-style in-place access) */
+double *osim_dptr(osim_t *, const char *name, int *count);
+int32_t *osim_iptr(osim_t *, const char *name, int *count);
+
+void osim_reset_data(osim_t *);          /* sim.reset(): qpos=qpos0, everything else 0 */
+void osim_forward(osim_t *);             /* sim.forward() */
+int osim_step(osim_t *);                 /* sim.step(); !=0 -> unstable (MujocoException analogue) */
+void osim_site_vel(osim_t *, int site, double *velp3, double *velr3); /* data.site_xvelp/xvelr */
+void osim_body_jac(osim_t *, int body, const double *point3, double *jacp_3xnv, double *jacr_3xnv);
+void osim_full_M(osim_t *, double *M_nvxnv);
+
+/* solver knobs: iterations, tolerance (<=0: fixed iterations), order (0 canonical) */
+void osim_set_solver(osim_t *, int iterations, double tolerance);
+int osim_last_solver_iters(osim_t *);
+void osim_set_solver_kind(osim_t *, int kind); /* 0 = PGS (dual), 1 = Newton (primal, MuJoCo default) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
