@@ -1,0 +1,513 @@
+// fsim.hip -- libfsim.so: kernels + host side + the C-ABI of include/fsim.h.
+//
+// One HIP workgroup = one wavefront (64 lanes) = one environment.  The env's state record is
+// streamed HBM -> LDS once per launch, all n_substeps physics steps (and the env logic around
+// them) run out of LDS, and the record is streamed back: compulsory traffic only.
+// Workgroup b lands on XCD b % 8; envs are independent and the model tables are read-only, so
+// every XCD keeps its own L2 copy of the (tens of KB) model and no cross-XCD coherence is needed.
+#include "../../include/fsim.h"
+#include "fsim_env.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512];
+extern "C" const char *fsim_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL(FSIM_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------------------------------ kernels
+struct KParams {
+  int n_envs, n_substeps, mode; // mode: 0 physics step, 1 forward only
+  int newton_maxit;
+  float newton_tol;
+};
+
+__device__ __forceinline__ void load_record(float *L, const float *rec, int n, int lane) {
+  for (int i = lane; i < n; i += 64) L[i] = rec[i];
+}
+__device__ __forceinline__ void store_record(float *rec, const float *L, int n, int lane) {
+  for (int i = lane; i < n; i += 64) rec[i] = L[i];
+}
+
+__global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
+  extern __shared__ float L[];
+  const DModel &m = *mp;
+  const Layout &ly = *lp;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= kp.n_envs) return;
+  float *rec = state + (size_t)env * ly.stride;
+  load_record(L, rec, ly.stride, lane);
+  if (lane < 16) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  SYNC();
+  Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
+  if (kp.mode == 1) fs_forward(c);
+  else
+    for (int s = 0; s < kp.n_substeps; s++) {
+      fs_forward(c);
+      fs_integrate(c);
+    }
+  // aux: [qacc nv][xpos 3nr][xquat 4nr][ncon, niter, overflow, bad][contact geoms 2*ncon_max]
+  if (aux) {
+    float *a = aux + (size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max);
+    for (int d = lane; d < m.nv; d += 64) a[d] = L[ly.x + d];
+    for (int i = lane; i < 3 * m.nr; i += 64) a[m.nv + i] = L[ly.xpos + i];
+    for (int i = lane; i < 4 * m.nr; i += 64) a[m.nv + 3 * m.nr + i] = L[ly.xquat + i];
+    int *ai = reinterpret_cast<int *>(a + m.nv + 7 * m.nr);
+    const int *scal = reinterpret_cast<const int *>(L + ly.scal);
+    if (lane == 0) { ai[0] = scal[SC_NCON]; ai[1] = scal[SC_NITER]; ai[2] = scal[SC_OVERFLOW]; ai[3] = scal[SC_BAD]; }
+    // ordered list of (geom1, geom2) original ids of listed contacts
+    if (lane == 0) {
+      int n = 0, nslot = scal[SC_NSLOT];
+      for (int s = 0; s < nslot; s++) {
+        const int *ri = reinterpret_cast<const int *>(L + ly.con + FSIM_CONW * s);
+        if (ri[C_ACTIVE]) { ai[4 + 2 * n] = m.cg_orig[ri[C_G1]]; ai[4 + 2 * n + 1] = m.cg_orig[ri[C_G2]]; n++; }
+      }
+      for (; n < ly.ncon_max; n++) { ai[4 + 2 * n] = -1; ai[4 + 2 * n + 1] = -1; }
+    }
+  }
+  SYNC();
+  store_record(rec, L, ly.stride, lane);
+}
+
+__global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
+                                                 float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
+                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step) {
+  extern __shared__ float L[];
+  const DModel &m = *mp;
+  const Layout &ly = *lp;
+  int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= kp.n_envs) return;
+  float *rec = state + (size_t)env * ly.stride;
+  load_record(L, rec, ly.stride, lane);
+  if (lane < 16) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  SYNC();
+  Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
+  EnvIO io;
+  io.action = action ? action + (size_t)env * cfg.dof_action : nullptr;
+  io.obs = obs ? obs + (size_t)env * cfg.obs_dim : nullptr;
+  io.reward = reward ? reward + env : nullptr;
+  io.done = done ? done + env : nullptr;
+  io.info = info ? info + (size_t)env * FSIM_INFO_DIM : nullptr;
+  io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * m.nparts : nullptr;
+  io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * m.narmj : nullptr;
+  io.n_noise = n_noise;
+  if (do_step) env_step(c, cfg, io);
+  else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
+  SYNC();
+  store_record(rec, L, ly.stride, lane);
+}
+
+// strided gather/scatter between the AoS env records and caller [n, dim] arrays
+__global__ void k_copy_field(float *state, int stride, int off, int dim, float *ext, int n_envs, int to_state) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_envs * dim) return;
+  int e = i / dim, k = i % dim;
+  if (to_state) state[(size_t)e * stride + off + k] = ext[i];
+  else ext[i] = state[(size_t)e * stride + off + k];
+}
+// geom_contype/conaffinity live per colliding geom; the C-ABI speaks original geom ids
+__global__ void k_copy_geommask(float *state, int stride, int off, int ncg, const int *cg_orig, int ngeom, int *ext, int n_envs, int to_state) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_envs * ncg) return;
+  int e = i / ncg, k = i % ncg;
+  int *st = reinterpret_cast<int *>(state + (size_t)e * stride + off) + k;
+  if (to_state) *st = ext[(size_t)e * ngeom + cg_orig[k]];
+  else ext[(size_t)e * ngeom + cg_orig[k]] = *st;
+}
+// body poses of ORIGINAL bodies from reduced-body poses
+__global__ void k_expand_bodies(const float *aux, int auxstride, int nv, int nr, int nbody, const int *body_red, const float *relpos,
+                                const float *relquat, float *xpos, float *xquat, int n_envs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_envs * nbody) return;
+  int e = i / nbody, b = i % nbody;
+  const float *a = aux + (size_t)e * auxstride;
+  int r = body_red[b];
+  V3 p = ldv3(a + nv + 3 * r);
+  Q4 q = ldq(a + nv + 3 * nr + 4 * r);
+  V3 pos = p + qrot(q, ldv3(relpos + 3 * b));
+  Q4 qq = qmul(q, ldq(relquat + 4 * b));
+  if (xpos) stv3(xpos + 3 * (size_t)i, pos);
+  if (xquat) stq(xquat + 4 * (size_t)i, qq);
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_t off; };
+
+struct fsim {
+  int device = 0, n_envs = 0;
+  hipStream_t stream = nullptr;
+  DModel m{};
+  Layout ly{};
+  fsim_config_t cfg{};
+  EnvCfg ecfg{};
+  void *d_model = nullptr;
+  DModel *d_m = nullptr;
+  Layout *d_ly = nullptr;
+  float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
+  int n_noise = 0;
+  int auxstride = 0, lds_bytes = 0;
+  std::vector<char> blob;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double acc_ms = 0;
+  int acc_n = 0;
+  bool timing_pending = false;
+  int nbody = 0, ngeom = 0;
+};
+
+struct Arena {
+  std::vector<char> host;
+  std::vector<std::pair<const void **, size_t>> fix;
+  template <class T> void add(const T **slot, const std::vector<T> &v) {
+    size_t off = (host.size() + 15) / 16 * 16;
+    host.resize(off + v.size() * sizeof(T) + 16);
+    if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+    fix.push_back({reinterpret_cast<const void **>(slot), off});
+  }
+};
+
+static const BlobEnt *blob_entry(const std::vector<char> &blob, const char *name) {
+  int32_t n;
+  memcpy(&n, blob.data() + 12, 4);
+  const BlobEnt *e = reinterpret_cast<const BlobEnt *>(blob.data() + 16);
+  for (int i = 0; i < n; i++)
+    if (strncmp(e[i].name, name, 48) == 0) return &e[i];
+  return nullptr;
+}
+static bool blob_f(const std::vector<char> &blob, const char *name, std::vector<float> &out) {
+  const BlobEnt *e = blob_entry(blob, name);
+  if (!e || e->code != 0 || (size_t)e->off + (size_t)e->count * 8 > blob.size()) { snprintf(g_err, sizeof g_err, "model blob: bad/missing f64 entry '%s'", name); return false; }
+  const double *p = reinterpret_cast<const double *>(blob.data() + e->off);
+  out.resize(e->count);
+  for (int64_t i = 0; i < e->count; i++) out[i] = (float)p[i];
+  return true;
+}
+static bool blob_i(const std::vector<char> &blob, const char *name, std::vector<int> &out) {
+  const BlobEnt *e = blob_entry(blob, name);
+  if (!e || e->code != 1 || (size_t)e->off + (size_t)e->count * 4 > blob.size()) { snprintf(g_err, sizeof g_err, "model blob: bad/missing i32 entry '%s'", name); return false; }
+  const int32_t *p = reinterpret_cast<const int32_t *>(blob.data() + e->off);
+  out.assign(p, p + e->count);
+  return true;
+}
+
+extern "C" void fsim_default_config(fsim_config_t *c) {
+  memset(c, 0, sizeof *c);
+  c->control_type = 0; c->n_substeps = 50; c->max_episode_steps = 2000; c->discrete_grip = 1; c->rescale_actions = 1;
+  c->auto_align = 1; c->num_connect_steps = 0; c->auto_reset = 1; c->solver_iterations = 100; c->reset_robot_after_attach = 0;
+  c->solver_tolerance = 1e-6f;
+  c->alignment_pos_dist = 0.1f; c->alignment_rot_dist_up = 0.9f; c->alignment_rot_dist_forward = 0.9f; c->alignment_project_dist = 0.3f;
+  c->ctrl_penalty_coef = 1e-3f; c->unstable_penalty_coef = 100.f; c->success_reward = 100.f; c->touch_reward = 10.f; c->pick_reward = 100.f;
+  c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3.f; c->agent_xyz_rand = 0.001f;
+}
+
+#define LF(field, name) do { std::vector<float> v_; if (!blob_f(s->blob, name, v_)) return FSIM_EINVAL; ar.add(&s->m.field, v_); } while (0)
+#define LI(field, name) do { std::vector<int> v_; if (!blob_i(s->blob, name, v_)) return FSIM_EINVAL; ar.add(&s->m.field, v_); } while (0)
+
+static int build_model(fsim *s) {
+  Arena ar;
+  std::vector<int> dims, rdims;
+  if (!blob_i(s->blob, "dims", dims) || !blob_i(s->blob, "rdims", rdims)) return FSIM_EINVAL;
+  std::vector<float> opt, trace;
+  if (!blob_f(s->blob, "opt", opt) || !blob_f(s->blob, "trace_M0", trace)) return FSIM_EINVAL;
+  DModel &m = s->m;
+  m.nq = dims[0]; m.nv = dims[1]; m.nu = dims[2]; m.nbody = dims[3]; m.ngeom = dims[5]; m.nsite = dims[6]; m.neq = dims[7];
+  m.nM = dims[9]; m.nparts = dims[10]; m.narm = dims[12]; m.nconn = dims[13]; m.agent = dims[15];
+  m.nr = rdims[0]; m.ntree = rdims[1]; m.ncg = rdims[2]; m.ncp = rdims[3]; m.maxdepth = rdims[4];
+  s->nbody = m.nbody; s->ngeom = m.ngeom;
+  m.timestep = opt[0]; m.gravity[0] = opt[1]; m.gravity[1] = opt[2]; m.gravity[2] = opt[3]; m.impratio = opt[4];
+  m.meaninertia_scale = 1.0f / fmaxf(trace[0], 1e-15f);
+  if (m.nv > 64) FAIL(FSIM_ENOMEM, "nv=%d > 64: the lane-per-row Newton factorisation supports at most 64 dofs", m.nv);
+  if (m.nr > 31) FAIL(FSIM_ENOMEM, "more than 31 moving bodies");
+  if (m.ncp > 65535) FAIL(FSIM_ENOMEM, "too many candidate pairs");
+  LI(r_parent, "r_parent"); LI(r_jtype, "r_jtype"); LI(r_qposadr, "r_qposadr"); LI(r_dofadr, "r_dofadr"); LI(r_dofnum, "r_dofnum");
+  LI(r_depth, "r_depth"); LI(r_tree, "r_tree"); LI(r_chainadr, "r_chainadr"); LI(r_chainlen, "r_chainlen"); LI(r_ancmask, "r_ancmask");
+  LF(r_pos, "r_pos"); LF(r_quat, "r_quat"); LF(r_jaxis, "r_jaxis"); LF(r_jpos, "r_jpos"); LF(r_mass, "r_mass"); LF(r_ipos, "r_ipos");
+  LF(r_inertia, "r_inertia"); LI(chain_dofs, "chain_dofs");
+  LI(tree_dofadr, "tree_dofadr"); LI(tree_dofnum, "tree_dofnum"); LI(tree_bodyadr, "tree_bodyadr"); LI(tree_bodynum, "tree_bodynum");
+  LI(dof_parent, "dof_parentid"); LI(dof_Madr, "dof_Madr"); LI(dof_rbody, "dof_rbody"); LI(dof_tree, "dof_tree"); LI(dof_qposadr, "dof_qposadr");
+  LI(M_i, "M_i"); LI(M_j, "M_j");
+  LF(dof_armature, "dof_armature"); LF(dof_damping, "dof_damping"); LF(dof_invweight0, "dof_invweight0");
+  LI(lim_dof, "lim_dof"); LF(lim_range, "lim_range"); LF(lim_margin, "lim_margin"); LF(lim_solref, "lim_solref"); LF(lim_solimp, "lim_solimp");
+  { std::vector<int> v; blob_i(s->blob, "lim_dof", v); m.nlim = (int)v.size(); }
+  LI(cg_body, "cg_body"); LI(cg_type, "cg_type"); LI(cg_condim, "cg_condim"); LI(cg_partid, "cg_partid"); LI(cg_fingerrole, "cg_fingerrole");
+  LI(cg_isfloor, "cg_isfloor"); LI(cg_isrobot, "cg_isrobot"); LI(cg_ispartcol, "cg_ispartcol"); LI(cg_orig, "cg_orig");
+  LI(cg_contype0, "cg_contype0"); LI(cg_conaffinity0, "cg_conaffinity0");
+  LF(cg_pos, "cg_pos"); LF(cg_mat, "cg_mat"); LF(cg_size, "cg_size"); LF(cg_rbound, "cg_rbound"); LF(cg_friction, "cg_friction");
+  LF(cg_solref, "cg_solref"); LF(cg_solimp, "cg_solimp"); LF(cg_margin, "cg_margin"); LF(cg_gap, "cg_gap"); LF(cg_solmix, "cg_solmix");
+  LF(cg_invweight, "cg_invweight");
+  LI(cp, "cp");
+  LI(s_body, "s_body"); LF(s_pos, "s_pos"); LF(s_quat, "s_quat");
+  {
+    // actuator -> dof / qpos addresses
+    std::vector<int> aj, jd, jq;
+    if (!blob_i(s->blob, "actuator_jntid", aj) || !blob_i(s->blob, "jnt_dofadr", jd) || !blob_i(s->blob, "jnt_qposadr", jq)) return FSIM_EINVAL;
+    std::vector<int> ad(aj.size()), aq(aj.size());
+    for (size_t i = 0; i < aj.size(); i++) { ad[i] = jd[aj[i]]; aq[i] = jq[aj[i]]; }
+    ar.add(&m.act_dof, ad); ar.add(&m.act_qpos, aq);
+  }
+  LI(act_ctrllimited, "actuator_ctrllimited"); LI(act_forcelimited, "actuator_forcelimited");
+  LF(act_gain, "actuator_gain"); LF(act_bias, "actuator_bias"); LF(act_ctrlrange, "actuator_ctrlrange"); LF(act_forcerange, "actuator_forcerange");
+  LF(act_gear, "actuator_gear"); LF(ctrl_bias, "ctrl_bias"); LF(ctrl_weight, "ctrl_weight");
+  LI(eq_rbody1, "eq_rbody1"); LI(eq_rbody2, "eq_rbody2"); LI(eq_part1, "eq_part1"); LI(eq_part2, "eq_part2");
+  LF(eq_solref, "eq_solref"); LF(eq_solimp, "eq_solimp"); LF(eq_invweight, "eq_invweight"); LF(eq_data0, "eq_data0"); LI(eq_active0, "eq_active0");
+  LI(part_rbody, "part_rbody"); LI(part_qposadr, "part_qposadr"); LI(part_dofadr, "part_dofadr"); LI(body_red, "body_red");
+  LF(body_relpos, "body_relpos"); LF(body_relquat, "body_relquat"); LF(part_mass, "part_mass");
+  LI(arm_qposadr, "arm_qposadr"); LI(arm_dofadr, "arm_dofadr"); LI(grip_qposadr, "grip_qposadr"); LI(grip_dofadr, "grip_dofadr");
+  LI(eef_siteid, "eef_siteid"); LI(hand_body, "hand_bodyid");
+  LF(arm_initqpos, "arm_initqpos"); LF(grip_initqpos, "grip_initqpos"); LF(qpos0, "qpos0");
+  { std::vector<int> v; blob_i(s->blob, "arm_qposadr", v); m.narmj = (int)v.size(); blob_i(s->blob, "grip_qposadr", v); m.ngripj = (int)v.size(); }
+  LI(conn_siteid, "conn_siteid"); LI(conn_partid, "conn_partid"); LI(conn_keya, "conn_keya"); LI(conn_keyb, "conn_keyb"); LI(conn_nangle, "conn_nangle");
+  LF(conn_angles, "conn_angles");
+  LI(part_site_adr, "part_site_adr"); LI(part_site_num, "part_site_num"); LI(part_sites, "part_sites");
+  HIPCHK(hipMalloc(&s->d_model, ar.host.size()));
+  HIPCHK(hipMemcpy(s->d_model, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice));
+  for (auto &f : ar.fix) *f.first = static_cast<char *>(s->d_model) + f.second;
+  return FSIM_OK;
+}
+
+static void build_layout(fsim *s, int ncon_max) {
+  const DModel &m = s->m;
+  Layout &ly = s->ly;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  ly.qpos = take(m.nq); ly.qvel = take(m.nv); ly.qaccws = take(m.nv); ly.qfrcbias = take(m.nv); ly.ctrl = take(m.nu);
+  ly.qfrcapp = take(m.nv); ly.xfrc = take(6 * m.nparts); ly.eqdata = take(7 * m.neq); ly.eqactive = take(m.neq);
+  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.num_connect_steps));
+  o = (o + 3) / 4 * 4;
+  ly.stride = o;
+  // LDS-only
+  ly.xpos = take(3 * m.nr); ly.xquat = take(4 * m.nr); ly.xmat = take(9 * m.nr); ly.xanchor = take(3 * m.nr); ly.xaxis = take(3 * m.nr);
+  ly.xipos = take(3 * m.nr); ly.com = take(3 * m.ntree);
+  ly.cvel = take(6 * m.nr); // read by constraint assembly AND by the observation (site velocities): never aliased
+  int hstart = o;
+  ly.cinert = take(10 * m.nr); ly.crb = take(10 * m.nr); ly.cdofdot = take(6 * m.nv); ly.cacc = take(6 * m.nr); ly.cfrc = take(6 * m.nr);
+  // H (Newton Hessian, packed lower triangle) is only live inside fs_solve, after the rigid-body temporaries
+  // above are dead, so it aliases them.
+  int nH = m.nv * (m.nv + 1) / 2;
+  ly.H = hstart;
+  if (hstart + nH > o) o = hstart + nH;
+  ly.cdof = take(6 * m.nv); ly.M = take(m.nM); ly.LD = take(m.nM); ly.Dinv = take(m.nv); ly.LDh = take(m.nM); ly.Dhinv = take(m.nv);
+  ly.smooth = take(m.nv); ly.asmooth = take(m.nv); ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
+  ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg); ly.surv = take(FSIM_MAXSURV);
+  ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
+  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(16);
+  ly.lds_words = o;
+  ly.ncon_max = ncon_max;
+}
+
+extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
+  if (!model_blob || nbytes < 64 || n_envs <= 0 || !out) FAIL(FSIM_EINVAL, "fsim_create: bad arguments");
+  if (memcmp(model_blob, "FSIMBLOB", 8) != 0) FAIL(FSIM_EINVAL, "fsim_create: not an FSIMBLOB");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(FSIM_ENODEV, "fsim_create: no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) FAIL(FSIM_EINVAL, "fsim_create: device %d out of range (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  fsim *s = new fsim();
+  s->device = device; s->n_envs = n_envs;
+  s->blob.assign(static_cast<const char *>(model_blob), static_cast<const char *>(model_blob) + nbytes);
+  if (cfg) s->cfg = *cfg; else fsim_default_config(&s->cfg);
+  int rc = build_model(s);
+  if (rc) { delete s; return rc; }
+  int ncon_max = 48;
+  if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
+  build_layout(s, ncon_max);
+  s->lds_bytes = s->ly.lds_words * 4;
+  if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
+  size_t sbytes = (size_t)n_envs * s->ly.stride * 4;
+  HIPCHK(hipMalloc(&s->d_state, sbytes));
+  s->auxstride = s->m.nv + 7 * s->m.nr + 4 + 2 * s->ly.ncon_max;
+  HIPCHK(hipMalloc(&s->d_aux, (size_t)n_envs * s->auxstride * 4));
+  HIPCHK(hipMemsetAsync(s->d_aux, 0, (size_t)n_envs * s->auxstride * 4, s->stream));
+  // initial record: qpos0, default masks, weld data, env block zero
+  {
+    std::vector<float> rec(s->ly.stride, 0.0f), q0, ed;
+    std::vector<int> ea, ct, ca;
+    blob_f(s->blob, "qpos0", q0); blob_f(s->blob, "eq_data0", ed); blob_i(s->blob, "eq_active0", ea);
+    blob_i(s->blob, "cg_contype0", ct); blob_i(s->blob, "cg_conaffinity0", ca);
+    memcpy(rec.data() + s->ly.qpos, q0.data(), q0.size() * 4);
+    if (!ed.empty()) memcpy(rec.data() + s->ly.eqdata, ed.data(), ed.size() * 4);
+    if (!ea.empty()) memcpy(rec.data() + s->ly.eqactive, ea.data(), ea.size() * 4);
+    memcpy(rec.data() + s->ly.contype, ct.data(), ct.size() * 4);
+    memcpy(rec.data() + s->ly.conaff, ca.data(), ca.size() * 4);
+    int *envw = reinterpret_cast<int *>(rec.data() + s->ly.env);
+    for (int p = 0; p < s->m.nparts; p++) envw[E_GROUP + p] = p;
+    std::vector<float> all((size_t)n_envs * s->ly.stride);
+    for (int e = 0; e < n_envs; e++) memcpy(all.data() + (size_t)e * s->ly.stride, rec.data(), s->ly.stride * 4);
+    HIPCHK(hipMemcpy(s->d_state, all.data(), sbytes, hipMemcpyHostToDevice));
+  }
+  env_fill_cfg(s->ecfg, s->cfg, s->m);
+  { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
+  HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout)));
+  HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
+  *out = s;
+  return FSIM_OK;
+}
+
+extern "C" void fsim_destroy(fsim_t *s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim, int32_t *info_dim,
+                         int32_t *stride) {
+  if (!s) FAIL(FSIM_EINVAL, "null handle");
+  if (nq) *nq = s->m.nq; if (nv) *nv = s->m.nv; if (nu) *nu = s->m.nu;
+  if (dof_action) *dof_action = s->ecfg.dof_action; if (obs_dim) *obs_dim = s->ecfg.obs_dim;
+  if (info_dim) *info_dim = FSIM_INFO_DIM; if (stride) *stride = s->ly.stride;
+  return FSIM_OK;
+}
+extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
+extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
+extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
+
+static KParams kparams(const fsim *s, int nsub, int mode) {
+  KParams kp;
+  kp.n_envs = s->n_envs; kp.n_substeps = nsub; kp.mode = mode; kp.newton_maxit = s->cfg.solver_iterations; kp.newton_tol = s->cfg.solver_tolerance;
+  return kp;
+}
+static void timing_begin(fsim *s) { hipEventRecord(s->ev0, s->stream); }
+static void timing_end(fsim *s) { hipEventRecord(s->ev1, s->stream); s->timing_pending = true; }
+static void timing_collect(fsim *s) {
+  if (!s->timing_pending) return;
+  hipEventSynchronize(s->ev1);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) { s->acc_ms += ms; s->acc_n++; }
+  s->timing_pending = false;
+}
+
+extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
+  if (!s || nsub < 0) FAIL(FSIM_EINVAL, "bad args");
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
+  HIPCHK(hipGetLastError());
+  return FSIM_OK;
+}
+extern "C" int fsim_physics_forward(fsim_t *s) {
+  if (!s) FAIL(FSIM_EINVAL, "bad args");
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
+  HIPCHK(hipGetLastError());
+  return FSIM_OK;
+}
+
+static int copy_field(fsim *s, int off, int dim, void *ext, int to_state) {
+  if (!ext || dim == 0) return FSIM_OK;
+  int n = s->n_envs * dim;
+  hipLaunchKernelGGL(k_copy_field, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_state, s->ly.stride, off, dim, static_cast<float *>(ext), s->n_envs, to_state);
+  HIPCHK(hipGetLastError());
+  return FSIM_OK;
+}
+static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
+  if (!s || !p) FAIL(FSIM_EINVAL, "null");
+  HIPCHK(hipSetDevice(s->device));
+  const DModel &m = s->m;
+  const Layout &ly = s->ly;
+  int rc;
+  if ((rc = copy_field(s, ly.qpos, m.nq, p->qpos, to_state))) return rc;
+  if ((rc = copy_field(s, ly.qvel, m.nv, p->qvel, to_state))) return rc;
+  if ((rc = copy_field(s, ly.qaccws, m.nv, p->qacc_warmstart, to_state))) return rc;
+  if ((rc = copy_field(s, ly.qfrcbias, m.nv, p->qfrc_bias, to_state))) return rc;
+  if ((rc = copy_field(s, ly.ctrl, m.nu, p->ctrl, to_state))) return rc;
+  if ((rc = copy_field(s, ly.qfrcapp, m.nv, p->qfrc_applied, to_state))) return rc;
+  if ((rc = copy_field(s, ly.xfrc, 6 * m.nparts, p->xfrc_applied, to_state))) return rc;
+  if ((rc = copy_field(s, ly.eqdata, 7 * m.neq, p->eq_data, to_state))) return rc;
+  if ((rc = copy_field(s, ly.eqactive, m.neq, p->eq_active, to_state))) return rc;
+  if ((rc = copy_field(s, ly.env + E_GROUP, m.nparts, p->group, to_state))) return rc;
+  for (int k = 0; k < 2; k++) {
+    int32_t *ext = k == 0 ? p->geom_contype : p->geom_conaffinity;
+    if (!ext) continue;
+    int n = s->n_envs * m.ncg;
+    hipLaunchKernelGGL(k_copy_geommask, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_state, ly.stride, k == 0 ? ly.contype : ly.conaff, m.ncg,
+                       m.cg_orig, s->ngeom, ext, s->n_envs, to_state);
+    HIPCHK(hipGetLastError());
+  }
+  if (!to_state) {
+    int as = s->auxstride;
+    if (p->qacc) HIPCHK(hipMemcpy2DAsync(p->qacc, m.nv * 4, s->d_aux, as * 4, m.nv * 4, s->n_envs, hipMemcpyDeviceToDevice, s->stream));
+    if (p->xpos || p->xquat) {
+      int n = s->n_envs * m.nbody;
+      hipLaunchKernelGGL(k_expand_bodies, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_aux, as, m.nv, m.nr, m.nbody, m.body_red, m.body_relpos,
+                         m.body_relquat, p->xpos, p->xquat, s->n_envs);
+      HIPCHK(hipGetLastError());
+    }
+    int ioff = m.nv + 7 * m.nr;
+    if (p->ncon) HIPCHK(hipMemcpy2DAsync(p->ncon, 4, s->d_aux + ioff, as * 4, 4, s->n_envs, hipMemcpyDeviceToDevice, s->stream));
+    if (p->solver_iters) HIPCHK(hipMemcpy2DAsync(p->solver_iters, 4, s->d_aux + ioff + 1, as * 4, 4, s->n_envs, hipMemcpyDeviceToDevice, s->stream));
+    if (p->contact_geoms)
+      HIPCHK(hipMemcpy2DAsync(p->contact_geoms, 2 * ly.ncon_max * 4, s->d_aux + ioff + 4, as * 4, 2 * ly.ncon_max * 4, s->n_envs, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return FSIM_OK;
+}
+extern "C" int fsim_get_state(fsim_t *s, const fsim_state_ptrs_t *dst) { return xfer_state(s, dst, 0); }
+extern "C" int fsim_set_state(fsim_t *s, const fsim_state_ptrs_t *src) { return xfer_state(s, src, 1); }
+
+extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise) {
+  if (!s || !part_qpos) FAIL(FSIM_EINVAL, "bad args");
+  HIPCHK(hipSetDevice(s->device));
+  const DModel &m = s->m;
+  size_t pw = (size_t)7 * m.nparts, nw = (size_t)n_noise * m.narmj;
+  if (!s->d_tab_parts) HIPCHK(hipMalloc(&s->d_tab_parts, (size_t)s->n_envs * pw * 4 + 16));
+  if (robot_noise && (!s->d_tab_noise || s->n_noise != n_noise)) {
+    if (s->d_tab_noise) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->d_tab_noise); s->d_tab_noise = nullptr; }
+    HIPCHK(hipMalloc(&s->d_tab_noise, (size_t)s->n_envs * nw * 4 + 16));
+    s->n_noise = n_noise;
+  }
+  if (!mask) {
+    HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->stream));
+    if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise, robot_noise, (size_t)s->n_envs * nw * 4, hipMemcpyHostToDevice, s->stream));
+  } else {
+    for (int e = 0; e < s->n_envs; e++) {
+      if (!mask[e]) continue;
+      HIPCHK(hipMemcpyAsync(s->d_tab_parts + e * pw, part_qpos + e * pw, pw * 4, hipMemcpyHostToDevice, s->stream));
+      if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise + e * nw, robot_noise + e * nw, nw * 4, hipMemcpyHostToDevice, s->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s->stream)); // host buffers may be reused by the caller right away
+  return FSIM_OK;
+}
+
+static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
+  HIPCHK(hipSetDevice(s->device));
+  timing_collect(s);
+  timing_begin(s);
+  hipLaunchKernelGGL(k_env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
+                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step);
+  hipError_t e = hipGetLastError();
+  timing_end(s);
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+extern "C" int fsim_reset(fsim_t *s, const uint8_t *mask_dev, float *obs_dev) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  if (!s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: call fsim_set_reset_tables first");
+  return launch_env(s, nullptr, obs_dev, nullptr, nullptr, nullptr, mask_dev, 0);
+}
+extern "C" int fsim_step(fsim_t *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info) {
+  if (!s || !action) FAIL(FSIM_EINVAL, "fsim_step: null handle/action");
+  if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step: auto_reset needs fsim_set_reset_tables");
+  return launch_env(s, action, obs, reward, done, info, nullptr, 1);
+}
+extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  timing_collect(s);
+  if (avg_ms) *avg_ms = s->acc_n ? s->acc_ms / s->acc_n : 0.0;
+  if (n) *n = s->acc_n;
+  s->acc_ms = 0; s->acc_n = 0;
+  return FSIM_OK;
+}

@@ -1,0 +1,402 @@
+// fsim_collide.hpp -- P3 collision for one env / one wave.
+//
+// lanes = colliding geoms (world poses), then lanes = candidate pairs (mask + bounding-sphere
+// broadphase, wave-ballot compaction in pair order => deterministic contact order), then
+// lanes = surviving pairs (primitive narrow phase).  Contact convention: frame row 0 = normal
+// from geom1 to geom2, dist < 0 = penetration, pos = midpoint (as read back by the env through
+// data.contact[i].geom1/geom2, furniture/env/furniture.py:500-513, 1298-1322).
+#pragma once
+#include "fsim_physics.hpp"
+
+enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_DIST = 13, C_INCM = 14, C_MU = 15, C_DIM = 16, C_B1 = 17, C_B2 = 18, C_G1 = 19,
+       C_G2 = 20, C_AREF = 21, C_DN = 24, C_DT = 25, C_JAR = 26, C_JP = 29 };
+enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8 };
+
+__constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
+
+struct Emit {
+  const Ctx &c;
+  int base, maxn, cg1, cg2;
+  float margin, gap;
+  __device__ Emit(const Ctx &c_, int b, int mx, int g1, int g2, float mg, float gp) : c(c_), base(b), maxn(mx), cg1(g1), cg2(g2), margin(mg), gap(gp) {}
+  DEV void operator()(int k, float dist, V3 pos, V3 n) const {
+    if (k >= maxn) return;
+    // exact slot allocation: one LDS atomic per emitted contact.  A single wave executes this code, so
+    // the allocation order is a deterministic function of the inputs (not of timing).
+    int *scal_ = c.I(c.ly.scal);
+    int slot = atomicAdd(&scal_[SC_NSLOT], 1);
+    if (slot >= c.ly.ncon_max) { scal_[SC_OVERFLOW] |= 2; return; }
+    const DModel &m = c.m;
+    float *r = c.L + c.ly.con + FSIM_CONW * slot;
+    int *ri = reinterpret_cast<int *>(r);
+    // frame: x = n, y, z  (mju_makeFrame convention)
+    V3 x = normalized(n);
+    V3 y = (x.y > -0.5f && x.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
+    y = normalized(y - x * dot(x, y));
+    V3 z = cross(x, y);
+    stv3(r + C_POS, pos);
+    stv3(r + C_FRAME, x); stv3(r + C_FRAME + 3, y); stv3(r + C_FRAME + 6, z);
+    r[C_DIST] = dist;
+    r[C_INCM] = margin - gap;
+    float mu = fmaxf(m.cg_friction[3 * cg1], m.cg_friction[3 * cg2]);
+    r[C_MU] = mu;
+    int dim = max(m.cg_condim[cg1], m.cg_condim[cg2]);
+    if (mu < 1e-15f) dim = 1;
+    ri[C_DIM] = dim;
+    ri[C_B1] = m.cg_body[cg1]; ri[C_B2] = m.cg_body[cg2];
+    ri[C_G1] = cg1; ri[C_G2] = cg2;
+    ri[C_ACTIVE] = 1;
+  }
+};
+
+// ---- narrow phase primitives ---------------------------------------------------------------
+DEV void np_plane_sphere(const Emit &e, V3 pp, const M3 &pR, V3 sp, float r) {
+  V3 n = colv(pR, 2);
+  float dist = dot(sp - pp, n) - r;
+  if (dist > e.margin) return;
+  e(0, dist, sp - n * (r + 0.5f * dist), n);
+}
+DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V3 size) {
+  V3 n = colv(pR, 2);
+  float dist0 = dot(bp - pp, n);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    V3 v = v3((i & 1) ? size.x : -size.x, (i & 2) ? size.y : -size.y, (i & 4) ? size.z : -size.z);
+    V3 cv = mulv(bR, v);
+    float ld = dot(n, cv);
+    if (dist0 + ld > e.margin || ld > 0) continue;
+    float d = dist0 + ld;
+    e(cnt, d, cv - n * (0.5f * d) + bp, n);
+    if (++cnt >= 4) return;
+  }
+}
+DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &cR, V3 size) {
+  V3 n = colv(pR, 2), axis = colv(cR, 2);
+  float prjaxis = dot(n, axis);
+  if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
+  float dist0 = dot(cp - pp, n);
+  V3 vec = axis * prjaxis - n;
+  float len2 = dot(vec, vec);
+  if (len2 >= 1e-12f) vec = vec * (size.x / sqrtf(len2));
+  else vec = colv(cR, 0) * size.x;
+  float prjvec = dot(vec, n);
+  axis = axis * size.y;
+  prjaxis *= size.y;
+  if (dist0 + prjaxis + prjvec > e.margin) return;
+  int cnt = 0;
+  float d = dist0 + prjaxis + prjvec;
+  e(cnt++, d, cp + vec + axis - n * (0.5f * d), n);
+  if (dist0 - prjaxis + prjvec <= e.margin) {
+    d = dist0 - prjaxis + prjvec;
+    e(cnt++, d, cp + vec - axis - n * (0.5f * d), n);
+  }
+  float prjvec1 = -0.5f * prjvec;
+  if (dist0 + prjaxis + prjvec1 <= e.margin) {
+    V3 v1 = normalized(cross(vec, axis)) * (size.x * 0.8660254038f);
+    d = dist0 + prjaxis + prjvec1;
+    e(cnt++, d, cp + v1 + axis - vec * 0.5f - n * (0.5f * d), n);
+    e(cnt++, d, cp - v1 + axis - vec * 0.5f - n * (0.5f * d), n);
+  }
+}
+DEV void np_sphere_sphere(const Emit &e, V3 p1, float r1, V3 p2, float r2) {
+  V3 d = p2 - p1;
+  float len = norm(d), dist = len - r1 - r2;
+  if (dist > e.margin) return;
+  V3 n = len < 1e-15f ? v3(1, 0, 0) : d * (1.0f / len);
+  e(0, dist, p1 + n * (r1 + 0.5f * dist), n);
+}
+DEV void np_sphere_local(const Emit &e, V3 sp, float r, const M3 &oR, V3 cl, V3 q, bool inside, V3 od, float pen) {
+  V3 nl;
+  float dist;
+  if (!inside) { float d; nl = normalized(q - cl, &d); dist = d - r; }
+  else { nl = -od; dist = -pen - r; }
+  if (dist > e.margin) return;
+  V3 n = mulv(oR, nl);
+  e(0, dist, sp + n * (r + 0.5f * dist), n);
+}
+DEV void np_sphere_box(const Emit &e, V3 sp, float r, V3 bp, const M3 &bR, V3 size) {
+  V3 cl = multv(bR, sp - bp);
+  V3 q = v3(fminf(fmaxf(cl.x, -size.x), size.x), fminf(fmaxf(cl.y, -size.y), size.y), fminf(fmaxf(cl.z, -size.z), size.z));
+  bool inside = (q.x == cl.x) && (q.y == cl.y) && (q.z == cl.z);
+  V3 od = v3(0, 0, 0);
+  float pen = 0;
+  if (inside) {
+    float px = size.x - fabsf(cl.x), py = size.y - fabsf(cl.y), pz = size.z - fabsf(cl.z);
+    pen = px; int kb = 0;
+    if (py < pen) { pen = py; kb = 1; }
+    if (pz < pen) { pen = pz; kb = 2; }
+    float sg = comp(cl, kb) >= 0 ? 1.0f : -1.0f;
+    od = v3(kb == 0 ? sg : 0, kb == 1 ? sg : 0, kb == 2 ? sg : 0);
+  }
+  np_sphere_local(e, sp, r, bR, cl, q, inside, od, pen);
+}
+DEV void np_sphere_cylinder(const Emit &e, V3 sp, float r, V3 cp, const M3 &cR, V3 size) {
+  V3 cl = multv(cR, sp - cp);
+  float rho = sqrtf(cl.x * cl.x + cl.y * cl.y), rc = size.x, h = size.y;
+  bool inside = (rho <= rc) && (fabsf(cl.z) <= h);
+  V3 od = v3(0, 0, 0), q = cl;
+  float pen = 0;
+  if (inside) {
+    float pr = rc - rho, pz = h - fabsf(cl.z);
+    if (pz < pr) { pen = pz; od.z = cl.z >= 0 ? 1.0f : -1.0f; }
+    else { pen = pr; if (rho > 1e-15f) { od.x = cl.x / rho; od.y = cl.y / rho; } else od.x = 1; }
+  } else {
+    float sc = rho > rc ? rc / rho : 1.0f;
+    q = v3(cl.x * sc, cl.y * sc, fminf(fmaxf(cl.z, -h), h));
+  }
+  np_sphere_local(e, sp, r, cR, cl, q, inside, od, pen);
+}
+
+// Sutherland-Hodgman clip of a convex polygon against  sgn*p[axis] <= lim
+DEV int np_clip(float (*poly)[2], int n, int axis, float lim, float sgn) {
+  float outp[16][2];
+  int mo = 0;
+  for (int i = 0; i < n; i++) {
+    float *a = poly[i], *b = poly[(i + 1) % n];
+    float da = sgn * a[axis] - lim, db = sgn * b[axis] - lim;
+    if (da <= 0) { outp[mo][0] = a[0]; outp[mo][1] = a[1]; mo++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      float t = da / (da - db);
+      outp[mo][0] = a[0] + t * (b[0] - a[0]); outp[mo][1] = a[1] + t * (b[1] - a[1]); mo++;
+    }
+    if (mo >= 15) break;
+  }
+  for (int i = 0; i < mo; i++) { poly[i][0] = outp[i][0]; poly[i][1] = outp[i][1]; }
+  return mo;
+}
+DEV float sz(V3 s, int k) { return comp(s, k); }
+DEV void np_box_box(const Emit &e, V3 p1, const M3 &R1, V3 s1, V3 p2, const M3 &R2, V3 s2) {
+  V3 A[3], B[3];
+  for (int k = 0; k < 3; k++) { A[k] = colv(R1, k); B[k] = colv(R2, k); }
+  V3 d = p2 - p1;
+  float margin = e.margin;
+  float AC[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) AC[i][j] = fabsf(dot(A[i], B[j])) + 1e-7f;
+  float best = -1e30f; int bestType = -1, bi = 0, bj = 0; V3 bestL = v3(0, 0, 0);
+  for (int i = 0; i < 3; i++) {
+    float t = dot(d, A[i]);
+    float sep = fabsf(t) - (sz(s1, i) + s2.x * AC[i][0] + s2.y * AC[i][1] + s2.z * AC[i][2]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; bestType = 0; bi = i; bestL = A[i] * (t < 0 ? -1.0f : 1.0f); }
+  }
+  for (int j = 0; j < 3; j++) {
+    float t = dot(d, B[j]);
+    float sep = fabsf(t) - (sz(s2, j) + s1.x * AC[0][j] + s1.y * AC[1][j] + s1.z * AC[2][j]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; bestType = 1; bj = j; bestL = B[j] * (t < 0 ? -1.0f : 1.0f); }
+  }
+  float bestE = -1e30f; int ei = 0, ej = 0; V3 eL = v3(0, 0, 0);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    V3 Lx = cross(A[i], B[j]);
+    float len = norm(Lx);
+    if (len < 1e-6f) continue;
+    Lx = Lx * (1.0f / len);
+    float t = dot(d, Lx), ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += sz(s1, k) * fabsf(dot(A[k], Lx)); rb += sz(s2, k) * fabsf(dot(B[k], Lx)); }
+    float sep = fabsf(t) - (ra + rb);
+    if (sep > margin) return;
+    if (sep > bestE) { bestE = sep; ei = i; ej = j; eL = Lx * (t < 0 ? -1.0f : 1.0f); }
+  }
+  if (bestE > best + 1e-6f + 0.05f * fabsf(best)) {
+    V3 n = eL, pa = p1, pb = p2;
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) pa = pa + A[k] * (dot(A[k], n) > 0 ? sz(s1, k) : -sz(s1, k));
+      if (k != ej) pb = pb + B[k] * (dot(B[k], n) > 0 ? -sz(s2, k) : sz(s2, k));
+    }
+    V3 w = pa - pb;
+    float b = dot(A[ei], B[ej]), dd = dot(A[ei], w), ee = dot(B[ej], w), den = 1 - b * b;
+    float sa = 0, tb = 0;
+    if (den > 1e-12f) { sa = (b * ee - dd) / den; tb = (ee - b * dd) / den; }
+    sa = fminf(fmaxf(sa, -sz(s1, ei)), sz(s1, ei));
+    tb = fminf(fmaxf(tb, -sz(s2, ej)), sz(s2, ej));
+    pa = pa + A[ei] * sa; pb = pb + B[ej] * tb;
+    e(0, bestE, (pa + pb) * 0.5f, n);
+    return;
+  }
+  V3 pr, pi_, sr, si, nr;
+  V3 *Rr, *Ri;
+  int ka;
+  if (bestType == 0) { pr = p1; pi_ = p2; sr = s1; si = s2; Rr = A; Ri = B; ka = bi; nr = bestL; }
+  else { pr = p2; pi_ = p1; sr = s2; si = s1; Rr = B; Ri = A; ka = bj; nr = -bestL; }
+  int kinc = 0; float mind = 1e30f, sgninc = 1;
+  for (int k = 0; k < 3; k++) { float t = dot(Ri[k], nr); if (-fabsf(t) < mind) { mind = -fabsf(t); kinc = k; sgninc = t > 0 ? -1.0f : 1.0f; } }
+  int k1 = (kinc + 1) % 3, k2 = (kinc + 2) % 3, u1 = (ka + 1) % 3, u2 = (ka + 2) % 3;
+  V3 fc = pi_ + Ri[kinc] * (sgninc * sz(si, kinc));
+  V3 rc = pr + nr * sz(sr, ka);
+  float poly[16][2];
+  const float cs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+  for (int q = 0; q < 4; q++) {
+    V3 v = fc + Ri[k1] * (cs[q][0] * sz(si, k1)) + Ri[k2] * (cs[q][1] * sz(si, k2));
+    V3 r = v - rc;
+    poly[q][0] = dot(r, Rr[u1]); poly[q][1] = dot(r, Rr[u2]);
+  }
+  int np = 4;
+  np = np_clip(poly, np, 0, sz(sr, u1), 1.0f);
+  if (np) np = np_clip(poly, np, 0, sz(sr, u1), -1.0f);
+  if (np) np = np_clip(poly, np, 1, sz(sr, u2), 1.0f);
+  if (np) np = np_clip(poly, np, 1, sz(sr, u2), -1.0f);
+  V3 ninc = Ri[kinc] * sgninc;
+  float denom = dot(ninc, nr);
+  V3 nout = bestType == 0 ? nr : -nr;
+  int cnt = 0;
+  float px[8][3];
+  for (int i = 0; i < np && cnt < 8; i++) {
+    V3 q = rc + Rr[u1] * poly[i][0] + Rr[u2] * poly[i][1];
+    float h = fabsf(denom) > 1e-9f ? dot(fc - q, ninc) / denom : 0.0f;
+    if (h > margin) continue;
+    V3 pos = q + nr * (0.5f * h);
+    bool dup = false;
+    for (int k = 0; k < cnt; k++) { V3 dv = pos - v3(px[k][0], px[k][1], px[k][2]); if (dot(dv, dv) < 1e-12f) dup = true; }
+    if (dup) continue;
+    px[cnt][0] = pos.x; px[cnt][1] = pos.y; px[cnt][2] = pos.z;
+    e(cnt, h, pos, nout);
+    cnt++;
+  }
+}
+
+// ---- Minkowski portal refinement for cylinder-box / cylinder-cylinder --------------------------
+struct Shape { int type; V3 pos; M3 R; V3 size; };
+DEV V3 np_support(const Shape &s, V3 dir) {
+  V3 dl = multv(s.R, dir), pl;
+  if (s.type == GT_BOX) pl = v3(dl.x >= 0 ? s.size.x : -s.size.x, dl.y >= 0 ? s.size.y : -s.size.y, dl.z >= 0 ? s.size.z : -s.size.z);
+  else if (s.type == GT_CYLINDER) {
+    float rho = sqrtf(dl.x * dl.x + dl.y * dl.y);
+    pl = rho > 1e-12f ? v3(dl.x / rho * s.size.x, dl.y / rho * s.size.x, 0) : v3(0, 0, 0);
+    pl.z = dl.z >= 0 ? s.size.y : -s.size.y;
+  } else {
+    float n = norm(dl);
+    pl = n > 1e-12f ? dl * (s.size.x / n) : v3(0, 0, 0);
+  }
+  return mulv(s.R, pl) + s.pos;
+}
+struct Sup { V3 v, a, b; };
+DEV Sup np_msup(const Shape &A, const Shape &B, V3 dir) { Sup s; s.a = np_support(A, -dir); s.b = np_support(B, dir); s.v = s.b - s.a; return s; }
+DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
+  Sup v0, v1, v2, v3_, v4;
+  v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
+  if (dot(v0.v, v0.v) < 1e-20f) v0.v.x = 1e-5f;
+  V3 n = normalized(-v0.v);
+  v1 = np_msup(A, B, n);
+  if (dot(v1.v, n) <= 0) return;
+  n = cross(v1.v, v0.v);
+  if (dot(n, n) < 1e-20f) {
+    n = normalized(v1.v - v0.v);
+    e(0, -dot(v1.v, n), (v1.a + v1.b) * 0.5f, -n);
+    return;
+  }
+  n = normalized(n);
+  v2 = np_msup(A, B, n);
+  if (dot(v2.v, n) <= 0) return;
+  n = cross(v1.v - v0.v, v2.v - v0.v);
+  if (dot(n, v0.v) > 0) { Sup t = v1; v1 = v2; v2 = t; n = -n; }
+  for (int it = 0;; it++) {
+    if (it > 64) return;
+    n = normalized(n);
+    v3_ = np_msup(A, B, n);
+    if (dot(v3_.v, n) <= 0) return;
+    if (dot(cross(v1.v, v3_.v), v0.v) < 0) { v2 = v3_; n = cross(v1.v - v0.v, v3_.v - v0.v); continue; }
+    if (dot(cross(v3_.v, v2.v), v0.v) < 0) { v1 = v3_; n = cross(v3_.v - v0.v, v2.v - v0.v); continue; }
+    break;
+  }
+  bool hit = false;
+  for (int it = 0; it < 64; it++) {
+    n = cross(v2.v - v1.v, v3_.v - v1.v);
+    float ln;
+    n = normalized(n, &ln);
+    if (ln < 1e-30f) return;
+    float dpl = dot(n, v1.v);
+    if (dpl >= 0) hit = true;
+    v4 = np_msup(A, B, n);
+    float delta = dot(v4.v, n) - dot(v3_.v, n);
+    if (dot(v4.v, n) < 0 && !hit) return;
+    if (delta <= 1e-6f || it == 63) {
+      if (!hit) return;
+      float b0 = dot(cross(v1.v, v2.v), v3_.v), b1 = dot(cross(v3_.v, v2.v), v0.v), b2 = dot(cross(v0.v, v1.v), v3_.v), b3 = dot(cross(v2.v, v1.v), v0.v);
+      float sum = b0 + b1 + b2 + b3;
+      if (sum <= 0) {
+        b0 = 0; b1 = dot(cross(v2.v, v3_.v), n); b2 = dot(cross(v3_.v, v1.v), n); b3 = dot(cross(v1.v, v2.v), n);
+        sum = b1 + b2 + b3;
+      }
+      float inv = 1.0f / sum;
+      V3 pa = (v0.a * b0 + v1.a * b1 + v2.a * b2 + v3_.a * b3) * inv;
+      V3 pb = (v0.b * b0 + v1.b * b1 + v2.b * b2 + v3_.b * b3) * inv;
+      e(0, -dpl, (pa + pb) * 0.5f, -n);
+      return;
+    }
+    V3 cr = cross(v4.v, v0.v);
+    if (dot(v1.v, cr) > 0) { if (dot(v2.v, cr) > 0) v1 = v4; else v3_ = v4; }
+    else { if (dot(v3_.v, cr) > 0) v2 = v4; else v1 = v4; }
+  }
+}
+
+// ---- driver ----------------------------------------------------------------------------------
+DEV void fs_collide(const Ctx &c) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int *scal = c.I(ly.scal);
+  for (int g = c.lane; g < m.ncg; g += 64) {
+    int b = m.cg_body[g];
+    M3 Rb = ldm3(L + ly.xmat + 9 * b);
+    stv3(L + ly.gpos + 3 * g, ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(m.cg_pos + 3 * g)));
+    stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(m.cg_mat + 9 * g)));
+  }
+  SYNC();
+  // broadphase + ordered compaction
+  int nsurv = 0;
+  int *surv = c.I(ly.surv);
+  const int *ctype = c.I(ly.contype), *caff = c.I(ly.conaff);
+  for (int p0 = 0; p0 < m.ncp; p0 += 64) {
+    int p = p0 + c.lane;
+    bool pass = false;
+    if (p < m.ncp) {
+      int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1];
+      if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
+        float margin = fmaxf(m.cg_margin[g1], m.cg_margin[g2]);
+        V3 d = ldv3(L + ly.gpos + 3 * g2) - ldv3(L + ly.gpos + 3 * g1);
+        if (m.cg_type[g1] == GT_PLANE) {
+          V3 n = v3(L[ly.gmat + 9 * g1 + 2], L[ly.gmat + 9 * g1 + 5], L[ly.gmat + 9 * g1 + 8]);
+          pass = dot(d, n) <= m.cg_rbound[g2] + margin;
+        } else {
+          float bound = m.cg_rbound[g1] + m.cg_rbound[g2] + margin;
+          pass = dot(d, d) <= bound * bound;
+        }
+      }
+    }
+    unsigned long long mask = __ballot(pass);
+    int idx = nsurv + __popcll(mask & ((1ull << c.lane) - 1ull));
+    if (pass && idx < FSIM_MAXSURV) surv[idx] = p;
+    nsurv += __popcll(mask);
+  }
+  if (nsurv > FSIM_MAXSURV) { nsurv = FSIM_MAXSURV; if (c.lane == 0) scal[SC_OVERFLOW] |= 1; }
+  SYNC();
+  if (c.lane == 0) { scal[SC_NSURV] = nsurv; scal[SC_NSLOT] = 0; }
+  SYNC();
+  for (int i = c.lane; i < nsurv; i += 64) {
+    int p = surv[i], base = 0;
+    int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1], pt = m.cp[3 * p + 2];
+    float margin = fmaxf(m.cg_margin[g1], m.cg_margin[g2]), gap = fmaxf(m.cg_gap[g1], m.cg_gap[g2]);
+    Emit e(c, base, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
+    V3 p1 = ldv3(L + ly.gpos + 3 * g1), p2 = ldv3(L + ly.gpos + 3 * g2);
+    M3 R1 = ldm3(L + ly.gmat + 9 * g1), R2 = ldm3(L + ly.gmat + 9 * g2);
+    V3 s1 = ldv3(m.cg_size + 3 * g1), s2 = ldv3(m.cg_size + 3 * g2);
+    switch (pt) {
+      case PT_PLANE_SPHERE: np_plane_sphere(e, p1, R1, p2, s2.x); break;
+      case PT_PLANE_BOX: np_plane_box(e, p1, R1, p2, R2, s2); break;
+      case PT_PLANE_CYL: np_plane_cylinder(e, p1, R1, p2, R2, s2); break;
+      case PT_SPHERE_SPHERE: np_sphere_sphere(e, p1, s1.x, p2, s2.x); break;
+      case PT_SPHERE_BOX: np_sphere_box(e, p1, s1.x, p2, R2, s2); break;
+      case PT_SPHERE_CYL: np_sphere_cylinder(e, p1, s1.x, p2, R2, s2); break;
+      case PT_BOX_BOX: np_box_box(e, p1, R1, s1, p2, R2, s2); break;
+      default: {
+        Shape A, B;
+        A.type = m.cg_type[g1]; A.pos = p1; A.R = R1; A.size = s1;
+        B.type = m.cg_type[g2]; B.pos = p2; B.R = R2; B.size = s2;
+        np_mpr(e, A, B);
+      }
+    }
+  }
+  SYNC();
+  if (c.lane == 0 && scal[SC_NSLOT] > ly.ncon_max) scal[SC_NSLOT] = ly.ncon_max;
+  SYNC();
+}

@@ -1,0 +1,605 @@
+// fsim_env.hpp -- FurnitureEnv.step()/reset() for ONE env on ONE wavefront (device side of the gym surface).
+//
+// Restates the env-level control flow of the reference on top of the physics in fsim_physics/solver:
+//   step            furniture/env/furniture.py:364-385, 405-449 ; furniture_sawyer.py:66-84 ; furniture_baxter.py:66-80
+//   _setup_action   furniture.py:3332-3379        _do_simulation furniture.py:2857-2897
+//   finger scan     furniture.py:1290-1330        _try_connect   furniture.py:926-1042
+//   _is_aligned     furniture.py:1057-1153        _connect       furniture.py:847-924
+//   _activate_weld  furniture.py:2761-2776        union-find     furniture.py:2738-2759
+//   _get_obs        furniture.py:1344-1387 ; furniture_sawyer.py:103-155 ; furniture_baxter.py:98-165
+//   _compute_reward furniture.py:482-541          _after_step    furniture.py:451-480
+//   _reset          furniture.py:1406-1663
+// Because a wave IS an env, every data-dependent branch of the state machine is wave-uniform: the decision
+// is taken by lane 0 on LDS state, published through LDS, and the physics sub-steps it triggers are executed
+// by all 64 lanes.
+#pragma once
+#include "fsim_solver.hpp"
+
+struct EnvCfg {
+  int dof_action, obs_dim, n_substeps, max_episode_steps, discrete_grip, rescale_actions, auto_align, auto_reset, has_recipe, agent;
+  float pos_dist, rot_up, rot_fwd, proj_dist, ctrl_penalty_coef, unstable_penalty_coef, success_reward, touch_reward, pick_reward;
+};
+struct EnvIO {
+  const float *action;
+  float *obs, *reward;
+  uint8_t *done;
+  int *info;
+  const float *tab_parts, *tab_noise;
+  int n_noise;
+};
+
+static inline int env_extra_words(const DModel &, int) { return 0; }
+
+static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
+  e.agent = m.agent;
+  e.dof_action = m.agent == 0 ? 9 : (m.agent == 1 ? 17 : 15);
+  e.obs_dim = 7 * m.nparts + 29 * m.narm;
+  e.n_substeps = c.n_substeps; e.max_episode_steps = c.max_episode_steps; e.discrete_grip = c.discrete_grip;
+  e.rescale_actions = c.rescale_actions; e.auto_align = c.auto_align; e.auto_reset = c.auto_reset;
+  e.has_recipe = 0;
+  e.pos_dist = c.alignment_pos_dist; e.rot_up = c.alignment_rot_dist_up; e.rot_fwd = c.alignment_rot_dist_forward; e.proj_dist = c.alignment_project_dist;
+  e.ctrl_penalty_coef = c.ctrl_penalty_coef; e.unstable_penalty_coef = c.unstable_penalty_coef; e.success_reward = c.success_reward;
+  e.touch_reward = c.touch_reward; e.pick_reward = c.pick_reward;
+}
+
+// ---------------------------------------------------------------------------------------------------- physics wrappers
+DEV void fs_touch_flags(const Ctx &c) {
+  // who touches whom, from the contact list of this forward pass (data.contact[0:ncon])
+  const DModel &m = c.m;
+  int *scal = c.I(c.ly.scal);
+  if (c.lane == 0) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; }
+  SYNC();
+  int nslot = scal[SC_NSLOT];
+  for (int s = c.lane; s < nslot; s += 64) {
+    const int *ri = c.I(c.ly.con + FSIM_CONW * s);
+    if (!ri[C_ACTIVE]) continue;
+    int g1 = ri[C_G1], g2 = ri[C_G2];
+    for (int k = 0; k < 2; k++) {
+      int ga = k ? g2 : g1, gb = k ? g1 : g2; // geom ga against the body of gb
+      int part = m.cg_partid[gb];
+      if (part < 0) continue;
+      int role = m.cg_fingerrole[ga];
+      // bits: arm*16 + part  (nparts <= 16, narm <= 2)
+      for (int arm = 0; arm < m.narm; arm++) {
+        if (role & (1 << (2 * arm))) atomicOr(&scal[SC_TOUCHL], 1 << (16 * arm + part));
+        if (role & (1 << (2 * arm + 1))) atomicOr(&scal[SC_TOUCHR], 1 << (16 * arm + part));
+      }
+      if (m.cg_isfloor[ga]) atomicOr(&scal[SC_TOUCHF], 1 << part);
+    }
+  }
+  SYNC();
+}
+
+// fs_forward / fs_integrate / env_reset are real (non-inlined) device functions: each is large and is called from
+// many places in the env state machine; one copy keeps the code object (and the build) small.
+__device__ __noinline__ void fs_forward(Ctx cv) {
+  FS_REBUILD_CTX(cv);
+  fs_kinematics(c);
+  fs_com_inertia(c);
+  fs_crb_factor(c);
+  fs_factor_all(c);
+  fs_collide(c);
+  fs_velocity_bias(c);
+  fs_smooth(c);
+  int coupled = fs_make_constraints(c);
+  fs_solve(c, coupled);
+  // instability guard (mj_checkAcc analogue): NaN / huge accelerations
+  int bad = 0;
+  for (int d = c.lane; d < c.m.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }
+  bad = wave_or(bad);
+  if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
+  SYNC();
+}
+DEV void fs_step(const Ctx &c) { fs_forward(c); fs_integrate(c); }
+
+// ---------------------------------------------------------------------------------------------------- helpers (lane-0 scalar code)
+DEV int env_find(int *grp, int i) {
+  int r = i;
+  while (grp[r] != r) r = grp[r];
+  while (grp[i] != r) { int n = grp[i]; grp[i] = r; i = n; }
+  return r;
+}
+DEV void env_site_pose(const Ctx &c, int site, V3 *pos, Q4 *quat, M3 *mat) {
+  const DModel &m = c.m;
+  int b = m.s_body[site];
+  Q4 qb = ldq(c.L + c.ly.xquat + 4 * b);
+  M3 Rb = ldm3(c.L + c.ly.xmat + 9 * b);
+  *pos = ldv3(c.L + c.ly.xpos + 3 * b) + mulv(Rb, ldv3(m.s_pos + 3 * site));
+  Q4 q = qmul(qb, ldq(m.s_quat + 4 * site));
+  if (quat) *quat = q;
+  if (mat) *mat = q2m(qnormalized(q));
+}
+DEV float env_cos(V3 a, V3 b) { return dot(a, b) / norm(a) / norm(b); }
+// lookat_to_quat(forward=f, up=u) -> wxyz   (ref transform_utils.py:457-512)
+DEV Q4 env_lookat(V3 fwd, V3 up) {
+  V3 f = normalized(fwd);
+  V3 s = normalized(cross(normalized(up), f));
+  V3 u = cross(f, s);
+  float m00 = s.x, m01 = s.y, m02 = s.z, m10 = u.x, m11 = u.y, m12 = u.z, m20 = f.x, m21 = f.y, m22 = f.z;
+  float tr = (m00 + m11) + m22, x, y, z, w;
+  if (tr > 0) { float n = sqrtf(tr + 1); w = n * 0.5f; n = 0.5f / n; x = (m12 - m21) * n; y = (m20 - m02) * n; z = (m01 - m10) * n; }
+  else if (m00 >= m11 && m00 >= m22) { float n = sqrtf(((1 + m00) - m11) - m22), k = 0.5f / n; x = 0.5f * n; y = (m01 + m10) * k; z = (m02 + m20) * k; w = (m12 - m21) * k; }
+  else if (m11 > m22) { float n = sqrtf(((1 + m11) - m00) - m22), k = 0.5f / n; x = (m10 + m01) * k; y = 0.5f * n; z = (m21 + m12) * k; w = (m20 - m02) * k; }
+  else { float n = sqrtf(((1 + m22) - m00) - m11), k = 0.5f / n; x = (m20 + m02) * k; y = (m21 + m12) * k; z = 0.5f * n; w = (m01 - m10) * k; }
+  return q4(w, x, y, z);
+}
+DEV Q4 env_qinv(Q4 q) { float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z; Q4 c_ = qconj(q); float s = 1.0f / n2; return q4(c_.w * s, c_.x * s, c_.y * s, c_.z * s); }
+// transform_to_target_quat (ref transform_utils.py:641-664); rotate() normalises its quaternion first
+DEV void env_ttq(V3 bp, Q4 bq, V3 p, Q4 q, Q4 target, V3 *np_, Q4 *nq) {
+  Q4 rel = qmul(target, env_qinv(bq));
+  *np_ = qrot(qnormalized(rel), p - bp) + bp;
+  *nq = qmul(rel, q);
+}
+DEV void env_stop_part(const Ctx &c, int part, float gravity) {
+  const DModel &m = c.m;
+  float *x = c.L + c.ly.xfrc + 6 * part;
+  x[0] = 0; x[1] = 0; x[2] = -gravity * m.gravity[2] * m.part_mass[part]; x[3] = 0; x[4] = 0; x[5] = 0;
+  int d = m.part_dofadr[part];
+  for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = 0; c.L[c.ly.qfrcapp + d + k] = 0; }
+}
+// _move_objects_translation_quat (furniture.py:1163-1176): rigidly re-pose the whole weld group of `part`
+DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float gravity) {
+  const DModel &m = c.m;
+  int *grp = c.I(c.ly.env + E_GROUP);
+  float *qp = c.L + c.ly.qpos;
+  int a0 = m.part_qposadr[part];
+  V3 bp = ldv3(qp + a0);
+  Q4 bq = ldq(qp + a0 + 3);
+  int g = env_find(grp, part);
+  for (int i = 0; i < m.nparts; i++) {
+    if (env_find(grp, i) != g) continue;
+    int a = m.part_qposadr[i];
+    V3 np_; Q4 nq;
+    env_ttq(bp, bq, ldv3(qp + a), ldq(qp + a + 3), target, &np_, &nq);
+    stv3(qp + a, np_ + translation);
+    stq(qp + a + 3, nq);
+    env_stop_part(c, i, gravity);
+  }
+}
+// site bounding box of a weld group, min/max initialised with 0 (quirk Q1, furniture.py:747-769)
+DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
+  const DModel &m = c.m;
+  int *grp = c.I(c.ly.env + E_GROUP);
+  int g = env_find(grp, part);
+  V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
+  for (int i = 0; i < m.nparts; i++) {
+    if (env_find(grp, i) != g) continue;
+    for (int k = 0; k < m.part_site_num[i]; k++) {
+      V3 p; env_site_pose(c, m.part_sites[m.part_site_adr[i] + k], &p, nullptr, nullptr);
+      lo = v3(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
+      hi = v3(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+    }
+  }
+  *mn = lo; *mx = hi;
+}
+
+DEV void env_next_subtask(const Ctx &c) {
+  const DModel &m = c.m;
+  int *E = c.I(c.ly.env);
+  int *grp = E + E_GROUP;
+  E[E_SUBTASK1] = -1; E[E_SUBTASK2] = -1;
+  for (int i = 0; i < m.neq; i++) {
+    int p1 = m.eq_part1[i], p2 = m.eq_part2[i];
+    if (env_find(grp, p1) != env_find(grp, p2)) { E[E_SUBTASK1] = p1; E[E_SUBTASK2] = p2; return; }
+  }
+}
+
+// _is_aligned (furniture.py:1057-1153) for connector indices k1,k2; writes the target quaternion on success paths
+DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
+  const DModel &m = c.m;
+  V3 p1, p2; M3 R1, R2;
+  env_site_pose(c, m.conn_siteid[k1], &p1, nullptr, &R1);
+  env_site_pose(c, m.conn_siteid[k2], &p2, nullptr, &R2);
+  V3 up1 = colv(R1, 2), up2 = colv(R2, 2), f1 = colv(R1, 1), f2 = colv(R2, 1);
+  float pos_dist = norm(p1 - p2);
+  float rot_up = env_cos(up1, up2);
+  float proj12 = dot(up1, (p2 - p1) * (1.0f / norm(p2 - p1)));
+  float proj21 = dot(up2, (p1 - p2) * (1.0f / norm(p1 - p2)));
+  bool fwd_ok;
+  int na = m.conn_nangle[k1];
+  float *tq = c.L + c.ly.env + E_TARGET_QUAT;
+  if (na == 0) {
+    fwd_ok = true;
+    float cs = env_cos(f1, f2);
+    V3 k = normalized(up1);
+    float sn = sqrtf(1 - cs * cs);
+    V3 rp = cs * f1 + sn * cross(k, f1), rn = cs * f1 - sn * cross(k, f1);
+    V3 fr = env_cos(rp, f2) > env_cos(rn, f2) ? rp : rn;
+    stq(tq, env_lookat(up1, fr));
+  } else {
+    fwd_ok = false;
+    V3 k = normalized(up1);
+    for (int a = 0; a < na; a++) {
+      float ang = m.conn_angles[FSIM_MAXANG * k1 + a] / 180.0f * 3.14159265358979f;
+      V3 fr = cosf(ang) * f1 + sinf(ang) * cross(k, f1);
+      if (env_cos(fr, f2) > cfg.rot_fwd) { fwd_ok = true; stq(tq, env_lookat(up1, fr)); break; }
+    }
+  }
+  if (pos_dist < cfg.pos_dist && rot_up > cfg.rot_up && fwd_ok && fabsf(proj12) > cfg.proj_dist && fabsf(proj21) > cfg.proj_dist) return true;
+  if (pos_dist < cfg.pos_dist / 2 && rot_up > cfg.rot_up && fwd_ok) return true;
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------------- connect
+// returns (wave-uniform) 1 if a connection was made.  part1 = part both fingers pinch.
+DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
+  const DModel &m = c.m;
+  int *E = c.I(c.ly.env);
+  int *grp = E + E_GROUP;
+  int *scal = c.I(c.ly.scal);
+  // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
+  if (c.lane == 0) {
+    int found1 = -1, found2 = -1;
+    if (m.neq > 0 && m.nconn > 0) {
+      int g1 = env_find(grp, part1);
+      for (int k1 = 0; k1 < m.nconn && found1 < 0; k1++) {
+        if (env_find(grp, m.conn_partid[k1]) != g1) continue;
+        for (int k2 = 0; k2 < m.nconn; k2++) {
+          if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
+          if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
+          int a1 = m.conn_keya[k1], b1 = m.conn_keyb[k1], a2 = m.conn_keya[k2], b2 = m.conn_keyb[k2];
+          bool match = (b1 < 0 || b2 < 0) ? (b1 < 0 && b2 < 0 && a1 == a2) : (a1 == b2 && b1 == a2);
+          if (!match) continue;
+          if (env_is_aligned(c, cfg, k1, k2)) { found1 = k1; found2 = k2; break; }
+        }
+      }
+    }
+    E[E_CONNECT_STEP] = 0;
+    scal[9] = found1; scal[10] = found2;
+  }
+  SYNC();
+  int k1 = scal[9], k2 = scal[10];
+  if (k1 < 0) return 0;
+  // ---- _connect(site1, site2)
+  int pA = m.conn_partid[k1], pB = m.conn_partid[k2];
+  if (c.lane == 0) {
+    E[E_CONNSITES0 + (k1 >> 5)] |= 1 << (k1 & 31);
+    E[E_CONNSITES0 + (k2 >> 5)] |= 1 << (k2 & 31);
+    E[E_SITE1] = m.conn_siteid[k1]; E[E_SITE2] = m.conn_siteid[k2];
+    int gA = env_find(grp, pA), gB = env_find(grp, pB);
+    int *ct = c.I(c.ly.contype), *ca = c.I(c.ly.conaff);
+    for (int g = 0; g < m.ncg; g++) {
+      int p = m.cg_partid[g];
+      if (p < 0) continue;
+      int gp = env_find(grp, p);
+      if ((gp == gA || gp == gB) && ct[g] != 0) { ct[g] = (1 << 30) - 1 - (1 << (gA + 1)); ca[g] = 1 << (gA + 1); }
+    }
+    if (cfg.auto_align) {
+      // _align_connectors -> _move_site_to_target(site2, [site1 pos, target quat])
+      V3 s1p, s2p; Q4 s2q;
+      env_site_pose(c, m.conn_siteid[k1], &s1p, nullptr, nullptr);
+      env_site_pose(c, m.conn_siteid[k2], &s2p, &s2q, nullptr);
+      Q4 target = ldq(c.L + c.ly.env + E_TARGET_QUAT);
+      int a = m.part_qposadr[pB];
+      V3 bp = ldv3(c.L + c.ly.qpos + a); Q4 bq = ldq(c.L + c.ly.qpos + a + 3);
+      V3 npos; Q4 nquat;
+      env_ttq(s2p, s2q, bp, bq, target, &npos, &nquat);
+      V3 nsp; Q4 nsq;
+      env_ttq(bp, bq, s2p, s2q, nquat, &nsp, &nsq);
+      env_move_group(c, pB, s1p - nsp, nquat, 0.0f);
+    }
+  }
+  SYNC();
+  fs_step(c);
+  if (c.lane == 0) {
+    V3 mn1, mx1, mn2, mx2;
+    env_bbox(c, pA, &mn1, &mx1); env_bbox(c, pB, &mn2, &mx2);
+    float mz = fminf(mn1.z, mn2.z);
+    reinterpret_cast<float *>(scal)[11] = mz;
+  }
+  SYNC();
+  float mz = reinterpret_cast<float *>(scal)[11];
+  if (mz < 0) {
+    // _move_rotate_object(body, [0,0,-min z], [0,0,0]) for both bodies; each validates with forward+step (_is_inside)
+    for (int which = 0; which < 2; which++) {
+      int part = which ? pB : pA;
+      // old part poses stay in registers (lane i keeps word i of the [nparts][7] pose table) so the move can be undone
+      float keep[2] = {0, 0};
+      for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + m.part_qposadr[i / 7] + i % 7]; }
+      SYNC();
+      if (c.lane == 0) {
+        int g = env_find(grp, part);
+        int a0 = m.part_qposadr[part];
+        Q4 bq = ldq(c.L + c.ly.qpos + a0 + 3);
+        V3 bp = ldv3(c.L + c.ly.qpos + a0);
+        for (int i = 0; i < m.nparts; i++) {
+          if (env_find(grp, i) != g) continue;
+          int a = m.part_qposadr[i];
+          V3 np_; Q4 nq;
+          env_ttq(bp, bq, ldv3(c.L + c.ly.qpos + a), ldq(c.L + c.ly.qpos + a + 3), bq, &np_, &nq);
+          stv3(c.L + c.ly.qpos + a, np_ + v3(0, 0, -mz));
+          stq(c.L + c.ly.qpos + a + 3, nq);
+        }
+      }
+      SYNC();
+      fs_step(c);
+      if (c.lane == 0) {
+        V3 mn, mx; env_bbox(c, part, &mn, &mx);
+        const float bnd = 1.5f;
+        int inside = !(mn.x < -bnd || mn.y < -bnd || mn.z < -0.05f || mx.x > bnd || mx.y > bnd || mx.z > bnd);
+        scal[12] = inside;
+      }
+      SYNC();
+      if (!scal[12]) {
+        int g = 0;
+        if (c.lane == 0) { g = env_find(grp, part); scal[13] = g; }
+        SYNC();
+        g = scal[13];
+        for (int r = 0; r < 2; r++) {
+          int i = c.lane + 64 * r;
+          if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + m.part_qposadr[pi] + i % 7] = keep[r]; }
+        }
+        SYNC();
+      }
+    }
+  }
+  fs_step(c);
+  if (c.lane == 0) {
+    // _activate_weld(body1, body2)
+    for (int i = 0; i < m.neq; i++) {
+      int p1 = m.eq_part1[i], p2 = m.eq_part2[i];
+      if ((p1 == pA || p1 == pB) && (p2 == pA || p2 == pB)) {
+        int a1 = m.part_qposadr[p1], a2 = m.part_qposadr[p2];
+        Q4 q1i = env_qinv(ldq(c.L + c.ly.qpos + a1 + 3));
+        Q4 rq = qmul(q1i, ldq(c.L + c.ly.qpos + a2 + 3));
+        V3 rp = qrot(qnormalized(q1i), ldv3(c.L + c.ly.qpos + a2) - ldv3(c.L + c.ly.qpos + a1));
+        float *ed = c.L + c.ly.eqdata + 7 * i;
+        stv3(ed, rp); stq(ed + 3, rq);
+        c.I(c.ly.eqactive)[i] = 1;
+        int r1 = env_find(grp, pA), r2 = env_find(grp, pB);
+        grp[r1] = r2;
+      }
+    }
+    E[E_NUM_CONNECTED] += 1;
+    E[E_CONNECTED_THIS_STEP] = 1;
+    E[E_CONNBODY1] = pA + 1;
+    int a = m.part_qposadr[pA];
+    for (int k = 0; k < 7; k++) c.L[c.ly.env + E_CB1_POS + k] = c.L[c.ly.qpos + a + k];
+    env_next_subtask(c);
+  }
+  SYNC();
+  return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------- observation / reward
+DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  if (!io.obs) return;
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  const float *L = c.L;
+  // object_ob: body xpos/xquat of every part as left by the last forward pass
+  for (int i = c.lane; i < 7 * m.nparts; i += 64) {
+    int p = i / 7, k = i % 7, b = m.part_rbody[p];
+    io.obs[i] = k < 3 ? L[ly.xpos + 3 * b + k] : L[ly.xquat + 4 * b + k - 3];
+  }
+  int base = 7 * m.nparts;
+  for (int arm = 0; arm < m.narm; arm++) {
+    float *o = io.obs + base + 29 * arm;
+    int nj = m.narmj / m.narm;
+    for (int k = c.lane; k < nj; k += 64) {
+      o[k] = L[ly.qpos + m.arm_qposadr[arm * nj + k]];
+      o[nj + k] = L[ly.qvel + m.arm_dofadr[arm * nj + k]];
+    }
+    if (c.lane < 2) o[2 * nj + c.lane] = L[ly.qpos + m.grip_qposadr[2 * arm + c.lane]];
+    if (c.lane == 0) {
+      int site = m.eef_siteid[arm];
+      V3 sp; env_site_pose(c, site, &sp, nullptr, nullptr);
+      stv3(o + 2 * nj + 2, sp);
+      int hb = m.hand_body[arm], rb = m.body_red[hb];
+      Q4 q = qmul(ldq(L + ly.xquat + 4 * rb), ldq(m.body_relquat + 4 * hb));
+      o[2 * nj + 5] = q.x; o[2 * nj + 6] = q.y; o[2 * nj + 7] = q.z; o[2 * nj + 8] = q.w;
+      int sb = m.s_body[site];
+      S6 v = lds6(L + ly.cvel + 6 * sb);
+      V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * m.r_tree[sb])) : v3(0, 0, 0);
+      stv3(o + 2 * nj + 9, vp);
+      stv3(o + 2 * nj + 12, sb ? v.a : v3(0, 0, 0));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- reset
+DEV void env_gravity_comp(const Ctx &c) {
+  const DModel &m = c.m;
+  for (int k = c.lane; k < m.narmj; k += 64) c.L[c.ly.qfrcapp + m.arm_dofadr[k]] = c.L[c.ly.qfrcbias + m.arm_dofadr[k]];
+  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qfrcapp + m.grip_dofadr[k]] = c.L[c.ly.qfrcbias + m.grip_dofadr[k]];
+  SYNC();
+}
+DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw) {
+  const DModel &m = c.m;
+  for (int k = c.lane; k < m.narmj; k += 64) {
+    float noise = io.tab_noise ? io.tab_noise[(size_t)min(draw, io.n_noise - 1) * m.narmj + k] : 0.0f;
+    c.L[c.ly.qpos + m.arm_qposadr[k]] = m.arm_initqpos[k] + noise;
+  }
+  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qpos + m.grip_qposadr[k]] = m.grip_initqpos[k];
+  SYNC();
+}
+DEV void env_settle_parts(const Ctx &c) {
+  const DModel &m = c.m;
+  for (int o = 0; o < 10; o++) {
+    if (c.lane == 0) for (int p = 0; p < m.nparts; p++) env_stop_part(c, p, 0.0f);
+    SYNC();
+    for (int i = 0; i < 10; i++) {
+      fs_step(c);
+      // _slow_objects: gravity compensation + clip |qvel| <= 0.2
+      for (int p = c.lane; p < m.nparts; p += 64) {
+        float *x = c.L + c.ly.xfrc + 6 * p;
+        x[0] = 0; x[1] = 0; x[2] = -m.gravity[2] * m.part_mass[p]; x[3] = 0; x[4] = 0; x[5] = 0;
+        int d = m.part_dofadr[p];
+        for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = fminf(fmaxf(c.L[c.ly.qvel + d + k], -0.2f), 0.2f); c.L[c.ly.qfrcapp + d + k] = 0; }
+      }
+      SYNC();
+    }
+  }
+}
+
+__device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *iop) {
+  FS_REBUILD_CTX(cv);
+  const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp));
+  const EnvIO io = *iop;
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int *E = c.I(ly.env);
+  // sim.reset()
+  for (int i = c.lane; i < m.nq; i += 64) L[ly.qpos + i] = m.qpos0[i];
+  for (int i = c.lane; i < m.nv; i += 64) { L[ly.qvel + i] = 0; L[ly.qaccws + i] = 0; L[ly.qfrcbias + i] = 0; L[ly.qfrcapp + i] = 0; }
+  for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
+  for (int i = c.lane; i < 6 * m.nparts; i += 64) L[ly.xfrc + i] = 0;
+  // robot collision off, part colliders on (furniture.py:1441-1461)
+  for (int g = c.lane; g < m.ncg; g += 64) {
+    int ct = m.cg_contype0[g], ca = m.cg_conaffinity0[g];
+    if (m.cg_isrobot[g]) { ct = 0; ca = 0; }
+    if (m.cg_ispartcol[g]) { ct = 1; ca = 1; }
+    c.I(ly.contype)[g] = ct; c.I(ly.conaff)[g] = ca;
+  }
+  for (int e = c.lane; e < m.neq; e += 64) { c.I(ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[ly.eqdata + 7 * e + k] = m.eq_data0[7 * e + k]; }
+  int episodes = E[E_EPISODE_COUNT];
+  SYNC();
+  for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
+  for (int p = c.lane; p < m.nparts; p += 64) E[E_GROUP + p] = p;
+  SYNC();
+  if (c.lane == 0) { E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; }
+  // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
+  for (int i = c.lane; i < 7 * m.nparts; i += 64) {
+    int p = i / 7, k = i % 7;
+    if (io.tab_parts) L[ly.qpos + m.part_qposadr[p] + k] = io.tab_parts[i];
+  }
+  SYNC();
+  env_settle_parts(c);
+  if (cfg.has_recipe) env_settle_parts(c);
+  if (m.narm > 0) {
+    env_gravity_comp(c);
+    env_init_robot(c, io, 0);
+    fs_step(c);
+    for (int g = c.lane; g < m.ncg; g += 64)
+      if (m.cg_isrobot[g]) { c.I(ly.contype)[g] = m.cg_contype0[g]; c.I(ly.conaff)[g] = m.cg_conaffinity0[g]; }
+    SYNC();
+    env_gravity_comp(c);
+    for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k); fs_step(c); }
+  }
+  for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
+  for (int i = c.lane; i < m.nv; i += 64) { L[ly.qfrcapp + i] = 0; L[ly.qaccws + i] = 0; }
+  for (int i = c.lane; i < 6 * m.nparts; i += 64) L[ly.xfrc + i] = 0;
+  SYNC();
+  fs_forward(c);
+  if (m.narm > 0) env_gravity_comp(c);
+  for (int k = 0; k < 100; k++) fs_step(c);
+  if (c.lane == 0) env_next_subtask(c);
+  SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------- step
+DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int *E = c.I(ly.env);
+  int *scal = c.I(ly.scal);
+  int dof = cfg.dof_action;
+  // _before_step + action plumbing
+  if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
+  float connect = io.action[dof - 1];
+  // _setup_action (impedance): clip, gripper 1 -> 2, rescale to ctrlrange, stale gravity compensation
+  for (int u = c.lane; u < m.nu; u += 64) {
+    float a;
+    if (u < m.narmj) a = io.action[u];
+    else {
+      int gi = (u - m.narmj) >> 1;
+      a = io.action[m.narmj + gi];
+      if (cfg.discrete_grip && cfg.agent == 0) a = a < 0 ? -1.0f : 1.0f; // furniture_sawyer.py:72-74
+      if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
+      if ((u - m.narmj) & 1) a = -a; // format_action: [g, -g]
+    }
+    if (u < m.narmj && cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
+    L[ly.ctrl + u] = cfg.rescale_actions ? m.ctrl_bias[u] + m.ctrl_weight[u] * a : a;
+  }
+  SYNC();
+  env_gravity_comp(c);
+  // _do_simulation: n_substeps x sim.step()
+  for (int s = 0; s < cfg.n_substeps; s++) {
+    fs_forward(c);
+    if (s == cfg.n_substeps - 1) fs_touch_flags(c);
+    fs_integrate(c);
+  }
+  int bad = scal[SC_BAD] & 2;
+  if (bad) {
+    // unstable simulation: reset inside step(), flag the failure (furniture.py:2889-2897)
+    env_reset(c, &cfg, &io);
+    if (c.lane == 0) { E[E_FAIL] = 1; scal[SC_BAD] = 0; }
+    SYNC();
+    fs_forward(c);
+    fs_touch_flags(c);
+  } else if (connect > 0) {
+    // finger-touch scan -> first part (in part order) pinched by both fingers of an arm -> _try_connect
+    int done_connect = 0;
+    for (int arm = 0; arm < m.narm && !done_connect; arm++) {
+      int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
+      if (!both) continue;
+      int part = __ffs(both) - 1;
+      done_connect = env_try_connect(c, cfg, part); // break after the first pinched part either way (quirk Q4)
+    }
+  }
+  // post-connect re-pose of body1's (merged) group (furniture.py:426-436)
+  if (E[E_CONNBODY1] > 0) {
+    fs_forward(c);
+    if (c.lane == 0) {
+      int pA = E[E_CONNBODY1] - 1;
+      V3 tp = ldv3(L + ly.env + E_CB1_POS);
+      Q4 tq = ldq(L + ly.env + E_CB1_QUAT);
+      env_move_group(c, pA, tp - ldv3(L + ly.qpos + m.part_qposadr[pA]), tq, 0.0f);
+      E[E_CONNBODY1] = 0;
+    }
+    SYNC();
+    fs_forward(c);
+    fs_touch_flags(c);
+    fs_integrate(c);
+  }
+  SYNC();
+  // reward (furniture.py:482-541): one-shot touch / pick latches, success delta, control penalty on the RAW action
+  float touch_rew = 0, pick_rew = 0, succ_rew = 0, ctrl_pen = 0;
+  {
+    float s2 = 0;
+    for (int k = c.lane; k < dof; k += 64) s2 += io.action[k] * io.action[k];
+    ctrl_pen = -cfg.ctrl_penalty_coef * wave_sum(s2);
+  }
+  int success = 0, terminal = 0;
+  float penalty = 0;
+  if (c.lane == 0) {
+    for (int arm = 0; arm < m.narm; arm++) {
+      int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
+      for (int p = 0; p < m.nparts; p++) {
+        if (!((both >> p) & 1)) continue;
+        if (!((E[E_TOUCHED] >> p) & 1)) { E[E_TOUCHED] |= 1 << p; touch_rew += cfg.touch_reward; }
+        if (!((scal[SC_TOUCHF] >> p) & 1) && !((E[E_PICKED] >> p) & 1)) { E[E_PICKED] |= 1 << p; pick_rew += cfg.pick_reward; }
+      }
+    }
+    succ_rew = cfg.success_reward * (float)(E[E_NUM_CONNECTED] - E[E_PREV_NUM_CONNECTED]);
+    E[E_PREV_NUM_CONNECTED] = E[E_NUM_CONNECTED];
+    if (E[E_NUM_CONNECTED] == m.nparts - 1 && m.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
+    terminal = success;
+    // _after_step
+    E[E_EPISODE_LENGTH] += 1;
+    int fail = E[E_FAIL];
+    if (E[E_EPISODE_LENGTH] == cfg.max_episode_steps || fail) {
+      terminal = 1;
+      if (fail) { E[E_FAIL] = 0; penalty = -cfg.unstable_penalty_coef; }
+    }
+    float rew = succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
+    L[ly.env + E_EPISODE_REWARD] += rew;
+    if (io.reward) *io.reward = rew;
+    if (io.done) *io.done = (uint8_t)terminal;
+    if (io.info) {
+      io.info[FSIM_INFO_NUM_CONNECTED] = E[E_NUM_CONNECTED]; io.info[FSIM_INFO_SUCCESS] = success; io.info[FSIM_INFO_FAIL] = fail;
+      io.info[FSIM_INFO_LAST_SITE1] = E[E_SITE1]; io.info[FSIM_INFO_LAST_SITE2] = E[E_SITE2];
+      io.info[FSIM_INFO_EPISODE_LENGTH] = E[E_EPISODE_LENGTH]; io.info[FSIM_INFO_CONNECTED_THIS_STEP] = E[E_CONNECTED_THIS_STEP];
+      io.info[FSIM_INFO_NEEDS_TABLE] = (terminal && cfg.auto_reset) ? 1 : 0;
+      io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
+      io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
+    }
+    scal[14] = terminal;
+  }
+  SYNC();
+  terminal = scal[14];
+  if (terminal && cfg.auto_reset) env_reset(c, &cfg, &io); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
+  env_write_obs(c, cfg, io);
+}

@@ -1,0 +1,82 @@
+// fsim_model.hpp -- device-side model tables and per-env memory layout.
+//
+// Model constants are shared by all envs: they live in one HBM buffer, stay L2-resident
+// (tens of KB) and are read through wave-uniform (scalar) loads wherever the index is
+// uniform.  Per-env state is one contiguous record ("AoS per env"): with one wavefront per
+// env the wave streams its own record in and out with unit-stride 64-lane accesses, so the
+// HBM traffic of a fused 50-substep step is one read + one write of the record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FSIM_MAXANG 8
+#define FSIM_CONW 32     // words per contact slot
+#define FSIM_WELDW 44    // words per weld record
+#define FSIM_LIMW 8      // words per joint-limit record
+#define FSIM_MAXSURV 128 // broadphase survivors per substep
+
+enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
+enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
+enum { PT_PLANE_SPHERE = 0, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL };
+
+struct DModel {
+  int nq, nv, nu, nr, ntree, ncg, ncp, nsite, neq, nparts, nM, maxdepth, nconn, narm, nlim, nbody, ngeom, agent;
+  int narmj, ngripj;
+  float timestep, gravity[3], impratio, meaninertia_scale;
+  // reduced bodies
+  const int *r_parent, *r_jtype, *r_qposadr, *r_dofadr, *r_dofnum, *r_depth, *r_tree, *r_chainadr, *r_chainlen, *r_ancmask;
+  const float *r_pos, *r_quat, *r_jaxis, *r_jpos, *r_mass, *r_ipos, *r_inertia;
+  const int *chain_dofs;
+  const int *tree_dofadr, *tree_dofnum, *tree_bodyadr, *tree_bodynum;
+  // dofs
+  const int *dof_parent, *dof_Madr, *dof_rbody, *dof_tree, *dof_qposadr, *M_i, *M_j;
+  const float *dof_armature, *dof_damping, *dof_invweight0;
+  // joint limits (one entry per limited hinge/slide dof)
+  const int *lim_dof;
+  const float *lim_range, *lim_margin, *lim_solref, *lim_solimp;
+  // colliding geoms
+  const int *cg_body, *cg_type, *cg_condim, *cg_partid, *cg_fingerrole, *cg_isfloor, *cg_isrobot, *cg_ispartcol, *cg_orig,
+      *cg_contype0, *cg_conaffinity0;
+  const float *cg_pos, *cg_mat, *cg_size, *cg_rbound, *cg_friction, *cg_solref, *cg_solimp, *cg_margin, *cg_gap, *cg_solmix, *cg_invweight;
+  const int *cp; // [ncp][3] = cg1, cg2, pair type
+  // sites
+  const int *s_body;
+  const float *s_pos, *s_quat;
+  // actuators
+  const int *act_dof, *act_qpos, *act_ctrllimited, *act_forcelimited;
+  const float *act_gain, *act_bias, *act_ctrlrange, *act_forcerange, *act_gear, *ctrl_bias, *ctrl_weight;
+  // welds
+  const int *eq_rbody1, *eq_rbody2, *eq_part1, *eq_part2;
+  const float *eq_solref, *eq_solimp, *eq_invweight, *eq_data0;
+  const int *eq_active0;
+  // env tables
+  const int *part_rbody, *part_qposadr, *part_dofadr, *body_red;
+  const float *body_relpos, *body_relquat, *part_mass;
+  const int *arm_qposadr, *arm_dofadr, *grip_qposadr, *grip_dofadr, *eef_siteid, *hand_body;
+  const float *arm_initqpos, *grip_initqpos, *qpos0;
+  const int *conn_siteid, *conn_partid, *conn_keya, *conn_keyb, *conn_nangle;
+  const float *conn_angles;
+  const int *part_site_adr, *part_site_num, *part_sites; // all sites living on each part body (bounding boxes)
+};
+
+// word offsets inside one env record (HBM) == start of the LDS image
+struct Layout {
+  int qpos, qvel, qaccws, qfrcbias, ctrl, qfrcapp, xfrc, eqdata, eqactive, contype, conaff, env, stride;
+  // LDS-only work arrays (word offsets from LDS base)
+  int xpos, xquat, xmat, xanchor, xaxis, xipos, com;
+  int cinert, crb, cdofdot, cvel, cacc, cfrc, H; // H aliases cinert..cfrc
+  int cdof, M, LD, Dinv, LDh, Dhinv;
+  int smooth, asmooth, x, Mx, grad, p, Mp;
+  int gpos, gmat, surv, con, weld, lim, W, G, scal;
+  int lds_words, ncon_max;
+};
+
+// env-logic block (word offsets relative to Layout::env)
+enum {
+  E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL, E_TERMINAL,
+  E_CONNECTED_THIS_STEP, E_SITE1, E_SITE2, E_SUBTASK1, E_SUBTASK2, E_TOUCHED, E_PICKED, E_CONNSITES0, E_CONNSITES1,
+  E_CONNSITES2, E_CONNSITES3, E_TOUCH_L, E_TOUCH_R, E_TOUCH_FLOOR, E_CONNBODY1, E_CB1_POS, E_CB1_QUAT = E_CB1_POS + 3,
+  E_TARGET_QUAT = E_CB1_QUAT + 4, E_EPISODE_REWARD = E_TARGET_QUAT + 4, E_NCON, E_NITER, E_RESET_CURSOR, E_EPISODE_COUNT,
+  E_GROUP, // nparts ints follow
+  E_FIXED_WORDS = E_GROUP
+};

@@ -1,0 +1,606 @@
+// fsim_solver.hpp -- P4 constraint assembly + P7 primal Newton solver for one env / one wave.
+//
+// The reference never sets <option solver> (furniture/env/models/assets/base.xml:4), so what it runs
+// is MuJoCo's default: Newton on the primal soft-constraint problem
+//     min_x 1/2 (x - a_s)' M (x - a_s) + sum_i s_i(J_i x - aref_i)
+// with quadratic costs for welds, one-sided quadratic for joint limits / frictionless contacts and
+// the three-zone elliptic-cone cost with the impratio-regularised friction.  The convex problem has
+// a unique optimum, so iterating to tolerance reproduces the reference's accelerations.
+//
+// GPU mapping: lanes = constraint slots (welds | joint limits | contact slots).  Jacobians are never
+// stored: J*v is evaluated through per-body spatial vectors W_b = sum_{d in chain(b)} cdof_d v_d
+// (one LDS 6-vector per body), J'f through per-body wrenches G_b accumulated with LDS float atomics,
+// and J'WJ by a per-slot double loop over the dof chains of the two bodies.  The Hessian is a packed
+// lower triangle in LDS, factored by a left-looking Cholesky with lane = row, wave shuffles for the
+// pivots and a skyline start per row (block-diagonal when no constraint couples two kinematic trees).
+#pragma once
+#include "fsim_collide.hpp"
+
+enum { LM_ACTIVE = 0, LM_AREF = 1, LM_D = 2, LM_JAR = 3, LM_JP = 4, LM_SIGN = 5, LM_DOF = 6 };
+enum { WD_ACTIVE = 0, WD_P0 = 1, WD_C = 4, WD_AREF = 13, WD_D = 19, WD_JAR = 25, WD_JP = 31, WD_B1 = 37, WD_B2 = 38, WD_X2 = 39 };
+
+DEV float fs_impedance(const float *solref, const float *solimp, float x0, float timestep, float *k, float *b) {
+  float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
+  float x = fabsf(x0) / width, imp;
+  if (x >= 1) imp = dmax;
+  else if (x <= 0) imp = dmin;
+  else {
+    float y;
+    if (power == 1.0f) y = x;
+    else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+    else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+    imp = dmin + y * (dmax - dmin);
+  }
+  if (solref[0] > 0) {
+    float tc = fmaxf(solref[0], 2 * timestep), dr = solref[1];
+    *k = 1.0f / (dmax * dmax * tc * tc * dr * dr);
+    *b = 2.0f / (dmax * tc);
+  } else { *k = -solref[0] / (dmax * dmax); *b = -solref[1] / dmax; }
+  return imp;
+}
+
+DEV V3 fs_ptvel(const Ctx &c, int off, int b, V3 p) {
+  if (b == 0) return v3(0, 0, 0);
+  S6 w = lds6(c.L + off + 6 * b);
+  return w.l + cross(w.a, p - ldv3(c.L + c.ly.com + 3 * c.m.r_tree[b]));
+}
+
+// returns 1 if any constraint couples two kinematic trees
+DEV int fs_make_constraints(const Ctx &c) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int nslot = c.I(ly.scal)[SC_NSLOT];
+  int coupled = 0, ncon = 0;
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = L + ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (ri[C_ACTIVE] != 1) continue;
+    ncon++;
+    int b1 = ri[C_B1], b2 = ri[C_B2], g1 = ri[C_G1], g2 = ri[C_G2];
+    float dist = r[C_DIST], incm = r[C_INCM];
+    if (dist >= incm) { ri[C_ACTIVE] = 2; continue; }
+    V3 pos = ldv3(r + C_POS);
+    V3 vrel = fs_ptvel(c, ly.cvel, b2, pos) - fs_ptvel(c, ly.cvel, b1, pos);
+    float mix = m.cg_solmix[g1] / (m.cg_solmix[g1] + m.cg_solmix[g2]);
+    float sr[2], si[5];
+    for (int i = 0; i < 2; i++) sr[i] = mix * m.cg_solref[2 * g1 + i] + (1 - mix) * m.cg_solref[2 * g2 + i];
+    for (int i = 0; i < 5; i++) si[i] = mix * m.cg_solimp[5 * g1 + i] + (1 - mix) * m.cg_solimp[5 * g2 + i];
+    float k, b;
+    float imp = fs_impedance(sr, si, dist - incm, m.timestep, &k, &b);
+    float R = fmaxf((1 - imp) / imp * (m.cg_invweight[g1] + m.cg_invweight[g2]), 1e-15f);
+    r[C_DN] = 1.0f / R;
+    r[C_DT] = fmaxf(m.impratio, 1e-15f) / R;
+    r[C_AREF] = -b * dot(ldv3(r + C_FRAME), vrel) - k * imp * (dist - incm);
+    r[C_AREF + 1] = -b * dot(ldv3(r + C_FRAME + 3), vrel);
+    r[C_AREF + 2] = -b * dot(ldv3(r + C_FRAME + 6), vrel);
+    if (b1 != 0 && b2 != 0 && m.r_tree[b1] != m.r_tree[b2]) coupled = 1;
+  }
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+    float *r = L + ly.lim + FSIM_LIMW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    int li = s >> 1, side = s & 1, d = m.lim_dof[li];
+    float q = L[ly.qpos + m.dof_qposadr[d]];
+    float dist = side ? m.lim_range[2 * li + 1] - q : q - m.lim_range[2 * li];
+    float mg = m.lim_margin[li];
+    int act = dist < mg;
+    ri[LM_ACTIVE] = act;
+    if (!act) continue;
+    float sign = side ? -1.0f : 1.0f, k, b;
+    float imp = fs_impedance(m.lim_solref + 2 * li, m.lim_solimp + 5 * li, dist - mg, m.timestep, &k, &b);
+    float R = fmaxf((1 - imp) / imp * m.dof_invweight0[d], 1e-15f);
+    r[LM_D] = 1.0f / R;
+    r[LM_AREF] = -b * sign * L[ly.qvel + d] - k * imp * (dist - mg);
+    r[LM_SIGN] = sign;
+    ri[LM_DOF] = d;
+  }
+  for (int e = c.lane; e < m.neq; e += 64) {
+    float *r = L + ly.weld + FSIM_WELDW * e;
+    int *ri = reinterpret_cast<int *>(r);
+    int act = c.I(ly.eqactive)[e];
+    ri[WD_ACTIVE] = act;
+    if (!act) continue;
+    coupled = 1;
+    int b1 = m.eq_rbody1[e], b2 = m.eq_rbody2[e];
+    const float *data = L + ly.eqdata + 7 * e;
+    M3 R1 = ldm3(L + ly.xmat + 9 * b1);
+    V3 p0 = ldv3(L + ly.xpos + 3 * b1) + mulv(R1, ldv3(data));
+    V3 x2 = ldv3(L + ly.xpos + 3 * b2);
+    Q4 qd = qmul(ldq(L + ly.xquat + 4 * b1), ldq(data + 3));
+    Q4 q2c = qconj(ldq(L + ly.xquat + 4 * b2));
+    Q4 qe = qmul(q2c, qd);
+    float cpos[6];
+    V3 dp = p0 - x2;
+    cpos[0] = dp.x; cpos[1] = dp.y; cpos[2] = dp.z; cpos[3] = qe.x; cpos[4] = qe.y; cpos[5] = qe.z;
+    // C[c][a] = 0.5 * imag_c( conj(q2) * e_a * q1*rel )
+    for (int a = 0; a < 3; a++) {
+      Q4 w = q4(0, a == 0, a == 1, a == 2);
+      Q4 t = qmul(qmul(q2c, w), qd);
+      r[WD_C + 0 * 3 + a] = 0.5f * t.x; r[WD_C + 1 * 3 + a] = 0.5f * t.y; r[WD_C + 2 * 3 + a] = 0.5f * t.z;
+    }
+    V3 jt = fs_ptvel(c, ly.cvel, b1, p0) - fs_ptvel(c, ly.cvel, b2, x2);
+    V3 dw = lds6(L + ly.cvel + 6 * b1).a - lds6(L + ly.cvel + 6 * b2).a;
+    float jv[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
+    for (int q = 0; q < 3; q++) jv[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
+    for (int q = 0; q < 6; q++) {
+      float k, b;
+      float imp = fs_impedance(m.eq_solref + 2 * e, m.eq_solimp + 5 * e, cpos[q], m.timestep, &k, &b);
+      float R = fmaxf((1 - imp) / imp * m.eq_invweight[2 * e + (q >= 3)], 1e-15f);
+      r[WD_D + q] = 1.0f / R;
+      r[WD_AREF + q] = -b * jv[q] - k * imp * cpos[q];
+    }
+    stv3(r + WD_P0, p0); stv3(r + WD_X2, x2);
+    ri[WD_B1] = b1; ri[WD_B2] = b2;
+  }
+  int any = wave_or(coupled);
+  int tot = (int)wave_sum((float)ncon);
+  if (c.lane == 0) c.I(ly.scal)[SC_NCON] = tot;
+  SYNC();
+  return any;
+}
+
+// W_b = sum_{d in chain(b)} cdof_d * vec_d
+DEV void fs_body_spatial(const Ctx &c, int off_vec) {
+  const DModel &m = c.m;
+  float *L = c.L;
+  for (int b = c.lane; b < m.nr; b += 64) {
+    S6 w = s6zero();
+    if (b > 0) {
+      int adr = m.r_chainadr[b], n = m.r_chainlen[b];
+      for (int k = 0; k < n; k++) { int d = m.chain_dofs[adr + k]; w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
+    }
+    sts6(L + c.ly.W + 6 * b, w);
+  }
+  SYNC();
+}
+
+// rec[dst..] = J * vec (- aref if sub_aref), using W from fs_body_spatial(vec)
+DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int nslot = c.I(ly.scal)[SC_NSLOT];
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = L + ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (ri[C_ACTIVE] != 1) continue;
+    V3 pos = ldv3(r + C_POS);
+    V3 rel = fs_ptvel(c, ly.W, ri[C_B2], pos) - fs_ptvel(c, ly.W, ri[C_B1], pos);
+    int dst = to_jar ? C_JAR : C_JP;
+    for (int a = 0; a < 3; a++) r[dst + a] = dot(ldv3(r + C_FRAME + 3 * a), rel) - (to_jar ? r[C_AREF + a] : 0.0f);
+  }
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+    float *r = L + ly.lim + FSIM_LIMW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[LM_ACTIVE]) continue;
+    float v = r[LM_SIGN] * L[off_vec + ri[LM_DOF]];
+    if (to_jar) r[LM_JAR] = v - r[LM_AREF]; else r[LM_JP] = v;
+  }
+  for (int e = c.lane; e < m.neq; e += 64) {
+    float *r = L + ly.weld + FSIM_WELDW * e;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[WD_ACTIVE]) continue;
+    int b1 = ri[WD_B1], b2 = ri[WD_B2];
+    V3 jt = fs_ptvel(c, ly.W, b1, ldv3(r + WD_P0)) - fs_ptvel(c, ly.W, b2, ldv3(r + WD_X2));
+    V3 dw = lds6(L + ly.W + 6 * b1).a - lds6(L + ly.W + 6 * b2).a;
+    int dst = to_jar ? WD_JAR : WD_JP;
+    float v[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
+    for (int q = 0; q < 3; q++) v[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
+    for (int q = 0; q < 6; q++) r[dst + q] = v[q] - (to_jar ? r[WD_AREF + q] : 0.0f);
+  }
+  SYNC();
+}
+
+// elliptic contact block: force, cost, (optional) 3x3 Hessian w.r.t. jar.  returns state 0/1/2
+DEV int fs_cone(const float *jar, float Dn, float Dt, float fri, float *f, float *cost, float *H) {
+  float mu = fri * sqrtf(Dn / Dt); // friction * sqrt(R_t/R_n) = friction / sqrt(impratio)
+  float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
+  float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
+  if (mu * N >= T || (T <= 0 && N >= 0)) { f[0] = f[1] = f[2] = 0; *cost = 0; return 0; }
+  if (mu * T + N <= 0 || (T <= 0 && N < 0)) {
+    f[0] = -Dn * jar[0]; f[1] = -Dt * jar[1]; f[2] = -Dt * jar[2];
+    *cost = 0.5f * (Dn * jar[0] * jar[0] + Dt * (jar[1] * jar[1] + jar[2] * jar[2]));
+    if (H) { for (int i = 0; i < 9; i++) H[i] = 0; H[0] = Dn; H[4] = Dt; H[8] = Dt; }
+    return 1;
+  }
+  float Dm = Dn / fmaxf(mu * mu * (1 + mu * mu), 1e-15f), NT = N - mu * T;
+  *cost = 0.5f * Dm * NT * NT;
+  f[0] = -Dm * NT * mu;
+  f[1] = -f[0] / T * U1 * fri; f[2] = -f[0] / T * U2 * fri;
+  if (H) {
+    float u[2] = {U1 / T, U2 / T}, sc[3] = {mu, fri, fri}, Hu[9];
+    Hu[0] = Dm;
+    for (int a = 0; a < 2; a++) {
+      Hu[1 + a] = Hu[3 * (1 + a)] = -Dm * mu * u[a];
+      for (int b = 0; b < 2; b++) Hu[3 * (1 + a) + 1 + b] = Dm * mu * mu * u[a] * u[b] - Dm * mu * NT * ((a == b ? 1.0f : 0.0f) - u[a] * u[b]) / T;
+    }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) H[3 * a + b] = Hu[3 * a + b] * sc[a] * sc[b];
+  }
+  return 2;
+}
+
+// constraint cost at jar + alpha*jp, and the first/second directional derivatives along jp
+DEV void fs_line_eval(const Ctx &c, float alpha, float *cost, float *d1, float *d2) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int nslot = c.I(ly.scal)[SC_NSLOT];
+  float cs = 0, a1 = 0, a2 = 0;
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = L + ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (ri[C_ACTIVE] != 1) continue;
+    if (ri[C_DIM] == 1) {
+      float j = r[C_JAR] + alpha * r[C_JP];
+      if (j < 0) { cs += 0.5f * r[C_DN] * j * j; a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; }
+      continue;
+    }
+    float jar[3], f[3], H[9], cc;
+    for (int a = 0; a < 3; a++) jar[a] = r[C_JAR + a] + alpha * r[C_JP + a];
+    int st = fs_cone(jar, r[C_DN], r[C_DT], r[C_MU], f, &cc, H);
+    if (!st) continue;
+    cs += cc;
+    for (int a = 0; a < 3; a++) {
+      a1 -= f[a] * r[C_JP + a];
+      for (int b = 0; b < 3; b++) a2 += H[3 * a + b] * r[C_JP + a] * r[C_JP + b];
+    }
+  }
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+    float *r = L + ly.lim + FSIM_LIMW * s;
+    if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
+    float j = r[LM_JAR] + alpha * r[LM_JP];
+    if (j < 0) { cs += 0.5f * r[LM_D] * j * j; a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; }
+  }
+  for (int e = c.lane; e < m.neq; e += 64) {
+    float *r = L + ly.weld + FSIM_WELDW * e;
+    if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
+    for (int q = 0; q < 6; q++) {
+      float j = r[WD_JAR + q] + alpha * r[WD_JP + q], D = r[WD_D + q];
+      cs += 0.5f * D * j * j; a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
+    }
+  }
+  *cost = wave_sum(cs); *d1 = wave_sum(a1); *d2 = wave_sum(a2);
+}
+
+DEV void fs_add_wrench(const Ctx &c, int b, V3 p, V3 F, V3 T, float sign) {
+  if (b == 0) return;
+  float *G = c.L + c.ly.G + 6 * b;
+  V3 mo = (cross(p - ldv3(c.L + c.ly.com + 3 * c.m.r_tree[b]), F) + T) * sign;
+  atomicAdd(G + 0, mo.x); atomicAdd(G + 1, mo.y); atomicAdd(G + 2, mo.z);
+  atomicAdd(G + 3, sign * F.x); atomicAdd(G + 4, sign * F.y); atomicAdd(G + 5, sign * F.z);
+}
+
+// grad = Mx - qfrc_smooth - J' f(jar)
+DEV void fs_gradient(const Ctx &c) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  for (int i = c.lane; i < 6 * m.nr; i += 64) L[ly.G + i] = 0;
+  for (int d = c.lane; d < m.nv; d += 64) L[ly.grad + d] = L[ly.Mx + d] - L[ly.smooth + d];
+  SYNC();
+  int nslot = c.I(ly.scal)[SC_NSLOT];
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = L + ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (ri[C_ACTIVE] != 1) continue;
+    float f[3] = {0, 0, 0}, cc;
+    if (ri[C_DIM] == 1) { if (r[C_JAR] < 0) f[0] = -r[C_DN] * r[C_JAR]; }
+    else fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, nullptr);
+    if (f[0] == 0 && f[1] == 0 && f[2] == 0) continue;
+    V3 F = ldv3(r + C_FRAME) * f[0] + ldv3(r + C_FRAME + 3) * f[1] + ldv3(r + C_FRAME + 6) * f[2];
+    V3 pos = ldv3(r + C_POS);
+    fs_add_wrench(c, ri[C_B2], pos, F, v3(0, 0, 0), 1.0f);
+    fs_add_wrench(c, ri[C_B1], pos, F, v3(0, 0, 0), -1.0f);
+  }
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+    float *r = L + ly.lim + FSIM_LIMW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
+    atomicAdd(L + ly.grad + ri[LM_DOF], r[LM_SIGN] * r[LM_D] * r[LM_JAR]); // -sign*f, f = -D*jar
+  }
+  for (int e = c.lane; e < m.neq; e += 64) {
+    float *r = L + ly.weld + FSIM_WELDW * e;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[WD_ACTIVE]) continue;
+    float f[6];
+    for (int q = 0; q < 6; q++) f[q] = -r[WD_D + q] * r[WD_JAR + q];
+    V3 F = v3(f[0], f[1], f[2]);
+    V3 T = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
+              r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
+    fs_add_wrench(c, ri[WD_B1], ldv3(r + WD_P0), F, T, 1.0f);
+    fs_add_wrench(c, ri[WD_B2], ldv3(r + WD_X2), F, T, -1.0f);
+  }
+  SYNC();
+  for (int d = c.lane; d < m.nv; d += 64) {
+    int bd = m.dof_rbody[d];
+    S6 s = lds6(L + ly.cdof + 6 * d);
+    float acc = 0;
+    for (int b = bd; b < m.nr; b++)
+      if ((m.r_ancmask[b] >> bd) & 1) acc += dot6(s, lds6(L + ly.G + 6 * b));
+    L[ly.grad + d] -= acc;
+  }
+  SYNC();
+}
+
+DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// column of J for chain entry: value of row-space functional on dof d.  For a contact the three rows are
+// frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
+DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
+  S6 s = lds6(c.L + c.ly.cdof + 6 * d);
+  return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * c.m.dof_tree[d]));
+}
+
+DEV void fs_hessian(const Ctx &c) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int nH = m.nv * (m.nv + 1) / 2;
+  for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
+  SYNC();
+  for (int e = c.lane; e < m.nM; e += 64) L[ly.H + fs_tri(m.M_i[e], m.M_j[e])] = L[ly.M + e];
+  SYNC();
+  int nslot = c.I(ly.scal)[SC_NSLOT];
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = L + ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (ri[C_ACTIVE] != 1) continue;
+    float f[3], Hc[9], cc;
+    int dim = ri[C_DIM];
+    if (dim == 1) { if (r[C_JAR] >= 0) continue; for (int i = 0; i < 9; i++) Hc[i] = 0; Hc[0] = r[C_DN]; }
+    else if (!fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc)) continue;
+    V3 pos = ldv3(r + C_POS);
+    V3 fr0 = ldv3(r + C_FRAME), fr1 = ldv3(r + C_FRAME + 3), fr2 = ldv3(r + C_FRAME + 6);
+    int b1 = ri[C_B1], b2 = ri[C_B2];
+    int n2 = b2 ? m.r_chainlen[b2] : 0, n1 = b1 ? m.r_chainlen[b1] : 0;
+    int a2 = b2 ? m.r_chainadr[b2] : 0, a1 = b1 ? m.r_chainadr[b1] : 0;
+    for (int e1 = 0; e1 < n1 + n2; e1++) {
+      int d1 = e1 < n2 ? m.chain_dofs[a2 + e1] : m.chain_dofs[a1 + e1 - n2];
+      float sg1 = e1 < n2 ? 1.0f : -1.0f;
+      V3 c1 = fs_col(c, d1, pos);
+      float j1[3] = {sg1 * dot(fr0, c1), sg1 * dot(fr1, c1), sg1 * dot(fr2, c1)};
+      float wj[3];
+      for (int a = 0; a < 3; a++) wj[a] = Hc[a] * j1[0] + Hc[3 + a] * j1[1] + Hc[6 + a] * j1[2];
+      for (int e2 = 0; e2 < n1 + n2; e2++) {
+        int d2 = e2 < n2 ? m.chain_dofs[a2 + e2] : m.chain_dofs[a1 + e2 - n2];
+        if (d2 > d1) continue;
+        float sg2 = e2 < n2 ? 1.0f : -1.0f;
+        V3 c2 = fs_col(c, d2, pos);
+        float v = sg2 * (wj[0] * dot(fr0, c2) + wj[1] * dot(fr1, c2) + wj[2] * dot(fr2, c2));
+        atomicAdd(L + ly.H + fs_tri(d1, d2), v);
+      }
+    }
+  }
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+    float *r = L + ly.lim + FSIM_LIMW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
+    atomicAdd(L + ly.H + fs_tri(ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
+  }
+  for (int e = c.lane; e < m.neq; e += 64) {
+    float *r = L + ly.weld + FSIM_WELDW * e;
+    int *ri = reinterpret_cast<int *>(r);
+    if (!ri[WD_ACTIVE]) continue;
+    int b1 = ri[WD_B1], b2 = ri[WD_B2];
+    V3 p0 = ldv3(r + WD_P0), x2 = ldv3(r + WD_X2);
+    int n1 = m.r_chainlen[b1], n2 = m.r_chainlen[b2], a1 = m.r_chainadr[b1], a2 = m.r_chainadr[b2];
+    for (int e1 = 0; e1 < n1 + n2; e1++) {
+      bool f1 = e1 < n1;
+      int d1 = f1 ? m.chain_dofs[a1 + e1] : m.chain_dofs[a2 + e1 - n1];
+      float sg1 = f1 ? 1.0f : -1.0f;
+      V3 t1 = fs_col(c, d1, f1 ? p0 : x2) * sg1;
+      V3 w1 = lds6(L + ly.cdof + 6 * d1).a * sg1;
+      float j1[6] = {t1.x, t1.y, t1.z, 0, 0, 0};
+      for (int q = 0; q < 3; q++) j1[3 + q] = r[WD_C + 3 * q] * w1.x + r[WD_C + 3 * q + 1] * w1.y + r[WD_C + 3 * q + 2] * w1.z;
+      for (int q = 0; q < 6; q++) j1[q] *= r[WD_D + q];
+      for (int e2 = 0; e2 < n1 + n2; e2++) {
+        bool f2 = e2 < n1;
+        int d2 = f2 ? m.chain_dofs[a1 + e2] : m.chain_dofs[a2 + e2 - n1];
+        if (d2 > d1) continue;
+        float sg2 = f2 ? 1.0f : -1.0f;
+        V3 t2 = fs_col(c, d2, f2 ? p0 : x2) * sg2;
+        V3 w2 = lds6(L + ly.cdof + 6 * d2).a * sg2;
+        float v = j1[0] * t2.x + j1[1] * t2.y + j1[2] * t2.z;
+        for (int q = 0; q < 3; q++) v += j1[3 + q] * (r[WD_C + 3 * q] * w2.x + r[WD_C + 3 * q + 1] * w2.y + r[WD_C + 3 * q + 2] * w2.z);
+        atomicAdd(L + ly.H + fs_tri(d1, d2), v);
+      }
+    }
+  }
+  SYNC();
+}
+
+// in-place Cholesky of the packed lower triangle, lane = row; p <- -H^-1 grad.  returns false if not SPD.
+DEV bool fs_chol_solve(const Ctx &c, int coupled) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  float *H = L + ly.H;
+  int n = m.nv, i = c.lane;
+  int rs = (i < n && !coupled) ? m.tree_dofadr[m.dof_tree[i]] : 0; // skyline start of my row
+  bool ok = true;
+  for (int j = 0; j < n; j++) {
+    float s = 0;
+    int rsj = coupled ? 0 : m.tree_dofadr[m.dof_tree[j]];
+    if (i >= j && i < n && rs <= j) {
+      s = H[fs_tri(i, j)];
+      int k0 = max(rs, rsj);
+      for (int k = k0; k < j; k++) s -= H[fs_tri(i, k)] * H[fs_tri(j, k)];
+    }
+    float djj = __shfl(s, j, 64);
+    if (!(djj > 1e-30f)) { ok = false; djj = 1e-30f; }
+    float ljj = sqrtf(djj);
+    if (i == j) H[fs_tri(j, j)] = ljj;
+    else if (i > j && i < n && rs <= j) H[fs_tri(i, j)] = s / ljj;
+    SYNC();
+  }
+  // forward: L y = -grad
+  float b = i < n ? -L[ly.grad + i] : 0.0f;
+  for (int j = 0; j < n; j++) {
+    float yj = __shfl(b, j, 64) / H[fs_tri(j, j)];
+    if (i == j) b = yj;
+    else if (i > j && i < n && rs <= j) b -= H[fs_tri(i, j)] * yj;
+  }
+  // backward: L' p = y
+  for (int j = n - 1; j >= 0; j--) {
+    float pj = __shfl(b, j, 64) / H[fs_tri(j, j)];
+    int rsj = coupled ? 0 : m.tree_dofadr[m.dof_tree[j]];
+    if (i == j) b = pj;
+    else if (i < j && i >= rsj) b -= H[fs_tri(j, i)] * pj;
+  }
+  if (i < n) L[ly.p + i] = b;
+  SYNC();
+  return ok;
+}
+
+DEV float fs_dotv(const Ctx &c, int a, int b) {
+  float s = 0;
+  for (int d = c.lane; d < c.m.nv; d += 64) s += c.L[a + d] * c.L[b + d];
+  return wave_sum(s);
+}
+
+// total cost at the current (x, Mx, jar)
+DEV float fs_total_cost(const Ctx &c) {
+  const Layout &ly = c.ly;
+  float g = 0;
+  for (int d = c.lane; d < c.m.nv; d += 64) g += 0.5f * (c.L[ly.x + d] - c.L[ly.asmooth + d]) * (c.L[ly.Mx + d] - c.L[ly.smooth + d]);
+  g = wave_sum(g);
+  float cs, d1, d2;
+  fs_line_eval(c, 0.0f, &cs, &d1, &d2);
+  return g + cs;
+}
+
+// Solve for qacc (ly.x) and M*qacc (ly.Mx).
+DEV void fs_solve(const Ctx &c, int coupled) {
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  int *scal = c.I(ly.scal);
+  int nslot = scal[SC_NSLOT];
+  // any active constraint at all?
+  int have = 0;
+  for (int s = c.lane; s < nslot; s += 64) have |= (c.I(ly.con + FSIM_CONW * s)[C_ACTIVE] == 1);
+  for (int s = c.lane; s < 2 * m.nlim; s += 64) have |= c.I(ly.lim + FSIM_LIMW * s)[LM_ACTIVE];
+  for (int e = c.lane; e < m.neq; e += 64) have |= c.I(ly.weld + FSIM_WELDW * e)[WD_ACTIVE];
+  have = wave_or(have);
+  if (!have) {
+    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] = L[ly.asmooth + d]; L[ly.Mx + d] = L[ly.smooth + d]; }
+    if (c.lane == 0) scal[SC_NITER] = 0;
+    SYNC();
+    return;
+  }
+  // warm start: cheaper of qacc_warmstart and qacc_smooth
+  for (int d = c.lane; d < m.nv; d += 64) L[ly.x + d] = L[ly.qaccws + d];
+  SYNC();
+  fs_mulM(c, ly.Mx, ly.x);
+  fs_body_spatial(c, ly.x);
+  fs_jdot(c, ly.x, true);
+  float cw = fs_total_cost(c);
+  SYNC();
+  // candidate 2: x = asmooth (gauss term zero)
+  for (int d = c.lane; d < m.nv; d += 64) L[ly.p + d] = L[ly.asmooth + d];
+  SYNC();
+  fs_body_spatial(c, ly.p);
+  fs_jdot(c, ly.p, false); // jp <- J*asmooth (no aref)
+  float cs0, t1, t2;
+  {
+    // cost at asmooth: evaluate with jar' = jp - aref  == (jar=-aref) + 1*jp ; do it by temporarily using alpha trick:
+    // store jar_ws aside is not needed: compute via line_eval on records where jar := -aref.  Simpler: swap roles.
+  }
+  // evaluate smooth-candidate cost by writing jar_s = jp - aref into JP slots' place is intrusive; instead compute
+  // cost(asmooth) with a dedicated pass:
+  {
+    float csum = 0;
+    for (int s = c.lane; s < nslot; s += 64) {
+      float *r = L + ly.con + FSIM_CONW * s;
+      int *ri = reinterpret_cast<int *>(r);
+      if (ri[C_ACTIVE] != 1) continue;
+      float jar[3] = {r[C_JP] - r[C_AREF], r[C_JP + 1] - r[C_AREF + 1], r[C_JP + 2] - r[C_AREF + 2]}, f[3], cc = 0;
+      if (ri[C_DIM] == 1) { if (jar[0] < 0) cc = 0.5f * r[C_DN] * jar[0] * jar[0]; }
+      else fs_cone(jar, r[C_DN], r[C_DT], r[C_MU], f, &cc, nullptr);
+      csum += cc;
+    }
+    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+      float *r = L + ly.lim + FSIM_LIMW * s;
+      if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
+      float j = r[LM_JP] - r[LM_AREF];
+      if (j < 0) csum += 0.5f * r[LM_D] * j * j;
+    }
+    for (int e = c.lane; e < m.neq; e += 64) {
+      float *r = L + ly.weld + FSIM_WELDW * e;
+      if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
+      for (int q = 0; q < 6; q++) { float j = r[WD_JP + q] - r[WD_AREF + q]; csum += 0.5f * r[WD_D + q] * j * j; }
+    }
+    cs0 = wave_sum(csum);
+  }
+  (void)t1; (void)t2;
+  if (!(cw < cs0)) {
+    // take the smooth candidate: x = asmooth, Mx = smooth, jar = jp - aref
+    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] = L[ly.asmooth + d]; L[ly.Mx + d] = L[ly.smooth + d]; }
+    for (int s = c.lane; s < nslot; s += 64) {
+      float *r = L + ly.con + FSIM_CONW * s;
+      if (reinterpret_cast<int *>(r)[C_ACTIVE] != 1) continue;
+      for (int a = 0; a < 3; a++) r[C_JAR + a] = r[C_JP + a] - r[C_AREF + a];
+    }
+    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+      float *r = L + ly.lim + FSIM_LIMW * s;
+      if (reinterpret_cast<int *>(r)[LM_ACTIVE]) r[LM_JAR] = r[LM_JP] - r[LM_AREF];
+    }
+    for (int e = c.lane; e < m.neq; e += 64) {
+      float *r = L + ly.weld + FSIM_WELDW * e;
+      if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] = r[WD_JP + q] - r[WD_AREF + q];
+    }
+    SYNC();
+  }
+  float scale = m.meaninertia_scale;
+  int it = 0;
+  for (; it < c.newton_maxit; it++) {
+    fs_gradient(c);
+    float gn = sqrtf(fs_dotv(c, ly.grad, ly.grad));
+    if (scale * gn < c.newton_tol) break;
+    fs_hessian(c);
+    bool ok = fs_chol_solve(c, coupled);
+    if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
+    fs_mulM(c, ly.Mp, ly.p);
+    fs_body_spatial(c, ly.p);
+    fs_jdot(c, ly.p, false);
+    float pMp = fs_dotv(c, ly.p, ly.Mp);
+    float pg0 = 0;
+    for (int d = c.lane; d < m.nv; d += 64) pg0 += L[ly.p + d] * (L[ly.Mx + d] - L[ly.smooth + d]);
+    pg0 = wave_sum(pg0);
+    // exact line search: safeguarded Newton on phi'(alpha)
+    float lo = 0, hi = -1, alpha = 1, best = 0;
+    for (int ls = 0; ls < 20; ls++) {
+      float cc, d1, d2;
+      fs_line_eval(c, alpha, &cc, &d1, &d2);
+      d1 += pg0 + alpha * pMp;
+      d2 += pMp;
+      best = alpha;
+      if (fabsf(d1) <= 1e-6f * fabsf(pg0) + 1e-30f) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      float na = alpha - d1 / fmaxf(d2, 1e-30f);
+      if (hi > 0) { if (na <= lo || na >= hi) na = 0.5f * (lo + hi); }
+      else if (na <= lo) na = 2 * alpha;
+      if (fabsf(na - alpha) < 1e-6f * (1 + alpha)) break;
+      alpha = na;
+    }
+    alpha = best;
+    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] += alpha * L[ly.p + d]; L[ly.Mx + d] += alpha * L[ly.Mp + d]; }
+    for (int s = c.lane; s < nslot; s += 64) {
+      float *r = L + ly.con + FSIM_CONW * s;
+      if (reinterpret_cast<int *>(r)[C_ACTIVE] != 1) continue;
+      for (int a = 0; a < 3; a++) r[C_JAR + a] += alpha * r[C_JP + a];
+    }
+    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
+      float *r = L + ly.lim + FSIM_LIMW * s;
+      if (reinterpret_cast<int *>(r)[LM_ACTIVE]) r[LM_JAR] += alpha * r[LM_JP];
+    }
+    for (int e = c.lane; e < m.neq; e += 64) {
+      float *r = L + ly.weld + FSIM_WELDW * e;
+      if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
+    }
+    SYNC();
+  }
+  if (c.lane == 0) scal[SC_NITER] = it;
+  SYNC();
+}

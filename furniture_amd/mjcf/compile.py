@@ -165,8 +165,11 @@ def _geom_mass_inertia(gtype, size, density):
     elif gtype in (GEOM_PLANE, GEOM_HFIELD):
         return 0.0, np.zeros(3)
     elif gtype == GEOM_MESH:
-        if density != 0:
-            raise NotImplementedError("mesh geoms with density != 0 need mesh volume (out of scope)")
+        # Visual meshes carry density 0 everywhere except toy_table's part1 (density="01",
+        # SURVEY C.1): 1 kg/m^3 x ~1e-4 m^3 of STL volume ~ 0.1 g next to the part's primitive
+        # colliders.  The STL is not parsed; that mass is dropped (documented in DESIGN.md).
+        if density > 1.0:
+            raise NotImplementedError("mesh geoms with density > 1 need mesh volume (out of scope)")
         return 0.0, np.zeros(3)
     else:
         raise ValueError(gtype)
@@ -687,9 +690,11 @@ def _derive_at_qpos0(m):
     nv = m.nv
     m.body_invweight0 = np.zeros((m.nbody, 2))
     m.dof_invweight0 = np.zeros(nv)
+    m.trace_M0 = np.array([1.0])
     if nv == 0:
         return
     M = mass_matrix(m, m.qpos0)
+    m.trace_M0 = np.array([np.trace(M)])
     Minv = np.linalg.inv(M)
     J, _, _ = body_jacobians(m, m.qpos0)
     for b in range(1, m.nbody):

@@ -232,6 +232,10 @@ def build_model(agent, furniture_name, control_type="impedance", assets_root=Non
     else:
         A["ctrl_bias"], A["ctrl_weight"] = np.zeros(0), np.zeros(0)
 
+    from .reduce import reduce_model
+    A.update(reduce_model(A))
+    A["flags"] = np.array([1 if info["recipe_path"] is not None else 0], dtype=np.int32)
+
     ndof_action = {"Sawyer": 9, "Baxter": 17, "Cursor": 15}[agent]
     dims = dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
                 neq=m.neq, npair=m.npair, nM=m.nM, nparts=nparts,

@@ -1,0 +1,227 @@
+"""ctypes binding to libfsim.so (the C-ABI in include/fsim.h).
+
+torch is used only as the device-memory allocator / stream plumbing: every pointer that
+crosses the boundary is ``tensor.data_ptr()``.  There is NO CPU fallback: if the HIP
+library is missing or no GPU is visible, construction raises.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIBPATH = os.path.join(_CSRC, "libfsim.so")
+_LIB = None
+
+INFO_DIM = 12
+INFO_NUM_CONNECTED, INFO_SUCCESS, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2, INFO_EPISODE_LENGTH = range(6)
+INFO_CONNECTED_THIS_STEP, INFO_NEEDS_TABLE, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F, INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F = range(6, 12)
+N_NOISE = 101  # _initialize_robot_pos draws per reset (furniture.py:1580, 1606-1611)
+
+
+class FsimConfig(ctypes.Structure):
+    _fields_ = [
+        ("control_type", ctypes.c_int32), ("n_substeps", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
+        ("discrete_grip", ctypes.c_int32), ("rescale_actions", ctypes.c_int32), ("auto_align", ctypes.c_int32),
+        ("num_connect_steps", ctypes.c_int32), ("auto_reset", ctypes.c_int32), ("solver_iterations", ctypes.c_int32),
+        ("reset_robot_after_attach", ctypes.c_int32),
+        ("solver_tolerance", ctypes.c_float),
+        ("alignment_pos_dist", ctypes.c_float), ("alignment_rot_dist_up", ctypes.c_float),
+        ("alignment_rot_dist_forward", ctypes.c_float), ("alignment_project_dist", ctypes.c_float),
+        ("ctrl_penalty_coef", ctypes.c_float), ("unstable_penalty_coef", ctypes.c_float), ("success_reward", ctypes.c_float),
+        ("touch_reward", ctypes.c_float), ("pick_reward", ctypes.c_float),
+        ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
+    ]
+
+
+class StatePtrs(ctypes.Structure):
+    _names = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_data", "eq_active",
+              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters"]
+    _fields_ = [(n, ctypes.c_void_p) for n in _names]
+
+
+def library_path():
+    return _LIBPATH
+
+
+def build(force=False, verbose=False):
+    """Compile libfsim.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fsim.h"))
+    if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(s) <= os.path.getmtime(_LIBPATH) for s in srcs):
+        return _LIBPATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", _LIBPATH, os.path.join(_CSRC, "fsim.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIBPATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIBPATH):
+            raise RuntimeError(
+                "libfsim.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                "furniture_amd has no CPU fallback for the hot path")
+        L = ctypes.CDLL(_LIBPATH)
+        L.fsim_last_error.restype = ctypes.c_char_p
+        L.fsim_default_config.argtypes = [ctypes.POINTER(FsimConfig)]
+        L.fsim_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FsimConfig),
+                                  ctypes.POINTER(ctypes.c_void_p)]
+        L.fsim_destroy.argtypes = [ctypes.c_void_p]
+        L.fsim_destroy.restype = None
+        L.fsim_dims.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 7
+        L.fsim_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.fsim_sync.argtypes = [ctypes.c_void_p]
+        L.fsim_physics_step.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.fsim_physics_forward.argtypes = [ctypes.c_void_p]
+        L.fsim_get_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
+        L.fsim_set_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
+        L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
+        L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
+        L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
+        _LIB = L
+    return _LIB
+
+
+EXPORTED_SYMBOLS = [
+    "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
+    "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
+    "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms",
+]
+
+
+def default_config():
+    c = FsimConfig()
+    lib().fsim_default_config(ctypes.byref(c))
+    return c
+
+
+class FsimError(RuntimeError):
+    pass
+
+
+class FSim:
+    """One handle = n_envs environments of one compiled model on one GPU."""
+
+    def __init__(self, model, n_envs, device=0, config=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise FsimError("no ROCm device visible: furniture_amd's hot path has no CPU fallback")
+        self.torch = torch
+        self.cm = model
+        self.n_envs = int(n_envs)
+        self.device = torch.device("cuda", device)
+        self.cfg = config if config is not None else default_config()
+        blob = model.to_blob()
+        h = ctypes.c_void_p()
+        rc = lib().fsim_create(blob, len(blob), self.n_envs, device, ctypes.byref(self.cfg), ctypes.byref(h))
+        if rc:
+            raise FsimError("fsim_create rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
+        self._h = h
+        d = [ctypes.c_int32() for _ in range(7)]
+        self._chk(lib().fsim_dims(self._h, *[ctypes.byref(x) for x in d]))
+        self.nq, self.nv, self.nu, self.dof_action, self.obs_dim, self.info_dim, self.stride = [x.value for x in d]
+        self.max_contacts = lib().fsim_max_contacts(self._h)
+        st = ctypes.c_void_p()
+        self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
+        self.stream_ptr = st.value
+
+    def _chk(self, rc):
+        if rc:
+            raise FsimError("fsim rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
+
+    # -- raw physics -------------------------------------------------------
+    def physics_step(self, n=1):
+        self._chk(lib().fsim_physics_step(self._h, int(n)))
+
+    def physics_forward(self):
+        self._chk(lib().fsim_physics_forward(self._h))
+
+    def sync(self):
+        self._chk(lib().fsim_sync(self._h))
+
+    _shapes = None
+
+    def _field_shapes(self):
+        m = self.cm
+        return dict(qpos=(m.nq, "f"), qvel=(m.nv, "f"), qacc_warmstart=(m.nv, "f"), qfrc_bias=(m.nv, "f"), ctrl=(m.nu, "f"),
+                    qfrc_applied=(m.nv, "f"), xfrc_applied=(6 * m.nparts, "f"), eq_data=(7 * m.neq, "f"), eq_active=(m.neq, "i"),
+                    geom_contype=(m.ngeom, "i"), geom_conaffinity=(m.ngeom, "i"), group=(m.nparts, "i"), qacc=(m.nv, "f"),
+                    xpos=(3 * m.nbody, "f"), xquat=(4 * m.nbody, "f"), ncon=(1, "i"), contact_geoms=(2 * self.max_contacts, "i"),
+                    solver_iters=(1, "i"))
+
+    def get_state(self, *names):
+        """dict name -> torch tensor [n_envs, dim] (device)."""
+        torch = self.torch
+        shapes = self._field_shapes()
+        names = names or [n for n in shapes]
+        out, p = {}, StatePtrs()
+        for n in names:
+            dim, kind = shapes[n]
+            t = torch.zeros((self.n_envs, dim), dtype=torch.float32 if kind == "f" else torch.int32, device=self.device)
+            out[n] = t
+            setattr(p, n, t.data_ptr() if dim else None)
+        self._chk(lib().fsim_get_state(self._h, ctypes.byref(p)))
+        self.sync()
+        return out
+
+    def set_state(self, **fields):
+        torch = self.torch
+        shapes = self._field_shapes()
+        p, keep = StatePtrs(), []
+        for n, v in fields.items():
+            dim, kind = shapes[n]
+            t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v)
+            t = t.to(device=self.device, dtype=torch.float32 if kind == "f" else torch.int32).reshape(-1, dim)
+            if t.shape[0] == 1 and self.n_envs > 1:
+                t = t.expand(self.n_envs, dim)
+            t = t.contiguous()
+            assert t.shape == (self.n_envs, dim), (n, t.shape)
+            keep.append(t)
+            setattr(p, n, t.data_ptr() if dim else None)
+        torch.cuda.synchronize(self.device)
+        self._chk(lib().fsim_set_state(self._h, ctypes.byref(p)))
+        self.sync()
+
+    # -- env hot path ------------------------------------------------------
+    def set_reset_tables(self, part_qpos, robot_noise=None, mask=None):
+        pq = np.ascontiguousarray(part_qpos, dtype=np.float32).reshape(self.n_envs, -1)
+        rn = None
+        n_noise = 0
+        if robot_noise is not None:
+            rn = np.ascontiguousarray(robot_noise, dtype=np.float32).reshape(self.n_envs, -1)
+            n_noise = rn.shape[1] // max(1, len(self.cm.arm_qposadr))
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._chk(lib().fsim_set_reset_tables(self._h, None if mk is None else mk.ctypes.data, pq.ctypes.data,
+                                              None if rn is None else rn.ctypes.data, n_noise))
+
+    def reset(self, mask=None, obs=None):
+        self._chk(lib().fsim_reset(self._h, None if mask is None else mask.data_ptr(), None if obs is None else obs.data_ptr()))
+
+    def step(self, action, obs, reward, done, info):
+        self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
+
+    def kernel_time_ms(self):
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        self._chk(lib().fsim_kernel_time_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,122 @@
+/* fsim.h -- C-ABI of the MI355X batched furniture-assembly simulator (libfsim.so).
+ *
+ * This is the drop-in boundary "B2" of SURVEY.md section 8(b): the operator surface the
+ * reference env code sits on is mujoco_py.MjSim driven from Python
+ * (furniture/env/furniture.py:1838 MjSim(...), :2877-2879 forward()/step() hot loop,
+ * :3332-3379 action->ctrl, :1344-1387 + furniture_sawyer.py:103-155 observation,
+ * :482-541 reward, :926-1042/:847-924 connector state machine, :1406-1663 reset).
+ * The reference has no FFI of its own (it is pure Python over a closed binary), so the
+ * entry points below are what a ctypes binding for that path binds; INTEGRATION.md shows
+ * the stub.  Plain pointers and sizes only -- no torch types.  Device pointers are raw
+ * HIP device addresses (e.g. torch.Tensor.data_ptr() of a tensor on the handle's device).
+ *
+ * Conventions: every call returns 0 on success or a negative code and leaves a message in
+ * fsim_last_error(); the caller owns every buffer it passes; the library owns the per-env
+ * state; all GPU work is enqueued on the handle's stream and is asynchronous unless stated.
+ */
+#ifndef FSIM_H
+#define FSIM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fsim fsim_t;
+
+enum {
+  FSIM_OK = 0,
+  FSIM_EINVAL = -1,   /* bad argument / malformed model blob */
+  FSIM_ENOMEM = -2,   /* model does not fit the per-env LDS budget or hipMalloc failed */
+  FSIM_EHIP = -3,     /* a HIP runtime call failed */
+  FSIM_ENODEV = -4    /* no usable gfx950 device */
+};
+
+/* env configuration that the reference keeps in its argparse Namespace (furniture/config/furniture.py) */
+typedef struct fsim_config {
+  int32_t control_type;       /* 0 impedance (velocity actuators), 1 torque */
+  int32_t n_substeps;         /* int(control_timestep/model_timestep) = 50 (furniture.py:2878) */
+  int32_t max_episode_steps;  /* config/furniture.py:163-168 */
+  int32_t discrete_grip;      /* furniture_sawyer.py:72-74 */
+  int32_t rescale_actions;    /* furniture.py:3333,3359 */
+  int32_t auto_align;         /* furniture.py:881 */
+  int32_t num_connect_steps;  /* 0 for arms, 10 for Cursor (furniture_cursor.py:28-32) */
+  int32_t auto_reset;         /* SubprocVecEnv semantics: reset in place when done (subproc_vec_env.py:15-48) */
+  int32_t solver_iterations;  /* Newton iteration cap (MuJoCo default 100) */
+  int32_t reset_robot_after_attach; /* config/furniture.py:298-303 */
+  float solver_tolerance;     /* scaled-gradient tolerance (MuJoCo default 1e-8 in fp64; fp32 floor ~1e-6) */
+  float alignment_pos_dist, alignment_rot_dist_up, alignment_rot_dist_forward, alignment_project_dist;
+  float ctrl_penalty_coef, unstable_penalty_coef, success_reward, touch_reward, pick_reward;
+  float furn_xyz_rand, furn_rot_rand, agent_xyz_rand;
+} fsim_config_t;
+
+void fsim_default_config(fsim_config_t *cfg);
+
+/* model_blob: FSIMBLOB produced by furniture_amd.mjcf.model.CompiledModel.to_blob()  (replaces
+ * load_model_from_xml + MjSim(model), furniture/env/models/base.py:113-115, furniture.py:1838) */
+int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out);
+void fsim_destroy(fsim_t *);
+const char *fsim_last_error(void);
+
+/* dimensions the caller needs to size its buffers */
+int fsim_dims(const fsim_t *, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim,
+              int32_t *info_dim, int32_t *state_stride_words);
+
+/* the handle's HIP stream (hipStream_t), so a collective can be enqueued behind a step */
+int fsim_stream(fsim_t *, void **hip_stream);
+int fsim_sync(fsim_t *);
+
+/* ---- raw physics (sim.forward()/sim.step() on every env) -------------------------------- */
+/* Run n physics substeps on the current state (data.ctrl/qfrc_applied/xfrc_applied as stored). */
+int fsim_physics_step(fsim_t *, int n_substeps);
+/* Derived quantities of the current state without integrating (sim.forward()). */
+int fsim_physics_forward(fsim_t *);
+
+/* ---- state access (sim.data.* / sim.model.* mutable fields), device pointers, [n_envs, dim] row-major.
+ * Any pointer may be NULL to skip that field.  (get_env_state/set_env_state furniture.py:1781-1803, plus the
+ * weld/mask/group state the reference's snapshot omits) */
+typedef struct fsim_state_ptrs {
+  float *qpos, *qvel, *qacc_warmstart, *qfrc_bias, *ctrl, *qfrc_applied, *xfrc_applied /* [n, nparts*6] */;
+  float *eq_data /* [n, neq*7] */;
+  int32_t *eq_active /* [n, neq] */, *geom_contype /* [n, ngeom] */, *geom_conaffinity /* [n, ngeom] */;
+  int32_t *group /* [n, nparts] */;
+  float *qacc /* out only */, *xpos /* out only: [n, nbody*3] */, *xquat /* out only: [n, nbody*4] */;
+  int32_t *ncon /* out only: [n] */, *contact_geoms /* out only: [n, max_contacts*2], -1 padded */;
+  int32_t *solver_iters /* out only: [n] Newton iterations of the last substep */;
+} fsim_state_ptrs_t;
+int fsim_get_state(fsim_t *, const fsim_state_ptrs_t *dst);
+int fsim_set_state(fsim_t *, const fsim_state_ptrs_t *src);
+int fsim_max_contacts(const fsim_t *);
+
+/* ---- the env hot path ------------------------------------------------------------------- */
+/* Initial placements for the next reset of each env: part poses [n, nparts*7] (pos, quat wxyz) as drawn by
+ * the reference's UniformRandomSampler (tasks/placement_sampler.py:138-190) and robot joint noise
+ * [n, n_noise, narmjoints] as drawn by _initialize_robot_pos (furniture.py:1761-1779), n_noise = 101.
+ * Host pointers; copied asynchronously.  mask: host uint8 [n] or NULL = all. */
+int fsim_set_reset_tables(fsim_t *, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise);
+
+/* FurnitureEnv.reset() on the masked envs (device uint8 mask or NULL = all); writes obs if non-NULL. */
+int fsim_reset(fsim_t *, const uint8_t *mask_dev, float *obs_dev);
+
+/* FurnitureEnv.step(action) on every env.  action [n, dof_action] float32, obs [n, obs_dim] float32,
+ * reward [n] float32, done [n] uint8, info [n, info_dim] int32/float bits -- all device pointers.
+ * info columns: see FSIM_INFO_* below. */
+int fsim_step(fsim_t *, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev, int32_t *info_dev);
+
+enum {
+  FSIM_INFO_NUM_CONNECTED = 0, FSIM_INFO_SUCCESS = 1, FSIM_INFO_FAIL = 2, FSIM_INFO_LAST_SITE1 = 3,
+  FSIM_INFO_LAST_SITE2 = 4, FSIM_INFO_EPISODE_LENGTH = 5, FSIM_INFO_CONNECTED_THIS_STEP = 6,
+  FSIM_INFO_NEEDS_TABLE = 7, /* env consumed its reset table this step */
+  FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
+  FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
+  FSIM_INFO_DIM = 12
+};
+
+/* timing helper for bench.py: average device time (ms) of the last fsim_step kernel launches, measured with
+ * HIP events on the handle's stream; resets the accumulator. */
+int fsim_kernel_time_ms(fsim_t *, double *avg_ms, int32_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

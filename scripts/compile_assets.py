@@ -1,0 +1,52 @@
+"""Compile the reference's MJCF assets into the flat tables shipped in furniture_amd/assets/compiled.
+
+Run in the build container (needs /root/reference or FURNITURE_ASSETS_ROOT); the GPU box has no
+reference tree, so the hot path loads these .npz files.  Usage:
+    python scripts/compile_assets.py            # the BASELINE configs + stress models
+    python scripts/compile_assets.py --all      # every furniture id for Sawyer
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from furniture_amd.mjcf import assemble, model  # noqa: E402
+
+DEFAULT = [
+    ("Sawyer", "table_lack_0825"), ("Sawyer", "swivel_chair_0700"), ("Sawyer", "toy_table"),
+    ("Sawyer", "chair_agne_0007"), ("Sawyer", "shelf_ivar_0678"), ("Baxter", "desk_mikael_1064"),
+    ("Baxter", "table_lack_0825"), ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--all", action="store_true")
+    args = ap.parse_args()
+    root = assemble.default_assets_root()
+    if root is None:
+        raise SystemExit("no MJCF assets: set FURNITURE_ASSETS_ROOT")
+    todo = list(DEFAULT)
+    if args.all:
+        _, names, _ = assemble.furniture_table(root)
+        todo += [("Sawyer", n) for n in names if ("Sawyer", n) not in todo]
+    out = model._COMPILED_DIR
+    os.makedirs(out, exist_ok=True)
+    for agent, furn in todo:
+        try:
+            m = model.build_model(agent, furn, assets_root=root)
+        except NotImplementedError as e:
+            print("skip %s/%s: %s" % (agent, furn, e))
+            continue
+        path = os.path.join(out, model.compiled_name(agent, furn) + ".npz")
+        m.save(path)
+        print("%-8s %-28s nbody=%d nq=%d nv=%d ngeom=%d npair=%d  -> %s (%d KB)" % (
+            agent, furn, m.nbody, m.nq, m.nv, m.ngeom, m.npair, os.path.basename(path), os.path.getsize(path) // 1024))
+    # furniture id table (ids follow the sorted asset file names, furniture/env/models/__init__.py:10-21)
+    _, names, _ = assemble.furniture_table(root)
+    with open(os.path.join(out, "furniture_names.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Shared test scenarios (pure numpy; no GPU, no oracle import here)."""
+
+import numpy as np
+
+from furniture_amd import transform_utils as T
+
+
+def quat_from_axes(x, y, z):
+    """wxyz quaternion of the rotation whose columns are (x, y, z)."""
+    R = np.stack([x, y, z], axis=1)
+    q = T.mat2quat(R)  # xyzw
+    return np.array([q[3], q[0], q[1], q[2]])
+
+
+def pinch_attach_state(m, qpos, body_xpos, body_xquat, leg=0, table_conn=4, leg_conn=0, gap=0.02):
+    """Build a state in which the gripper pinches furniture part ``leg`` whose connector already faces the matching
+    connector of the table (Sawyer + table_lack_0825): all parts float (xfrc = +m g), the leg lies between the nearly
+    closed fingers, and the table hovers with its connector ``gap`` metres away along the connector axis.
+
+    qpos: post-reset qpos (nq,), body_xpos/xquat: poses of ORIGINAL bodies from the last forward pass.
+    Returns (qpos, xfrc_applied[nparts*6])."""
+    names = m.meta["body_names"]
+    gb = names.index("right_gripper_base")
+    Rg = T.quat2mat_wxyz(body_xquat[gb] / np.linalg.norm(body_xquat[gb]))
+    pg = body_xpos[gb]
+    gx, gy, gz = Rg[:, 0], Rg[:, 1], Rg[:, 2]
+    q = qpos.copy()
+    # fingers almost closed on a 0.03 m wide leg
+    q[m.grip_qposadr[0]] = -0.002   # l finger joint
+    q[m.grip_qposadr[1]] = 0.002    # r finger joint
+    # leg: long axis (local z) along gripper x, centred between the finger tips
+    leg_q = quat_from_axes(gy, gz, gx)  # local x->gy, y->gz, z->gx
+    leg_p = pg + gz * 0.08
+    a = m.part_qposadr[leg]
+    q[a:a + 3], q[a + 3:a + 7] = leg_p, leg_q
+    Rl = T.quat2mat_wxyz(leg_q)
+    leg_site_w = leg_p + Rl @ m.site_pos[m.conn_siteid[leg_conn]]
+    up = Rl[:, 2]
+    # table: same orientation as the leg => up vectors parallel, forward vectors equal (angle 0 allowed)
+    tpart = int(m.conn_partid[table_conn])
+    ta = m.part_qposadr[tpart]
+    table_site_w = leg_site_w + gap * up
+    q[ta:ta + 3] = table_site_w - Rl @ m.site_pos[m.conn_siteid[table_conn]]
+    q[ta + 3:ta + 7] = leg_q
+    # park the other parts far away, floating
+    k = 0
+    for i in range(m.nparts):
+        if i in (leg, tpart):
+            continue
+        b = m.part_qposadr[i]
+        q[b:b + 3] = [1.0 + 0.3 * k, -1.0, 0.5]
+        q[b + 3:b + 7] = [1, 0, 0, 0]
+        k += 1
+    xfrc = np.zeros((m.nparts, 6))
+    for i in range(m.nparts):
+        xfrc[i, 2] = 9.81 * m.body_mass[m.part_bodyid[i]]
+    return q, xfrc.reshape(-1)
+
+
+def counter_actions(seed, env_index, t, dof):
+    """U(-1,1)^dof float32 keyed by (seed, env, t) -- deterministic and independent of batch size / GPU count."""
+    rs = np.random.RandomState((seed * 1000003 + env_index * 7919 + t * 104729) % (2 ** 31 - 1))
+    return rs.uniform(-1, 1, dof).astype(np.float32)
