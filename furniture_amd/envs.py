@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's env surface for the accelerated path.
+
+* ``FurnitureBatchEnv``  -- the batched replacement of ``SubprocVecEnv`` (furniture/util/subproc_vec_env.py):
+  n envs of one (agent, furniture) pair on one GPU, VecEnv-shaped (reset / step_async / step_wait / step).
+* ``FurnitureSawyerEnv`` / ``FurnitureBaxterEnv`` / ``FurnitureCursorEnv`` -- single-env classes with the reference's
+  ``reset()/step()/observation_space/action_space/dof`` (furniture/env/furniture_{sawyer,baxter,cursor}.py).
+* ``make_env`` / ``make`` -- name and gym-id registry (furniture/env/base.py:14-52, furniture/env/__init__.py:19-114).
+
+Everything numeric happens in libfsim.so; this file is plumbing (config intake, reset-table sampling with the
+reference's RNG stream, tensor allocation).  No CPU fallback: without the HIP library / a GPU construction raises.
+"""
+
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import spaces
+from . import transform_utils as T
+from .mjcf.model import load_compiled
+from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
+                  INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUCCESS, N_NOISE, default_config)
+
+# furniture/config/furniture.py defaults that matter on the hot path (file:line in the reference)
+DEFAULTS = dict(
+    unity=True,                 # :21-23  (must be disabled: rendering is out of scope)
+    control_type="ik",          # :54-57
+    control_freq=10,            # :71-73
+    rescale_actions=True,       # :74-79
+    discrete_grip=True,         # :89-94
+    auto_align=True,            # :95-100
+    record_vid=True,            # :146-148 (must be disabled)
+    record_demo=False,
+    max_episode_steps=2000,     # :163-168
+    furn_xyz_rand=0.02, furn_rot_rand=3, agent_xyz_rand=0.001, furn_size_rand=0.0,   # :177-200
+    alignment_pos_dist=0.1, alignment_rot_dist_up=0.9, alignment_rot_dist_forward=0.9, alignment_project_dist=0.3,  # :203-226
+    robot_ob=True, object_ob=True, object_ob_all=True, visual_ob=False, subtask_ob=False,  # :229-252
+    ctrl_penalty_coef=1e-3, unstable_penalty_coef=100, success_reward=100, touch_reward=10, pick_reward=100,  # :291-295
+    reset_robot_after_attach=False, no_collision=False,
+    furniture_name=None, furniture_id=0, seed=123, move_speed=0.1,
+)
+# furniture/config/furniture_sawyer_dense.py:5-14
+DENSE_OVERRIDES = dict(max_episode_steps=150, control_type="impedance", furniture_name="table_lack_0825", unity=False,
+                       auto_align=False, alignment_pos_dist=0.02, alignment_rot_dist_up=0.99, alignment_rot_dist_forward=0.99,
+                       alignment_project_dist=0.0)
+
+GYM_IDS = {  # furniture/env/__init__.py:19-114
+    "IKEACursor-v0": ("FurnitureCursorEnv", dict(furniture_id=0)),
+    "IKEASawyer-v0": ("FurnitureSawyerEnv", dict(furniture_name="swivel_chair_0700")),
+    "IKEABaxter-v0": ("FurnitureBaxterEnv", dict(furniture_id=1)),
+}
+
+
+def make_config(**kw):
+    cfg = dict(DEFAULTS)
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+def furniture_names():
+    import os
+    from .mjcf.model import _COMPILED_DIR
+    with open(os.path.join(_COMPILED_DIR, "furniture_names.txt")) as f:
+        return [x.strip() for x in f if x.strip()]
+
+
+class ResetTableSampler:
+    """Per-env replay of the reference's reset-time RNG stream (``self._rng = RandomState(seed)``, furniture.py:72):
+    UniformRandomSampler.sample() draws (tasks/placement_sampler.py:138-190) followed by the 101 joint-noise draws of
+    _initialize_robot_pos() (furniture.py:1761-1779 called at :1580 and 100x at :1606-1611).  Env i of the global batch
+    is seeded seed + i (furniture/env/base.py:77), independent of how the batch is split over GPUs."""
+
+    def __init__(self, model, cfg, seed, first_env_index, n_envs):
+        self.m, self.cfg = model, cfg
+        self.rngs = [np.random.RandomState(seed + first_env_index + i) for i in range(n_envs)]
+        self.narm = len(model.arm_qposadr)
+
+    def _placement(self, rng):
+        m, r = self.m, self.cfg.furn_xyz_rand
+        lo, hi = min(-r, r), max(-r, r)
+        rot_hi = max(-self.cfg.furn_rot_rand, self.cfg.furn_rot_rand)
+        out = np.zeros((m.nparts, 7))
+        placed = []
+        for i in range(m.nparts):
+            base, rad = m.part_initqpos[i], m.part_hradius[i]
+            for _ in range(10000):
+                x = base[0] + rng.uniform(high=hi, low=lo)
+                y = base[1] + rng.uniform(high=hi, low=lo)
+                if all(np.linalg.norm([x - px, y - py], 2) > pr + rad for px, py, pr in placed):
+                    noise = rng.uniform(high=rot_hi, low=rot_hi)  # reference quirk: constant angle, one draw consumed
+                    quat = T.euler_to_quat([noise, 0, 0], base[3:7])
+                    out[i] = [x, y, base[2] + 0.01] + list(quat)
+                    placed.append((x, y, rad))
+                    break
+            else:
+                raise RuntimeError("Cannot place all objects on the desk")
+        return out
+
+    def draw(self, mask=None):
+        """(part_qpos [n, nparts*7], robot_noise [n, 101*narm]) for the envs selected by mask (others zero)."""
+        n = len(self.rngs)
+        parts = np.zeros((n, self.m.nparts * 7), dtype=np.float32)
+        noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
+        for i, rng in enumerate(self.rngs):
+            if mask is not None and not mask[i]:
+                continue
+            parts[i] = self._placement(rng).reshape(-1)
+            if self.narm:
+                a = self.cfg.agent_xyz_rand
+                # one (101, narm) draw consumes the Mersenne-Twister stream exactly like 101 successive size-narm draws
+                noise[i] = rng.uniform(low=-a, high=a, size=(N_NOISE, self.narm)).reshape(-1)
+        return parts, noise
+
+
+_AGENT_OF = {"FurnitureSawyerEnv": "Sawyer", "FurnitureBaxterEnv": "Baxter", "FurnitureCursorEnv": "Cursor"}
+
+
+class FurnitureBatchEnv:
+    """n_envs copies of FurnitureEnv on one GPU.  Observations / rewards / dones are torch tensors on the device."""
+
+    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, **kw):
+        cfg = config if config is not None else make_config()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        if cfg.unity or cfg.record_vid or cfg.visual_ob:
+            raise ValueError("unity / record_vid / visual_ob must be False: rendering is outside the accelerated hot path")
+        if cfg.control_type != "impedance":
+            raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' (ik needs pybullet; "
+                                      "the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl)" % cfg.control_type)
+        if agent == "Cursor":
+            raise NotImplementedError("FurnitureCursorEnv is CPU-checker-only in this round (BASELINE config 1)")
+        if cfg.furn_size_rand != 0:
+            raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
+        names = furniture_names()
+        fname = cfg.furniture_name or names[cfg.furniture_id]
+        self.agent, self.furniture_name, self.config = agent, fname, cfg
+        self.model = load_compiled(agent, fname)
+        c = default_config()
+        c.n_substeps = int((1.0 / cfg.control_freq) / float(self.model.opt[0]))
+        c.max_episode_steps = int(cfg.max_episode_steps)
+        c.discrete_grip, c.rescale_actions, c.auto_align = int(cfg.discrete_grip), int(cfg.rescale_actions), int(cfg.auto_align)
+        c.auto_reset = 1 if auto_reset else 0
+        for k in ("alignment_pos_dist", "alignment_rot_dist_up", "alignment_rot_dist_forward", "alignment_project_dist",
+                  "ctrl_penalty_coef", "unstable_penalty_coef", "success_reward", "touch_reward", "pick_reward",
+                  "furn_xyz_rand", "furn_rot_rand", "agent_xyz_rand"):
+            setattr(c, k, float(getattr(cfg, k)))
+        if getattr(cfg, "solver_tolerance", None) is not None:
+            c.solver_tolerance = float(cfg.solver_tolerance)
+        self.sim = FSim(self.model, num_envs, device=device, config=c)
+        self.num_envs = num_envs
+        torch = self.sim.torch
+        dev = self.sim.device
+        self._obs = torch.zeros((num_envs, self.sim.obs_dim), dtype=torch.float32, device=dev)
+        self._rew = torch.zeros(num_envs, dtype=torch.float32, device=dev)
+        self._done = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._info = torch.zeros((num_envs, INFO_DIM), dtype=torch.int32, device=dev)
+        self._act = torch.zeros((num_envs, self.sim.dof_action), dtype=torch.float32, device=dev)
+        self._sampler = ResetTableSampler(self.model, cfg, cfg.seed, first_env_index, num_envs)
+        self._tables_fresh = False
+        self.n_obj = self.model.nparts
+        self.refill_tables_every_step = True
+
+    # -- spaces (furniture.py:215-310, furniture_sawyer.py:28-64) ---------------------------------------
+    @property
+    def dof(self):
+        return self.sim.dof_action
+
+    @property
+    def observation_space(self):
+        return spaces.Dict([("object_ob", spaces.Box(-np.inf, np.inf, shape=(7 * self.n_obj,))),
+                            ("robot_ob", spaces.Box(-np.inf, np.inf, shape=(self.sim.obs_dim - 7 * self.n_obj,)))])
+
+    @property
+    def action_space(self):
+        return spaces.Dict([("default", spaces.Box(-1, 1, shape=(self.dof,), dtype=np.float32))])
+
+    def _split(self, flat):
+        k = 7 * self.n_obj
+        return OrderedDict([("object_ob", flat[:, :k]), ("robot_ob", flat[:, k:])])
+
+    def _refill(self, mask=None):
+        parts, noise = self._sampler.draw(mask)
+        self.sim.set_reset_tables(parts, noise, mask=mask)
+
+    def reset(self):
+        self._refill()
+        self.sim.reset(None, self._obs)
+        self._refill()  # tables for the first auto-reset
+        self.sim.sync()
+        return self._split(self._obs)
+
+    def step_async(self, actions):
+        torch = self.sim.torch
+        a = actions
+        if isinstance(a, dict):
+            a = a["default"]
+        if not torch.is_tensor(a):
+            a = torch.as_tensor(np.asarray(a, dtype=np.float32))
+        self._act.copy_(a.reshape(self.num_envs, -1), non_blocking=True)
+        torch.cuda.current_stream(self.sim.device).synchronize()  # action must be resident before the handle's stream runs
+        self.sim.step(self._act, self._obs, self._rew, self._done, self._info)
+
+    def step_wait(self):
+        self.sim.sync()
+        if self.refill_tables_every_step:
+            need = self._info[:, INFO_NEEDS_TABLE].bool()
+            if bool(need.any()):
+                self._refill(need.cpu().numpy())
+        info = self._info
+        infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
+                     site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
+                     connected=info[:, INFO_CONNECTED_THIS_STEP])
+        return self._split(self._obs), self._rew, self._done.bool(), infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def get_env_state(self):
+        """Full snapshot (the reference's {qpos, qvel} plus the weld/mask/group state it omits)."""
+        return self.sim.get_state("qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group")
+
+    def close(self):
+        self.sim.close()
+
+
+class _SingleEnv:
+    """n_envs = 1 view with numpy / python scalars, shaped like the reference's env classes."""
+
+    _agent = None
+
+    def __init__(self, config=None, device=0, **kw):
+        self._b = FurnitureBatchEnv(self._agent, 1, config=config, device=device, auto_reset=False, **kw)
+        self._max_episode_steps = self._b.config.max_episode_steps
+
+    # reference surface -------------------------------------------------------------------------------
+    @property
+    def dof(self):
+        return self._b.dof
+
+    @property
+    def observation_space(self):
+        return self._b.observation_space
+
+    @property
+    def action_space(self):
+        return self._b.action_space
+
+    @property
+    def action_size(self):
+        return spaces.flatdim(self.action_space)
+
+    @property
+    def max_episode_steps(self):
+        return self._max_episode_steps
+
+    def num_subtask(self):
+        return self._b.n_obj - 1
+
+    def _np(self, ob):
+        return OrderedDict((k, v[0].double().cpu().numpy()) for k, v in ob.items())
+
+    def reset(self, furniture_id=None, background=None):
+        if furniture_id is not None and self._b.furniture_name != furniture_names()[furniture_id]:
+            raise NotImplementedError("changing furniture_id on reset: construct a new env instead")
+        return self._np(self._b.reset())
+
+    def step(self, action):
+        if isinstance(action, list):
+            action = {k: v for a in action for k, v in a.items()}
+        if isinstance(action, dict):
+            action = np.concatenate([action[k] for k in self.action_space.spaces.keys()])
+        # single-env semantics: no auto-reset inside step (the caller resets, as with the reference's gym.Env)
+        ob, rew, done, info = self._b.step(np.asarray(action, dtype=np.float32)[None])
+        return self._np(ob), float(rew[0]), bool(done[0]), {k: int(v[0]) for k, v in info.items()}
+
+    def get_env_state(self):
+        s = self._b.get_env_state()
+        return {k: v[0].cpu().numpy() for k, v in s.items()}
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering (Unity / MuJoCo viewer) is outside the accelerated hot path")
+
+    def close(self):
+        self._b.close()
+
+
+class FurnitureSawyerEnv(_SingleEnv):
+    _agent = "Sawyer"
+
+
+class FurnitureBaxterEnv(_SingleEnv):
+    _agent = "Baxter"
+
+
+class FurnitureCursorEnv(_SingleEnv):
+    _agent = "Cursor"
+
+
+REGISTRY = {"FurnitureSawyerEnv": FurnitureSawyerEnv, "FurnitureBaxterEnv": FurnitureBaxterEnv, "FurnitureCursorEnv": FurnitureCursorEnv}
+
+
+def make_env(name, config=None, **kw):
+    """furniture/env/base.py:14-24: bad env name -> Exception."""
+    if name not in REGISTRY:
+        raise Exception("No such environment: %s (accelerated path: %s)" % (name, ", ".join(REGISTRY)))
+    return REGISTRY[name](config=config, **kw)
+
+
+def make(env_id, **kw):
+    """gym.make(id, **kw) equivalent for the registered ids."""
+    if env_id in ("IKEASawyerDense-v0", "furniture-sawyer-densereward-v0"):
+        raise NotImplementedError("the dense-reward env is SURVEY row f1 (next), not part of this round")
+    if env_id not in GYM_IDS:
+        raise Exception("unknown env id %s" % env_id)
+    name, defaults = GYM_IDS[env_id]
+    merged = dict(defaults)
+    merged.update(kw)
+    return make_env(name, make_config(**merged))
+
+
+def make_vec_env(agent, num_envs, config=None, device=0, first_env_index=0, **kw):
+    """furniture/env/base.py:55-80 replacement: one batched env instead of num_envs subprocesses."""
+    return FurnitureBatchEnv(agent, num_envs, config=config, device=device, first_env_index=first_env_index, **kw)

@@ -34,11 +34,15 @@ for t_ in range(10):
 # scripted attach on env 0..N-1 (same state everywhere) vs oracle env 0
 st = sim.get_state("qpos", "xpos", "xquat")
 q0 = st["qpos"][0].cpu().numpy().astype(np.float64)
-q, xfrc = pinch_attach_state(m, envs[0].sim.data.qpos.copy(), envs[0].sim.data.xpos.copy(), envs[0].sim.data.xquat.copy())
+q, xfrc, masks = pinch_attach_state(m, envs[0].sim.data.qpos.copy(), envs[0].sim.data.xpos.copy(), envs[0].sim.data.xquat.copy())
 o = envs[0]
 o.sim.data.qpos[:] = q; o.sim.data.qvel[:] = 0; o.sim.data.qacc_warmstart[:] = 0
 for i in range(m.nparts): o.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
-sim.set_state(qpos=q[None], qvel=np.zeros((1, m.nv)), qacc_warmstart=np.zeros((1, m.nv)), xfrc_applied=xfrc[None])
+gm = sim.get_state("geom_contype", "geom_conaffinity")
+for g, (ct, ca) in masks.items():
+    o.sim.model.geom_contype[g], o.sim.model.geom_conaffinity[g] = ct, ca
+    gm["geom_contype"][:, g] = ct; gm["geom_conaffinity"][:, g] = ca
+sim.set_state(qpos=q[None], qvel=np.zeros((1, m.nv)), qacc_warmstart=np.zeros((1, m.nv)), xfrc_applied=xfrc[None], geom_contype=gm["geom_contype"], geom_conaffinity=gm["geom_conaffinity"])
 a = np.zeros(9, dtype=np.float32); a[7] = 1.0; a[8] = 1.0
 for t_ in range(3):
     act.copy_(torch.as_tensor(np.tile(a, (N, 1)))); sim.step(act, obs, rew, done, info); sim.sync()

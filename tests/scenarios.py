@@ -18,7 +18,9 @@ def pinch_attach_state(m, qpos, body_xpos, body_xquat, leg=0, table_conn=4, leg_
     closed fingers, and the table hovers with its connector ``gap`` metres away along the connector axis.
 
     qpos: post-reset qpos (nq,), body_xpos/xquat: poses of ORIGINAL bodies from the last forward pass.
-    Returns (qpos, xfrc_applied[nparts*6])."""
+    The table's collider is given contype = conaffinity = 2 so that it is a ghost for the robot, the floor and the leg
+    (the 0.64 m top would otherwise hit arm links in most arm poses); _connect() rewrites the masks of both groups anyway.
+    Returns (qpos, xfrc_applied[nparts*6], {geom id: (contype, conaffinity)})."""
     names = m.meta["body_names"]
     gb = names.index("right_gripper_base")
     Rg = T.quat2mat_wxyz(body_xquat[gb] / np.linalg.norm(body_xquat[gb]))
@@ -36,12 +38,17 @@ def pinch_attach_state(m, qpos, body_xpos, body_xquat, leg=0, table_conn=4, leg_
     Rl = T.quat2mat_wxyz(leg_q)
     leg_site_w = leg_p + Rl @ m.site_pos[m.conn_siteid[leg_conn]]
     up = Rl[:, 2]
-    # table: same orientation as the leg => up vectors parallel, forward vectors equal (angle 0 allowed)
+    # table: same "up" (local z) as the leg, local x chosen among the leg's +-x/+-y so that the 0.64 m long top
+    # extends upwards, away from the floor (forward vectors then differ by a multiple of 90 degrees, which is allowed)
     tpart = int(m.conn_partid[table_conn])
     ta = m.part_qposadr[tpart]
+    cands = [gy, -gy, gz, -gz]
+    tx = cands[int(np.argmax([c[2] for c in cands]))]
+    Rt = np.stack([tx, np.cross(up, tx), up], axis=1)
+    table_q = quat_from_axes(Rt[:, 0], Rt[:, 1], Rt[:, 2])
     table_site_w = leg_site_w + gap * up
-    q[ta:ta + 3] = table_site_w - Rl @ m.site_pos[m.conn_siteid[table_conn]]
-    q[ta + 3:ta + 7] = leg_q
+    q[ta:ta + 3] = table_site_w - Rt @ m.site_pos[m.conn_siteid[table_conn]]
+    q[ta + 3:ta + 7] = table_q
     # park the other parts far away, floating
     k = 0
     for i in range(m.nparts):
@@ -54,7 +61,8 @@ def pinch_attach_state(m, qpos, body_xpos, body_xquat, leg=0, table_conn=4, leg_
     xfrc = np.zeros((m.nparts, 6))
     for i in range(m.nparts):
         xfrc[i, 2] = 9.81 * m.body_mass[m.part_bodyid[i]]
-    return q, xfrc.reshape(-1)
+    masks = {g: (2, 2) for g in range(m.ngeom) if m.geom_is_partcol[g] and m.body_partid[m.geom_bodyid[g]] == tpart}
+    return q, xfrc.reshape(-1), masks
 
 
 def counter_actions(seed, env_index, t, dof):

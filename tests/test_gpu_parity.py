@@ -1,0 +1,228 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs,
+plus size-independent properties at BASELINE size (4096 envs).  Tolerances: the device integrates in fp32, the oracle
+in fp64; connector/attach indices, collision masks and weld activity are integers and must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from furniture_amd.mjcf.model import load_compiled
+from furniture_amd.sim import FSim, INFO_DIM, default_config
+from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+from oracle.oracle_sim import OracleSim
+from tests.scenarios import counter_actions, pinch_attach_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _initial(m, n, rng, arm_noise=0.3, vel=0.2):
+    q = np.tile(m.qpos0, (n, 1))
+    q[:, m.arm_qposadr] = m.arm_initqpos + rng.uniform(-arm_noise, arm_noise, (n, len(m.arm_qposadr)))
+    q[:, m.grip_qposadr] = m.grip_initqpos
+    for i in range(m.nparts):
+        a = m.part_qposadr[i]
+        q[:, a:a + 7] = m.part_initqpos[i]
+        q[:, a:a + 2] += rng.uniform(-0.02, 0.02, (n, 2))
+        q[:, a + 2] += 0.01
+    return q, rng.uniform(-vel, vel, (n, m.nv))
+
+
+@pytest.mark.parametrize("key", [("Sawyer", "table_lack_0825"), ("Sawyer", "swivel_chair_0700"), ("Baxter", "desk_mikael_1064")])
+def test_forward_dynamics_match_oracle(key):
+    """kinematics, RNE bias and accelerations of random states (free space + velocities)."""
+    m = load_compiled(*key)
+    n = 32
+    q, v = _initial(m, n, np.random.RandomState(0), arm_noise=0.2)
+    sim = FSim(m, n)
+    sim.set_state(qpos=q, qvel=v)
+    sim.physics_forward()
+    st = {k: t.cpu().numpy() for k, t in sim.get_state("qacc", "xpos", "xquat", "qfrc_bias", "ncon").items()}
+    orc = OracleSim(m)
+    orc.set_solver(100, 1e-10, "newton")
+    checked = 0
+    for e in range(n):
+        orc.reset()
+        orc.data.qpos[:], orc.data.qvel[:] = q[e], v[e]
+        orc.forward()
+        assert np.abs(st["xpos"][e].reshape(-1, 3) - orc.data.xpos).max() < 2e-6
+        assert np.abs(st["xquat"][e].reshape(-1, 4) - orc.data.xquat).max() < 2e-6
+        assert np.abs(st["qfrc_bias"][e] - orc.data.qfrc_bias).max() < 2e-4 * (1 + np.abs(orc.data.qfrc_bias).max())
+        if orc.ncon == 0 and st["ncon"][e, 0] <= 1:  # (the l0/base sphere-cylinder pair touches at exactly 0 distance)
+            assert np.abs(st["qacc"][e] - orc.data.qacc).max() < 1e-5 * (1 + np.abs(orc.data.qacc).max())
+            checked += 1
+    assert checked >= n // 2
+    sim.close()
+
+
+def test_contact_trajectory_matches_oracle(sawyer_lack):
+    """parts dropped on the floor, arm gravity-compensated: 400 substeps stay within 1e-5 of the fp64 oracle."""
+    m = sawyer_lack
+    n = 16
+    q, _ = _initial(m, n, np.random.RandomState(1), arm_noise=0.0)
+    sim = FSim(m, n)
+    sim.set_state(qpos=q, qvel=np.zeros((n, m.nv)), qacc_warmstart=np.zeros((n, m.nv)))
+    sim.physics_forward()
+    bias = sim.get_state("qfrc_bias")["qfrc_bias"].cpu().numpy()
+    rd = np.concatenate([m.arm_dofadr, m.grip_dofadr])
+    app = np.zeros((n, m.nv))
+    app[:, rd] = bias[:, rd]
+    sim.set_state(qfrc_applied=app)
+    sim.physics_step(400)
+    st = sim.get_state("qpos", "qvel", "contact_geoms", "ncon")
+    for e in range(3):
+        o = OracleSim(m)
+        o.set_solver(100, 1e-10, "newton")
+        o.reset()
+        o.data.qpos[:] = q[e]
+        o.forward()
+        o.data.qfrc_applied[rd] = o.data.qfrc_bias[rd]
+        for _ in range(400):
+            o.step()
+        assert np.abs(st["qpos"][e].cpu().numpy() - o.data.qpos).max() < 1e-5
+        assert np.abs(st["qvel"][e].cpu().numpy() - o.data.qvel).max() < 1e-4
+        cg = st["contact_geoms"][e].cpu().numpy().reshape(-1, 2)
+        gpu = sorted(tuple(int(x) for x in r) for r in cg if r[0] >= 0)
+        floor = m.floor_geomid[0]
+        assert [c for c in gpu if c[0] == floor] == sorted(c for c in o.contacts() if c[0] == floor)  # 5 parts x 4 corners
+    sim.close()
+
+
+def test_env_reset_steps_and_attach_match_oracle(sawyer_lack):
+    m = sawyer_lack
+    n = 4
+    cfg = default_config()
+    cfg.max_episode_steps = 150
+    cfg.auto_reset = 0
+    sim = FSim(m, n, config=cfg)
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10)) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+    noise = np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs])
+    sim.set_reset_tables(parts, noise)
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    for e in range(n):
+        assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(obs_o[e])).max() < 5e-5
+    act = torch.zeros((n, 9), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    for t in range(5):
+        a = np.stack([counter_actions(123, i, t, 9) for i in range(n)])
+        act.copy_(torch.as_tensor(a))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        for e in range(n):
+            ob, r, d, inf = envs[e].step(a[e])
+            assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob)).max() < 2e-4
+            assert abs(float(rew[e]) - r) < 1e-5 and bool(done[e]) == d
+    # scripted pinch + connect: integer results bit-exact
+    o = envs[0]
+    q, xfrc, masks = pinch_attach_state(m, o.sim.data.qpos.copy(), o.sim.data.xpos.copy(), o.sim.data.xquat.copy())
+    o.sim.data.qpos[:], o.sim.data.qvel[:], o.sim.data.qacc_warmstart[:] = q, 0, 0
+    for i in range(m.nparts):
+        o.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+    gm = sim.get_state("geom_contype", "geom_conaffinity")
+    for g, (ct, ca) in masks.items():
+        o.sim.model.geom_contype[g], o.sim.model.geom_conaffinity[g] = ct, ca
+        gm["geom_contype"][:, g], gm["geom_conaffinity"][:, g] = ct, ca
+    sim.set_state(qpos=q[None], qvel=np.zeros((1, m.nv)), qacc_warmstart=np.zeros((1, m.nv)), xfrc_applied=xfrc[None],
+                  geom_contype=gm["geom_contype"], geom_conaffinity=gm["geom_conaffinity"])
+    a = np.zeros(9, dtype=np.float32)
+    a[7] = a[8] = 1.0
+    act.copy_(torch.as_tensor(np.tile(a, (n, 1))))
+    torch.cuda.synchronize()
+    sim.step(act, obs, rew, done, info)
+    sim.sync()
+    ob, r, d, inf = o.step(a)
+    gi = info[0].cpu().numpy()
+    assert inf["num_connected"] == 1
+    assert (gi[0], gi[3], gi[4], gi[6]) == (inf["num_connected"], inf["site1"], inf["site2"], inf["connected_this_step"])
+    assert abs(float(rew[0]) - r) < 1e-4
+    st = sim.get_state("eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group")
+    assert np.array_equal(st["eq_active"][0].cpu().numpy(), o.sim.model.eq_active)
+    assert np.array_equal(st["geom_contype"][0].cpu().numpy(), o.sim.model.geom_contype)
+    assert np.array_equal(st["geom_conaffinity"][0].cpu().numpy(), o.sim.model.geom_conaffinity)
+    assert [int(x) for x in st["group"][0].cpu().numpy()] == [o._find_group(i) if o._group[i] != i else i for i in range(m.nparts)] or \
+        sorted(set(int(x) for x in st["group"][0].cpu().numpy())) == sorted(set(o._find_group(i) for i in range(m.nparts)))
+    assert np.abs(st["eq_data"][0].cpu().numpy().reshape(-1, 7) - o.sim.model.eq_data).max() < 1e-5
+    # all n device envs saw the same state and action: identical integer outcomes
+    assert torch.equal(info[:, [0, 3, 4, 6]], info[0:1, [0, 3, 4, 6]].expand(n, 4))
+    sim.close()
+
+
+def test_determinism_and_batch_invariance(sawyer_lack):
+    """Same inputs -> bit-identical state, run to run and independent of batch size / env position in the batch."""
+    m = sawyer_lack
+    q, v = _initial(m, 64, np.random.RandomState(3), arm_noise=0.2)
+
+    def run(idx):
+        sim = FSim(m, len(idx))
+        sim.set_state(qpos=q[idx], qvel=v[idx])
+        sim.physics_step(100)
+        out = sim.get_state("qpos", "qvel")
+        sim.close()
+        return out["qpos"].cpu().numpy(), out["qvel"].cpu().numpy()
+
+    a = run(np.arange(64))
+    b = run(np.arange(64))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c = run(np.arange(17, 30))
+    assert np.array_equal(a[0][17:30], c[0]) and np.array_equal(a[1][17:30], c[1])
+
+
+def test_baseline_size_properties(sawyer_lack):
+    """BASELINE config 2 size (4096 envs): random-action steps stay finite, episodes terminate at the time limit with
+    auto-reset, parts rest on the floor, state round-trips through get/set."""
+    m = sawyer_lack
+    n = 4096
+    cfg = default_config()
+    cfg.max_episode_steps = 3
+    sim = FSim(m, n, config=cfg)
+    from furniture_amd.envs import ResetTableSampler
+    from types import SimpleNamespace
+    parts, noise = ResetTableSampler(m, SimpleNamespace(furn_xyz_rand=0.02, furn_rot_rand=3, agent_xyz_rand=0.001), 123, 0, 64).draw()
+    sim.set_reset_tables(np.tile(parts, (n // 64, 1)), np.tile(noise, (n // 64, 1)))
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    act = torch.empty((n, 9), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    dones = []
+    for t in range(4):
+        act.uniform_(-1, 1, generator=g)
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        dones.append(int(done.sum()))
+    assert dones[:2] == [0, 0] and dones[2] == n and dones[3] == 0  # equality time limit (Q9) + auto-reset
+    assert int(info[:, 5].max()) == 1  # episode_length restarted
+    z = obs[:, 2:35:7]  # part heights from object_ob
+    assert float(z.min()) > 0.005 and float(z.max()) < 0.05
+    # state round trip
+    st = sim.get_state("qpos", "qvel", "eq_active", "geom_contype")
+    sim.set_state(qpos=st["qpos"], qvel=st["qvel"], eq_active=st["eq_active"], geom_contype=st["geom_contype"])
+    st2 = sim.get_state("qpos", "qvel", "eq_active", "geom_contype")
+    for k in st:
+        assert torch.equal(st[k], st2[k])
+    sim.close()
+
+
+def test_batched_env_surface():
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    env = FurnitureBatchEnv("Sawyer", 8, config=make_config(unity=False, record_vid=False, control_type="impedance",
+                                                            furniture_name="table_lack_0825", max_episode_steps=150))
+    ob = env.reset()
+    assert ob["object_ob"].shape == (8, 35) and ob["robot_ob"].shape == (8, 29)
+    assert env.action_space.spaces["default"].shape == (9,) and env.dof == 9
+    ob, rew, done, info = env.step(np.zeros((8, 9), dtype=np.float32))
+    assert rew.shape == (8,) and done.dtype == torch.bool and int(info["episode_length"][0]) == 1
+    assert torch.allclose(rew, torch.zeros_like(rew))  # zero action: no ctrl penalty, nothing touched
+    env.close()
