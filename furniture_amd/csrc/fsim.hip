@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 16) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  if (lane < 32) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   if (kp.mode == 1) fs_forward(c);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *
 
 __global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
-                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step) {
+                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof) {
   extern __shared__ float L[];
   const DModel &m = *mp;
   const Layout &ly = *lp;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout 
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 16) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  if (lane < 32) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   EnvIO io;
@@ -100,6 +100,9 @@ __global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout 
   if (do_step) env_step(c, cfg, io);
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   SYNC();
+#ifdef FSIM_PROFILE
+  if (prof && lane < 16) prof[(size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max) + lane] = reinterpret_cast<int *>(L + ly.scal)[16 + lane];
+#endif
   store_record(rec, L, ly.stride, lane);
 }
 
@@ -295,7 +298,7 @@ static void build_layout(fsim *s, int ncon_max) {
   ly.smooth = take(m.nv); ly.asmooth = take(m.nv); ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
   ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg); ly.surv = take(FSIM_MAXSURV);
   ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(16);
+  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(32);
   ly.lds_words = o;
   ly.ncon_max = ncon_max;
 }
@@ -487,7 +490,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   timing_collect(s);
   timing_begin(s);
   hipLaunchKernelGGL(k_env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
-                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step);
+                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux));
   hipError_t e = hipGetLastError();
   timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

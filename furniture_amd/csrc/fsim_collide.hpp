@@ -21,6 +21,8 @@ struct Emit {
   __device__ Emit(const Ctx &c_, int b, int mx, int g1, int g2, float mg, float gp) : c(c_), base(b), maxn(mx), cg1(g1), cg2(g2), margin(mg), gap(gp) {}
   DEV void operator()(int k, float dist, V3 pos, V3 n) const {
     if (k >= maxn) return;
+    // a degenerate narrow-phase result (fp32 portal refinement on near-parallel faces) must never reach the solver
+    if (!(isfinite(dist) && isfinite(pos.x + pos.y + pos.z) && isfinite(n.x + n.y + n.z)) || dot(n, n) < 1e-12f) return;
     // exact slot allocation: one LDS atomic per emitted contact.  A single wave executes this code, so
     // the allocation order is a deterministic function of the inputs (not of timing).
     int *scal_ = c.I(c.ly.scal);
@@ -317,9 +319,15 @@ DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
         b0 = 0; b1 = dot(cross(v2.v, v3_.v), n); b2 = dot(cross(v3_.v, v1.v), n); b3 = dot(cross(v1.v, v2.v), n);
         sum = b1 + b2 + b3;
       }
-      float inv = 1.0f / sum;
-      V3 pa = (v0.a * b0 + v1.a * b1 + v2.a * b2 + v3_.a * b3) * inv;
-      V3 pb = (v0.b * b0 + v1.b * b1 + v2.b * b2 + v3_.b * b3) * inv;
+      V3 pa, pb;
+      if (sum > 1e-30f) {
+        float inv = 1.0f / sum;
+        pa = (v0.a * b0 + v1.a * b1 + v2.a * b2 + v3_.a * b3) * inv;
+        pb = (v0.b * b0 + v1.b * b1 + v2.b * b2 + v3_.b * b3) * inv;
+      } else { // degenerate portal: fall back to the centroid of the portal's support points
+        pa = (v1.a + v2.a + v3_.a) * (1.0f / 3.0f);
+        pb = (v1.b + v2.b + v3_.b) * (1.0f / 3.0f);
+      }
       e(0, -dpl, (pa + pb) * 0.5f, -n);
       return;
     }

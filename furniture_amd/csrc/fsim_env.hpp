@@ -74,15 +74,45 @@ DEV void fs_touch_flags(const Ctx &c) {
 // many places in the env state machine; one copy keeps the code object (and the build) small.
 __device__ __noinline__ void fs_forward(Ctx cv) {
   FS_REBUILD_CTX(cv);
+#ifdef FSIM_PROFILE
+  // per-phase shader-clock accounting (development builds only): scal[16..] = cycles of
+  // {kinematics+inertia+crb+factor, collide, velocity+smooth, constraints, solve}, then counters
+  long long t0_ = clock64(), t1_;
+#define FS_PROF(slot) do { t1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16 + slot] += (int)((t1_ - t0_) >> 4); t0_ = t1_; } while (0)
+#else
+#define FS_PROF(slot) do { } while (0)
+#endif
   fs_kinematics(c);
   fs_com_inertia(c);
   fs_crb_factor(c);
   fs_factor_all(c);
+  FS_PROF(0);
   fs_collide(c);
+  FS_PROF(1);
   fs_velocity_bias(c);
   fs_smooth(c);
+  FS_PROF(2);
   int coupled = fs_make_constraints(c);
+  FS_PROF(3);
+#ifdef FSIM_PROFILE
+  {
+    int bad_ = 0;
+    for (int d = c.lane; d < c.m.nv; d += 64) bad_ |= !isfinite(c.L[c.ly.asmooth + d]) | (!isfinite(c.L[c.ly.qfrcbias + d]) << 1);
+    int ns_ = c.I(c.ly.scal)[SC_NSLOT];
+    for (int s_ = c.lane; s_ < ns_; s_ += 64) { const float *r_ = c.L + c.ly.con + FSIM_CONW * s_; if (c.I(c.ly.con + FSIM_CONW * s_)[C_ACTIVE] == 1) bad_ |= (!isfinite(r_[C_AREF] + r_[C_AREF + 1] + r_[C_AREF + 2] + r_[C_DN]) << 2) | ((fabsf(r_[C_POS]) + fabsf(r_[C_POS + 1]) + fabsf(r_[C_POS + 2]) > 100.f) << 3); }
+    bad_ = wave_or(bad_);
+    if (bad_ && c.lane == 0 && !c.I(c.ly.scal)[27]) { c.I(c.ly.scal)[27] = 1000 + bad_; c.I(c.ly.scal)[28] = c.I(c.ly.scal)[21]; }
+  }
+#endif
   fs_solve(c, coupled);
+  FS_PROF(4);
+#ifdef FSIM_PROFILE
+  if (c.lane == 0) {
+    int *sc_ = c.I(c.ly.scal);
+    sc_[21] += 1; sc_[22] += sc_[SC_NITER]; sc_[23] += coupled; sc_[24] += sc_[SC_NSURV]; sc_[25] += sc_[SC_NSLOT];
+    if (sc_[SC_NITER] > sc_[26]) sc_[26] = sc_[SC_NITER];
+  }
+#endif
   // instability guard (mj_checkAcc analogue): NaN / huge accelerations
   int bad = 0;
   for (int d = c.lane; d < c.m.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }

@@ -197,8 +197,8 @@ DEV int fs_cone(const float *jar, float Dn, float Dt, float fri, float *f, float
   float mu = fri * sqrtf(Dn / Dt); // friction * sqrt(R_t/R_n) = friction / sqrt(impratio)
   float U0 = jar[0] * mu, U1 = jar[1] * fri, U2 = jar[2] * fri;
   float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
-  if (mu * N >= T || (T <= 0 && N >= 0)) { f[0] = f[1] = f[2] = 0; *cost = 0; return 0; }
-  if (mu * T + N <= 0 || (T <= 0 && N < 0)) {
+  if (N >= mu * T || (T <= 0 && N >= 0)) { f[0] = f[1] = f[2] = 0; *cost = 0; return 0; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
     f[0] = -Dn * jar[0]; f[1] = -Dt * jar[1]; f[2] = -Dt * jar[2];
     *cost = 0.5f * (Dn * jar[0] * jar[0] + Dt * (jar[1] * jar[1] + jar[2] * jar[2]));
     if (H) { for (int i = 0; i < 9; i++) H[i] = 0; H[0] = Dn; H[4] = Dt; H[8] = Dt; }
@@ -553,13 +553,21 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     SYNC();
   }
   float scale = m.meaninertia_scale;
+  float cost = (cw < cs0) ? cw : cs0;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
     fs_gradient(c);
     float gn = sqrtf(fs_dotv(c, ly.grad, ly.grad));
+#ifdef FSIM_PROFILE
+    if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
+    if (!isfinite(cost) && c.lane == 0 && !scal[27]) { scal[27] = 200 + it; scal[28] = scal[21]; }
+#endif
     if (scale * gn < c.newton_tol) break;
     fs_hessian(c);
     bool ok = fs_chol_solve(c, coupled);
+#ifdef FSIM_PROFILE
+    if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
+#endif
     if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
     fs_mulM(c, ly.Mp, ly.p);
     fs_body_spatial(c, ly.p);
@@ -585,6 +593,10 @@ DEV void fs_solve(const Ctx &c, int coupled) {
       alpha = na;
     }
     alpha = best;
+#ifdef FSIM_PROFILE
+    if (!isfinite(alpha) && c.lane == 0 && !scal[27]) { scal[27] = 400 + it; scal[28] = scal[21]; }
+    if (!isfinite(pMp) && c.lane == 0 && !scal[27]) { scal[27] = 500 + it; scal[28] = scal[21]; }
+#endif
     for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] += alpha * L[ly.p + d]; L[ly.Mx + d] += alpha * L[ly.Mp + d]; }
     for (int s = c.lane; s < nslot; s += 64) {
       float *r = L + ly.con + FSIM_CONW * s;
@@ -600,6 +612,12 @@ DEV void fs_solve(const Ctx &c, int coupled) {
       if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
     }
     SYNC();
+    // MuJoCo's second stopping rule: scaled cost improvement below tolerance (also catches fp32 stalls, where the
+    // gradient test alone would spin to the iteration cap)
+    float newcost = fs_total_cost(c);
+    float improvement = scale * (cost - newcost);
+    cost = newcost;
+    if (improvement < c.newton_tol) { it++; break; }
   }
   if (c.lane == 0) scal[SC_NITER] = it;
   SYNC();

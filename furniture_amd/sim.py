@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIBPATH = os.path.join(_CSRC, "libfsim.so")
+_LIBPATH = os.environ.get("FSIM_LIB", os.path.join(_CSRC, "libfsim.so"))
 _LIB = None
 
 INFO_DIM = 12

@@ -1,0 +1,35 @@
+"""Per-phase shader-clock breakdown of k_env_step using the -DFSIM_PROFILE build (development aid)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FSIM_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "furniture_amd", "csrc", "libfsim_prof.so"))
+import torch
+from furniture_amd.mjcf.model import load_compiled
+from furniture_amd.sim import FSim, default_config, INFO_DIM
+from furniture_amd.envs import ResetTableSampler, make_config
+m = load_compiled("Sawyer", "table_lack_0825")
+N = 4096
+cfg = default_config(); cfg.max_episode_steps = 150
+sim = FSim(m, N, config=cfg)
+sampler = ResetTableSampler(m, make_config(), 123, 0, N)
+sim.set_reset_tables(*sampler.draw())
+dev = sim.device
+obs = torch.zeros((N, sim.obs_dim), device=dev); rew = torch.zeros(N, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev); info = torch.zeros((N, INFO_DIM), dtype=torch.int32, device=dev)
+act = torch.empty((N, 9), device=dev); g = torch.Generator(device=dev); g.manual_seed(123)
+sim.reset(None, obs); sim.sync()
+names = ["kin+crb+factor", "collide", "vel+smooth", "constraints", "solve"]
+for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
+    act.uniform_(-1, 1, generator=g); torch.cuda.synchronize()
+    t0 = time.time(); sim.step(act, obs, rew, done, info); sim.sync(); dt = time.time() - t0
+    p = sim.get_state("qacc")["qacc"].view(torch.int32)[:, :16].cpu().numpy().astype(np.int64)
+    cyc = p[:, :5] * 16
+    tot = cyc.sum(axis=1)
+    nsub, nit, ncoup, nsurv, nslot, maxit = p[:, 5], p[:, 6], p[:, 7], p[:, 8], p[:, 9], p[:, 10]
+    print("step %2d: %.1f ms | mean Mcyc/env %.2f (p50 %.2f p99 %.2f max %.2f) | %s | substeps %.0f newton it/substep %.2f (max per substep %d) coupled frac %.3f surv/substep %.1f slots %.1f" % (
+        t, dt * 1e3, tot.mean() / 1e6, np.percentile(tot, 50) / 1e6, np.percentile(tot, 99) / 1e6, tot.max() / 1e6,
+        " ".join("%s %.0f%%" % (n, 100 * cyc[:, i].sum() / tot.sum()) for i, n in enumerate(names)),
+        nsub.mean(), nit.sum() / max(1, nsub.sum()), maxit.max(), ncoup.sum() / max(1, nsub.sum()), nsurv.sum() / max(1, nsub.sum()), nslot.sum() / max(1, nsub.sum())))
+    if t in (3, 8):
+        order = np.argsort(-tot)[:5]
+        for e in order:
+            print("    slow env %d: Mcyc %.2f phases %s it/sub %.2f coupled %.2f surv %.1f" % (e, tot[e] / 1e6, (cyc[e] / 1e6).round(2), nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e]), nsurv[e] / max(1, nsub[e])))

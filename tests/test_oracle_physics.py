@@ -190,3 +190,29 @@ def test_mpr_matches_sphere_limit(pair):
         assert len(hits) == 1
     else:
         assert half > 0  # cylinder-cylinder pairs only exist between robot links; covered by GPU-vs-oracle parity
+
+
+def test_sliding_friction_primal_dual_agree(sawyer_lack):
+    """Sliding contacts put the elliptic cones on their surface (middle zone): the primal Newton solver and the dual
+    PGS solver only agree there if the zone tests / regularised mu of the cone cost are right."""
+    m = sawyer_lack
+    s = OracleSim(m)
+    s.set_solver(100, 1e-12, "newton")
+    _standing(m, s, lift=0.0)
+    for _ in range(100):
+        s.step()
+    for i in range(m.nparts):
+        d = m.part_dofadr[i]
+        s.data.qvel[d:d + 6] = [1.0, 0.5, 0, 0, 0, 3.0]
+    st = (s.data.qpos.copy(), s.data.qvel.copy(), s.data.qacc_warmstart.copy())
+
+    def solve(kind, it, tol):
+        s.data.qpos[:], s.data.qvel[:], s.data.qacc_warmstart[:] = st
+        s.set_solver(it, tol, kind)
+        s.forward()
+        return s.data.qacc.copy()
+
+    a_n = solve("newton", 100, 1e-14)
+    a_p = solve("pgs", 200000, 0.0)
+    assert np.abs(a_n).max() > 100  # genuinely dynamic
+    assert np.abs(a_n - a_p).max() < 1e-6 * np.abs(a_n).max()
