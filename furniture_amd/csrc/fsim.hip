@@ -9,6 +9,7 @@
 #include "fsim_env.hpp"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,7 +36,7 @@ __device__ __forceinline__ void store_record(float *rec, const float *L, int n, 
   for (int i = lane; i < n; i += 64) rec[i] = L[i];
 }
 
-__global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
+__global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
   extern __shared__ float L[];
   const DModel &m = *mp;
   const Layout &ly = *lp;
@@ -43,9 +44,10 @@ __global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 32) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  if (lane < 64) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
+  fs_load_cache(c);
   if (kp.mode == 1) fs_forward(c);
   else
     for (int s = 0; s < kp.n_substeps; s++) {
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64) void k_physics(const DModel *mp, const Layout *
   store_record(rec, L, ly.stride, lane);
 }
 
-__global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
+__global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
                                                  const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof) {
   extern __shared__ float L[];
@@ -85,9 +87,10 @@ __global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout 
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 32) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  if (lane < 64) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
+  fs_load_cache(c);
   EnvIO io;
   io.action = action ? action + (size_t)env * cfg.dof_action : nullptr;
   io.obs = obs ? obs + (size_t)env * cfg.obs_dim : nullptr;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64) void k_env_step(const DModel *mp, const Layout 
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   SYNC();
 #ifdef FSIM_PROFILE
-  if (prof && lane < 16) prof[(size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max) + lane] = reinterpret_cast<int *>(L + ly.scal)[16 + lane];
+  if (prof && lane < 48) prof[(size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max) + lane] = reinterpret_cast<int *>(L + ly.scal)[16 + lane];
 #endif
   store_record(rec, L, ly.stride, lane);
 }
@@ -294,11 +297,27 @@ static void build_layout(fsim *s, int ncon_max) {
   int nH = m.nv * (m.nv + 1) / 2;
   ly.H = hstart;
   if (hstart + nH > o) o = hstart + nH;
-  ly.cdof = take(6 * m.nv); ly.M = take(m.nM); ly.LD = take(m.nM); ly.Dinv = take(m.nv); ly.LDh = take(m.nM); ly.Dhinv = take(m.nv);
-  ly.smooth = take(m.nv); ly.asmooth = take(m.nv); ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
+  ly.cdof = take(6 * m.nv); ly.M = take(m.nM); ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
+  ly.smooth = take(m.nv); ly.asmooth = ly.smooth; ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
   ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg); ly.surv = take(FSIM_MAXSURV);
   ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(32);
+  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(64);
+  // LDS model cache
+  {
+    std::vector<int> ca, cl;
+    blob_i(s->blob, "r_chainadr", ca); blob_i(s->blob, "r_chainlen", cl);
+    int nchain = 0;
+    for (size_t b = 0; b < ca.size(); b++) nchain = std::max(nchain, ca[b] + cl[b]);
+    ly.k_begin = o;
+    ly.k_dof_parent = take(m.nv); ly.k_dof_Madr = take(m.nv); ly.k_dof_rbody = take(m.nv); ly.k_dof_tree = take(m.nv);
+    ly.k_r_parent = take(m.nr); ly.k_r_jtype = take(m.nr); ly.k_r_qposadr = take(m.nr); ly.k_r_dofadr = take(m.nr); ly.k_r_depth = take(m.nr);
+    ly.k_r_tree = take(m.nr); ly.k_r_chainadr = take(m.nr); ly.k_r_chainlen = take(m.nr); ly.k_r_ancmask = take(m.nr); ly.k_chain_dofs = take(nchain);
+    ly.k_tree_dofadr = take(m.ntree); ly.k_tree_dofnum = take(m.ntree); ly.k_tree_bodyadr = take(m.ntree); ly.k_tree_bodynum = take(m.ntree);
+    ly.k_M_i = take(m.nM); ly.k_M_j = take(m.nM);
+    ly.k_r_pos = take(3 * m.nr); ly.k_r_quat = take(4 * m.nr); ly.k_r_jpos = take(3 * m.nr); ly.k_r_jaxis = take(3 * m.nr); ly.k_r_ipos = take(3 * m.nr);
+    ly.k_r_mass = take(m.nr); ly.k_r_inertia = take(6 * m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv);
+    ly.k_end = o;
+  }
   ly.lds_words = o;
   ly.ncon_max = ncon_max;
 }
@@ -318,6 +337,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (rc) { delete s; return rc; }
   int ncon_max = 48;
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
+  if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
   build_layout(s, ncon_max);
   s->lds_bytes = s->ly.lds_words * 4;
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
@@ -346,6 +366,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     std::vector<float> all((size_t)n_envs * s->ly.stride);
     for (int e = 0; e < n_envs; e++) memcpy(all.data() + (size_t)e * s->ly.stride, rec.data(), s->ly.stride * 4);
     HIPCHK(hipMemcpy(s->d_state, all.data(), sbytes, hipMemcpyHostToDevice));
+  }
+  if (getenv("FSIM_VERBOSE")) {
+    int nb = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_env_step), 64, s->lds_bytes);
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_env_step));
+    fprintf(stderr, "[fsim] lds_bytes=%d stride_words=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu ncon_max=%d\n", s->lds_bytes, s->ly.stride, nb,
+            fa.numRegs, (size_t)fa.localSizeBytes, s->ly.ncon_max);
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }

@@ -338,11 +338,19 @@ DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
 }
 
 // ---- driver ----------------------------------------------------------------------------------
+#ifdef FSIM_PROFILE
+#define FS_CPROF(slot) do { long long t1c_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16 + slot] += (int)((t1c_ - t0c_) >> 4); t0c_ = t1c_; } while (0)
+#else
+#define FS_CPROF(slot) do { } while (0)
+#endif
 DEV void fs_collide(const Ctx &c) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
   int *scal = c.I(ly.scal);
+#ifdef FSIM_PROFILE
+  long long t0c_ = clock64();
+#endif
   for (int g = c.lane; g < m.ncg; g += 64) {
     int b = m.cg_body[g];
     M3 Rb = ldm3(L + ly.xmat + 9 * b);
@@ -350,6 +358,7 @@ DEV void fs_collide(const Ctx &c) {
     stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(m.cg_mat + 9 * g)));
   }
   SYNC();
+  FS_CPROF(29);
   // broadphase + ordered compaction
   int nsurv = 0;
   int *surv = c.I(ly.surv);
@@ -366,8 +375,32 @@ DEV void fs_collide(const Ctx &c) {
           V3 n = v3(L[ly.gmat + 9 * g1 + 2], L[ly.gmat + 9 * g1 + 5], L[ly.gmat + 9 * g1 + 8]);
           pass = dot(d, n) <= m.cg_rbound[g2] + margin;
         } else {
-          float bound = m.cg_rbound[g1] + m.cg_rbound[g2] + margin;
+          float r1 = m.cg_rbound[g1], r2 = m.cg_rbound[g2];
+          float bound = r1 + r2 + margin;
           pass = dot(d, d) <= bound * bound;
+          // second, tighter test for flat / long shapes (a 0.64 x 0.24 x 0.04 table top has a 0.34 m bounding sphere):
+          // distance from the OTHER geom's centre to this box / cylinder (exact point-solid distance) must be within the
+          // other geom's bounding radius.  Conservative: never rejects a pair that can touch.
+          if (pass) {
+            for (int side = 0; side < 2 && pass; side++) {
+              int gs = side ? g1 : g2, ty = m.cg_type[gs];       // solid tested
+              float ro = (side ? r2 : r1) + margin;              // other geom's radius
+              if (ty != GT_BOX && ty != GT_CYLINDER) continue;
+              V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
+              const float *R = L + ly.gmat + 9 * gs;
+              V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
+              V3 sz_ = ldv3(m.cg_size + 3 * gs);
+              float dist2;
+              if (ty == GT_BOX) {
+                V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
+                dist2 = dot(e, e);
+              } else {
+                float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz_.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz_.y, 0.0f);
+                dist2 = er * er + ez * ez;
+              }
+              if (dist2 > ro * ro) pass = false;
+            }
+          }
         }
       }
     }
@@ -380,6 +413,7 @@ DEV void fs_collide(const Ctx &c) {
   SYNC();
   if (c.lane == 0) { scal[SC_NSURV] = nsurv; scal[SC_NSLOT] = 0; }
   SYNC();
+  FS_CPROF(30);
   for (int i = c.lane; i < nsurv; i += 64) {
     int p = surv[i], base = 0;
     int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1], pt = m.cp[3 * p + 2];
@@ -388,6 +422,9 @@ DEV void fs_collide(const Ctx &c) {
     V3 p1 = ldv3(L + ly.gpos + 3 * g1), p2 = ldv3(L + ly.gpos + 3 * g2);
     M3 R1 = ldm3(L + ly.gmat + 9 * g1), R2 = ldm3(L + ly.gmat + 9 * g2);
     V3 s1 = ldv3(m.cg_size + 3 * g1), s2 = ldv3(m.cg_size + 3 * g2);
+#ifdef FSIM_PROFILE
+    long long tp0_ = clock64();
+#endif
     switch (pt) {
       case PT_PLANE_SPHERE: np_plane_sphere(e, p1, R1, p2, s2.x); break;
       case PT_PLANE_BOX: np_plane_box(e, p1, R1, p2, R2, s2); break;
@@ -403,8 +440,12 @@ DEV void fs_collide(const Ctx &c) {
         np_mpr(e, A, B);
       }
     }
+#ifdef FSIM_PROFILE
+    atomicAdd(&scal[48 + pt], (int)((clock64() - tp0_) >> 4));
+#endif
   }
   SYNC();
   if (c.lane == 0 && scal[SC_NSLOT] > ly.ncon_max) scal[SC_NSLOT] = ly.ncon_max;
   SYNC();
+  FS_CPROF(31);
 }

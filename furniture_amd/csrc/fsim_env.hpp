@@ -83,15 +83,17 @@ __device__ __noinline__ void fs_forward(Ctx cv) {
 #define FS_PROF(slot) do { } while (0)
 #endif
   fs_kinematics(c);
+  FS_PROF(16);
   fs_com_inertia(c);
+  FS_PROF(17);
   fs_crb_factor(c);
-  fs_factor_all(c);
-  FS_PROF(0);
+  FS_PROF(18);
   fs_collide(c);
   FS_PROF(1);
   fs_velocity_bias(c);
+  FS_PROF(20);
   fs_smooth(c);
-  FS_PROF(2);
+  FS_PROF(21);
   int coupled = fs_make_constraints(c);
   FS_PROF(3);
 #ifdef FSIM_PROFILE
@@ -420,7 +422,7 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       o[2 * nj + 5] = q.x; o[2 * nj + 6] = q.y; o[2 * nj + 7] = q.z; o[2 * nj + 8] = q.w;
       int sb = m.s_body[site];
       S6 v = lds6(L + ly.cvel + 6 * sb);
-      V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * m.r_tree[sb])) : v3(0, 0, 0);
+      V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * KI(r_tree, sb))) : v3(0, 0, 0);
       stv3(o + 2 * nj + 9, vp);
       stv3(o + 2 * nj + 12, sb ? v.a : v3(0, 0, 0));
     }

@@ -69,6 +69,9 @@ struct Layout {
   int smooth, asmooth, x, Mx, grad, p, Mp;
   int gpos, gmat, surv, con, weld, lim, W, G, scal;
   int lds_words, ncon_max;
+  // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
+  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_i, k_M_j, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature;
+  int k_begin, k_end;
 };
 
 // env-logic block (word offsets relative to Layout::env)

@@ -37,22 +37,51 @@ DEV const void *fs_uniform_ptr(const void *p) {
         __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((cv).newton_tol))))
 
 
+#define KI(field, idx) (c.I(c.ly.k_##field)[idx])
+#define KF(field, idx) (c.L[c.ly.k_##field + (idx)])
+#define KFP(field) (c.L + c.ly.k_##field)
+
+// copy the hot model tables HBM -> LDS (once per kernel launch; the 50 substeps then never leave the CU for them)
+DEV void fs_load_cache(const Ctx &c) {
+  const DModel &m = c.m;
+  int nb = m.nr, nv = m.nv, nchain = 0;
+  for (int b = 0; b < nb; b++) nchain = max(nchain, m.r_chainadr[b] + m.r_chainlen[b]);
+#define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
+#define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
+  CPI(dof_parent, nv); CPI(dof_Madr, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
+  CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_depth, nb); CPI(r_tree, nb);
+  CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(r_ancmask, nb); CPI(chain_dofs, nchain);
+  CPI(tree_dofadr, m.ntree); CPI(tree_dofnum, m.ntree); CPI(tree_bodyadr, m.ntree); CPI(tree_bodynum, m.ntree);
+  CPI(M_i, m.nM); CPI(M_j, m.nM);
+  CPF(r_pos, 3 * nb); CPF(r_quat, 4 * nb); CPF(r_jpos, 3 * nb); CPF(r_jaxis, 3 * nb); CPF(r_ipos, 3 * nb); CPF(r_mass, nb);
+  CPF(r_inertia, 6 * nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
+#undef CPI
+#undef CPF
+  SYNC();
+}
+
 // ------------------------------------------------------------------------------------------ P1
 DEV void fs_kinematics(const Ctx &c) {
+  // One lane per kinematic tree walks its bodies parent-before-child (no per-level barriers: the 8-deep Sawyer chain
+  // costs 8 dependent body updates in ONE lane instead of 8 workgroup-wide rounds); the pose of the body just
+  // computed stays in registers because it is the parent of the next one along a chain.
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
-  if (c.lane == 0) {
+  if (c.lane == 63) {
     stv3(L + ly.xpos, v3(0, 0, 0));
     stq(L + ly.xquat, q4(1, 0, 0, 0));
     M3 I = q2m(q4(1, 0, 0, 0));
     stm3(L + ly.xmat, I);
   }
-  SYNC();
-  for (int d = 1; d <= m.maxdepth; d++) {
-    for (int b = c.lane; b < m.nr; b += 64) {
-      if (b == 0 || m.r_depth[b] != d) continue;
-      int p = m.r_parent[b], jt = m.r_jtype[b], qa = m.r_qposadr[b];
+  for (int t = c.lane; t < m.ntree; t += 64) {
+    int b0 = KI(tree_bodyadr, t), nbod = KI(tree_bodynum, t);
+    int pid = -1;
+    V3 ppos = v3(0, 0, 0);
+    Q4 pquat = q4(1, 0, 0, 0);
+    M3 pR = q2m(pquat);
+    for (int b = b0; b < b0 + nbod; b++) {
+      int p = KI(r_parent, b), jt = KI(r_jtype, b), qa = KI(r_qposadr, b);
       V3 pos;
       Q4 quat;
       V3 anchor, axis = v3(0, 0, 1);
@@ -63,14 +92,17 @@ DEV void fs_kinematics(const Ctx &c) {
         stq(L + ly.qpos + qa + 3, quat); // MuJoCo normalises the stored quaternion in place
         anchor = pos;
       } else {
-        M3 Rp = ldm3(L + ly.xmat + 9 * p);
-        pos = ldv3(L + ly.xpos + 3 * p) + mulv(Rp, ldv3(m.r_pos + 3 * b));
-        quat = qmul(ldq(L + ly.xquat + 4 * p), ldq(m.r_quat + 4 * b));
+        if (p != pid) {
+          if (p == 0) { ppos = v3(0, 0, 0); pquat = q4(1, 0, 0, 0); pR = q2m(pquat); }
+          else { ppos = ldv3(L + ly.xpos + 3 * p); pquat = ldq(L + ly.xquat + 4 * p); pR = ldm3(L + ly.xmat + 9 * p); }
+        }
+        pos = ppos + mulv(pR, ldv3(KFP(r_pos) + 3 * b));
+        quat = qmul(pquat, ldq(KFP(r_quat) + 4 * b));
         M3 R = q2m(quat);
-        V3 jpos = ldv3(m.r_jpos + 3 * b), jax = ldv3(m.r_jaxis + 3 * b);
+        V3 jpos = ldv3(KFP(r_jpos) + 3 * b), jax = ldv3(KFP(r_jaxis) + 3 * b);
         anchor = pos + mulv(R, jpos);
         axis = mulv(R, jax);
-        float q = L[ly.qpos + qa] - m.qpos0[qa];
+        float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
         if (jt == JT_SLIDE) pos = pos + axis * q;
         else {
           quat = qmul(quat, axisangle(jax, q));
@@ -84,10 +116,11 @@ DEV void fs_kinematics(const Ctx &c) {
       stm3(L + ly.xmat + 9 * b, R);
       stv3(L + ly.xanchor + 3 * b, anchor);
       stv3(L + ly.xaxis + 3 * b, axis);
-      stv3(L + ly.xipos + 3 * b, pos + mulv(R, ldv3(m.r_ipos + 3 * b)));
+      stv3(L + ly.xipos + 3 * b, pos + mulv(R, ldv3(KFP(r_ipos) + 3 * b)));
+      pid = b; ppos = pos; pquat = quat; pR = R;
     }
-    SYNC();
   }
+  SYNC();
 }
 
 // per-tree centre of mass, body inertias about it, motion axes (mj_comPos)
@@ -98,19 +131,19 @@ DEV void fs_com_inertia(const Ctx &c) {
   for (int t = c.lane; t < m.ntree; t += 64) {
     V3 s = v3(0, 0, 0);
     float tot = 0;
-    for (int b = m.tree_bodyadr[t]; b < m.tree_bodyadr[t] + m.tree_bodynum[t]; b++) {
-      float ms = m.r_mass[b];
+    for (int b = KI(tree_bodyadr, t); b < KI(tree_bodyadr, t) + KI(tree_bodynum, t); b++) {
+      float ms = KF(r_mass, b);
       s = s + ms * ldv3(L + ly.xipos + 3 * b);
       tot += ms;
     }
-    stv3(L + ly.com + 3 * t, tot > 0 ? s * (1.0f / tot) : ldv3(L + ly.xpos + 3 * m.tree_bodyadr[t]));
+    stv3(L + ly.com + 3 * t, tot > 0 ? s * (1.0f / tot) : ldv3(L + ly.xpos + 3 * KI(tree_bodyadr, t)));
   }
   SYNC();
   for (int b = c.lane; b < m.nr; b += 64) {
     float *I = L + ly.cinert + 10 * b;
     if (b == 0) { for (int k = 0; k < 10; k++) I[k] = 0; continue; }
     M3 R = ldm3(L + ly.xmat + 9 * b);
-    const float *ib = m.r_inertia + 6 * b; // xx yy zz xy xz yz in body frame
+    const float *ib = KFP(r_inertia) + 6 * b; // xx yy zz xy xz yz in body frame
     M3 Ib;
     Ib.m[0] = ib[0]; Ib.m[4] = ib[1]; Ib.m[8] = ib[2]; Ib.m[1] = Ib.m[3] = ib[3]; Ib.m[2] = Ib.m[6] = ib[4]; Ib.m[5] = Ib.m[7] = ib[5];
     M3 T = mulm(R, Ib);
@@ -121,16 +154,16 @@ DEV void fs_com_inertia(const Ctx &c) {
       int i = ij[e][0], j = ij[e][1];
       w[e] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
     }
-    float ms = m.r_mass[b];
-    V3 d = ldv3(L + ly.xipos + 3 * b) - ldv3(L + ly.com + 3 * m.r_tree[b]);
+    float ms = KF(r_mass, b);
+    V3 d = ldv3(L + ly.xipos + 3 * b) - ldv3(L + ly.com + 3 * KI(r_tree, b));
     float dd = dot(d, d);
     I[0] = w[0] + ms * (dd - d.x * d.x); I[1] = w[1] + ms * (dd - d.y * d.y); I[2] = w[2] + ms * (dd - d.z * d.z);
     I[3] = w[3] - ms * d.x * d.y; I[4] = w[4] - ms * d.x * d.z; I[5] = w[5] - ms * d.y * d.z;
     I[6] = ms * d.x; I[7] = ms * d.y; I[8] = ms * d.z; I[9] = ms;
   }
   for (int d = c.lane; d < m.nv; d += 64) {
-    int b = m.dof_rbody[d], jt = m.r_jtype[b], k = d - m.r_dofadr[b];
-    V3 com = ldv3(L + ly.com + 3 * m.r_tree[b]);
+    int b = KI(dof_rbody, d), jt = KI(r_jtype, b), k = d - KI(r_dofadr, b);
+    V3 com = ldv3(L + ly.com + 3 * KI(r_tree, b));
     S6 s;
     if (jt == JT_FREE) {
       if (k < 3) { s.a = v3(0, 0, 0); s.l = v3(k == 0, k == 1, k == 2); }
@@ -157,59 +190,17 @@ DEV void fs_crb_factor(const Ctx &c) {
     for (int k = 0; k < 10; k++) acc[k] = 0;
     if (b > 0)
       for (int d = b; d < m.nr; d++)
-        if ((m.r_ancmask[d] >> b) & 1) { const float *I = L + ly.cinert + 10 * d; for (int k = 0; k < 10; k++) acc[k] += I[k]; }
+        if ((KI(r_ancmask, d) >> b) & 1) { const float *I = L + ly.cinert + 10 * d; for (int k = 0; k < 10; k++) acc[k] += I[k]; }
     for (int k = 0; k < 10; k++) L[ly.crb + 10 * b + k] = acc[k];
   }
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = m.M_i[e], j = m.M_j[e];
-    S6 f = inert_mul(L + ly.crb + 10 * m.dof_rbody[i], lds6(L + ly.cdof + 6 * i));
+    int i = KI(M_i, e), j = KI(M_j, e);
+    S6 f = inert_mul(L + ly.crb + 10 * KI(dof_rbody, i), lds6(L + ly.cdof + 6 * i));
     float v = dot6(lds6(L + ly.cdof + 6 * j), f);
-    if (i == j) v += m.dof_armature[i];
+    if (i == j) v += KF(dof_armature, i);
     L[ly.M + e] = v;
-    L[ly.LD + e] = v;
-    L[ly.LDh + e] = v + (i == j ? m.timestep * m.dof_damping[i] : 0.0f);
   }
-  SYNC();
-}
-
-// sparse L'DL of one tree (mj_factorM restricted to the tree's dof range), executed by one lane
-DEV void fs_factor_tree(const DModel &m, float *LD, float *Dinv, int adr, int num) {
-  for (int k = adr + num - 1; k >= adr; k--) {
-    int akk = m.dof_Madr[k];
-    float Mkk = LD[akk];
-    int i = m.dof_parent[k], aki = akk + 1;
-    while (i >= 0) {
-      float tmp = LD[aki] / Mkk;
-      int aij = m.dof_Madr[i], akj = aki, j = i;
-      while (j >= 0) { LD[aij++] -= tmp * LD[akj++]; j = m.dof_parent[j]; }
-      LD[aki] = tmp;
-      i = m.dof_parent[i];
-      aki++;
-    }
-    Dinv[k] = 1.0f / LD[akk];
-  }
-}
-DEV void fs_solve_tree(const DModel &m, const float *LD, const float *Dinv, float *x, int adr, int num) {
-  for (int i = adr + num - 1; i >= adr; i--) {
-    float xi = x[i];
-    if (xi != 0.0f) { int j = m.dof_parent[i], a = m.dof_Madr[i] + 1; while (j >= 0) { x[j] -= LD[a++] * xi; j = m.dof_parent[j]; } }
-  }
-  for (int i = adr; i < adr + num; i++) x[i] *= Dinv[i];
-  for (int i = adr; i < adr + num; i++) {
-    int j = m.dof_parent[i], a = m.dof_Madr[i] + 1;
-    float xi = x[i];
-    while (j >= 0) { xi -= LD[a++] * x[j]; j = m.dof_parent[j]; }
-    x[i] = xi;
-  }
-}
-DEV void fs_factor_all(const Ctx &c) {
-  const DModel &m = c.m;
-  float *L = c.L;
-  // lanes [0,ntree): M ; lanes [ntree, 2 ntree): M + h*diag(damping)
-  int t = c.lane;
-  if (t < m.ntree) fs_factor_tree(m, L + c.ly.LD, L + c.ly.Dinv, m.tree_dofadr[t], m.tree_dofnum[t]);
-  else if (t < 2 * m.ntree) { t -= m.ntree; fs_factor_tree(m, L + c.ly.LDh, L + c.ly.Dhinv, m.tree_dofadr[t], m.tree_dofnum[t]); }
   SYNC();
 }
 
@@ -220,7 +211,7 @@ DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   for (int d = c.lane; d < m.nv; d += 64) L[off_y + d] = 0;
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = m.M_i[e], j = m.M_j[e];
+    int i = KI(M_i, e), j = KI(M_j, e);
     float Me = L[c.ly.M + e];
     atomicAdd(L + off_y + i, Me * L[off_v + j]);
     if (i != j) atomicAdd(L + off_y + j, Me * L[off_v + i]);
@@ -235,12 +226,12 @@ DEV void fs_velocity_bias(const Ctx &c) {
   float *L = c.L;
   // cdof_dot: velocity of everything *before* the dof in the chain, crossed with the axis
   for (int d = c.lane; d < m.nv; d += 64) {
-    int b = m.dof_rbody[d], jt = m.r_jtype[b], k = d - m.r_dofadr[b];
+    int b = KI(dof_rbody, d), jt = KI(r_jtype, b), k = d - KI(r_dofadr, b);
     S6 v = s6zero();
     if (jt == JT_FREE) {
-      if (k >= 3) for (int t = 0; t < 3; t++) { int dd = m.r_dofadr[b] + t; v = v + lds6(L + ly.cdof + 6 * dd) * L[ly.qvel + dd]; }
+      if (k >= 3) for (int t = 0; t < 3; t++) { int dd = KI(r_dofadr, b) + t; v = v + lds6(L + ly.cdof + 6 * dd) * L[ly.qvel + dd]; }
     } else {
-      for (int a = m.dof_parent[d]; a >= 0; a = m.dof_parent[a]) v = v + lds6(L + ly.cdof + 6 * a) * L[ly.qvel + a];
+      for (int a = KI(dof_parent, d); a >= 0; a = KI(dof_parent, a)) v = v + lds6(L + ly.cdof + 6 * a) * L[ly.qvel + a];
     }
     S6 sd = (jt == JT_FREE && k < 3) ? s6zero() : cross_motion(v, lds6(L + ly.cdof + 6 * d));
     sts6(L + ly.cdofdot + 6 * d, sd);
@@ -250,9 +241,9 @@ DEV void fs_velocity_bias(const Ctx &c) {
     S6 v = s6zero(), a = s6zero();
     a.l = v3(-m.gravity[0], -m.gravity[1], -m.gravity[2]);
     if (b > 0) {
-      int adr = m.r_chainadr[b], n = m.r_chainlen[b];
+      int adr = KI(r_chainadr, b), n = KI(r_chainlen, b);
       for (int k = 0; k < n; k++) {
-        int d = m.chain_dofs[adr + k];
+        int d = KI(chain_dofs, adr + k);
         float qd = L[ly.qvel + d];
         v = v + lds6(L + ly.cdof + 6 * d) * qd;
         a = a + lds6(L + ly.cdofdot + 6 * d) * qd;
@@ -268,11 +259,11 @@ DEV void fs_velocity_bias(const Ctx &c) {
   }
   SYNC();
   for (int d = c.lane; d < m.nv; d += 64) {
-    int bd = m.dof_rbody[d];
+    int bd = KI(dof_rbody, d);
     S6 s = lds6(L + ly.cdof + 6 * d);
     float acc = 0;
     for (int b = bd; b < m.nr; b++)
-      if ((m.r_ancmask[b] >> bd) & 1) acc += dot6(s, lds6(L + ly.cfrc + 6 * b));
+      if ((KI(r_ancmask, b) >> bd) & 1) acc += dot6(s, lds6(L + ly.cfrc + 6 * b));
     L[ly.qfrcbias + d] = acc;
   }
   SYNC();
@@ -283,7 +274,7 @@ DEV void fs_smooth(const Ctx &c) {
   const Layout &ly = c.ly;
   float *L = c.L;
   for (int d = c.lane; d < m.nv; d += 64)
-    L[ly.smooth + d] = -m.dof_damping[d] * L[ly.qvel + d] - L[ly.qfrcbias + d] + L[ly.qfrcapp + d];
+    L[ly.smooth + d] = -KF(dof_damping, d) * L[ly.qvel + d] - L[ly.qfrcbias + d] + L[ly.qfrcapp + d];
   SYNC();
   for (int u = c.lane; u < m.nu; u += 64) {
     float ct = L[ly.ctrl + u];
@@ -306,41 +297,5 @@ DEV void fs_smooth(const Ctx &c) {
     }
   }
   SYNC();
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.asmooth + d] = L[ly.smooth + d];
-  SYNC();
-  if (c.lane < m.ntree) fs_solve_tree(m, L + ly.LD, L + ly.Dinv, L + ly.asmooth, m.tree_dofadr[c.lane], m.tree_dofnum[c.lane]);
-  SYNC();
 }
 
-// ------------------------------------------------------------------------------------------ P8
-// qacc in ly.x, M*qacc in ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
-__device__ __noinline__ void fs_integrate(Ctx cv) {
-  FS_REBUILD_CTX(cv);
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
-  float *L = c.L;
-  float h = m.timestep;
-  for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = L[ly.Mx + d]; }
-  SYNC();
-  if (c.lane < m.ntree) fs_solve_tree(m, L + ly.LDh, L + ly.Dhinv, L + ly.grad, m.tree_dofadr[c.lane], m.tree_dofnum[c.lane]);
-  SYNC();
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.qvel + d] += h * L[ly.grad + d];
-  SYNC();
-  for (int b = c.lane; b < m.nr; b += 64) {
-    if (b == 0) continue;
-    int jt = m.r_jtype[b], qa = m.r_qposadr[b], d = m.r_dofadr[b];
-    if (jt == JT_FREE) {
-      for (int k = 0; k < 3; k++) L[ly.qpos + qa + k] += h * L[ly.qvel + d + k];
-      V3 w = ldv3(L + ly.qvel + d + 3);
-      float wn;
-      V3 ax = normalized(w, &wn);
-      float ang = wn * h;
-      if (ang > 0) {
-        Q4 q = qnormalized(qmul(ldq(L + ly.qpos + qa + 3), axisangle(ax, ang)));
-        stq(L + ly.qpos + qa + 3, q);
-      }
-    } else
-      L[ly.qpos + qa] += h * L[ly.qvel + d];
-  }
-  SYNC();
-}

@@ -43,7 +43,7 @@ DEV float fs_impedance(const float *solref, const float *solimp, float x0, float
 DEV V3 fs_ptvel(const Ctx &c, int off, int b, V3 p) {
   if (b == 0) return v3(0, 0, 0);
   S6 w = lds6(c.L + off + 6 * b);
-  return w.l + cross(w.a, p - ldv3(c.L + c.ly.com + 3 * c.m.r_tree[b]));
+  return w.l + cross(w.a, p - ldv3(c.L + c.ly.com + 3 * KI(r_tree, b)));
 }
 
 // returns 1 if any constraint couples two kinematic trees
@@ -75,7 +75,7 @@ DEV int fs_make_constraints(const Ctx &c) {
     r[C_AREF] = -b * dot(ldv3(r + C_FRAME), vrel) - k * imp * (dist - incm);
     r[C_AREF + 1] = -b * dot(ldv3(r + C_FRAME + 3), vrel);
     r[C_AREF + 2] = -b * dot(ldv3(r + C_FRAME + 6), vrel);
-    if (b1 != 0 && b2 != 0 && m.r_tree[b1] != m.r_tree[b2]) coupled = 1;
+    if (b1 != 0 && b2 != 0 && KI(r_tree, b1) != KI(r_tree, b2)) coupled = 1;
   }
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
@@ -147,8 +147,8 @@ DEV void fs_body_spatial(const Ctx &c, int off_vec) {
   for (int b = c.lane; b < m.nr; b += 64) {
     S6 w = s6zero();
     if (b > 0) {
-      int adr = m.r_chainadr[b], n = m.r_chainlen[b];
-      for (int k = 0; k < n; k++) { int d = m.chain_dofs[adr + k]; w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
+      int adr = KI(r_chainadr, b), n = KI(r_chainlen, b);
+      for (int k = 0; k < n; k++) { int d = KI(chain_dofs, adr + k); w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
     }
     sts6(L + c.ly.W + 6 * b, w);
   }
@@ -266,7 +266,7 @@ DEV void fs_line_eval(const Ctx &c, float alpha, float *cost, float *d1, float *
 DEV void fs_add_wrench(const Ctx &c, int b, V3 p, V3 F, V3 T, float sign) {
   if (b == 0) return;
   float *G = c.L + c.ly.G + 6 * b;
-  V3 mo = (cross(p - ldv3(c.L + c.ly.com + 3 * c.m.r_tree[b]), F) + T) * sign;
+  V3 mo = (cross(p - ldv3(c.L + c.ly.com + 3 * KI(r_tree, b)), F) + T) * sign;
   atomicAdd(G + 0, mo.x); atomicAdd(G + 1, mo.y); atomicAdd(G + 2, mo.z);
   atomicAdd(G + 3, sign * F.x); atomicAdd(G + 4, sign * F.y); atomicAdd(G + 5, sign * F.z);
 }
@@ -313,11 +313,11 @@ DEV void fs_gradient(const Ctx &c) {
   }
   SYNC();
   for (int d = c.lane; d < m.nv; d += 64) {
-    int bd = m.dof_rbody[d];
+    int bd = KI(dof_rbody, d);
     S6 s = lds6(L + ly.cdof + 6 * d);
     float acc = 0;
     for (int b = bd; b < m.nr; b++)
-      if ((m.r_ancmask[b] >> bd) & 1) acc += dot6(s, lds6(L + ly.G + 6 * b));
+      if ((KI(r_ancmask, b) >> bd) & 1) acc += dot6(s, lds6(L + ly.G + 6 * b));
     L[ly.grad + d] -= acc;
   }
   SYNC();
@@ -329,7 +329,7 @@ DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
 DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
   S6 s = lds6(c.L + c.ly.cdof + 6 * d);
-  return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * c.m.dof_tree[d]));
+  return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(dof_tree, d)));
 }
 
 DEV void fs_hessian(const Ctx &c) {
@@ -339,36 +339,60 @@ DEV void fs_hessian(const Ctx &c) {
   int nH = m.nv * (m.nv + 1) / 2;
   for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
   SYNC();
-  for (int e = c.lane; e < m.nM; e += 64) L[ly.H + fs_tri(m.M_i[e], m.M_j[e])] = L[ly.M + e];
+  for (int e = c.lane; e < m.nM; e += 64) L[ly.H + fs_tri(KI(M_i, e), KI(M_j, e))] = L[ly.M + e];
   SYNC();
-  int nslot = c.I(ly.scal)[SC_NSLOT];
-  for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + ly.con + FSIM_CONW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (ri[C_ACTIVE] != 1) continue;
-    float f[3], Hc[9], cc;
-    int dim = ri[C_DIM];
-    if (dim == 1) { if (r[C_JAR] >= 0) continue; for (int i = 0; i < 9; i++) Hc[i] = 0; Hc[0] = r[C_DN]; }
-    else if (!fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc)) continue;
-    V3 pos = ldv3(r + C_POS);
-    V3 fr0 = ldv3(r + C_FRAME), fr1 = ldv3(r + C_FRAME + 3), fr2 = ldv3(r + C_FRAME + 6);
-    int b1 = ri[C_B1], b2 = ri[C_B2];
-    int n2 = b2 ? m.r_chainlen[b2] : 0, n1 = b1 ? m.r_chainlen[b1] : 0;
-    int a2 = b2 ? m.r_chainadr[b2] : 0, a1 = b1 ? m.r_chainadr[b1] : 0;
-    for (int e1 = 0; e1 < n1 + n2; e1++) {
-      int d1 = e1 < n2 ? m.chain_dofs[a2 + e1] : m.chain_dofs[a1 + e1 - n2];
+  // Contacts: work items = (slot, chain entry e1); an item owns row d1 of the slot's J'WJ block and walks the chain for
+  // the columns.  Items are enumerated with a wave scan over the slots' chain lengths, so 20 part-floor contacts give
+  // 120 busy lanes instead of 20 lanes each running a 6x6 double loop (and a robot contact 15 lanes instead of one).
+  int nslot = c.I(ly.scal)[SC_NSLOT]; // <= 64 (fsim_create enforces ncon_max <= 64)
+  int *ibase = c.I(ly.surv), *icnt = c.I(ly.surv) + 64;
+  {
+    int s_ = c.lane, cnt = 0;
+    if (s_ < nslot) {
+      const float *r = L + ly.con + FSIM_CONW * s_;
+      const int *ri = reinterpret_cast<const int *>(r);
+      if (ri[C_ACTIVE] == 1) {
+        bool on;
+        if (ri[C_DIM] == 1) on = r[C_JAR] < 0;
+        else { float f_[3], cc_; on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f_, &cc_, nullptr) != 0; }
+        if (on) { int b1 = ri[C_B1], b2 = ri[C_B2]; cnt = (b2 ? KI(r_chainlen, b2) : 0) + (b1 ? KI(r_chainlen, b1) : 0); }
+      }
+    }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (c.lane >= o) incl += v; }
+    ibase[c.lane] = incl - cnt;
+    icnt[c.lane] = cnt;
+    int total = __shfl(incl, 63, 64);
+    SYNC();
+    for (int it = c.lane; it < total; it += 64) {
+      int lo = 0, hi = 63; // last slot with base <= it and cnt > 0 : binary search on the (non-decreasing) bases
+      while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ibase[mid] <= it) lo = mid; else hi = mid - 1; }
+      while (icnt[lo] == 0 && lo > 0) lo--; // skip empty slots that share the same base
+      int s2 = lo, e1 = it - ibase[s2];
+      float *r = L + ly.con + FSIM_CONW * s2;
+      int *ri = reinterpret_cast<int *>(r);
+      float f[3], Hc[9], cc;
+      if (ri[C_DIM] == 1) { for (int q = 0; q < 9; q++) Hc[q] = 0; Hc[0] = r[C_DN]; }
+      else fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc);
+      V3 pos = ldv3(r + C_POS);
+      V3 fr0 = ldv3(r + C_FRAME), fr1 = ldv3(r + C_FRAME + 3), fr2 = ldv3(r + C_FRAME + 6);
+      int b1 = ri[C_B1], b2 = ri[C_B2];
+      int n2 = b2 ? KI(r_chainlen, b2) : 0, n1 = b1 ? KI(r_chainlen, b1) : 0;
+      int a2 = b2 ? KI(r_chainadr, b2) : 0, a1 = b1 ? KI(r_chainadr, b1) : 0;
+      int d1 = e1 < n2 ? KI(chain_dofs, a2 + e1) : KI(chain_dofs, a1 + e1 - n2);
       float sg1 = e1 < n2 ? 1.0f : -1.0f;
       V3 c1 = fs_col(c, d1, pos);
       float j1[3] = {sg1 * dot(fr0, c1), sg1 * dot(fr1, c1), sg1 * dot(fr2, c1)};
-      float wj[3];
-      for (int a = 0; a < 3; a++) wj[a] = Hc[a] * j1[0] + Hc[3 + a] * j1[1] + Hc[6 + a] * j1[2];
+      // w = Hc * j1, pre-contracted with the frame: v(d2) = sg2 * (wv . col(d2))
+      float w0 = Hc[0] * j1[0] + Hc[3] * j1[1] + Hc[6] * j1[2], w1 = Hc[1] * j1[0] + Hc[4] * j1[1] + Hc[7] * j1[2],
+            w2 = Hc[2] * j1[0] + Hc[5] * j1[1] + Hc[8] * j1[2];
+      V3 wv = fr0 * w0 + fr1 * w1 + fr2 * w2;
+      const int rowb = d1 * (d1 + 1) / 2;
       for (int e2 = 0; e2 < n1 + n2; e2++) {
-        int d2 = e2 < n2 ? m.chain_dofs[a2 + e2] : m.chain_dofs[a1 + e2 - n2];
+        int d2 = e2 < n2 ? KI(chain_dofs, a2 + e2) : KI(chain_dofs, a1 + e2 - n2);
         if (d2 > d1) continue;
         float sg2 = e2 < n2 ? 1.0f : -1.0f;
-        V3 c2 = fs_col(c, d2, pos);
-        float v = sg2 * (wj[0] * dot(fr0, c2) + wj[1] * dot(fr1, c2) + wj[2] * dot(fr2, c2));
-        atomicAdd(L + ly.H + fs_tri(d1, d2), v);
+        atomicAdd(L + ly.H + rowb + d2, sg2 * dot(wv, fs_col(c, d2, pos)));
       }
     }
   }
@@ -384,10 +408,10 @@ DEV void fs_hessian(const Ctx &c) {
     if (!ri[WD_ACTIVE]) continue;
     int b1 = ri[WD_B1], b2 = ri[WD_B2];
     V3 p0 = ldv3(r + WD_P0), x2 = ldv3(r + WD_X2);
-    int n1 = m.r_chainlen[b1], n2 = m.r_chainlen[b2], a1 = m.r_chainadr[b1], a2 = m.r_chainadr[b2];
+    int n1 = KI(r_chainlen, b1), n2 = KI(r_chainlen, b2), a1 = KI(r_chainadr, b1), a2 = KI(r_chainadr, b2);
     for (int e1 = 0; e1 < n1 + n2; e1++) {
       bool f1 = e1 < n1;
-      int d1 = f1 ? m.chain_dofs[a1 + e1] : m.chain_dofs[a2 + e1 - n1];
+      int d1 = f1 ? KI(chain_dofs, a1 + e1) : KI(chain_dofs, a2 + e1 - n1);
       float sg1 = f1 ? 1.0f : -1.0f;
       V3 t1 = fs_col(c, d1, f1 ? p0 : x2) * sg1;
       V3 w1 = lds6(L + ly.cdof + 6 * d1).a * sg1;
@@ -396,7 +420,7 @@ DEV void fs_hessian(const Ctx &c) {
       for (int q = 0; q < 6; q++) j1[q] *= r[WD_D + q];
       for (int e2 = 0; e2 < n1 + n2; e2++) {
         bool f2 = e2 < n1;
-        int d2 = f2 ? m.chain_dofs[a1 + e2] : m.chain_dofs[a2 + e2 - n1];
+        int d2 = f2 ? KI(chain_dofs, a1 + e2) : KI(chain_dofs, a2 + e2 - n1);
         if (d2 > d1) continue;
         float sg2 = f2 ? 1.0f : -1.0f;
         V3 t2 = fs_col(c, d2, f2 ? p0 : x2) * sg2;
@@ -411,46 +435,127 @@ DEV void fs_hessian(const Ctx &c) {
 }
 
 // in-place Cholesky of the packed lower triangle, lane = row; p <- -H^-1 grad.  returns false if not SPD.
+DEV float fs_readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// Dense (coupled) case: every lane keeps ITS ROW of the factor in registers; column j's pivot row is broadcast
+// entry by entry with v_readlane (the column loop is fully unrolled, so register indices and lane ids are
+// compile-time constants).  No LDS traffic and no barriers inside the factorisation: ~n^2/2 (readlane + fma) pairs.
+template <int NMAX>
+DEV bool fs_chol_solve_regs(const Ctx &c) {
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  float *H = L + ly.H;
+  const int n = c.m.nv, i = c.lane;
+  const bool row = i < n;
+  const int ri = i * (i + 1) / 2;
+  float Lr[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) Lr[k] = (row && k <= i) ? H[ri + k] : 0.0f;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      float s = Lr[j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= Lr[k] * fs_readlane(Lr[k], j);
+      float djj = fs_readlane(s, j);
+      if (!(djj > 1e-30f)) { bad = 1; djj = 1e-30f; }
+      float ljj = sqrtf(djj);
+      Lr[j] = (i == j) ? ljj : s / ljj;
+    }
+  }
+  // forward substitution in registers: L y = -grad
+  float b = row ? -L[ly.grad + i] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      float yj = fs_readlane(b, j) / fs_readlane(Lr[j], j);
+      b = (i == j) ? yj : (i > j ? b - Lr[j] * yj : b);
+    }
+  }
+  // backward substitution needs column access: park the factor rows in LDS and sweep
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) if (row && k <= i) H[ri + k] = Lr[k];
+  SYNC();
+  for (int j = n - 1; j >= 0; j--) {
+    const int rj = j * (j + 1) / 2;
+    float pj = fs_readlane(b, j) / H[rj + j];
+    if (i == j) b = pj;
+    else if (i < j) b -= H[rj + i] * pj;
+  }
+  if (row) L[ly.p + i] = b;
+  SYNC();
+  return !bad;
+}
+
 DEV bool fs_chol_solve(const Ctx &c, int coupled) {
+  if (coupled && c.m.nv <= 48) return fs_chol_solve_regs<48>(c);
+
+  // lane = row.  Uncoupled: H is block diagonal by kinematic tree, and ALL tree blocks are factored
+  // simultaneously (step jj works on column bs0+jj of every block at once; pivots travel by per-lane
+  // shuffles), so the sequential depth is the largest block (9 for Sawyer) instead of nv (39).
+  // Coupled: one block = the whole matrix.
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
   float *H = L + ly.H;
   int n = m.nv, i = c.lane;
-  int rs = (i < n && !coupled) ? m.tree_dofadr[m.dof_tree[i]] : 0; // skyline start of my row
-  bool ok = true;
-  for (int j = 0; j < n; j++) {
+  bool row = i < n;
+  int t = row ? KI(dof_tree, i) : 0;
+  int bs0 = (row && !coupled) ? KI(tree_dofadr, t) : 0;
+  int bn = row ? (coupled ? n : KI(tree_dofnum, t)) : 0;
+  int steps = (int)wave_max((float)bn);
+  int bad = 0;
+  const int ri = i * (i + 1) / 2; // my row's base in the packed triangle (hoisted: integer multiplies are slow)
+  for (int jj = 0; jj < steps; jj++) {
+    int j = bs0 + jj;
+    bool act = row && jj < bn;
+    const int rj = j * (j + 1) / 2;
     float s = 0;
-    int rsj = coupled ? 0 : m.tree_dofadr[m.dof_tree[j]];
-    if (i >= j && i < n && rs <= j) {
-      s = H[fs_tri(i, j)];
-      int k0 = max(rs, rsj);
-      for (int k = k0; k < j; k++) s -= H[fs_tri(i, k)] * H[fs_tri(j, k)];
+    if (act && i >= j) {
+      const float *Hi = H + ri + bs0, *Hj = H + rj + bs0;
+      float s0 = H[ri + j], s1 = 0;
+      int k = 0;
+      for (; k + 1 < jj; k += 2) { s0 -= Hi[k] * Hj[k]; s1 -= Hi[k + 1] * Hj[k + 1]; }
+      if (k < jj) s0 -= Hi[k] * Hj[k];
+      s = s0 + s1;
     }
-    float djj = __shfl(s, j, 64);
-    if (!(djj > 1e-30f)) { ok = false; djj = 1e-30f; }
-    float ljj = sqrtf(djj);
-    if (i == j) H[fs_tri(j, j)] = ljj;
-    else if (i > j && i < n && rs <= j) H[fs_tri(i, j)] = s / ljj;
+    float djj = __shfl(s, act ? j : i, 64);
+    if (act && !(djj > 1e-30f)) { bad = 1; djj = 1e-30f; }
+    float ljj = sqrtf(fmaxf(djj, 1e-30f));
+    if (act) {
+      if (i == j) H[rj + j] = ljj;
+      else if (i > j) H[ri + j] = s / ljj;
+    }
     SYNC();
   }
   // forward: L y = -grad
-  float b = i < n ? -L[ly.grad + i] : 0.0f;
-  for (int j = 0; j < n; j++) {
-    float yj = __shfl(b, j, 64) / H[fs_tri(j, j)];
-    if (i == j) b = yj;
-    else if (i > j && i < n && rs <= j) b -= H[fs_tri(i, j)] * yj;
+  float b = row ? -L[ly.grad + i] : 0.0f;
+  for (int jj = 0; jj < steps; jj++) {
+    int j = bs0 + jj;
+    bool act = row && jj < bn;
+    float yj = __shfl(b, act ? j : i, 64);
+    if (act) {
+      yj /= H[j * (j + 1) / 2 + j];
+      if (i == j) b = yj;
+      else if (i > j) b -= H[ri + j] * yj;
+    }
   }
   // backward: L' p = y
-  for (int j = n - 1; j >= 0; j--) {
-    float pj = __shfl(b, j, 64) / H[fs_tri(j, j)];
-    int rsj = coupled ? 0 : m.tree_dofadr[m.dof_tree[j]];
-    if (i == j) b = pj;
-    else if (i < j && i >= rsj) b -= H[fs_tri(j, i)] * pj;
+  for (int jj = steps - 1; jj >= 0; jj--) {
+    int j = bs0 + jj;
+    bool act = row && jj < bn;
+    float pj = __shfl(b, act ? j : i, 64);
+    if (act) {
+      const int rj = j * (j + 1) / 2;
+      pj /= H[rj + j];
+      if (i == j) b = pj;
+      else if (i < j) b -= H[rj + i] * pj;
+    }
   }
-  if (i < n) L[ly.p + i] = b;
+  if (row) L[ly.p + i] = b;
   SYNC();
-  return ok;
+  return !wave_or(bad);
 }
 
 DEV float fs_dotv(const Ctx &c, int a, int b) {
@@ -463,7 +568,7 @@ DEV float fs_dotv(const Ctx &c, int a, int b) {
 DEV float fs_total_cost(const Ctx &c) {
   const Layout &ly = c.ly;
   float g = 0;
-  for (int d = c.lane; d < c.m.nv; d += 64) g += 0.5f * (c.L[ly.x + d] - c.L[ly.asmooth + d]) * (c.L[ly.Mx + d] - c.L[ly.smooth + d]);
+  for (int d = c.lane; d < c.m.nv; d += 64) g += c.L[ly.x + d] * (0.5f * c.L[ly.Mx + d] - c.L[ly.smooth + d]);
   g = wave_sum(g);
   float cs, d1, d2;
   fs_line_eval(c, 0.0f, &cs, &d1, &d2);
@@ -471,25 +576,22 @@ DEV float fs_total_cost(const Ctx &c) {
 }
 
 // Solve for qacc (ly.x) and M*qacc (ly.Mx).
+#ifdef FSIM_PROFILE
+#define FS_SPROF(slot) do { long long t1s_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16 + slot] += (int)((t1s_ - t0s_) >> 4); t0s_ = t1s_; } while (0)
+#else
+#define FS_SPROF(slot) do { } while (0)
+#endif
 DEV void fs_solve(const Ctx &c, int coupled) {
+#ifdef FSIM_PROFILE
+  long long t0s_ = clock64();
+#endif
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
   int *scal = c.I(ly.scal);
   int nslot = scal[SC_NSLOT];
-  // any active constraint at all?
-  int have = 0;
-  for (int s = c.lane; s < nslot; s += 64) have |= (c.I(ly.con + FSIM_CONW * s)[C_ACTIVE] == 1);
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) have |= c.I(ly.lim + FSIM_LIMW * s)[LM_ACTIVE];
-  for (int e = c.lane; e < m.neq; e += 64) have |= c.I(ly.weld + FSIM_WELDW * e)[WD_ACTIVE];
-  have = wave_or(have);
-  if (!have) {
-    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] = L[ly.asmooth + d]; L[ly.Mx + d] = L[ly.smooth + d]; }
-    if (c.lane == 0) scal[SC_NITER] = 0;
-    SYNC();
-    return;
-  }
-  // warm start: cheaper of qacc_warmstart and qacc_smooth
+  // Start from the previous step's acceleration (qacc_warmstart).  Unconstrained envs take the same path: with no
+  // active slot the first Newton step (H = M, alpha = 1) is exactly M^-1 qfrc_smooth, so M is never factored on its own.
   for (int d = c.lane; d < m.nv; d += 64) L[ly.x + d] = L[ly.qaccws + d];
   SYNC();
   fs_mulM(c, ly.Mx, ly.x);
@@ -497,74 +599,22 @@ DEV void fs_solve(const Ctx &c, int coupled) {
   fs_jdot(c, ly.x, true);
   float cw = fs_total_cost(c);
   SYNC();
-  // candidate 2: x = asmooth (gauss term zero)
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.p + d] = L[ly.asmooth + d];
-  SYNC();
-  fs_body_spatial(c, ly.p);
-  fs_jdot(c, ly.p, false); // jp <- J*asmooth (no aref)
-  float cs0, t1, t2;
-  {
-    // cost at asmooth: evaluate with jar' = jp - aref  == (jar=-aref) + 1*jp ; do it by temporarily using alpha trick:
-    // store jar_ws aside is not needed: compute via line_eval on records where jar := -aref.  Simpler: swap roles.
-  }
-  // evaluate smooth-candidate cost by writing jar_s = jp - aref into JP slots' place is intrusive; instead compute
-  // cost(asmooth) with a dedicated pass:
-  {
-    float csum = 0;
-    for (int s = c.lane; s < nslot; s += 64) {
-      float *r = L + ly.con + FSIM_CONW * s;
-      int *ri = reinterpret_cast<int *>(r);
-      if (ri[C_ACTIVE] != 1) continue;
-      float jar[3] = {r[C_JP] - r[C_AREF], r[C_JP + 1] - r[C_AREF + 1], r[C_JP + 2] - r[C_AREF + 2]}, f[3], cc = 0;
-      if (ri[C_DIM] == 1) { if (jar[0] < 0) cc = 0.5f * r[C_DN] * jar[0] * jar[0]; }
-      else fs_cone(jar, r[C_DN], r[C_DT], r[C_MU], f, &cc, nullptr);
-      csum += cc;
-    }
-    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-      float *r = L + ly.lim + FSIM_LIMW * s;
-      if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
-      float j = r[LM_JP] - r[LM_AREF];
-      if (j < 0) csum += 0.5f * r[LM_D] * j * j;
-    }
-    for (int e = c.lane; e < m.neq; e += 64) {
-      float *r = L + ly.weld + FSIM_WELDW * e;
-      if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
-      for (int q = 0; q < 6; q++) { float j = r[WD_JP + q] - r[WD_AREF + q]; csum += 0.5f * r[WD_D + q] * j * j; }
-    }
-    cs0 = wave_sum(csum);
-  }
-  (void)t1; (void)t2;
-  if (!(cw < cs0)) {
-    // take the smooth candidate: x = asmooth, Mx = smooth, jar = jp - aref
-    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] = L[ly.asmooth + d]; L[ly.Mx + d] = L[ly.smooth + d]; }
-    for (int s = c.lane; s < nslot; s += 64) {
-      float *r = L + ly.con + FSIM_CONW * s;
-      if (reinterpret_cast<int *>(r)[C_ACTIVE] != 1) continue;
-      for (int a = 0; a < 3; a++) r[C_JAR + a] = r[C_JP + a] - r[C_AREF + a];
-    }
-    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-      float *r = L + ly.lim + FSIM_LIMW * s;
-      if (reinterpret_cast<int *>(r)[LM_ACTIVE]) r[LM_JAR] = r[LM_JP] - r[LM_AREF];
-    }
-    for (int e = c.lane; e < m.neq; e += 64) {
-      float *r = L + ly.weld + FSIM_WELDW * e;
-      if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] = r[WD_JP + q] - r[WD_AREF + q];
-    }
-    SYNC();
-  }
   float scale = m.meaninertia_scale;
-  float cost = (cw < cs0) ? cw : cs0;
+  float cost = cw;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
     fs_gradient(c);
     float gn = sqrtf(fs_dotv(c, ly.grad, ly.grad));
+    FS_SPROF(23);
 #ifdef FSIM_PROFILE
     if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
     if (!isfinite(cost) && c.lane == 0 && !scal[27]) { scal[27] = 200 + it; scal[28] = scal[21]; }
 #endif
     if (scale * gn < c.newton_tol) break;
     fs_hessian(c);
+    FS_SPROF(24);
     bool ok = fs_chol_solve(c, coupled);
+    FS_SPROF(25);
 #ifdef FSIM_PROFILE
     if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
 #endif
@@ -576,6 +626,7 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     float pg0 = 0;
     for (int d = c.lane; d < m.nv; d += 64) pg0 += L[ly.p + d] * (L[ly.Mx + d] - L[ly.smooth + d]);
     pg0 = wave_sum(pg0);
+    FS_SPROF(26);
     // exact line search: safeguarded Newton on phi'(alpha)
     float lo = 0, hi = -1, alpha = 1, best = 0;
     for (int ls = 0; ls < 20; ls++) {
@@ -593,6 +644,7 @@ DEV void fs_solve(const Ctx &c, int coupled) {
       alpha = na;
     }
     alpha = best;
+    FS_SPROF(27);
 #ifdef FSIM_PROFILE
     if (!isfinite(alpha) && c.lane == 0 && !scal[27]) { scal[27] = 400 + it; scal[28] = scal[21]; }
     if (!isfinite(pMp) && c.lane == 0 && !scal[27]) { scal[27] = 500 + it; scal[28] = scal[21]; }
@@ -615,10 +667,51 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     // MuJoCo's second stopping rule: scaled cost improvement below tolerance (also catches fp32 stalls, where the
     // gradient test alone would spin to the iteration cap)
     float newcost = fs_total_cost(c);
+    FS_SPROF(28);
     float improvement = scale * (cost - newcost);
     cost = newcost;
     if (improvement < c.newton_tol) { it++; break; }
   }
   if (c.lane == 0) scal[SC_NITER] = it;
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ P8
+// qacc in ly.x, M*qacc in ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
+__device__ __noinline__ void fs_integrate(Ctx cv) {
+  FS_REBUILD_CTX(cv);
+  const DModel &m = c.m;
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  float h = m.timestep;
+  // (M + h D) a' = M a : the same lane-per-row block Cholesky as the Newton step, on H = M + h diag(damping)
+  int nH = m.nv * (m.nv + 1) / 2;
+  for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
+  for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = -L[ly.Mx + d]; }
+  SYNC();
+  for (int e = c.lane; e < m.nM; e += 64) {
+    int i = KI(M_i, e), j = KI(M_j, e);
+    L[ly.H + fs_tri(i, j)] = L[ly.M + e] + (i == j ? h * KF(dof_damping, i) : 0.0f);
+  }
+  SYNC();
+  fs_chol_solve(c, 0);
+  for (int d = c.lane; d < m.nv; d += 64) L[ly.qvel + d] += h * L[ly.p + d];
+  SYNC();
+  for (int b = c.lane; b < m.nr; b += 64) {
+    if (b == 0) continue;
+    int jt = KI(r_jtype, b), qa = KI(r_qposadr, b), d = KI(r_dofadr, b);
+    if (jt == JT_FREE) {
+      for (int k = 0; k < 3; k++) L[ly.qpos + qa + k] += h * L[ly.qvel + d + k];
+      V3 w = ldv3(L + ly.qvel + d + 3);
+      float wn;
+      V3 ax = normalized(w, &wn);
+      float ang = wn * h;
+      if (ang > 0) {
+        Q4 q = qnormalized(qmul(ldq(L + ly.qpos + qa + 3), axisangle(ax, ang)));
+        stq(L + ly.qpos + qa + 3, q);
+      }
+    } else
+      L[ly.qpos + qa] += h * L[ly.qvel + d];
+  }
   SYNC();
 }

@@ -9,7 +9,7 @@ from furniture_amd.sim import FSim, default_config, INFO_DIM
 from furniture_amd.envs import ResetTableSampler, make_config
 m = load_compiled("Sawyer", "table_lack_0825")
 N = 4096
-cfg = default_config(); cfg.max_episode_steps = 150
+cfg = default_config(); cfg.max_episode_steps = 150; cfg.solver_tolerance = float(os.environ.get('FSIM_TOL', '1e-6'))
 sim = FSim(m, N, config=cfg)
 sampler = ResetTableSampler(m, make_config(), 123, 0, N)
 sim.set_reset_tables(*sampler.draw())
@@ -21,7 +21,8 @@ names = ["kin+crb+factor", "collide", "vel+smooth", "constraints", "solve"]
 for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     act.uniform_(-1, 1, generator=g); torch.cuda.synchronize()
     t0 = time.time(); sim.step(act, obs, rew, done, info); sim.sync(); dt = time.time() - t0
-    p = sim.get_state("qacc")["qacc"].view(torch.int32)[:, :16].cpu().numpy().astype(np.int64)
+    pall = sim.get_state("qacc")["qacc"].view(torch.int32)[:, :48].cpu().numpy().astype(np.int64)
+    p = pall[:, :16]
     cyc = p[:, :5] * 16
     tot = cyc.sum(axis=1)
     nsub, nit, ncoup, nsurv, nslot, maxit = p[:, 5], p[:, 6], p[:, 7], p[:, 8], p[:, 9], p[:, 10]
@@ -29,6 +30,18 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         t, dt * 1e3, tot.mean() / 1e6, np.percentile(tot, 50) / 1e6, np.percentile(tot, 99) / 1e6, tot.max() / 1e6,
         " ".join("%s %.0f%%" % (n, 100 * cyc[:, i].sum() / tot.sum()) for i, n in enumerate(names)),
         nsub.mean(), nit.sum() / max(1, nsub.sum()), maxit.max(), ncoup.sum() / max(1, nsub.sum()), nsurv.sum() / max(1, nsub.sum()), nslot.sum() / max(1, nsub.sum())))
+    fine = pall[:, 16:29] * 16
+    cfine = pall[:, 29:32] * 16
+    fn = ["kinematics", "com_inertia", "crb+M", "factor", "vel_bias", "smooth", "solve:setup", "grad", "hessian", "chol", "Mp+jp", "linesearch", "update+cost"]
+    if t in (0, 5):
+        med = np.median(fine, axis=0) / 50
+        print("    per-substep kcycles (median env): " + " ".join("%s %.1f" % (n, v / 1e3) for n, v in zip(fn, med)) + " | collide %.1f (geom %.1f broad %.1f narrow %.1f) constraints %.1f" % (np.median(cyc[:, 1]) / 50e3, np.median(cfine[:, 0]) / 50e3, np.median(cfine[:, 1]) / 50e3, np.median(cfine[:, 2]) / 50e3, np.median(cyc[:, 3]) / 50e3))
+    if t in (0, 5):
+        tn = ['pl_sph','pl_box','pl_cyl','sph_sph','sph_box','sph_cyl','box_box','cyl_box','cyl_cyl']
+        print('    narrowphase per-type kcyc/substep (median env, sum over lanes): ' + ' '.join('%s %.1f' % (n, v / 50e3) for n, v in zip(tn, np.median(pall[:, 32:41] * 16, axis=0))))
+    if t == 5:
+        for e in np.argsort(-tot)[:3]:
+            print("    SLOW env %d: Mcyc %.1f it/sub %.2f coupled %.2f | per-substep kcyc: " % (e, tot[e] / 1e6, nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e])) + " ".join("%s %.1f" % (n, v / 50e3) for n, v in zip(fn, fine[e])) + " | collide %.1f constraints %.1f" % (cyc[e, 1] / 50e3, cyc[e, 3] / 50e3))
     if t in (3, 8):
         order = np.argsort(-tot)[:5]
         for e in order:
