@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layou
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 64) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + ly.scal)[i] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   fs_load_cache(c);
@@ -79,15 +79,18 @@ __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layou
 
 __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
-                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof) {
+                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost) {
   extern __shared__ float L[];
   const DModel &m = *mp;
   const Layout &ly = *lp;
-  int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= kp.n_envs) return;
+  long long t_entry = clock64();
+  int lane = threadIdx.x;
+  if ((int)blockIdx.x >= kp.n_envs) return;
+  // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
+  int env = order ? order[blockIdx.x] : (int)blockIdx.x;
   float *rec = state + (size_t)env * ly.stride;
   load_record(L, rec, ly.stride, lane);
-  if (lane < 64) reinterpret_cast<int *>(L + ly.scal)[lane] = 0;
+  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + ly.scal)[i] = 0;
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   fs_load_cache(c);
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
   io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * m.nparts : nullptr;
   io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * m.narmj : nullptr;
   io.n_noise = n_noise;
+  io.cost = cost ? cost + env : nullptr;
+  io.t0 = t_entry;
   if (do_step) env_step(c, cfg, io);
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   SYNC();
@@ -107,6 +112,37 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
   if (prof && lane < 48) prof[(size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max) + lane] = reinterpret_cast<int *>(L + ly.scal)[16 + lane];
 #endif
   store_record(rec, L, ly.stride, lane);
+}
+
+// Longest-job-first launch order.  An env-step's cost varies 5x with its contact state (robot gripping a part =>
+// coupled Newton systems) and 7x when the episode ends inside the launch (in-kernel reset), and the kernel's duration
+// is the finish time of the last wave: sorting the grid by predicted cost keeps the long jobs off the tail.
+// One workgroup, bucket sort by cost (256 linear buckets below the max, bucket 0 = envs that will reset), order inside a
+// bucket is arbitrary -- it only affects timing, never results (envs are independent).
+__global__ __launch_bounds__(1024) void k_schedule(const int *cost, int *order, int n) {
+  __shared__ int hist[257], mx;
+  int tid = threadIdx.x;
+  if (tid < 257) hist[tid] = 0;
+  if (tid == 0) mx = 0;
+  __syncthreads();
+  int lm = 0;
+  for (int i = tid; i < n; i += 1024) lm = max(lm, cost[i]);
+  atomicMax(&mx, lm);
+  __syncthreads();
+  long long M = (long long)mx + 1;
+  for (int i = tid; i < n; i += 1024) {
+    int cv = cost[i];
+    int b = cv < 0 ? 0 : 256 - (int)((long long)cv * 256 / M);
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int b = 0; b < 257; b++) { int h = hist[b]; hist[b] = acc; acc += h; } }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    int cv = cost[i];
+    int b = cv < 0 ? 0 : 256 - (int)((long long)cv * 256 / M);
+    order[atomicAdd(&hist[b], 1)] = i;
+  }
 }
 
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays
@@ -156,6 +192,8 @@ struct fsim {
   DModel *d_m = nullptr;
   Layout *d_ly = nullptr;
   float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
+  int *d_cost = nullptr, *d_order = nullptr; // longest-job-first scheduling (k_schedule)
+  bool lpt = true;
   int n_noise = 0;
   int auxstride = 0, lds_bytes = 0;
   std::vector<char> blob;
@@ -301,7 +339,7 @@ static void build_layout(fsim *s, int ncon_max) {
   ly.smooth = take(m.nv); ly.asmooth = ly.smooth; ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
   ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg); ly.surv = take(FSIM_MAXSURV);
   ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(64);
+  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(SC_WORDS);
   // LDS model cache
   {
     std::vector<int> ca, cl;
@@ -338,6 +376,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   int ncon_max = 48;
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
+  if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
   build_layout(s, ncon_max);
   s->lds_bytes = s->ly.lds_words * 4;
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
@@ -350,6 +389,9 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   s->auxstride = s->m.nv + 7 * s->m.nr + 4 + 2 * s->ly.ncon_max;
   HIPCHK(hipMalloc(&s->d_aux, (size_t)n_envs * s->auxstride * 4));
   HIPCHK(hipMemsetAsync(s->d_aux, 0, (size_t)n_envs * s->auxstride * 4, s->stream));
+  HIPCHK(hipMalloc(&s->d_cost, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_order, (size_t)n_envs * 4));
+  HIPCHK(hipMemsetAsync(s->d_cost, 0, (size_t)n_envs * 4, s->stream));
+  s->lpt = !getenv("FSIM_NO_LPT");
   // initial record: qpos0, default masks, weld data, env block zero
   {
     std::vector<float> rec(s->ly.stride, 0.0f), q0, ed;
@@ -388,7 +430,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -516,9 +558,12 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
   timing_collect(s);
+  bool sched = do_step && s->lpt;
+  if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
   timing_begin(s);
   hipLaunchKernelGGL(k_env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
-                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux));
+                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
+                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr);
   hipError_t e = hipGetLastError();
   timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

@@ -10,15 +10,18 @@
 
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_DIST = 13, C_INCM = 14, C_MU = 15, C_DIM = 16, C_B1 = 17, C_B2 = 18, C_G1 = 19,
        C_G2 = 20, C_AREF = 21, C_DN = 24, C_DT = 25, C_JAR = 26, C_JP = 29 };
-enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8 };
+enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8, SC_ADJ = 64, SC_ISL = 80, SC_WORDS = 96 };
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
 
 struct Emit {
   const Ctx &c;
-  int base, maxn, cg1, cg2;
+  int maxn, cg1, cg2;
   float margin, gap;
-  __device__ Emit(const Ctx &c_, int b, int mx, int g1, int g2, float mg, float gp) : c(c_), base(b), maxn(mx), cg1(g1), cg2(g2), margin(mg), gap(gp) {}
+  __device__ Emit(const Ctx &c_, int mx, int g1, int g2, float mg, float gp) : c(c_), maxn(mx), cg1(g1), cg2(g2), margin(mg), gap(gp) {}
+  // Raw contact: position, (unnormalised) normal, distance and the geom pair.  The frame and the pair's solver
+  // parameters are filled in afterwards by fs_finish_contacts with one lane per slot (uniform control flow), so the
+  // many inlined copies of this call stay small.
   DEV void operator()(int k, float dist, V3 pos, V3 n) const {
     if (k >= maxn) return;
     // a degenerate narrow-phase result (fp32 portal refinement on near-parallel faces) must never reach the solver
@@ -28,28 +31,38 @@ struct Emit {
     int *scal_ = c.I(c.ly.scal);
     int slot = atomicAdd(&scal_[SC_NSLOT], 1);
     if (slot >= c.ly.ncon_max) { scal_[SC_OVERFLOW] |= 2; return; }
-    const DModel &m = c.m;
     float *r = c.L + c.ly.con + FSIM_CONW * slot;
     int *ri = reinterpret_cast<int *>(r);
-    // frame: x = n, y, z  (mju_makeFrame convention)
-    V3 x = normalized(n);
+    stv3(r + C_POS, pos);
+    stv3(r + C_FRAME, n);
+    r[C_DIST] = dist;
+    r[C_INCM] = margin - gap;
+    ri[C_G1] = cg1; ri[C_G2] = cg2;
+    ri[C_ACTIVE] = 1;
+  }
+};
+
+// lane = slot: contact frame (mju_makeFrame convention: x = n, then y, z) and the geom pair's parameters
+DEV void fs_finish_contacts(const Ctx &c) {
+  const DModel &m = c.m;
+  int nslot = min(c.I(c.ly.scal)[SC_NSLOT], c.ly.ncon_max);
+  for (int s = c.lane; s < nslot; s += 64) {
+    float *r = c.L + c.ly.con + FSIM_CONW * s;
+    int *ri = reinterpret_cast<int *>(r);
+    int cg1 = ri[C_G1], cg2 = ri[C_G2];
+    V3 x = normalized(ldv3(r + C_FRAME));
     V3 y = (x.y > -0.5f && x.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
     y = normalized(y - x * dot(x, y));
     V3 z = cross(x, y);
-    stv3(r + C_POS, pos);
     stv3(r + C_FRAME, x); stv3(r + C_FRAME + 3, y); stv3(r + C_FRAME + 6, z);
-    r[C_DIST] = dist;
-    r[C_INCM] = margin - gap;
     float mu = fmaxf(m.cg_friction[3 * cg1], m.cg_friction[3 * cg2]);
     r[C_MU] = mu;
     int dim = max(m.cg_condim[cg1], m.cg_condim[cg2]);
     if (mu < 1e-15f) dim = 1;
     ri[C_DIM] = dim;
     ri[C_B1] = m.cg_body[cg1]; ri[C_B2] = m.cg_body[cg2];
-    ri[C_G1] = cg1; ri[C_G2] = cg2;
-    ri[C_ACTIVE] = 1;
   }
-};
+}
 
 // ---- narrow phase primitives ---------------------------------------------------------------
 DEV void np_plane_sphere(const Emit &e, V3 pp, const M3 &pR, V3 sp, float r) {
@@ -62,6 +75,7 @@ DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V
   V3 n = colv(pR, 2);
   float dist0 = dot(bp - pp, n);
   int cnt = 0;
+#pragma unroll 1
   for (int i = 0; i < 8; i++) {
     V3 v = v3((i & 1) ? size.x : -size.x, (i & 2) ? size.y : -size.y, (i & 4) ? size.z : -size.z);
     V3 cv = mulv(bR, v);
@@ -149,110 +163,137 @@ DEV void np_sphere_cylinder(const Emit &e, V3 sp, float r, V3 cp, const M3 &cR, 
   np_sphere_local(e, sp, r, cR, cl, q, inside, od, pen);
 }
 
-// Sutherland-Hodgman clip of a convex polygon against  sgn*p[axis] <= lim
-DEV int np_clip(float (*poly)[2], int n, int axis, float lim, float sgn) {
-  float outp[16][2];
-  int mo = 0;
-  for (int i = 0; i < n; i++) {
-    float *a = poly[i], *b = poly[(i + 1) % n];
-    float da = sgn * a[axis] - lim, db = sgn * b[axis] - lim;
-    if (da <= 0) { outp[mo][0] = a[0]; outp[mo][1] = a[1]; mo++; }
-    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
-      float t = da / (da - db);
-      outp[mo][0] = a[0] + t * (b[0] - a[0]); outp[mo][1] = a[1] + t * (b[1] - a[1]); mo++;
-    }
-    if (mo >= 15) break;
-  }
-  for (int i = 0; i < mo; i++) { poly[i][0] = outp[i][0]; poly[i][1] = outp[i][1]; }
-  return mo;
-}
+// dynamic pick of one of three values without a (scratch-backed) indexed local array
+DEV V3 pick3(V3 a, V3 b, V3 c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
 DEV float sz(V3 s, int k) { return comp(s, k); }
+
+// box-box: 15-axis separating-axis test, then either one edge-edge contact or the face manifold
+//   reference face rectangle  (x) incident face quad, both projected on the reference face:
+//   manifold = {quad vertices inside the rectangle} + {quad edge x rectangle side crossings} + {rectangle corners
+//   strictly inside the quad}  (the vertex set of the clipped polygon, <= 8 points, no polygon buffers needed).
 DEV void np_box_box(const Emit &e, V3 p1, const M3 &R1, V3 s1, V3 p2, const M3 &R2, V3 s2) {
-  V3 A[3], B[3];
-  for (int k = 0; k < 3; k++) { A[k] = colv(R1, k); B[k] = colv(R2, k); }
-  V3 d = p2 - p1;
-  float margin = e.margin;
-  float AC[3][3];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) AC[i][j] = fabsf(dot(A[i], B[j])) + 1e-7f;
-  float best = -1e30f; int bestType = -1, bi = 0, bj = 0; V3 bestL = v3(0, 0, 0);
-  for (int i = 0; i < 3; i++) {
-    float t = dot(d, A[i]);
-    float sep = fabsf(t) - (sz(s1, i) + s2.x * AC[i][0] + s2.y * AC[i][1] + s2.z * AC[i][2]);
-    if (sep > margin) return;
-    if (sep > best) { best = sep; bestType = 0; bi = i; bestL = A[i] * (t < 0 ? -1.0f : 1.0f); }
-  }
-  for (int j = 0; j < 3; j++) {
-    float t = dot(d, B[j]);
-    float sep = fabsf(t) - (sz(s2, j) + s1.x * AC[0][j] + s1.y * AC[1][j] + s1.z * AC[2][j]);
-    if (sep > margin) return;
-    if (sep > best) { best = sep; bestType = 1; bj = j; bestL = B[j] * (t < 0 ? -1.0f : 1.0f); }
-  }
+  const V3 A0 = colv(R1, 0), A1 = colv(R1, 1), A2 = colv(R1, 2), B0 = colv(R2, 0), B1 = colv(R2, 1), B2 = colv(R2, 2);
+  const V3 d = p2 - p1;
+  const float margin = e.margin;
+  float best = -1e30f; int bestType = 0, bk = 0; float bsgn = 1;
   float bestE = -1e30f; int ei = 0, ej = 0; V3 eL = v3(0, 0, 0);
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-    V3 Lx = cross(A[i], B[j]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    V3 Ai = i == 0 ? A0 : (i == 1 ? A1 : A2);
+    float c0 = fabsf(dot(Ai, B0)) + 1e-7f, c1 = fabsf(dot(Ai, B1)) + 1e-7f, c2 = fabsf(dot(Ai, B2)) + 1e-7f;
+    float t = dot(d, Ai);
+    float sep = fabsf(t) - (sz(s1, i) + s2.x * c0 + s2.y * c1 + s2.z * c2);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; bestType = 0; bk = i; bsgn = t < 0 ? -1.0f : 1.0f; }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    V3 Bj = j == 0 ? B0 : (j == 1 ? B1 : B2);
+    float c0 = fabsf(dot(A0, Bj)) + 1e-7f, c1 = fabsf(dot(A1, Bj)) + 1e-7f, c2 = fabsf(dot(A2, Bj)) + 1e-7f;
+    float t = dot(d, Bj);
+    float sep = fabsf(t) - (sz(s2, j) + s1.x * c0 + s1.y * c1 + s1.z * c2);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; bestType = 1; bk = j; bsgn = t < 0 ? -1.0f : 1.0f; }
+  }
+#pragma unroll 1
+  for (int ij = 0; ij < 9; ij++) {
+    int i = ij / 3, j = ij - 3 * i;
+    V3 Lx = cross(pick3(A0, A1, A2, i), pick3(B0, B1, B2, j));
     float len = norm(Lx);
     if (len < 1e-6f) continue;
     Lx = Lx * (1.0f / len);
-    float t = dot(d, Lx), ra = 0, rb = 0;
-    for (int k = 0; k < 3; k++) { ra += sz(s1, k) * fabsf(dot(A[k], Lx)); rb += sz(s2, k) * fabsf(dot(B[k], Lx)); }
+    float t = dot(d, Lx);
+    float ra = s1.x * fabsf(dot(A0, Lx)) + s1.y * fabsf(dot(A1, Lx)) + s1.z * fabsf(dot(A2, Lx));
+    float rb = s2.x * fabsf(dot(B0, Lx)) + s2.y * fabsf(dot(B1, Lx)) + s2.z * fabsf(dot(B2, Lx));
     float sep = fabsf(t) - (ra + rb);
     if (sep > margin) return;
     if (sep > bestE) { bestE = sep; ei = i; ej = j; eL = Lx * (t < 0 ? -1.0f : 1.0f); }
   }
   if (bestE > best + 1e-6f + 0.05f * fabsf(best)) {
+    // edge-edge contact: closest points of the two support edges along eL
     V3 n = eL, pa = p1, pb = p2;
+#pragma unroll
     for (int k = 0; k < 3; k++) {
-      if (k != ei) pa = pa + A[k] * (dot(A[k], n) > 0 ? sz(s1, k) : -sz(s1, k));
-      if (k != ej) pb = pb + B[k] * (dot(B[k], n) > 0 ? -sz(s2, k) : sz(s2, k));
+      V3 Ak = k == 0 ? A0 : (k == 1 ? A1 : A2), Bk = k == 0 ? B0 : (k == 1 ? B1 : B2);
+      if (k != ei) pa = pa + Ak * (dot(Ak, n) > 0 ? sz(s1, k) : -sz(s1, k));
+      if (k != ej) pb = pb + Bk * (dot(Bk, n) > 0 ? -sz(s2, k) : sz(s2, k));
     }
+    V3 Ae = pick3(A0, A1, A2, ei), Be = pick3(B0, B1, B2, ej);
+    float sae = sz(s1, ei), sbe = sz(s2, ej);
     V3 w = pa - pb;
-    float b = dot(A[ei], B[ej]), dd = dot(A[ei], w), ee = dot(B[ej], w), den = 1 - b * b;
+    float b = dot(Ae, Be), dd = dot(Ae, w), ee = dot(Be, w), den = 1 - b * b;
     float sa = 0, tb = 0;
     if (den > 1e-12f) { sa = (b * ee - dd) / den; tb = (ee - b * dd) / den; }
-    sa = fminf(fmaxf(sa, -sz(s1, ei)), sz(s1, ei));
-    tb = fminf(fmaxf(tb, -sz(s2, ej)), sz(s2, ej));
-    pa = pa + A[ei] * sa; pb = pb + B[ej] * tb;
+    sa = fminf(fmaxf(sa, -sae), sae);
+    tb = fminf(fmaxf(tb, -sbe), sbe);
+    pa = pa + Ae * sa; pb = pb + Be * tb;
     e(0, bestE, (pa + pb) * 0.5f, n);
     return;
   }
-  V3 pr, pi_, sr, si, nr;
-  V3 *Rr, *Ri;
-  int ka;
-  if (bestType == 0) { pr = p1; pi_ = p2; sr = s1; si = s2; Rr = A; Ri = B; ka = bi; nr = bestL; }
-  else { pr = p2; pi_ = p1; sr = s2; si = s1; Rr = B; Ri = A; ka = bj; nr = -bestL; }
+  // face contact.  reference box r (face axis ka, outward normal nr towards the incident box), incident box i
+  const bool f0 = bestType == 0;
+  const V3 pr = f0 ? p1 : p2, pi_ = f0 ? p2 : p1, sr = f0 ? s1 : s2, si = f0 ? s2 : s1;
+  const V3 Rr0 = f0 ? A0 : B0, Rr1 = f0 ? A1 : B1, Rr2 = f0 ? A2 : B2, Ri0 = f0 ? B0 : A0, Ri1 = f0 ? B1 : A1, Ri2 = f0 ? B2 : A2;
+  const int ka = bk;
+  const V3 nr = pick3(Rr0, Rr1, Rr2, ka) * (f0 ? bsgn : -bsgn);
   int kinc = 0; float mind = 1e30f, sgninc = 1;
-  for (int k = 0; k < 3; k++) { float t = dot(Ri[k], nr); if (-fabsf(t) < mind) { mind = -fabsf(t); kinc = k; sgninc = t > 0 ? -1.0f : 1.0f; } }
-  int k1 = (kinc + 1) % 3, k2 = (kinc + 2) % 3, u1 = (ka + 1) % 3, u2 = (ka + 2) % 3;
-  V3 fc = pi_ + Ri[kinc] * (sgninc * sz(si, kinc));
-  V3 rc = pr + nr * sz(sr, ka);
-  float poly[16][2];
-  const float cs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
-  for (int q = 0; q < 4; q++) {
-    V3 v = fc + Ri[k1] * (cs[q][0] * sz(si, k1)) + Ri[k2] * (cs[q][1] * sz(si, k2));
-    V3 r = v - rc;
-    poly[q][0] = dot(r, Rr[u1]); poly[q][1] = dot(r, Rr[u2]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float t = dot(k == 0 ? Ri0 : (k == 1 ? Ri1 : Ri2), nr);
+    if (-fabsf(t) < mind) { mind = -fabsf(t); kinc = k; sgninc = t > 0 ? -1.0f : 1.0f; }
   }
-  int np = 4;
-  np = np_clip(poly, np, 0, sz(sr, u1), 1.0f);
-  if (np) np = np_clip(poly, np, 0, sz(sr, u1), -1.0f);
-  if (np) np = np_clip(poly, np, 1, sz(sr, u2), 1.0f);
-  if (np) np = np_clip(poly, np, 1, sz(sr, u2), -1.0f);
-  V3 ninc = Ri[kinc] * sgninc;
-  float denom = dot(ninc, nr);
-  V3 nout = bestType == 0 ? nr : -nr;
+  const int k1 = (kinc + 1) % 3, k2 = (kinc + 2) % 3, u1 = (ka + 1) % 3, u2 = (ka + 2) % 3;
+  const V3 Rik = pick3(Ri0, Ri1, Ri2, kinc), E1 = pick3(Ri0, Ri1, Ri2, k1) * sz(si, k1), E2 = pick3(Ri0, Ri1, Ri2, k2) * sz(si, k2);
+  const V3 U1 = pick3(Rr0, Rr1, Rr2, u1), U2 = pick3(Rr0, Rr1, Rr2, u2);
+  const float hu = sz(sr, u1), hv = sz(sr, u2);
+  const V3 fc = pi_ + Rik * (sgninc * sz(si, kinc));
+  const V3 rc = pr + nr * sz(sr, ka);
+  // incident quad in reference-face coordinates: centre (cx, cy), edge vectors (e1x, e1y), (e2x, e2y);
+  // vertex q = centre + sx*e1 + sy*e2 with (sx, sy) = (1,1), (-1,1), (-1,-1), (1,-1)
+  const V3 rcen = fc - rc;
+  const float cx = dot(rcen, U1), cy = dot(rcen, U2), e1x = dot(E1, U1), e1y = dot(E1, U2), e2x = dot(E2, U1), e2y = dot(E2, U2);
+  const V3 ninc = Rik * sgninc;
+  const float denom = dot(ninc, nr);
+  const V3 nout = f0 ? nr : -nr;
   int cnt = 0;
-  float px[8][3];
-  for (int i = 0; i < np && cnt < 8; i++) {
-    V3 q = rc + Rr[u1] * poly[i][0] + Rr[u2] * poly[i][1];
+  auto lift = [&](float x, float y) {
+    V3 q = rc + U1 * x + U2 * y;
     float h = fabsf(denom) > 1e-9f ? dot(fc - q, ninc) / denom : 0.0f;
-    if (h > margin) continue;
-    V3 pos = q + nr * (0.5f * h);
-    bool dup = false;
-    for (int k = 0; k < cnt; k++) { V3 dv = pos - v3(px[k][0], px[k][1], px[k][2]); if (dot(dv, dv) < 1e-12f) dup = true; }
-    if (dup) continue;
-    px[cnt][0] = pos.x; px[cnt][1] = pos.y; px[cnt][2] = pos.z;
-    e(cnt, h, pos, nout);
+    if (h > margin) return;
+    e(cnt, h, q + nr * (0.5f * h), nout);
     cnt++;
+  };
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    float sx = (q == 0 || q == 3) ? 1.0f : -1.0f, sy = q < 2 ? 1.0f : -1.0f;
+    float ax = cx + sx * e1x + sy * e2x, ay = cy + sx * e1y + sy * e2y;
+    if (fabsf(ax) <= hu && fabsf(ay) <= hv) lift(ax, ay);
+    // edge q -> q+1 against the four rectangle sides
+    int q1 = (q + 1) & 3;
+    float tx = (q1 == 0 || q1 == 3) ? 1.0f : -1.0f, ty = q1 < 2 ? 1.0f : -1.0f;
+    float bx = cx + tx * e1x + ty * e2x, by = cy + tx * e1y + ty * e2y;
+#pragma unroll 1
+    for (int side = 0; side < 4; side++) {
+      bool xs = side < 2;                       // sides 0,1: x = +-hu;  sides 2,3: y = +-hv
+      float sg = (side & 1) ? -1.0f : 1.0f, lim = xs ? hu : hv, olim = xs ? hv : hu;
+      float da = sg * (xs ? ax : ay) - lim, db = sg * (xs ? bx : by) - lim;
+      if (!((da < 0 && db > 0) || (da > 0 && db < 0))) continue;
+      float t = da / (da - db);
+      float px = ax + t * (bx - ax), py = ay + t * (by - ay);
+      float o = fabsf(xs ? py : px);
+      if (xs ? (o <= olim) : (o < olim)) lift(px, py); // corner crossings belong to the x sides only
+    }
+  }
+  // rectangle corners strictly inside the quad: |local coords| < 1 in the quad's own (e1, e2) basis
+  float det = e1x * e2y - e1y * e2x;
+  if (fabsf(det) > 1e-12f) {
+    float idet = 1.0f / det;
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+      float x = ((q == 0 || q == 3) ? hu : -hu) - cx, y = (q < 2 ? hv : -hv) - cy;
+      float a = (x * e2y - y * e2x) * idet, b = (e1x * y - e1y * x) * idet;
+      if (fabsf(a) < 1.0f && fabsf(b) < 1.0f) lift(x + cx, y + cy);
+    }
   }
 }
 
@@ -415,16 +456,13 @@ DEV void fs_collide(const Ctx &c) {
   SYNC();
   FS_CPROF(30);
   for (int i = c.lane; i < nsurv; i += 64) {
-    int p = surv[i], base = 0;
+    int p = surv[i];
     int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1], pt = m.cp[3 * p + 2];
     float margin = fmaxf(m.cg_margin[g1], m.cg_margin[g2]), gap = fmaxf(m.cg_gap[g1], m.cg_gap[g2]);
-    Emit e(c, base, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
+    Emit e(c, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
     V3 p1 = ldv3(L + ly.gpos + 3 * g1), p2 = ldv3(L + ly.gpos + 3 * g2);
     M3 R1 = ldm3(L + ly.gmat + 9 * g1), R2 = ldm3(L + ly.gmat + 9 * g2);
     V3 s1 = ldv3(m.cg_size + 3 * g1), s2 = ldv3(m.cg_size + 3 * g2);
-#ifdef FSIM_PROFILE
-    long long tp0_ = clock64();
-#endif
     switch (pt) {
       case PT_PLANE_SPHERE: np_plane_sphere(e, p1, R1, p2, s2.x); break;
       case PT_PLANE_BOX: np_plane_box(e, p1, R1, p2, R2, s2); break;
@@ -440,11 +478,9 @@ DEV void fs_collide(const Ctx &c) {
         np_mpr(e, A, B);
       }
     }
-#ifdef FSIM_PROFILE
-    atomicAdd(&scal[48 + pt], (int)((clock64() - tp0_) >> 4));
-#endif
   }
   SYNC();
+  fs_finish_contacts(c);
   if (c.lane == 0 && scal[SC_NSLOT] > ly.ncon_max) scal[SC_NSLOT] = ly.ncon_max;
   SYNC();
   FS_CPROF(31);

@@ -26,6 +26,8 @@ struct EnvIO {
   int *info;
   const float *tab_parts, *tab_noise;
   int n_noise;
+  int *cost;      // scheduler key written by env_step (shader cycles >> 10 of the step just taken, -1 = will time out next step)
+  long long t0;   // shader clock at kernel entry
 };
 
 static inline int env_extra_words(const DModel &, int) { return 0; }
@@ -629,6 +631,14 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
     }
     scal[14] = terminal;
+    if (io.cost) {
+      // longest-job-first key for the next launch: this step's cost predicts the next one (contact state persists);
+      // an env that will hit max_episode_steps next step pays an in-kernel reset on top and goes to the front.
+      long long dt = clock64() - io.t0;
+      int key = (int)min(dt >> 10, (long long)(1 << 24));
+      bool timeout_next = !terminal && cfg.auto_reset && E[E_EPISODE_LENGTH] + 1 >= cfg.max_episode_steps;
+      *io.cost = timeout_next ? -1 : key;
+    }
   }
   SYNC();
   terminal = scal[14];

@@ -97,15 +97,43 @@ DEV S6 inert_mul(const float *I, S6 v) {
   return f;
 }
 
+// Wave-wide reductions on the DPP network (no LDS crossbar round trips): two quad permutes, half-row mirror and row
+// mirror give every lane its 16-lane row total; row_bcast15 / row_bcast31 chain the four rows into lane 63, whose value
+// is broadcast through an SGPR.  ~8 VALU instructions instead of six dependent ds_bpermute shuffles.  All 64 lanes
+// must be active at the call site.
+#define FS_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 DEV float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x;
+#define FS_STEP(ctrl, rmask) x = FS_DPP(0, __float_as_int(v), ctrl, rmask); v += __int_as_float(x)
+  FS_STEP(0xB1, 0xf);  // quad_perm [1,0,3,2]
+  FS_STEP(0x4E, 0xf);  // quad_perm [2,3,0,1]
+  FS_STEP(0x141, 0xf); // row_half_mirror
+  FS_STEP(0x140, 0xf); // row_mirror
+  FS_STEP(0x142, 0xa); // row_bcast15 -> rows 1, 3
+  FS_STEP(0x143, 0xc); // row_bcast31 -> rows 2, 3
+#undef FS_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 DEV float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  int x;
+#define FS_STEP(ctrl, rmask) x = FS_DPP(__float_as_int(v), __float_as_int(v), ctrl, rmask); v = fmaxf(v, __int_as_float(x))
+  FS_STEP(0xB1, 0xf);
+  FS_STEP(0x4E, 0xf);
+  FS_STEP(0x141, 0xf);
+  FS_STEP(0x140, 0xf);
+  FS_STEP(0x142, 0xa);
+  FS_STEP(0x143, 0xc);
+#undef FS_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 DEV int wave_or(int v) {
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
+#define FS_STEP(ctrl, rmask) v |= FS_DPP(0, v, ctrl, rmask)
+  FS_STEP(0xB1, 0xf);
+  FS_STEP(0x4E, 0xf);
+  FS_STEP(0x141, 0xf);
+  FS_STEP(0x140, 0xf);
+  FS_STEP(0x142, 0xa);
+  FS_STEP(0x143, 0xc);
+#undef FS_STEP
+  return __builtin_amdgcn_readlane(v, 63);
 }

@@ -19,6 +19,9 @@
 enum { LM_ACTIVE = 0, LM_AREF = 1, LM_D = 2, LM_JAR = 3, LM_JP = 4, LM_SIGN = 5, LM_DOF = 6 };
 enum { WD_ACTIVE = 0, WD_P0 = 1, WD_C = 4, WD_AREF = 13, WD_D = 19, WD_JAR = 25, WD_JP = 31, WD_B1 = 37, WD_B2 = 38, WD_X2 = 39 };
 
+// x^p for x in (0, 1): the MuJoCo default solimp power is 2; anything else goes through the hardware exp2/log2
+DEV float fs_pow01(float x, float p) { return p == 2.0f ? x * x : __builtin_exp2f(p * __builtin_log2f(x)); }
+
 DEV float fs_impedance(const float *solref, const float *solimp, float x0, float timestep, float *k, float *b) {
   float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
   float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
@@ -28,8 +31,8 @@ DEV float fs_impedance(const float *solref, const float *solimp, float x0, float
   else {
     float y;
     if (power == 1.0f) y = x;
-    else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
-    else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+    else if (x <= mid) y = fs_pow01(x, power) / (power == 2.0f ? mid : fs_pow01(mid, power - 1));
+    else y = 1 - fs_pow01(1 - x, power) / (power == 2.0f ? 1 - mid : fs_pow01(1 - mid, power - 1));
     imp = dmin + y * (dmax - dmin);
   }
   if (solref[0] > 0) {
@@ -53,6 +56,9 @@ DEV int fs_make_constraints(const Ctx &c) {
   float *L = c.L;
   int nslot = c.I(ly.scal)[SC_NSLOT];
   int coupled = 0, ncon = 0;
+  int *adj = c.I(ly.scal) + SC_ADJ; // tree adjacency bitmasks (islands for the block Cholesky)
+  if (c.lane < m.ntree) adj[c.lane] = 1 << c.lane;
+  SYNC();
   for (int s = c.lane; s < nslot; s += 64) {
     float *r = L + ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
@@ -75,7 +81,10 @@ DEV int fs_make_constraints(const Ctx &c) {
     r[C_AREF] = -b * dot(ldv3(r + C_FRAME), vrel) - k * imp * (dist - incm);
     r[C_AREF + 1] = -b * dot(ldv3(r + C_FRAME + 3), vrel);
     r[C_AREF + 2] = -b * dot(ldv3(r + C_FRAME + 6), vrel);
-    if (b1 != 0 && b2 != 0 && KI(r_tree, b1) != KI(r_tree, b2)) coupled = 1;
+    if (b1 != 0 && b2 != 0) {
+      int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
+      if (t1 != t2) { coupled = 1; atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
+    }
   }
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
@@ -103,6 +112,10 @@ DEV int fs_make_constraints(const Ctx &c) {
     if (!act) continue;
     coupled = 1;
     int b1 = m.eq_rbody1[e], b2 = m.eq_rbody2[e];
+    if (b1 != 0 && b2 != 0) {
+      int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
+      if (t1 != t2) { atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
+    }
     const float *data = L + ly.eqdata + 7 * e;
     M3 R1 = ldm3(L + ly.xmat + 9 * b1);
     V3 p0 = ldv3(L + ly.xpos + 3 * b1) + mulv(R1, ldv3(data));
@@ -136,6 +149,15 @@ DEV int fs_make_constraints(const Ctx &c) {
   int any = wave_or(coupled);
   int tot = (int)wave_sum((float)ncon);
   if (c.lane == 0) c.I(ly.scal)[SC_NCON] = tot;
+  SYNC();
+  if (c.lane < m.ntree) { // transitive closure of the (<= 16 node) tree graph
+    int reach = adj[c.lane], prev;
+    do {
+      prev = reach;
+      for (int tt = prev; tt; tt &= tt - 1) reach |= adj[__ffs(tt) - 1];
+    } while (reach != prev);
+    c.I(ly.scal)[SC_ISL + c.lane] = reach;
+  }
   SYNC();
   return any;
 }
@@ -434,123 +456,88 @@ DEV void fs_hessian(const Ctx &c) {
   SYNC();
 }
 
-// in-place Cholesky of the packed lower triangle, lane = row; p <- -H^-1 grad.  returns false if not SPD.
-DEV float fs_readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-
-// Dense (coupled) case: every lane keeps ITS ROW of the factor in registers; column j's pivot row is broadcast
-// entry by entry with v_readlane (the column loop is fully unrolled, so register indices and lane ids are
-// compile-time constants).  No LDS traffic and no barriers inside the factorisation: ~n^2/2 (readlane + fma) pairs.
-template <int NMAX>
-DEV bool fs_chol_solve_regs(const Ctx &c) {
-  const Layout &ly = c.ly;
-  float *L = c.L;
-  float *H = L + ly.H;
-  const int n = c.m.nv, i = c.lane;
-  const bool row = i < n;
-  const int ri = i * (i + 1) / 2;
-  float Lr[NMAX];
-#pragma unroll
-  for (int k = 0; k < NMAX; k++) Lr[k] = (row && k <= i) ? H[ri + k] : 0.0f;
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < NMAX; j++) {
-    if (j < n) {
-      float s = Lr[j];
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= Lr[k] * fs_readlane(Lr[k], j);
-      float djj = fs_readlane(s, j);
-      if (!(djj > 1e-30f)) { bad = 1; djj = 1e-30f; }
-      float ljj = sqrtf(djj);
-      Lr[j] = (i == j) ? ljj : s / ljj;
-    }
-  }
-  // forward substitution in registers: L y = -grad
-  float b = row ? -L[ly.grad + i] : 0.0f;
-#pragma unroll
-  for (int j = 0; j < NMAX; j++) {
-    if (j < n) {
-      float yj = fs_readlane(b, j) / fs_readlane(Lr[j], j);
-      b = (i == j) ? yj : (i > j ? b - Lr[j] * yj : b);
-    }
-  }
-  // backward substitution needs column access: park the factor rows in LDS and sweep
-#pragma unroll
-  for (int k = 0; k < NMAX; k++) if (row && k <= i) H[ri + k] = Lr[k];
-  SYNC();
-  for (int j = n - 1; j >= 0; j--) {
-    const int rj = j * (j + 1) / 2;
-    float pj = fs_readlane(b, j) / H[rj + j];
-    if (i == j) b = pj;
-    else if (i < j) b -= H[rj + i] * pj;
-  }
-  if (row) L[ly.p + i] = b;
-  SYNC();
-  return !bad;
-}
-
-DEV bool fs_chol_solve(const Ctx &c, int coupled) {
-  if (coupled && c.m.nv <= 48) return fs_chol_solve_regs<48>(c);
-
-  // lane = row.  Uncoupled: H is block diagonal by kinematic tree, and ALL tree blocks are factored
-  // simultaneously (step jj works on column bs0+jj of every block at once; pivots travel by per-lane
-  // shuffles), so the sequential depth is the largest block (9 for Sawyer) instead of nv (39).
-  // Coupled: one block = the whole matrix.
+// Island Cholesky + solve: p <- -H^-1 grad, in place on the packed lower triangle, lane = row.  returns false if not SPD.
+//
+// H is block diagonal over "islands" = sets of kinematic trees joined by an active constraint (computed once per
+// substep by fs_make_constraints: SC_ISL + t = bitmask of the trees in tree t's island).  All islands are factored
+// simultaneously: at step jj every lane works on the jj-th member column of ITS island, pivots travel by per-lane
+// shuffles, so the sequential depth is the largest island (9 dofs for a free Sawyer, 15 when it grips one part)
+// instead of nv (39).  Trees own contiguous dof ranges, so the inner products run over a few contiguous segments.
+// The diagonal is stored as its reciprocal square root (v_rsq) and the substitutions multiply instead of divide.
+DEV bool fs_chol_solve(const Ctx &c, int use_islands) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
   float *H = L + ly.H;
-  int n = m.nv, i = c.lane;
-  bool row = i < n;
-  int t = row ? KI(dof_tree, i) : 0;
-  int bs0 = (row && !coupled) ? KI(tree_dofadr, t) : 0;
-  int bn = row ? (coupled ? n : KI(tree_dofnum, t)) : 0;
-  int steps = (int)wave_max((float)bn);
+  const int n = m.nv, i = c.lane;
+  const bool row = i < n;
+  const int t = row ? KI(dof_tree, i) : 0;
+  const int tm = row ? (use_islands ? c.I(ly.scal)[SC_ISL + t] : (1 << t)) : 0;
+  unsigned long long mask = 0;
+  for (int tt = tm; tt; tt &= tt - 1) {
+    int u = __ffs(tt) - 1;
+    mask |= ((1ull << KI(tree_dofnum, u)) - 1ull) << KI(tree_dofadr, u);
+  }
+  const int steps = (int)wave_max((float)__popcll(mask));
+  const int ri = i * (i + 1) / 2;
   int bad = 0;
-  const int ri = i * (i + 1) / 2; // my row's base in the packed triangle (hoisted: integer multiplies are slow)
+  float mydinv = 0.0f;
+  unsigned long long rem = mask;
   for (int jj = 0; jj < steps; jj++) {
-    int j = bs0 + jj;
-    bool act = row && jj < bn;
+    const bool act = rem != 0;
+    const int j = act ? __ffsll((long long)rem) - 1 : i;
+    rem &= rem - 1;
     const int rj = j * (j + 1) / 2;
     float s = 0;
     if (act && i >= j) {
-      const float *Hi = H + ri + bs0, *Hj = H + rj + bs0;
-      float s0 = H[ri + j], s1 = 0;
-      int k = 0;
-      for (; k + 1 < jj; k += 2) { s0 -= Hi[k] * Hj[k]; s1 -= Hi[k + 1] * Hj[k + 1]; }
-      if (k < jj) s0 -= Hi[k] * Hj[k];
+      const float *Hi = H + ri, *Hj = H + rj;
+      float s0 = Hi[j], s1 = 0;
+      for (int tt = tm; tt; tt &= tt - 1) {
+        int u = __ffs(tt) - 1, k = KI(tree_dofadr, u), e = min(k + KI(tree_dofnum, u), j);
+        // chunks of 6 (a free body's dofs) with clamped addresses: all 12 LDS reads of a chunk are in flight together
+        for (; k < e; k += 6) {
+          float hi[6], hj[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) { int kk = min(k + q, e - 1); hi[q] = Hi[kk]; hj[q] = Hj[kk]; }
+#pragma unroll
+          for (int q = 0; q < 6; q++) { float pr = (k + q < e) ? hi[q] * hj[q] : 0.0f; if (q & 1) s1 -= pr; else s0 -= pr; }
+        }
+        if (e == j) break;
+      }
       s = s0 + s1;
     }
-    float djj = __shfl(s, act ? j : i, 64);
+    float djj = __shfl(s, j, 64);
     if (act && !(djj > 1e-30f)) { bad = 1; djj = 1e-30f; }
-    float ljj = sqrtf(fmaxf(djj, 1e-30f));
+    float rinv = rsqrtf(fmaxf(djj, 1e-30f));
     if (act) {
-      if (i == j) H[rj + j] = ljj;
-      else if (i > j) H[ri + j] = s / ljj;
+      if (i == j) { H[rj + j] = djj * rinv; mydinv = rinv; }
+      else if (i > j) H[ri + j] = s * rinv;
     }
     SYNC();
   }
   // forward: L y = -grad
   float b = row ? -L[ly.grad + i] : 0.0f;
+  rem = mask;
   for (int jj = 0; jj < steps; jj++) {
-    int j = bs0 + jj;
-    bool act = row && jj < bn;
-    float yj = __shfl(b, act ? j : i, 64);
+    const bool act = rem != 0;
+    const int j = act ? __ffsll((long long)rem) - 1 : i;
+    rem &= rem - 1;
+    float yj = __shfl(b * mydinv, j, 64);
     if (act) {
-      yj /= H[j * (j + 1) / 2 + j];
       if (i == j) b = yj;
       else if (i > j) b -= H[ri + j] * yj;
     }
   }
   // backward: L' p = y
-  for (int jj = steps - 1; jj >= 0; jj--) {
-    int j = bs0 + jj;
-    bool act = row && jj < bn;
-    float pj = __shfl(b, act ? j : i, 64);
+  rem = mask;
+  for (int jj = 0; jj < steps; jj++) {
+    const bool act = rem != 0;
+    const int j = act ? 63 - __clzll((long long)rem) : i;
+    if (act) rem &= ~(1ull << j);
+    float pj = __shfl(b * mydinv, j, 64);
     if (act) {
-      const int rj = j * (j + 1) / 2;
-      pj /= H[rj + j];
       if (i == j) b = pj;
-      else if (i < j) b -= H[rj + i] * pj;
+      else if (i < j) b -= H[j * (j + 1) / 2 + i] * pj;
     }
   }
   if (row) L[ly.p + i] = b;
@@ -597,10 +584,7 @@ DEV void fs_solve(const Ctx &c, int coupled) {
   fs_mulM(c, ly.Mx, ly.x);
   fs_body_spatial(c, ly.x);
   fs_jdot(c, ly.x, true);
-  float cw = fs_total_cost(c);
-  SYNC();
   float scale = m.meaninertia_scale;
-  float cost = cw;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
     fs_gradient(c);
@@ -608,17 +592,17 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     FS_SPROF(23);
 #ifdef FSIM_PROFILE
     if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
-    if (!isfinite(cost) && c.lane == 0 && !scal[27]) { scal[27] = 200 + it; scal[28] = scal[21]; }
 #endif
     if (scale * gn < c.newton_tol) break;
     fs_hessian(c);
     FS_SPROF(24);
-    bool ok = fs_chol_solve(c, coupled);
+    bool ok = fs_chol_solve(c, 1);
     FS_SPROF(25);
 #ifdef FSIM_PROFILE
     if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
 #endif
     if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
+    float dphi0 = fs_dotv(c, ly.p, ly.grad); // phi'(0) along the Newton direction (= -g' H^-1 g < 0)
     fs_mulM(c, ly.Mp, ly.p);
     fs_body_spatial(c, ly.p);
     fs_jdot(c, ly.p, false);
@@ -664,12 +648,15 @@ DEV void fs_solve(const Ctx &c, int coupled) {
       if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
     }
     SYNC();
-    // MuJoCo's second stopping rule: scaled cost improvement below tolerance (also catches fp32 stalls, where the
-    // gradient test alone would spin to the iteration cap)
-    float newcost = fs_total_cost(c);
+    // MuJoCo's second stopping rule: scaled cost improvement of the step below tolerance.  The improvement is taken
+    // from the line-search model, phi(0) - phi(alpha) = -1/2 alpha phi'(0) at an exact minimiser of a (piecewise)
+    // quadratic, instead of differencing two O(1e3) costs: in fp32 that difference is noise at the 1e-6 level and
+    // kept robot-contact envs iterating (5.5 iterations/substep where the fp64 oracle needs 2.5).
     FS_SPROF(28);
-    float improvement = scale * (cost - newcost);
-    cost = newcost;
+    float improvement = scale * 0.5f * alpha * fmaxf(-dphi0, 0.0f);
+#ifdef FSIM_PROFILE
+    if (c.lane == 0 && it >= 2 && it < 9) scal[48 + it - 2] = __float_as_int(improvement);
+#endif
     if (improvement < c.newton_tol) { it++; break; }
   }
   if (c.lane == 0) scal[SC_NITER] = it;

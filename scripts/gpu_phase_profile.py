@@ -36,12 +36,13 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     if t in (0, 5):
         med = np.median(fine, axis=0) / 50
         print("    per-substep kcycles (median env): " + " ".join("%s %.1f" % (n, v / 1e3) for n, v in zip(fn, med)) + " | collide %.1f (geom %.1f broad %.1f narrow %.1f) constraints %.1f" % (np.median(cyc[:, 1]) / 50e3, np.median(cfine[:, 0]) / 50e3, np.median(cfine[:, 1]) / 50e3, np.median(cfine[:, 2]) / 50e3, np.median(cyc[:, 3]) / 50e3))
-    if t in (0, 5):
-        tn = ['pl_sph','pl_box','pl_cyl','sph_sph','sph_box','sph_cyl','box_box','cyl_box','cyl_cyl']
-        print('    narrowphase per-type kcyc/substep (median env, sum over lanes): ' + ' '.join('%s %.1f' % (n, v / 50e3) for n, v in zip(tn, np.median(pall[:, 32:41] * 16, axis=0))))
     if t == 5:
         for e in np.argsort(-tot)[:3]:
             print("    SLOW env %d: Mcyc %.1f it/sub %.2f coupled %.2f | per-substep kcyc: " % (e, tot[e] / 1e6, nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e])) + " ".join("%s %.1f" % (n, v / 50e3) for n, v in zip(fn, fine[e])) + " | collide %.1f constraints %.1f" % (cyc[e, 1] / 50e3, cyc[e, 3] / 50e3))
+    if t == 5:
+        for e in np.argsort(-tot)[:6]:
+            seq = pall[e, 32:39].astype(np.int32).view(np.float32)
+            print("    env %d Newton trace: scaled improvement at iterations 2..8 (last substep that got there): " % e + " ".join("%.2e" % r for r in seq))
     if t in (3, 8):
         order = np.argsort(-tot)[:5]
         for e in order:
