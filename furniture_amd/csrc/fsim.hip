@@ -337,9 +337,15 @@ static void build_layout(fsim *s, int ncon_max) {
   if (hstart + nH > o) o = hstart + nH;
   ly.cdof = take(6 * m.nv); ly.M = take(m.nM); ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
   ly.smooth = take(m.nv); ly.asmooth = ly.smooth; ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
-  ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg); ly.surv = take(FSIM_MAXSURV);
+  ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg);
+  {
+    int need = 21 * m.nr + 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
+    ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * m.nr;
+    if (need > 12 * m.ncg) take(need - 12 * m.ncg);
+  }
+  ly.surv = take(FSIM_MAXSURV);
   ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(SC_WORDS);
+  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(SC_WORDS); ly.hmap = take(3 * m.nv);
   // LDS model cache
   {
     std::vector<int> ca, cl;
@@ -353,7 +359,7 @@ static void build_layout(fsim *s, int ncon_max) {
     ly.k_tree_dofadr = take(m.ntree); ly.k_tree_dofnum = take(m.ntree); ly.k_tree_bodyadr = take(m.ntree); ly.k_tree_bodynum = take(m.ntree);
     ly.k_M_i = take(m.nM); ly.k_M_j = take(m.nM);
     ly.k_r_pos = take(3 * m.nr); ly.k_r_quat = take(4 * m.nr); ly.k_r_jpos = take(3 * m.nr); ly.k_r_jaxis = take(3 * m.nr); ly.k_r_ipos = take(3 * m.nr);
-    ly.k_r_mass = take(m.nr); ly.k_r_inertia = take(6 * m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv);
+    ly.k_r_mass = take(m.nr); ly.k_r_inertia = take(6 * m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv); ly.k_tmap = take(3 * m.nv);
     ly.k_end = o;
   }
   ly.lds_words = o;

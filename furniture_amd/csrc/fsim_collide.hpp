@@ -10,7 +10,7 @@
 
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_DIST = 13, C_INCM = 14, C_MU = 15, C_DIM = 16, C_B1 = 17, C_B2 = 18, C_G1 = 19,
        C_G2 = 20, C_AREF = 21, C_DN = 24, C_DT = 25, C_JAR = 26, C_JP = 29 };
-enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8, SC_ADJ = 64, SC_ISL = 80, SC_WORDS = 96 };
+enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8, SC_HWORDS = 160, SC_TWORDS = 161, SC_ADJ = 64, SC_ISL = 80, SC_TMP = 96, SC_PADJ = 144, SC_WORDS = 164 }; // 9..14 are scratch of the env logic (fsim_env.hpp), 16..63 profile counters
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
 

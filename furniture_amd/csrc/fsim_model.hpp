@@ -68,9 +68,11 @@ struct Layout {
   int cdof, M, LD, Dinv, LDh, Dhinv;
   int smooth, asmooth, x, Mx, grad, p, Mp;
   int gpos, gmat, surv, con, weld, lim, W, G, scal;
+  int hmap;   // [3][nv] per-substep island map of the Newton system: row base | (local idx, island size, first lane) | lane -> dof
+  int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int lds_words, ncon_max;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
-  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_i, k_M_j, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature;
+  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_i, k_M_j, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
   int k_begin, k_end;
 };
 

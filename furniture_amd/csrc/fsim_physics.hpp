@@ -57,67 +57,81 @@ DEV void fs_load_cache(const Ctx &c) {
   CPF(r_inertia, 6 * nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
 #undef CPI
 #undef CPF
+  // static "tree map" of a block-diagonal-by-tree system (M + h*D in fs_integrate): same format as the per-substep
+  // island map (Layout::hmap), see fs_hidx / fs_chol_solve
+  for (int i = c.lane; i < nv; i += 64) {
+    int t = m.dof_tree[i], adr = m.tree_dofadr[t], num = m.tree_dofnum[t], l = i - adr, base = 0;
+    for (int u = 0; u < t; u++) base += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    c.I(c.ly.k_tmap)[i] = base + l * (l + 1) / 2;
+    c.I(c.ly.k_tmap)[nv + i] = l | (num << 8) | (adr << 16);
+    c.I(c.ly.k_tmap)[2 * nv + i] = i;
+  }
+  if (c.lane == 0) {
+    int w = 0;
+    for (int u = 0; u < m.ntree; u++) w += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    c.I(c.ly.scal)[161] = w; // SC_TWORDS (fsim_collide.hpp): packed size of the tree-block system
+  }
   SYNC();
 }
 
 // ------------------------------------------------------------------------------------------ P1
 DEV void fs_kinematics(const Ctx &c) {
-  // One lane per kinematic tree walks its bodies parent-before-child (no per-level barriers: the 8-deep Sawyer chain
-  // costs 8 dependent body updates in ONE lane instead of 8 workgroup-wide rounds); the pose of the body just
-  // computed stays in registers because it is the parent of the next one along a chain.
+  // Three passes.  (A) lane = body: joint transform relative to the parent frame (trig, quaternion products) -- parallel;
+  // (B) lane = tree: compose parent * local down the chain with the parent pose held in registers -- the only serial
+  // part, ~40 instructions per body for the 8-deep Sawyer chain; (C) lane = body: rotation matrix, joint anchor / axis
+  // and inertial-frame origin in world coordinates -- parallel.
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
-  if (c.lane == 63) {
-    stv3(L + ly.xpos, v3(0, 0, 0));
-    stq(L + ly.xquat, q4(1, 0, 0, 0));
-    M3 I = q2m(q4(1, 0, 0, 0));
-    stm3(L + ly.xmat, I);
+  for (int b = c.lane; b < m.nr; b += 64) {
+    if (b == 0) { stv3(L + ly.xpos, v3(0, 0, 0)); stq(L + ly.xquat, q4(1, 0, 0, 0)); continue; }
+    int jt = KI(r_jtype, b), qa = KI(r_qposadr, b);
+    V3 pl, al, axl = v3(0, 0, 1);
+    Q4 ql;
+    if (jt == JT_FREE) {
+      const float *q = L + ly.qpos + qa;
+      pl = ldv3(q);
+      ql = qnormalized(ldq(q + 3));
+      stq(L + ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
+      al = pl;
+    } else {
+      Q4 q0 = ldq(KFP(r_quat) + 4 * b);
+      V3 p0 = ldv3(KFP(r_pos) + 3 * b), jpos = ldv3(KFP(r_jpos) + 3 * b), jax = ldv3(KFP(r_jaxis) + 3 * b);
+      al = p0 + qrot(q0, jpos);
+      axl = qrot(q0, jax);
+      float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
+      if (jt == JT_SLIDE) { ql = q0; pl = p0 + axl * q; }
+      else { ql = qmul(q0, axisangle(jax, q)); pl = al - qrot(ql, jpos); }
+    }
+    stv3(L + ly.xpos + 3 * b, pl); stq(L + ly.xquat + 4 * b, ql);
+    stv3(L + ly.xanchor + 3 * b, al); stv3(L + ly.xaxis + 3 * b, axl);
   }
+  SYNC();
   for (int t = c.lane; t < m.ntree; t += 64) {
     int b0 = KI(tree_bodyadr, t), nbod = KI(tree_bodynum, t);
-    int pid = -1;
+    int pid = 0;
     V3 ppos = v3(0, 0, 0);
     Q4 pquat = q4(1, 0, 0, 0);
-    M3 pR = q2m(pquat);
     for (int b = b0; b < b0 + nbod; b++) {
-      int p = KI(r_parent, b), jt = KI(r_jtype, b), qa = KI(r_qposadr, b);
-      V3 pos;
-      Q4 quat;
-      V3 anchor, axis = v3(0, 0, 1);
-      if (jt == JT_FREE) {
-        const float *q = L + ly.qpos + qa;
-        pos = ldv3(q);
-        quat = qnormalized(ldq(q + 3));
-        stq(L + ly.qpos + qa + 3, quat); // MuJoCo normalises the stored quaternion in place
-        anchor = pos;
-      } else {
-        if (p != pid) {
-          if (p == 0) { ppos = v3(0, 0, 0); pquat = q4(1, 0, 0, 0); pR = q2m(pquat); }
-          else { ppos = ldv3(L + ly.xpos + 3 * p); pquat = ldq(L + ly.xquat + 4 * p); pR = ldm3(L + ly.xmat + 9 * p); }
-        }
-        pos = ppos + mulv(pR, ldv3(KFP(r_pos) + 3 * b));
-        quat = qmul(pquat, ldq(KFP(r_quat) + 4 * b));
-        M3 R = q2m(quat);
-        V3 jpos = ldv3(KFP(r_jpos) + 3 * b), jax = ldv3(KFP(r_jaxis) + 3 * b);
-        anchor = pos + mulv(R, jpos);
-        axis = mulv(R, jax);
-        float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
-        if (jt == JT_SLIDE) pos = pos + axis * q;
-        else {
-          quat = qmul(quat, axisangle(jax, q));
-          pos = anchor - mulv(q2m(quat), jpos);
-        }
-        quat = qnormalized(quat);
-      }
-      M3 R = q2m(quat);
-      stv3(L + ly.xpos + 3 * b, pos);
-      stq(L + ly.xquat + 4 * b, quat);
-      stm3(L + ly.xmat + 9 * b, R);
-      stv3(L + ly.xanchor + 3 * b, anchor);
-      stv3(L + ly.xaxis + 3 * b, axis);
-      stv3(L + ly.xipos + 3 * b, pos + mulv(R, ldv3(KFP(r_ipos) + 3 * b)));
-      pid = b; ppos = pos; pquat = quat; pR = R;
+      int p = KI(r_parent, b);
+      if (p != pid) { ppos = ldv3(L + ly.xpos + 3 * p); pquat = ldq(L + ly.xquat + 4 * p); pid = p; } // branch: parent already final
+      V3 pos = ppos + qrot(pquat, ldv3(L + ly.xpos + 3 * b));
+      Q4 quat = qnormalized(qmul(pquat, ldq(L + ly.xquat + 4 * b)));
+      stv3(L + ly.xpos + 3 * b, pos); stq(L + ly.xquat + 4 * b, quat);
+      pid = b; ppos = pos; pquat = quat;
+    }
+  }
+  SYNC();
+  for (int b = c.lane; b < m.nr; b += 64) {
+    M3 R = q2m(ldq(L + ly.xquat + 4 * b));
+    stm3(L + ly.xmat + 9 * b, R);
+    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(KFP(r_ipos) + 3 * b)));
+    if (b > 0) { // joint anchor / axis were left in the parent frame by pass A
+      int p = KI(r_parent, b);
+      V3 pp = ldv3(L + ly.xpos + 3 * p);
+      Q4 pq = ldq(L + ly.xquat + 4 * p);
+      stv3(L + ly.xanchor + 3 * b, pp + qrot(pq, ldv3(L + ly.xanchor + 3 * b)));
+      stv3(L + ly.xaxis + 3 * b, qrot(pq, ldv3(L + ly.xaxis + 3 * b)));
     }
   }
   SYNC();

@@ -150,13 +150,55 @@ DEV int fs_make_constraints(const Ctx &c) {
   int tot = (int)wave_sum((float)ncon);
   if (c.lane == 0) c.I(ly.scal)[SC_NCON] = tot;
   SYNC();
+  int *scal_ = c.I(ly.scal);
+  // the island structure rarely changes between substeps: keep last substep's closure + map when the adjacency is the same
+  bool changed = c.lane < m.ntree && adj[c.lane] != scal_[SC_PADJ + c.lane];
+  if (!__ballot(changed)) return any;
+  if (c.lane < m.ntree) scal_[SC_PADJ + c.lane] = adj[c.lane];
   if (c.lane < m.ntree) { // transitive closure of the (<= 16 node) tree graph
     int reach = adj[c.lane], prev;
     do {
       prev = reach;
       for (int tt = prev; tt; tt &= tt - 1) reach |= adj[__ffs(tt) - 1];
     } while (reach != prev);
-    c.I(ly.scal)[SC_ISL + c.lane] = reach;
+    scal_[SC_ISL + c.lane] = reach;
+  }
+  SYNC();
+  // Island map of the Newton system (Layout::hmap): islands ordered by their lowest tree, trees ascending inside an
+  // island => every island owns a contiguous range of "solver lanes" and a dense packed lower triangle in H.
+  const int *isl = scal_ + SC_ISL;
+  int *tmp = scal_ + SC_TMP; // [0..16) first lane of tree, [16..32) island size, [32..48) island H base
+  if (c.lane < m.ntree) {
+    int t = c.lane, my = isl[t], rep = __ffs(my) - 1, lanebase = 0, nI = 0;
+    for (int u = 0; u < m.ntree; u++) {
+      int ru = __ffs(isl[u]) - 1, nu = KI(tree_dofnum, u);
+      if (ru < rep || (ru == rep && u < t)) lanebase += nu;
+      if ((my >> u) & 1) nI += nu;
+    }
+    tmp[t] = lanebase; tmp[16 + t] = nI;
+  }
+  SYNC();
+  if (c.lane < m.ntree) {
+    int t = c.lane, rep = __ffs(isl[t]) - 1, hb = 0, tot = 0;
+    for (int u = 0; u < m.ntree; u++) {
+      if (__ffs(isl[u]) - 1 != u) continue; // u is not an island representative
+      int n = tmp[16 + u], w = n * (n + 1) / 2;
+      if (u < rep) hb += w;
+      tot += w;
+    }
+    tmp[32 + t] = hb;
+    if (t == 0) scal_[SC_HWORDS] = tot;
+  }
+  SYNC();
+  {
+    int *hm = c.I(ly.hmap);
+    for (int i = c.lane; i < m.nv; i += 64) {
+      int t = KI(dof_tree, i), rep = __ffs(isl[t]) - 1, ib = tmp[rep];
+      int l = tmp[t] - ib + i - KI(tree_dofadr, t);
+      hm[i] = tmp[32 + t] + l * (l + 1) / 2;
+      hm[m.nv + i] = l | (tmp[16 + t] << 8) | (ib << 16);
+      hm[2 * m.nv + ib + l] = i;
+    }
   }
   SYNC();
   return any;
@@ -346,6 +388,8 @@ DEV void fs_gradient(const Ctx &c) {
 }
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
+// packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
+DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return A[i] + (A[c.m.nv + j] & 255); }
 
 // column of J for chain entry: value of row-space functional on dof d.  For a contact the three rows are
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
@@ -354,75 +398,156 @@ DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
   return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(dof_tree, d)));
 }
 
+#define FSIM_NPAIR 8 // body-pair cross blocks assembled per pass
+
+// H = M + J' W J assembled at BODY level, like a composite-rigid-body pass with "stiffness inertias":
+//   a contact point on body b with world-frame stiffness K (3x3, = frame' * cone Hessian * frame) acts on the dofs of
+//   chain(b) through P = [-[r]x, I] (r = point - tree com), so it adds the 6x6 symmetric block A_b += P' K P;
+//   summing A over each subtree (A^c) gives  H[i][j] += cdof_i' A^c_body(i) cdof_j  on exactly M's sparsity pattern;
+//   a contact between two moving bodies (lo, hi) additionally adds -cdof_d1' X cdof_d2, X = P_lo' K P_hi, on
+//   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
+//   collapse into 5 blocks) and every projection runs with one lane per output entry.
 DEV void fs_hessian(const Ctx &c) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
-  int nH = m.nv * (m.nv + 1) / 2;
+  const int nH = c.I(ly.scal)[SC_HWORDS]; // packed island triangles
+  const int hm = ly.hmap;
+  float *A = L + ly.hA;                    // [nr][21]: aa(xx,xy,xz,yy,yz,zz) al(9, row = ang comp) ll(xx,xy,xz,yy,yz,zz)
+  float *X = L + ly.hP;                    // [NPAIR][36] cross blocks, row = lo's spatial comp, col = hi's
+  int *pmeta = c.I(ly.hP + 36 * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
   for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
+  for (int i = c.lane; i < 21 * m.nr; i += 64) A[i] = 0;
   SYNC();
-  for (int e = c.lane; e < m.nM; e += 64) L[ly.H + fs_tri(KI(M_i, e), KI(M_j, e))] = L[ly.M + e];
-  SYNC();
-  // Contacts: work items = (slot, chain entry e1); an item owns row d1 of the slot's J'WJ block and walks the chain for
-  // the columns.  Items are enumerated with a wave scan over the slots' chain lengths, so 20 part-floor contacts give
-  // 120 busy lanes instead of 20 lanes each running a 6x6 double loop (and a robot contact 15 lanes instead of one).
-  int nslot = c.I(ly.scal)[SC_NSLOT]; // <= 64 (fsim_create enforces ncon_max <= 64)
-  int *ibase = c.I(ly.surv), *icnt = c.I(ly.surv) + 64;
-  {
-    int s_ = c.lane, cnt = 0;
-    if (s_ < nslot) {
-      const float *r = L + ly.con + FSIM_CONW * s_;
-      const int *ri = reinterpret_cast<const int *>(r);
-      if (ri[C_ACTIVE] == 1) {
-        bool on;
-        if (ri[C_DIM] == 1) on = r[C_JAR] < 0;
-        else { float f_[3], cc_; on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f_, &cc_, nullptr) != 0; }
-        if (on) { int b1 = ri[C_B1], b2 = ri[C_B2]; cnt = (b2 ? KI(r_chainlen, b2) : 0) + (b1 ? KI(r_chainlen, b1) : 0); }
+  // ---- contacts: lane = slot (ncon_max <= 64)
+  const int nslot = c.I(ly.scal)[SC_NSLOT];
+  bool on = false;
+  int blo = 0, bhi = 0;
+  float K[6] = {0, 0, 0, 0, 0, 0};
+  V3 pos = v3(0, 0, 0);
+  if (c.lane < nslot) {
+    const float *r = L + ly.con + FSIM_CONW * c.lane;
+    const int *ri = reinterpret_cast<const int *>(r);
+    if (ri[C_ACTIVE] == 1) {
+      float Hc[9];
+      if (ri[C_DIM] == 1) { on = r[C_JAR] < 0; for (int q = 0; q < 9; q++) Hc[q] = 0; Hc[0] = r[C_DN]; }
+      else { float f_[3], cc_; on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f_, &cc_, Hc) != 0; }
+      if (on) {
+        V3 f0 = ldv3(r + C_FRAME), f1 = ldv3(r + C_FRAME + 3), f2 = ldv3(r + C_FRAME + 6);
+        V3 w0 = f0 * Hc[0] + f1 * Hc[1] + f2 * Hc[2], w1 = f0 * Hc[3] + f1 * Hc[4] + f2 * Hc[5], w2 = f0 * Hc[6] + f1 * Hc[7] + f2 * Hc[8];
+        K[0] = f0.x * w0.x + f1.x * w1.x + f2.x * w2.x; K[1] = f0.x * w0.y + f1.x * w1.y + f2.x * w2.y; K[2] = f0.x * w0.z + f1.x * w1.z + f2.x * w2.z;
+        K[3] = f0.y * w0.y + f1.y * w1.y + f2.y * w2.y; K[4] = f0.y * w0.z + f1.y * w1.z + f2.y * w2.z; K[5] = f0.z * w0.z + f1.z * w1.z + f2.z * w2.z;
+        pos = ldv3(r + C_POS);
+        int b1 = ri[C_B1], b2 = ri[C_B2];
+        blo = min(b1, b2); bhi = max(b1, b2);
       }
     }
-    int incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (c.lane >= o) incl += v; }
-    ibase[c.lane] = incl - cnt;
-    icnt[c.lane] = cnt;
-    int total = __shfl(incl, 63, 64);
+  }
+  // rows of K, G = [r]x K (ang-lin block), and the diagonal blocks
+  const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
+  V3 Glo0 = v3(0, 0, 0), Glo1 = Glo0, Glo2 = Glo0, rhi = Glo0;
+  if (on) {
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      int b = side ? bhi : blo;
+      if (b == 0) continue;
+      V3 rr = pos - ldv3(L + ly.com + 3 * KI(r_tree, b));
+      // G[:, c] = rr x K[:, c]  (K symmetric: column c = row c); stored by rows G_a = (G[a][0], G[a][1], G[a][2])
+      V3 c0 = cross(rr, K0), c1 = cross(rr, K1), c2 = cross(rr, K2);
+      V3 G0 = v3(c0.x, c1.x, c2.x), G1 = v3(c0.y, c1.y, c2.y), G2 = v3(c0.z, c1.z, c2.z);
+      // A_aa rows = rr x G_a   (= [r]x K [r]x')
+      V3 a0 = cross(rr, G0), a1 = cross(rr, G1), a2 = cross(rr, G2);
+      float *Ab = A + 21 * b;
+      atomicAdd(Ab + 0, a0.x); atomicAdd(Ab + 1, a0.y); atomicAdd(Ab + 2, a0.z); atomicAdd(Ab + 3, a1.y); atomicAdd(Ab + 4, a1.z); atomicAdd(Ab + 5, a2.z);
+      atomicAdd(Ab + 6, G0.x); atomicAdd(Ab + 7, G0.y); atomicAdd(Ab + 8, G0.z); atomicAdd(Ab + 9, G1.x); atomicAdd(Ab + 10, G1.y); atomicAdd(Ab + 11, G1.z);
+      atomicAdd(Ab + 12, G2.x); atomicAdd(Ab + 13, G2.y); atomicAdd(Ab + 14, G2.z);
+      atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]);
+      if (side == 0) { Glo0 = G0; Glo1 = G1; Glo2 = G2; } else rhi = rr;
+    }
+  }
+  SYNC();
+  // ---- composite blocks: children are numbered after their parents
+  for (int b = m.nr - 1; b >= 1; b--) {
+    int p = KI(r_parent, b);
+    if (p > 0 && c.lane < 21) A[21 * p + c.lane] += A[21 * b + c.lane];
+    if (p > 0) SYNC();
+  }
+  // ---- tree blocks on M's pattern: lane = M entry
+  for (int e = c.lane; e < m.nM; e += 64) {
+    int i = KI(M_i, e), j = KI(M_j, e);
+    const float *Ab = A + 21 * KI(dof_rbody, i);
+    S6 si = lds6(L + ly.cdof + 6 * i), sj = lds6(L + ly.cdof + 6 * j);
+    // t = A * sj
+    V3 ta = v3(Ab[0] * sj.a.x + Ab[1] * sj.a.y + Ab[2] * sj.a.z + Ab[6] * sj.l.x + Ab[7] * sj.l.y + Ab[8] * sj.l.z,
+               Ab[1] * sj.a.x + Ab[3] * sj.a.y + Ab[4] * sj.a.z + Ab[9] * sj.l.x + Ab[10] * sj.l.y + Ab[11] * sj.l.z,
+               Ab[2] * sj.a.x + Ab[4] * sj.a.y + Ab[5] * sj.a.z + Ab[12] * sj.l.x + Ab[13] * sj.l.y + Ab[14] * sj.l.z);
+    V3 tl = v3(Ab[6] * sj.a.x + Ab[9] * sj.a.y + Ab[12] * sj.a.z + Ab[15] * sj.l.x + Ab[16] * sj.l.y + Ab[17] * sj.l.z,
+               Ab[7] * sj.a.x + Ab[10] * sj.a.y + Ab[13] * sj.a.z + Ab[16] * sj.l.x + Ab[18] * sj.l.y + Ab[19] * sj.l.z,
+               Ab[8] * sj.a.x + Ab[11] * sj.a.y + Ab[14] * sj.a.z + Ab[17] * sj.l.x + Ab[19] * sj.l.y + Ab[20] * sj.l.z);
+    L[ly.H + fs_hidx(c, hm, i, j)] = L[ly.M + e] + dot(si.a, ta) + dot(si.l, tl);
+  }
+  SYNC();
+  // ---- body-pair cross blocks, FSIM_NPAIR distinct pairs per pass
+  bool haskey = on && blo != 0 && bhi != blo;
+  const int key = blo * 256 + bhi;
+  unsigned long long pending = __ballot(haskey);
+  while (pending) {
+    int pid = -1, np = 0, total = 0;
+    if (c.lane == 0) pmeta[2 * FSIM_NPAIR] = 0;
+    while (pending && np < FSIM_NPAIR) {
+      int leader = __ffsll((long long)pending) - 1;
+      int k = __builtin_amdgcn_readlane(key, leader);
+      bool mt = haskey && key == k;
+      if (mt) pid = np;
+      int lo = k >> 8, hi = k & 255;
+      total += KI(r_chainlen, lo) * KI(r_chainlen, hi);
+      if (c.lane == 0) { pmeta[np] = lo; pmeta[FSIM_NPAIR + np] = hi; pmeta[2 * FSIM_NPAIR + np + 1] = total; }
+      pending &= ~__ballot(mt);
+      np++;
+    }
+    for (int i = c.lane; i < 36 * np; i += 64) X[i] = 0;
+    SYNC();
+    if (pid >= 0) {
+      // X = [[Glo * Rhi, Glo], [K * Rhi, K]],  v' * Rhi = v' * (-[rhi]x) = (rhi x v)'  row-wise
+      float *Xp = X + 36 * pid;
+      V3 x0 = cross(rhi, Glo0), x1 = cross(rhi, Glo1), x2 = cross(rhi, Glo2), y0 = cross(rhi, K0), y1 = cross(rhi, K1), y2 = cross(rhi, K2);
+      atomicAdd(Xp + 0, x0.x); atomicAdd(Xp + 1, x0.y); atomicAdd(Xp + 2, x0.z); atomicAdd(Xp + 3, Glo0.x); atomicAdd(Xp + 4, Glo0.y); atomicAdd(Xp + 5, Glo0.z);
+      atomicAdd(Xp + 6, x1.x); atomicAdd(Xp + 7, x1.y); atomicAdd(Xp + 8, x1.z); atomicAdd(Xp + 9, Glo1.x); atomicAdd(Xp + 10, Glo1.y); atomicAdd(Xp + 11, Glo1.z);
+      atomicAdd(Xp + 12, x2.x); atomicAdd(Xp + 13, x2.y); atomicAdd(Xp + 14, x2.z); atomicAdd(Xp + 15, Glo2.x); atomicAdd(Xp + 16, Glo2.y); atomicAdd(Xp + 17, Glo2.z);
+      atomicAdd(Xp + 18, y0.x); atomicAdd(Xp + 19, y0.y); atomicAdd(Xp + 20, y0.z); atomicAdd(Xp + 21, K0.x); atomicAdd(Xp + 22, K0.y); atomicAdd(Xp + 23, K0.z);
+      atomicAdd(Xp + 24, y1.x); atomicAdd(Xp + 25, y1.y); atomicAdd(Xp + 26, y1.z); atomicAdd(Xp + 27, K1.x); atomicAdd(Xp + 28, K1.y); atomicAdd(Xp + 29, K1.z);
+      atomicAdd(Xp + 30, y2.x); atomicAdd(Xp + 31, y2.y); atomicAdd(Xp + 32, y2.z); atomicAdd(Xp + 33, K2.x); atomicAdd(Xp + 34, K2.y); atomicAdd(Xp + 35, K2.z);
+      haskey = false;
+    }
     SYNC();
     for (int it = c.lane; it < total; it += 64) {
-      int lo = 0, hi = 63; // last slot with base <= it and cnt > 0 : binary search on the (non-decreasing) bases
-      while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ibase[mid] <= it) lo = mid; else hi = mid - 1; }
-      while (icnt[lo] == 0 && lo > 0) lo--; // skip empty slots that share the same base
-      int s2 = lo, e1 = it - ibase[s2];
-      float *r = L + ly.con + FSIM_CONW * s2;
-      int *ri = reinterpret_cast<int *>(r);
-      float f[3], Hc[9], cc;
-      if (ri[C_DIM] == 1) { for (int q = 0; q < 9; q++) Hc[q] = 0; Hc[0] = r[C_DN]; }
-      else fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc);
-      V3 pos = ldv3(r + C_POS);
-      V3 fr0 = ldv3(r + C_FRAME), fr1 = ldv3(r + C_FRAME + 3), fr2 = ldv3(r + C_FRAME + 6);
-      int b1 = ri[C_B1], b2 = ri[C_B2];
-      int n2 = b2 ? KI(r_chainlen, b2) : 0, n1 = b1 ? KI(r_chainlen, b1) : 0;
-      int a2 = b2 ? KI(r_chainadr, b2) : 0, a1 = b1 ? KI(r_chainadr, b1) : 0;
-      int d1 = e1 < n2 ? KI(chain_dofs, a2 + e1) : KI(chain_dofs, a1 + e1 - n2);
-      float sg1 = e1 < n2 ? 1.0f : -1.0f;
-      V3 c1 = fs_col(c, d1, pos);
-      float j1[3] = {sg1 * dot(fr0, c1), sg1 * dot(fr1, c1), sg1 * dot(fr2, c1)};
-      // w = Hc * j1, pre-contracted with the frame: v(d2) = sg2 * (wv . col(d2))
-      float w0 = Hc[0] * j1[0] + Hc[3] * j1[1] + Hc[6] * j1[2], w1 = Hc[1] * j1[0] + Hc[4] * j1[1] + Hc[7] * j1[2],
-            w2 = Hc[2] * j1[0] + Hc[5] * j1[1] + Hc[8] * j1[2];
-      V3 wv = fr0 * w0 + fr1 * w1 + fr2 * w2;
-      const int rowb = d1 * (d1 + 1) / 2;
-      for (int e2 = 0; e2 < n1 + n2; e2++) {
-        int d2 = e2 < n2 ? KI(chain_dofs, a2 + e2) : KI(chain_dofs, a1 + e2 - n2);
-        if (d2 > d1) continue;
-        float sg2 = e2 < n2 ? 1.0f : -1.0f;
-        atomicAdd(L + ly.H + rowb + d2, sg2 * dot(wv, fs_col(c, d2, pos)));
+      int q = 0;
+      while (q + 1 < np && it >= pmeta[2 * FSIM_NPAIR + q + 1]) q++;
+      int rem = it - pmeta[2 * FSIM_NPAIR + q];
+      int lo = pmeta[q], hi = pmeta[FSIM_NPAIR + q];
+      int nhi = KI(r_chainlen, hi);
+      int e1 = (int)(((float)rem + 0.5f) / (float)nhi), e2 = rem - e1 * nhi;
+      int d1 = KI(chain_dofs, KI(r_chainadr, lo) + e1), d2 = KI(chain_dofs, KI(r_chainadr, hi) + e2);
+      const float *Xp = X + 36 * q;
+      const float *s1 = L + ly.cdof + 6 * d1, *s2 = L + ly.cdof + 6 * d2;
+      float v = 0;
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+        float t = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) t += Xp[6 * rr + cc] * s2[cc];
+        v += s1[rr] * t;
       }
+      if (d1 == d2) v *= 2.0f;
+      atomicAdd(L + ly.H + fs_hidx(c, hm, max(d1, d2), min(d1, d2)), -v);
     }
+    SYNC();
   }
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
-    atomicAdd(L + ly.H + fs_tri(ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
+    atomicAdd(L + ly.H + fs_hidx(c, hm, ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
   }
   for (int e = c.lane; e < m.neq; e += 64) {
     float *r = L + ly.weld + FSIM_WELDW * e;
@@ -449,100 +574,93 @@ DEV void fs_hessian(const Ctx &c) {
         V3 w2 = lds6(L + ly.cdof + 6 * d2).a * sg2;
         float v = j1[0] * t2.x + j1[1] * t2.y + j1[2] * t2.z;
         for (int q = 0; q < 3; q++) v += j1[3 + q] * (r[WD_C + 3 * q] * w2.x + r[WD_C + 3 * q + 1] * w2.y + r[WD_C + 3 * q + 2] * w2.z);
-        atomicAdd(L + ly.H + fs_tri(d1, d2), v);
+        atomicAdd(L + ly.H + fs_hidx(c, hm, d1, d2), v);
       }
     }
   }
   SYNC();
 }
 
-// Island Cholesky + solve: p <- -H^-1 grad, in place on the packed lower triangle, lane = row.  returns false if not SPD.
+// Island Cholesky + solve: p <- -H^-1 grad.  returns false if not SPD.
 //
-// H is block diagonal over "islands" = sets of kinematic trees joined by an active constraint (computed once per
-// substep by fs_make_constraints: SC_ISL + t = bitmask of the trees in tree t's island).  All islands are factored
-// simultaneously: at step jj every lane works on the jj-th member column of ITS island, pivots travel by per-lane
-// shuffles, so the sequential depth is the largest island (9 dofs for a free Sawyer, 15 when it grips one part)
-// instead of nv (39).  Trees own contiguous dof ranges, so the inner products run over a few contiguous segments.
-// The diagonal is stored as its reciprocal square root (v_rsq) and the substitutions multiply instead of divide.
-DEV bool fs_chol_solve(const Ctx &c, int use_islands) {
-  const DModel &m = c.m;
+// H is block diagonal over "islands" (sets of kinematic trees joined by an active constraint; a lone tree is its own
+// island).  The map at `mp` (fs_make_constraints for the Newton system, fs_load_cache for the per-tree M + hD system)
+// gives every island a contiguous range of solver lanes and a dense packed lower triangle in LDS.  Solver lane
+// = one row.  The factor lives in REGISTERS (row l of an island in Lr[0..l]); the factorisation is right-looking:
+// at step jj every island scales its column jj and applies the rank-1 update of its trailing rows, the column
+// travelling between lanes with ds_bpermute (source lane = island base + k).  All islands advance together, so the
+// sequential depth is the largest island (9 for a free Sawyer, 15 when it grips one part), and a step costs
+// 2 * (island size - jj) instructions with no LDS round trip in the dependency chain.  Only the back substitution
+// reads the factor by columns, from a copy written once to LDS.
+template <int NLOC>
+DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   const Layout &ly = c.ly;
   float *L = c.L;
   float *H = L + ly.H;
-  const int n = m.nv, i = c.lane;
-  const bool row = i < n;
-  const int t = row ? KI(dof_tree, i) : 0;
-  const int tm = row ? (use_islands ? c.I(ly.scal)[SC_ISL + t] : (1 << t)) : 0;
-  unsigned long long mask = 0;
-  for (int tt = tm; tt; tt &= tt - 1) {
-    int u = __ffs(tt) - 1;
-    mask |= ((1ull << KI(tree_dofnum, u)) - 1ull) << KI(tree_dofadr, u);
-  }
-  const int steps = (int)wave_max((float)__popcll(mask));
-  const int ri = i * (i + 1) / 2;
+  const int nv = c.m.nv;
+  const bool row = c.lane < nv;
+  const int i = row ? c.I(mp)[2 * nv + c.lane] : 0;
+  const int B = row ? c.I(mp)[nv + i] : 0;
+  const int l = B & 255, nI = row ? (B >> 8) & 255 : 0, ib = B >> 16;
+  const int rowb = c.I(mp)[i];
+  float Lr[NLOC];
+#pragma unroll
+  for (int k = 0; k < NLOC; k++) Lr[k] = (row && k <= l) ? H[rowb + k] : 0.0f;
   int bad = 0;
   float mydinv = 0.0f;
-  unsigned long long rem = mask;
-  for (int jj = 0; jj < steps; jj++) {
-    const bool act = rem != 0;
-    const int j = act ? __ffsll((long long)rem) - 1 : i;
-    rem &= rem - 1;
-    const int rj = j * (j + 1) / 2;
-    float s = 0;
-    if (act && i >= j) {
-      const float *Hi = H + ri, *Hj = H + rj;
-      float s0 = Hi[j], s1 = 0;
-      for (int tt = tm; tt; tt &= tt - 1) {
-        int u = __ffs(tt) - 1, k = KI(tree_dofadr, u), e = min(k + KI(tree_dofnum, u), j);
-        // chunks of 6 (a free body's dofs) with clamped addresses: all 12 LDS reads of a chunk are in flight together
-        for (; k < e; k += 6) {
-          float hi[6], hj[6];
 #pragma unroll
-          for (int q = 0; q < 6; q++) { int kk = min(k + q, e - 1); hi[q] = Hi[kk]; hj[q] = Hj[kk]; }
+  for (int jj = 0; jj < NLOC; jj++) {
+    if (jj < steps) {
+      const bool act = jj < nI;
+      float d = __shfl(Lr[jj], ib + jj, 64);
+      if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+      float rinv = act ? rsqrtf(d) : 0.0f;
+      float lij = (l >= jj) ? Lr[jj] * rinv : 0.0f; // column jj of the factor: this lane holds L[l][jj]
+      Lr[jj] = lij;
+      if (l == jj) mydinv = rinv;
 #pragma unroll
-          for (int q = 0; q < 6; q++) { float pr = (k + q < e) ? hi[q] * hj[q] : 0.0f; if (q & 1) s1 -= pr; else s0 -= pr; }
-        }
-        if (e == j) break;
+      for (int k = jj + 1; k < NLOC; k++) {
+        if ((k & 7) == ((jj + 1) & 7) && k >= steps) break; // uniform early-out, checked every 8 columns
+        Lr[k] -= lij * __shfl(lij, ib + k, 64);
       }
-      s = s0 + s1;
     }
-    float djj = __shfl(s, j, 64);
-    if (act && !(djj > 1e-30f)) { bad = 1; djj = 1e-30f; }
-    float rinv = rsqrtf(fmaxf(djj, 1e-30f));
-    if (act) {
-      if (i == j) { H[rj + j] = djj * rinv; mydinv = rinv; }
-      else if (i > j) H[ri + j] = s * rinv;
-    }
-    SYNC();
   }
   // forward: L y = -grad
   float b = row ? -L[ly.grad + i] : 0.0f;
-  rem = mask;
-  for (int jj = 0; jj < steps; jj++) {
-    const bool act = rem != 0;
-    const int j = act ? __ffsll((long long)rem) - 1 : i;
-    rem &= rem - 1;
-    float yj = __shfl(b * mydinv, j, 64);
-    if (act) {
-      if (i == j) b = yj;
-      else if (i > j) b -= H[ri + j] * yj;
+#pragma unroll
+  for (int jj = 0; jj < NLOC; jj++) {
+    if (jj < steps) {
+      float yj = __shfl(b * mydinv, ib + jj, 64);
+      if (jj < nI) b = (l == jj) ? yj : (l > jj ? b - Lr[jj] * yj : b);
     }
   }
-  // backward: L' p = y
-  rem = mask;
-  for (int jj = 0; jj < steps; jj++) {
-    const bool act = rem != 0;
-    const int j = act ? 63 - __clzll((long long)rem) : i;
-    if (act) rem &= ~(1ull << j);
-    float pj = __shfl(b * mydinv, j, 64);
-    if (act) {
-      if (i == j) b = pj;
-      else if (i < j) b -= H[j * (j + 1) / 2 + i] * pj;
+  // backward: L' p = y, column access through LDS
+#pragma unroll
+  for (int k = 0; k < NLOC; k++) if (k < steps && row && k <= l) H[rowb + k] = Lr[k];
+  SYNC();
+  const int hI = rowb - l * (l + 1) / 2;
+  for (int jj = steps - 1; jj >= 0; jj--) {
+    float pj = __shfl(b * mydinv, ib + jj, 64);
+    if (jj < nI) {
+      if (l == jj) b = pj;
+      else if (l < jj) b -= H[hI + jj * (jj + 1) / 2 + l] * pj;
     }
   }
   if (row) L[ly.p + i] = b;
   SYNC();
   return !wave_or(bad);
+}
+
+DEV bool fs_chol_solve(const Ctx &c, int mp) {
+  const int nv = c.m.nv;
+  int nI = c.lane < nv ? (c.I(mp)[nv + c.lane] >> 8) & 255 : 0;
+  const int steps = (int)wave_max((float)nI);
+#ifdef FSIM_PROFILE
+  if (mp == c.ly.hmap && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
+#endif
+  if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
+  if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
+  return fs_chol_regs<64>(c, mp, steps);
 }
 
 DEV float fs_dotv(const Ctx &c, int a, int b) {
@@ -596,7 +714,7 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     if (scale * gn < c.newton_tol) break;
     fs_hessian(c);
     FS_SPROF(24);
-    bool ok = fs_chol_solve(c, 1);
+    bool ok = fs_chol_solve(c, ly.hmap);
     FS_SPROF(25);
 #ifdef FSIM_PROFILE
     if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
@@ -654,9 +772,6 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     // kept robot-contact envs iterating (5.5 iterations/substep where the fp64 oracle needs 2.5).
     FS_SPROF(28);
     float improvement = scale * 0.5f * alpha * fmaxf(-dphi0, 0.0f);
-#ifdef FSIM_PROFILE
-    if (c.lane == 0 && it >= 2 && it < 9) scal[48 + it - 2] = __float_as_int(improvement);
-#endif
     if (improvement < c.newton_tol) { it++; break; }
   }
   if (c.lane == 0) scal[SC_NITER] = it;
@@ -672,16 +787,16 @@ __device__ __noinline__ void fs_integrate(Ctx cv) {
   float *L = c.L;
   float h = m.timestep;
   // (M + h D) a' = M a : the same lane-per-row block Cholesky as the Newton step, on H = M + h diag(damping)
-  int nH = m.nv * (m.nv + 1) / 2;
+  int nH = c.I(ly.scal)[SC_TWORDS];
   for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
   for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = -L[ly.Mx + d]; }
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
     int i = KI(M_i, e), j = KI(M_j, e);
-    L[ly.H + fs_tri(i, j)] = L[ly.M + e] + (i == j ? h * KF(dof_damping, i) : 0.0f);
+    L[ly.H + fs_hidx(c, ly.k_tmap, i, j)] = L[ly.M + e] + (i == j ? h * KF(dof_damping, i) : 0.0f);
   }
   SYNC();
-  fs_chol_solve(c, 0);
+  fs_chol_solve(c, ly.k_tmap);
   for (int d = c.lane; d < m.nv; d += 64) L[ly.qvel + d] += h * L[ly.p + d];
   SYNC();
   for (int b = c.lane; b < m.nr; b += 64) {
