@@ -79,7 +79,7 @@ def main():
     import torch
     import torch.distributed as dist
     from furniture_amd.dist import gather_observations, shard_range
-    from furniture_amd.envs import ResetTableSampler, make_config
+    from furniture_amd.envs import ResetTableQueue, ResetTableSampler, make_config
     from furniture_amd.mjcf.model import load_compiled
     from furniture_amd.sim import FSim, INFO_DIM, INFO_NEEDS_TABLE, default_config
 
@@ -115,8 +115,8 @@ def main():
         sl = Slab()
         sl.sim = FSim(m, ng, device=local, config=cfg)
         dev = sl.sim.device
-        sl.sampler = ResetTableSampler(m, ecfg, SEED, lo + g * ng, ng)
-        sl.sim.set_reset_tables(*sl.sampler.draw())
+        sl.tables = ResetTableQueue(ResetTableSampler(m, ecfg, SEED, lo + g * ng, ng))  # reference RNG stream, drawn one reset ahead
+        sl.sim.set_reset_tables(*sl.tables.take())
         sl.obs = torch.zeros((ng, sl.sim.obs_dim), device=dev)
         sl.rew = torch.zeros(ng, device=dev)
         sl.done = torch.zeros(ng, dtype=torch.uint8, device=dev)
@@ -127,7 +127,7 @@ def main():
         sl.inflight = False
         sl.sim.reset(None, sl.obs)
         sl.sim.sync()
-        sl.sim.set_reset_tables(*sl.sampler.draw())  # tables for the first auto-reset
+        sl.sim.set_reset_tables(*sl.tables.take())  # tables for the first auto-reset
         slabs.append(sl)
     dev = slabs[0].sim.device
 
@@ -140,7 +140,7 @@ def main():
         need = sl.info[:, INFO_NEEDS_TABLE]
         if bool(need.any()):  # host-side reference RNG stream for the envs that just consumed their reset table
             mask = need.bool().cpu().numpy()
-            p, nz = sl.sampler.draw(mask)
+            p, nz = sl.tables.take(mask)
             sl.sim.set_reset_tables(p, nz, mask=mask)
 
     def launch(sl):
@@ -208,6 +208,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line))
     for sl in slabs:
+        sl.tables.close()
         sl.sim.close()
     if world > 1:
         dist.destroy_process_group()

@@ -117,8 +117,9 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
 // Longest-job-first launch order.  An env-step's cost varies 5x with its contact state (robot gripping a part =>
 // coupled Newton systems) and 7x when the episode ends inside the launch (in-kernel reset), and the kernel's duration
 // is the finish time of the last wave: sorting the grid by predicted cost keeps the long jobs off the tail.
-// One workgroup, bucket sort by cost (256 linear buckets below the max, bucket 0 = envs that will reset), order inside a
-// bucket is arbitrary -- it only affects timing, never results (envs are independent).
+// Key (written by env_step): -1 = will reset; bit 30 = a robot hand is near a part (likely to couple); low bits = shader
+// cycles >> 10 of the step just taken.  One workgroup, bucket sort: [reset | near, by cost | the rest, by cost]; order
+// inside a bucket is arbitrary -- it only affects timing, never results (envs are independent).
 __global__ __launch_bounds__(1024) void k_schedule(const int *cost, int *order, int n) {
   __shared__ int hist[257], mx;
   int tid = threadIdx.x;
@@ -126,23 +127,20 @@ __global__ __launch_bounds__(1024) void k_schedule(const int *cost, int *order, 
   if (tid == 0) mx = 0;
   __syncthreads();
   int lm = 0;
-  for (int i = tid; i < n; i += 1024) lm = max(lm, cost[i]);
+  for (int i = tid; i < n; i += 1024) { int cv = cost[i]; if (cv >= 0) lm = max(lm, cv & 0x3fffffff); }
   atomicMax(&mx, lm);
   __syncthreads();
   long long M = (long long)mx + 1;
-  for (int i = tid; i < n; i += 1024) {
-    int cv = cost[i];
-    int b = cv < 0 ? 0 : 256 - (int)((long long)cv * 256 / M);
-    atomicAdd(&hist[b], 1);
-  }
+  auto bucket = [&](int cv) {
+    if (cv < 0) return 0;
+    int base = (cv >> 30) & 1 ? 1 : 129;
+    return base + 127 - (int)((long long)(cv & 0x3fffffff) * 128 / M);
+  };
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bucket(cost[i])], 1);
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int b = 0; b < 257; b++) { int h = hist[b]; hist[b] = acc; acc += h; } }
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    int cv = cost[i];
-    int b = cv < 0 ? 0 : 256 - (int)((long long)cv * 256 / M);
-    order[atomicAdd(&hist[b], 1)] = i;
-  }
+  for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
 }
 
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays

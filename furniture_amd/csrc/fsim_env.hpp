@@ -115,6 +115,8 @@ __device__ __noinline__ void fs_forward(Ctx cv) {
     int *sc_ = c.I(c.ly.scal);
     sc_[21] += 1; sc_[22] += sc_[SC_NITER]; sc_[23] += coupled; sc_[24] += sc_[SC_NSURV]; sc_[25] += sc_[SC_NSLOT];
     if (sc_[SC_NITER] > sc_[26]) sc_[26] = sc_[SC_NITER];
+    if (sc_[SC_NSLOT] > sc_[51]) sc_[51] = sc_[SC_NSLOT];
+    if (sc_[SC_NSURV] > sc_[52]) sc_[52] = sc_[SC_NSURV];
   }
 #endif
   // instability guard (mj_checkAcc analogue): NaN / huge accelerations
@@ -597,6 +599,21 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     ctrl_pen = -cfg.ctrl_penalty_coef * wave_sum(s2);
   }
   int success = 0, terminal = 0;
+  // scheduler hint: is a robot hand within 10 cm of a furniture part's collision geom?  (an env about to enter robot-part
+  // contact is the expensive kind next step even if this step was cheap)
+  int near = 0;
+  if (io.cost) {
+    for (int g = c.lane; g < m.ncg; g += 64) {
+      if (!m.cg_ispartcol[g]) continue;
+      int b = m.cg_body[g];
+      V3 ctr = ldv3(L + ly.xpos + 3 * b) + mulv(ldm3(L + ly.xmat + 9 * b), ldv3(m.cg_pos + 3 * g));
+      for (int arm = 0; arm < m.narm; arm++) {
+        V3 hp = ldv3(L + ly.xpos + 3 * m.body_red[m.hand_body[arm]]);
+        if (norm(ctr - hp) - m.cg_rbound[g] < 0.10f) near = 1;
+      }
+    }
+    near = wave_or(near);
+  }
   float penalty = 0;
   if (c.lane == 0) {
     for (int arm = 0; arm < m.narm; arm++) {
@@ -637,7 +654,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       long long dt = clock64() - io.t0;
       int key = (int)min(dt >> 10, (long long)(1 << 24));
       bool timeout_next = !terminal && cfg.auto_reset && E[E_EPISODE_LENGTH] + 1 >= cfg.max_episode_steps;
-      *io.cost = timeout_next ? -1 : key;
+      *io.cost = timeout_next ? -1 : (key | (near << 30));
     }
   }
   SYNC();

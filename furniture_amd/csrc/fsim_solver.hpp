@@ -612,16 +612,19 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   for (int jj = 0; jj < NLOC; jj++) {
     if (jj < steps) {
       const bool act = jj < nI;
-      float d = __shfl(Lr[jj], ib + jj, 64);
-      if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
-      float rinv = act ? rsqrtf(d) : 0.0f;
-      float lij = (l >= jj) ? Lr[jj] * rinv : 0.0f; // column jj of the factor: this lane holds L[l][jj]
-      Lr[jj] = lij;
-      if (l == jj) mydinv = rinv;
+      const float ci = (l >= jj) ? Lr[jj] : 0.0f;
+      {
+        float d = __shfl(ci, ib + jj, 64);
+        if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+        const float rinv = act ? rsqrtf(d) : 0.0f;
+        const float lij = ci * rinv;
+        Lr[jj] = lij;
+        if (l == jj) mydinv = rinv;
 #pragma unroll
-      for (int k = jj + 1; k < NLOC; k++) {
-        if ((k & 7) == ((jj + 1) & 7) && k >= steps) break; // uniform early-out, checked every 8 columns
-        Lr[k] -= lij * __shfl(lij, ib + k, 64);
+        for (int k = jj + 1; k < NLOC; k++) {
+          if ((k & 7) == ((jj + 1) & 7) && k >= steps) break;
+          Lr[k] -= lij * __shfl(lij, ib + k, 64);
+        }
       }
     }
   }
@@ -651,7 +654,59 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   return !wave_or(bad);
 }
 
-DEV bool fs_chol_solve(const Ctx &c, int mp) {
+// islands larger than 32 dofs (e.g. the fully welded table plus the robot): same algorithm with the factor left in LDS,
+// left-looking, no unrolling -- slow path, kept small on purpose
+DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
+  const Layout &ly = c.ly;
+  float *L = c.L;
+  float *H = L + ly.H;
+  const int nv = c.m.nv;
+  const bool row = c.lane < nv;
+  const int i = row ? c.I(mp)[2 * nv + c.lane] : 0;
+  const int B = row ? c.I(mp)[nv + i] : 0;
+  const int l = B & 255, nI = row ? (B >> 8) & 255 : 0, ib = B >> 16;
+  const int rowb = c.I(mp)[i], hI = rowb - l * (l + 1) / 2;
+  int bad = 0;
+  float mydinv = 0.0f;
+#pragma unroll 1
+  for (int jj = 0; jj < steps; jj++) {
+    const bool act = jj < nI;
+    const int rj = hI + jj * (jj + 1) / 2;
+    float s = 0;
+    if (act && l >= jj) {
+      s = H[rowb + jj];
+#pragma unroll 2
+      for (int k = 0; k < jj; k++) s -= H[rowb + k] * H[rj + k];
+    }
+    float d = __shfl(s, ib + jj, 64);
+    if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+    const float rinv = act ? rsqrtf(d) : 0.0f;
+    if (act) {
+      if (l == jj) { H[rj + jj] = d * rinv; mydinv = rinv; }
+      else if (l > jj) H[rowb + jj] = s * rinv;
+    }
+    SYNC();
+  }
+  float b = row ? -L[ly.grad + i] : 0.0f;
+#pragma unroll 1
+  for (int jj = 0; jj < steps; jj++) {
+    float yj = __shfl(b * mydinv, ib + jj, 64);
+    if (jj < nI) { if (l == jj) b = yj; else if (l > jj) b -= H[rowb + jj] * yj; }
+  }
+#pragma unroll 1
+  for (int jj = steps - 1; jj >= 0; jj--) {
+    float pj = __shfl(b * mydinv, ib + jj, 64);
+    if (jj < nI) { if (l == jj) b = pj; else if (l < jj) b -= H[hI + jj * (jj + 1) / 2 + l] * pj; }
+  }
+  if (row) L[ly.p + i] = b;
+  SYNC();
+  return !wave_or(bad);
+}
+
+// one out-of-line copy shared by the Newton step (fs_solve) and the damped integrator (fs_integrate)
+__device__ __noinline__ bool fs_chol_solve(Ctx cv, int mp_) {
+  FS_REBUILD_CTX(cv);
+  const int mp = __builtin_amdgcn_readfirstlane(mp_);
   const int nv = c.m.nv;
   int nI = c.lane < nv ? (c.I(mp)[nv + c.lane] >> 8) & 255 : 0;
   const int steps = (int)wave_max((float)nI);
@@ -660,7 +715,7 @@ DEV bool fs_chol_solve(const Ctx &c, int mp) {
 #endif
   if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
   if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
-  return fs_chol_regs<64>(c, mp, steps);
+  return fs_chol_lds(c, mp, steps);
 }
 
 DEV float fs_dotv(const Ctx &c, int a, int b) {

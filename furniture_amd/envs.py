@@ -13,6 +13,8 @@ reference's RNG stream, tensor allocation).  No CPU fallback: without the HIP li
 from collections import OrderedDict
 from types import SimpleNamespace
 
+import math
+
 import numpy as np
 
 from . import spaces
@@ -79,17 +81,23 @@ class ResetTableSampler:
         m, r = self.m, self.cfg.furn_xyz_rand
         lo, hi = min(-r, r), max(-r, r)
         rot_hi = max(-self.cfg.furn_rot_rand, self.cfg.furn_rot_rand)
+        if getattr(self, "_quat_cache", None) is None:
+            # reference quirk: uniform(high=rot_hi, low=rot_hi) is the constant rot_hi (one draw is still consumed), so the
+            # per-part orientation does not depend on the stream
+            self._quat_cache = [list(T.euler_to_quat([rot_hi, 0, 0], m.part_initqpos[i][3:7])) for i in range(m.nparts)]
         out = np.zeros((m.nparts, 7))
         placed = []
+        uni = rng.uniform
         for i in range(m.nparts):
-            base, rad = m.part_initqpos[i], m.part_hradius[i]
+            base, rad = m.part_initqpos[i], float(m.part_hradius[i])
+            bx, by = float(base[0]), float(base[1])
             for _ in range(10000):
-                x = base[0] + rng.uniform(high=hi, low=lo)
-                y = base[1] + rng.uniform(high=hi, low=lo)
-                if all(np.linalg.norm([x - px, y - py], 2) > pr + rad for px, py, pr in placed):
-                    noise = rng.uniform(high=rot_hi, low=rot_hi)  # reference quirk: constant angle, one draw consumed
-                    quat = T.euler_to_quat([noise, 0, 0], base[3:7])
-                    out[i] = [x, y, base[2] + 0.01] + list(quat)
+                x = bx + uni(high=hi, low=lo)
+                y = by + uni(high=hi, low=lo)
+                if all(math.hypot(x - px, y - py) > pr + rad for px, py, pr in placed):
+                    uni(high=rot_hi, low=rot_hi)
+                    out[i, 0], out[i, 1], out[i, 2] = x, y, base[2] + 0.01
+                    out[i, 3:7] = self._quat_cache[i]
                     placed.append((x, y, rad))
                     break
             else:
@@ -110,6 +118,41 @@ class ResetTableSampler:
                 # one (101, narm) draw consumes the Mersenne-Twister stream exactly like 101 successive size-narm draws
                 noise[i] = rng.uniform(low=-a, high=a, size=(N_NOISE, self.narm)).reshape(-1)
         return parts, noise
+
+
+class ResetTableQueue:
+    """Keeps one reset table per env drawn AHEAD on the host, so that handing a table to the device after an in-kernel
+    auto-reset is a copy, and the reference RNG stream of the consumed envs is advanced by a worker thread while the GPU
+    runs the following steps (the main thread sits in hipStreamSynchronize with the GIL released).  Per-env draw order
+    is unchanged, so results are identical to calling ResetTableSampler.draw() synchronously."""
+
+    def __init__(self, sampler):
+        from concurrent.futures import ThreadPoolExecutor
+        self._s = sampler
+        self._pool = ThreadPoolExecutor(1)
+        self._parts, self._noise = sampler.draw()
+        self._fut = None
+
+    def _refill(self, mask):
+        p, nz = self._s.draw(mask)
+        self._parts[mask] = p[mask]
+        self._noise[mask] = nz[mask]
+
+    def take(self, mask=None):
+        """Tables for the envs in mask (all if None); schedules their replacements."""
+        if self._fut is not None:
+            self._fut.result()
+            self._fut = None
+        n = self._parts.shape[0]
+        m = np.ones(n, dtype=bool) if mask is None else np.asarray(mask, dtype=bool).copy()
+        parts, noise = self._parts.copy(), self._noise.copy()
+        self._fut = self._pool.submit(self._refill, m)
+        return parts, noise
+
+    def close(self):
+        if self._fut is not None:
+            self._fut.result()
+        self._pool.shutdown()
 
 
 _AGENT_OF = {"FurnitureSawyerEnv": "Sawyer", "FurnitureBaxterEnv": "Baxter", "FurnitureCursorEnv": "Cursor"}
@@ -179,7 +222,9 @@ class FurnitureBatchEnv:
         return OrderedDict([("object_ob", flat[:, :k]), ("robot_ob", flat[:, k:])])
 
     def _refill(self, mask=None):
-        parts, noise = self._sampler.draw(mask)
+        if getattr(self, "_table_queue", None) is None:
+            self._table_queue = ResetTableQueue(self._sampler)
+        parts, noise = self._table_queue.take(mask)
         self.sim.set_reset_tables(parts, noise, mask=mask)
 
     def reset(self):
@@ -221,6 +266,9 @@ class FurnitureBatchEnv:
         return self.sim.get_state("qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group")
 
     def close(self):
+        if getattr(self, "_table_queue", None) is not None:
+            self._table_queue.close()
+            self._table_queue = None
         self.sim.close()
 
 

@@ -6,9 +6,9 @@ import sys
 def main(db, out, note=""):
     c = sqlite3.connect(db)
     lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % db.split("/")[-1], note, "",
-             "%-60s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
+             "%-60s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct")]
     for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 12"):
-        lines.append("%-60s %8d %14.1f %14.1f %8.3f" % (name[:60], calls, tot / 1e3, avg / 1e3, pct))
+        lines.append("%-60s %8d %14.3f %14.3f %8.3f" % (name[:60], calls, tot / 1e3, avg / 1e3, pct))
     lines += ["", "# per-dispatch resources of the hot kernel (first dispatch)"]
     row = c.execute("select name,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels where name like 'k_env_step%' or name like 'k_physics%' limit 1").fetchone()
     if row:
