@@ -153,6 +153,55 @@ def test_env_reset_steps_and_attach_match_oracle(sawyer_lack):
     sim.close()
 
 
+def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack):
+    """All four welds active + the gripper pinching a leg: one 39-dof island (robot + 5 welded parts), i.e. the
+    large-island Cholesky path and the weld/contact cross blocks of the Hessian, against the fp64 oracle."""
+    from furniture_amd import transform_utils as T
+    m = sawyer_lack
+    o = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150))
+    o.reset()
+    q, xfrc, masks = pinch_attach_state(m, o.sim.data.qpos.copy(), o.sim.data.xpos.copy(), o.sim.data.xquat.copy())
+    pq = lambda i: q[m.part_qposadr[i]:m.part_qposadr[i] + 7]
+    eq_data = np.stack([T.rel_pose(pq(int(m.eq_part1[e])), pq(int(m.eq_part2[e]))) for e in range(len(m.eq_part1))])
+    n = 4
+    sim = FSim(m, n)
+    gm = sim.get_state("geom_contype", "geom_conaffinity")
+    osim = OracleSim(m)
+    osim.set_solver(100, 1e-10, "newton")
+    osim.reset()
+    for g, (ct, ca) in masks.items():
+        osim.model.geom_contype[g], osim.model.geom_conaffinity[g] = ct, ca
+        gm["geom_contype"][:, g], gm["geom_conaffinity"][:, g] = ct, ca
+    osim.data.qpos[:], osim.data.qvel[:], osim.data.qacc_warmstart[:] = q, 0, 0
+    osim.model.eq_active[:] = 1
+    osim.model.eq_data[:] = eq_data
+    for i in range(m.nparts):
+        osim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+    sim.set_state(qpos=np.tile(q, (n, 1)), qvel=np.zeros((n, m.nv)), qacc_warmstart=np.zeros((n, m.nv)),
+                  xfrc_applied=np.tile(xfrc, (n, 1)), geom_contype=gm["geom_contype"], geom_conaffinity=gm["geom_conaffinity"],
+                  eq_active=np.ones((n, len(m.eq_part1)), dtype=np.int32), eq_data=np.tile(eq_data.reshape(-1), (n, 1)))
+    # close the fingers on the leg with the arm gravity-compensated
+    sim.physics_forward()
+    osim.forward()
+    bias = sim.get_state("qfrc_bias")["qfrc_bias"].cpu().numpy()
+    app = np.zeros((n, m.nv))
+    app[:, m.arm_dofadr] = bias[:, m.arm_dofadr]
+    ctrl = np.zeros(m.nu)
+    ctrl[-2:] = (m.ctrl_bias + m.ctrl_weight)[-2:]  # gripper actuators: action +1 = close
+    sim.set_state(qfrc_applied=app, ctrl=np.tile(ctrl, (n, 1)))
+    osim.data.qfrc_applied[m.arm_dofadr] = osim.data.qfrc_bias[m.arm_dofadr]
+    osim.data.ctrl[:] = ctrl
+    sim.physics_step(60)
+    for _ in range(60):
+        osim.step()
+    st = sim.get_state("qpos", "qvel", "ncon")
+    assert int(st["ncon"][0, 0]) >= 2  # the pads do hold the leg
+    assert np.abs(st["qpos"][0].cpu().numpy() - osim.data.qpos).max() < 2e-4
+    assert np.abs(st["qvel"][0].cpu().numpy() - osim.data.qvel).max() < 5e-3
+    assert torch.equal(st["qpos"][0], st["qpos"][n - 1])
+    sim.close()
+
+
 def test_determinism_and_batch_invariance(sawyer_lack):
     """Same inputs -> bit-identical state, run to run and independent of batch size / env position in the batch."""
     m = sawyer_lack
