@@ -323,11 +323,13 @@ static void build_layout(fsim *s, int ncon_max) {
   o = (o + 3) / 4 * 4;
   ly.stride = o;
   // LDS-only
-  ly.xpos = take(3 * m.nr); ly.xquat = take(4 * m.nr); ly.xmat = take(9 * m.nr); ly.xanchor = take(3 * m.nr); ly.xaxis = take(3 * m.nr);
+  ly.xpos = take(3 * m.nr); ly.xquat = take(4 * m.nr); ly.xmat = take(9 * m.nr);
   ly.xipos = take(3 * m.nr); ly.com = take(3 * m.ntree);
   ly.cvel = take(6 * m.nr); // read by constraint assembly AND by the observation (site velocities): never aliased
   int hstart = o;
   ly.cinert = take(10 * m.nr); ly.crb = take(10 * m.nr); ly.cdofdot = take(6 * m.nv); ly.cacc = take(6 * m.nr); ly.cfrc = take(6 * m.nr);
+  // joint anchors / axes are only live between kinematics and the motion-axis computation: they sit in the unused cacc slot
+  ly.xanchor = ly.cacc; ly.xaxis = ly.cacc + 3 * m.nr;
   // H (Newton Hessian, packed lower triangle) is only live inside fs_solve, after the rigid-body temporaries
   // above are dead, so it aliases them.
   int nH = m.nv * (m.nv + 1) / 2;
@@ -339,11 +341,14 @@ static void build_layout(fsim *s, int ncon_max) {
   {
     int need = 21 * m.nr + 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
     ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * m.nr;
+    if (need < 12 * m.nr) need = 12 * m.nr;
     if (need > 12 * m.ncg) take(need - 12 * m.ncg);
+    // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
+    ly.W = ly.gpos; ly.G = ly.gpos + 6 * m.nr;
   }
   ly.surv = take(FSIM_MAXSURV);
   ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.W = take(6 * m.nr); ly.G = take(6 * m.nr); ly.scal = take(SC_WORDS); ly.hmap = take(3 * m.nv);
+  ly.scal = take(SC_WORDS); ly.hmap = take(2 * m.nv);
   // LDS model cache
   {
     std::vector<int> ca, cl;
@@ -355,9 +360,9 @@ static void build_layout(fsim *s, int ncon_max) {
     ly.k_r_parent = take(m.nr); ly.k_r_jtype = take(m.nr); ly.k_r_qposadr = take(m.nr); ly.k_r_dofadr = take(m.nr); ly.k_r_depth = take(m.nr);
     ly.k_r_tree = take(m.nr); ly.k_r_chainadr = take(m.nr); ly.k_r_chainlen = take(m.nr); ly.k_r_ancmask = take(m.nr); ly.k_chain_dofs = take(nchain);
     ly.k_tree_dofadr = take(m.ntree); ly.k_tree_dofnum = take(m.ntree); ly.k_tree_bodyadr = take(m.ntree); ly.k_tree_bodynum = take(m.ntree);
-    ly.k_M_i = take(m.nM); ly.k_M_j = take(m.nM);
-    ly.k_r_pos = take(3 * m.nr); ly.k_r_quat = take(4 * m.nr); ly.k_r_jpos = take(3 * m.nr); ly.k_r_jaxis = take(3 * m.nr); ly.k_r_ipos = take(3 * m.nr);
-    ly.k_r_mass = take(m.nr); ly.k_r_inertia = take(6 * m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv); ly.k_tmap = take(3 * m.nv);
+    ly.k_M_ij = take(m.nM);
+    ly.k_r_pos = ly.k_r_quat = ly.k_r_jpos = ly.k_r_jaxis = ly.k_r_ipos = ly.k_r_inertia = 0; // not cached
+    ly.k_r_mass = take(m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv); ly.k_tmap = take(2 * m.nv);
     ly.k_end = o;
   }
   ly.lds_words = o;
@@ -383,6 +388,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
   build_layout(s, ncon_max);
   s->lds_bytes = s->ly.lds_words * 4;
+  if (const char *e = getenv("FSIM_LDS_PAD")) s->lds_bytes += atoi(e); // development: lower the occupancy on purpose
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));

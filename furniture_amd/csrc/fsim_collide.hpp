@@ -8,8 +8,10 @@
 #pragma once
 #include "fsim_physics.hpp"
 
-enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_DIST = 13, C_INCM = 14, C_MU = 15, C_DIM = 16, C_B1 = 17, C_B2 = 18, C_G1 = 19,
-       C_G2 = 20, C_AREF = 21, C_DN = 24, C_DT = 25, C_JAR = 26, C_JP = 29 };
+// contact slot (FSIM_CONW = 24 words).  Only the normal is stored; the tangents are rebuilt where needed (fs_frame).
+// C_DIST / C_INCM are consumed by fs_make_constraints before it writes C_AREF + 1 / + 2 over them.
+enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2 = 10, C_G1 = 11, C_G2 = 12, C_AREF = 13,
+       C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17, C_JAR = 18, C_JP = 21 };
 enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8, SC_HWORDS = 160, SC_TWORDS = 161, SC_ADJ = 64, SC_ISL = 80, SC_TMP = 96, SC_PADJ = 144, SC_WORDS = 164 }; // 9..14 are scratch of the env logic (fsim_env.hpp), 16..63 profile counters
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
@@ -42,7 +44,16 @@ struct Emit {
   }
 };
 
-// lane = slot: contact frame (mju_makeFrame convention: x = n, then y, z) and the geom pair's parameters
+// contact frame from the stored unit normal (mju_makeFrame convention: x = n, y = the world y (or z) axis made orthogonal
+// to x, z = x cross y)
+DEV void fs_frame(const float *r, V3 &x, V3 &y, V3 &z) {
+  x = ldv3(r + C_FRAME);
+  V3 e = (x.y > -0.5f && x.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
+  y = normalized(e - x * dot(x, e));
+  z = cross(x, y);
+}
+
+// lane = slot: unit normal and the geom pair's parameters
 DEV void fs_finish_contacts(const Ctx &c) {
   const DModel &m = c.m;
   int nslot = min(c.I(c.ly.scal)[SC_NSLOT], c.ly.ncon_max);
@@ -50,11 +61,7 @@ DEV void fs_finish_contacts(const Ctx &c) {
     float *r = c.L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     int cg1 = ri[C_G1], cg2 = ri[C_G2];
-    V3 x = normalized(ldv3(r + C_FRAME));
-    V3 y = (x.y > -0.5f && x.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
-    y = normalized(y - x * dot(x, y));
-    V3 z = cross(x, y);
-    stv3(r + C_FRAME, x); stv3(r + C_FRAME + 3, y); stv3(r + C_FRAME + 6, z);
+    stv3(r + C_FRAME, normalized(ldv3(r + C_FRAME)));
     float mu = fmaxf(m.cg_friction[3 * cg1], m.cg_friction[3 * cg2]);
     r[C_MU] = mu;
     int dim = max(m.cg_condim[cg1], m.cg_condim[cg2]);

@@ -10,10 +10,10 @@
 #include <stdint.h>
 
 #define FSIM_MAXANG 8
-#define FSIM_CONW 32     // words per contact slot
+#define FSIM_CONW 24     // words per contact slot
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 8      // words per joint-limit record
-#define FSIM_MAXSURV 128 // broadphase survivors per substep
+#define FSIM_MAXSURV 64  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
@@ -72,7 +72,7 @@ struct Layout {
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int lds_words, ncon_max;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
-  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_i, k_M_j, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
+  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
   int k_begin, k_end;
 };
 

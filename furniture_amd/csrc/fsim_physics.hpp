@@ -38,6 +38,8 @@ DEV const void *fs_uniform_ptr(const void *p) {
 
 
 #define KI(field, idx) (c.I(c.ly.k_##field)[idx])
+#define KM_I(e) (c.I(c.ly.k_M_ij)[e] >> 8)
+#define KM_J(e) (c.I(c.ly.k_M_ij)[e] & 255)
 #define KF(field, idx) (c.L[c.ly.k_##field + (idx)])
 #define KFP(field) (c.L + c.ly.k_##field)
 
@@ -52,9 +54,10 @@ DEV void fs_load_cache(const Ctx &c) {
   CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_depth, nb); CPI(r_tree, nb);
   CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(r_ancmask, nb); CPI(chain_dofs, nchain);
   CPI(tree_dofadr, m.ntree); CPI(tree_dofnum, m.ntree); CPI(tree_bodyadr, m.ntree); CPI(tree_bodynum, m.ntree);
-  CPI(M_i, m.nM); CPI(M_j, m.nM);
-  CPF(r_pos, 3 * nb); CPF(r_quat, 4 * nb); CPF(r_jpos, 3 * nb); CPF(r_jaxis, 3 * nb); CPF(r_ipos, 3 * nb); CPF(r_mass, nb);
-  CPF(r_inertia, 6 * nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
+  for (int i_ = c.lane; i_ < m.nM; i_ += 64) c.I(c.ly.k_M_ij)[i_] = (m.M_i[i_] << 8) | m.M_j[i_];
+  // (body-frame constants r_pos/r_quat/r_jpos/r_jaxis/r_ipos/r_inertia are read once per substep by lane-per-body
+  //  passes: they stay in HBM/L2 and their 330 words of LDS buy an extra workgroup per CU instead)
+  CPF(r_mass, nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
 #undef CPI
 #undef CPF
   // static "tree map" of a block-diagonal-by-tree system (M + h*D in fs_integrate): same format as the per-substep
@@ -62,9 +65,8 @@ DEV void fs_load_cache(const Ctx &c) {
   for (int i = c.lane; i < nv; i += 64) {
     int t = m.dof_tree[i], adr = m.tree_dofadr[t], num = m.tree_dofnum[t], l = i - adr, base = 0;
     for (int u = 0; u < t; u++) base += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
-    c.I(c.ly.k_tmap)[i] = base + l * (l + 1) / 2;
-    c.I(c.ly.k_tmap)[nv + i] = l | (num << 8) | (adr << 16);
-    c.I(c.ly.k_tmap)[2 * nv + i] = i;
+    c.I(c.ly.k_tmap)[i] = (base + l * (l + 1) / 2) | (l << 12) | (num << 18) | (adr << 25);
+    c.I(c.ly.k_tmap)[nv + i] = i;
   }
   if (c.lane == 0) {
     int w = 0;
@@ -95,8 +97,8 @@ DEV void fs_kinematics(const Ctx &c) {
       stq(L + ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
       al = pl;
     } else {
-      Q4 q0 = ldq(KFP(r_quat) + 4 * b);
-      V3 p0 = ldv3(KFP(r_pos) + 3 * b), jpos = ldv3(KFP(r_jpos) + 3 * b), jax = ldv3(KFP(r_jaxis) + 3 * b);
+      Q4 q0 = ldq(m.r_quat + 4 * b);
+      V3 p0 = ldv3(m.r_pos + 3 * b), jpos = ldv3(m.r_jpos + 3 * b), jax = ldv3(m.r_jaxis + 3 * b);
       al = p0 + qrot(q0, jpos);
       axl = qrot(q0, jax);
       float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
@@ -125,7 +127,7 @@ DEV void fs_kinematics(const Ctx &c) {
   for (int b = c.lane; b < m.nr; b += 64) {
     M3 R = q2m(ldq(L + ly.xquat + 4 * b));
     stm3(L + ly.xmat + 9 * b, R);
-    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(KFP(r_ipos) + 3 * b)));
+    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(m.r_ipos + 3 * b)));
     if (b > 0) { // joint anchor / axis were left in the parent frame by pass A
       int p = KI(r_parent, b);
       V3 pp = ldv3(L + ly.xpos + 3 * p);
@@ -157,7 +159,7 @@ DEV void fs_com_inertia(const Ctx &c) {
     float *I = L + ly.cinert + 10 * b;
     if (b == 0) { for (int k = 0; k < 10; k++) I[k] = 0; continue; }
     M3 R = ldm3(L + ly.xmat + 9 * b);
-    const float *ib = KFP(r_inertia) + 6 * b; // xx yy zz xy xz yz in body frame
+    const float *ib = m.r_inertia + 6 * b; // xx yy zz xy xz yz in body frame
     M3 Ib;
     Ib.m[0] = ib[0]; Ib.m[4] = ib[1]; Ib.m[8] = ib[2]; Ib.m[1] = Ib.m[3] = ib[3]; Ib.m[2] = Ib.m[6] = ib[4]; Ib.m[5] = Ib.m[7] = ib[5];
     M3 T = mulm(R, Ib);
@@ -209,7 +211,7 @@ DEV void fs_crb_factor(const Ctx &c) {
   }
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KI(M_i, e), j = KI(M_j, e);
+    int i = KM_I(e), j = KM_J(e);
     S6 f = inert_mul(L + ly.crb + 10 * KI(dof_rbody, i), lds6(L + ly.cdof + 6 * i));
     float v = dot6(lds6(L + ly.cdof + 6 * j), f);
     if (i == j) v += KF(dof_armature, i);
@@ -225,7 +227,7 @@ DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   for (int d = c.lane; d < m.nv; d += 64) L[off_y + d] = 0;
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KI(M_i, e), j = KI(M_j, e);
+    int i = KM_I(e), j = KM_J(e);
     float Me = L[c.ly.M + e];
     atomicAdd(L + off_y + i, Me * L[off_v + j]);
     if (i != j) atomicAdd(L + off_y + j, Me * L[off_v + i]);

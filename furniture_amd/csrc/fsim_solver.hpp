@@ -78,9 +78,11 @@ DEV int fs_make_constraints(const Ctx &c) {
     float R = fmaxf((1 - imp) / imp * (m.cg_invweight[g1] + m.cg_invweight[g2]), 1e-15f);
     r[C_DN] = 1.0f / R;
     r[C_DT] = fmaxf(m.impratio, 1e-15f) / R;
-    r[C_AREF] = -b * dot(ldv3(r + C_FRAME), vrel) - k * imp * (dist - incm);
-    r[C_AREF + 1] = -b * dot(ldv3(r + C_FRAME + 3), vrel);
-    r[C_AREF + 2] = -b * dot(ldv3(r + C_FRAME + 6), vrel);
+    V3 fx, fy, fz;
+    fs_frame(r, fx, fy, fz);
+    r[C_AREF] = -b * dot(fx, vrel) - k * imp * (dist - incm);
+    r[C_AREF + 1] = -b * dot(fy, vrel); // (overwrites C_DIST / C_INCM, already in registers)
+    r[C_AREF + 2] = -b * dot(fz, vrel);
     if (b1 != 0 && b2 != 0) {
       int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
       if (t1 != t2) { coupled = 1; atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
@@ -195,9 +197,8 @@ DEV int fs_make_constraints(const Ctx &c) {
     for (int i = c.lane; i < m.nv; i += 64) {
       int t = KI(dof_tree, i), rep = __ffs(isl[t]) - 1, ib = tmp[rep];
       int l = tmp[t] - ib + i - KI(tree_dofadr, t);
-      hm[i] = tmp[32 + t] + l * (l + 1) / 2;
-      hm[m.nv + i] = l | (tmp[16 + t] << 8) | (ib << 16);
-      hm[2 * m.nv + ib + l] = i;
+      hm[i] = (tmp[32 + t] + l * (l + 1) / 2) | (l << 12) | (tmp[16 + t] << 18) | (ib << 25);
+      hm[m.nv + ib + l] = i;
     }
   }
   SYNC();
@@ -232,7 +233,11 @@ DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
     V3 pos = ldv3(r + C_POS);
     V3 rel = fs_ptvel(c, ly.W, ri[C_B2], pos) - fs_ptvel(c, ly.W, ri[C_B1], pos);
     int dst = to_jar ? C_JAR : C_JP;
-    for (int a = 0; a < 3; a++) r[dst + a] = dot(ldv3(r + C_FRAME + 3 * a), rel) - (to_jar ? r[C_AREF + a] : 0.0f);
+    V3 fx, fy, fz;
+    fs_frame(r, fx, fy, fz);
+    r[dst] = dot(fx, rel) - (to_jar ? r[C_AREF] : 0.0f);
+    r[dst + 1] = dot(fy, rel) - (to_jar ? r[C_AREF + 1] : 0.0f);
+    r[dst + 2] = dot(fz, rel) - (to_jar ? r[C_AREF + 2] : 0.0f);
   }
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
@@ -352,7 +357,9 @@ DEV void fs_gradient(const Ctx &c) {
     if (ri[C_DIM] == 1) { if (r[C_JAR] < 0) f[0] = -r[C_DN] * r[C_JAR]; }
     else fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, nullptr);
     if (f[0] == 0 && f[1] == 0 && f[2] == 0) continue;
-    V3 F = ldv3(r + C_FRAME) * f[0] + ldv3(r + C_FRAME + 3) * f[1] + ldv3(r + C_FRAME + 6) * f[2];
+    V3 fx, fy, fz;
+    fs_frame(r, fx, fy, fz);
+    V3 F = fx * f[0] + fy * f[1] + fz * f[2];
     V3 pos = ldv3(r + C_POS);
     fs_add_wrench(c, ri[C_B2], pos, F, v3(0, 0, 0), 1.0f);
     fs_add_wrench(c, ri[C_B1], pos, F, v3(0, 0, 0), -1.0f);
@@ -389,7 +396,8 @@ DEV void fs_gradient(const Ctx &c) {
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
-DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return A[i] + (A[c.m.nv + j] & 255); }
+// map word of dof i: packed row base (12 bits) | local index (6) | island size (7) | first solver lane (6); [nv + lane] = dof of a solver lane
+DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return (A[i] & 0xfff) + ((A[j] >> 12) & 63); }
 
 // column of J for chain entry: value of row-space functional on dof d.  For a contact the three rows are
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
@@ -398,7 +406,7 @@ DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
   return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(dof_tree, d)));
 }
 
-#define FSIM_NPAIR 8 // body-pair cross blocks assembled per pass
+#define FSIM_NPAIR 4 // body-pair cross blocks assembled per pass
 
 // H = M + J' W J assembled at BODY level, like a composite-rigid-body pass with "stiffness inertias":
 //   a contact point on body b with world-frame stiffness K (3x3, = frame' * cone Hessian * frame) acts on the dofs of
@@ -433,7 +441,8 @@ DEV void fs_hessian(const Ctx &c) {
       if (ri[C_DIM] == 1) { on = r[C_JAR] < 0; for (int q = 0; q < 9; q++) Hc[q] = 0; Hc[0] = r[C_DN]; }
       else { float f_[3], cc_; on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f_, &cc_, Hc) != 0; }
       if (on) {
-        V3 f0 = ldv3(r + C_FRAME), f1 = ldv3(r + C_FRAME + 3), f2 = ldv3(r + C_FRAME + 6);
+        V3 f0, f1, f2;
+        fs_frame(r, f0, f1, f2);
         V3 w0 = f0 * Hc[0] + f1 * Hc[1] + f2 * Hc[2], w1 = f0 * Hc[3] + f1 * Hc[4] + f2 * Hc[5], w2 = f0 * Hc[6] + f1 * Hc[7] + f2 * Hc[8];
         K[0] = f0.x * w0.x + f1.x * w1.x + f2.x * w2.x; K[1] = f0.x * w0.y + f1.x * w1.y + f2.x * w2.y; K[2] = f0.x * w0.z + f1.x * w1.z + f2.x * w2.z;
         K[3] = f0.y * w0.y + f1.y * w1.y + f2.y * w2.y; K[4] = f0.y * w0.z + f1.y * w1.z + f2.y * w2.z; K[5] = f0.z * w0.z + f1.z * w1.z + f2.z * w2.z;
@@ -474,7 +483,7 @@ DEV void fs_hessian(const Ctx &c) {
   }
   // ---- tree blocks on M's pattern: lane = M entry
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KI(M_i, e), j = KI(M_j, e);
+    int i = KM_I(e), j = KM_J(e);
     const float *Ab = A + 21 * KI(dof_rbody, i);
     S6 si = lds6(L + ly.cdof + 6 * i), sj = lds6(L + ly.cdof + 6 * j);
     // t = A * sj
@@ -599,10 +608,10 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   float *H = L + ly.H;
   const int nv = c.m.nv;
   const bool row = c.lane < nv;
-  const int i = row ? c.I(mp)[2 * nv + c.lane] : 0;
-  const int B = row ? c.I(mp)[nv + i] : 0;
-  const int l = B & 255, nI = row ? (B >> 8) & 255 : 0, ib = B >> 16;
-  const int rowb = c.I(mp)[i];
+  const int i = row ? c.I(mp)[nv + c.lane] : 0;
+  const int B = row ? c.I(mp)[i] : 0;
+  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, ib = (B >> 25) & 63;
+  const int rowb = B & 0xfff;
   float Lr[NLOC];
 #pragma unroll
   for (int k = 0; k < NLOC; k++) Lr[k] = (row && k <= l) ? H[rowb + k] : 0.0f;
@@ -662,10 +671,10 @@ DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
   float *H = L + ly.H;
   const int nv = c.m.nv;
   const bool row = c.lane < nv;
-  const int i = row ? c.I(mp)[2 * nv + c.lane] : 0;
-  const int B = row ? c.I(mp)[nv + i] : 0;
-  const int l = B & 255, nI = row ? (B >> 8) & 255 : 0, ib = B >> 16;
-  const int rowb = c.I(mp)[i], hI = rowb - l * (l + 1) / 2;
+  const int i = row ? c.I(mp)[nv + c.lane] : 0;
+  const int B = row ? c.I(mp)[i] : 0;
+  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, ib = (B >> 25) & 63;
+  const int rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
   int bad = 0;
   float mydinv = 0.0f;
 #pragma unroll 1
@@ -708,7 +717,7 @@ __device__ __noinline__ bool fs_chol_solve(Ctx cv, int mp_) {
   FS_REBUILD_CTX(cv);
   const int mp = __builtin_amdgcn_readfirstlane(mp_);
   const int nv = c.m.nv;
-  int nI = c.lane < nv ? (c.I(mp)[nv + c.lane] >> 8) & 255 : 0;
+  int nI = c.lane < nv ? (c.I(mp)[c.lane] >> 18) & 127 : 0;
   const int steps = (int)wave_max((float)nI);
 #ifdef FSIM_PROFILE
   if (mp == c.ly.hmap && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
@@ -847,7 +856,7 @@ __device__ __noinline__ void fs_integrate(Ctx cv) {
   for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = -L[ly.Mx + d]; }
   SYNC();
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KI(M_i, e), j = KI(M_j, e);
+    int i = KM_I(e), j = KM_J(e);
     L[ly.H + fs_hidx(c, ly.k_tmap, i, j)] = L[ly.M + e] + (i == j ? h * KF(dof_damping, i) : 0.0f);
   }
   SYNC();
