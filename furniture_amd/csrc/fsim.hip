@@ -283,6 +283,21 @@ static int build_model(fsim *s) {
   LF(cg_solref, "cg_solref"); LF(cg_solimp, "cg_solimp"); LF(cg_margin, "cg_margin"); LF(cg_gap, "cg_gap"); LF(cg_solmix, "cg_solmix");
   LF(cg_invweight, "cg_invweight");
   LI(cp, "cp");
+  {
+    std::vector<int> cp_, ty_;
+    std::vector<float> mg_, gp_, rb_, sz_;
+    blob_i(s->blob, "cp", cp_); blob_i(s->blob, "cg_type", ty_); blob_f(s->blob, "cg_margin", mg_); blob_f(s->blob, "cg_gap", gp_);
+    blob_f(s->blob, "cg_rbound", rb_); blob_f(s->blob, "cg_size", sz_);
+    std::vector<float> rec((size_t)16 * std::max(m.ncp, 1), 0.0f);
+    for (int p = 0; p < m.ncp; p++) {
+      int g1 = cp_[3 * p], g2 = cp_[3 * p + 1], w[4] = {g1, g2, cp_[3 * p + 2], ty_[g1] | (ty_[g2] << 8)};
+      float *r = rec.data() + 16 * p;
+      memcpy(r, w, 16);
+      r[4] = std::max(mg_[g1], mg_[g2]); r[5] = std::max(gp_[g1], gp_[g2]); r[6] = rb_[g1]; r[7] = rb_[g2];
+      for (int k = 0; k < 3; k++) { r[8 + k] = sz_[3 * g1 + k]; r[12 + k] = sz_[3 * g2 + k]; }
+    }
+    ar.add(&s->m.pair_rec, rec);
+  }
   LI(s_body, "s_body"); LF(s_pos, "s_pos"); LF(s_quat, "s_quat");
   {
     // actuator -> dof / qpos addresses
@@ -335,7 +350,12 @@ static void build_layout(fsim *s, int ncon_max) {
   int nH = m.nv * (m.nv + 1) / 2;
   ly.H = hstart;
   if (hstart + nH > o) o = hstart + nH;
-  ly.cdof = take(6 * m.nv); ly.M = take(m.nM); ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
+  ly.cdof = take(6 * m.nv);
+  { // M lives in the tree-packed triangle layout of k_tmap (dense lower triangle per kinematic tree)
+    std::vector<int> tn; blob_i(s->blob, "tree_dofnum", tn);
+    int w = 0; for (int n_ : tn) w += n_ * (n_ + 1) / 2;
+    ly.M = take(w);
+  } ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
   ly.smooth = take(m.nv); ly.asmooth = ly.smooth; ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
   ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg);
   {
@@ -356,9 +376,9 @@ static void build_layout(fsim *s, int ncon_max) {
     int nchain = 0;
     for (size_t b = 0; b < ca.size(); b++) nchain = std::max(nchain, ca[b] + cl[b]);
     ly.k_begin = o;
-    ly.k_dof_parent = take(m.nv); ly.k_dof_Madr = take(m.nv); ly.k_dof_rbody = take(m.nv); ly.k_dof_tree = take(m.nv);
-    ly.k_r_parent = take(m.nr); ly.k_r_jtype = take(m.nr); ly.k_r_qposadr = take(m.nr); ly.k_r_dofadr = take(m.nr); ly.k_r_depth = take(m.nr);
-    ly.k_r_tree = take(m.nr); ly.k_r_chainadr = take(m.nr); ly.k_r_chainlen = take(m.nr); ly.k_r_ancmask = take(m.nr); ly.k_chain_dofs = take(nchain);
+    ly.k_dof_parent = take(m.nv); ly.k_r_submask = take(m.nr); ly.k_dof_rbody = take(m.nv); ly.k_dof_tree = take(m.nv);
+    ly.k_r_parent = take(m.nr); ly.k_r_jtype = take(m.nr); ly.k_r_qposadr = take(m.nr); ly.k_r_dofadr = take(m.nr); ly.k_r_chain = take(m.nr);
+    ly.k_r_tree = take(m.nr); ly.k_r_chainadr = take(m.nr); ly.k_r_chainlen = take(m.nr); ly.k_r_ancmask = 0; ly.k_chain_dofs = take(nchain);
     ly.k_tree_dofadr = take(m.ntree); ly.k_tree_dofnum = take(m.ntree); ly.k_tree_bodyadr = take(m.ntree); ly.k_tree_bodynum = take(m.ntree);
     ly.k_M_ij = take(m.nM);
     ly.k_r_pos = ly.k_r_quat = ly.k_r_jpos = ly.k_r_jaxis = ly.k_r_ipos = ly.k_r_inertia = 0; // not cached
@@ -385,6 +405,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   int ncon_max = 48;
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
+  if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
   if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
   build_layout(s, ncon_max);
   s->lds_bytes = s->ly.lds_words * 4;

@@ -79,16 +79,21 @@ DEV void np_plane_sphere(const Emit &e, V3 pp, const M3 &pR, V3 sp, float r) {
   e(0, dist, sp - n * (r + 0.5f * dist), n);
 }
 DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V3 size) {
+  // corner i = bp +- c0 +- c1 +- c2 (scaled box axes); its height over the plane is dist0 +- a +- b +- cc, so the
+  // eight depth tests cost three adds each and the corner itself is only formed for the (<= 4) contacts that are kept
   V3 n = colv(pR, 2);
   float dist0 = dot(bp - pp, n);
+  V3 c0 = colv(bR, 0) * size.x, c1 = colv(bR, 1) * size.y, c2 = colv(bR, 2) * size.z;
+  float a = dot(n, c0), b = dot(n, c1), cc = dot(n, c2);
+  if (dist0 - fabsf(a) - fabsf(b) - fabsf(cc) > e.margin) return; // deepest corner still above the margin
   int cnt = 0;
 #pragma unroll 1
   for (int i = 0; i < 8; i++) {
-    V3 v = v3((i & 1) ? size.x : -size.x, (i & 2) ? size.y : -size.y, (i & 4) ? size.z : -size.z);
-    V3 cv = mulv(bR, v);
-    float ld = dot(n, cv);
+    float sx = (i & 1) ? 1.0f : -1.0f, sy = (i & 2) ? 1.0f : -1.0f, sz_ = (i & 4) ? 1.0f : -1.0f;
+    float ld = sx * a + sy * b + sz_ * cc;
     if (dist0 + ld > e.margin || ld > 0) continue;
     float d = dist0 + ld;
+    V3 cv = c0 * sx + c1 * sy + c2 * sz_;
     e(cnt, d, cv - n * (0.5f * d) + bp, n);
     if (++cnt >= 4) return;
   }
@@ -304,6 +309,55 @@ DEV void np_box_box(const Emit &e, V3 p1, const M3 &R1, V3 s1, V3 p2, const M3 &
   }
 }
 
+// distance between the axis segments p1 +- h1*a1 and p2 +- h2*a2 (closest points of two segments, clamped)
+DEV float np_capsule_gap(V3 p1, V3 a1, float h1, V3 p2, V3 a2, float h2) {
+  V3 d1 = a1 * (2 * h1), d2 = a2 * (2 * h2), q1 = p1 - a1 * h1, q2 = p2 - a2 * h2, r = q1 - q2;
+  float A = dot(d1, d1), E = dot(d2, d2), F = dot(d2, r), C = dot(d1, r), B = dot(d1, d2), den = A * E - B * B;
+  float sN = den > 1e-12f ? fminf(fmaxf((B * F - C * E) / den, 0.0f), 1.0f) : 0.0f;
+  float tN = E > 1e-12f ? (B * sN + F) / E : 0.0f;
+  if (tN < 0) { tN = 0; sN = A > 1e-12f ? fminf(fmaxf(-C / A, 0.0f), 1.0f) : 0.0f; }
+  else if (tN > 1) { tN = 1; sN = A > 1e-12f ? fminf(fmaxf((B - C) / A, 0.0f), 1.0f) : 0.0f; }
+  V3 dv = r + d1 * sN - d2 * tN;
+  return norm(dv);
+}
+
+// conservative separating-axis pre-test for two cylinders: both axes, their cross product, the two radial directions
+// towards the other centre and the centre line (e.g. a link cylinder resting 7 mm above the flat top of the base)
+DEV bool np_cyl_cyl_separated(V3 p1, V3 a1, V3 s1, V3 p2, V3 a2, V3 s2, float margin) {
+  const V3 d = p2 - p1;
+  bool sep = false;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    V3 Lx = k == 0 ? a1 : (k == 1 ? a2 : (k == 2 ? cross(a1, a2) : (k == 3 ? d - a1 * dot(d, a1) : (k == 4 ? d - a2 * dot(d, a2) : d))));
+    float ln = norm(Lx);
+    if (ln < 1e-9f) continue;
+    Lx = Lx * (1.0f / ln);
+    float c1 = dot(a1, Lx), c2 = dot(a2, Lx);
+    float r1 = s1.y * fabsf(c1) + s1.x * sqrtf(fmaxf(1.0f - c1 * c1, 0.0f)), r2 = s2.y * fabsf(c2) + s2.x * sqrtf(fmaxf(1.0f - c2 * c2, 0.0f));
+    if (fabsf(dot(d, Lx)) > r1 + r2 + margin) sep = true;
+  }
+  return sep;
+}
+
+// conservative separating-axis pre-test for cylinder (geom 1) vs box (geom 2): the box face normals, the cylinder axis and
+// the radial direction towards the box centre.  true => some axis separates the two by more than the margin, no contact
+DEV bool np_cyl_box_separated(V3 pc, const M3 &Rc, V3 sc, V3 pb, const M3 &Rb, V3 sb, float margin) {
+  const V3 a = colv(Rc, 2), d = pb - pc, B0 = colv(Rb, 0), B1 = colv(Rb, 1), B2 = colv(Rb, 2);
+  V3 rad = d - a * dot(d, a);
+  float rl = norm(rad);
+  rad = rl > 1e-9f ? rad * (1.0f / rl) : B0;
+  bool sep = false;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    V3 Lx = k == 0 ? B0 : (k == 1 ? B1 : (k == 2 ? B2 : (k == 3 ? a : rad)));
+    float al = dot(a, Lx);
+    float rc = sc.y * fabsf(al) + sc.x * sqrtf(fmaxf(1.0f - al * al, 0.0f));
+    float rb = sb.x * fabsf(dot(B0, Lx)) + sb.y * fabsf(dot(B1, Lx)) + sb.z * fabsf(dot(B2, Lx));
+    if (fabsf(dot(d, Lx)) > rc + rb + margin) sep = true;
+  }
+  return sep;
+}
+
 // ---- Minkowski portal refinement for cylinder-box / cylinder-cylinder --------------------------
 struct Shape { int type; V3 pos; M3 R; V3 size; };
 DEV V3 np_support(const Shape &s, V3 dir) {
@@ -415,29 +469,33 @@ DEV void fs_collide(const Ctx &c) {
     int p = p0 + c.lane;
     bool pass = false;
     if (p < m.ncp) {
-      int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1];
+      // one 64-byte record per pair (g1 g2 pt types | margin gap r1 r2 | size1 | size2): no dependent table lookups
+      const int4 q0 = reinterpret_cast<const int4 *>(m.pair_rec)[4 * p];
+      const float4 q1 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 1];
+      const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
       if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
-        float margin = fmaxf(m.cg_margin[g1], m.cg_margin[g2]);
+        const float margin = q1.x, r1 = q1.z, r2 = q1.w;
         V3 d = ldv3(L + ly.gpos + 3 * g2) - ldv3(L + ly.gpos + 3 * g1);
-        if (m.cg_type[g1] == GT_PLANE) {
+        if (t1 == GT_PLANE) {
           V3 n = v3(L[ly.gmat + 9 * g1 + 2], L[ly.gmat + 9 * g1 + 5], L[ly.gmat + 9 * g1 + 8]);
-          pass = dot(d, n) <= m.cg_rbound[g2] + margin;
+          pass = dot(d, n) <= r2 + margin;
         } else {
-          float r1 = m.cg_rbound[g1], r2 = m.cg_rbound[g2];
           float bound = r1 + r2 + margin;
           pass = dot(d, d) <= bound * bound;
           // second, tighter test for flat / long shapes (a 0.64 x 0.24 x 0.04 table top has a 0.34 m bounding sphere):
           // distance from the OTHER geom's centre to this box / cylinder (exact point-solid distance) must be within the
           // other geom's bounding radius.  Conservative: never rejects a pair that can touch.
           if (pass) {
-            for (int side = 0; side < 2 && pass; side++) {
-              int gs = side ? g1 : g2, ty = m.cg_type[gs];       // solid tested
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+              int gs = side ? g1 : g2, ty = side ? t1 : t2;       // solid tested
               float ro = (side ? r2 : r1) + margin;              // other geom's radius
-              if (ty != GT_BOX && ty != GT_CYLINDER) continue;
+              if (!pass || (ty != GT_BOX && ty != GT_CYLINDER)) continue;
               V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
               const float *R = L + ly.gmat + 9 * gs;
               V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
-              V3 sz_ = ldv3(m.cg_size + 3 * gs);
+              const float4 qs = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + (side ? 2 : 3)];
+              V3 sz_ = v3(qs.x, qs.y, qs.z);
               float dist2;
               if (ty == GT_BOX) {
                 V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
@@ -464,12 +522,20 @@ DEV void fs_collide(const Ctx &c) {
   FS_CPROF(30);
   for (int i = c.lane; i < nsurv; i += 64) {
     int p = surv[i];
-    int g1 = m.cp[3 * p], g2 = m.cp[3 * p + 1], pt = m.cp[3 * p + 2];
-    float margin = fmaxf(m.cg_margin[g1], m.cg_margin[g2]), gap = fmaxf(m.cg_gap[g1], m.cg_gap[g2]);
+    const int4 q0 = reinterpret_cast<const int4 *>(m.pair_rec)[4 * p];
+    const float4 q1 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 1], q2 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 2],
+                 q3 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 3];
+    const int g1 = q0.x, g2 = q0.y, pt = q0.z;
+    const float margin = q1.x, gap = q1.y;
     Emit e(c, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
     V3 p1 = ldv3(L + ly.gpos + 3 * g1), p2 = ldv3(L + ly.gpos + 3 * g2);
     M3 R1 = ldm3(L + ly.gmat + 9 * g1), R2 = ldm3(L + ly.gmat + 9 * g2);
-    V3 s1 = ldv3(m.cg_size + 3 * g1), s2 = ldv3(m.cg_size + 3 * g2);
+    V3 s1 = v3(q2.x, q2.y, q2.z), s2 = v3(q3.x, q3.y, q3.z);
+#ifdef FSIM_NPPROF
+    // development: run the pair types one after the other so that each type's path length can be timed on its own
+    for (int ptq = 0; ptq < 9; ptq++) {
+      long long tq0_ = clock64();
+      if (pt == ptq) {
     switch (pt) {
       case PT_PLANE_SPHERE: np_plane_sphere(e, p1, R1, p2, s2.x); break;
       case PT_PLANE_BOX: np_plane_box(e, p1, R1, p2, R2, s2); break;
@@ -479,12 +545,44 @@ DEV void fs_collide(const Ctx &c) {
       case PT_SPHERE_CYL: np_sphere_cylinder(e, p1, s1.x, p2, R2, s2); break;
       case PT_BOX_BOX: np_box_box(e, p1, R1, s1, p2, R2, s2); break;
       default: {
+        // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
+        // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)
+        if (pt == PT_CYL_CYL && (np_capsule_gap(p1, colv(R1, 2), s1.y, p2, colv(R2, 2), s2.y) - s1.x - s2.x > margin ||
+                                 np_cyl_cyl_separated(p1, colv(R1, 2), s1, p2, colv(R2, 2), s2, margin))) break;
+        if (pt == PT_CYL_BOX && np_cyl_box_separated(p1, R1, s1, p2, R2, s2, margin)) break;
         Shape A, B;
-        A.type = m.cg_type[g1]; A.pos = p1; A.R = R1; A.size = s1;
-        B.type = m.cg_type[g2]; B.pos = p2; B.R = R2; B.size = s2;
+        A.type = q0.w & 255; A.pos = p1; A.R = R1; A.size = s1;
+        B.type = q0.w >> 8; B.pos = p2; B.R = R2; B.size = s2;
         np_mpr(e, A, B);
       }
     }
+      }
+      long long dq_ = clock64() - tq0_;
+      int slotq_ = ptq == PT_PLANE_BOX ? 53 : (ptq == PT_BOX_BOX ? 54 : (ptq >= PT_CYL_BOX ? 48 : 49));
+      if (c.lane == 0) scal[slotq_] += (int)(dq_ >> 4);
+    }
+#else
+    switch (pt) {
+      case PT_PLANE_SPHERE: np_plane_sphere(e, p1, R1, p2, s2.x); break;
+      case PT_PLANE_BOX: np_plane_box(e, p1, R1, p2, R2, s2); break;
+      case PT_PLANE_CYL: np_plane_cylinder(e, p1, R1, p2, R2, s2); break;
+      case PT_SPHERE_SPHERE: np_sphere_sphere(e, p1, s1.x, p2, s2.x); break;
+      case PT_SPHERE_BOX: np_sphere_box(e, p1, s1.x, p2, R2, s2); break;
+      case PT_SPHERE_CYL: np_sphere_cylinder(e, p1, s1.x, p2, R2, s2); break;
+      case PT_BOX_BOX: np_box_box(e, p1, R1, s1, p2, R2, s2); break;
+      default: {
+        // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
+        // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)
+        if (pt == PT_CYL_CYL && (np_capsule_gap(p1, colv(R1, 2), s1.y, p2, colv(R2, 2), s2.y) - s1.x - s2.x > margin ||
+                                 np_cyl_cyl_separated(p1, colv(R1, 2), s1, p2, colv(R2, 2), s2, margin))) break;
+        if (pt == PT_CYL_BOX && np_cyl_box_separated(p1, R1, s1, p2, R2, s2, margin)) break;
+        Shape A, B;
+        A.type = q0.w & 255; A.pos = p1; A.R = R1; A.size = s1;
+        B.type = q0.w >> 8; B.pos = p2; B.R = R2; B.size = s2;
+        np_mpr(e, A, B);
+      }
+    }
+#endif
   }
   SYNC();
   fs_finish_contacts(c);

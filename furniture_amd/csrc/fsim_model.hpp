@@ -39,6 +39,9 @@ struct DModel {
       *cg_contype0, *cg_conaffinity0;
   const float *cg_pos, *cg_mat, *cg_size, *cg_rbound, *cg_friction, *cg_solref, *cg_solimp, *cg_margin, *cg_gap, *cg_solmix, *cg_invweight;
   const int *cp; // [ncp][3] = cg1, cg2, pair type
+  // [ncp][16] one 64-byte record per candidate pair with everything the broad/narrow phase needs from the two geoms:
+  // g1 g2 pairtype (type1 | type2 << 8) | margin gap rbound1 rbound2 | size1 xyz - | size2 xyz -   (built by fsim_create)
+  const float *pair_rec;
   // sites
   const int *s_body;
   const float *s_pos, *s_quat;
@@ -72,7 +75,7 @@ struct Layout {
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int lds_words, ncon_max;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
-  int k_dof_parent, k_dof_Madr, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_depth, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
+  int k_dof_parent, k_r_submask, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_chain, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
   int k_begin, k_end;
 };
 

@@ -38,8 +38,9 @@ DEV const void *fs_uniform_ptr(const void *p) {
 
 
 #define KI(field, idx) (c.I(c.ly.k_##field)[idx])
-#define KM_I(e) (c.I(c.ly.k_M_ij)[e] >> 8)
+#define KM_I(e) ((c.I(c.ly.k_M_ij)[e] >> 8) & 255)
 #define KM_J(e) (c.I(c.ly.k_M_ij)[e] & 255)
+#define KM_P(e) (c.I(c.ly.k_M_ij)[e] >> 16)
 #define KF(field, idx) (c.L[c.ly.k_##field + (idx)])
 #define KFP(field) (c.L + c.ly.k_##field)
 
@@ -50,16 +51,25 @@ DEV void fs_load_cache(const Ctx &c) {
   for (int b = 0; b < nb; b++) nchain = max(nchain, m.r_chainadr[b] + m.r_chainlen[b]);
 #define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
 #define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
-  CPI(dof_parent, nv); CPI(dof_Madr, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
-  CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_depth, nb); CPI(r_tree, nb);
-  CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(r_ancmask, nb); CPI(chain_dofs, nchain);
+  CPI(dof_parent, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
+  CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_tree, nb);
+  CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(chain_dofs, nchain);
   CPI(tree_dofadr, m.ntree); CPI(tree_dofnum, m.ntree); CPI(tree_bodyadr, m.ntree); CPI(tree_bodynum, m.ntree);
-  for (int i_ = c.lane; i_ < m.nM; i_ += 64) c.I(c.ly.k_M_ij)[i_] = (m.M_i[i_] << 8) | m.M_j[i_];
   // (body-frame constants r_pos/r_quat/r_jpos/r_jaxis/r_ipos/r_inertia are read once per substep by lane-per-body
   //  passes: they stay in HBM/L2 and their 330 words of LDS buy an extra workgroup per CU instead)
   CPF(r_mass, nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
 #undef CPI
 #undef CPF
+  // bit tables that replace index-list walks (an index load feeding a data load is two dependent LDS round trips per
+  // element): r_submask[b] = bodies in b's subtree; r_chain[b] = (first dof of b's tree) << 26 | bitmask of the dofs on
+  // the path root -> b, relative to that first dof (<= 26 dofs per tree, checked by the model compiler)
+  for (int b = c.lane; b < nb; b += 64) {
+    int sub = 0, ch = 0, base = b > 0 ? m.tree_dofadr[m.r_tree[b]] : 0;
+    for (int d = b; d < nb; d++) if (b > 0 && ((m.r_ancmask[d] >> b) & 1)) sub |= 1 << d;
+    if (b > 0) for (int k = 0; k < m.r_chainlen[b]; k++) ch |= 1 << (m.chain_dofs[m.r_chainadr[b] + k] - base);
+    c.I(c.ly.k_r_submask)[b] = sub;
+    c.I(c.ly.k_r_chain)[b] = (base << 26) | ch;
+  }
   // static "tree map" of a block-diagonal-by-tree system (M + h*D in fs_integrate): same format as the per-substep
   // island map (Layout::hmap), see fs_hidx / fs_chol_solve
   for (int i = c.lane; i < nv; i += 64) {
@@ -67,6 +77,19 @@ DEV void fs_load_cache(const Ctx &c) {
     for (int u = 0; u < t; u++) base += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
     c.I(c.ly.k_tmap)[i] = (base + l * (l + 1) / 2) | (l << 12) | (num << 18) | (adr << 25);
     c.I(c.ly.k_tmap)[nv + i] = i;
+  }
+  SYNC();
+  // M entry e -> (i, j, packed index in the tree-packed triangle); the entries of M that are structurally zero
+  // (two branches of one tree) are zeroed once here and never written again
+  for (int e = c.lane; e < m.nM; e += 64) {
+    int i = m.M_i[e], j = m.M_j[e];
+    int pidx = (c.I(c.ly.k_tmap)[i] & 0xfff) + ((c.I(c.ly.k_tmap)[j] >> 12) & 63);
+    c.I(c.ly.k_M_ij)[e] = (pidx << 16) | (i << 8) | j;
+  }
+  {
+    int w = 0;
+    for (int u = 0; u < m.ntree; u++) w += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    for (int k = c.lane; k < w; k += 64) c.L[c.ly.M + k] = 0.0f;
   }
   if (c.lane == 0) {
     int w = 0;
@@ -204,9 +227,10 @@ DEV void fs_crb_factor(const Ctx &c) {
   for (int b = c.lane; b < m.nr; b += 64) {
     float acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
-    if (b > 0)
-      for (int d = b; d < m.nr; d++)
-        if ((KI(r_ancmask, d) >> b) & 1) { const float *I = L + ly.cinert + 10 * d; for (int k = 0; k < 10; k++) acc[k] += I[k]; }
+    for (int mm = KI(r_submask, b); mm; mm &= mm - 1) {
+      const float *I = L + ly.cinert + 10 * (__ffs(mm) - 1);
+      for (int k = 0; k < 10; k++) acc[k] += I[k];
+    }
     for (int k = 0; k < 10; k++) L[ly.crb + 10 * b + k] = acc[k];
   }
   SYNC();
@@ -215,22 +239,25 @@ DEV void fs_crb_factor(const Ctx &c) {
     S6 f = inert_mul(L + ly.crb + 10 * KI(dof_rbody, i), lds6(L + ly.cdof + 6 * i));
     float v = dot6(lds6(L + ly.cdof + 6 * j), f);
     if (i == j) v += KF(dof_armature, i);
-    L[ly.M + e] = v;
+    L[ly.M + KM_P(e)] = v;
   }
   SYNC();
 }
 
-// y = M v  (sparse symmetric; LDS float atomics, one wave => deterministic order)
+// y = M v.  M is a dense packed lower triangle per kinematic tree (layout of k_tmap), so lane = dof gathers its row
+// with computed addresses: no index loads, no atomics, one barrier.
 DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   const DModel &m = c.m;
   float *L = c.L;
-  for (int d = c.lane; d < m.nv; d += 64) L[off_y + d] = 0;
-  SYNC();
-  for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KM_I(e), j = KM_J(e);
-    float Me = L[c.ly.M + e];
-    atomicAdd(L + off_y + i, Me * L[off_v + j]);
-    if (i != j) atomicAdd(L + off_y + j, Me * L[off_v + i]);
+  for (int i = c.lane; i < m.nv; i += 64) {
+    const int w = c.I(c.ly.k_tmap)[i];
+    const int li = (w >> 12) & 63, n = (w >> 18) & 127, a = (w >> 25) & 63; // local index, tree size, first dof
+    const int rowi = w & 0xfff, tb = rowi - li * (li + 1) / 2;
+    const float *Mt = L + c.ly.M;
+    float acc = 0;
+    for (int lj = 0; lj <= li; lj++) acc += Mt[rowi + lj] * L[off_v + a + lj];
+    for (int lj = li + 1; lj < n; lj++) acc += Mt[tb + lj * (lj + 1) / 2 + li] * L[off_v + a + lj];
+    L[off_y + i] = acc;
   }
   SYNC();
 }
@@ -256,10 +283,10 @@ DEV void fs_velocity_bias(const Ctx &c) {
   for (int b = c.lane; b < m.nr; b += 64) {
     S6 v = s6zero(), a = s6zero();
     a.l = v3(-m.gravity[0], -m.gravity[1], -m.gravity[2]);
-    if (b > 0) {
-      int adr = KI(r_chainadr, b), n = KI(r_chainlen, b);
-      for (int k = 0; k < n; k++) {
-        int d = KI(chain_dofs, adr + k);
+    {
+      const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
+      for (int mm = ch & 0x3ffffff; mm; mm &= mm - 1) {
+        int d = base + __ffs(mm) - 1;
         float qd = L[ly.qvel + d];
         v = v + lds6(L + ly.cdof + 6 * d) * qd;
         a = a + lds6(L + ly.cdofdot + 6 * d) * qd;
@@ -278,8 +305,7 @@ DEV void fs_velocity_bias(const Ctx &c) {
     int bd = KI(dof_rbody, d);
     S6 s = lds6(L + ly.cdof + 6 * d);
     float acc = 0;
-    for (int b = bd; b < m.nr; b++)
-      if ((KI(r_ancmask, b) >> bd) & 1) acc += dot6(s, lds6(L + ly.cfrc + 6 * b));
+    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + ly.cfrc + 6 * (__ffs(mm) - 1)));
     L[ly.qfrcbias + d] = acc;
   }
   SYNC();

@@ -211,9 +211,9 @@ DEV void fs_body_spatial(const Ctx &c, int off_vec) {
   float *L = c.L;
   for (int b = c.lane; b < m.nr; b += 64) {
     S6 w = s6zero();
-    if (b > 0) {
-      int adr = KI(r_chainadr, b), n = KI(r_chainlen, b);
-      for (int k = 0; k < n; k++) { int d = KI(chain_dofs, adr + k); w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
+    {
+      const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
+      for (int mm = ch & 0x3ffffff; mm; mm &= mm - 1) { int d = base + __ffs(mm) - 1; w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
     }
     sts6(L + c.ly.W + 6 * b, w);
   }
@@ -387,8 +387,7 @@ DEV void fs_gradient(const Ctx &c) {
     int bd = KI(dof_rbody, d);
     S6 s = lds6(L + ly.cdof + 6 * d);
     float acc = 0;
-    for (int b = bd; b < m.nr; b++)
-      if ((KI(r_ancmask, b) >> bd) & 1) acc += dot6(s, lds6(L + ly.G + 6 * b));
+    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + ly.G + 6 * (__ffs(mm) - 1)));
     L[ly.grad + d] -= acc;
   }
   SYNC();
@@ -493,7 +492,7 @@ DEV void fs_hessian(const Ctx &c) {
     V3 tl = v3(Ab[6] * sj.a.x + Ab[9] * sj.a.y + Ab[12] * sj.a.z + Ab[15] * sj.l.x + Ab[16] * sj.l.y + Ab[17] * sj.l.z,
                Ab[7] * sj.a.x + Ab[10] * sj.a.y + Ab[13] * sj.a.z + Ab[16] * sj.l.x + Ab[18] * sj.l.y + Ab[19] * sj.l.z,
                Ab[8] * sj.a.x + Ab[11] * sj.a.y + Ab[14] * sj.a.z + Ab[17] * sj.l.x + Ab[19] * sj.l.y + Ab[20] * sj.l.z);
-    L[ly.H + fs_hidx(c, hm, i, j)] = L[ly.M + e] + dot(si.a, ta) + dot(si.l, tl);
+    L[ly.H + fs_hidx(c, hm, i, j)] = L[ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
   }
   SYNC();
   // ---- body-pair cross blocks, FSIM_NPAIR distinct pairs per pass
@@ -852,13 +851,10 @@ __device__ __noinline__ void fs_integrate(Ctx cv) {
   float h = m.timestep;
   // (M + h D) a' = M a : the same lane-per-row block Cholesky as the Newton step, on H = M + h diag(damping)
   int nH = c.I(ly.scal)[SC_TWORDS];
-  for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
   for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = -L[ly.Mx + d]; }
+  for (int k = c.lane; k < nH; k += 64) L[ly.H + k] = L[ly.M + k]; // same tree-packed layout
   SYNC();
-  for (int e = c.lane; e < m.nM; e += 64) {
-    int i = KM_I(e), j = KM_J(e);
-    L[ly.H + fs_hidx(c, ly.k_tmap, i, j)] = L[ly.M + e] + (i == j ? h * KF(dof_damping, i) : 0.0f);
-  }
+  for (int d = c.lane; d < m.nv; d += 64) L[ly.H + fs_hidx(c, ly.k_tmap, d, d)] += h * KF(dof_damping, d);
   SYNC();
   fs_chol_solve(c, ly.k_tmap);
   for (int d = c.lane; d < m.nv; d += 64) L[ly.qvel + d] += h * L[ly.p + d];
