@@ -611,16 +611,45 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   const int B = row ? c.I(mp)[i] : 0;
   const int l = (B >> 12) & 63, nI = (B >> 18) & 127, ib = (B >> 25) & 63;
   const int rowb = B & 0xfff;
+#ifdef FSIM_PROFILE
+  long long tq_ = clock64();
+#define FS_CHPROF(slot) do { long long t1q_ = clock64(); if (c.lane == 0) c.I(ly.scal)[slot] += (int)((t1q_ - tq_) >> 4); tq_ = t1q_; } while (0)
+#else
+#define FS_CHPROF(slot) do { } while (0)
+#endif
   float Lr[NLOC];
 #pragma unroll
   for (int k = 0; k < NLOC; k++) Lr[k] = (row && k <= l) ? H[rowb + k] : 0.0f;
   int bad = 0;
   float mydinv = 0.0f;
+  float b = row ? -L[ly.grad + i] : 0.0f; // right-hand side; forward substitution rides along with the factorisation
+  FS_CHPROF(48);
 #pragma unroll
   for (int jj = 0; jj < NLOC; jj++) {
     if (jj < steps) {
       const bool act = jj < nI;
       const float ci = (l >= jj) ? Lr[jj] : 0.0f;
+#ifdef FSIM_CHOL_STAGE
+      { // column jj through a 64-word LDS staging buffer (ping-pong p / Mp): one write + one batch of broadcast reads
+        float *cb = L + ((jj & 1) ? ly.Mp : ly.p);
+        if (row) cb[c.lane] = ci;
+        SYNC();
+        const float *cI = cb + ib;
+        float d = cI[jj];
+        if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+        const float rp = act ? 1.0f / d : 0.0f, rinv = act ? rsqrtf(d) : 0.0f;
+        const float t = ci * rp;
+        Lr[jj] = ci * rinv;
+        if (l == jj) mydinv = rinv;
+        const float yj = __shfl(b * rinv, ib + jj, 64);
+        if (act) b = (l == jj) ? yj : (l > jj ? b - ci * rinv * yj : b);
+#pragma unroll
+        for (int k = jj + 1; k < NLOC; k++) {
+          if ((k & 7) == ((jj + 1) & 7) && k >= steps) break;
+          Lr[k] -= t * cI[k];
+        }
+      }
+#else
       {
         float d = __shfl(ci, ib + jj, 64);
         if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
@@ -628,37 +657,42 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
         const float lij = ci * rinv;
         Lr[jj] = lij;
         if (l == jj) mydinv = rinv;
+        // forward substitution, column form: y_jj = b_jj / L_jj, then b_l -= L[l][jj] * y_jj for the rows below
+        const float yj = __shfl(b * rinv, ib + jj, 64);
+        if (act) b = (l == jj) ? yj : (l > jj ? b - lij * yj : b);
 #pragma unroll
         for (int k = jj + 1; k < NLOC; k++) {
           if ((k & 7) == ((jj + 1) & 7) && k >= steps) break;
           Lr[k] -= lij * __shfl(lij, ib + k, 64);
         }
       }
+#endif
     }
   }
-  // forward: L y = -grad
-  float b = row ? -L[ly.grad + i] : 0.0f;
-#pragma unroll
-  for (int jj = 0; jj < NLOC; jj++) {
-    if (jj < steps) {
-      float yj = __shfl(b * mydinv, ib + jj, 64);
-      if (jj < nI) b = (l == jj) ? yj : (l > jj ? b - Lr[jj] * yj : b);
-    }
-  }
+  FS_CHPROF(49);
+  FS_CHPROF(50);
   // backward: L' p = y, column access through LDS
 #pragma unroll
   for (int k = 0; k < NLOC; k++) if (k < steps && row && k <= l) H[rowb + k] = Lr[k];
   SYNC();
   const int hI = rowb - l * (l + 1) / 2;
-  for (int jj = steps - 1; jj >= 0; jj--) {
+  // the column entries do not depend on the running solution: they are fetched (clamped address) ahead of the shuffle
+  // that carries the dependency, two steps per trip
+  int jj = steps - 1;
+  for (; jj >= 1; jj -= 2) {
+    const float h0 = H[hI + jj * (jj + 1) / 2 + min(l, jj)], h1 = H[hI + (jj - 1) * jj / 2 + min(l, jj - 1)];
     float pj = __shfl(b * mydinv, ib + jj, 64);
-    if (jj < nI) {
-      if (l == jj) b = pj;
-      else if (l < jj) b -= H[hI + jj * (jj + 1) / 2 + l] * pj;
-    }
+    if (jj < nI) b = (l == jj) ? pj : (l < jj ? b - h0 * pj : b);
+    pj = __shfl(b * mydinv, ib + jj - 1, 64);
+    if (jj - 1 < nI) b = (l == jj - 1) ? pj : (l < jj - 1 ? b - h1 * pj : b);
+  }
+  if (jj == 0) {
+    float pj = __shfl(b * mydinv, ib, 64);
+    if (0 < nI && l == 0) b = pj;
   }
   if (row) L[ly.p + i] = b;
   SYNC();
+  FS_CHPROF(53);
   return !wave_or(bad);
 }
 
@@ -719,7 +753,7 @@ __device__ __noinline__ bool fs_chol_solve(Ctx cv, int mp_) {
   int nI = c.lane < nv ? (c.I(mp)[c.lane] >> 18) & 127 : 0;
   const int steps = (int)wave_max((float)nI);
 #ifdef FSIM_PROFILE
-  if (mp == c.ly.hmap && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
+  if (0 && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
 #endif
   if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
   if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
