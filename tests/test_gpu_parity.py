@@ -153,6 +153,45 @@ def test_env_reset_steps_and_attach_match_oracle(sawyer_lack):
     sim.close()
 
 
+@pytest.mark.parametrize("key", [("Sawyer", "swivel_chair_0700"), ("Baxter", "desk_mikael_1064")])
+def test_env_reset_and_steps_match_oracle_other_models(key):
+    """BASELINE configs 3 and 4 (Sawyer + swivel chair, bimanual Baxter + desk): in-kernel reset and random steps against
+    the oracle env, same reset tables and actions."""
+    m = load_compiled(*key)
+    n = 2
+    cfg = default_config()
+    cfg.max_episode_steps = 150
+    cfg.auto_reset = 0
+    sim = FSim(m, n, config=cfg)
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10)) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+    noise = np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs])
+    sim.set_reset_tables(parts, noise)
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    for e in range(n):
+        assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(obs_o[e])).max() < 1e-4
+    dof = sim.dof_action
+    act = torch.zeros((n, dof), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    for t in range(3):
+        a = np.stack([counter_actions(321, i, t, dof) for i in range(n)])
+        act.copy_(torch.as_tensor(a))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        for e in range(n):
+            ob, r, d, inf = envs[e].step(a[e])
+            assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob)).max() < 5e-4
+            assert abs(float(rew[e]) - r) < 1e-4 and bool(done[e]) == d
+    sim.close()
+
+
 def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack):
     """All four welds active + the gripper pinching a leg: one 39-dof island (robot + 5 welded parts), i.e. the
     large-island Cholesky path and the weld/contact cross blocks of the Hessian, against the fp64 oracle."""
