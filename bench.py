@@ -188,6 +188,14 @@ def main():
         total_env_steps = world * n * args.steps
         value = total_env_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * ng / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        traffic, traffic_note = None, None
+        try:  # HBM bytes measured offline with rocprofv3 --pmc (bench.py cannot profile itself); see profiles/hbm_traffic.json
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                tj = json.load(f)
+            traffic = tj["bytes_per_env_step"] * ng
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), %d B per env-step x %d envs per launch" % (tj["bytes_per_env_step"], ng)
+        except Exception:
+            pass
         line = {
             "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -199,7 +207,7 @@ def main():
                        "physics_substeps_per_s": value * 50, "obs_finite": finite,
                        "reference_published_single_core_env_steps_per_s": 225},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_env_step", "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                          "note": "fused 50-substep step keeps state in LDS: the kernel is VALU/LDS-latency bound, HBM fraction is ~0 by design"},

@@ -48,12 +48,8 @@ __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layou
   SYNC();
   Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   fs_load_cache(c);
-  if (kp.mode == 1) fs_forward(c);
-  else
-    for (int s = 0; s < kp.n_substeps; s++) {
-      fs_forward(c);
-      fs_integrate(c);
-    }
+  if (kp.mode == 1) fs_substeps(c, 1, 1);
+  else fs_substeps(c, kp.n_substeps, 0);
   // aux: [qacc nv][xpos 3nr][xquat 4nr][ncon, niter, overflow, bad][contact geoms 2*ncon_max]
   if (aux) {
     float *a = aux + (size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max);

@@ -72,10 +72,8 @@ DEV void fs_touch_flags(const Ctx &c) {
   SYNC();
 }
 
-// fs_forward / fs_integrate / env_reset are real (non-inlined) device functions: each is large and is called from
-// many places in the env state machine; one copy keeps the code object (and the build) small.
-__device__ __noinline__ void fs_forward(Ctx cv) {
-  FS_REBUILD_CTX(cv);
+// One forward pass (inlined exactly once, into fs_substeps below).
+DEV void fs_forward_body(const Ctx &c) {
 #ifdef FSIM_PROFILE
   // per-phase shader-clock accounting (development builds only): scal[16..] = cycles of
   // {kinematics+inertia+crb+factor, collide, velocity+smooth, constraints, solve}, then counters
@@ -126,7 +124,30 @@ __device__ __noinline__ void fs_forward(Ctx cv) {
   if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
   SYNC();
 }
-DEV void fs_step(const Ctx &c) { fs_forward(c); fs_integrate(c); }
+
+// The ONE out-of-line physics routine: n x (forward [+ finger-touch scan on the last pass] + integrate), or a single
+// forward pass.  fs_substeps and env_reset are real (non-inlined) functions because they are large and called from many
+// places in the env state machine; the substep LOOP lives inside the callee so that the callee-saved register
+// save/restore to scratch (tens of dwords per lane per call) is paid once per env step instead of once per substep --
+// with per-substep calls it was 2.6 GB of HBM writes per 4096-env step (rocprofv3 WRITE_SIZE), 300x the state traffic.
+//   mode bit 0: forward only (no integration);  mode bit 1: run fs_touch_flags after the last forward pass
+__device__ __noinline__ void fs_substeps(Ctx cv, int n_, int mode_) {
+  FS_REBUILD_CTX(cv);
+  const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
+  if (mode & 1) {
+    fs_forward_body(c);
+    if (mode & 2) fs_touch_flags(c);
+    return;
+  }
+#pragma unroll 1
+  for (int s = 0; s < n; s++) {
+    fs_forward_body(c);
+    if ((mode & 2) && s == n - 1) fs_touch_flags(c);
+    fs_integrate_body(c);
+  }
+}
+DEV void fs_forward(const Ctx &c) { fs_substeps(c, 1, 1); }
+DEV void fs_step(const Ctx &c) { fs_substeps(c, 1, 0); }
 
 // ---------------------------------------------------------------------------------------------------- helpers (lane-0 scalar code)
 DEV int env_find(int *grp, int i) {
@@ -552,19 +573,14 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   SYNC();
   env_gravity_comp(c);
   // _do_simulation: n_substeps x sim.step()
-  for (int s = 0; s < cfg.n_substeps; s++) {
-    fs_forward(c);
-    if (s == cfg.n_substeps - 1) fs_touch_flags(c);
-    fs_integrate(c);
-  }
+  fs_substeps(c, cfg.n_substeps, 2);
   int bad = scal[SC_BAD] & 2;
   if (bad) {
     // unstable simulation: reset inside step(), flag the failure (furniture.py:2889-2897)
     env_reset(c, &cfg, &io);
     if (c.lane == 0) { E[E_FAIL] = 1; scal[SC_BAD] = 0; }
     SYNC();
-    fs_forward(c);
-    fs_touch_flags(c);
+    fs_substeps(c, 1, 3);
   } else if (connect > 0) {
     // finger-touch scan -> first part (in part order) pinched by both fingers of an arm -> _try_connect
     int done_connect = 0;
@@ -586,9 +602,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       E[E_CONNBODY1] = 0;
     }
     SYNC();
-    fs_forward(c);
-    fs_touch_flags(c);
-    fs_integrate(c);
+    fs_substeps(c, 1, 2);
   }
   SYNC();
   // reward (furniture.py:482-541): one-shot touch / pick latches, success delta, control penalty on the RAW action

@@ -745,10 +745,8 @@ DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
   return !wave_or(bad);
 }
 
-// one out-of-line copy shared by the Newton step (fs_solve) and the damped integrator (fs_integrate)
-__device__ __noinline__ bool fs_chol_solve(Ctx cv, int mp_) {
-  FS_REBUILD_CTX(cv);
-  const int mp = __builtin_amdgcn_readfirstlane(mp_);
+// (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
+DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int nv = c.m.nv;
   int nI = c.lane < nv ? (c.I(mp)[c.lane] >> 18) & 127 : 0;
   const int steps = (int)wave_max((float)nI);
@@ -877,8 +875,7 @@ DEV void fs_solve(const Ctx &c, int coupled) {
 
 // ------------------------------------------------------------------------------------------ P8
 // qacc in ly.x, M*qacc in ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
-__device__ __noinline__ void fs_integrate(Ctx cv) {
-  FS_REBUILD_CTX(cv);
+DEV void fs_integrate_body(const Ctx &c) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
