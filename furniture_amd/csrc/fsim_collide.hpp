@@ -67,7 +67,9 @@ DEV void fs_finish_contacts(const Ctx &c) {
     int dim = max(m.cg_condim[cg1], m.cg_condim[cg2]);
     if (mu < 1e-15f) dim = 1;
     ri[C_DIM] = dim;
-    ri[C_B1] = m.cg_body[cg1]; ri[C_B2] = m.cg_body[cg2];
+    // body | tree << 8: the tree id rides along so that the solver loops reach the tree's CoM without a dependent lookup
+    int b1_ = m.cg_body[cg1], b2_ = m.cg_body[cg2];
+    ri[C_B1] = b1_ | (KI(r_tree, b1_) << 8); ri[C_B2] = b2_ | (KI(r_tree, b2_) << 8);
   }
 }
 

@@ -43,10 +43,13 @@ DEV float fs_impedance(const float *solref, const float *solimp, float x0, float
   return imp;
 }
 
-DEV V3 fs_ptvel(const Ctx &c, int off, int b, V3 p) {
+// bt = body | tree << 8 (contact slots store it that way; fs_bt builds it for other callers)
+DEV int fs_bt(const Ctx &c, int b) { return b | (KI(r_tree, b) << 8); }
+DEV V3 fs_ptvel(const Ctx &c, int off, int bt, V3 p) {
+  const int b = bt & 255;
   if (b == 0) return v3(0, 0, 0);
   S6 w = lds6(c.L + off + 6 * b);
-  return w.l + cross(w.a, p - ldv3(c.L + c.ly.com + 3 * KI(r_tree, b)));
+  return w.l + cross(w.a, p - ldv3(c.L + c.ly.com + 3 * (bt >> 8)));
 }
 
 // returns 1 if any constraint couples two kinematic trees
@@ -64,11 +67,11 @@ DEV int fs_make_constraints(const Ctx &c) {
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     ncon++;
-    int b1 = ri[C_B1], b2 = ri[C_B2], g1 = ri[C_G1], g2 = ri[C_G2];
+    const int bt1 = ri[C_B1], bt2 = ri[C_B2], b1 = bt1 & 255, b2 = bt2 & 255, g1 = ri[C_G1], g2 = ri[C_G2];
     float dist = r[C_DIST], incm = r[C_INCM];
     if (dist >= incm) { ri[C_ACTIVE] = 2; continue; }
     V3 pos = ldv3(r + C_POS);
-    V3 vrel = fs_ptvel(c, ly.cvel, b2, pos) - fs_ptvel(c, ly.cvel, b1, pos);
+    V3 vrel = fs_ptvel(c, ly.cvel, bt2, pos) - fs_ptvel(c, ly.cvel, bt1, pos);
     float mix = m.cg_solmix[g1] / (m.cg_solmix[g1] + m.cg_solmix[g2]);
     float sr[2], si[5];
     for (int i = 0; i < 2; i++) sr[i] = mix * m.cg_solref[2 * g1 + i] + (1 - mix) * m.cg_solref[2 * g2 + i];
@@ -84,7 +87,7 @@ DEV int fs_make_constraints(const Ctx &c) {
     r[C_AREF + 1] = -b * dot(fy, vrel); // (overwrites C_DIST / C_INCM, already in registers)
     r[C_AREF + 2] = -b * dot(fz, vrel);
     if (b1 != 0 && b2 != 0) {
-      int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
+      int t1 = bt1 >> 8, t2 = bt2 >> 8;
       if (t1 != t2) { coupled = 1; atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
     }
   }
@@ -134,7 +137,7 @@ DEV int fs_make_constraints(const Ctx &c) {
       Q4 t = qmul(qmul(q2c, w), qd);
       r[WD_C + 0 * 3 + a] = 0.5f * t.x; r[WD_C + 1 * 3 + a] = 0.5f * t.y; r[WD_C + 2 * 3 + a] = 0.5f * t.z;
     }
-    V3 jt = fs_ptvel(c, ly.cvel, b1, p0) - fs_ptvel(c, ly.cvel, b2, x2);
+    V3 jt = fs_ptvel(c, ly.cvel, fs_bt(c, b1), p0) - fs_ptvel(c, ly.cvel, fs_bt(c, b2), x2);
     V3 dw = lds6(L + ly.cvel + 6 * b1).a - lds6(L + ly.cvel + 6 * b2).a;
     float jv[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
     for (int q = 0; q < 3; q++) jv[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
@@ -251,7 +254,7 @@ DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[WD_ACTIVE]) continue;
     int b1 = ri[WD_B1], b2 = ri[WD_B2];
-    V3 jt = fs_ptvel(c, ly.W, b1, ldv3(r + WD_P0)) - fs_ptvel(c, ly.W, b2, ldv3(r + WD_X2));
+    V3 jt = fs_ptvel(c, ly.W, fs_bt(c, b1), ldv3(r + WD_P0)) - fs_ptvel(c, ly.W, fs_bt(c, b2), ldv3(r + WD_X2));
     V3 dw = lds6(L + ly.W + 6 * b1).a - lds6(L + ly.W + 6 * b2).a;
     int dst = to_jar ? WD_JAR : WD_JP;
     float v[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
@@ -332,10 +335,11 @@ DEV void fs_line_eval(const Ctx &c, float alpha, float *cost, float *d1, float *
   *cost = wave_sum(cs); *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
-DEV void fs_add_wrench(const Ctx &c, int b, V3 p, V3 F, V3 T, float sign) {
+DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
+  const int b = bt & 255;
   if (b == 0) return;
   float *G = c.L + c.ly.G + 6 * b;
-  V3 mo = (cross(p - ldv3(c.L + c.ly.com + 3 * KI(r_tree, b)), F) + T) * sign;
+  V3 mo = (cross(p - ldv3(c.L + c.ly.com + 3 * (bt >> 8)), F) + T) * sign;
   atomicAdd(G + 0, mo.x); atomicAdd(G + 1, mo.y); atomicAdd(G + 2, mo.z);
   atomicAdd(G + 3, sign * F.x); atomicAdd(G + 4, sign * F.y); atomicAdd(G + 5, sign * F.z);
 }
@@ -379,8 +383,8 @@ DEV void fs_gradient(const Ctx &c) {
     V3 F = v3(f[0], f[1], f[2]);
     V3 T = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
               r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
-    fs_add_wrench(c, ri[WD_B1], ldv3(r + WD_P0), F, T, 1.0f);
-    fs_add_wrench(c, ri[WD_B2], ldv3(r + WD_X2), F, T, -1.0f);
+    fs_add_wrench(c, fs_bt(c, ri[WD_B1]), ldv3(r + WD_P0), F, T, 1.0f);
+    fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T, -1.0f);
   }
   SYNC();
   for (int d = c.lane; d < m.nv; d += 64) {
@@ -429,7 +433,7 @@ DEV void fs_hessian(const Ctx &c) {
   // ---- contacts: lane = slot (ncon_max <= 64)
   const int nslot = c.I(ly.scal)[SC_NSLOT];
   bool on = false;
-  int blo = 0, bhi = 0;
+  int blo = 0, bhi = 0, tlo = 0, thi = 0;
   float K[6] = {0, 0, 0, 0, 0, 0};
   V3 pos = v3(0, 0, 0);
   if (c.lane < nslot) {
@@ -446,8 +450,9 @@ DEV void fs_hessian(const Ctx &c) {
         K[0] = f0.x * w0.x + f1.x * w1.x + f2.x * w2.x; K[1] = f0.x * w0.y + f1.x * w1.y + f2.x * w2.y; K[2] = f0.x * w0.z + f1.x * w1.z + f2.x * w2.z;
         K[3] = f0.y * w0.y + f1.y * w1.y + f2.y * w2.y; K[4] = f0.y * w0.z + f1.y * w1.z + f2.y * w2.z; K[5] = f0.z * w0.z + f1.z * w1.z + f2.z * w2.z;
         pos = ldv3(r + C_POS);
-        int b1 = ri[C_B1], b2 = ri[C_B2];
-        blo = min(b1, b2); bhi = max(b1, b2);
+        const int wb1 = ri[C_B1], wb2 = ri[C_B2]; // body | tree << 8
+        const int wl = (wb1 & 255) <= (wb2 & 255) ? wb1 : wb2, wh = (wb1 & 255) <= (wb2 & 255) ? wb2 : wb1;
+        blo = wl & 255; bhi = wh & 255; tlo = wl >> 8; thi = wh >> 8;
       }
     }
   }
@@ -459,7 +464,7 @@ DEV void fs_hessian(const Ctx &c) {
     for (int side = 0; side < 2; side++) {
       int b = side ? bhi : blo;
       if (b == 0) continue;
-      V3 rr = pos - ldv3(L + ly.com + 3 * KI(r_tree, b));
+      V3 rr = pos - ldv3(L + ly.com + 3 * (side ? thi : tlo));
       // G[:, c] = rr x K[:, c]  (K symmetric: column c = row c); stored by rows G_a = (G[a][0], G[a][1], G[a][2])
       V3 c0 = cross(rr, K0), c1 = cross(rr, K1), c2 = cross(rr, K2);
       V3 G0 = v3(c0.x, c1.x, c2.x), G1 = v3(c0.y, c1.y, c2.y), G2 = v3(c0.z, c1.z, c2.z);
@@ -473,12 +478,19 @@ DEV void fs_hessian(const Ctx &c) {
       if (side == 0) { Glo0 = G0; Glo1 = G1; Glo2 = G2; } else rhi = rr;
     }
   }
+  // the subtree sums are only needed when a non-root body (a robot link beyond the base) carries a contact block
+  const bool deep = on && ((blo > 0 && KI(r_parent, blo) > 0) || (bhi > 0 && KI(r_parent, bhi) > 0));
   SYNC();
   // ---- composite blocks: children are numbered after their parents
-  for (int b = m.nr - 1; b >= 1; b--) {
-    int p = KI(r_parent, b);
-    if (p > 0 && c.lane < 21) A[21 * p + c.lane] += A[21 * b + c.lane];
-    if (p > 0) SYNC();
+  if (__ballot(deep)) {
+    // lane = component: a lane only ever touches its own component of every block, so the child -> parent chain needs
+    // no barrier (a wave's LDS operations complete in order)
+    if (c.lane < 21)
+      for (int b = m.nr - 1; b >= 1; b--) {
+        int p = KI(r_parent, b);
+        if (p > 0) A[21 * p + c.lane] += A[21 * b + c.lane];
+      }
+    SYNC();
   }
   // ---- tree blocks on M's pattern: lane = M entry
   for (int e = c.lane; e < m.nM; e += 64) {

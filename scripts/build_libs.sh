@@ -1,8 +1,14 @@
 #!/bin/bash
-# builds libfsim.so and the -DFSIM_PROFILE development variant
+# builds libfsim.so and the -DFSIM_PROFILE development variant; fails loudly
 cd "$(dirname "$0")/.." || exit 1
+rc=0
 for f in "" "-DFSIM_PROFILE"; do
   out=libfsim.so; [ -n "$f" ] && out=libfsim_prof.so
-  hipcc --offload-arch=gfx950 -O3 -fno-hip-fp32-correctly-rounded-divide-sqrt -std=c++17 -shared -fPIC -Wno-unused-value $f -o furniture_amd/csrc/$out furniture_amd/csrc/fsim.hip 2>&1 | grep -E "error" -A6 | head -20; [ ${PIPESTATUS[0]} -eq 0 ] || echo "BUILD FAILED: $out"
+  if ! hipcc --offload-arch=gfx950 -O3 -fno-hip-fp32-correctly-rounded-divide-sqrt -std=c++17 -shared -fPIC -Wno-unused-value $f -o furniture_amd/csrc/$out.tmp furniture_amd/csrc/fsim.hip > /tmp/build_libs.log 2>&1; then
+    echo "BUILD FAILED: $out"; grep -E "error" -A4 /tmp/build_libs.log | head -30; rc=1; rm -f furniture_amd/csrc/$out.tmp
+  else
+    mv furniture_amd/csrc/$out.tmp furniture_amd/csrc/$out
+  fi
 done
 ls -la furniture_amd/csrc/*.so | awk '{print $5, $6, $7, $8, $9}'
+exit $rc
