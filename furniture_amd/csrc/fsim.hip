@@ -147,6 +147,21 @@ __global__ void k_copy_field(float *state, int stride, int off, int dim, float *
   if (to_state) state[(size_t)e * stride + off + k] = ext[i];
   else ext[i] = state[(size_t)e * stride + off + k];
 }
+// Cursor agent: [pos0 pos1 sel0 sel1] <-> the EC_* block of the env record (selection stored as int part + 1)
+__global__ void k_copy_cursor(float *state, int stride, int off, float *ext, int n_envs, int to_state) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  float *ec = state + (size_t)e * stride + off;
+  int *eci = reinterpret_cast<int *>(ec);
+  float *x = ext + (size_t)e * 8;
+  if (to_state) {
+    for (int k = 0; k < 6; k++) { ec[EC_POS + k] = x[k]; ec[EC_XPOS + k] = x[k]; }
+    eci[EC_SEL] = (int)x[6]; eci[EC_SEL + 1] = (int)x[7];
+  } else {
+    for (int k = 0; k < 6; k++) x[k] = ec[EC_POS + k];
+    x[6] = (float)eci[EC_SEL]; x[7] = (float)eci[EC_SEL + 1];
+  }
+}
 // geom_contype/conaffinity live per colliding geom; the C-ABI speaks original geom ids
 __global__ void k_copy_geommask(float *state, int stride, int off, int ncg, const int *cg_orig, int ngeom, int *ext, int n_envs, int to_state) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,6 +256,7 @@ extern "C" void fsim_default_config(fsim_config_t *c) {
   c->alignment_pos_dist = 0.1f; c->alignment_rot_dist_up = 0.9f; c->alignment_rot_dist_forward = 0.9f; c->alignment_project_dist = 0.3f;
   c->ctrl_penalty_coef = 1e-3f; c->unstable_penalty_coef = 100.f; c->success_reward = 100.f; c->touch_reward = 10.f; c->pick_reward = 100.f;
   c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3.f; c->agent_xyz_rand = 0.001f;
+  c->move_speed = 0.1f; c->rotate_speed = 22.5f; c->cursor_boundary = 1.5f;
 }
 
 #define LF(field, name) do { std::vector<float> v_; if (!blob_f(s->blob, name, v_)) return FSIM_EINVAL; ar.add(&s->m.field, v_); } while (0)
@@ -275,6 +291,7 @@ static int build_model(fsim *s) {
   LI(cg_body, "cg_body"); LI(cg_type, "cg_type"); LI(cg_condim, "cg_condim"); LI(cg_partid, "cg_partid"); LI(cg_fingerrole, "cg_fingerrole");
   LI(cg_isfloor, "cg_isfloor"); LI(cg_isrobot, "cg_isrobot"); LI(cg_ispartcol, "cg_ispartcol"); LI(cg_orig, "cg_orig");
   LI(cg_contype0, "cg_contype0"); LI(cg_conaffinity0, "cg_conaffinity0");
+  LI(cg_cursor, "cg_cursor"); LI(cg_namepart, "cg_namepart"); LF(cursor_pos0, "cursor_pos0");
   LF(cg_pos, "cg_pos"); LF(cg_mat, "cg_mat"); LF(cg_size, "cg_size"); LF(cg_rbound, "cg_rbound"); LF(cg_friction, "cg_friction");
   LF(cg_solref, "cg_solref"); LF(cg_solimp, "cg_solimp"); LF(cg_margin, "cg_margin"); LF(cg_gap, "cg_gap"); LF(cg_solmix, "cg_solmix");
   LF(cg_invweight, "cg_invweight");
@@ -529,6 +546,12 @@ static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if ((rc = copy_field(s, ly.eqdata, 7 * m.neq, p->eq_data, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqactive, m.neq, p->eq_active, to_state))) return rc;
   if ((rc = copy_field(s, ly.env + E_GROUP, m.nparts, p->group, to_state))) return rc;
+  if (p->cursor) {
+    if (m.agent != 2) FAIL(FSIM_EINVAL, "state field 'cursor' exists for the Cursor agent only");
+    int n = s->n_envs;
+    hipLaunchKernelGGL(k_copy_cursor, dim3((n + 63) / 64), dim3(64), 0, s->stream, s->d_state, ly.stride, ly.env + E_GROUP + m.nparts, p->cursor, n, to_state);
+    HIPCHK(hipGetLastError());
+  }
   for (int k = 0; k < 2; k++) {
     int32_t *ext = k == 0 ? p->geom_contype : p->geom_conaffinity;
     if (!ext) continue;

@@ -458,7 +458,12 @@ DEV void fs_collide(const Ctx &c) {
   for (int g = c.lane; g < m.ncg; g += 64) {
     int b = m.cg_body[g];
     M3 Rb = ldm3(L + ly.xmat + 9 * b);
-    stv3(L + ly.gpos + 3 * g, ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(m.cg_pos + 3 * g)));
+    V3 gp = ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(m.cg_pos + 3 * g));
+    if (m.agent == 2) { // cursor boxes are world geoms whose body_pos the env rewrites (furniture.py:3139)
+      int cm = m.cg_cursor[g];
+      if (cm) { int k = (cm & 1) ? 0 : 1; gp = gp + ldv3(L + ly.env + E_GROUP + m.nparts + EC_POS + 3 * k) - ldv3(m.cursor_pos0 + 3 * k); }
+    }
+    stv3(L + ly.gpos + 3 * g, gp);
     stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(m.cg_mat + 9 * g)));
   }
   SYNC();

@@ -18,6 +18,9 @@
 struct EnvCfg {
   int dof_action, obs_dim, n_substeps, max_episode_steps, discrete_grip, rescale_actions, auto_align, auto_reset, has_recipe, agent;
   float pos_dist, rot_up, rot_fwd, proj_dist, ctrl_penalty_coef, unstable_penalty_coef, success_reward, touch_reward, pick_reward;
+  // Cursor agent (furniture_cursor.py:28-32, config/furniture.py:84-90)
+  int num_connect_steps, gravity_comp;
+  float move_speed, rotate_speed, cursor_boundary;
 };
 struct EnvIO {
   const float *action;
@@ -30,12 +33,15 @@ struct EnvIO {
   long long t0;   // shader clock at kernel entry
 };
 
-static inline int env_extra_words(const DModel &, int) { return 0; }
+static inline int env_extra_words(const DModel &m, int) { return m.agent == 2 ? EC_WORDS : 0; }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
   e.agent = m.agent;
   e.dof_action = m.agent == 0 ? 9 : (m.agent == 1 ? 17 : 15);
-  e.obs_dim = 7 * m.nparts + 29 * m.narm;
+  e.obs_dim = 7 * m.nparts + (m.agent == 2 ? 8 : 29 * m.narm);
+  e.num_connect_steps = m.agent == 2 ? (c.num_connect_steps > 0 ? c.num_connect_steps : 10) : c.num_connect_steps;
+  e.gravity_comp = m.agent == 2;
+  e.move_speed = c.move_speed; e.rotate_speed = c.rotate_speed; e.cursor_boundary = c.cursor_boundary;
   e.n_substeps = c.n_substeps; e.max_episode_steps = c.max_episode_steps; e.discrete_grip = c.discrete_grip;
   e.rescale_actions = c.rescale_actions; e.auto_align = c.auto_align; e.auto_reset = c.auto_reset;
   e.has_recipe = 0;
@@ -83,6 +89,10 @@ DEV void fs_forward_body(const Ctx &c) {
 #define FS_PROF(slot) do { } while (0)
 #endif
   fs_kinematics(c);
+  if (c.m.agent == 2 && c.lane < 6) { // data.xpos of the cursor bodies follows model.body_pos at every forward pass
+    float *ec = c.L + c.ly.env + E_GROUP + c.m.nparts;
+    ec[EC_XPOS + c.lane] = ec[EC_POS + c.lane];
+  }
   FS_PROF(16);
   fs_com_inertia(c);
   FS_PROF(17);
@@ -117,6 +127,21 @@ DEV void fs_forward_body(const Ctx &c) {
     if (sc_[SC_NSURV] > sc_[52]) sc_[52] = sc_[SC_NSURV];
   }
 #endif
+  if (c.m.agent == 2) {
+    // parts named in a contact with cursor K (on_collision, furniture.py:3290-3310): kept in the env block because the
+    // env reads data.contact of the PREVIOUS step when it selects (and LDS does not survive the launch)
+    int t0m = 0, t1m = 0;
+    int ns = c.I(c.ly.scal)[SC_NSLOT];
+    for (int s_ = c.lane; s_ < ns; s_ += 64) {
+      const int *ri = c.I(c.ly.con + FSIM_CONW * s_);
+      if (!ri[C_ACTIVE]) continue;
+      int cm = c.m.cg_cursor[ri[C_G1]] | c.m.cg_cursor[ri[C_G2]], pm = c.m.cg_namepart[ri[C_G1]] | c.m.cg_namepart[ri[C_G2]];
+      if (cm & 1) t0m |= pm;
+      if (cm & 2) t1m |= pm;
+    }
+    t0m = wave_or(t0m); t1m = wave_or(t1m);
+    if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.m.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
+  }
   // instability guard (mj_checkAcc analogue): NaN / huge accelerations
   int bad = 0;
   for (int d = c.lane; d < c.m.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }
@@ -278,8 +303,95 @@ DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
 }
 
 // ---------------------------------------------------------------------------------------------------- connect
-// returns (wave-uniform) 1 if a connection was made.  part1 = part both fingers pinch.
-DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
+DEV int env_ecur(const Ctx &c) { return c.ly.env + E_GROUP + c.m.nparts; }
+
+// euler_to_quat(rotation_deg, quat) = quat * (qz * qy * qx)   (transform_utils.py:617-630)
+DEV Q4 env_euler_quat(V3 deg, Q4 q) {
+  const float k = 3.14159265358979f / 180.0f;
+  Q4 qx = axisangle(v3(1, 0, 0), deg.x * k), qy = axisangle(v3(0, 1, 0), deg.y * k), qz = axisangle(v3(0, 0, 1), deg.z * k);
+  return qmul(q, qmul(qz, qmul(qy, qx)));
+}
+// quat_slerp (transform_utils.py:122-160), shortest path, no spin
+DEV Q4 env_slerp(Q4 q0, Q4 q1, float fraction) {
+  Q4 a = qnormalized(q0), b = qnormalized(q1);
+  if (fraction == 0.0f) return a;
+  if (fraction == 1.0f) return b;
+  float d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
+  const float eps = 8.8817841970012523e-16f; // numpy float64 eps * 4, as in the reference
+  if (fabsf(fabsf(d) - 1.0f) < eps) return a;
+  if (d < 0.0f) { d = -d; b = q4(-b.w, -b.x, -b.y, -b.z); }
+  d = fminf(d, 1.0f);
+  float ang = acosf(d);
+  if (fabsf(ang) < eps) return a;
+  float isin = 1.0f / sinf(ang), sa = sinf((1.0f - fraction) * ang) * isin, sb = sinf(fraction * ang) * isin;
+  return q4(a.w * sa + b.w * sb, a.x * sa + b.x * sb, a.y * sa + b.y * sb, a.z * sa + b.z * sb);
+}
+
+// _stop_selected_objects (furniture.py:771-779): every part in a selected group is frozen with gravity compensation
+DEV void env_stop_selected(const Ctx &c, float gravity) {
+  const DModel &m = c.m;
+  if (c.lane == 0) {
+    int *grp = c.I(c.ly.env + E_GROUP);
+    const int *ec = c.I(env_ecur(c));
+    for (int i = 0; i < m.nparts; i++) {
+      int g = env_find(grp, i);
+      for (int k = 0; k < 2; k++)
+        if (ec[EC_SEL + k] && env_find(grp, ec[EC_SEL + k] - 1) == g) { env_stop_part(c, i, gravity); break; }
+    }
+  }
+  SYNC();
+}
+
+// _move_rotate_object (furniture.py:708-745): rigidly rotate the weld group of `part` by rot_deg about the part and shift
+// it by `move`, validate with one forward+step and the site bounding box (_is_inside), undo the poses if it left the
+// workspace.  returns (wave-uniform) 1 if the move was kept.
+DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) {
+  const DModel &m = c.m;
+  int *grp = c.I(c.ly.env + E_GROUP);
+  int *scal = c.I(c.ly.scal);
+  // old part poses stay in registers (lane i keeps word i of the [nparts][7] pose table) so the move can be undone
+  float keep[2] = {0, 0};
+  for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + m.part_qposadr[i / 7] + i % 7]; }
+  SYNC();
+  if (c.lane == 0) {
+    int g = env_find(grp, part);
+    int a0 = m.part_qposadr[part];
+    Q4 bq = ldq(c.L + c.ly.qpos + a0 + 3);
+    V3 bp = ldv3(c.L + c.ly.qpos + a0);
+    Q4 target = env_euler_quat(rot_deg, bq);
+    for (int i = 0; i < m.nparts; i++) {
+      if (env_find(grp, i) != g) continue;
+      int a = m.part_qposadr[i];
+      V3 np_; Q4 nq;
+      env_ttq(bp, bq, ldv3(c.L + c.ly.qpos + a), ldq(c.L + c.ly.qpos + a + 3), target, &np_, &nq);
+      stv3(c.L + c.ly.qpos + a, np_ + move);
+      stq(c.L + c.ly.qpos + a + 3, nq);
+    }
+  }
+  SYNC();
+  fs_step(c);
+  if (c.lane == 0) {
+    V3 mn, mx; env_bbox(c, part, &mn, &mx);
+    int inside = !(mn.x < -bnd || mn.y < -bnd || mn.z < -0.05f || mx.x > bnd || mx.y > bnd || mx.z > bnd);
+    scal[12] = inside;
+    scal[13] = env_find(grp, part);
+  }
+  SYNC();
+  int inside = scal[12];
+  if (!inside) {
+    int g = scal[13];
+    for (int r = 0; r < 2; r++) {
+      int i = c.lane + 64 * r;
+      if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + m.part_qposadr[pi] + i % 7] = keep[r]; }
+    }
+    SYNC();
+  }
+  return inside;
+}
+
+// _try_connect(part1, part2) (furniture.py:926-1042).  part2 < 0: any part (the arm agents).  returns (wave-uniform) 1 if a
+// connection was made; with num_connect_steps > 0 (Cursor) an aligned pair is first approached over that many calls.
+DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
   const DModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
@@ -287,11 +399,20 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
   // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
   if (c.lane == 0) {
     int found1 = -1, found2 = -1;
-    if (m.neq > 0 && m.nconn > 0) {
-      int g1 = env_find(grp, part1);
+    bool weld_ok = m.neq > 0 && m.nconn > 0;
+    int g1 = env_find(grp, part1), g2 = part2 >= 0 ? env_find(grp, part2) : -1;
+    if (weld_ok && part2 >= 0) { // some <weld> must join two bodies of group(part1) U group(part2) (activity is not checked)
+      weld_ok = false;
+      for (int i = 0; i < m.neq && !weld_ok; i++) {
+        int ga = env_find(grp, m.eq_part1[i]), gb = env_find(grp, m.eq_part2[i]);
+        weld_ok = (ga == g1 || ga == g2) && (gb == g1 || gb == g2);
+      }
+    }
+    if (weld_ok) {
       for (int k1 = 0; k1 < m.nconn && found1 < 0; k1++) {
         if (env_find(grp, m.conn_partid[k1]) != g1) continue;
         for (int k2 = 0; k2 < m.nconn; k2++) {
+          if (g2 >= 0 && env_find(grp, m.conn_partid[k2]) != g2) continue;
           if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
           if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
           int a1 = m.conn_keya[k1], b1 = m.conn_keyb[k1], a2 = m.conn_keya[k2], b2 = m.conn_keyb[k2];
@@ -301,7 +422,32 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
         }
       }
     }
-    E[E_CONNECT_STEP] = 0;
+    if (found1 >= 0 && E[E_CONNECT_STEP] < cfg.num_connect_steps) {
+      // approach phase (furniture.py:993-1034): slerp / lerp part2's group towards the aligned pose, one increment per call
+      const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP];
+      float *ec = c.L + env_ecur(c);
+      int p2 = m.conn_partid[found2], a = m.part_qposadr[p2];
+      V3 p2p = ldv3(c.L + c.ly.qpos + a); Q4 p2q = ldq(c.L + c.ly.qpos + a + 3);
+      if (step == 0) {
+        V3 s1p, s2p; Q4 s2q;
+        env_site_pose(c, m.conn_siteid[found1], &s1p, nullptr, nullptr);
+        env_site_pose(c, m.conn_siteid[found2], &s2p, &s2q, nullptr);
+        V3 bpos; Q4 brot;
+        env_ttq(s2p, s2q, p2p, p2q, ldq(c.L + c.ly.env + E_TARGET_QUAT), &bpos, &brot);
+        bpos = bpos + (s1p - s2p);
+        stv3(ec + EC_P2Q0, p2p); stq(ec + EC_P2Q0 + 3, p2q); stv3(ec + EC_BODY_POS, bpos); stq(ec + EC_BODY_ROT, brot);
+      }
+      V3 p0 = ldv3(ec + EC_P2Q0), bpos = ldv3(ec + EC_BODY_POS);
+      Q4 q0 = ldq(ec + EC_P2Q0 + 3), brot = ldq(ec + EC_BODY_ROT);
+      float lo = 1.0f / n, x = n > 1 ? lo + (0.9f - lo) * step / (n - 1) : lo; // np.linspace(1/n, 0.9, n)[step]
+      V3 npos = p0 + (bpos - p0) * x;
+      Q4 nrot = env_slerp(q0, brot, (float)(step + 1) / n);
+      env_move_group(c, p2, npos - p2p, nrot, 1.0f);
+      E[E_CONNECT_STEP] = step + 1;
+      found1 = -1;
+    } else {
+      E[E_CONNECT_STEP] = 0;
+    }
     scal[9] = found1; scal[10] = found2;
   }
   SYNC();
@@ -333,10 +479,11 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
       env_ttq(s2p, s2q, bp, bq, target, &npos, &nquat);
       V3 nsp; Q4 nsq;
       env_ttq(bp, bq, s2p, s2q, nquat, &nsp, &nsq);
-      env_move_group(c, pB, s1p - nsp, nquat, 0.0f);
+      env_move_group(c, pB, s1p - nsp, nquat, cfg.gravity_comp ? 1.0f : 0.0f);
     }
   }
   SYNC();
+  if (m.agent == 2) env_stop_selected(c, 1.0f);
   fs_step(c);
   if (c.lane == 0) {
     V3 mn1, mx1, mn2, mx2;
@@ -348,48 +495,10 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
   float mz = reinterpret_cast<float *>(scal)[11];
   if (mz < 0) {
     // _move_rotate_object(body, [0,0,-min z], [0,0,0]) for both bodies; each validates with forward+step (_is_inside)
-    for (int which = 0; which < 2; which++) {
-      int part = which ? pB : pA;
-      // old part poses stay in registers (lane i keeps word i of the [nparts][7] pose table) so the move can be undone
-      float keep[2] = {0, 0};
-      for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + m.part_qposadr[i / 7] + i % 7]; }
-      SYNC();
-      if (c.lane == 0) {
-        int g = env_find(grp, part);
-        int a0 = m.part_qposadr[part];
-        Q4 bq = ldq(c.L + c.ly.qpos + a0 + 3);
-        V3 bp = ldv3(c.L + c.ly.qpos + a0);
-        for (int i = 0; i < m.nparts; i++) {
-          if (env_find(grp, i) != g) continue;
-          int a = m.part_qposadr[i];
-          V3 np_; Q4 nq;
-          env_ttq(bp, bq, ldv3(c.L + c.ly.qpos + a), ldq(c.L + c.ly.qpos + a + 3), bq, &np_, &nq);
-          stv3(c.L + c.ly.qpos + a, np_ + v3(0, 0, -mz));
-          stq(c.L + c.ly.qpos + a + 3, nq);
-        }
-      }
-      SYNC();
-      fs_step(c);
-      if (c.lane == 0) {
-        V3 mn, mx; env_bbox(c, part, &mn, &mx);
-        const float bnd = 1.5f;
-        int inside = !(mn.x < -bnd || mn.y < -bnd || mn.z < -0.05f || mx.x > bnd || mx.y > bnd || mx.z > bnd);
-        scal[12] = inside;
-      }
-      SYNC();
-      if (!scal[12]) {
-        int g = 0;
-        if (c.lane == 0) { g = env_find(grp, part); scal[13] = g; }
-        SYNC();
-        g = scal[13];
-        for (int r = 0; r < 2; r++) {
-          int i = c.lane + 64 * r;
-          if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + m.part_qposadr[pi] + i % 7] = keep[r]; }
-        }
-        SYNC();
-      }
-    }
+    env_move_rotate(c, pA, v3(0, 0, -mz), v3(0, 0, 0), cfg.cursor_boundary);
+    env_move_rotate(c, pB, v3(0, 0, -mz), v3(0, 0, 0), cfg.cursor_boundary);
   }
+  if (m.agent == 2) env_stop_selected(c, 1.0f);
   fs_step(c);
   if (c.lane == 0) {
     // _activate_weld(body1, body2)
@@ -407,6 +516,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
         grp[r1] = r2;
       }
     }
+    if (m.agent == 2) c.I(env_ecur(c))[EC_SEL + 1] = 0; // furniture.py:914-915
     E[E_NUM_CONNECTED] += 1;
     E[E_CONNECTED_THIS_STEP] = 1;
     E[E_CONNBODY1] = pA + 1;
@@ -416,6 +526,60 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1) {
   }
   SYNC();
   return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------- Cursor agent
+// _step_discrete (furniture.py:800-845) + helpers _move_cursor / _select_object (furniture.py:700-798, 3290-3310).
+DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
+  const DModel &m = c.m;
+  int *E = c.I(c.ly.env);
+  int *grp = E + E_GROUP;
+  int *scal = c.I(c.ly.scal);
+  int *eci = c.I(env_ecur(c));
+  float *ecf = c.L + env_ecur(c);
+  const float b = cfg.cursor_boundary;
+  for (int k = 0; k < 2; k++) {
+    V3 move = v3(a[7 * k], a[7 * k + 1], a[7 * k + 2]) * cfg.move_speed;
+    V3 rot = v3(a[7 * k + 3], a[7 * k + 4], a[7 * k + 5]) * cfg.rotate_speed;
+    bool select = a[7 * k + 6] > 0;
+    if (c.lane == 0) {
+      if (!select) eci[EC_SEL + k] = 0;
+      V3 pos = ldv3(ecf + EC_XPOS + 3 * k) + move; // _cursor_pos() reads data.xpos
+      int ok = fabsf(pos.x) < b && fabsf(pos.y) < b && fabsf(pos.z) < b && pos.z >= cfg.move_speed * 0.45f;
+      if (ok) stv3(ecf + EC_POS + 3 * k, pos);
+      scal[9] = ok; scal[10] = eci[EC_SEL + k];
+    }
+    SYNC();
+    if (!scal[9]) continue;
+    int sel = scal[10];
+    if (sel) {
+      if (!env_move_rotate(c, sel - 1, move, rot, b)) {
+        if (c.lane == 0) { // _move_cursor(k, -move): data.xpos already reflects the moved cursor (forward ran inside _is_inside)
+          V3 pos = ldv3(ecf + EC_XPOS + 3 * k) - move;
+          if (fabsf(pos.x) < b && fabsf(pos.y) < b && fabsf(pos.z) < b && pos.z >= cfg.move_speed * 0.45f) stv3(ecf + EC_POS + 3 * k, pos);
+        }
+        SYNC();
+        continue;
+      }
+    }
+    if (c.lane == 0 && select && eci[EC_SEL + k] == 0) {
+      // _select_object: first part (in part order) not in an already selected group that touches this cursor
+      int hit = 0;
+      for (int i = 0; i < m.nparts && !hit; i++) {
+        int g = env_find(grp, i);
+        bool taken = false;
+        for (int q = 0; q < 2; q++) if (eci[EC_SEL + q] && env_find(grp, eci[EC_SEL + q] - 1) == g) taken = true;
+        if (taken) continue;
+        if ((eci[EC_TOUCH + k] >> i) & 1) hit = i + 1;
+      }
+      eci[EC_SEL + k] = hit;
+    }
+    SYNC();
+  }
+  float connect = a[14];
+  int s0 = eci[EC_SEL], s1 = eci[EC_SEL + 1];
+  if (connect > 0 && s0 && s1) env_try_connect(c, cfg, s0 - 1, s1 - 1);
+  else { if (c.lane == 0 && E[E_CONNECT_STEP] > 0) E[E_CONNECT_STEP] = 0; SYNC(); }
 }
 
 // ---------------------------------------------------------------------------------------------------- observation / reward
@@ -430,6 +594,11 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     io.obs[i] = k < 3 ? L[ly.xpos + 3 * b + k] : L[ly.xquat + 4 * b + k - 3];
   }
   int base = 7 * m.nparts;
+  if (m.agent == 2) { // furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
+    const float *ec = L + ly.env + E_GROUP + m.nparts;
+    if (c.lane < 6) io.obs[base + c.lane] = ec[EC_XPOS + c.lane];
+    if (c.lane < 2) io.obs[base + 6 + c.lane] = reinterpret_cast<const int *>(ec)[EC_SEL + c.lane] ? 1.0f : 0.0f;
+  }
   for (int arm = 0; arm < m.narm; arm++) {
     float *o = io.obs + base + 29 * arm;
     int nj = m.narmj / m.narm;
@@ -461,8 +630,12 @@ DEV void env_gravity_comp(const Ctx &c) {
   for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qfrcapp + m.grip_dofadr[k]] = c.L[c.ly.qfrcbias + m.grip_dofadr[k]];
   SYNC();
 }
-DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw) {
+DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw, float move_speed) {
   const DModel &m = c.m;
+  if (m.agent == 2 && c.lane < 2) { // furniture.py:1763-1768: cursors at x = -+0.2, half a move step above the floor
+    float *p = c.L + c.ly.env + E_GROUP + m.nparts + EC_POS + 3 * c.lane;
+    p[0] = c.lane ? 0.2f : -0.2f; p[1] = 0.0f; p[2] = move_speed * 0.5f;
+  }
   for (int k = c.lane; k < m.narmj; k += 64) {
     float noise = io.tab_noise ? io.tab_noise[(size_t)min(draw, io.n_noise - 1) * m.narmj + k] : 0.0f;
     c.L[c.ly.qpos + m.arm_qposadr[k]] = m.arm_initqpos[k] + noise;
@@ -514,6 +687,7 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   SYNC();
   for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
   for (int p = c.lane; p < m.nparts; p += 64) E[E_GROUP + p] = p;
+  if (m.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + m.nparts + i] = 0;
   SYNC();
   if (c.lane == 0) { E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; }
   // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
@@ -524,15 +698,15 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   SYNC();
   env_settle_parts(c);
   if (cfg.has_recipe) env_settle_parts(c);
-  if (m.narm > 0) {
-    env_gravity_comp(c);
-    env_init_robot(c, io, 0);
+  {
+    if (m.narm > 0) env_gravity_comp(c);
+    env_init_robot(c, io, 0, cfg.move_speed);
     fs_step(c);
     for (int g = c.lane; g < m.ncg; g += 64)
       if (m.cg_isrobot[g]) { c.I(ly.contype)[g] = m.cg_contype0[g]; c.I(ly.conaff)[g] = m.cg_conaffinity0[g]; }
     SYNC();
-    env_gravity_comp(c);
-    for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k); fs_step(c); }
+    if (m.narm > 0) env_gravity_comp(c);
+    for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k, cfg.move_speed); fs_step(c); }
   }
   for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
   for (int i = c.lane; i < m.nv; i += 64) { L[ly.qfrcapp + i] = 0; L[ly.qaccws + i] = 0; }
@@ -571,9 +745,28 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     L[ly.ctrl + u] = cfg.rescale_actions ? m.ctrl_bias[u] + m.ctrl_weight[u] * a : a;
   }
   SYNC();
-  env_gravity_comp(c);
-  // _do_simulation: n_substeps x sim.step()
-  fs_substeps(c, cfg.n_substeps, 2);
+  if (m.agent == 2) {
+    // FurnitureCursorEnv._step: _step_discrete(a) then _do_simulation(None) (furniture_cursor.py:59-70, furniture.py:2857-2897)
+    connect = 0; // the arm agents' finger scan below does not apply
+    env_cursor_discrete(c, cfg, io.action);
+    if (c.lane == 0) { // parts in a selected group float (gravity compensated), the others are only stopped
+      int *grp = E + E_GROUP;
+      const int *eci = c.I(env_ecur(c));
+      for (int i = 0; i < m.nparts; i++) {
+        int g = env_find(grp, i);
+        bool sel = false;
+        for (int q = 0; q < 2; q++) if (eci[EC_SEL + q] && env_find(grp, eci[EC_SEL + q] - 1) == g) sel = true;
+        env_stop_part(c, i, sel ? 1.0f : 0.0f);
+      }
+    }
+    SYNC();
+    fs_substeps(c, cfg.n_substeps, 0);
+    env_stop_selected(c, 1.0f);
+  } else {
+    env_gravity_comp(c);
+    // _do_simulation: n_substeps x sim.step()
+    fs_substeps(c, cfg.n_substeps, 2);
+  }
   int bad = scal[SC_BAD] & 2;
   if (bad) {
     // unstable simulation: reset inside step(), flag the failure (furniture.py:2889-2897)
@@ -588,7 +781,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
       if (!both) continue;
       int part = __ffs(both) - 1;
-      done_connect = env_try_connect(c, cfg, part); // break after the first pinched part either way (quirk Q4)
+      done_connect = env_try_connect(c, cfg, part, -1); // break after the first pinched part either way (quirk Q4)
     }
   }
   // post-connect re-pose of body1's (merged) group (furniture.py:426-436)
@@ -598,7 +791,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       int pA = E[E_CONNBODY1] - 1;
       V3 tp = ldv3(L + ly.env + E_CB1_POS);
       Q4 tq = ldq(L + ly.env + E_CB1_QUAT);
-      env_move_group(c, pA, tp - ldv3(L + ly.qpos + m.part_qposadr[pA]), tq, 0.0f);
+      env_move_group(c, pA, tp - ldv3(L + ly.qpos + m.part_qposadr[pA]), tq, cfg.gravity_comp ? 1.0f : 0.0f);
       E[E_CONNBODY1] = 0;
     }
     SYNC();
@@ -610,7 +803,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   {
     float s2 = 0;
     for (int k = c.lane; k < dof; k += 64) s2 += io.action[k] * io.action[k];
-    ctrl_pen = -cfg.ctrl_penalty_coef * wave_sum(s2);
+    ctrl_pen = m.agent == 2 ? 0.0f : -cfg.ctrl_penalty_coef * wave_sum(s2); // (wave_sum is evaluated by all lanes either way)
   }
   int success = 0, terminal = 0;
   // scheduler hint: is a robot hand within 10 cm of a furniture part's collision geom?  (an env about to enter robot-part

@@ -36,7 +36,8 @@ struct DModel {
   const float *lim_range, *lim_margin, *lim_solref, *lim_solimp;
   // colliding geoms
   const int *cg_body, *cg_type, *cg_condim, *cg_partid, *cg_fingerrole, *cg_isfloor, *cg_isrobot, *cg_ispartcol, *cg_orig,
-      *cg_contype0, *cg_conaffinity0;
+      *cg_contype0, *cg_conaffinity0, *cg_cursor, *cg_namepart; // cg_cursor: bit K = geom of cursor K; cg_namepart: parts named in the geom's name
+  const float *cursor_pos0; // [2][3] model body_pos of the cursor bodies (Cursor agent)
   const float *cg_pos, *cg_mat, *cg_size, *cg_rbound, *cg_friction, *cg_solref, *cg_solimp, *cg_margin, *cg_gap, *cg_solmix, *cg_invweight;
   const int *cp; // [ncp][3] = cg1, cg2, pair type
   // [ncp][16] one 64-byte record per candidate pair with everything the broad/narrow phase needs from the two geoms:
@@ -88,3 +89,8 @@ enum {
   E_GROUP, // nparts ints follow
   E_FIXED_WORDS = E_GROUP
 };
+// Cursor agent block, placed after the group table (env_extra_words): word offsets relative to Layout::env + E_GROUP + nparts
+enum { EC_SEL = 0 /* 2 ints: selected part + 1, 0 = none */, EC_POS = 2 /* model.body_pos of the two cursors */,
+       EC_XPOS = 8 /* data.xpos of the cursors = EC_POS as of the last forward pass */,
+       EC_P2Q0 = 14 /* gradual connect (furniture.py:993-1034): part pose at connect step 0 */, EC_BODY_POS = 21, EC_BODY_ROT = 24,
+       EC_TOUCH = 28 /* 2 ints: parts in contact with cursor K at the last forward pass */, EC_WORDS = 30 };

@@ -167,11 +167,9 @@ class FurnitureBatchEnv:
             setattr(cfg, k, v)
         if cfg.unity or cfg.record_vid or cfg.visual_ob:
             raise ValueError("unity / record_vid / visual_ob must be False: rendering is outside the accelerated hot path")
-        if cfg.control_type != "impedance":
+        if agent != "Cursor" and cfg.control_type != "impedance":
             raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' (ik needs pybullet; "
                                       "the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl)" % cfg.control_type)
-        if agent == "Cursor":
-            raise NotImplementedError("FurnitureCursorEnv is CPU-checker-only in this round (BASELINE config 1)")
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         names = furniture_names()
@@ -187,6 +185,9 @@ class FurnitureBatchEnv:
                   "ctrl_penalty_coef", "unstable_penalty_coef", "success_reward", "touch_reward", "pick_reward",
                   "furn_xyz_rand", "furn_rot_rand", "agent_xyz_rand"):
             setattr(c, k, float(getattr(cfg, k)))
+        for k in ("move_speed", "rotate_speed", "cursor_boundary"):  # Cursor agent (config/furniture.py:84-90)
+            if getattr(cfg, k, None) is not None:
+                setattr(c, k, float(getattr(cfg, k)))
         if getattr(cfg, "solver_tolerance", None) is not None:
             c.solver_tolerance = float(cfg.solver_tolerance)
         self.sim = FSim(self.model, num_envs, device=device, config=c)

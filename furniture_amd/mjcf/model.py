@@ -65,14 +65,40 @@ class CompiledModel:
         meta = json.loads(bytes(z["__meta__"]).decode())
         return CompiledModel(arrays, meta)
 
+    def _cursor_tables(self):
+        """Tables the device Cursor agent needs, derived from the stored arrays and names (furniture.py:3290-3310
+        on_collision is a SUBSTRING match of 'cursorK' / the part name on the two geom names of a contact):
+        cg_cursor[g] = 1 + K for the colliding geom of cursor K (else 0); cursor_pos0 = model body_pos of the two
+        cursor bodies; cg_namepart[g] = bitmask of the parts whose name is a substring of colliding geom g's name."""
+        A = self.arrays
+        ncg = len(A["cg_orig"])
+        cur = np.zeros(ncg, dtype=np.int32)
+        pos0 = np.zeros(6, dtype=np.float64)
+        names = self.meta.get("geom_names", [])
+        parts = self.meta.get("part_names", [])
+        namepart = np.zeros(ncg, dtype=np.int32)
+        for g in range(ncg):
+            nm = names[int(A["cg_orig"][g])] if names else ""
+            for k in range(2):
+                if ("cursor%d" % k) in nm:
+                    cur[g] |= 1 << k
+            for i, pn in enumerate(parts):
+                if pn in nm:
+                    namepart[g] |= 1 << i
+        if "cursor_bodyid" in A and "body_pos" in A:
+            pos0 = np.asarray(A["body_pos"], dtype=np.float64).reshape(-1, 3)[np.asarray(A["cursor_bodyid"])].reshape(-1)
+        return {"cg_cursor": cur, "cursor_pos0": pos0, "cg_namepart": namepart}
+
     def to_blob(self):
         """magic, version, n, then n x {name[48], dtype(i32: 0=f64,1=i32), count(i64), offset(i64)}, data."""
-        names = sorted(self.arrays.keys())
+        arrays = dict(self.arrays)
+        arrays.update(self._cursor_tables())
+        names = sorted(arrays.keys())
         head = 8 + 4 + 4 + len(names) * (48 + 4 + 4 + 8 + 8)
         off = (head + 63) // 64 * 64
         table, chunks = [], []
         for n in names:
-            a = self.arrays[n]
+            a = arrays[n]
             if a.dtype.kind == "f":
                 a, code = np.ascontiguousarray(a, dtype="<f8"), 0
             else:

@@ -34,12 +34,13 @@ class FsimConfig(ctypes.Structure):
         ("ctrl_penalty_coef", ctypes.c_float), ("unstable_penalty_coef", ctypes.c_float), ("success_reward", ctypes.c_float),
         ("touch_reward", ctypes.c_float), ("pick_reward", ctypes.c_float),
         ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
+        ("move_speed", ctypes.c_float), ("rotate_speed", ctypes.c_float), ("cursor_boundary", ctypes.c_float),
     ]
 
 
 class StatePtrs(ctypes.Structure):
     _names = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_data", "eq_active",
-              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters"]
+              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters", "cursor"]
     _fields_ = [(n, ctypes.c_void_p) for n in _names]
 
 
@@ -157,13 +158,13 @@ class FSim:
                     qfrc_applied=(m.nv, "f"), xfrc_applied=(6 * m.nparts, "f"), eq_data=(7 * m.neq, "f"), eq_active=(m.neq, "i"),
                     geom_contype=(m.ngeom, "i"), geom_conaffinity=(m.ngeom, "i"), group=(m.nparts, "i"), qacc=(m.nv, "f"),
                     xpos=(3 * m.nbody, "f"), xquat=(4 * m.nbody, "f"), ncon=(1, "i"), contact_geoms=(2 * self.max_contacts, "i"),
-                    solver_iters=(1, "i"))
+                    solver_iters=(1, "i"), cursor=(8, "f"))
 
     def get_state(self, *names):
         """dict name -> torch tensor [n_envs, dim] (device)."""
         torch = self.torch
         shapes = self._field_shapes()
-        names = names or [n for n in shapes]
+        names = names or [n for n in shapes if n != "cursor" or self.cm.meta.get("agent") == "Cursor"]
         out, p = {}, StatePtrs()
         for n in names:
             dim, kind = shapes[n]

@@ -48,6 +48,7 @@ typedef struct fsim_config {
   float alignment_pos_dist, alignment_rot_dist_up, alignment_rot_dist_forward, alignment_project_dist;
   float ctrl_penalty_coef, unstable_penalty_coef, success_reward, touch_reward, pick_reward;
   float furn_xyz_rand, furn_rot_rand, agent_xyz_rand;
+  float move_speed, rotate_speed, cursor_boundary; /* Cursor agent: config/furniture.py move_speed 0.05? see furniture_cursor.py; degrees per step; workspace half-extent */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -83,6 +84,8 @@ typedef struct fsim_state_ptrs {
   float *qacc /* out only */, *xpos /* out only: [n, nbody*3] */, *xquat /* out only: [n, nbody*4] */;
   int32_t *ncon /* out only: [n] */, *contact_geoms /* out only: [n, max_contacts*2], -1 padded */;
   int32_t *solver_iters /* out only: [n] Newton iterations of the last substep */;
+  float *cursor /* Cursor agent only: [n, 8] = model.body_pos of cursor0, cursor1 (furniture.py:3139), then the selected part
+                   index + 1 of each cursor (0 = none) as floats (furniture_cursor.py _cursor_selected) */;
 } fsim_state_ptrs_t;
 int fsim_get_state(fsim_t *, const fsim_state_ptrs_t *dst);
 int fsim_set_state(fsim_t *, const fsim_state_ptrs_t *src);

@@ -69,3 +69,27 @@ def counter_actions(seed, env_index, t, dof):
     """U(-1,1)^dof float32 keyed by (seed, env, t) -- deterministic and independent of batch size / GPU count."""
     rs = np.random.RandomState((seed * 1000003 + env_index * 7919 + t * 104729) % (2 ** 31 - 1))
     return rs.uniform(-1, 1, dof).astype(np.float32)
+
+
+def cursor_attach_state(m, qpos, leg=0, table_conn=4, leg_conn=0, gap=0.03):
+    """Cursor + table_lack_0825: part ``leg`` hovers horizontally at (0, 0.3, 0.5) and the table hovers with its matching
+    connector ``gap`` metres from the leg's connector along the connector axis, forward vectors a multiple of 90 degrees
+    apart (an aligned pair for _is_aligned).  The other parts keep their poses.  Returns (qpos, table part index)."""
+    gx, gy, gz = np.eye(3)
+    q = qpos.copy()
+    leg_q = quat_from_axes(gy, gz, gx)  # leg's local z (its connector's up axis) along world x
+    leg_p = np.array([0.0, 0.3, 0.5])
+    a = m.part_qposadr[leg]
+    q[a:a + 3], q[a + 3:a + 7] = leg_p, leg_q
+    Rl = T.quat2mat_wxyz(leg_q)
+    leg_site_w = leg_p + Rl @ m.site_pos[m.conn_siteid[leg_conn]]
+    up = Rl[:, 2]
+    tpart = int(m.conn_partid[table_conn])
+    ta = m.part_qposadr[tpart]
+    tx = gz
+    Rt = np.stack([tx, np.cross(up, tx), up], axis=1)
+    table_q = quat_from_axes(Rt[:, 0], Rt[:, 1], Rt[:, 2])
+    table_site_w = leg_site_w + gap * up
+    q[ta:ta + 3] = table_site_w - Rt @ m.site_pos[m.conn_siteid[table_conn]]
+    q[ta + 3:ta + 7] = table_q
+    return q, tpart

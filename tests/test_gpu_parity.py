@@ -9,7 +9,7 @@ from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, INFO_DIM, default_config
 from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
 from oracle.oracle_sim import OracleSim
-from tests.scenarios import counter_actions, pinch_attach_state
+from tests.scenarios import counter_actions, cursor_attach_state, pinch_attach_state
 
 pytestmark = pytest.mark.gpu
 
@@ -238,6 +238,80 @@ def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack):
     assert np.abs(st["qpos"][0].cpu().numpy() - osim.data.qpos).max() < 2e-4
     assert np.abs(st["qvel"][0].cpu().numpy() - osim.data.qvel).max() < 5e-3
     assert torch.equal(st["qpos"][0], st["qpos"][n - 1])
+    sim.close()
+
+
+def test_cursor_agent_matches_oracle():
+    """FurnitureCursorEnv on the device: reset, random 15-dof steps (cursor moves, selection by contact), then
+    a scripted attach -- both cursors hold an aligned leg / table pair and ask to connect: ten approach steps
+    (slerp / lerp of the held group) and the connect itself, all against the oracle env."""
+    m = load_compiled("Cursor", "table_lack_0825")
+    n = 2
+    cfg = default_config()
+    cfg.max_episode_steps = 150
+    cfg.auto_reset = 0
+    sim = FSim(m, n, config=cfg)
+    assert sim.dof_action == 15 and sim.obs_dim == 7 * m.nparts + 8
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10)) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+    sim.set_reset_tables(parts, None)
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    for e in range(n):
+        assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(obs_o[e])).max() < 1e-4
+    act = torch.zeros((n, 15), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+
+    def step_both(a, tol):
+        act.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        out = []
+        for e in range(n):
+            ob, r, d, inf = envs[e].step(np.asarray(a[e], dtype=np.float64))
+            assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob)).max() < tol, (e, np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob)).max())
+            assert abs(float(rew[e]) - r) < 1e-4 and bool(done[e]) == d
+            out.append(inf)
+        return out
+
+    for t in range(6):  # cursors wander; select flags are random, selection needs a contact
+        step_both(np.stack([counter_actions(77, i, t, 15) for i in range(n)]), 5e-4)
+    # scripted attach
+    cur = sim.get_state("cursor")["cursor"].cpu().numpy()
+    qs = []
+    for e in range(n):
+        o = envs[e]
+        q, tpart = cursor_attach_state(m, o.sim.data.qpos.copy())
+        o.sim.data.qpos[:], o.sim.data.qvel[:], o.sim.data.qacc_warmstart[:] = q, 0, 0
+        o._cursor_selected = [0, tpart]
+        o._connect_step = 0
+        o.sim.forward()
+        qs.append(q)
+        cur[e, 6], cur[e, 7] = 0 + 1, tpart + 1
+    sim.set_state(qpos=np.stack(qs), qvel=np.zeros((n, m.nv)), qacc_warmstart=np.zeros((n, m.nv)), cursor=cur)
+    sim.physics_forward()
+    a = np.zeros((n, 15), dtype=np.float32)
+    a[:, 6] = a[:, 13] = 1.0   # keep both selections
+    a[:, 14] = 1.0             # connect
+    connected_at = None
+    for t in range(13):
+        infs = step_both(a, 2e-3)
+        gi = info.cpu().numpy()
+        for e in range(n):
+            assert (gi[e, 0], gi[e, 6]) == (infs[e]["num_connected"], infs[e]["connected_this_step"])
+        if infs[0]["connected_this_step"] and connected_at is None:
+            connected_at = t
+    assert connected_at == 10  # ten approach steps (_num_connect_steps = 10), then _connect
+    st = sim.get_state("eq_active", "eq_data", "cursor")
+    assert np.array_equal(st["eq_active"][0].cpu().numpy(), envs[0].sim.model.eq_active)
+    assert np.abs(st["eq_data"][0].cpu().numpy().reshape(-1, 7) - envs[0].sim.model.eq_data).max() < 2e-3
+    assert st["cursor"][0, 7].item() == 0  # _connect drops cursor 1's selection (furniture.py:914-915)
     sim.close()
 
 

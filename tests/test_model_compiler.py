@@ -66,7 +66,8 @@ def test_blob_roundtrip(sawyer_lack):
     blob = sawyer_lack.to_blob()
     assert blob[:8] == BLOB_MAGIC
     ver, n = struct.unpack("<ii", blob[8:16])
-    assert n == len(sawyer_lack.arrays)
+    derived = {"cg_cursor", "cursor_pos0", "cg_namepart"}  # Cursor-agent tables derived from names at blob time
+    assert n == len(sawyer_lack.arrays) + len(derived)
     found = {}
     for i in range(n):
         name, code, _, count, off = struct.unpack("<48siiqq", blob[16 + i * 72: 16 + (i + 1) * 72])
@@ -75,6 +76,7 @@ def test_blob_roundtrip(sawyer_lack):
         found[name] = np.frombuffer(blob, dtype=dt, count=count, offset=off)
     for k, v in sawyer_lack.arrays.items():
         assert np.array_equal(found[k], np.asarray(v).reshape(-1).astype(found[k].dtype)), k
+    assert derived <= set(found) and not found["cg_cursor"].any()  # no cursor geoms in a Sawyer scene
 
 
 def test_shipped_tables_match_fresh_compile(have_reference):
