@@ -388,3 +388,24 @@ def test_batched_env_surface():
     assert rew.shape == (8,) and done.dtype == torch.bool and int(info["episode_length"][0]) == 1
     assert torch.allclose(rew, torch.zeros_like(rew))  # zero action: no ctrl penalty, nothing touched
     env.close()
+
+
+def test_single_env_classes_incl_cursor():
+    """The reference-shaped single-env classes (gym surface B1): Sawyer and the Cursor agent (BASELINE config 1's env)."""
+    from furniture_amd.envs import FurnitureCursorEnv, FurnitureSawyerEnv, make_config
+    env = FurnitureCursorEnv(make_config(unity=False, record_vid=False, furniture_name="toy_table", max_episode_steps=20))
+    ob = env.reset()
+    assert ob["object_ob"].shape == (35,) and ob["robot_ob"].shape == (8,) and env.dof == 15
+    assert np.allclose(ob["robot_ob"][:6], [-0.2, 0, 0.05, 0.2, 0, 0.05], atol=1e-6)
+    rng = np.random.RandomState(123)
+    for _ in range(5):
+        ob, rew, done, info = env.step(rng.uniform(-1, 1, 15).astype(np.float32))
+        assert rew in (0.0, 100.0) and np.isfinite(ob["object_ob"]).all()
+        assert np.all(np.abs(ob["robot_ob"][:6]) < 1.5) and ob["robot_ob"][2] >= 0.045
+    env.close()
+    env = FurnitureSawyerEnv(make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                         max_episode_steps=20))
+    ob = env.reset()
+    ob, rew, done, info = env.step(np.zeros(9, dtype=np.float32))
+    assert ob["robot_ob"].shape == (29,) and not done
+    env.close()
