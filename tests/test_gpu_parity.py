@@ -86,6 +86,36 @@ def test_contact_trajectory_matches_oracle(sawyer_lack):
     sim.close()
 
 
+def test_thousand_substeps_within_1e4_of_oracle(sawyer_lack):
+    """north_star's bar: qpos/qvel within 1e-4 of the CPU path over 1000 (physics) steps on fixed seeds -- parts settling
+    on the floor with the arm gravity-compensated and a constant gripper command (fp32 device vs fp64 oracle)."""
+    m = sawyer_lack
+    n = 4
+    q, _ = _initial(m, n, np.random.RandomState(7), arm_noise=0.05)
+    sim = FSim(m, n)
+    sim.set_state(qpos=q, qvel=np.zeros((n, m.nv)), qacc_warmstart=np.zeros((n, m.nv)))
+    sim.physics_forward()
+    bias = sim.get_state("qfrc_bias")["qfrc_bias"].cpu().numpy()
+    rd = np.concatenate([m.arm_dofadr, m.grip_dofadr])
+    app = np.zeros((n, m.nv))
+    app[:, rd] = bias[:, rd]
+    sim.set_state(qfrc_applied=app)
+    sim.physics_step(1000)
+    st = sim.get_state("qpos", "qvel")
+    for e in range(2):
+        o = OracleSim(m)
+        o.set_solver(100, 1e-10, "newton")
+        o.reset()
+        o.data.qpos[:] = q[e]
+        o.forward()
+        o.data.qfrc_applied[rd] = o.data.qfrc_bias[rd]
+        for _ in range(1000):
+            o.step()
+        assert np.abs(st["qpos"][e].cpu().numpy() - o.data.qpos).max() < 1e-4
+        assert np.abs(st["qvel"][e].cpu().numpy() - o.data.qvel).max() < 1e-4
+    sim.close()
+
+
 def test_env_reset_steps_and_attach_match_oracle(sawyer_lack):
     m = sawyer_lack
     n = 4
