@@ -41,8 +41,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
             print("    SLOW env %d: Mcyc %.1f it/sub %.2f coupled %.2f | per-substep kcyc: " % (e, tot[e] / 1e6, nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e])) + " ".join("%s %.1f" % (n, v / 50e3) for n, v in zip(fn, fine[e])) + " | collide %.1f constraints %.1f" % (cyc[e, 1] / 50e3, cyc[e, 3] / 50e3))
     if t == 5:
         for e in list(np.argsort(-tot)[:2]) + [int(np.argsort(tot)[N // 2])]:
-            print("    env %d Cholesky split kcyc/substep (Newton + integrator solves): load rows %.1f factor %.1f forward %.1f store+backward %.1f" % (
-                e, pall[e, 32] * 16 / 50e3, pall[e, 33] * 16 / 50e3, pall[e, 34] * 16 / 50e3, pall[e, 37] * 16 / 50e3))
+            print("    env %d Hessian split kcyc/substep: zero+contact blocks %.1f composite %.1f tree projection %.1f body pairs %.1f limits+welds %.1f" % (
+                e, pall[e, 32] * 16 / 50e3, pall[e, 33] * 16 / 50e3, pall[e, 34] * 16 / 50e3, pall[e, 37] * 16 / 50e3, pall[e, 38] * 16 / 50e3))
     if t in (3, 8):
         order = np.argsort(-tot)[:5]
         for e in order:
