@@ -853,6 +853,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       io.info[FSIM_INFO_NEEDS_TABLE] = (terminal && cfg.auto_reset) ? 1 : 0;
       io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
+      io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
     }
     scal[14] = terminal;
     if (io.cost) {

@@ -255,7 +255,7 @@ class FurnitureBatchEnv:
         info = self._info
         infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
                      site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
-                     connected=info[:, INFO_CONNECTED_THIS_STEP])
+                     connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
         return self._split(self._obs), self._rew, self._done.bool(), infos
 
     def step(self, actions):

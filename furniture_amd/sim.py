@@ -16,7 +16,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 _LIBPATH = os.environ.get("FSIM_LIB", os.path.join(_CSRC, "libfsim.so"))
 _LIB = None
 
-INFO_DIM = 12
+INFO_DIM = 13
+INFO_OVERFLOW = 12
 INFO_NUM_CONNECTED, INFO_SUCCESS, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2, INFO_EPISODE_LENGTH = range(6)
 INFO_CONNECTED_THIS_STEP, INFO_NEEDS_TABLE, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F, INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F = range(6, 12)
 N_NOISE = 101  # _initialize_robot_pos draws per reset (furniture.py:1580, 1606-1611)

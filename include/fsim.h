@@ -112,7 +112,8 @@ enum {
   FSIM_INFO_NEEDS_TABLE = 7, /* env consumed its reset table this step */
   FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
   FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
-  FSIM_INFO_DIM = 12
+  FSIM_INFO_OVERFLOW = 12, /* bit 0: broadphase survivor list truncated, bit 1: contact slots exhausted (contacts dropped) in this step */
+  FSIM_INFO_DIM = 13
 };
 
 /* timing helper for bench.py: average device time (ms) of the last fsim_step kernel launches, measured with

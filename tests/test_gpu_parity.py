@@ -393,6 +393,7 @@ def test_baseline_size_properties(sawyer_lack):
         sim.step(act, obs, rew, done, info)
         sim.sync()
         assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert int((info[:, 12] != 0).sum()) <= n // 100  # contact-slot / survivor-list overflow is reported and rare
         dones.append(int(done.sum()))
     assert dones[:2] == [0, 0] and dones[2] == n and dones[3] == 0  # equality time limit (Q9) + auto-reset
     assert int(info[:, 5].max()) == 1  # episode_length restarted
