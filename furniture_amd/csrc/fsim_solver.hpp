@@ -345,10 +345,17 @@ DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
 }
 
 // grad = Mx - qfrc_smooth - J' f(jar)
-DEV void fs_gradient(const Ctx &c) {
+// What the gradient pass already knows about this lane's contact slot and the Hessian pass needs again: whether the
+// cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
+struct SlotK { bool on; float K[6]; };
+
+DEV SlotK fs_gradient(const Ctx &c) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
+  SlotK sk;
+  sk.on = false;
+  for (int q = 0; q < 6; q++) sk.K[q] = 0;
   for (int i = c.lane; i < 6 * m.nr; i += 64) L[ly.G + i] = 0;
   for (int d = c.lane; d < m.nv; d += 64) L[ly.grad + d] = L[ly.Mx + d] - L[ly.smooth + d];
   SYNC();
@@ -357,12 +364,23 @@ DEV void fs_gradient(const Ctx &c) {
     float *r = L + ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
-    float f[3] = {0, 0, 0}, cc;
-    if (ri[C_DIM] == 1) { if (r[C_JAR] < 0) f[0] = -r[C_DN] * r[C_JAR]; }
-    else fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, nullptr);
-    if (f[0] == 0 && f[1] == 0 && f[2] == 0) continue;
+    float f[3] = {0, 0, 0}, cc, Hc[9];
+    bool on;
+    if (ri[C_DIM] == 1) {
+      on = r[C_JAR] < 0;
+      if (on) f[0] = -r[C_DN] * r[C_JAR];
+      for (int q = 0; q < 9; q++) Hc[q] = 0;
+      Hc[0] = r[C_DN];
+    } else on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc) != 0;
+    if (!on) continue; // top zone: zero force, zero Hessian
     V3 fx, fy, fz;
     fs_frame(r, fx, fy, fz);
+    {
+      V3 w0 = fx * Hc[0] + fy * Hc[1] + fz * Hc[2], w1 = fx * Hc[3] + fy * Hc[4] + fz * Hc[5], w2 = fx * Hc[6] + fy * Hc[7] + fz * Hc[8];
+      sk.on = true;
+      sk.K[0] = fx.x * w0.x + fy.x * w1.x + fz.x * w2.x; sk.K[1] = fx.x * w0.y + fy.x * w1.y + fz.x * w2.y; sk.K[2] = fx.x * w0.z + fy.x * w1.z + fz.x * w2.z;
+      sk.K[3] = fx.y * w0.y + fy.y * w1.y + fz.y * w2.y; sk.K[4] = fx.y * w0.z + fy.y * w1.z + fz.y * w2.z; sk.K[5] = fx.z * w0.z + fy.z * w1.z + fz.z * w2.z;
+    }
     V3 F = fx * f[0] + fy * f[1] + fz * f[2];
     V3 pos = ldv3(r + C_POS);
     fs_add_wrench(c, ri[C_B2], pos, F, v3(0, 0, 0), 1.0f);
@@ -395,6 +413,7 @@ DEV void fs_gradient(const Ctx &c) {
     L[ly.grad + d] -= acc;
   }
   SYNC();
+  return sk;
 }
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -421,7 +440,7 @@ DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   a contact between two moving bodies (lo, hi) additionally adds -cdof_d1' X cdof_d2, X = P_lo' K P_hi, on
 //   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
-DEV void fs_hessian(const Ctx &c) {
+DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
   const DModel &m = c.m;
   const Layout &ly = c.ly;
   float *L = c.L;
@@ -441,29 +460,18 @@ DEV void fs_hessian(const Ctx &c) {
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
   const int nslot = c.I(ly.scal)[SC_NSLOT];
-  bool on = false;
+  const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
   int blo = 0, bhi = 0, tlo = 0, thi = 0;
-  float K[6] = {0, 0, 0, 0, 0, 0};
+  float K[6];
+  for (int q = 0; q < 6; q++) K[q] = sk.K[q];
   V3 pos = v3(0, 0, 0);
-  if (c.lane < nslot) {
+  if (on) {
     const float *r = L + ly.con + FSIM_CONW * c.lane;
     const int *ri = reinterpret_cast<const int *>(r);
-    if (ri[C_ACTIVE] == 1) {
-      float Hc[9];
-      if (ri[C_DIM] == 1) { on = r[C_JAR] < 0; for (int q = 0; q < 9; q++) Hc[q] = 0; Hc[0] = r[C_DN]; }
-      else { float f_[3], cc_; on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f_, &cc_, Hc) != 0; }
-      if (on) {
-        V3 f0, f1, f2;
-        fs_frame(r, f0, f1, f2);
-        V3 w0 = f0 * Hc[0] + f1 * Hc[1] + f2 * Hc[2], w1 = f0 * Hc[3] + f1 * Hc[4] + f2 * Hc[5], w2 = f0 * Hc[6] + f1 * Hc[7] + f2 * Hc[8];
-        K[0] = f0.x * w0.x + f1.x * w1.x + f2.x * w2.x; K[1] = f0.x * w0.y + f1.x * w1.y + f2.x * w2.y; K[2] = f0.x * w0.z + f1.x * w1.z + f2.x * w2.z;
-        K[3] = f0.y * w0.y + f1.y * w1.y + f2.y * w2.y; K[4] = f0.y * w0.z + f1.y * w1.z + f2.y * w2.z; K[5] = f0.z * w0.z + f1.z * w1.z + f2.z * w2.z;
-        pos = ldv3(r + C_POS);
-        const int wb1 = ri[C_B1], wb2 = ri[C_B2]; // body | tree << 8
-        const int wl = (wb1 & 255) <= (wb2 & 255) ? wb1 : wb2, wh = (wb1 & 255) <= (wb2 & 255) ? wb2 : wb1;
-        blo = wl & 255; bhi = wh & 255; tlo = wl >> 8; thi = wh >> 8;
-      }
-    }
+    pos = ldv3(r + C_POS);
+    const int wb1 = ri[C_B1], wb2 = ri[C_B2]; // body | tree << 8
+    const int wl = (wb1 & 255) <= (wb2 & 255) ? wb1 : wb2, wh = (wb1 & 255) <= (wb2 & 255) ? wb2 : wb1;
+    blo = wl & 255; bhi = wh & 255; tlo = wl >> 8; thi = wh >> 8;
   }
   // rows of K, G = [r]x K (ang-lin block), and the diagonal blocks
   const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
@@ -827,14 +835,14 @@ DEV void fs_solve(const Ctx &c, int coupled) {
   float scale = m.meaninertia_scale;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
-    fs_gradient(c);
+    const SlotK sk = fs_gradient(c);
     float gn = sqrtf(fs_dotv(c, ly.grad, ly.grad));
     FS_SPROF(23);
 #ifdef FSIM_PROFILE
     if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
 #endif
     if (scale * gn < c.newton_tol) break;
-    fs_hessian(c);
+    fs_hessian(c, sk);
     FS_SPROF(24);
     bool ok = fs_chol_solve(c, ly.hmap);
     FS_SPROF(25);
