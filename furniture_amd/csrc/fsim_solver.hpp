@@ -502,8 +502,9 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
   // ---- composite blocks: children are numbered after their parents
   if (__ballot(deep)) {
     // lane = component: a lane only ever touches its own component of every block, so the child -> parent chain needs
-    // no barrier (a wave's LDS operations complete in order).  (A lane-per-(body, component) bitmask version with
-    // register staging was measured slower: 25 vs 21 kcycles per substep on gripping envs.)
+    // no barrier (a wave's LDS operations complete in order).  (Measured alternatives, both slower on gripping envs, 21 kcycles/substep here:
+    // lane-per-(body, component) bitmask sums with register staging 25, register-carried chain with prefetch 28 --
+    // this code is bound by instruction count, not by the LDS round trips.)
     if (c.lane < 21)
       for (int b = m.nr - 1; b >= 1; b--) {
         int p = KI(r_parent, b);
@@ -789,6 +790,7 @@ DEV bool fs_chol_solve(const Ctx &c, int mp) {
   if (0 && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
 #endif
   if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
+  if (steps <= 24) return fs_chol_regs<24>(c, mp, steps); // robot + two parts (21): the common size of a gripping env
   if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
   return fs_chol_lds(c, mp, steps);
 }
