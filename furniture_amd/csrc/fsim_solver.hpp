@@ -789,6 +789,7 @@ DEV bool fs_chol_solve(const Ctx &c, int mp) {
 #ifdef FSIM_PROFILE
   if (0 && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
 #endif
+  if (steps <= 10) return fs_chol_regs<10>(c, mp, steps); // free Sawyer (9) / Baxter arm trees, free parts (6)
   if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
   if (steps <= 24) return fs_chol_regs<24>(c, mp, steps); // robot + two parts (21): the common size of a gripping env
   if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
