@@ -38,8 +38,8 @@ __device__ __forceinline__ void store_record(float *rec, const float *L, int n, 
 
 __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
   extern __shared__ float L[];
-  const DModel &m = *mp;
-  const Layout &ly = *lp;
+  CModel &m = *(CModel *)mp;
+  CLayout &ly = *(CLayout *)lp;
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= kp.n_envs) return;
   float *rec = state + (size_t)env * ly.stride;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
                                                  const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost) {
   extern __shared__ float L[];
-  const DModel &m = *mp;
-  const Layout &ly = *lp;
+  CModel &m = *(CModel *)mp;
+  CLayout &ly = *(CLayout *)lp;
   long long t_entry = clock64();
   int lane = threadIdx.x;
   if ((int)blockIdx.x >= kp.n_envs) return;

@@ -55,14 +55,14 @@ DEV void fs_frame(const float *r, V3 &x, V3 &y, V3 &z) {
 
 // lane = slot: unit normal and the geom pair's parameters
 DEV void fs_finish_contacts(const Ctx &c) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int nslot = min(c.I(c.ly.scal)[SC_NSLOT], c.ly.ncon_max);
   for (int s = c.lane; s < nslot; s += 64) {
     float *r = c.L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     int cg1 = ri[C_G1], cg2 = ri[C_G2];
     stv3(r + C_FRAME, normalized(ldv3(r + C_FRAME)));
-    float mu = fmaxf(m.cg_friction[3 * cg1], m.cg_friction[3 * cg2]);
+    float mu = fmaxf(GP(m.cg_friction)[3 * cg1], GP(m.cg_friction)[3 * cg2]);
     r[C_MU] = mu;
     int dim = max(m.cg_condim[cg1], m.cg_condim[cg2]);
     if (mu < 1e-15f) dim = 1;
@@ -448,8 +448,8 @@ DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
 #define FS_CPROF(slot) do { } while (0)
 #endif
 DEV void fs_collide(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int *scal = c.I(ly.scal);
 #ifdef FSIM_PROFILE
@@ -458,13 +458,13 @@ DEV void fs_collide(const Ctx &c) {
   for (int g = c.lane; g < m.ncg; g += 64) {
     int b = m.cg_body[g];
     M3 Rb = ldm3(L + ly.xmat + 9 * b);
-    V3 gp = ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(m.cg_pos + 3 * g));
+    V3 gp = ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(GP(m.cg_pos) + 3 * g));
     if (m.agent == 2) { // cursor boxes are world geoms whose body_pos the env rewrites (furniture.py:3139)
       int cm = m.cg_cursor[g];
-      if (cm) { int k = (cm & 1) ? 0 : 1; gp = gp + ldv3(L + ly.env + E_GROUP + m.nparts + EC_POS + 3 * k) - ldv3(m.cursor_pos0 + 3 * k); }
+      if (cm) { int k = (cm & 1) ? 0 : 1; gp = gp + ldv3(L + ly.env + E_GROUP + m.nparts + EC_POS + 3 * k) - ldv3(GP(m.cursor_pos0) + 3 * k); }
     }
     stv3(L + ly.gpos + 3 * g, gp);
-    stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(m.cg_mat + 9 * g)));
+    stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(GP(m.cg_mat) + 9 * g)));
   }
   SYNC();
   FS_CPROF(29);
@@ -477,8 +477,8 @@ DEV void fs_collide(const Ctx &c) {
     bool pass = false;
     if (p < m.ncp) {
       // one 64-byte record per pair (g1 g2 pt types | margin gap r1 r2 | size1 | size2): no dependent table lookups
-      const int4 q0 = reinterpret_cast<const int4 *>(m.pair_rec)[4 * p];
-      const float4 q1 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 1];
+      const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
+      const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
       const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
       if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
         const float margin = q1.x, r1 = q1.z, r2 = q1.w;
@@ -501,7 +501,7 @@ DEV void fs_collide(const Ctx &c) {
               V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
               const float *R = L + ly.gmat + 9 * gs;
               V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
-              const float4 qs = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + (side ? 2 : 3)];
+              const f4_t qs = GPC<f4_t>(m.pair_rec)[4 * p + (side ? 2 : 3)];
               V3 sz_ = v3(qs.x, qs.y, qs.z);
               float dist2;
               if (ty == GT_BOX) {
@@ -529,9 +529,9 @@ DEV void fs_collide(const Ctx &c) {
   FS_CPROF(30);
   for (int i = c.lane; i < nsurv; i += 64) {
     int p = surv[i];
-    const int4 q0 = reinterpret_cast<const int4 *>(m.pair_rec)[4 * p];
-    const float4 q1 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 1], q2 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 2],
-                 q3 = reinterpret_cast<const float4 *>(m.pair_rec)[4 * p + 3];
+    const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
+    const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1], q2 = GPC<f4_t>(m.pair_rec)[4 * p + 2],
+                 q3 = GPC<f4_t>(m.pair_rec)[4 * p + 3];
     const int g1 = q0.x, g2 = q0.y, pt = q0.z;
     const float margin = q1.x, gap = q1.y;
     Emit e(c, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);

@@ -53,7 +53,7 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
 DEV void fs_touch_flags(const Ctx &c) {
   // who touches whom, from the contact list of this forward pass (data.contact[0:ncon])
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *scal = c.I(c.ly.scal);
   if (c.lane == 0) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; }
   SYNC();
@@ -182,12 +182,12 @@ DEV int env_find(int *grp, int i) {
   return r;
 }
 DEV void env_site_pose(const Ctx &c, int site, V3 *pos, Q4 *quat, M3 *mat) {
-  const DModel &m = c.m;
-  int b = m.s_body[site];
+  CModel &m = c.m;
+  int b = GP(m.s_body)[site];
   Q4 qb = ldq(c.L + c.ly.xquat + 4 * b);
   M3 Rb = ldm3(c.L + c.ly.xmat + 9 * b);
-  *pos = ldv3(c.L + c.ly.xpos + 3 * b) + mulv(Rb, ldv3(m.s_pos + 3 * site));
-  Q4 q = qmul(qb, ldq(m.s_quat + 4 * site));
+  *pos = ldv3(c.L + c.ly.xpos + 3 * b) + mulv(Rb, ldv3(GP(m.s_pos) + 3 * site));
+  Q4 q = qmul(qb, ldq(GP(m.s_quat) + 4 * site));
   if (quat) *quat = q;
   if (mat) *mat = q2m(qnormalized(q));
 }
@@ -213,24 +213,24 @@ DEV void env_ttq(V3 bp, Q4 bq, V3 p, Q4 q, Q4 target, V3 *np_, Q4 *nq) {
   *nq = qmul(rel, q);
 }
 DEV void env_stop_part(const Ctx &c, int part, float gravity) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   float *x = c.L + c.ly.xfrc + 6 * part;
-  x[0] = 0; x[1] = 0; x[2] = -gravity * m.gravity[2] * m.part_mass[part]; x[3] = 0; x[4] = 0; x[5] = 0;
-  int d = m.part_dofadr[part];
+  x[0] = 0; x[1] = 0; x[2] = -gravity * m.gravity[2] * GP(m.part_mass)[part]; x[3] = 0; x[4] = 0; x[5] = 0;
+  int d = GP(m.part_dofadr)[part];
   for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = 0; c.L[c.ly.qfrcapp + d + k] = 0; }
 }
 // _move_objects_translation_quat (furniture.py:1163-1176): rigidly re-pose the whole weld group of `part`
 DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float gravity) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   float *qp = c.L + c.ly.qpos;
-  int a0 = m.part_qposadr[part];
+  int a0 = GP(m.part_qposadr)[part];
   V3 bp = ldv3(qp + a0);
   Q4 bq = ldq(qp + a0 + 3);
   int g = env_find(grp, part);
   for (int i = 0; i < m.nparts; i++) {
     if (env_find(grp, i) != g) continue;
-    int a = m.part_qposadr[i];
+    int a = GP(m.part_qposadr)[i];
     V3 np_; Q4 nq;
     env_ttq(bp, bq, ldv3(qp + a), ldq(qp + a + 3), target, &np_, &nq);
     stv3(qp + a, np_ + translation);
@@ -240,14 +240,14 @@ DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float
 }
 // site bounding box of a weld group, min/max initialised with 0 (quirk Q1, furniture.py:747-769)
 DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   int g = env_find(grp, part);
   V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
   for (int i = 0; i < m.nparts; i++) {
     if (env_find(grp, i) != g) continue;
-    for (int k = 0; k < m.part_site_num[i]; k++) {
-      V3 p; env_site_pose(c, m.part_sites[m.part_site_adr[i] + k], &p, nullptr, nullptr);
+    for (int k = 0; k < GP(m.part_site_num)[i]; k++) {
+      V3 p; env_site_pose(c, GP(m.part_sites)[GP(m.part_site_adr)[i] + k], &p, nullptr, nullptr);
       lo = v3(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
       hi = v3(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
     }
@@ -256,29 +256,29 @@ DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
 }
 
 DEV void env_next_subtask(const Ctx &c) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
   E[E_SUBTASK1] = -1; E[E_SUBTASK2] = -1;
   for (int i = 0; i < m.neq; i++) {
-    int p1 = m.eq_part1[i], p2 = m.eq_part2[i];
+    int p1 = GP(m.eq_part1)[i], p2 = GP(m.eq_part2)[i];
     if (env_find(grp, p1) != env_find(grp, p2)) { E[E_SUBTASK1] = p1; E[E_SUBTASK2] = p2; return; }
   }
 }
 
 // _is_aligned (furniture.py:1057-1153) for connector indices k1,k2; writes the target quaternion on success paths
 DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   V3 p1, p2; M3 R1, R2;
-  env_site_pose(c, m.conn_siteid[k1], &p1, nullptr, &R1);
-  env_site_pose(c, m.conn_siteid[k2], &p2, nullptr, &R2);
+  env_site_pose(c, GP(m.conn_siteid)[k1], &p1, nullptr, &R1);
+  env_site_pose(c, GP(m.conn_siteid)[k2], &p2, nullptr, &R2);
   V3 up1 = colv(R1, 2), up2 = colv(R2, 2), f1 = colv(R1, 1), f2 = colv(R2, 1);
   float pos_dist = norm(p1 - p2);
   float rot_up = env_cos(up1, up2);
   float proj12 = dot(up1, (p2 - p1) * (1.0f / norm(p2 - p1)));
   float proj21 = dot(up2, (p1 - p2) * (1.0f / norm(p1 - p2)));
   bool fwd_ok;
-  int na = m.conn_nangle[k1];
+  int na = GP(m.conn_nangle)[k1];
   float *tq = c.L + c.ly.env + E_TARGET_QUAT;
   if (na == 0) {
     fwd_ok = true;
@@ -292,7 +292,7 @@ DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
     fwd_ok = false;
     V3 k = normalized(up1);
     for (int a = 0; a < na; a++) {
-      float ang = m.conn_angles[FSIM_MAXANG * k1 + a] / 180.0f * 3.14159265358979f;
+      float ang = GP(m.conn_angles)[FSIM_MAXANG * k1 + a] / 180.0f * 3.14159265358979f;
       V3 fr = cosf(ang) * f1 + sinf(ang) * cross(k, f1);
       if (env_cos(fr, f2) > cfg.rot_fwd) { fwd_ok = true; stq(tq, env_lookat(up1, fr)); break; }
     }
@@ -329,7 +329,7 @@ DEV Q4 env_slerp(Q4 q0, Q4 q1, float fraction) {
 
 // _stop_selected_objects (furniture.py:771-779): every part in a selected group is frozen with gravity compensation
 DEV void env_stop_selected(const Ctx &c, float gravity) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   if (c.lane == 0) {
     int *grp = c.I(c.ly.env + E_GROUP);
     const int *ec = c.I(env_ecur(c));
@@ -346,22 +346,22 @@ DEV void env_stop_selected(const Ctx &c, float gravity) {
 // it by `move`, validate with one forward+step and the site bounding box (_is_inside), undo the poses if it left the
 // workspace.  returns (wave-uniform) 1 if the move was kept.
 DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   int *scal = c.I(c.ly.scal);
   // old part poses stay in registers (lane i keeps word i of the [nparts][7] pose table) so the move can be undone
   float keep[2] = {0, 0};
-  for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + m.part_qposadr[i / 7] + i % 7]; }
+  for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + GP(m.part_qposadr)[i / 7] + i % 7]; }
   SYNC();
   if (c.lane == 0) {
     int g = env_find(grp, part);
-    int a0 = m.part_qposadr[part];
+    int a0 = GP(m.part_qposadr)[part];
     Q4 bq = ldq(c.L + c.ly.qpos + a0 + 3);
     V3 bp = ldv3(c.L + c.ly.qpos + a0);
     Q4 target = env_euler_quat(rot_deg, bq);
     for (int i = 0; i < m.nparts; i++) {
       if (env_find(grp, i) != g) continue;
-      int a = m.part_qposadr[i];
+      int a = GP(m.part_qposadr)[i];
       V3 np_; Q4 nq;
       env_ttq(bp, bq, ldv3(c.L + c.ly.qpos + a), ldq(c.L + c.ly.qpos + a + 3), target, &np_, &nq);
       stv3(c.L + c.ly.qpos + a, np_ + move);
@@ -382,7 +382,7 @@ DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) 
     int g = scal[13];
     for (int r = 0; r < 2; r++) {
       int i = c.lane + 64 * r;
-      if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + m.part_qposadr[pi] + i % 7] = keep[r]; }
+      if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + GP(m.part_qposadr)[pi] + i % 7] = keep[r]; }
     }
     SYNC();
   }
@@ -392,7 +392,7 @@ DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) 
 // _try_connect(part1, part2) (furniture.py:926-1042).  part2 < 0: any part (the arm agents).  returns (wave-uniform) 1 if a
 // connection was made; with num_connect_steps > 0 (Cursor) an aligned pair is first approached over that many calls.
 DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
   int *scal = c.I(c.ly.scal);
@@ -404,18 +404,18 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     if (weld_ok && part2 >= 0) { // some <weld> must join two bodies of group(part1) U group(part2) (activity is not checked)
       weld_ok = false;
       for (int i = 0; i < m.neq && !weld_ok; i++) {
-        int ga = env_find(grp, m.eq_part1[i]), gb = env_find(grp, m.eq_part2[i]);
+        int ga = env_find(grp, GP(m.eq_part1)[i]), gb = env_find(grp, GP(m.eq_part2)[i]);
         weld_ok = (ga == g1 || ga == g2) && (gb == g1 || gb == g2);
       }
     }
     if (weld_ok) {
       for (int k1 = 0; k1 < m.nconn && found1 < 0; k1++) {
-        if (env_find(grp, m.conn_partid[k1]) != g1) continue;
+        if (env_find(grp, GP(m.conn_partid)[k1]) != g1) continue;
         for (int k2 = 0; k2 < m.nconn; k2++) {
-          if (g2 >= 0 && env_find(grp, m.conn_partid[k2]) != g2) continue;
+          if (g2 >= 0 && env_find(grp, GP(m.conn_partid)[k2]) != g2) continue;
           if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
           if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
-          int a1 = m.conn_keya[k1], b1 = m.conn_keyb[k1], a2 = m.conn_keya[k2], b2 = m.conn_keyb[k2];
+          int a1 = GP(m.conn_keya)[k1], b1 = GP(m.conn_keyb)[k1], a2 = GP(m.conn_keya)[k2], b2 = GP(m.conn_keyb)[k2];
           bool match = (b1 < 0 || b2 < 0) ? (b1 < 0 && b2 < 0 && a1 == a2) : (a1 == b2 && b1 == a2);
           if (!match) continue;
           if (env_is_aligned(c, cfg, k1, k2)) { found1 = k1; found2 = k2; break; }
@@ -426,12 +426,12 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
       // approach phase (furniture.py:993-1034): slerp / lerp part2's group towards the aligned pose, one increment per call
       const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP];
       float *ec = c.L + env_ecur(c);
-      int p2 = m.conn_partid[found2], a = m.part_qposadr[p2];
+      int p2 = GP(m.conn_partid)[found2], a = GP(m.part_qposadr)[p2];
       V3 p2p = ldv3(c.L + c.ly.qpos + a); Q4 p2q = ldq(c.L + c.ly.qpos + a + 3);
       if (step == 0) {
         V3 s1p, s2p; Q4 s2q;
-        env_site_pose(c, m.conn_siteid[found1], &s1p, nullptr, nullptr);
-        env_site_pose(c, m.conn_siteid[found2], &s2p, &s2q, nullptr);
+        env_site_pose(c, GP(m.conn_siteid)[found1], &s1p, nullptr, nullptr);
+        env_site_pose(c, GP(m.conn_siteid)[found2], &s2p, &s2q, nullptr);
         V3 bpos; Q4 brot;
         env_ttq(s2p, s2q, p2p, p2q, ldq(c.L + c.ly.env + E_TARGET_QUAT), &bpos, &brot);
         bpos = bpos + (s1p - s2p);
@@ -454,11 +454,11 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
   int k1 = scal[9], k2 = scal[10];
   if (k1 < 0) return 0;
   // ---- _connect(site1, site2)
-  int pA = m.conn_partid[k1], pB = m.conn_partid[k2];
+  int pA = GP(m.conn_partid)[k1], pB = GP(m.conn_partid)[k2];
   if (c.lane == 0) {
     E[E_CONNSITES0 + (k1 >> 5)] |= 1 << (k1 & 31);
     E[E_CONNSITES0 + (k2 >> 5)] |= 1 << (k2 & 31);
-    E[E_SITE1] = m.conn_siteid[k1]; E[E_SITE2] = m.conn_siteid[k2];
+    E[E_SITE1] = GP(m.conn_siteid)[k1]; E[E_SITE2] = GP(m.conn_siteid)[k2];
     int gA = env_find(grp, pA), gB = env_find(grp, pB);
     int *ct = c.I(c.ly.contype), *ca = c.I(c.ly.conaff);
     for (int g = 0; g < m.ncg; g++) {
@@ -470,10 +470,10 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     if (cfg.auto_align) {
       // _align_connectors -> _move_site_to_target(site2, [site1 pos, target quat])
       V3 s1p, s2p; Q4 s2q;
-      env_site_pose(c, m.conn_siteid[k1], &s1p, nullptr, nullptr);
-      env_site_pose(c, m.conn_siteid[k2], &s2p, &s2q, nullptr);
+      env_site_pose(c, GP(m.conn_siteid)[k1], &s1p, nullptr, nullptr);
+      env_site_pose(c, GP(m.conn_siteid)[k2], &s2p, &s2q, nullptr);
       Q4 target = ldq(c.L + c.ly.env + E_TARGET_QUAT);
-      int a = m.part_qposadr[pB];
+      int a = GP(m.part_qposadr)[pB];
       V3 bp = ldv3(c.L + c.ly.qpos + a); Q4 bq = ldq(c.L + c.ly.qpos + a + 3);
       V3 npos; Q4 nquat;
       env_ttq(s2p, s2q, bp, bq, target, &npos, &nquat);
@@ -503,9 +503,9 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
   if (c.lane == 0) {
     // _activate_weld(body1, body2)
     for (int i = 0; i < m.neq; i++) {
-      int p1 = m.eq_part1[i], p2 = m.eq_part2[i];
+      int p1 = GP(m.eq_part1)[i], p2 = GP(m.eq_part2)[i];
       if ((p1 == pA || p1 == pB) && (p2 == pA || p2 == pB)) {
-        int a1 = m.part_qposadr[p1], a2 = m.part_qposadr[p2];
+        int a1 = GP(m.part_qposadr)[p1], a2 = GP(m.part_qposadr)[p2];
         Q4 q1i = env_qinv(ldq(c.L + c.ly.qpos + a1 + 3));
         Q4 rq = qmul(q1i, ldq(c.L + c.ly.qpos + a2 + 3));
         V3 rp = qrot(qnormalized(q1i), ldv3(c.L + c.ly.qpos + a2) - ldv3(c.L + c.ly.qpos + a1));
@@ -520,7 +520,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     E[E_NUM_CONNECTED] += 1;
     E[E_CONNECTED_THIS_STEP] = 1;
     E[E_CONNBODY1] = pA + 1;
-    int a = m.part_qposadr[pA];
+    int a = GP(m.part_qposadr)[pA];
     for (int k = 0; k < 7; k++) c.L[c.ly.env + E_CB1_POS + k] = c.L[c.ly.qpos + a + k];
     env_next_subtask(c);
   }
@@ -531,7 +531,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
 // ---------------------------------------------------------------------------------------------------- Cursor agent
 // _step_discrete (furniture.py:800-845) + helpers _move_cursor / _select_object (furniture.py:700-798, 3290-3310).
 DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
   int *scal = c.I(c.ly.scal);
@@ -585,12 +585,12 @@ DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
 // ---------------------------------------------------------------------------------------------------- observation / reward
 DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   if (!io.obs) return;
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   const float *L = c.L;
   // object_ob: body xpos/xquat of every part as left by the last forward pass
   for (int i = c.lane; i < 7 * m.nparts; i += 64) {
-    int p = i / 7, k = i % 7, b = m.part_rbody[p];
+    int p = i / 7, k = i % 7, b = GP(m.part_rbody)[p];
     io.obs[i] = k < 3 ? L[ly.xpos + 3 * b + k] : L[ly.xquat + 4 * b + k - 3];
   }
   int base = 7 * m.nparts;
@@ -603,18 +603,18 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     float *o = io.obs + base + 29 * arm;
     int nj = m.narmj / m.narm;
     for (int k = c.lane; k < nj; k += 64) {
-      o[k] = L[ly.qpos + m.arm_qposadr[arm * nj + k]];
-      o[nj + k] = L[ly.qvel + m.arm_dofadr[arm * nj + k]];
+      o[k] = L[ly.qpos + GP(m.arm_qposadr)[arm * nj + k]];
+      o[nj + k] = L[ly.qvel + GP(m.arm_dofadr)[arm * nj + k]];
     }
-    if (c.lane < 2) o[2 * nj + c.lane] = L[ly.qpos + m.grip_qposadr[2 * arm + c.lane]];
+    if (c.lane < 2) o[2 * nj + c.lane] = L[ly.qpos + GP(m.grip_qposadr)[2 * arm + c.lane]];
     if (c.lane == 0) {
-      int site = m.eef_siteid[arm];
+      int site = GP(m.eef_siteid)[arm];
       V3 sp; env_site_pose(c, site, &sp, nullptr, nullptr);
       stv3(o + 2 * nj + 2, sp);
-      int hb = m.hand_body[arm], rb = m.body_red[hb];
-      Q4 q = qmul(ldq(L + ly.xquat + 4 * rb), ldq(m.body_relquat + 4 * hb));
+      int hb = GP(m.hand_body)[arm], rb = GP(m.body_red)[hb];
+      Q4 q = qmul(ldq(L + ly.xquat + 4 * rb), ldq(GP(m.body_relquat) + 4 * hb));
       o[2 * nj + 5] = q.x; o[2 * nj + 6] = q.y; o[2 * nj + 7] = q.z; o[2 * nj + 8] = q.w;
-      int sb = m.s_body[site];
+      int sb = GP(m.s_body)[site];
       S6 v = lds6(L + ly.cvel + 6 * sb);
       V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * KI(r_tree, sb))) : v3(0, 0, 0);
       stv3(o + 2 * nj + 9, vp);
@@ -625,26 +625,26 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
 
 // ---------------------------------------------------------------------------------------------------- reset
 DEV void env_gravity_comp(const Ctx &c) {
-  const DModel &m = c.m;
-  for (int k = c.lane; k < m.narmj; k += 64) c.L[c.ly.qfrcapp + m.arm_dofadr[k]] = c.L[c.ly.qfrcbias + m.arm_dofadr[k]];
-  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qfrcapp + m.grip_dofadr[k]] = c.L[c.ly.qfrcbias + m.grip_dofadr[k]];
+  CModel &m = c.m;
+  for (int k = c.lane; k < m.narmj; k += 64) c.L[c.ly.qfrcapp + GP(m.arm_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.arm_dofadr)[k]];
+  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qfrcapp + GP(m.grip_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.grip_dofadr)[k]];
   SYNC();
 }
 DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw, float move_speed) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   if (m.agent == 2 && c.lane < 2) { // furniture.py:1763-1768: cursors at x = -+0.2, half a move step above the floor
     float *p = c.L + c.ly.env + E_GROUP + m.nparts + EC_POS + 3 * c.lane;
     p[0] = c.lane ? 0.2f : -0.2f; p[1] = 0.0f; p[2] = move_speed * 0.5f;
   }
   for (int k = c.lane; k < m.narmj; k += 64) {
     float noise = io.tab_noise ? io.tab_noise[(size_t)min(draw, io.n_noise - 1) * m.narmj + k] : 0.0f;
-    c.L[c.ly.qpos + m.arm_qposadr[k]] = m.arm_initqpos[k] + noise;
+    c.L[c.ly.qpos + GP(m.arm_qposadr)[k]] = GP(m.arm_initqpos)[k] + noise;
   }
-  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qpos + m.grip_qposadr[k]] = m.grip_initqpos[k];
+  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qpos + GP(m.grip_qposadr)[k]] = GP(m.grip_initqpos)[k];
   SYNC();
 }
 DEV void env_settle_parts(const Ctx &c) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   for (int o = 0; o < 10; o++) {
     if (c.lane == 0) for (int p = 0; p < m.nparts; p++) env_stop_part(c, p, 0.0f);
     SYNC();
@@ -653,8 +653,8 @@ DEV void env_settle_parts(const Ctx &c) {
       // _slow_objects: gravity compensation + clip |qvel| <= 0.2
       for (int p = c.lane; p < m.nparts; p += 64) {
         float *x = c.L + c.ly.xfrc + 6 * p;
-        x[0] = 0; x[1] = 0; x[2] = -m.gravity[2] * m.part_mass[p]; x[3] = 0; x[4] = 0; x[5] = 0;
-        int d = m.part_dofadr[p];
+        x[0] = 0; x[1] = 0; x[2] = -m.gravity[2] * GP(m.part_mass)[p]; x[3] = 0; x[4] = 0; x[5] = 0;
+        int d = GP(m.part_dofadr)[p];
         for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = fminf(fmaxf(c.L[c.ly.qvel + d + k], -0.2f), 0.2f); c.L[c.ly.qfrcapp + d + k] = 0; }
       }
       SYNC();
@@ -666,12 +666,12 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   FS_REBUILD_CTX(cv);
   const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp));
   const EnvIO io = *iop;
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int *E = c.I(ly.env);
   // sim.reset()
-  for (int i = c.lane; i < m.nq; i += 64) L[ly.qpos + i] = m.qpos0[i];
+  for (int i = c.lane; i < m.nq; i += 64) L[ly.qpos + i] = GP(m.qpos0)[i];
   for (int i = c.lane; i < m.nv; i += 64) { L[ly.qvel + i] = 0; L[ly.qaccws + i] = 0; L[ly.qfrcbias + i] = 0; L[ly.qfrcapp + i] = 0; }
   for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
   for (int i = c.lane; i < 6 * m.nparts; i += 64) L[ly.xfrc + i] = 0;
@@ -682,7 +682,7 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
     if (m.cg_ispartcol[g]) { ct = 1; ca = 1; }
     c.I(ly.contype)[g] = ct; c.I(ly.conaff)[g] = ca;
   }
-  for (int e = c.lane; e < m.neq; e += 64) { c.I(ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[ly.eqdata + 7 * e + k] = m.eq_data0[7 * e + k]; }
+  for (int e = c.lane; e < m.neq; e += 64) { c.I(ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
   int episodes = E[E_EPISODE_COUNT];
   SYNC();
   for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
@@ -693,7 +693,7 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
   for (int i = c.lane; i < 7 * m.nparts; i += 64) {
     int p = i / 7, k = i % 7;
-    if (io.tab_parts) L[ly.qpos + m.part_qposadr[p] + k] = io.tab_parts[i];
+    if (io.tab_parts) L[ly.qpos + GP(m.part_qposadr)[p] + k] = io.tab_parts[i];
   }
   SYNC();
   env_settle_parts(c);
@@ -721,8 +721,8 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
 
 // ---------------------------------------------------------------------------------------------------- step
 DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int *E = c.I(ly.env);
   int *scal = c.I(ly.scal);
@@ -742,7 +742,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       if ((u - m.narmj) & 1) a = -a; // format_action: [g, -g]
     }
     if (u < m.narmj && cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
-    L[ly.ctrl + u] = cfg.rescale_actions ? m.ctrl_bias[u] + m.ctrl_weight[u] * a : a;
+    L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
   }
   SYNC();
   if (m.agent == 2) {
@@ -791,7 +791,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       int pA = E[E_CONNBODY1] - 1;
       V3 tp = ldv3(L + ly.env + E_CB1_POS);
       Q4 tq = ldq(L + ly.env + E_CB1_QUAT);
-      env_move_group(c, pA, tp - ldv3(L + ly.qpos + m.part_qposadr[pA]), tq, cfg.gravity_comp ? 1.0f : 0.0f);
+      env_move_group(c, pA, tp - ldv3(L + ly.qpos + GP(m.part_qposadr)[pA]), tq, cfg.gravity_comp ? 1.0f : 0.0f);
       E[E_CONNBODY1] = 0;
     }
     SYNC();
@@ -813,10 +813,10 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     for (int g = c.lane; g < m.ncg; g += 64) {
       if (!m.cg_ispartcol[g]) continue;
       int b = m.cg_body[g];
-      V3 ctr = ldv3(L + ly.xpos + 3 * b) + mulv(ldm3(L + ly.xmat + 9 * b), ldv3(m.cg_pos + 3 * g));
+      V3 ctr = ldv3(L + ly.xpos + 3 * b) + mulv(ldm3(L + ly.xmat + 9 * b), ldv3(GP(m.cg_pos) + 3 * g));
       for (int arm = 0; arm < m.narm; arm++) {
-        V3 hp = ldv3(L + ly.xpos + 3 * m.body_red[m.hand_body[arm]]);
-        if (norm(ctr - hp) - m.cg_rbound[g] < 0.10f) near = 1;
+        V3 hp = ldv3(L + ly.xpos + 3 * GP(m.body_red)[GP(m.hand_body)[arm]]);
+        if (norm(ctr - hp) - GP(m.cg_rbound)[g] < 0.10f) near = 1;
       }
     }
     near = wave_or(near);

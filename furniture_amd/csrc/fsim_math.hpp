@@ -5,9 +5,22 @@
 #define FS_MINVAL 1e-15f
 #define DEV __device__ __forceinline__
 
+// Model tables live in global memory, but a pointer loaded from a struct that was itself reached through a pointer is
+// "flat" to the compiler: every such load becomes flat_load_dword, which also ticks the LDS counter (lgkmcnt), so LDS
+// waits get stuck behind HBM/L2 latencies.  GP() launders the pointer through address space 1 => global_load_dword.
+template <class T> __device__ __forceinline__ const __attribute__((address_space(1))) T *GP(const T *p) {
+  return (const __attribute__((address_space(1))) T *)p;
+}
+template <class U, class T> __device__ __forceinline__ const __attribute__((address_space(1))) U *GPC(const T *p) { // + element type change
+  return (const __attribute__((address_space(1))) U *)p;
+}
+
+typedef float f4_t __attribute__((ext_vector_type(4))); // plain vector types: loadable through any address space
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
 struct V3 { float x, y, z; };
 DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-DEV V3 ldv3(const float *p) { return v3(p[0], p[1], p[2]); }
+template <class P> DEV V3 ldv3(P p) { return v3(p[0], p[1], p[2]); } // P: generic, LDS or global (GP) float pointer
 DEV void stv3(float *p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -27,7 +40,7 @@ DEV float comp(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 
 struct Q4 { float w, x, y, z; };
 DEV Q4 q4(float w, float x, float y, float z) { Q4 q; q.w = w; q.x = x; q.y = y; q.z = z; return q; }
-DEV Q4 ldq(const float *p) { return q4(p[0], p[1], p[2], p[3]); }
+template <class P> DEV Q4 ldq(P p) { return q4(p[0], p[1], p[2], p[3]); }
 DEV void stq(float *p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 DEV Q4 qmul(Q4 a, Q4 b) {
   return q4(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
@@ -61,7 +74,7 @@ DEV M3 q2m(Q4 q) {
   R.m[6] = 2 * (x * z - w * y); R.m[7] = 2 * (y * z + w * x); R.m[8] = 1 - 2 * (x * x + y * y);
   return R;
 }
-DEV M3 ldm3(const float *p) { M3 R; for (int i = 0; i < 9; i++) R.m[i] = p[i]; return R; }
+template <class P> DEV M3 ldm3(P p) { M3 R; for (int i = 0; i < 9; i++) R.m[i] = p[i]; return R; }
 DEV void stm3(float *p, const M3 &R) { for (int i = 0; i < 9; i++) p[i] = R.m[i]; }
 DEV V3 mulv(const M3 &R, V3 v) {
   return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);

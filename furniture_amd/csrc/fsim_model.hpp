@@ -80,6 +80,12 @@ struct Layout {
   int k_begin, k_end;
 };
 
+// Device code reaches the (read-only, launch-constant) model and layout structs through the CONSTANT address space:
+// their fields then come in by scalar loads (s_load_dword through the scalar cache, hoistable and CSE-able across
+// stores) instead of flat vector loads that tick both memory counters and serialise behind every LDS wait.
+typedef const __attribute__((address_space(4))) DModel CModel;
+typedef const __attribute__((address_space(4))) Layout CLayout;
+
 // env-logic block (word offsets relative to Layout::env)
 enum {
   E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL, E_TERMINAL,

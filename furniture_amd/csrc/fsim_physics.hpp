@@ -13,26 +13,26 @@
 
 struct Ctx {
   float *L;          // LDS base (state image followed by work arrays)
-  const DModel &m;
-  const Layout &ly;
+  CModel &m;
+  CLayout &ly;
   int lane;
   int newton_maxit;
   float newton_tol;
-  __device__ Ctx(float *L_, const DModel &m_, const Layout &ly_, int lane_, int it, float tol)
+  __device__ Ctx(float *L_, CModel &m_, CLayout &ly_, int lane_, int it, float tol)
       : L(L_), m(m_), ly(ly_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
 };
 
 // Re-derive wave-uniform values after a real function call so the callee's model-table loads stay scalar.
-DEV const void *fs_uniform_ptr(const void *p) {
-  unsigned long long v = reinterpret_cast<unsigned long long>(p);
+template <class T> DEV T *fs_uniform_ptr(T *p) {
+  unsigned long long v = (unsigned long long)p;
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+  return (T *)(((unsigned long long)hi << 32) | lo);
 }
 #define FS_REBUILD_CTX(cv)                                                                                      \
   extern __shared__ float fs_lds_[];                                                                            \
-  const DModel &m_u_ = *static_cast<const DModel *>(fs_uniform_ptr(&(cv).m));                                   \
-  const Layout &ly_u_ = *static_cast<const Layout *>(fs_uniform_ptr(&(cv).ly));                                 \
+  CModel &m_u_ = *fs_uniform_ptr(&(cv).m);                                                                      \
+  CLayout &ly_u_ = *fs_uniform_ptr(&(cv).ly);                                                                   \
   Ctx c(fs_lds_, m_u_, ly_u_, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((cv).newton_maxit),              \
         __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((cv).newton_tol))))
 
@@ -46,9 +46,9 @@ DEV const void *fs_uniform_ptr(const void *p) {
 
 // copy the hot model tables HBM -> LDS (once per kernel launch; the 50 substeps then never leave the CU for them)
 DEV void fs_load_cache(const Ctx &c) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   int nb = m.nr, nv = m.nv, nchain = 0;
-  for (int b = 0; b < nb; b++) nchain = max(nchain, m.r_chainadr[b] + m.r_chainlen[b]);
+  for (int b = 0; b < nb; b++) nchain = max(nchain, GP(m.r_chainadr)[b] + GP(m.r_chainlen)[b]);
 #define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
 #define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
   CPI(dof_parent, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
@@ -64,17 +64,17 @@ DEV void fs_load_cache(const Ctx &c) {
   // element): r_submask[b] = bodies in b's subtree; r_chain[b] = (first dof of b's tree) << 26 | bitmask of the dofs on
   // the path root -> b, relative to that first dof (<= 26 dofs per tree, checked by the model compiler)
   for (int b = c.lane; b < nb; b += 64) {
-    int sub = 0, ch = 0, base = b > 0 ? m.tree_dofadr[m.r_tree[b]] : 0;
-    for (int d = b; d < nb; d++) if (b > 0 && ((m.r_ancmask[d] >> b) & 1)) sub |= 1 << d;
-    if (b > 0) for (int k = 0; k < m.r_chainlen[b]; k++) ch |= 1 << (m.chain_dofs[m.r_chainadr[b] + k] - base);
+    int sub = 0, ch = 0, base = b > 0 ? GP(m.tree_dofadr)[GP(m.r_tree)[b]] : 0;
+    for (int d = b; d < nb; d++) if (b > 0 && ((GP(m.r_ancmask)[d] >> b) & 1)) sub |= 1 << d;
+    if (b > 0) for (int k = 0; k < GP(m.r_chainlen)[b]; k++) ch |= 1 << (GP(m.chain_dofs)[GP(m.r_chainadr)[b] + k] - base);
     c.I(c.ly.k_r_submask)[b] = sub;
     c.I(c.ly.k_r_chain)[b] = (base << 26) | ch;
   }
   // static "tree map" of a block-diagonal-by-tree system (M + h*D in fs_integrate): same format as the per-substep
   // island map (Layout::hmap), see fs_hidx / fs_chol_solve
   for (int i = c.lane; i < nv; i += 64) {
-    int t = m.dof_tree[i], adr = m.tree_dofadr[t], num = m.tree_dofnum[t], l = i - adr, base = 0;
-    for (int u = 0; u < t; u++) base += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    int t = GP(m.dof_tree)[i], adr = GP(m.tree_dofadr)[t], num = GP(m.tree_dofnum)[t], l = i - adr, base = 0;
+    for (int u = 0; u < t; u++) base += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     c.I(c.ly.k_tmap)[i] = (base + l * (l + 1) / 2) | (l << 12) | (num << 18) | (adr << 25);
     c.I(c.ly.k_tmap)[nv + i] = i;
   }
@@ -82,18 +82,18 @@ DEV void fs_load_cache(const Ctx &c) {
   // M entry e -> (i, j, packed index in the tree-packed triangle); the entries of M that are structurally zero
   // (two branches of one tree) are zeroed once here and never written again
   for (int e = c.lane; e < m.nM; e += 64) {
-    int i = m.M_i[e], j = m.M_j[e];
+    int i = GP(m.M_i)[e], j = GP(m.M_j)[e];
     int pidx = (c.I(c.ly.k_tmap)[i] & 0xfff) + ((c.I(c.ly.k_tmap)[j] >> 12) & 63);
     c.I(c.ly.k_M_ij)[e] = (pidx << 16) | (i << 8) | j;
   }
   {
     int w = 0;
-    for (int u = 0; u < m.ntree; u++) w += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    for (int u = 0; u < m.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     for (int k = c.lane; k < w; k += 64) c.L[c.ly.M + k] = 0.0f;
   }
   if (c.lane == 0) {
     int w = 0;
-    for (int u = 0; u < m.ntree; u++) w += m.tree_dofnum[u] * (m.tree_dofnum[u] + 1) / 2;
+    for (int u = 0; u < m.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     c.I(c.ly.scal)[161] = w; // SC_TWORDS (fsim_collide.hpp): packed size of the tree-block system
   }
   SYNC();
@@ -105,8 +105,8 @@ DEV void fs_kinematics(const Ctx &c) {
   // (B) lane = tree: compose parent * local down the chain with the parent pose held in registers -- the only serial
   // part, ~40 instructions per body for the 8-deep Sawyer chain; (C) lane = body: rotation matrix, joint anchor / axis
   // and inertial-frame origin in world coordinates -- parallel.
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   for (int b = c.lane; b < m.nr; b += 64) {
     if (b == 0) { stv3(L + ly.xpos, v3(0, 0, 0)); stq(L + ly.xquat, q4(1, 0, 0, 0)); continue; }
@@ -120,8 +120,8 @@ DEV void fs_kinematics(const Ctx &c) {
       stq(L + ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
       al = pl;
     } else {
-      Q4 q0 = ldq(m.r_quat + 4 * b);
-      V3 p0 = ldv3(m.r_pos + 3 * b), jpos = ldv3(m.r_jpos + 3 * b), jax = ldv3(m.r_jaxis + 3 * b);
+      Q4 q0 = ldq(GP(m.r_quat) + 4 * b);
+      V3 p0 = ldv3(GP(m.r_pos) + 3 * b), jpos = ldv3(GP(m.r_jpos) + 3 * b), jax = ldv3(GP(m.r_jaxis) + 3 * b);
       al = p0 + qrot(q0, jpos);
       axl = qrot(q0, jax);
       float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
@@ -150,7 +150,7 @@ DEV void fs_kinematics(const Ctx &c) {
   for (int b = c.lane; b < m.nr; b += 64) {
     M3 R = q2m(ldq(L + ly.xquat + 4 * b));
     stm3(L + ly.xmat + 9 * b, R);
-    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(m.r_ipos + 3 * b)));
+    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(GP(m.r_ipos) + 3 * b)));
     if (b > 0) { // joint anchor / axis were left in the parent frame by pass A
       int p = KI(r_parent, b);
       V3 pp = ldv3(L + ly.xpos + 3 * p);
@@ -164,8 +164,8 @@ DEV void fs_kinematics(const Ctx &c) {
 
 // per-tree centre of mass, body inertias about it, motion axes (mj_comPos)
 DEV void fs_com_inertia(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   for (int t = c.lane; t < m.ntree; t += 64) {
     V3 s = v3(0, 0, 0);
@@ -182,7 +182,7 @@ DEV void fs_com_inertia(const Ctx &c) {
     float *I = L + ly.cinert + 10 * b;
     if (b == 0) { for (int k = 0; k < 10; k++) I[k] = 0; continue; }
     M3 R = ldm3(L + ly.xmat + 9 * b);
-    const float *ib = m.r_inertia + 6 * b; // xx yy zz xy xz yz in body frame
+    auto ib = GP(m.r_inertia) + 6 * b; // xx yy zz xy xz yz in body frame
     M3 Ib;
     Ib.m[0] = ib[0]; Ib.m[4] = ib[1]; Ib.m[8] = ib[2]; Ib.m[1] = Ib.m[3] = ib[3]; Ib.m[2] = Ib.m[6] = ib[4]; Ib.m[5] = Ib.m[7] = ib[5];
     M3 T = mulm(R, Ib);
@@ -220,8 +220,8 @@ DEV void fs_com_inertia(const Ctx &c) {
 
 // ------------------------------------------------------------------------------------------ P2
 DEV void fs_crb_factor(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   // composite inertia: sum over descendants (no serial tree pass: each lane scans the body list)
   for (int b = c.lane; b < m.nr; b += 64) {
@@ -247,7 +247,7 @@ DEV void fs_crb_factor(const Ctx &c) {
 // y = M v.  M is a dense packed lower triangle per kinematic tree (layout of k_tmap), so lane = dof gathers its row
 // with computed addresses: no index loads, no atomics, one barrier.
 DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   float *L = c.L;
   for (int i = c.lane; i < m.nv; i += 64) {
     const int w = c.I(c.ly.k_tmap)[i];
@@ -264,8 +264,8 @@ DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
 
 // ------------------------------------------------------------------------------------------ P5/P6
 DEV void fs_velocity_bias(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   // cdof_dot: velocity of everything *before* the dof in the chain, crossed with the axis
   for (int d = c.lane; d < m.nv; d += 64) {
@@ -312,26 +312,26 @@ DEV void fs_velocity_bias(const Ctx &c) {
 }
 
 DEV void fs_smooth(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   for (int d = c.lane; d < m.nv; d += 64)
     L[ly.smooth + d] = -KF(dof_damping, d) * L[ly.qvel + d] - L[ly.qfrcbias + d] + L[ly.qfrcapp + d];
   SYNC();
   for (int u = c.lane; u < m.nu; u += 64) {
     float ct = L[ly.ctrl + u];
-    if (m.act_ctrllimited[u]) ct = fminf(fmaxf(ct, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
-    float g = m.act_gear[u];
-    float len = L[ly.qpos + m.act_qpos[u]] * g, vel = L[ly.qvel + m.act_dof[u]] * g;
-    float f = m.act_gain[u] * ct + m.act_bias[3 * u] + m.act_bias[3 * u + 1] * len + m.act_bias[3 * u + 2] * vel;
-    if (m.act_forcelimited[u]) f = fminf(fmaxf(f, m.act_forcerange[2 * u]), m.act_forcerange[2 * u + 1]);
-    atomicAdd(L + ly.smooth + m.act_dof[u], f * g);
+    if (GP(m.act_ctrllimited)[u]) ct = fminf(fmaxf(ct, GP(m.act_ctrlrange)[2 * u]), GP(m.act_ctrlrange)[2 * u + 1]);
+    float g = GP(m.act_gear)[u];
+    float len = L[ly.qpos + GP(m.act_qpos)[u]] * g, vel = L[ly.qvel + GP(m.act_dof)[u]] * g;
+    float f = GP(m.act_gain)[u] * ct + GP(m.act_bias)[3 * u] + GP(m.act_bias)[3 * u + 1] * len + GP(m.act_bias)[3 * u + 2] * vel;
+    if (GP(m.act_forcelimited)[u]) f = fminf(fmaxf(f, GP(m.act_forcerange)[2 * u]), GP(m.act_forcerange)[2 * u + 1]);
+    atomicAdd(L + ly.smooth + GP(m.act_dof)[u], f * g);
   }
   for (int p = c.lane; p < m.nparts; p += 64) {
     const float *F = L + ly.xfrc + 6 * p;
     V3 f = ldv3(F), t = ldv3(F + 3);
     if (f.x != 0 || f.y != 0 || f.z != 0 || t.x != 0 || t.y != 0 || t.z != 0) {
-      int b = m.part_rbody[p], d = m.part_dofadr[p];
+      int b = GP(m.part_rbody)[p], d = GP(m.part_dofadr)[p];
       M3 R = ldm3(L + ly.xmat + 9 * b);
       V3 tq = multv(R, t + cross(ldv3(L + ly.xipos + 3 * b) - ldv3(L + ly.xpos + 3 * b), f));
       atomicAdd(L + ly.smooth + d, f.x); atomicAdd(L + ly.smooth + d + 1, f.y); atomicAdd(L + ly.smooth + d + 2, f.z);

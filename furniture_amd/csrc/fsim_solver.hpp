@@ -22,7 +22,7 @@ enum { WD_ACTIVE = 0, WD_P0 = 1, WD_C = 4, WD_AREF = 13, WD_D = 19, WD_JAR = 25,
 // x^p for x in (0, 1): the MuJoCo default solimp power is 2; anything else goes through the hardware exp2/log2
 DEV float fs_pow01(float x, float p) { return p == 2.0f ? x * x : __builtin_exp2f(p * __builtin_log2f(x)); }
 
-DEV float fs_impedance(const float *solref, const float *solimp, float x0, float timestep, float *k, float *b) {
+template <class P1, class P2> DEV float fs_impedance(P1 solref, P2 solimp, float x0, float timestep, float *k, float *b) {
   float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
   float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
   float x = fabsf(x0) / width, imp;
@@ -54,8 +54,8 @@ DEV V3 fs_ptvel(const Ctx &c, int off, int bt, V3 p) {
 
 // returns 1 if any constraint couples two kinematic trees
 DEV int fs_make_constraints(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int nslot = c.I(ly.scal)[SC_NSLOT];
   int coupled = 0, ncon = 0;
@@ -72,13 +72,13 @@ DEV int fs_make_constraints(const Ctx &c) {
     if (dist >= incm) { ri[C_ACTIVE] = 2; continue; }
     V3 pos = ldv3(r + C_POS);
     V3 vrel = fs_ptvel(c, ly.cvel, bt2, pos) - fs_ptvel(c, ly.cvel, bt1, pos);
-    float mix = m.cg_solmix[g1] / (m.cg_solmix[g1] + m.cg_solmix[g2]);
+    float mix = GP(m.cg_solmix)[g1] / (GP(m.cg_solmix)[g1] + GP(m.cg_solmix)[g2]);
     float sr[2], si[5];
-    for (int i = 0; i < 2; i++) sr[i] = mix * m.cg_solref[2 * g1 + i] + (1 - mix) * m.cg_solref[2 * g2 + i];
-    for (int i = 0; i < 5; i++) si[i] = mix * m.cg_solimp[5 * g1 + i] + (1 - mix) * m.cg_solimp[5 * g2 + i];
+    for (int i = 0; i < 2; i++) sr[i] = mix * GP(m.cg_solref)[2 * g1 + i] + (1 - mix) * GP(m.cg_solref)[2 * g2 + i];
+    for (int i = 0; i < 5; i++) si[i] = mix * GP(m.cg_solimp)[5 * g1 + i] + (1 - mix) * GP(m.cg_solimp)[5 * g2 + i];
     float k, b;
     float imp = fs_impedance(sr, si, dist - incm, m.timestep, &k, &b);
-    float R = fmaxf((1 - imp) / imp * (m.cg_invweight[g1] + m.cg_invweight[g2]), 1e-15f);
+    float R = fmaxf((1 - imp) / imp * (GP(m.cg_invweight)[g1] + GP(m.cg_invweight)[g2]), 1e-15f);
     r[C_DN] = 1.0f / R;
     r[C_DT] = fmaxf(m.impratio, 1e-15f) / R;
     V3 fx, fy, fz;
@@ -94,16 +94,16 @@ DEV int fs_make_constraints(const Ctx &c) {
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
-    int li = s >> 1, side = s & 1, d = m.lim_dof[li];
-    float q = L[ly.qpos + m.dof_qposadr[d]];
-    float dist = side ? m.lim_range[2 * li + 1] - q : q - m.lim_range[2 * li];
-    float mg = m.lim_margin[li];
+    int li = s >> 1, side = s & 1, d = GP(m.lim_dof)[li];
+    float q = L[ly.qpos + GP(m.dof_qposadr)[d]];
+    float dist = side ? GP(m.lim_range)[2 * li + 1] - q : q - GP(m.lim_range)[2 * li];
+    float mg = GP(m.lim_margin)[li];
     int act = dist < mg;
     ri[LM_ACTIVE] = act;
     if (!act) continue;
     float sign = side ? -1.0f : 1.0f, k, b;
-    float imp = fs_impedance(m.lim_solref + 2 * li, m.lim_solimp + 5 * li, dist - mg, m.timestep, &k, &b);
-    float R = fmaxf((1 - imp) / imp * m.dof_invweight0[d], 1e-15f);
+    float imp = fs_impedance(GP(m.lim_solref) + 2 * li, GP(m.lim_solimp) + 5 * li, dist - mg, m.timestep, &k, &b);
+    float R = fmaxf((1 - imp) / imp * GP(m.dof_invweight0)[d], 1e-15f);
     r[LM_D] = 1.0f / R;
     r[LM_AREF] = -b * sign * L[ly.qvel + d] - k * imp * (dist - mg);
     r[LM_SIGN] = sign;
@@ -116,7 +116,7 @@ DEV int fs_make_constraints(const Ctx &c) {
     ri[WD_ACTIVE] = act;
     if (!act) continue;
     coupled = 1;
-    int b1 = m.eq_rbody1[e], b2 = m.eq_rbody2[e];
+    int b1 = GP(m.eq_rbody1)[e], b2 = GP(m.eq_rbody2)[e];
     if (b1 != 0 && b2 != 0) {
       int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
       if (t1 != t2) { atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
@@ -143,8 +143,8 @@ DEV int fs_make_constraints(const Ctx &c) {
     for (int q = 0; q < 3; q++) jv[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
     for (int q = 0; q < 6; q++) {
       float k, b;
-      float imp = fs_impedance(m.eq_solref + 2 * e, m.eq_solimp + 5 * e, cpos[q], m.timestep, &k, &b);
-      float R = fmaxf((1 - imp) / imp * m.eq_invweight[2 * e + (q >= 3)], 1e-15f);
+      float imp = fs_impedance(GP(m.eq_solref) + 2 * e, GP(m.eq_solimp) + 5 * e, cpos[q], m.timestep, &k, &b);
+      float R = fmaxf((1 - imp) / imp * GP(m.eq_invweight)[2 * e + (q >= 3)], 1e-15f);
       r[WD_D + q] = 1.0f / R;
       r[WD_AREF + q] = -b * jv[q] - k * imp * cpos[q];
     }
@@ -210,7 +210,7 @@ DEV int fs_make_constraints(const Ctx &c) {
 
 // W_b = sum_{d in chain(b)} cdof_d * vec_d
 DEV void fs_body_spatial(const Ctx &c, int off_vec) {
-  const DModel &m = c.m;
+  CModel &m = c.m;
   float *L = c.L;
   for (int b = c.lane; b < m.nr; b += 64) {
     S6 w = s6zero();
@@ -225,8 +225,8 @@ DEV void fs_body_spatial(const Ctx &c, int off_vec) {
 
 // rec[dst..] = J * vec (- aref if sub_aref), using W from fs_body_spatial(vec)
 DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int nslot = c.I(ly.scal)[SC_NSLOT];
   for (int s = c.lane; s < nslot; s += 64) {
@@ -294,8 +294,8 @@ DEV int fs_cone(const float *jar, float Dn, float Dt, float fri, float *f, float
 
 // constraint cost at jar + alpha*jp, and the first/second directional derivatives along jp
 DEV void fs_line_eval(const Ctx &c, float alpha, float *cost, float *d1, float *d2) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int nslot = c.I(ly.scal)[SC_NSLOT];
   float cs = 0, a1 = 0, a2 = 0;
@@ -350,8 +350,8 @@ DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
 struct SlotK { bool on; float K[6]; };
 
 DEV SlotK fs_gradient(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   SlotK sk;
   sk.on = false;
@@ -441,8 +441,8 @@ DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
 DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   const int nH = c.I(ly.scal)[SC_HWORDS]; // packed island triangles
   const int hm = ly.hmap;
@@ -638,7 +638,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
 // reads the factor by columns, from a copy written once to LDS.
 template <int NLOC>
 DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
-  const Layout &ly = c.ly;
+  CLayout &ly = c.ly;
   float *L = c.L;
   float *H = L + ly.H;
   const int nv = c.m.nv;
@@ -735,7 +735,7 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
 // islands larger than 32 dofs (e.g. the fully welded table plus the robot): same algorithm with the factor left in LDS,
 // left-looking, no unrolling -- slow path, kept small on purpose
 DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
-  const Layout &ly = c.ly;
+  CLayout &ly = c.ly;
   float *L = c.L;
   float *H = L + ly.H;
   const int nv = c.m.nv;
@@ -804,7 +804,7 @@ DEV float fs_dotv(const Ctx &c, int a, int b) {
 
 // total cost at the current (x, Mx, jar)
 DEV float fs_total_cost(const Ctx &c) {
-  const Layout &ly = c.ly;
+  CLayout &ly = c.ly;
   float g = 0;
   for (int d = c.lane; d < c.m.nv; d += 64) g += c.L[ly.x + d] * (0.5f * c.L[ly.Mx + d] - c.L[ly.smooth + d]);
   g = wave_sum(g);
@@ -823,8 +823,8 @@ DEV void fs_solve(const Ctx &c, int coupled) {
 #ifdef FSIM_PROFILE
   long long t0s_ = clock64();
 #endif
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   int *scal = c.I(ly.scal);
   int nslot = scal[SC_NSLOT];
@@ -914,8 +914,8 @@ DEV void fs_solve(const Ctx &c, int coupled) {
 // ------------------------------------------------------------------------------------------ P8
 // qacc in ly.x, M*qacc in ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
 DEV void fs_integrate_body(const Ctx &c) {
-  const DModel &m = c.m;
-  const Layout &ly = c.ly;
+  CModel &m = c.m;
+  CLayout &ly = c.ly;
   float *L = c.L;
   float h = m.timestep;
   // (M + h D) a' = M a : the same lane-per-row block Cholesky as the Newton step, on H = M + h diag(damping)
