@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fsim.h"))
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(s) <= os.path.getmtime(_LIBPATH) for s in srcs):
         return _LIBPATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            "-o", _LIBPATH, os.path.join(_CSRC, "fsim.hip")]
     if verbose:
         print(" ".join(cmd))
