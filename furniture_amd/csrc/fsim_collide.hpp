@@ -12,7 +12,6 @@
 // C_DIST / C_INCM are consumed by fs_make_constraints before it writes C_AREF + 1 / + 2 over them.
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2 = 10, C_G1 = 11, C_G2 = 12, C_AREF = 13,
        C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17, C_JAR = 18, C_JP = 21 };
-enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8, SC_HWORDS = 160, SC_TWORDS = 161, SC_ADJ = 64, SC_ISL = 80, SC_TMP = 96, SC_PADJ = 144, SC_WORDS = 164 }; // 9..14 are scratch of the env logic (fsim_env.hpp), 16..63 profile counters
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
 

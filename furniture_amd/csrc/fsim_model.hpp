@@ -10,10 +10,10 @@
 #include <stdint.h>
 
 #define FSIM_MAXANG 8
-#define FSIM_CONW 24     // words per contact slot
+#define FSIM_CONW 25     // words per contact slot: 24 used + 1 pad -- an ODD stride spreads lane = slot accesses over all 64 LDS banks (24 would hit 8)
 #define FSIM_WELDW 44    // words per weld record
-#define FSIM_LIMW 8      // words per joint-limit record
-#define FSIM_MAXSURV 64  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
+#define FSIM_LIMW 9      // words per joint-limit record (7 used; odd stride, see FSIM_CONW)
+#define FSIM_MAXSURV 48  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
@@ -79,6 +79,17 @@ struct Layout {
   int k_dof_parent, k_r_submask, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_chain, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
   int k_begin, k_end;
 };
+
+// per-env scalars in LDS (Layout::scal).  0..8 named, 9..14 scratch of the env logic (fsim_env.hpp), then -- in
+// -DFSIM_PROFILE builds only -- 48 words of profile counters (16..63), then the island bookkeeping of the Newton system.
+#ifdef FSIM_PROFILE
+#define FSIM_SC_BASE 64
+#else
+#define FSIM_SC_BASE 16
+#endif
+enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8,
+       SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 80,
+       SC_HWORDS = FSIM_SC_BASE + 96, SC_TWORDS = FSIM_SC_BASE + 97, SC_WORDS = FSIM_SC_BASE + 100 };
 
 // Device code reaches the (read-only, launch-constant) model and layout structs through the CONSTANT address space:
 // their fields then come in by scalar loads (s_load_dword through the scalar cache, hoistable and CSE-able across

@@ -94,7 +94,7 @@ DEV void fs_load_cache(const Ctx &c) {
   if (c.lane == 0) {
     int w = 0;
     for (int u = 0; u < m.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
-    c.I(c.ly.scal)[161] = w; // SC_TWORDS (fsim_collide.hpp): packed size of the tree-block system
+    c.I(c.ly.scal)[SC_TWORDS] = w; // packed size of the tree-block system
   }
   SYNC();
 }
