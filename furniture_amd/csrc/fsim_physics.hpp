@@ -9,7 +9,14 @@
 #include "fsim_math.hpp"
 #include "fsim_model.hpp"
 
+// Ordering point between lanes of the env's wavefront (a workgroup is exactly one wave).  A compiler-only barrier
+// (-DFSIM_SW_SYNC: a wave's LDS instructions execute in issue order, so no s_barrier / s_waitcnt is strictly needed) passes
+// every test but measures the same (10.15 vs 10.25 ms per step), so the real barrier stays the default.
+#ifdef FSIM_SW_SYNC
+#define SYNC() __asm__ volatile("" ::: "memory")
+#else
 #define SYNC() __syncthreads()
+#endif
 
 struct Ctx {
   float *L;          // LDS base (state image followed by work arrays)
