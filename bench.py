@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--agent", default=AGENT, help="(exploration only; the benchmark workload is the default)")
+    ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
@@ -94,8 +96,8 @@ def main():
     n = args.envs_per_gpu
     lo, hi = shard_range(rank, world, n)
 
-    m = load_compiled(AGENT, FURNITURE)
-    ecfg = make_config(unity=False, record_vid=False, control_type="impedance", furniture_name=FURNITURE,
+    m = load_compiled(args.agent, args.furniture)
+    ecfg = make_config(unity=False, record_vid=False, control_type="impedance", furniture_name=args.furniture,
                        max_episode_steps=MAX_EPISODE_STEPS, seed=SEED)
     cfg = default_config()
     cfg.max_episode_steps = MAX_EPISODE_STEPS
@@ -197,11 +199,12 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n) == (AGENT, FURNITURE, ENVS_PER_GPU)
+            else "env-steps/sec (whole node), EXPLORATION %s+%s %d envs/GPU" % (args.agent, args.furniture, n), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FurnitureSawyerEnv + table_lack_0825, impedance control, %d envs/GPU, U(-1,1)^9 actions, "
-                                   "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % n,
+            "config": {"workload": "Furniture%sEnv + %s, impedance control, %d envs/GPU, U(-1,1)^%d actions, "
+                                   "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
                        "physics_substeps_per_s": value * 50, "obs_finite": finite,
