@@ -5,7 +5,10 @@ TEST INFRASTRUCTURE (see oracle/fsim_oracle.h): this is the behavioural spec the
 toy_table, 1 env, CPU reference step(), plumbing, no GPU").  Each method cites the reference lines
 it follows; ``F.py`` = /root/reference/furniture/env/furniture.py.
 
-PARITY UNPINNED against MuJoCo itself (the physics under ``self.sim`` is oracle/fsim_oracle.c).
+PARITY UNPINNED against MuJoCo itself (the physics under ``self.sim`` is oracle/fsim_oracle.c).  The env LOGIC here is
+pinned where the reference's own methods can be run without MuJoCo: _is_aligned, _find_group/_merge_groups,
+_compute_reward and _try_connect reproduce the outputs of FurnitureEnv's methods called on a fake ``self``
+(tests/golden/env_logic.npz, scripts/make_golden_env_logic.py, tests/test_env_logic_golden.py).
 """
 
 import os

@@ -1,0 +1,235 @@
+"""Generate tests/golden/env_logic.npz by calling the REFERENCE's own FurnitureEnv methods on a fake `self`.
+
+Runs only in the build container (needs /root/reference).  The reference module imports mujoco_py, gym, pyquaternion,
+hjson, ... none of which exist here: a meta-path finder hands out inert stub modules for them, which is enough because
+the methods exercised are plain numpy code on values we inject:
+  * FurnitureEnv._is_aligned          (furniture.py:1057-1153)  -> bool + _target_connector_xquat
+  * FurnitureEnv._find_group/_merge_groups (furniture.py:2738-2759) -> union-find with path compression
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+
+STUBS = {"gym", "pyquaternion", "hjson", "mujoco_py", "colorlog", "cv2", "imageio", "moviepy", "pybullet", "PIL", "glfw",
+         "matplotlib", "tqdm", "h5py", "wandb", "mpi4py", "gdown"}
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __getattr__(self, n):
+        return _Dummy()
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        full = self.__name__ + "." + name
+        if full in sys.modules:
+            return sys.modules[full]
+        return type(name, (_Dummy,), {})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in STUBS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, "/root/reference")
+    for _ in range(12):  # stub whatever else is missing, one module at a time
+        try:
+            import furniture.env.furniture as F
+            return F
+        except ModuleNotFoundError as e:
+            STUBS.add(e.name.split(".")[0])
+            for k in [k for k in sys.modules if k.startswith("furniture")]:
+                del sys.modules[k]
+    raise RuntimeError("could not import the reference")
+
+
+def rand_rot(rng):
+    q = rng.randn(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def axis_rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def main():
+    F = import_reference()
+    Env = F.FurnitureEnv
+    rng = np.random.RandomState(11)
+    n = 400
+    P1, R1, P2, R2, NANG, ANG, OK, TQ = [], [], [], [], [], [], [], []
+    for case in range(n):
+        r1 = rand_rot(rng)
+        p1 = rng.uniform(-0.5, 0.5, 3)
+        kind = case % 4
+        angles = [[], [0.0, 90.0, 180.0, 270.0], [0.0, 180.0], [45.0]][kind]
+        # second site: roughly opposed / aligned, perturbed so that every branch of the test is taken
+        tilt = axis_rot(rng.randn(3), rng.choice([0.02, 0.2, 0.6]) * rng.rand())
+        spin = axis_rot(r1[:, 2], np.deg2rad(rng.choice([0, 45, 90, 180, 270]) + rng.uniform(-30, 30)))
+        r2 = tilt @ spin @ r1
+        d = rng.choice([0.02, 0.06, 0.12]) * (0.5 + rng.rand())
+        direction = r1[:, 2] * rng.choice([-1, 1]) if rng.rand() < 0.6 else rng.randn(3)
+        direction = direction / np.linalg.norm(direction)
+        p2 = p1 + d * direction
+        name1 = "a-b," + "".join("%g," % a for a in angles) + "conn_site1"
+        name2 = "b-a," + "".join("%g," % a for a in angles) + "conn_site2"
+        poses = {name1: (p1, r1), name2: (p2, r2)}
+        fake = types.SimpleNamespace()
+        fake._config = types.SimpleNamespace(alignment_pos_dist=0.1, alignment_rot_dist_up=0.9, alignment_rot_dist_forward=0.9,
+                                             alignment_project_dist=0.3)
+        fake._site_xpos_xquat = lambda nm: np.concatenate([poses[nm][0], [1, 0, 0, 0]])
+        fake._get_up_vector = lambda nm: poses[nm][1][:, 2].copy()
+        fake._get_forward_vector = lambda nm: poses[nm][1][:, 1].copy()
+        fake._target_connector_xquat = np.full(4, np.nan)
+        ok = Env._is_aligned(fake, name1, name2)
+        P1.append(p1); R1.append(r1); P2.append(p2); R2.append(r2)
+        NANG.append(len(angles)); ANG.append(angles + [0.0] * (4 - len(angles)))
+        OK.append(bool(ok)); TQ.append(np.asarray(fake._target_connector_xquat, dtype=np.float64))
+    out = dict(p1=np.array(P1), R1=np.array(R1), p2=np.array(P2), R2=np.array(R2), nang=np.array(NANG), angles=np.array(ANG),
+               aligned=np.array(OK), target_quat=np.array(TQ))
+    # union-find traces
+    ops, groups = [], []
+    for trial in range(20):
+        fake = types.SimpleNamespace(_object_group=list(range(7)), _object_name2id={})
+        fake._find_group = lambda i, f=fake: Env._find_group(f, i)
+        seq = []
+        for _ in range(10):
+            a, b = rng.randint(0, 7, 2)
+            Env._merge_groups(fake, int(a), int(b))
+            seq.append((a, b))
+            _ = Env._find_group(fake, int(rng.randint(0, 7)))
+        ops.append(seq)
+        groups.append([Env._find_group(fake, i) for i in range(7)])
+    # _compute_reward (furniture.py:482-541): stateful touch / pick latches over a random contact history.
+    # scene: geom 0 = FLOOR (body 0); geoms 1,2 = left finger (body 1); 3,4 = right finger (body 2); 5..10 = three parts
+    geom_body = np.array([0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5])
+    part_bodies = [3, 4, 5]
+    hist_g1, hist_g2, hist_n, hist_rew, hist_info, hist_ac, hist_conn = [], [], [], [], [], [], []
+    fake = types.SimpleNamespace()
+    fake._agent_type = "Sawyer"
+    fake._arms = ["right"]
+    fake._object_body_ids = part_bodies
+    fake.l_finger_geom_ids = {"right": [1, 2]}
+    fake.r_finger_geom_ids = {"right": [3, 4]}
+    fake._touched = {b: False for b in part_bodies}
+    fake._picked = {b: False for b in part_bodies}
+    fake._config = types.SimpleNamespace(touch_reward=10, pick_reward=100, success_reward=100, ctrl_penalty_coef=1e-3)
+    fake._ctrl_penalty_coef = 1e-3
+    fake._num_connected = 0
+    fake._prev_num_connected = 0
+    fake._ctrl_penalty = lambda a, f=fake: Env._ctrl_penalty(f, a)
+    fake.sim = types.SimpleNamespace(model=types.SimpleNamespace(geom_name2id=lambda nm: 0, geom_bodyid=geom_body), data=types.SimpleNamespace())
+    for t in range(60):
+        ncon = int(rng.randint(0, 9))
+        g1 = rng.randint(0, 11, 8)
+        g2 = rng.randint(0, 11, 8)
+        fake.sim.data.ncon = ncon
+        fake.sim.data.contact = [types.SimpleNamespace(geom1=int(a), geom2=int(b)) for a, b in zip(g1, g2)]
+        if rng.rand() < 0.15:
+            fake._num_connected += 1
+        ac = rng.uniform(-1, 1, 9)
+        rew, done, info = Env._compute_reward(fake, ac)
+        hist_g1.append(g1); hist_g2.append(g2); hist_n.append(ncon); hist_rew.append(rew); hist_ac.append(ac)
+        hist_conn.append(fake._num_connected)
+        hist_info.append([info["success_reward"], info["touch_reward"], info["pick_reward"], info["ctrl_penalty"]])
+    out.update(rw_geom_body=geom_body, rw_g1=np.array(hist_g1), rw_g2=np.array(hist_g2), rw_ncon=np.array(hist_n), rw_reward=np.array(hist_rew),
+               rw_info=np.array(hist_info), rw_action=np.array(hist_ac), rw_num_connected=np.array(hist_conn))
+    # _try_connect (furniture.py:926-1042): candidate-site search order, name-pair matching, weld-existence test, used-site
+    # skipping and the _connect_step bookkeeping, on the REAL site / body / weld tables of Sawyer + table_lack_0825
+    # (from the compiled model shipped in this repo); _is_aligned / _connect / _move_objects_target are recorders.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd import transform_utils as MyT
+    cm = load_compiled("Sawyer", "table_lack_0825")
+    site_names, body_names = list(cm.meta["site_names"]), list(cm.meta["body_names"])
+    parts = list(cm.meta["part_names"])
+    tc = dict(part1=[], part2=[], merges=[], used=[], aligned=[], nsteps=[], step_in=[], ret=[], conn=[], step_out=[], moved=[])
+    for trial in range(120):
+        fake = types.SimpleNamespace()
+        fake._object_names = parts
+        fake._object_name2id = {n: i for i, n in enumerate(parts)}
+        fake._object_group = list(range(len(parts)))
+        fake._find_group = lambda i, f=fake: Env._find_group(f, i)
+        merges = []
+        for _ in range(int(rng.randint(0, 3))):
+            a, b = rng.randint(0, len(parts), 2)
+            Env._merge_groups(fake, int(a), int(b))
+            merges.append((int(a), int(b)))
+        conn_sites = [j for j, nm in enumerate(site_names) if "conn_site" in nm]
+        used = [j for j in conn_sites if rng.rand() < 0.15]
+        fake._connected_sites = set(used)
+        truth = {(a, b) for a in conn_sites for b in conn_sites if rng.rand() < 0.08}
+        calls = dict(conn=(-1, -1), moved=-1)
+        fake._is_aligned = lambda n1, n2: (site_names.index(n1), site_names.index(n2)) in truth
+        fake._connect = lambda s1, s2, aa: calls.__setitem__("conn", (int(s1), int(s2)))
+        fake._move_objects_target = lambda part, pos, rot, gravity=1: calls.__setitem__("moved", parts.index(part))
+        fake._site_xpos_xquat = lambda nm: np.array([0.1, 0.2, 0.3, 1, 0, 0, 0], dtype=float)
+        fake._get_qpos = lambda nm: np.array([0.0, 0.0, 0.1, 1, 0, 0, 0], dtype=float)
+        fake._target_connector_xquat = np.array([1.0, 0, 0, 0])
+        fake._auto_align = True
+        nsteps = int(rng.choice([0, 3]))
+        fake._num_connect_steps = nsteps
+        fake._connect_step = int(rng.randint(0, nsteps + 1)) if nsteps else 0
+        if fake._connect_step > 0:  # tables exist from an earlier call
+            fake.next_pos = [np.zeros(3)] * nsteps
+            fake.next_rot = [np.array([1.0, 0, 0, 0])] * nsteps
+        step_in = fake._connect_step
+        fake.sim = types.SimpleNamespace(model=types.SimpleNamespace(
+            body_name2id=lambda nm: body_names.index(nm), site_names=site_names, site_bodyid=np.asarray(cm.site_bodyid),
+            eq_obj1id=np.asarray(cm.eq_obj1id), eq_obj2id=np.asarray(cm.eq_obj2id), body_names=body_names))
+        p1 = int(rng.randint(0, len(parts)))
+        p2 = int(rng.randint(0, len(parts))) if rng.rand() < 0.5 else -1
+        # transform_to_target_quat needs pyquaternion: point the stub at this repo's Quaternion (only used when nsteps > 0)
+        F.T.Quaternion = MyT.Quaternion
+        ret = Env._try_connect(fake, parts[p1], parts[p2] if p2 >= 0 else None)
+        tc["part1"].append(p1); tc["part2"].append(p2)
+        tc["merges"].append(merges + [(-1, -1)] * (2 - len(merges)))
+        tc["used"].append([1 if j in fake._connected_sites and j in used else 0 for j in range(len(site_names))])
+        al = np.zeros((len(site_names), len(site_names)), dtype=np.uint8)
+        for a, b in truth:
+            al[a, b] = 1
+        tc["aligned"].append(al)
+        tc["nsteps"].append(nsteps); tc["step_in"].append(step_in); tc["ret"].append(bool(ret))
+        tc["conn"].append(calls["conn"]); tc["step_out"].append(fake._connect_step); tc["moved"].append(calls["moved"])
+    for k, v in tc.items():
+        out["tc_" + k] = np.array(v)
+    out["uf_ops"] = np.array(ops)
+    out["uf_roots"] = np.array(groups)
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "env_logic.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, "aligned fraction %.2f" % np.mean(OK), "with target quat set in %d cases" % int(np.isfinite(np.array(TQ)).all(axis=1).sum()))
+
+
+if __name__ == "__main__":
+    main()
