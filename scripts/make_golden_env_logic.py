@@ -224,6 +224,58 @@ def main():
         tc["conn"].append(calls["conn"]); tc["step_out"].append(fake._connect_step); tc["moved"].append(calls["moved"])
     for k, v in tc.items():
         out["tc_" + k] = np.array(v)
+    # _connect / _activate_weld / _get_next_subtask (furniture.py:847-924, 2761-2776, 2723-2736): collision-mask rewrite,
+    # weld data + activation, group merge, counters and next subtask on the real tables; motion helpers are no-ops.
+    cn = dict(s1=[], s2=[], merges=[], qpos=[], ct=[], ca=[], eq_active=[], eq_data=[], roots=[], sub=[], ncon=[])
+    geom_bodyid = np.asarray(cm.geom_bodyid)
+    part_body = [body_names.index(pn) for pn in parts]
+    for trial in range(40):
+        fake = types.SimpleNamespace()
+        fake._object_names = parts
+        fake._object_name2id = {n: i for i, n in enumerate(parts)}
+        fake._object_body_id2name = {b: n for b, n in zip(part_body, parts)}
+        fake._object_group = list(range(len(parts)))
+        fake._find_group = lambda i, f=fake: Env._find_group(f, i)
+        fake._merge_groups = lambda a, b, f=fake: Env._merge_groups(f, a, b)
+        merges = []
+        for _ in range(int(rng.randint(0, 3))):
+            a, b = rng.randint(0, len(parts), 2)
+            Env._merge_groups(fake, int(a), int(b))
+            merges.append((int(a), int(b)))
+        conn_sites = [j for j, nm in enumerate(site_names) if "conn_site" in nm]
+        s1, s2 = [int(x) for x in rng.choice(conn_sites, 2, replace=False)]
+        qpos = {pn: np.concatenate([rng.uniform(-0.5, 0.5, 3), (lambda q: q / np.linalg.norm(q))(rng.randn(4))]) for pn in parts}
+        ct0 = np.asarray(cm.geom_contype).copy()
+        ca0 = np.asarray(cm.geom_conaffinity).copy()
+        pc = np.asarray(cm.geom_is_partcol).astype(bool)
+        ct0[pc] = 1; ca0[pc] = 1   # as left by _reset for the part colliders
+        model = types.SimpleNamespace(site_names=site_names, site_bodyid=np.asarray(cm.site_bodyid), body_names=body_names,
+                                      body_id2name=lambda b: body_names[b], geom_bodyid=geom_bodyid, geom_contype=ct0, geom_conaffinity=ca0,
+                                      eq_obj1id=np.asarray(cm.eq_obj1id), eq_obj2id=np.asarray(cm.eq_obj2id),
+                                      eq_data=np.zeros((len(cm.eq_obj1id), 7)), eq_active=np.zeros(len(cm.eq_obj1id), dtype=int))
+        fake.sim = types.SimpleNamespace(model=model, forward=lambda: None, step=lambda: None)
+        fake._connected_sites = set()
+        fake._gravity_compensation = 0
+        fake._align_connectors = lambda a, b, gravity=1: None
+        fake._agent_type = "Sawyer"
+        fake._get_bounding_box = lambda body: (np.array([0.0, 0.0, 0.01]), np.array([0.1, 0.1, 0.1]))
+        fake._move_rotate_object = lambda *a, **k: True
+        fake._get_qpos = lambda nm: qpos[nm]
+        fake._activate_weld = lambda a, b, f=fake: Env._activate_weld(f, a, b)
+        fake._get_next_subtask = lambda f=fake: Env._get_next_subtask(f)
+        fake._num_connected = int(rng.randint(0, 3))
+        n0 = fake._num_connected
+        fake._config = types.SimpleNamespace(reset_robot_after_attach=False)
+        F.T.Quaternion = MyT.Quaternion
+        Env._connect(fake, s1, s2, True)
+        cn["s1"].append(s1); cn["s2"].append(s2); cn["merges"].append(merges + [(-1, -1)] * (2 - len(merges)))
+        cn["qpos"].append(np.stack([qpos[pn] for pn in parts]))
+        cn["ct"].append(model.geom_contype.copy()); cn["ca"].append(model.geom_conaffinity.copy())
+        cn["eq_active"].append(model.eq_active.copy()); cn["eq_data"].append(model.eq_data.copy())
+        cn["roots"].append([Env._find_group(fake, i) for i in range(len(parts))])
+        cn["sub"].append([fake._subtask_part1, fake._subtask_part2]); cn["ncon"].append([n0, fake._num_connected])
+    for k, v in cn.items():
+        out["cn_" + k] = np.array(v)
     out["uf_ops"] = np.array(ops)
     out["uf_roots"] = np.array(groups)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "env_logic.npz")
