@@ -276,6 +276,63 @@ def main():
         cn["sub"].append([fake._subtask_part1, fake._subtask_part2]); cn["ncon"].append([n0, fake._num_connected])
     for k, v in cn.items():
         out["cn_" + k] = np.array(v)
+    # _setup_action (furniture.py:3332-3379) with the reference's REAL gripper classes (format_action 1 -> 2) and the
+    # actuator_ctrlrange of the compiled Sawyer / Baxter models
+    from furniture.env.models.grippers import gripper_factory
+    for agent, furn, ndof, arms in (("Sawyer", "table_lack_0825", 7, ["right"]), ("Baxter", "desk_mikael_1064", 14, ["right", "left"])):
+        cmx = load_compiled(agent, furn)
+        acts, outs, frcs = [], [], []
+        for trial in range(16):
+            fake = types.SimpleNamespace()
+            fake._rescale_actions = True
+            fake._agent_type = agent
+            fake.mujoco_robot = types.SimpleNamespace(dof=ndof)
+            fake.gripper = {a: gripper_factory("TwoFingerGripper") for a in arms}
+            bias = rng.randn(cmx.nv)
+            fake.sim = types.SimpleNamespace(model=types.SimpleNamespace(actuator_ctrlrange=np.asarray(cmx.actuator_ctrlrange)),
+                                             data=types.SimpleNamespace(qfrc_applied=np.zeros(cmx.nv), qfrc_bias=bias))
+            fake._ref_joint_vel_indexes_all = list(np.asarray(cmx.arm_dofadr))
+            fake._ref_gripper_joint_vel_indexes_all = list(np.asarray(cmx.grip_dofadr))
+            a = rng.uniform(-1.5, 1.5, ndof + len(arms))
+            ctrl = Env._setup_action(fake, a.copy())
+            acts.append(a); outs.append(np.asarray(ctrl, dtype=float)); frcs.append(np.concatenate([bias, fake.sim.data.qfrc_applied]))
+        out["sa_%s_action" % agent] = np.array(acts)
+        out["sa_%s_ctrl" % agent] = np.array(outs)
+        out["sa_%s_bias_applied" % agent] = np.array(frcs)
+    # _get_obs (furniture.py:1344-1387 + furniture_sawyer.py:103-155 / furniture_baxter.py:98-165): component order of
+    # object_ob / robot_ob on random simulator arrays, using real instances created without __init__
+    import furniture.env.furniture_sawyer as FS
+    import furniture.env.furniture_baxter as FB
+    for agent, furn, cls, arms in (("Sawyer", "table_lack_0825", FS.FurnitureSawyerEnv, ["right"]),
+                                   ("Baxter", "desk_mikael_1064", FB.FurnitureBaxterEnv, ["right", "left"])):
+        cmx = load_compiled(agent, furn)
+        bn, sn = list(cmx.meta["body_names"]), list(cmx.meta["site_names"])
+        pnames = list(cmx.meta["part_names"])
+        nj = len(cmx.arm_qposadr) // len(arms)
+        xpos, xquat = rng.randn(len(bn), 3), rng.randn(len(bn), 4)
+        qpos, qvel = rng.randn(cmx.nq), rng.randn(cmx.nv)
+        sxpos, svp, svr = rng.randn(len(sn), 3), rng.randn(len(sn), 3), rng.randn(len(sn), 3)
+        inst = object.__new__(cls)
+        inst._unity = None  # (read by the destructor)
+        inst._visual_ob = inst._segmentation_ob = inst._subtask_ob = False
+        inst._object_ob = inst._object_ob_all = inst._robot_ob = True
+        inst._object_names = pnames
+        inst._subtask_part1 = inst._subtask_part2 = 0
+        inst._control_type = "impedance"
+        inst._arms = arms
+        inst._ref_joint_pos_indexes = {a: list(np.asarray(cmx.arm_qposadr)[i * nj:(i + 1) * nj]) for i, a in enumerate(arms)}
+        inst._ref_joint_vel_indexes = {a: list(np.asarray(cmx.arm_dofadr)[i * nj:(i + 1) * nj]) for i, a in enumerate(arms)}
+        inst._ref_gripper_joint_pos_indexes = {a: list(np.asarray(cmx.grip_qposadr)[2 * i:2 * i + 2]) for i, a in enumerate(arms)}
+        inst.eef_site_id = {a: int(cmx.eef_siteid[i]) for i, a in enumerate(arms)}
+        data = types.SimpleNamespace(qpos=qpos, qvel=qvel, site_xpos=sxpos, site_xvelp=svp, site_xvelr=svr, body_xquat=xquat,
+                                     get_body_xpos=lambda nm: xpos[bn.index(nm)], get_body_xquat=lambda nm: xquat[bn.index(nm)])
+        inst.sim = types.SimpleNamespace(data=data, model=types.SimpleNamespace(body_names=bn, geom_names=[], site_names=sn,
+                                                                                   body_name2id=lambda nm: bn.index(nm)))
+        ob = cls._get_obs(inst)
+        out["ob_%s_xpos" % agent], out["ob_%s_xquat" % agent] = xpos, xquat
+        out["ob_%s_qpos" % agent], out["ob_%s_qvel" % agent] = qpos, qvel
+        out["ob_%s_site" % agent] = np.concatenate([sxpos, svp, svr], axis=1)
+        out["ob_%s_object_ob" % agent], out["ob_%s_robot_ob" % agent] = ob["object_ob"], ob["robot_ob"]
     out["uf_ops"] = np.array(ops)
     out["uf_roots"] = np.array(groups)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "env_logic.npz")
