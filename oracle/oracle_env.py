@@ -7,7 +7,8 @@ it follows; ``F.py`` = /root/reference/furniture/env/furniture.py.
 
 PARITY UNPINNED against MuJoCo itself (the physics under ``self.sim`` is oracle/fsim_oracle.c).  The env LOGIC here is
 pinned where the reference's own methods can be run without MuJoCo: _is_aligned, _find_group/_merge_groups,
-_compute_reward and _try_connect reproduce the outputs of FurnitureEnv's methods called on a fake ``self``
+_compute_reward, _try_connect, _connect/_activate_weld/_get_next_subtask, _setup_action, _get_obs and _step_discrete
+reproduce the outputs of FurnitureEnv's methods called on a fake ``self``
 (tests/golden/env_logic.npz, scripts/make_golden_env_logic.py, tests/test_env_logic_golden.py).
 """
 

@@ -333,6 +333,47 @@ def main():
         out["ob_%s_qpos" % agent], out["ob_%s_qvel" % agent] = qpos, qvel
         out["ob_%s_site" % agent] = np.concatenate([sxpos, svp, svr], axis=1)
         out["ob_%s_object_ob" % agent], out["ob_%s_robot_ob" % agent] = ob["object_ob"], ob["robot_ob"]
+    # _step_discrete (furniture.py:800-845): the Cursor agent's control flow with scripted helper outcomes; the trace of
+    # helper calls (kind, cursor, payload) is the golden
+    sd = dict(action=[], sel_in=[], outcomes=[], cstep_in=[], trace=[], sel_out=[], cstep_out=[])
+    for trial in range(240):
+        a = rng.uniform(-1, 1, 15)
+        sel_in = [None if rng.rand() < 0.5 else "part%d" % rng.randint(0, 5) for _ in range(2)]
+        outc = rng.rand(8) < 0.7      # move0, moverot0, move1, moverot1, (spare), and select results below
+        picks = [None if rng.rand() < 0.4 else "part%d" % rng.randint(0, 5) for _ in range(2)]
+        fake = types.SimpleNamespace(_move_speed=0.1, _rotate_speed=22.5, _cursor_selected=list(sel_in))
+        fake._connect_step = int(rng.randint(0, 3))
+        cstep_in = fake._connect_step
+        trace = []
+        qm, qr, qs = list(outc[:4]), list(outc[4:6]), list(picks)   # helper results are consumed in call order
+
+        def move_cursor(i, off, trace=trace, qm=qm):
+            trace.append((0, i, int(round(off[0] * 1e6))))
+            return bool(qm.pop(0))
+
+        def move_rotate(obj, mo, ro, trace=trace, qr=qr):
+            trace.append((1, int(obj[-1]), int(round(ro[2] * 1e3))))
+            return bool(qr.pop(0))
+
+        def select(i, trace=trace, qs=qs):
+            r = qs.pop(0)
+            trace.append((2, i, -1 if r is None else int(r[-1])))
+            return r
+
+        def try_connect(p1, p2, trace=trace):
+            trace.append((3, int(p1[-1]), int(p2[-1])))
+
+        fake._move_cursor, fake._move_rotate_object, fake._select_object, fake._try_connect = move_cursor, move_rotate, select, try_connect
+        Env._step_discrete(fake, a.copy())
+        enc = lambda v: -1 if v is None else int(v[-1])
+        sd["action"].append(a); sd["sel_in"].append([enc(v) for v in sel_in]); sd["outcomes"].append(outc.astype(np.uint8))
+        sd["cstep_in"].append(cstep_in); sd["sel_out"].append([enc(v) for v in fake._cursor_selected]); sd["cstep_out"].append(fake._connect_step)
+        tr = np.full((8, 3), -9, dtype=np.int64)
+        tr[:len(trace)] = np.array(trace).reshape(-1, 3)
+        sd["trace"].append(tr)
+        sd.setdefault("picks", []).append([enc(v) for v in picks])
+    for k, v in sd.items():
+        out["sd_" + k] = np.array(v)
     out["uf_ops"] = np.array(ops)
     out["uf_roots"] = np.array(groups)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "env_logic.npz")
