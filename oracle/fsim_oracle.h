@@ -11,7 +11,10 @@
  * below restates MuJoCo's *published* computation (kinematics, CRB, RNE, soft
  * constraint model with solref/solimp impedance, elliptic cones, PGS dual solver,
  * semi-implicit Euler with implicit joint damping) and is pinned only by analytic
- * invariants (tests/test_oracle_physics.py) and by the reference's MJCF geometry.
+ * invariants (tests/test_oracle_physics.py), by the reference's MJCF geometry, and by ONE
+ * trajectory recorded from MuJoCo itself: the first 62 frames of the reference's
+ * demos/Cursor_7.pkl are replayed within 1.5 mm (tests/test_demo_replay.py).  That is
+ * evidence, not a pin of the solver: the status stays PARITY UNPINNED.
  */
 #ifndef FSIM_ORACLE_H
 #define FSIM_ORACLE_H

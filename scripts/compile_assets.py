@@ -15,7 +15,7 @@ from furniture_amd.mjcf import assemble, model  # noqa: E402
 DEFAULT = [
     ("Sawyer", "table_lack_0825"), ("Sawyer", "swivel_chair_0700"), ("Sawyer", "toy_table"),
     ("Sawyer", "chair_agne_0007"), ("Sawyer", "shelf_ivar_0678"), ("Baxter", "desk_mikael_1064"),
-    ("Baxter", "table_lack_0825"), ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"),
+    ("Baxter", "table_lack_0825"), ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"), ("Cursor", "swivel_chair_0700"),
 ]
 
 
