@@ -202,6 +202,7 @@ struct fsim {
   Layout *d_ly = nullptr;
   float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
   int *d_cost = nullptr, *d_order = nullptr; // longest-job-first scheduling (k_schedule)
+  float *d_dense = nullptr; // dense-reward tables: DC_WORDS coefficients, then nsub rows of DS_WORDS
   bool lpt = true;
   int n_noise = 0;
   int auxstride = 0, lds_bytes = 0;
@@ -347,7 +348,7 @@ static void build_layout(fsim *s, int ncon_max) {
   auto take = [&](int n) { int r = o; o += n; return r; };
   ly.qpos = take(m.nq); ly.qvel = take(m.nv); ly.qaccws = take(m.nv); ly.qfrcbias = take(m.nv); ly.ctrl = take(m.nu);
   ly.qfrcapp = take(m.nv); ly.xfrc = take(6 * m.nparts); ly.eqdata = take(7 * m.neq); ly.eqactive = take(m.neq);
-  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.num_connect_steps));
+  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.dense_reward));
   o = (o + 3) / 4 * 4;
   ly.stride = o;
   // LDS-only
@@ -418,6 +419,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   int ncon_max = 48;
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
+  if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
   if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
   if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
   build_layout(s, ncon_max);
@@ -474,7 +476,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -546,6 +548,10 @@ static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if ((rc = copy_field(s, ly.eqdata, 7 * m.neq, p->eq_data, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqactive, m.neq, p->eq_active, to_state))) return rc;
   if ((rc = copy_field(s, ly.env + E_GROUP, m.nparts, p->group, to_state))) return rc;
+  if (p->dense) {
+    if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "state field 'dense' exists for dense_reward handles only");
+    if ((rc = copy_field(s, ly.env + E_GROUP + m.nparts, ED_WORDS, p->dense, to_state))) return rc;
+  }
   if (p->cursor) {
     if (m.agent != 2) FAIL(FSIM_EINVAL, "state field 'cursor' exists for the Cursor agent only");
     int n = s->n_envs;
@@ -619,14 +625,94 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
   return FSIM_OK;
 }
+// ---- dense-reward env
+static_assert(DC_WORDS == FSIM_DENSE_NCOEF && DS_WORDS == FSIM_DENSE_SUBW && ED_WORDS == FSIM_DENSE_STATEW, "fsim.h dense sizes");
+static int dense_check(const float *coef, int ncoef, const float *sub, int nsub, int nsite, int nparts, int nconn) {
+  if (!coef || !sub || ncoef != DC_WORDS || nsub < 1 || nsub > 16) FAIL(FSIM_EINVAL, "dense reward: need %d coefficients and 1..16 subtasks", DC_WORDS);
+  if (nsite >= 0) {
+    auto bad = [&](float v, int n) { return !(v >= 0 && v < n && v == (float)(int)v); };
+    if (bad(coef[DC_GRIPTIP_SITE], nsite) || bad(coef[DC_GRIP_SITE], nsite)) FAIL(FSIM_EINVAL, "dense reward: bad gripper site id");
+    for (int i = 0; i < nsub; i++) {
+      const float *t = sub + DS_WORDS * i;
+      if (bad(t[DS_LEG_PART], nparts) || bad(t[DS_TABLE_PART], nparts) || bad(t[DS_LEG_SITE], nsite) || bad(t[DS_TABLE_SITE], nsite) ||
+          bad(t[DS_GL_SITE], nsite) || bad(t[DS_GR_SITE], nsite) || bad(t[DS_K_LEG], nconn) || bad(t[DS_K_TABLE], nconn))
+        FAIL(FSIM_EINVAL, "dense reward: subtask %d refers to a part/site/connector that does not exist", i);
+    }
+  }
+  return FSIM_OK;
+}
+extern "C" int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *sub, int nsub) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "fsim_set_dense_reward: the handle was not created with dense_reward = 1");
+  if (int rc = dense_check(coef, ncoef, sub, nsub, s->m.nsite, s->m.nparts, s->m.nconn)) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->d_dense) { hipFree(s->d_dense); s->d_dense = nullptr; }
+  HIPCHK(hipMalloc(&s->d_dense, (size_t)(DC_WORDS + DS_WORDS * nsub) * 4));
+  HIPCHK(hipMemcpy(s->d_dense, coef, DC_WORDS * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->d_dense + DC_WORDS, sub, (size_t)DS_WORDS * nsub * 4, hipMemcpyHostToDevice));
+  s->ecfg.dense_coef = s->d_dense; s->ecfg.dense_sub = s->d_dense + DC_WORDS; s->ecfg.dense_nsub = nsub;
+  return FSIM_OK;
+}
+
+struct DenseReplayP { // sensor values from recorded arrays ([nsub][FSIM_DENSE_OBSW], oracle/dense_reward.py O_*)
+  const float *o;
+  DEV void obs(int st, DObs &d) const {
+    const float *p = o + FSIM_DENSE_OBSW * st;
+    d.eef = ldv3(p); d.gl = ldv3(p + 3); d.gr = ldv3(p + 6); d.leg = ldv3(p + 9); d.legsite = ldv3(p + 12); d.tablesite = ldv3(p + 15);
+    d.legup = ldv3(p + 18); d.tableup = ldv3(p + 21); d.legfwd = ldv3(p + 24); d.tablefwd = ldv3(p + 27); d.gripup = ldv3(p + 30);
+    d.gripfwd = ldv3(p + 33); d.touch_l = p[36] != 0.0f; d.touch_r = p[37] != 0.0f;
+  }
+  DEV bool aligned(int st) const { return o[FSIM_DENSE_OBSW * st + 38] != 0.0f; }
+};
+__global__ void k_dense_replay(const float *coef, const float *sub, int nsub, int n_pre, const float *obs0, const float *obs, const float *ac,
+                               int dof, const uint8_t *connected, int T, float *out_reward, int *out_flags) {
+  if (threadIdx.x || blockIdx.x) return;
+  float S[ED_WORDS];
+  DenseReplayP p{obs0};
+  dense_reset(S, coef, sub, p, n_pre);
+  for (int t = 0; t < T; t++) {
+    p.o = obs + (size_t)t * nsub * FSIM_DENSE_OBSW;
+    DenseOut d = dense_compute(S, coef, sub, nsub, p, ac + (size_t)t * dof, dof, connected[t] != 0);
+    out_reward[t] = d.reward;
+    out_flags[4 * t] = d.done; out_flags[4 * t + 1] = d.success; out_flags[4 * t + 2] = (int)S[ED_PHASE]; out_flags[4 * t + 3] = (int)S[ED_SUBTASK];
+  }
+}
+extern "C" int fsim_dense_replay(int device, const float *coef, int ncoef, const float *sub, int nsub, int n_pre, const float *obs0,
+                                 const float *obs, const float *ac, int dof, const uint8_t *connected, int T, float *out_reward,
+                                 int32_t *out_flags) {
+  if (!obs0 || !obs || !ac || !connected || !out_reward || !out_flags || T < 1 || dof < 3 || n_pre < 0 || n_pre >= nsub) FAIL(FSIM_EINVAL, "fsim_dense_replay: bad args");
+  if (int rc = dense_check(coef, ncoef, sub, nsub, -1, 0, 0)) return rc;
+  HIPCHK(hipSetDevice(device));
+  size_t nc = DC_WORDS, ns = (size_t)DS_WORDS * nsub, no0 = (size_t)nsub * FSIM_DENSE_OBSW, no = no0 * T, na = (size_t)T * dof;
+  float *d = nullptr;
+  uint8_t *dc = nullptr;
+  HIPCHK(hipMalloc(&d, (nc + ns + no0 + no + na + T + 4 * (size_t)T) * 4));
+  HIPCHK(hipMalloc(&dc, T));
+  float *d_c = d, *d_s = d_c + nc, *d_o0 = d_s + ns, *d_o = d_o0 + no0, *d_a = d_o + no, *d_r = d_a + na;
+  int *d_f = reinterpret_cast<int *>(d_r + T);
+  hipMemcpy(d_c, coef, nc * 4, hipMemcpyHostToDevice); hipMemcpy(d_s, sub, ns * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_o0, obs0, no0 * 4, hipMemcpyHostToDevice); hipMemcpy(d_o, obs, no * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_a, ac, na * 4, hipMemcpyHostToDevice); hipMemcpy(dc, connected, T, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_dense_replay, dim3(1), dim3(64), 0, 0, d_c, d_s, nsub, n_pre, d_o0, d_o, d_a, dof, dc, T, d_r, d_f);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out_reward, d_r, (size_t)T * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_flags, d_f, (size_t)T * 16, hipMemcpyDeviceToHost);
+  hipFree(d); hipFree(dc);
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "fsim_dense_replay: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+
 extern "C" int fsim_reset(fsim_t *s, const uint8_t *mask_dev, float *obs_dev) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (!s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: call fsim_set_reset_tables first");
+  if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_reset: dense_reward needs fsim_set_dense_reward first");
   return launch_env(s, nullptr, obs_dev, nullptr, nullptr, nullptr, mask_dev, 0);
 }
 extern "C" int fsim_step(fsim_t *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info) {
   if (!s || !action) FAIL(FSIM_EINVAL, "fsim_step: null handle/action");
   if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step: auto_reset needs fsim_set_reset_tables");
+  if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step: dense_reward needs fsim_set_dense_reward first");
   return launch_env(s, action, obs, reward, done, info, nullptr, 1);
 }
 extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {

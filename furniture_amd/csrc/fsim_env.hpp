@@ -14,6 +14,7 @@
 // by all 64 lanes.
 #pragma once
 #include "fsim_solver.hpp"
+#include "fsim_dense.hpp"
 
 struct EnvCfg {
   int dof_action, obs_dim, n_substeps, max_episode_steps, discrete_grip, rescale_actions, auto_align, auto_reset, has_recipe, agent;
@@ -21,6 +22,9 @@ struct EnvCfg {
   // Cursor agent (furniture_cursor.py:28-32, config/furniture.py:84-90)
   int num_connect_steps, gravity_comp;
   float move_speed, rotate_speed, cursor_boundary;
+  // dense-reward env (fsim_dense.hpp): tables uploaded by fsim_set_dense_reward
+  int dense, dense_nsub;
+  const float *dense_coef, *dense_sub;
 };
 struct EnvIO {
   const float *action;
@@ -33,7 +37,7 @@ struct EnvIO {
   long long t0;   // shader clock at kernel entry
 };
 
-static inline int env_extra_words(const DModel &m, int) { return m.agent == 2 ? EC_WORDS : 0; }
+static inline int env_extra_words(const DModel &m, int dense) { return m.agent == 2 ? EC_WORDS : (dense ? ED_WORDS : 0); }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
   e.agent = m.agent;
@@ -48,6 +52,7 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
   e.pos_dist = c.alignment_pos_dist; e.rot_up = c.alignment_rot_dist_up; e.rot_fwd = c.alignment_rot_dist_forward; e.proj_dist = c.alignment_project_dist;
   e.ctrl_penalty_coef = c.ctrl_penalty_coef; e.unstable_penalty_coef = c.unstable_penalty_coef; e.success_reward = c.success_reward;
   e.touch_reward = c.touch_reward; e.pick_reward = c.pick_reward;
+  e.dense = c.dense_reward; e.dense_nsub = 0; e.dense_coef = nullptr; e.dense_sub = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
@@ -301,6 +306,38 @@ DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
   if (pos_dist < cfg.pos_dist / 2 && rot_up > cfg.rot_up && fwd_ok) return true;
   return false;
 }
+
+// sensor values of the dense reward from the poses of the last forward pass (furniture_sawyer_dense.py:222-271)
+struct DenseSimP {
+  const Ctx &c;
+  const EnvCfg &cfg;
+  DEV void obs(int st, DObs &o) const {
+    CModel &m = c.m;
+    auto C = GP(cfg.dense_coef);
+    auto T = GP(cfg.dense_sub) + DS_WORDS * st;
+    M3 R;
+    env_site_pose(c, (int)C[DC_GRIPTIP_SITE], &o.eef, nullptr, nullptr);
+    V3 dummy;
+    env_site_pose(c, (int)C[DC_GRIP_SITE], &dummy, nullptr, &R);
+    o.gripup = colv(R, 2); o.gripfwd = colv(R, 1);
+    env_site_pose(c, (int)T[DS_GL_SITE], &o.gl, nullptr, nullptr);
+    env_site_pose(c, (int)T[DS_GR_SITE], &o.gr, nullptr, nullptr);
+    int leg = (int)T[DS_LEG_PART];
+    o.leg = ldv3(c.L + c.ly.xpos + 3 * GP(m.part_rbody)[leg]);
+    env_site_pose(c, (int)T[DS_LEG_SITE], &o.legsite, nullptr, &R);
+    o.legup = colv(R, 2); o.legfwd = colv(R, 1);
+    env_site_pose(c, (int)T[DS_TABLE_SITE], &o.tablesite, nullptr, &R);
+    o.tableup = colv(R, 2); o.tablefwd = colv(R, 1);
+    // _finger_contact(leg) of the (single) arm: furniture_sawyer.py:220-245
+    const int *scal = c.I(c.ly.scal);
+    o.touch_l = (scal[SC_TOUCHL] >> leg) & 1; o.touch_r = (scal[SC_TOUCHR] >> leg) & 1;
+  }
+  DEV bool aligned(int st) const {
+    auto T = GP(cfg.dense_sub) + DS_WORDS * st;
+    return env_is_aligned(c, cfg, (int)T[DS_K_LEG], (int)T[DS_K_TABLE]);
+  }
+};
+DEV float *env_edense(const Ctx &c) { return c.L + c.ly.env + E_GROUP + c.m.nparts; }
 
 // ---------------------------------------------------------------------------------------------------- connect
 DEV int env_ecur(const Ctx &c) { return c.ly.env + E_GROUP + c.m.nparts; }
@@ -715,7 +752,13 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   fs_forward(c);
   if (m.narm > 0) env_gravity_comp(c);
   for (int k = 0; k < 100; k++) fs_step(c);
-  if (c.lane == 0) env_next_subtask(c);
+  if (c.lane == 0) {
+    env_next_subtask(c);
+    if (cfg.dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
+      DenseSimP dp{c, cfg};
+      dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, 0);
+    }
+  }
   SYNC();
 }
 
@@ -821,7 +864,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     }
     near = wave_or(near);
   }
-  float penalty = 0;
+  float penalty = 0, dense_rew = 0;
   if (c.lane == 0) {
     for (int arm = 0; arm < m.narm; arm++) {
       int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
@@ -835,6 +878,18 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     E[E_PREV_NUM_CONNECTED] = E[E_NUM_CONNECTED];
     if (E[E_NUM_CONNECTED] == m.nparts - 1 && m.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
     terminal = success;
+    int dense_phase = 0;
+    if (cfg.dense) {
+      // FurnitureSawyerEnv._step (furniture_sawyer.py:76-79): the dense _compute_reward replaces the reward and owns _success;
+      // done = (all parts connected) or its own done
+      DenseSimP dp{c, cfg};
+      DenseOut d = dense_compute(env_edense(c), cfg.dense_coef, cfg.dense_sub, cfg.dense_nsub, dp, io.action, dof, E[E_CONNECTED_THIS_STEP] != 0);
+      success = d.success; E[E_SUCCESS] = success;
+      terminal = terminal || d.done;
+      dense_phase = d.phase_info;
+      touch_rew = 0; pick_rew = 0; ctrl_pen = 0; succ_rew = d.phase_bonus;
+      dense_rew = d.reward;
+    }
     // _after_step
     E[E_EPISODE_LENGTH] += 1;
     int fail = E[E_FAIL];
@@ -842,7 +897,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       terminal = 1;
       if (fail) { E[E_FAIL] = 0; penalty = -cfg.unstable_penalty_coef; }
     }
-    float rew = succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
+    float rew = cfg.dense ? dense_rew + penalty : succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
     L[ly.env + E_EPISODE_REWARD] += rew;
     if (io.reward) *io.reward = rew;
     if (io.done) *io.done = (uint8_t)terminal;
@@ -854,6 +909,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
       io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
+      io.info[FSIM_INFO_DENSE_PHASE] = dense_phase;
     }
     scal[14] = terminal;
     if (io.cost) {

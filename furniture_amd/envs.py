@@ -20,7 +20,8 @@ import numpy as np
 from . import spaces
 from . import transform_utils as T
 from .mjcf.model import load_compiled
-from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
+from .dense import DENSE_COEF_DEFAULTS, pack_dense
+from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DENSE_PHASE, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
                   INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUCCESS, N_NOISE, default_config)
 
 # furniture/config/furniture.py defaults that matter on the hot path (file:line in the reference)
@@ -50,6 +51,8 @@ GYM_IDS = {  # furniture/env/__init__.py:19-114
     "IKEACursor-v0": ("FurnitureCursorEnv", dict(furniture_id=0)),
     "IKEASawyer-v0": ("FurnitureSawyerEnv", dict(furniture_name="swivel_chair_0700")),
     "IKEABaxter-v0": ("FurnitureBaxterEnv", dict(furniture_id=1)),
+    "IKEASawyerDense-v0": ("FurnitureSawyerDenseRewardEnv", DENSE_OVERRIDES),
+    "furniture-sawyer-densereward-v0": ("FurnitureSawyerDenseRewardEnv", DENSE_OVERRIDES),
 }
 
 
@@ -161,10 +164,19 @@ _AGENT_OF = {"FurnitureSawyerEnv": "Sawyer", "FurnitureBaxterEnv": "Baxter", "Fu
 class FurnitureBatchEnv:
     """n_envs copies of FurnitureEnv on one GPU.  Observations / rewards / dones are torch tensors on the device."""
 
-    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, **kw):
-        cfg = config if config is not None else make_config()
+    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, dense=False, **kw):
+        """dense=True: FurnitureSawyerDenseRewardEnv semantics (furniture_sawyer_dense.py) -- the config then carries the
+        config/furniture_sawyer_dense.py overrides and, optionally, any of its reward coefficients."""
+        cfg = config if config is not None else make_config(**(DENSE_OVERRIDES if dense else {}))
         for k, v in kw.items():
             setattr(cfg, k, v)
+        if dense:
+            if agent != "Sawyer":
+                raise ValueError("the dense-reward env exists for the Sawyer agent only")
+            if not getattr(cfg, "diff_rew", True):
+                raise NotImplementedError("diff_rew=False: the reference itself fails in grasp_leg (furniture_sawyer_dense.py:668)")
+            if getattr(cfg, "phase_ob", False) or getattr(cfg, "preassembled", None):
+                raise NotImplementedError("phase_ob / preassembled are not part of the accelerated dense-reward path")
         if cfg.unity or cfg.record_vid or cfg.visual_ob:
             raise ValueError("unity / record_vid / visual_ob must be False: rendering is outside the accelerated hot path")
         if agent != "Cursor" and cfg.control_type != "impedance":
@@ -190,7 +202,13 @@ class FurnitureBatchEnv:
                 setattr(c, k, float(getattr(cfg, k)))
         if getattr(cfg, "solver_tolerance", None) is not None:
             c.solver_tolerance = float(cfg.solver_tolerance)
+        c.dense_reward = 1 if dense else 0
+        self.dense = bool(dense)
         self.sim = FSim(self.model, num_envs, device=device, config=c)
+        if dense:
+            coef = {k: float(getattr(cfg, k)) for k, _ in DENSE_COEF_DEFAULTS
+                    if k not in ("z_finedist", "griptip_site", "grip_site") and getattr(cfg, k, None) is not None}
+            self.sim.set_dense_reward(*pack_dense(self.model, coef))
         self.num_envs = num_envs
         torch = self.sim.torch
         dev = self.sim.device
@@ -256,6 +274,8 @@ class FurnitureBatchEnv:
         infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
                      site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
                      connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
+        if self.dense:
+            infos["phase_i"] = info[:, INFO_DENSE_PHASE]  # phase + 8 * subtask (furniture_sawyer_dense.py:347)
         return self._split(self._obs), self._rew, self._done.bool(), infos
 
     def step(self, actions):
@@ -264,7 +284,8 @@ class FurnitureBatchEnv:
 
     def get_env_state(self):
         """Full snapshot (the reference's {qpos, qvel} plus the weld/mask/group state it omits)."""
-        return self.sim.get_state("qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group")
+        names = ["qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group"] + (["dense"] if self.dense else [])
+        return self.sim.get_state(*names)
 
     def close(self):
         if getattr(self, "_table_queue", None) is not None:
@@ -277,9 +298,10 @@ class _SingleEnv:
     """n_envs = 1 view with numpy / python scalars, shaped like the reference's env classes."""
 
     _agent = None
+    _dense = False
 
     def __init__(self, config=None, device=0, **kw):
-        self._b = FurnitureBatchEnv(self._agent, 1, config=config, device=device, auto_reset=False, **kw)
+        self._b = FurnitureBatchEnv(self._agent, 1, config=config, device=device, auto_reset=False, dense=self._dense, **kw)
         self._max_episode_steps = self._b.config.max_episode_steps
 
     # reference surface -------------------------------------------------------------------------------
@@ -338,6 +360,12 @@ class FurnitureSawyerEnv(_SingleEnv):
     _agent = "Sawyer"
 
 
+class FurnitureSawyerDenseRewardEnv(_SingleEnv):
+    """furniture_sawyer_dense.py: Sawyer + table_lack_0825 with the 8-phase dense reward."""
+    _agent = "Sawyer"
+    _dense = True
+
+
 class FurnitureBaxterEnv(_SingleEnv):
     _agent = "Baxter"
 
@@ -346,7 +374,8 @@ class FurnitureCursorEnv(_SingleEnv):
     _agent = "Cursor"
 
 
-REGISTRY = {"FurnitureSawyerEnv": FurnitureSawyerEnv, "FurnitureBaxterEnv": FurnitureBaxterEnv, "FurnitureCursorEnv": FurnitureCursorEnv}
+REGISTRY = {"FurnitureSawyerEnv": FurnitureSawyerEnv, "FurnitureBaxterEnv": FurnitureBaxterEnv, "FurnitureCursorEnv": FurnitureCursorEnv,
+            "FurnitureSawyerDenseRewardEnv": FurnitureSawyerDenseRewardEnv}
 
 
 def make_env(name, config=None, **kw):
@@ -358,8 +387,6 @@ def make_env(name, config=None, **kw):
 
 def make(env_id, **kw):
     """gym.make(id, **kw) equivalent for the registered ids."""
-    if env_id in ("IKEASawyerDense-v0", "furniture-sawyer-densereward-v0"):
-        raise NotImplementedError("the dense-reward env is SURVEY row f1 (next), not part of this round")
     if env_id not in GYM_IDS:
         raise Exception("unknown env id %s" % env_id)
     name, defaults = GYM_IDS[env_id]

@@ -276,12 +276,15 @@ def build_model(agent, furniture_name, control_type="impedance", assets_root=Non
                 has_recipe=info["recipe_path"] is not None, move_speed=move_speed,
                 conn_keys=sorted(keys, key=keys.get))
     if info["recipe_path"] is not None:
-        meta["site_recipe"] = _read_site_recipe(info["recipe_path"])
+        rec = _read_recipe(info["recipe_path"])
+        meta["site_recipe"] = [list(x) for x in rec.get("site_recipe", [])]
+        # what the dense-reward env reads from the recipe (furniture_sawyer_dense.py:149-216, 243)
+        meta["recipe"] = {k: rec[k] for k in ("recipe", "waypoints", "grip_init_pos", "z_finedist", "num_connects") if k in rec}
     return CompiledModel(A, meta)
 
 
-def _read_site_recipe(path):
-    """site_recipe entries [[site1, site2, angle?], ...] (ref util/__init__.py:54-61 loader)."""
+def _read_recipe(path):
+    """the furniture's recipe yaml; site_recipe entries are [[site1, site2, angle?], ...] (ref util/__init__.py:54-61 loader)."""
     import yaml
 
     class _L(yaml.SafeLoader):
@@ -290,4 +293,4 @@ def _read_site_recipe(path):
     _L.add_constructor("tag:yaml.org,2002:python/tuple", lambda l, n: list(l.construct_sequence(n)))
     with open(path) as f:
         rec = yaml.load(f, Loader=_L)
-    return [list(x) for x in rec.get("site_recipe", [])]
+    return rec

@@ -16,7 +16,9 @@ _CSRC = os.path.join(_HERE, "csrc")
 _LIBPATH = os.environ.get("FSIM_LIB", os.path.join(_CSRC, "libfsim.so"))
 _LIB = None
 
-INFO_DIM = 13
+INFO_DIM = 14
+INFO_DENSE_PHASE = 13
+DENSE_STATEW = 27  # FSIM_DENSE_STATEW; ED_* of csrc/fsim_dense.hpp (subtask, phase, flags, fine-aligned, 4 x vec3, 11 prev values)
 INFO_OVERFLOW = 12
 INFO_NUM_CONNECTED, INFO_SUCCESS, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2, INFO_EPISODE_LENGTH = range(6)
 INFO_CONNECTED_THIS_STEP, INFO_NEEDS_TABLE, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F, INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F = range(6, 12)
@@ -36,12 +38,13 @@ class FsimConfig(ctypes.Structure):
         ("touch_reward", ctypes.c_float), ("pick_reward", ctypes.c_float),
         ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
         ("move_speed", ctypes.c_float), ("rotate_speed", ctypes.c_float), ("cursor_boundary", ctypes.c_float),
+        ("dense_reward", ctypes.c_int32),
     ]
 
 
 class StatePtrs(ctypes.Structure):
     _names = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_data", "eq_active",
-              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters", "cursor"]
+              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters", "cursor", "dense"]
     _fields_ = [(n, ctypes.c_void_p) for n in _names]
 
 
@@ -70,6 +73,8 @@ def lib():
             raise RuntimeError(
                 "libfsim.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                 "furniture_amd has no CPU fallback for the hot path")
+        import torch  # noqa: F401  -- first: torch must bind ITS HIP runtime before libfsim.so pulls in /opt/rocm's (else
+        #                             torch.cuda.is_available() turns False in this process)
         L = ctypes.CDLL(_LIBPATH)
         L.fsim_last_error.restype = ctypes.c_char_p
         L.fsim_default_config.argtypes = [ctypes.POINTER(FsimConfig)]
@@ -89,6 +94,9 @@ def lib():
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
         L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
+        L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.fsim_dense_replay.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
+            [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
     return _LIB
 
@@ -96,7 +104,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
-    "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms",
+    "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
 ]
 
 
@@ -108,6 +116,23 @@ def default_config():
 
 class FsimError(RuntimeError):
     pass
+
+
+def dense_replay(coef, subtasks, n_pre, obs0, obs, ac, connected, device=0):
+    """fsim_dense_replay: the device reward state machine alone on recorded sensor values (parity hook).
+    -> (reward float32 [T], flags int32 [T, 4] = done, success, phase, subtask)."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    coef, subtasks, obs0, obs, ac = f32(coef), f32(subtasks), f32(obs0), f32(obs), f32(ac)
+    connected = np.ascontiguousarray(connected, dtype=np.uint8)
+    T, nsub = len(ac), len(subtasks)
+    assert obs.shape == (T, nsub, 40) and obs0.shape == (nsub, 40)
+    rew, flags = np.zeros(T, np.float32), np.zeros((T, 4), np.int32)
+    rc = lib().fsim_dense_replay(device, coef.ctypes.data, len(coef), subtasks.ctypes.data, nsub, int(n_pre), obs0.ctypes.data,
+                                 obs.ctypes.data, ac.ctypes.data, ac.shape[1], connected.ctypes.data, T, rew.ctypes.data,
+                                 flags.ctypes.data)
+    if rc:
+        raise FsimError("fsim_dense_replay rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
+    return rew, flags
 
 
 class FSim:
@@ -137,6 +162,12 @@ class FSim:
         self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
         self.stream_ptr = st.value
 
+    def set_dense_reward(self, coef, subtasks):
+        """Upload the dense-reward tables (furniture_amd.dense.pack_dense)."""
+        coef = np.ascontiguousarray(coef, dtype=np.float32)
+        subtasks = np.ascontiguousarray(subtasks, dtype=np.float32)
+        self._chk(lib().fsim_set_dense_reward(self._h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
     def _chk(self, rc):
         if rc:
             raise FsimError("fsim rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
@@ -159,13 +190,14 @@ class FSim:
                     qfrc_applied=(m.nv, "f"), xfrc_applied=(6 * m.nparts, "f"), eq_data=(7 * m.neq, "f"), eq_active=(m.neq, "i"),
                     geom_contype=(m.ngeom, "i"), geom_conaffinity=(m.ngeom, "i"), group=(m.nparts, "i"), qacc=(m.nv, "f"),
                     xpos=(3 * m.nbody, "f"), xquat=(4 * m.nbody, "f"), ncon=(1, "i"), contact_geoms=(2 * self.max_contacts, "i"),
-                    solver_iters=(1, "i"), cursor=(8, "f"))
+                    solver_iters=(1, "i"), cursor=(8, "f"), dense=(DENSE_STATEW, "f"))
 
     def get_state(self, *names):
         """dict name -> torch tensor [n_envs, dim] (device)."""
         torch = self.torch
         shapes = self._field_shapes()
-        names = names or [n for n in shapes if n != "cursor" or self.cm.meta.get("agent") == "Cursor"]
+        names = names or [n for n in shapes if (n != "cursor" or self.cm.meta.get("agent") == "Cursor")
+                          and (n != "dense" or self.cfg.dense_reward)]
         out, p = {}, StatePtrs()
         for n in names:
             dim, kind = shapes[n]

@@ -49,6 +49,8 @@ typedef struct fsim_config {
   float ctrl_penalty_coef, unstable_penalty_coef, success_reward, touch_reward, pick_reward;
   float furn_xyz_rand, furn_rot_rand, agent_xyz_rand;
   float move_speed, rotate_speed, cursor_boundary; /* Cursor agent: config/furniture.py move_speed 0.05? see furniture_cursor.py; degrees per step; workspace half-extent */
+  int32_t dense_reward;       /* 1: FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py): the 8-phase reward replaces the sparse
+                                 one; the tables must be uploaded with fsim_set_dense_reward before the first reset.  Sawyer only. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -86,6 +88,9 @@ typedef struct fsim_state_ptrs {
   int32_t *solver_iters /* out only: [n] Newton iterations of the last substep */;
   float *cursor /* Cursor agent only: [n, 8] = model.body_pos of cursor0, cursor1 (furniture.py:3139), then the selected part
                    index + 1 of each cursor (0 = none) as floats (furniture_cursor.py _cursor_selected) */;
+  float *dense /* dense_reward handles only: [n, FSIM_DENSE_STATEW] the reward state machine's variables
+                  (furniture_sawyer_dense.py:128-216: subtask, phase, flags, fine-aligned count, init table-site / leg / lift / eef
+                  positions, the eleven _prev_* distances), so that a snapshot restores the reward too */;
 } fsim_state_ptrs_t;
 int fsim_get_state(fsim_t *, const fsim_state_ptrs_t *dst);
 int fsim_set_state(fsim_t *, const fsim_state_ptrs_t *src);
@@ -113,8 +118,25 @@ enum {
   FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
   FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
   FSIM_INFO_OVERFLOW = 12, /* bit 0: broadphase survivor list truncated, bit 1: contact slots exhausted (contacts dropped) in this step */
-  FSIM_INFO_DIM = 13
+  FSIM_INFO_DENSE_PHASE = 13, /* dense-reward env: info["phase_i"] = phase + 8 * subtask (furniture_sawyer_dense.py:347); then
+                                 FSIM_INFO_SUCCESS_REWARD_F carries info["phase_bonus"] and the other *_F columns are 0 */
+  FSIM_INFO_DIM = 14
 };
+
+/* ---- dense-reward env (FurnitureSawyerDenseRewardEnv) -------------------------------------- */
+/* coef: FSIM_DENSE_NCOEF floats = the config/furniture_sawyer_dense.py coefficients + z_finedist + the griptip/grip site ids, in
+ * the order of furniture_amd/dense.py DENSE_COEF_DEFAULTS; subtasks: [nsub][FSIM_DENSE_SUBW] floats, one row per recipe step
+ * (furniture_sawyer_dense.py:149-216: leg/table part, leg/table connector site, grasp-target sites, angle (NaN = None), ...).
+ * Host pointers, copied before return. */
+enum { FSIM_DENSE_NCOEF = 33, FSIM_DENSE_SUBW = 16, FSIM_DENSE_OBSW = 40, FSIM_DENSE_STATEW = 27 };
+int fsim_set_dense_reward(fsim_t *, const float *coef, int ncoef, const float *subtasks, int nsub);
+
+/* Parity hook: run the device implementation of the reward state machine alone, on recorded sensor values (the layout of
+ * oracle/dense_reward.py O_*: obs0 [nsub][40] at reset, obs [T][nsub][40], ac [T][dof], connected [T]); out_reward [T],
+ * out_flags [T][4] = done, success, phase, subtask after each step.  Host pointers; synchronous; needs no handle. */
+int fsim_dense_replay(int device, const float *coef, int ncoef, const float *subtasks, int nsub, int n_pre, const float *obs0,
+                      const float *obs, const float *ac, int dof, const uint8_t *connected, int T, float *out_reward,
+                      int32_t *out_flags);
 
 /* timing helper for bench.py: average device time (ms) of the last fsim_step kernel launches, measured with
  * HIP events on the handle's stream; resets the accumulator. */

@@ -51,6 +51,7 @@ class OracleConfig:
         self.solver = "newton"
         self.solver_iterations = 100
         self.solver_tolerance = 1e-8
+        self.dense = None  # an oracle.dense_reward.DenseConfig -> FurnitureSawyerDenseRewardEnv behaviour
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -107,6 +108,29 @@ class FurnitureEnvOracle:
         self.init_quat = None
         self.reset_draws = None  # filled by reset(): what a device reset table must contain
         self._fail = False
+        self._dense = None
+        if self.cfg.dense is not None:
+            from furniture_amd.dense import dense_subtasks
+            from oracle.dense_reward import DenseReward
+            self._dsub, zf, self._griptip_site, self._grip_site = dense_subtasks(model)
+            self._dense = DenseReward(self.cfg.dense, self._dsub, zf, self.nparts - 1, 0)
+
+    def _dense_obs(self, st):
+        """observables of subtask st (oracle/dense_reward.py O_*) from the current sim state."""
+        from oracle.dense_reward import O_DIM
+        d, s = self.sim.data, self._dsub[st]
+        R = lambda site: d.site_xmat[site].reshape(3, 3)
+        o = np.zeros(O_DIM)
+        o[0:3] = d.site_xpos[self._griptip_site]
+        o[3:6], o[6:9] = d.site_xpos[s["gl_site"]], d.site_xpos[s["gr_site"]]
+        o[9:12] = d.xpos[self.m.part_bodyid[s["leg_part"]]]
+        o[12:15], o[15:18] = d.site_xpos[s["leg_site"]], d.site_xpos[s["table_site"]]
+        o[18:21], o[21:24] = R(s["leg_site"])[:, 2], R(s["table_site"])[:, 2]
+        o[24:27], o[27:30] = R(s["leg_site"])[:, 1], R(s["table_site"])[:, 1]
+        o[30:33], o[33:36] = R(self._grip_site)[:, 2], R(self._grip_site)[:, 1]
+        L, Rr, _ = self._touch_sets()[0]
+        o[36], o[37] = s["leg_part"] in L, s["leg_part"] in Rr
+        return o
 
     # ---- small accessors (F.py:3107-3310) --------------------------------------------------
     def _part_qpos(self, i):
@@ -233,6 +257,8 @@ class FurnitureEnvOracle:
         self._terminal = False
         self._success = False
         self._fail = False
+        if self._dense is not None:
+            self._dense.reset(self._dense_obs)  # _reset_reward_variables (furniture_sawyer_dense.py:218-220)
         return self._get_obs()
 
     def _settle(self):
@@ -552,7 +578,13 @@ class FurnitureEnvOracle:
         if self._num_connected == self._success_num_conn and self.nparts > 1:
             self._success = True
             done = True
-        reward, info = self._compute_reward(action)
+        if self._dense is not None:
+            # FurnitureSawyerEnv._step: done = done or _done of the dense _compute_reward, which also owns _success (:78-79)
+            reward, d2, self._success, info = self._dense.compute(
+                action, lambda st: self._is_aligned(self._dsub[st]["k_leg"], self._dsub[st]["k_table"]), self._connected)
+            done = done or d2
+        else:
+            reward, info = self._compute_reward(action)
         # _after_step
         self._episode_reward += reward
         self._episode_length += 1

@@ -1,0 +1,163 @@
+"""Dense-reward env on the GPU (FurnitureSawyerDenseRewardEnv, furniture_sawyer_dense.py):
+  * the device reward state machine alone, replayed on the reference's own golden vectors (tests/golden/dense_reward.npz,
+    produced by the reference's _compute_reward; see scripts/make_golden_dense.py) through fsim_dense_replay;
+  * the whole env (physics + connect + reward) against the fp64 oracle env on the same resets / actions, including a scripted
+    pinch-and-connect that advances the subtask."""
+import os
+
+import numpy as np
+import pytest
+
+from furniture_amd.dense import DENSE_COEF_DEFAULTS, DS_ANGLE, DS_GRIP_INIT0, DS_GRIP_INIT_N, DS_HAS_ANGLES, DS_WAYPOINT_Z, DS_WORDS, pack_dense
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "dense_reward.npz"))
+
+
+def test_device_reward_state_machine_on_reference_golden_vectors():
+    from furniture_amd.sim import dense_replay
+    nsub = len(G["angles"])
+    sub = np.zeros((nsub, DS_WORDS), np.float32)
+    for i in range(nsub):
+        sub[i, DS_ANGLE], sub[i, DS_HAS_ANGLES], sub[i, DS_WAYPOINT_Z] = G["angles"][i], G["has_angles"][i], G["waypoint_z"][i]
+        gi = G["grip_init"][i]
+        n = int(np.sum(~np.isnan(gi)))
+        sub[i, DS_GRIP_INIT_N] = n
+        sub[i, DS_GRIP_INIT0:DS_GRIP_INIT0 + n] = gi[:n]
+    nsteps, phases, worst = 0, set(), 0.0
+    for e in range(int(G["n_ep"])):
+        diff, early, rra, n_pre = G["ep%d_flags" % e]
+        assert diff
+        c = dict(DENSE_COEF_DEFAULTS)
+        c["early_termination"], c["reset_robot_after_attach"] = float(early), float(rra)
+        coef = np.array([c[k] for k, _ in DENSE_COEF_DEFAULTS], np.float32)
+        rew, flags = dense_replay(coef, sub, int(n_pre), G["ep%d_obs0" % e], G["ep%d_obs" % e], G["ep%d_ac" % e], G["ep%d_connected" % e])
+        ref = G["ep%d_reward" % e]
+        # state machine: bit-exact; reward: fp32 arithmetic on fp32-rounded sensor values, terms up to 1e4 in magnitude
+        assert np.array_equal(flags[:, 2], G["ep%d_phase" % e]) and np.array_equal(flags[:, 3], G["ep%d_subtask" % e]), e
+        assert np.array_equal(flags[:, 0].astype(bool), G["ep%d_done" % e]) and np.array_equal(flags[:, 1].astype(bool), G["ep%d_success" % e]), e
+        err = np.abs(rew - ref) / (1.0 + 1e-3 * np.abs(ref))
+        worst = max(worst, float(err.max()))
+        assert err.max() < 0.02, (e, int(err.argmax()), rew[err.argmax()], ref[err.argmax()])
+        nsteps += len(ref)
+        phases |= set(int(x) for x in flags[:, 2])
+    assert nsteps > 3000 and phases == set(range(8))
+    print("dense replay: %d steps, worst scaled reward error %.2e" % (nsteps, worst))
+
+
+def test_dense_env_matches_oracle():
+    import torch
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.sim import FSim, INFO_DENSE_PHASE, INFO_DIM, default_config
+    from oracle.dense_reward import DenseConfig
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions, pinch_attach_state
+
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n = 2
+    # the base env's lenient alignment thresholds and a lenient eef_rot_threshold, so that the scripted pinch below (arm pose
+    # as left by the reset, gripper ~30 deg off vertical) walks the state machine: early pick -> lift_leg, connect -> next subtask
+    kw = dict(max_episode_steps=150, auto_align=False)
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset, cfg.auto_align, cfg.dense_reward = 150, 0, 0, 1
+    sim = FSim(m, n, config=cfg)
+    with pytest.raises(Exception):
+        sim.reset(None, None)  # tables missing -> loud failure
+    sim.set_dense_reward(*pack_dense(m, dict(eef_rot_threshold=0.8)))
+    envs = [FurnitureEnvOracle(m, OracleConfig(seed=321 + i, solver_tolerance=1e-10, dense=DenseConfig(eef_rot_threshold=0.8), **kw))
+            for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    sim.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]),
+                         np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    act = torch.zeros((n, 9), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+
+    def resync():
+        """oracle <- device state (physics + reward variables), so that each scripted step below is a ONE-step comparison: the
+        pinch is a stiff contact transient in which fp32 and fp64 trajectories separate by millimetres within a few steps."""
+        st = sim.get_state("qpos", "qvel", "qacc_warmstart", "dense")
+        for e in range(n):
+            d = envs[e].sim.data
+            d.qpos[:], d.qvel[:] = st["qpos"][e].cpu().numpy(), st["qvel"][e].cpu().numpy()
+            d.qacc_warmstart[:] = st["qacc_warmstart"][e].cpu().numpy()
+            v = st["dense"][e].cpu().numpy().astype(np.float64)
+            D = envs[e]._dense
+            assert (D.subtask_step, D.phase_i) == (int(v[0]), int(v[1]))
+            D.init_table_site_pos, D.init_lift_leg_pos, D.lift_leg_pos, D.init_eef_pos = v[4:7].copy(), v[7:10].copy(), v[10:13].copy(), v[13:16].copy()
+            (D.prev_init_eef_dist, D.prev_eef_above_leg_dist, D.prev_eef_leg_dist, D.prev_grasp_dist, D.prev_lift_leg_z_dist,
+             D.prev_lift_leg_xy_dist, D.prev_move_pos_dist, D.prev_move_up_ang_dist, D.prev_move_forward_ang_dist, D.prev_proj_t,
+             D.prev_proj_l) = v[16:27]
+
+    def both(a, scripted=False, rtol=1e-4, atol=0.05):
+        if scripted:
+            resync()
+        act.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        out = []
+        for e in range(n):
+            ob, r, d, inf = envs[e].step(np.asarray(a[e], dtype=np.float64))
+            # reward terms scale distances by up to 1e4: 2e-6 m of fp32 physics noise -> 2e-2
+            assert abs(float(rew[e]) - r) < atol + rtol * abs(r), (e, float(rew[e]), r)
+            assert bool(done[e]) == d and int(info[e, INFO_DENSE_PHASE]) == inf["phase_i"], (e, inf)
+            bonus = float(info[e, 8:9].view(torch.float32))  # FSIM_INFO_SUCCESS_REWARD_F carries phase_bonus
+            assert abs(bonus - inf["phase_bonus"]) < 1e-3 * max(1.0, abs(bonus)), (bonus, inf["phase_bonus"])
+            if not scripted:
+                assert np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob)).max() < 5e-4
+            out.append((r, d, inf))
+        return out
+
+    for t in range(6):
+        both(np.stack([counter_actions(321, i, t, 9) for i in range(n)]))
+    # scripted: the gripper pinches the leg of recipe step 0 (part 1, connector 1) next to its table connector (5)
+    for e in range(n):
+        o = envs[e]
+        q, xfrc, masks = pinch_attach_state(m, o.sim.data.qpos.copy(), o.sim.data.xpos.copy(), o.sim.data.xquat.copy(), leg=1,
+                                            table_conn=5, leg_conn=1, gap=0.02)
+        o.sim.data.qpos[:], o.sim.data.qvel[:], o.sim.data.qacc_warmstart[:] = q, 0, 0
+        for i in range(m.nparts):
+            o.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+        for g, (ct, ca) in masks.items():
+            o.sim.model.geom_contype[g], o.sim.model.geom_conaffinity[g] = ct, ca
+        if e == 0:
+            Q, X, M = [q], [xfrc], masks
+        else:
+            Q.append(q); X.append(xfrc)
+    gm = sim.get_state("geom_contype", "geom_conaffinity")
+    for g, (ct, ca) in M.items():
+        gm["geom_contype"][:, g], gm["geom_conaffinity"][:, g] = ct, ca
+    sim.set_state(qpos=np.stack(Q), qvel=np.zeros((n, m.nv)), qacc_warmstart=np.zeros((n, m.nv)), xfrc_applied=np.stack(X),
+                  geom_contype=gm["geom_contype"], geom_conaffinity=gm["geom_conaffinity"])
+    # the scenario teleported the table: re-anchor the reward's "table must not move" reference on both sides (the device
+    # state block is part of the snapshot: state field 'dense', ED_INIT_TABLE_SITE = 4..6)
+    ds = sim.get_state("dense")["dense"]
+    for e in range(n):
+        envs[e].sim.forward()
+        tsite = envs[e].sim.data.site_xpos[envs[e]._dsub[0]["table_site"]].copy()
+        envs[e]._dense.init_table_site_pos = tsite
+        ds[e, 4:7] = torch.as_tensor(tsite, dtype=torch.float32)
+    sim.set_state(dense=ds)
+    a = np.zeros((n, 9), dtype=np.float32)
+    a[:, 7] = 1.0   # close the gripper, do not connect yet
+    a[:, 8] = -1.0
+    seen = set()
+    for t in range(3):
+        # (the very first step digests the teleport: finger pads start inside the leg)
+        for (_, _, inf) in both(a, scripted=True, rtol=1e-2 if t == 0 else 1e-4, atol=1.0):
+            seen.add(inf["phase_i"] % 8)
+    a[:, 8] = 1.0   # connect
+    res = both(a, scripted=True, atol=1.0)
+    for (_, _, inf) in res:
+        seen.add(inf["phase_i"] % 8)
+    print("phases visited:", sorted(seen), "after connect:", [(r[2]["phase_i"], r[2]["num_connected"], r[2]["subtask"]) for r in res])
+    assert all(r[2]["num_connected"] == 1 and r[2]["subtask"] == 1 for r in res) and 4 in seen
+    for t in range(2):
+        both(a, scripted=True, atol=1.0)
+    sim.close()
