@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--agent", default=AGENT, help="(exploration only; the benchmark workload is the default)")
     ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
+    ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
@@ -102,6 +103,10 @@ def main():
     cfg = default_config()
     cfg.max_episode_steps = MAX_EPISODE_STEPS
     cfg.auto_reset = 1
+    if args.dense:  # config/furniture_sawyer_dense.py:4-14
+        from furniture_amd.dense import pack_dense
+        cfg.dense_reward, cfg.auto_align = 1, 0
+        cfg.alignment_pos_dist, cfg.alignment_rot_dist_up, cfg.alignment_rot_dist_forward, cfg.alignment_project_dist = 0.02, 0.99, 0.99, 0.0
     # The rank's envs are split into `groups` equal slabs, each with its own FSim handle and HIP stream.  A step of the
     # batch = one step of every slab; the slabs are software-pipelined (while slab A's long-tail envs finish, slab B's
     # kernel fills the CUs), which is how a learner double-buffers a vectorised env (VecEnv step_async/step_wait).
@@ -116,6 +121,8 @@ def main():
     for g in range(G):
         sl = Slab()
         sl.sim = FSim(m, ng, device=local, config=cfg)
+        if args.dense:
+            sl.sim.set_dense_reward(*pack_dense(m))
         dev = sl.sim.device
         sl.tables = ResetTableQueue(ResetTableSampler(m, ecfg, SEED, lo + g * ng, ng))  # reference RNG stream, drawn one reset ahead
         sl.sim.set_reset_tables(*sl.tables.take())
@@ -199,8 +206,8 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n) == (AGENT, FURNITURE, ENVS_PER_GPU)
-            else "env-steps/sec (whole node), EXPLORATION %s+%s %d envs/GPU" % (args.agent, args.furniture, n), "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n, args.dense) == (AGENT, FURNITURE, ENVS_PER_GPU, False)
+            else "env-steps/sec (whole node), EXPLORATION %s+%s%s %d envs/GPU" % (args.agent, args.furniture, " dense-reward" if args.dense else "", n), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Furniture%sEnv + %s, impedance control, %d envs/GPU, U(-1,1)^%d actions, "

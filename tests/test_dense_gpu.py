@@ -161,3 +161,36 @@ def test_dense_env_matches_oracle():
     for t in range(2):
         both(a, scripted=True, atol=1.0)
     sim.close()
+
+
+def test_dense_env_classes_and_auto_reset():
+    """gym id / class surface (furniture/env/__init__.py:102-114) and the batched env with in-kernel auto-reset: the reward
+    state is re-initialised by every reset (furniture_sawyer_dense.py:218-220)."""
+    import torch
+    from furniture_amd.envs import make, make_vec_env
+
+    env = make("IKEASawyerDense-v0", record_vid=False)  # (rendering is out of scope: must be disabled explicitly)
+    assert type(env).__name__ == "FurnitureSawyerDenseRewardEnv" and env.max_episode_steps == 150
+    ob = env.reset()
+    assert ob["object_ob"].shape == (35,) and ob["robot_ob"].shape == (29,)
+    ob, r, d, info = env.step(np.zeros(9, dtype=np.float32))
+    assert np.isfinite(r) and not d and info["phase_i"] in (0, 1)
+    st = env.get_env_state()
+    assert st["dense"].shape == (27,) and int(st["dense"][1]) == info["phase_i"]
+    env.close()
+
+    venv = make_vec_env("Sawyer", 64, dense=True, record_vid=False, max_episode_steps=5, seed=7)
+    venv.reset()
+    g = torch.Generator(device=venv.sim.device)
+    g.manual_seed(0)
+    for t in range(12):
+        a = torch.empty((64, 9), device=venv.sim.device).uniform_(-1, 1, generator=g)
+        ob, rew, done, info = venv.step(a)
+        assert bool(torch.isfinite(rew).all()) and bool(torch.isfinite(ob["robot_ob"]).all())
+        assert bool(done.all()) == (t % 5 == 4) and bool(done.any()) == (t % 5 == 4)
+        ds = venv.sim.get_state("dense")["dense"]
+        assert bool((ds[:, 0] == 0).all()) and bool((ds[:, 1] == 1).all())  # subtask 0 has no grip_init_pos: starts in phase 1
+        assert bool((info["phase_i"] == 1).all())
+        if t % 5 == 4:  # fresh episode: _prev_grasp_dist = -1, lift distances reset (:214-216)
+            assert bool((ds[:, 19] == -1).all()) and bool((ds[:, 20] - 0.1).abs().max() < 1e-6)
+    venv.close()
