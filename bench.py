@@ -103,6 +103,8 @@ def main():
     cfg = default_config()
     cfg.max_episode_steps = MAX_EPISODE_STEPS
     cfg.auto_reset = 1
+    if os.environ.get("FSIM_BENCH_TOL"):  # development: Newton tolerance sweep (the shipped default is fsim_default_config's)
+        cfg.solver_tolerance = float(os.environ["FSIM_BENCH_TOL"])
     if args.dense:  # config/furniture_sawyer_dense.py:4-14
         from furniture_amd.dense import pack_dense
         cfg.dense_reward, cfg.auto_align = 1, 0

@@ -492,6 +492,7 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
   return FSIM_OK;
 }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
+extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg.dense_reward) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
 
@@ -547,6 +548,7 @@ static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if ((rc = copy_field(s, ly.xfrc, 6 * m.nparts, p->xfrc_applied, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqdata, 7 * m.neq, p->eq_data, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqactive, m.neq, p->eq_active, to_state))) return rc;
+  if ((rc = copy_field(s, ly.env, E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.dense_reward), p->env_block, to_state))) return rc; // (first: the named fields below win)
   if ((rc = copy_field(s, ly.env + E_GROUP, m.nparts, p->group, to_state))) return rc;
   if (p->dense) {
     if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "state field 'dense' exists for dense_reward handles only");

@@ -910,6 +910,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
       io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
       io.info[FSIM_INFO_DENSE_PHASE] = dense_phase;
+      io.info[FSIM_INFO_EPISODE_REWARD_F] = __float_as_int(L[ly.env + E_EPISODE_REWARD]);
     }
     scal[14] = terminal;
     if (io.cost) {

@@ -284,8 +284,17 @@ class FurnitureBatchEnv:
 
     def get_env_state(self):
         """Full snapshot (the reference's {qpos, qvel} plus the weld/mask/group state it omits)."""
-        names = ["qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group"] + (["dense"] if self.dense else [])
+        # every field of the per-env record: restoring it reproduces the trajectory bit for bit (qfrc_bias of the last forward
+        # pass is what the next step's gravity compensation reads, furniture.py:3346-3353)
+        names = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_active", "eq_data",
+                 "geom_contype", "geom_conaffinity", "group", "env_block"] + (["dense"] if self.dense else [])
         return self.sim.get_state(*names)
+
+    def set_env_state(self, state):
+        """Restore a snapshot taken by get_env_state (dict of [n_envs, dim] arrays / tensors).  The derived quantities (poses,
+        contacts) are recomputed by the first forward pass of the next step, as after the reference's set_env_state +
+        sim.forward() (furniture.py:1795-1803); the observation buffer is not refreshed until then."""
+        self.sim.set_state(**{k: v for k, v in state.items()})
 
     def close(self):
         if getattr(self, "_table_queue", None) is not None:

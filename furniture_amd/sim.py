@@ -16,8 +16,9 @@ _CSRC = os.path.join(_HERE, "csrc")
 _LIBPATH = os.environ.get("FSIM_LIB", os.path.join(_CSRC, "libfsim.so"))
 _LIB = None
 
-INFO_DIM = 14
+INFO_DIM = 15
 INFO_DENSE_PHASE = 13
+INFO_EPISODE_REWARD_F = 14
 DENSE_STATEW = 27  # FSIM_DENSE_STATEW; ED_* of csrc/fsim_dense.hpp (subtask, phase, flags, fine-aligned, 4 x vec3, 11 prev values)
 INFO_OVERFLOW = 12
 INFO_NUM_CONNECTED, INFO_SUCCESS, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2, INFO_EPISODE_LENGTH = range(6)
@@ -44,7 +45,7 @@ class FsimConfig(ctypes.Structure):
 
 class StatePtrs(ctypes.Structure):
     _names = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_data", "eq_active",
-              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters", "cursor", "dense"]
+              "geom_contype", "geom_conaffinity", "group", "qacc", "xpos", "xquat", "ncon", "contact_geoms", "solver_iters", "cursor", "dense", "env_block"]
     _fields_ = [(n, ctypes.c_void_p) for n in _names]
 
 
@@ -90,6 +91,7 @@ def lib():
         L.fsim_get_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_set_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
+        L.fsim_env_block_words.argtypes = [ctypes.c_void_p]
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
@@ -105,6 +107,7 @@ EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
+    "fsim_env_block_words",
 ]
 
 
@@ -158,6 +161,7 @@ class FSim:
         self._chk(lib().fsim_dims(self._h, *[ctypes.byref(x) for x in d]))
         self.nq, self.nv, self.nu, self.dof_action, self.obs_dim, self.info_dim, self.stride = [x.value for x in d]
         self.max_contacts = lib().fsim_max_contacts(self._h)
+        self.env_block_words = lib().fsim_env_block_words(self._h)
         st = ctypes.c_void_p()
         self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
         self.stream_ptr = st.value
@@ -190,7 +194,7 @@ class FSim:
                     qfrc_applied=(m.nv, "f"), xfrc_applied=(6 * m.nparts, "f"), eq_data=(7 * m.neq, "f"), eq_active=(m.neq, "i"),
                     geom_contype=(m.ngeom, "i"), geom_conaffinity=(m.ngeom, "i"), group=(m.nparts, "i"), qacc=(m.nv, "f"),
                     xpos=(3 * m.nbody, "f"), xquat=(4 * m.nbody, "f"), ncon=(1, "i"), contact_geoms=(2 * self.max_contacts, "i"),
-                    solver_iters=(1, "i"), cursor=(8, "f"), dense=(DENSE_STATEW, "f"))
+                    solver_iters=(1, "i"), cursor=(8, "f"), dense=(DENSE_STATEW, "f"), env_block=(self.env_block_words, "i"))
 
     def get_state(self, *names):
         """dict name -> torch tensor [n_envs, dim] (device)."""

@@ -91,10 +91,14 @@ typedef struct fsim_state_ptrs {
   float *dense /* dense_reward handles only: [n, FSIM_DENSE_STATEW] the reward state machine's variables
                   (furniture_sawyer_dense.py:128-216: subtask, phase, flags, fine-aligned count, init table-site / leg / lift / eef
                   positions, the eleven _prev_* distances), so that a snapshot restores the reward too */;
+  int32_t *env_block /* [n, fsim_env_block_words()] the env-logic variables of the record as opaque words (episode length and reward,
+                        _num_connected, connected-site set, touched/picked latches, pending connect, groups, Cursor / dense
+                        blocks): with qpos, qvel, qacc_warmstart, eq_*, geom_* this makes get/set_state a complete snapshot */;
 } fsim_state_ptrs_t;
 int fsim_get_state(fsim_t *, const fsim_state_ptrs_t *dst);
 int fsim_set_state(fsim_t *, const fsim_state_ptrs_t *src);
 int fsim_max_contacts(const fsim_t *);
+int fsim_env_block_words(const fsim_t *);
 
 /* ---- the env hot path ------------------------------------------------------------------- */
 /* Initial placements for the next reset of each env: part poses [n, nparts*7] (pos, quat wxyz) as drawn by
@@ -120,7 +124,9 @@ enum {
   FSIM_INFO_OVERFLOW = 12, /* bit 0: broadphase survivor list truncated, bit 1: contact slots exhausted (contacts dropped) in this step */
   FSIM_INFO_DENSE_PHASE = 13, /* dense-reward env: info["phase_i"] = phase + 8 * subtask (furniture_sawyer_dense.py:347); then
                                  FSIM_INFO_SUCCESS_REWARD_F carries info["phase_bonus"] and the other *_F columns are 0 */
-  FSIM_INFO_DIM = 14
+  FSIM_INFO_EPISODE_REWARD_F = 14, /* float bits: the episode's reward so far incl. this step (step_log["episode_reward"] at done,
+                                      furniture.py:468-470) */
+  FSIM_INFO_DIM = 15
 };
 
 /* ---- dense-reward env (FurnitureSawyerDenseRewardEnv) -------------------------------------- */

@@ -1,0 +1,65 @@
+"""SubprocVecEnv-shaped surface (furniture/util/vec_env.py:53-163, subproc_vec_env.py:15-121, base.py:55-80) and
+the full-state snapshot (the reference's {qpos, qvel} snapshot loses welds / masks / groups)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vec_env_surface_auto_reset_and_infos():
+    from furniture_amd.vec_env import AlreadySteppingError, NotSteppingError, make_vec_env
+
+    n = 16
+    venv = make_vec_env("IKEASawyer-v0", n, env_kwargs=dict(unity=False, record_vid=False, control_type="impedance",
+                                                            furniture_name="table_lack_0825", max_episode_steps=4, seed=11))
+    assert venv.num_envs == n and venv.unwrapped is venv
+    ob = venv.reset()
+    assert ob["object_ob"].shape == (n, 35) and ob["robot_ob"].shape == (n, 29) and ob["object_ob"].dtype == np.float64
+    with pytest.raises(NotSteppingError):
+        venv.step_wait()
+    rng = np.random.RandomState(0)
+    ep_rew = np.zeros(n)
+    for t in range(9):
+        a = rng.uniform(-1, 1, (n, 9)).astype(np.float32)
+        venv.step_async(a)
+        with pytest.raises(AlreadySteppingError):
+            venv.step_async(a)
+        ob2, rew, done, infos = venv.step_wait()
+        assert rew.shape == (n,) and done.shape == (n,) and len(infos) == n and isinstance(infos[0], dict)
+        ep_rew += rew
+        assert done.all() == (t % 4 == 3) and done.any() == (t % 4 == 3)
+        if done.all():
+            # terminal step_log (furniture.py:466-476) and the RESET observation in place of the terminal one
+            for i in range(n):
+                assert infos[i]["episode_length"] == 4 and abs(infos[i]["episode_reward"] - ep_rew[i]) < 1e-3
+                assert infos[i]["episode_success"] == 0 and infos[i]["episode_unstable"] == 0
+            ep_rew[:] = 0
+            assert np.abs(ob2["robot_ob"][:, 7:14]).max() < 1.0  # joint velocities right after a reset are small
+        else:
+            assert "episode_reward" not in infos[0]
+    with pytest.raises(NotImplementedError):
+        venv.get_images()
+    venv.close()
+    assert venv.closed
+    venv.close()  # idempotent
+
+
+def test_full_state_snapshot_restores_the_trajectory_bit_exactly():
+    from furniture_amd.vec_env import make_vec_env
+
+    n = 8
+    venv = make_vec_env("IKEASawyerDense-v0", n, env_kwargs=dict(record_vid=False, seed=5))
+    venv.reset()
+    rng = np.random.RandomState(1)
+    acts = rng.uniform(-1, 1, (8, n, 9)).astype(np.float32)
+    for t in range(3):
+        venv.step(acts[t])
+    snap = venv.get_env_state()
+    assert {"qpos", "qvel", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group", "env_block", "dense"} <= set(snap)
+    first = [venv.step(acts[t]) for t in range(3, 8)]
+    venv.set_env_state(snap)
+    second = [venv.step(acts[t]) for t in range(3, 8)]
+    for (o1, r1, d1, i1), (o2, r2, d2, i2) in zip(first, second):
+        assert np.array_equal(o1["object_ob"], o2["object_ob"]) and np.array_equal(o1["robot_ob"], o2["robot_ob"])
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and i1 == i2
+    venv.close()
