@@ -104,8 +104,14 @@ DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &
   float prjaxis = dot(n, axis);
   if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
   float dist0 = dot(cp - pp, n);
-  V3 vec = axis * prjaxis - n;
-  float len2 = dot(vec, vec);
+  // vec = axis (n.axis) - n = minus the part of n perpendicular to the axis.  Written through the cylinder's own x/y axes
+  // it has no cancellation: for a disc lying flat, |vec| ~ tilt, and in fp32 the difference of two unit vectors leaves the
+  // direction of the lowest rim point (hence the 3-point support triangle) to rounding noise -- the part then never comes
+  // to rest (seat of chair_agne_0007 wobbled at 6e-4 rad where the fp64 oracle settles to 1e-7).
+  V3 c0 = colv(cR, 0), c1 = colv(cR, 1);
+  float a0 = dot(n, c0), a1 = dot(n, c1);
+  V3 vec = -(c0 * a0 + c1 * a1);
+  float len2 = a0 * a0 + a1 * a1;
   if (len2 >= 1e-12f) vec = vec * (size.x / sqrtf(len2));
   else vec = colv(cR, 0) * size.x;
   float prjvec = dot(vec, n);

@@ -75,9 +75,12 @@ class ResetTableSampler:
     _initialize_robot_pos() (furniture.py:1761-1779 called at :1580 and 100x at :1606-1611).  Env i of the global batch
     is seeded seed + i (furniture/env/base.py:77), independent of how the batch is split over GPUs."""
 
-    def __init__(self, model, cfg, seed, first_env_index, n_envs):
+    def __init__(self, model, cfg, seed, first_env_index, n_envs, env_indices=None):
+        """env_indices: explicit global env index per row (mixed-furniture batches own non-contiguous lanes)."""
         self.m, self.cfg = model, cfg
-        self.rngs = [np.random.RandomState(seed + first_env_index + i) for i in range(n_envs)]
+        idx = [first_env_index + i for i in range(n_envs)] if env_indices is None else [int(i) for i in env_indices]
+        assert len(idx) == n_envs
+        self.rngs = [np.random.RandomState(seed + i) for i in idx]
         self.narm = len(model.arm_qposadr)
 
     def _placement(self, rng):
@@ -164,7 +167,7 @@ _AGENT_OF = {"FurnitureSawyerEnv": "Sawyer", "FurnitureBaxterEnv": "Baxter", "Fu
 class FurnitureBatchEnv:
     """n_envs copies of FurnitureEnv on one GPU.  Observations / rewards / dones are torch tensors on the device."""
 
-    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, dense=False, **kw):
+    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, dense=False, env_indices=None, **kw):
         """dense=True: FurnitureSawyerDenseRewardEnv semantics (furniture_sawyer_dense.py) -- the config then carries the
         config/furniture_sawyer_dense.py overrides and, optionally, any of its reward coefficients."""
         cfg = config if config is not None else make_config(**(DENSE_OVERRIDES if dense else {}))
@@ -217,7 +220,7 @@ class FurnitureBatchEnv:
         self._done = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
         self._info = torch.zeros((num_envs, INFO_DIM), dtype=torch.int32, device=dev)
         self._act = torch.zeros((num_envs, self.sim.dof_action), dtype=torch.float32, device=dev)
-        self._sampler = ResetTableSampler(self.model, cfg, cfg.seed, first_env_index, num_envs)
+        self._sampler = ResetTableSampler(self.model, cfg, cfg.seed, first_env_index, num_envs, env_indices=env_indices)
         self._tables_fresh = False
         self.n_obj = self.model.nparts
         self.refill_tables_every_step = True
