@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--agent", default=AGENT, help="(exploration only; the benchmark workload is the default)")
     ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
+    ap.add_argument("--control-type", default="impedance", help="(exploration only) a torque-level arm controller, e.g. position_orientation")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
@@ -97,12 +98,15 @@ def main():
     n = args.envs_per_gpu
     lo, hi = shard_range(rank, world, n)
 
-    m = load_compiled(args.agent, args.furniture)
-    ecfg = make_config(unity=False, record_vid=False, control_type="impedance", furniture_name=args.furniture,
+    m = load_compiled(args.agent, args.furniture, args.control_type)
+    ecfg = make_config(unity=False, record_vid=False, control_type=args.control_type, furniture_name=args.furniture,
                        max_episode_steps=MAX_EPISODE_STEPS, seed=SEED)
     cfg = default_config()
     cfg.max_episode_steps = MAX_EPISODE_STEPS
     cfg.auto_reset = 1
+    if args.control_type != "impedance":
+        from furniture_amd.envs import CONTROLLER_CODES
+        cfg.control_type = CONTROLLER_CODES[args.control_type]
     if os.environ.get("FSIM_BENCH_TOL"):  # development: Newton tolerance sweep (the shipped default is fsim_default_config's)
         cfg.solver_tolerance = float(os.environ["FSIM_BENCH_TOL"])
     if args.dense:  # config/furniture_sawyer_dense.py:4-14
@@ -208,12 +212,12 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n, args.dense) == (AGENT, FURNITURE, ENVS_PER_GPU, False)
-            else "env-steps/sec (whole node), EXPLORATION %s+%s%s %d envs/GPU" % (args.agent, args.furniture, " dense-reward" if args.dense else "", n), "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n, args.dense, args.control_type) == (AGENT, FURNITURE, ENVS_PER_GPU, False, "impedance")
+            else "env-steps/sec (whole node), EXPLORATION %s+%s%s %d envs/GPU" % (args.agent, args.furniture, (" dense-reward" if args.dense else "") + ("" if args.control_type == "impedance" else " control_type=" + args.control_type), n), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Furniture%sEnv + %s, impedance control, %d envs/GPU, U(-1,1)^%d actions, "
-                                   "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, n, slabs[0].sim.dof_action),
+            "config": {"workload": "Furniture%sEnv + %s, %s control, %d envs/GPU, U(-1,1)^%d actions, "
+                                   "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
                        "physics_substeps_per_s": value * 50, "obs_finite": finite,

@@ -348,7 +348,7 @@ static void build_layout(fsim *s, int ncon_max) {
   auto take = [&](int n) { int r = o; o += n; return r; };
   ly.qpos = take(m.nq); ly.qvel = take(m.nv); ly.qaccws = take(m.nv); ly.qfrcbias = take(m.nv); ly.ctrl = take(m.nu);
   ly.qfrcapp = take(m.nv); ly.xfrc = take(6 * m.nparts); ly.eqdata = take(7 * m.neq); ly.eqactive = take(m.neq);
-  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.dense_reward));
+  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg));
   o = (o + 3) / 4 * 4;
   ly.stride = o;
   // LDS-only
@@ -420,6 +420,12 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
+  if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 6) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance) and 2..6 (arm controllers) are built; the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl", cfg ? cfg->control_type : 0); }
+  if (env_controller_kind(s->cfg)) {
+    if (s->m.agent != 0 || s->cfg.dense_reward) { delete s; FAIL(FSIM_EINVAL, "arm controllers (control_type 2..6) are built for the Sawyer agent, sparse reward"); }
+    std::vector<float> ag; blob_f(s->blob, "actuator_gain", ag);
+    if (s->m.nu != 9 || ag.size() != 9 || ag[0] != 1.0f) { delete s; FAIL(FSIM_EINVAL, "arm controllers need the motor-actuated model (compiled with a torque-level control_type, robot_torque.xml)"); }
+  }
   if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
   if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
   build_layout(s, ncon_max);
@@ -451,6 +457,11 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     memcpy(rec.data() + s->ly.conaff, ca.data(), ca.size() * 4);
     int *envw = reinterpret_cast<int *>(rec.data() + s->ly.env);
     for (int p = 0; p < s->m.nparts; p++) envw[E_GROUP + p] = p;
+    if (int ck = env_controller_kind(s->cfg)) { // Controller.reset() state (arm_controller.py:570-575): identity orientations
+      float *K = rec.data() + s->ly.env + E_GROUP + s->m.nparts;
+      reinterpret_cast<int *>(K)[EK_KIND] = ck;
+      if (ck <= CK_POS) for (int i = 0; i < 3; i++) K[EK_LGO + 4 * i] = K[EK_OINIT + 4 * i] = K[EK_GORI + 4 * i] = 1.0f;
+    }
     std::vector<float> all((size_t)n_envs * s->ly.stride);
     for (int e = 0; e < n_envs; e++) memcpy(all.data() + (size_t)e * s->ly.stride, rec.data(), s->ly.stride * 4);
     HIPCHK(hipMemcpy(s->d_state, all.data(), sbytes, hipMemcpyHostToDevice));
@@ -492,7 +503,7 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
   return FSIM_OK;
 }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
-extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg.dense_reward) : 0; }
+extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
 
@@ -548,7 +559,7 @@ static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if ((rc = copy_field(s, ly.xfrc, 6 * m.nparts, p->xfrc_applied, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqdata, 7 * m.neq, p->eq_data, to_state))) return rc;
   if ((rc = copy_field(s, ly.eqactive, m.neq, p->eq_active, to_state))) return rc;
-  if ((rc = copy_field(s, ly.env, E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg.dense_reward), p->env_block, to_state))) return rc; // (first: the named fields below win)
+  if ((rc = copy_field(s, ly.env, E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg), p->env_block, to_state))) return rc; // (first: the named fields below win)
   if ((rc = copy_field(s, ly.env + E_GROUP, m.nparts, p->group, to_state))) return rc;
   if (p->dense) {
     if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "state field 'dense' exists for dense_reward handles only");

@@ -15,6 +15,7 @@
 #pragma once
 #include "fsim_solver.hpp"
 #include "fsim_dense.hpp"
+#include "fsim_ctrl.hpp"
 
 struct EnvCfg {
   int dof_action, obs_dim, n_substeps, max_episode_steps, discrete_grip, rescale_actions, auto_align, auto_reset, has_recipe, agent;
@@ -25,6 +26,7 @@ struct EnvCfg {
   // dense-reward env (fsim_dense.hpp): tables uploaded by fsim_set_dense_reward
   int dense, dense_nsub;
   const float *dense_coef, *dense_sub;
+  int controller; // CK_* (fsim_ctrl.hpp): torque-level arm controller run before every physics substep, 0 = none
 };
 struct EnvIO {
   const float *action;
@@ -37,7 +39,10 @@ struct EnvIO {
   long long t0;   // shader clock at kernel entry
 };
 
-static inline int env_extra_words(const DModel &m, int dense) { return m.agent == 2 ? EC_WORDS : (dense ? ED_WORDS : 0); }
+static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
+static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
+  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : 0));
+}
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
   e.agent = m.agent;
@@ -53,6 +58,11 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
   e.ctrl_penalty_coef = c.ctrl_penalty_coef; e.unstable_penalty_coef = c.unstable_penalty_coef; e.success_reward = c.success_reward;
   e.touch_reward = c.touch_reward; e.pick_reward = c.pick_reward;
   e.dense = c.dense_reward; e.dense_nsub = 0; e.dense_coef = nullptr; e.dense_sub = nullptr;
+  e.controller = env_controller_kind(c);
+  if (e.controller) { // action = [arm command, grip, connect]; robot_ob without joint_pos / joint_vel (furniture_sawyer.py:112-153)
+    e.dof_action = (e.controller == CK_POS_ORI ? 6 : (e.controller == CK_POS ? 3 : 7)) + 2;
+    e.obs_dim = 7 * m.nparts + 15 * m.narm;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
@@ -166,7 +176,10 @@ DEV void fs_forward_body(const Ctx &c) {
 // save/restore to scratch (tens of dwords per lane per call) is paid once per env step instead of once per substep --
 // with per-substep calls it was 2.6 GB of HBM writes per 4096-env step (rocprofv3 WRITE_SIZE), 300x the state traffic.
 //   mode bit 0: forward only (no integration);  mode bit 1: run fs_touch_flags after the last forward pass
-__device__ __noinline__ void fs_substeps(Ctx cv, int n_, int mode_) {
+//   CTRL (separate instantiation, so the default path's code and register allocation are untouched): the torque-level arm
+//   controller runs before every substep (_do_controller_step, furniture.py:3065-3093); pass -1 is the sim.forward() that
+//   precedes the loop, whose results the first _pre_action reads.
+template <bool CTRL> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
   FS_REBUILD_CTX(cv);
   const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
   if (mode & 1) {
@@ -175,12 +188,15 @@ __device__ __noinline__ void fs_substeps(Ctx cv, int n_, int mode_) {
     return;
   }
 #pragma unroll 1
-  for (int s = 0; s < n; s++) {
+  for (int s = CTRL ? -1 : 0; s < n; s++) {
+    if (CTRL && s >= 0) fs_controller(c, s == 0);
     fs_forward_body(c);
+    if (CTRL && s < 0) continue;
     if ((mode & 2) && s == n - 1) fs_touch_flags(c);
     fs_integrate_body(c);
   }
 }
+DEV void fs_substeps(const Ctx &c, int n, int mode) { fs_substeps_t<false>(c, n, mode); }
 DEV void fs_forward(const Ctx &c) { fs_substeps(c, 1, 1); }
 DEV void fs_step(const Ctx &c) { fs_substeps(c, 1, 0); }
 
@@ -636,17 +652,22 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     io.obs[i] = k < 3 ? L[ly.xpos + 3 * b + k] : L[ly.xquat + 4 * b + k - 3];
   }
   int base = 7 * m.nparts;
+  // data.site_xvelp / site_xvelr in mujoco_py are jac(site) . qvel: the Jacobian of the LAST forward pass (one integration
+  // old after sim.step()) times the CURRENT qvel -- not mj_objectVelocity's cvel of that pass.
+  if (m.narm) fs_body_spatial(c, ly.qvel);
   if (m.agent == 2) { // furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
     const float *ec = L + ly.env + E_GROUP + m.nparts;
     if (c.lane < 6) io.obs[base + c.lane] = ec[EC_XPOS + c.lane];
     if (c.lane < 2) io.obs[base + 6 + c.lane] = reinterpret_cast<const int *>(ec)[EC_SEL + c.lane] ? 1.0f : 0.0f;
   }
   for (int arm = 0; arm < m.narm; arm++) {
-    float *o = io.obs + base + 29 * arm;
-    int nj = m.narmj / m.narm;
+    const int njm = m.narmj / m.narm;
+    // joint_pos / joint_vel are part of robot_ob for impedance / torque only (furniture_sawyer.py:112-124)
+    const int nj = cfg.controller ? 0 : njm;
+    float *o = io.obs + base + (2 * nj + 15) * arm;
     for (int k = c.lane; k < nj; k += 64) {
-      o[k] = L[ly.qpos + GP(m.arm_qposadr)[arm * nj + k]];
-      o[nj + k] = L[ly.qvel + GP(m.arm_dofadr)[arm * nj + k]];
+      o[k] = L[ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
+      o[nj + k] = L[ly.qvel + GP(m.arm_dofadr)[arm * njm + k]];
     }
     if (c.lane < 2) o[2 * nj + c.lane] = L[ly.qpos + GP(m.grip_qposadr)[2 * arm + c.lane]];
     if (c.lane == 0) {
@@ -657,7 +678,7 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       Q4 q = qmul(ldq(L + ly.xquat + 4 * rb), ldq(GP(m.body_relquat) + 4 * hb));
       o[2 * nj + 5] = q.x; o[2 * nj + 6] = q.y; o[2 * nj + 7] = q.z; o[2 * nj + 8] = q.w;
       int sb = GP(m.s_body)[site];
-      S6 v = lds6(L + ly.cvel + 6 * sb);
+      S6 v = lds6(L + ly.W + 6 * sb);
       V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * KI(r_tree, sb))) : v3(0, 0, 0);
       stv3(o + 2 * nj + 9, vp);
       stv3(o + 2 * nj + 12, sb ? v.a : v3(0, 0, 0));
@@ -778,6 +799,22 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   // _before_step + action plumbing
   if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
   float connect = io.action[dof - 1];
+  if (cfg.controller) {
+    // FurnitureSawyerEnv._step discretises the grip (furniture_sawyer.py:72-74); _do_controller_step scales the first three
+    // entries by move_speed and permutes them [-a1, a0, a2] whatever the controller kind (furniture.py:3069-3071)
+    float *K = L + ly.env + E_GROUP + m.nparts;
+    const int cd = dof - 2;
+    if (c.lane < 8) {
+      float v = 0;
+      if (c.lane == 0) v = -io.action[1] * cfg.move_speed;
+      else if (c.lane == 1) v = io.action[0] * cfg.move_speed;
+      else if (c.lane == 2) v = io.action[2] * cfg.move_speed;
+      else if (c.lane < cd) v = io.action[c.lane];
+      else if (c.lane == 7) { v = io.action[cd]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
+      K[EK_ACT + c.lane] = v;
+    }
+    if (c.lane == 0) reinterpret_cast<int *>(K)[EK_KIND] = cfg.controller;
+  } else
   // _setup_action (impedance): clip, gripper 1 -> 2, rescale to ctrlrange, stale gravity compensation
   for (int u = c.lane; u < m.nu; u += 64) {
     float a;
@@ -810,6 +847,10 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     SYNC();
     fs_substeps(c, cfg.n_substeps, 0);
     env_stop_selected(c, 1.0f);
+  } else if (cfg.controller) {
+    // _do_controller_step: sim.forward(), then n_substeps x (_pre_action, sim.step()); no _setup_action, so qfrc_applied keeps
+    // the gravity compensation the reset left (furniture.py:1624-1632) on top of the qfrc_bias inside ctrl
+    fs_substeps_t<true>(c, cfg.n_substeps, 2);
   } else {
     env_gravity_comp(c);
     // _do_simulation: n_substeps x sim.step()

@@ -47,6 +47,9 @@ DENSE_OVERRIDES = dict(max_episode_steps=150, control_type="impedance", furnitur
                        auto_align=False, alignment_pos_dist=0.02, alignment_rot_dist_up=0.99, alignment_rot_dist_forward=0.99,
                        alignment_project_dist=0.0)
 
+# furniture.py:41-47 (NEW_CONTROLLERS) -> fsim_config_t.control_type: torque-level arm controllers run per physics substep
+CONTROLLER_CODES = {"position_orientation": 2, "position": 3, "joint_impedance": 4, "joint_velocity": 5, "joint_torque": 6}
+
 GYM_IDS = {  # furniture/env/__init__.py:19-114
     "IKEACursor-v0": ("FurnitureCursorEnv", dict(furniture_id=0)),
     "IKEASawyer-v0": ("FurnitureSawyerEnv", dict(furniture_name="swivel_chair_0700")),
@@ -182,16 +185,20 @@ class FurnitureBatchEnv:
                 raise NotImplementedError("phase_ob / preassembled are not part of the accelerated dense-reward path")
         if cfg.unity or cfg.record_vid or cfg.visual_ob:
             raise ValueError("unity / record_vid / visual_ob must be False: rendering is outside the accelerated hot path")
-        if agent != "Cursor" and cfg.control_type != "impedance":
-            raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' (ik needs pybullet; "
-                                      "the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl)" % cfg.control_type)
+        if agent != "Cursor" and cfg.control_type != "impedance" and cfg.control_type not in CONTROLLER_CODES:
+            raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
+                                      "controllers %s (ik needs pybullet; the reference's 'torque' path writes an 8-vector into "
+                                      "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
+        if cfg.control_type in CONTROLLER_CODES and (agent != "Sawyer" or dense):
+            raise NotImplementedError("the arm controllers are built for the Sawyer agent with the sparse reward")
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         names = furniture_names()
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg
-        self.model = load_compiled(agent, fname)
+        self.model = load_compiled(agent, fname, cfg.control_type if agent != "Cursor" else "impedance")
         c = default_config()
+        c.control_type = CONTROLLER_CODES.get(cfg.control_type, 0) if agent != "Cursor" else 0
         c.n_substeps = int((1.0 / cfg.control_freq) / float(self.model.opt[0]))
         c.max_episode_steps = int(cfg.max_episode_steps)
         c.discrete_grip, c.rescale_actions, c.auto_align = int(cfg.discrete_grip), int(cfg.rescale_actions), int(cfg.auto_align)

@@ -239,7 +239,7 @@ def assemble_scene(assets_root, agent, furniture_name, control_type="impedance",
 
     Returns (root Element, info) where info carries the name tables the env needs.
     """
-    use_torque = control_type == "torque"
+    use_torque = control_type in ("torque", "position", "position_orientation", "joint_impedance", "joint_torque", "joint_velocity")
     world = XmlDoc(os.path.join(assets_root, "base.xml"))
 
     arena = XmlDoc(os.path.join(assets_root, "arenas/floor_arena.xml"))

@@ -125,8 +125,12 @@ _DIMS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "neq", "npair", "n
 _AGENT_CODE = {"Sawyer": 0, "Baxter": 1, "Cursor": 2}
 
 
+# furniture.py:41-47 (NEW_CONTROLLERS) and :1893: these control types load the robot's motor-actuated MJCF (robot_torque.xml)
+TORQUE_CONTROL_TYPES = ("torque", "position", "position_orientation", "joint_impedance", "joint_torque", "joint_velocity")
+
+
 def compiled_name(agent, furniture_name, control_type="impedance"):
-    ct = "torque" if control_type == "torque" else "vel"
+    ct = "torque" if control_type in TORQUE_CONTROL_TYPES else "vel"
     return "%s__%s__%s" % (agent, furniture_name, ct)
 
 

@@ -34,7 +34,10 @@ enum {
 
 /* env configuration that the reference keeps in its argparse Namespace (furniture/config/furniture.py) */
 typedef struct fsim_config {
-  int32_t control_type;       /* 0 impedance (velocity actuators), 1 torque */
+  int32_t control_type;       /* 0 impedance (velocity actuators), 1 torque (rejected), and the torque-level arm controllers of
+                                 furniture/env/controllers/arm_controller.py run per physics substep (furniture.py:41-47, 3065-3093;
+                                 Sawyer, motor-actuated model): 2 position_orientation, 3 position, 4 joint_impedance,
+                                 5 joint_velocity, 6 joint_torque.  Action = [arm command (6|3|7|7|7), grip, connect]. */
   int32_t n_substeps;         /* int(control_timestep/model_timestep) = 50 (furniture.py:2878) */
   int32_t max_episode_steps;  /* config/furniture.py:163-168 */
   int32_t discrete_grip;      /* furniture_sawyer.py:72-74 */

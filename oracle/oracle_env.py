@@ -52,6 +52,7 @@ class OracleConfig:
         self.solver_iterations = 100
         self.solver_tolerance = 1e-8
         self.dense = None  # an oracle.dense_reward.DenseConfig -> FurnitureSawyerDenseRewardEnv behaviour
+        self.control_type = "impedance"  # or one of NEW_CONTROLLERS (furniture.py:41-47): needs the __torque compiled model
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -109,6 +110,14 @@ class FurnitureEnvOracle:
         self.reset_draws = None  # filled by reset(): what a device reset table must contain
         self._fail = False
         self._dense = None
+        self._ctrl = None
+        if self.cfg.control_type != "impedance":
+            # _load_controller (F.py:1665-1704) builds one controller per arm at construction; controller.reset() runs only in
+            # _reset_internal (F.py:1885-1887), i.e. on the FIRST reset -- the controller state survives later resets.
+            from oracle import controllers as C
+            assert self.cfg.control_type in C.TYPES and self.agent == "Sawyer", self.cfg.control_type
+            self._C = C
+            self._ctrl = [C.new_state(self.cfg.control_type) for _ in self.arms]
         if self.cfg.dense is not None:
             from furniture_amd.dense import dense_subtasks
             from oracle.dense_reward import DenseReward
@@ -297,8 +306,9 @@ class FurnitureEnvOracle:
         for a in range(len(self.arms)):
             site = m.eef_siteid[a]
             velp, velr = self.sim.site_vel(site)
-            rs += [d.qpos[m.arm_qposadr[a * nj:(a + 1) * nj]], d.qvel[m.arm_dofadr[a * nj:(a + 1) * nj]],
-                   d.qpos[m.grip_qposadr[2 * a:2 * a + 2]], d.site_xpos[site].copy(),
+            if getattr(self, "_ctrl", None) is None:  # joint_pos / joint_vel only for impedance / torque (furniture_sawyer.py:112-124)
+                rs += [d.qpos[m.arm_qposadr[a * nj:(a + 1) * nj]], d.qvel[m.arm_dofadr[a * nj:(a + 1) * nj]]]
+            rs += [d.qpos[m.grip_qposadr[2 * a:2 * a + 2]], d.site_xpos[site].copy(),
                    T.convert_quat(d.xquat[m.hand_bodyid[a]], to="xyzw"), velp, velr]
         ob["robot_ob"] = np.concatenate([np.asarray(x, dtype=float).ravel() for x in rs])
         return ob
@@ -545,6 +555,31 @@ class FurnitureEnvOracle:
             self.reset()
             self._fail = True
 
+    def _do_controller_step(self, action):
+        """F.py:3065-3093 + _pre_action (F.py:1706-1759).  update_model (arm_controller.py:109-136) reads MuJoCo's memory as
+        sim.step() left it: poses / Jacobian / mass matrix / qfrc_bias of the forward pass BEFORE the last integration, qpos and
+        qvel after it; body_xvelp/xvelr are mujoco_py's jac . qvel."""
+        C, m, sim = self._C, self.m, self.sim
+        act = C.preprocess_action(action, self.cfg.move_speed)
+        arm_q, arm_d, grip_d = m.arm_qposadr.astype(int), m.arm_dofadr.astype(int), m.grip_dofadr.astype(int)
+        try:
+            sim.forward()
+            for i in range(self._n_substeps):
+                d = sim.data
+                hb = int(m.hand_bodyid[0])
+                jp, jr = sim.body_jac(hb, d.xpos[hb])
+                model = dict(pos=d.xpos[hb].copy(), mat=d.xmat[hb].reshape(3, 3).copy(), velp=jp @ d.qvel, velr=jr @ d.qvel,
+                             q=d.qpos[arm_q].copy(), qd=d.qvel[arm_d].copy(), Jx=jp[:, arm_d], Jr=jr[:, arm_d],
+                             M=sim.full_M()[np.ix_(arm_d, arm_d)])
+                arm, grip = C.pre_action_ctrl(self._ctrl[0], act, i == 0, model, d.qfrc_bias[arm_d], m.ctrl_bias[grip_d],
+                                              m.ctrl_weight[grip_d], float(m.opt[0]))
+                d.ctrl[arm_d] = arm      # (the reference indexes ctrl with the joint-velocity indices, F.py:1756)
+                d.ctrl[grip_d] = grip
+                sim.step()
+        except SimUnstable:
+            self.reset()
+            self._fail = True
+
     def step(self, action):
         action = np.asarray(action, dtype=np.float64).copy()
         self._connected = False
@@ -556,8 +591,11 @@ class FurnitureEnvOracle:
             self._do_simulation(None)
         else:
             connect = a[-1]
-            ctrl = self._setup_action(a[:-1])
-            self._do_simulation(ctrl)
+            if self._ctrl is not None:
+                self._do_controller_step(a)
+            else:
+                ctrl = self._setup_action(a[:-1])
+                self._do_simulation(ctrl)
             if connect > 0:
                 for (L, R, _) in self._touch_sets():
                     hit = False

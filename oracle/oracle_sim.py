@@ -128,6 +128,13 @@ class OracleSim:
         return list(zip(self._cg1[:n].tolist(), self._cg2[:n].tolist()))
 
     def site_vel(self, site_id):
+        """data.site_xvelp[site], data.site_xvelr[site] as mujoco_py computes them: jac(site) . qvel, i.e. the Jacobian
+        of the last forward pass (one integration old after sim.step()) times the current qvel."""
+        jp, jr = self.body_jac(int(self.cm.site_bodyid[site_id]), self.data.site_xpos[site_id])
+        return jp @ self.data.qvel, jr @ self.data.qvel
+
+    def site_vel_cvel(self, site_id):
+        """mj_objectVelocity-style: from the body velocities (cvel) of the last forward pass."""
         vp, vr = np.zeros(3), np.zeros(3)
         lib().osim_site_vel(self._h, int(site_id), vp.ctypes.data, vr.ctypes.data)
         return vp, vr

@@ -16,6 +16,8 @@ DEFAULT = [
     ("Sawyer", "table_lack_0825"), ("Sawyer", "swivel_chair_0700"), ("Sawyer", "toy_table"),
     ("Sawyer", "chair_agne_0007"), ("Sawyer", "shelf_ivar_0678"), ("Baxter", "desk_mikael_1064"),
     ("Baxter", "table_lack_0825"), ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"), ("Cursor", "swivel_chair_0700"),
+    # motor-actuated robot (robot_torque.xml) for the torque-level arm controllers (furniture.py:1893)
+    ("Sawyer", "table_lack_0825", "joint_torque"), ("Sawyer", "swivel_chair_0700", "joint_torque"),
 ]
 
 
@@ -32,13 +34,15 @@ def main():
         todo += [("Sawyer", n) for n in names if ("Sawyer", n) not in todo]
     out = model._COMPILED_DIR
     os.makedirs(out, exist_ok=True)
-    for agent, furn in todo:
+    for item in todo:
+        agent, furn = item[0], item[1]
+        ctype = item[2] if len(item) > 2 else "impedance"
         try:
-            m = model.build_model(agent, furn, assets_root=root)
+            m = model.build_model(agent, furn, control_type=ctype, assets_root=root)
         except NotImplementedError as e:
             print("skip %s/%s: %s" % (agent, furn, e))
             continue
-        path = os.path.join(out, model.compiled_name(agent, furn) + ".npz")
+        path = os.path.join(out, model.compiled_name(agent, furn, ctype) + ".npz")
         m.save(path)
         print("%-8s %-28s nbody=%d nq=%d nv=%d ngeom=%d npair=%d  -> %s (%d KB)" % (
             agent, furn, m.nbody, m.nq, m.nv, m.ngeom, m.npair, os.path.basename(path), os.path.getsize(path) // 1024))

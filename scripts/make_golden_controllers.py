@@ -1,0 +1,236 @@
+"""Generate tests/golden/controllers.npz from the REFERENCE's own arm controllers.
+
+Runs only in the build container (needs /root/reference).  `furniture/env/controllers/arm_controller.py` is plain numpy /
+scipy code once `mujoco_py` is stubbed: every quantity it reads from the simulator (`update_model`, :109-136) is injected
+through a fake `sim`, and `mujoco_py.cymj._mj_fullM` is replaced by a copy of a dense matrix we supply.  The five
+controller classes are constructed exactly as `FurnitureEnv._load_controller` does (`furniture.py:1665-1704`): parameters
+from `controllers/controller_config.hjson`, no overrides.  Recorded per physics substep: the injected inputs and the torques
+returned by `action_to_torques(action, policy_step)`.
+
+A second block pins `FurnitureEnv._do_controller_step` / `_pre_action` (`furniture.py:1706-1759, 3065-3093`) themselves: the
+reference methods run on a fake `self` whose `sim.step()` only advances a scripted state; the `ctrl` vector they write at
+every substep is recorded.
+"""
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden_env_logic import import_reference, rand_rot  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "controllers.npz")
+TYPES = ["position_orientation", "position", "joint_impedance", "joint_velocity", "joint_torque"]
+NV, NARM = 12, 7
+HAND = "right_hand"
+
+
+def load_hjson(path):
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    return json.loads(txt)
+
+
+class FakeModel:
+    def __init__(self):
+        self.opt = types.SimpleNamespace(timestep=0.002)
+        self.actuator_ctrlrange = np.array([[-80.0, 80.0]] * 5 + [[-12.0, 12.0]] * 2 + [[-0.0115, 0.020833], [-0.020833, 0.0115]])
+
+    def body_name2id(self, name):
+        assert name == HAND
+        return 3
+
+
+class FakeData:
+    def __init__(self):
+        self.body_xpos = np.zeros((5, 3))
+        self.body_xmat = np.zeros((5, 9))
+        self.body_xvelp = np.zeros((5, 3))
+        self.body_xvelr = np.zeros((5, 3))
+        self.qpos = np.zeros(NV + 3)
+        self.qvel = np.zeros(NV)
+        self.qM = np.zeros(NV * NV)
+        self.jacp = np.zeros((3, NV))
+        self.jacr = np.zeros((3, NV))
+        self.ctrl = np.zeros(9)
+        self.qfrc_bias = np.zeros(NV)
+
+    def get_body_jacp(self, name):
+        assert name == HAND
+        return self.jacp.reshape(-1).copy()
+
+    def get_body_jacr(self, name):
+        assert name == HAND
+        return self.jacr.reshape(-1).copy()
+
+
+class FakeSim:
+    def __init__(self):
+        self.model, self.data = FakeModel(), FakeData()
+        self.calls = []
+
+    def forward(self):
+        self.calls.append("forward")
+
+    def step(self):
+        self.calls.append("step")
+        if self.on_step is not None:
+            self.on_step()
+
+    on_step = None
+
+
+def spd(rng, n, lo=0.3, hi=3.0):
+    q, _ = np.linalg.qr(rng.randn(n, n))
+    return (q * rng.uniform(lo, hi, n)) @ q.T
+
+
+class Scene:
+    """A smooth scripted 'robot': joint state random walk, hand pose drifting, Jacobian and mass matrix slowly varying."""
+
+    def __init__(self, rng, singular=False, fast=False):
+        self.rng = rng
+        self.q = rng.uniform(-1, 1, NARM)
+        self.qd = rng.uniform(-0.5, 0.5, NARM) * (12.0 if fast else 1.0)
+        self.pos = rng.uniform(-0.5, 0.5, 3) + np.array([0.5, 0, 1.0])
+        self.R = rand_rot(rng)
+        self.J = rng.uniform(-0.6, 0.6, (6, NV))
+        self.J[:, NARM:] = 0
+        if singular:
+            # Jx and Jr nearly lose a direction: one singular value of Jx M^-1 Jx' (Jr ...) falls below 0.00025 and is zeroed
+            # (:782-790); exactly singular would make the reference's own scipy.linalg.inv of the 6x6 raise (:770)
+            self.J[2, :NARM] *= 2e-3
+            self.J[3, :NARM] *= 1e-2
+        self.M = spd(rng, NV)
+
+    def advance(self):
+        rng = self.rng
+        self.qd = self.qd + rng.uniform(-0.02, 0.02, NARM)
+        self.q = self.q + 0.002 * self.qd
+        self.pos = self.pos + rng.uniform(-2e-4, 2e-4, 3)
+        w = rng.uniform(-2e-3, 2e-3, 3)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        u, _, vt = np.linalg.svd((np.eye(3) + K) @ self.R)
+        self.R = u @ vt
+        self.J = self.J * (1 + rng.uniform(-1e-3, 1e-3, self.J.shape))
+        d = rng.uniform(-1e-3, 1e-3, (NV, NV))
+        self.M = self.M + d + d.T
+
+    def write(self, sim):
+        d = sim.data
+        d.body_xpos[3] = self.pos
+        d.body_xmat[3] = self.R.reshape(-1)
+        qv = np.zeros(NV)
+        qv[:NARM] = self.qd
+        d.body_xvelp[3] = self.J[:3] @ qv
+        d.body_xvelr[3] = self.J[3:] @ qv
+        d.qpos[:NARM] = self.q
+        d.qvel[:NARM] = self.qd
+        d.jacp[:] = self.J[:3]
+        d.jacr[:] = self.J[3:]
+        d.qM[:] = self.M.reshape(-1)
+
+    def record(self):
+        qv = np.zeros(NV)
+        qv[:NARM] = self.qd
+        return np.concatenate([self.pos, self.R.reshape(-1), self.J[:3] @ qv, self.J[3:] @ qv, self.q, self.qd,
+                               self.J[:3, :NARM].reshape(-1), self.J[3:, :NARM].reshape(-1), self.M[:NARM, :NARM].reshape(-1)])
+
+
+def main():
+    F = import_reference()
+    import mujoco_py
+    import furniture.env.controllers.arm_controller as AC
+
+    def full_m(model, dst, qM):
+        dst[:] = np.asarray(qM).reshape(-1)
+
+    mujoco_py.cymj = types.SimpleNamespace(_mj_fullM=full_m)
+    AC.mujoco_py = mujoco_py
+    params = load_hjson("/root/reference/furniture/env/controllers/controller_config.hjson")
+    ctor = {"position_orientation": AC.PositionOrientationController, "position": AC.PositionController,
+            "joint_impedance": AC.JointImpedanceController, "joint_velocity": AC.JointVelocityController,
+            "joint_torque": AC.JointTorqueController}
+    joint_index = list(range(NARM))
+    out = {"types": np.array(TYPES), "params_json": np.array(json.dumps({k: params[k] for k in TYPES}))}
+    rng = np.random.RandomState(20260924)
+    n_policy, n_sub = 3, 10
+    for ti, tname in enumerate(TYPES):
+        for si in range(3):
+            scene = Scene(rng, singular=(si == 1), fast=(si == 2))
+            sim = FakeSim()
+            c = ctor[tname](**dict(params[tname]))
+            c.reset()
+            cd = c.control_dim
+            ins, acts, flags, outs = [], [], [], []
+            for p in range(n_policy):
+                a = rng.uniform(-1.3, 1.3, cd)  # beyond [-1, 1]: transform_action clips (:99-107)
+                for s in range(n_sub):
+                    scene.write(sim)
+                    c.update_model(sim, id_name=HAND, joint_index=joint_index)
+                    tq = np.array(c.action_to_torques(a.copy(), s == 0), dtype=np.float64)
+                    ins.append(scene.record())
+                    acts.append(a)
+                    flags.append(s == 0)
+                    outs.append(tq)
+                    scene.advance()
+            k = "%s_%d" % (tname, si)
+            out[k + "_in"], out[k + "_act"] = np.array(ins), np.array(acts)
+            out[k + "_policy"], out[k + "_torque"] = np.array(flags), np.array(outs)
+            out[k + "_interp_steps"] = np.array(c.interpolation_steps)
+
+    # ---- FurnitureEnv._do_controller_step / _pre_action on a fake self -------------------------------------------------
+    TG = __import__("furniture.env.models.grippers.two_finger_gripper", fromlist=["TwoFingerGripper"])
+    for tname in ("position_orientation", "joint_velocity"):
+        scene = Scene(rng)
+        sim = FakeSim()
+        c = ctor[tname](**dict(params[tname]))
+        c.reset()
+        env = types.SimpleNamespace()
+        env._control_type = tname
+        env._agent_type = "Sawyer"
+        env._arms = ["right"]
+        env._move_speed = 0.1
+        env._control_timestep, env._model_timestep, env._cur_time = 0.02, 0.002, 0.0  # 10 substeps keep the fixture small
+        env.sim = sim
+        env.controller = {"right": c}
+        env.gripper = {"right": types.SimpleNamespace(dof=1, format_action=lambda a: TG.TwoFingerGripper.format_action(None, a))}
+        env._ref_joint_pos_indexes = {"right": joint_index}
+        env._ref_joint_vel_indexes = {"right": joint_index}
+        env._ref_gripper_joint_vel_indexes = {"right": [7, 8]}
+        env._pre_action = types.MethodType(F.FurnitureEnv._pre_action, env)
+        ctrls, biases, ins = [], [], []
+
+        def on_step():
+            ctrls.append(sim.data.ctrl.copy())
+            scene.advance()
+            scene.write(sim)
+            sim.data.qfrc_bias[:] = rng.uniform(-3, 3, NV)
+            biases.append(sim.data.qfrc_bias.copy())
+            ins.append(scene.record())
+
+        sim.on_step = on_step
+        scene.write(sim)
+        sim.data.qfrc_bias[:] = rng.uniform(-3, 3, NV)
+        bias0, in0 = sim.data.qfrc_bias.copy(), scene.record()
+        acts = []
+        for p in range(3):
+            a = rng.uniform(-1, 1, c.control_dim + 2)
+            a[c.control_dim] = -1.0 if a[c.control_dim] < 0 else 1.0  # grip already discretised by FurnitureSawyerEnv._step
+            acts.append(a.copy())
+            F.FurnitureEnv._do_controller_step(env, a)
+        k = "envstep_%s" % tname
+        out[k + "_act"], out[k + "_ctrl"] = np.array(acts), np.array(ctrls)
+        out[k + "_bias"], out[k + "_in"] = np.array([bias0] + biases), np.array([in0] + ins)
+        out[k + "_calls"] = np.array(sim.calls)
+        out[k + "_ctrlrange"] = sim.model.actuator_ctrlrange
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
