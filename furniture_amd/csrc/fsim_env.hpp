@@ -16,6 +16,7 @@
 #include "fsim_solver.hpp"
 #include "fsim_dense.hpp"
 #include "fsim_ctrl.hpp"
+#include "fsim_ik.hpp"
 
 struct EnvCfg {
   int dof_action, obs_dim, n_substeps, max_episode_steps, discrete_grip, rescale_actions, auto_align, auto_reset, has_recipe, agent;
@@ -27,6 +28,7 @@ struct EnvCfg {
   int dense, dense_nsub;
   const float *dense_coef, *dense_sub;
   int controller; // CK_* (fsim_ctrl.hpp): torque-level arm controller run before every physics substep, 0 = none
+  int ik;         // control_type "ik" (fsim_ik.hpp)
 };
 struct EnvIO {
   const float *action;
@@ -41,7 +43,7 @@ struct EnvIO {
 
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
-  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : 0));
+  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 ? EI_WORDS : 0)));
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
@@ -63,6 +65,8 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
     e.dof_action = (e.controller == CK_POS_ORI ? 6 : (e.controller == CK_POS ? 3 : 7)) + 2;
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
   }
+  e.ik = c.control_type == 7;
+  if (e.ik) { e.dof_action = 8; e.obs_dim = 7 * m.nparts + 15 * m.narm; } // furniture_sawyer.py:40-62
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
@@ -663,7 +667,7 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   for (int arm = 0; arm < m.narm; arm++) {
     const int njm = m.narmj / m.narm;
     // joint_pos / joint_vel are part of robot_ob for impedance / torque only (furniture_sawyer.py:112-124)
-    const int nj = cfg.controller ? 0 : njm;
+    const int nj = (cfg.controller || cfg.ik) ? 0 : njm;
     float *o = io.obs + base + (2 * nj + 15) * arm;
     for (int k = c.lane; k < nj; k += 64) {
       o[k] = L[ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
@@ -778,6 +782,7 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
   fs_forward(c);
   if (m.narm > 0) env_gravity_comp(c);
   for (int k = 0; k < 100; k++) fs_step(c);
+  if (cfg.ik) env_ik_sync(c); // furniture.py:1643-1650
   if (c.lane == 0) {
     env_next_subtask(c);
     if (cfg.dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
@@ -799,7 +804,19 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   // _before_step + action plumbing
   if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
   float connect = io.action[dof - 1];
-  if (cfg.controller) {
+  if (cfg.ik) {
+    // _do_ik_step (furniture.py:2911-2924): d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed in env_ik)
+    float *K = L + ly.env + E_GROUP + m.nparts;
+    if (c.lane < 7) {
+      float v;
+      if (c.lane == 0) v = -io.action[1] * cfg.move_speed;
+      else if (c.lane == 1) v = io.action[0] * cfg.move_speed;
+      else if (c.lane == 2) v = io.action[2] * cfg.move_speed;
+      else if (c.lane < 6) v = io.action[c.lane];
+      else { v = io.action[6]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
+      K[EI_ACT + c.lane] = v;
+    }
+  } else if (cfg.controller) {
     // FurnitureSawyerEnv._step discretises the grip (furniture_sawyer.py:72-74); _do_controller_step scales the first three
     // entries by move_speed and permutes them [-a1, a0, a2] whatever the controller kind (furniture.py:3069-3071)
     float *K = L + ly.env + E_GROUP + m.nparts;
@@ -847,6 +864,27 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     SYNC();
     fs_substeps(c, cfg.n_substeps, 0);
     env_stop_selected(c, 1.0f);
+  } else if (cfg.ik) {
+    SYNC();
+    // the hand pose _do_ik_step reads (gripper_pos for _bounded_d_pos): LDS does not survive the launch, so the body poses are
+    // recomputed at the current state (the reference reads the pass before the last integration: < 1 mm apart, and it only
+    // matters while the workspace bound is active)
+    fs_kinematics(c);
+    env_ik(c, cfg.rotate_speed);
+    const float *K = L + ly.env + E_GROUP + m.nparts;
+    for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions
+      // get_control's P controller (sawyer_ik_controller.py:75-84), then _setup_action on [velocities, gripper]
+      for (int u = c.lane; u < m.nu; u += 64) {
+        float a;
+        if (u < 7) a = fminf(fmaxf(-5.0f * (L[ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u]), -1.0f), 1.0f);
+        else { a = K[EI_ACT + 6]; if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f); if ((u - 7) & 1) a = -a; }
+        L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
+      }
+      SYNC();
+      env_gravity_comp(c);
+      fs_substeps(c, cfg.n_substeps, rep == 2 ? 2 : 0);
+      if (scal[SC_BAD] & 2) break;
+    }
   } else if (cfg.controller) {
     // _do_controller_step: sim.forward(), then n_substeps x (_pre_action, sim.step()); no _setup_action, so qfrc_applied keeps
     // the gravity compensation the reset left (furniture.py:1624-1632) on top of the qfrc_bias inside ctrl

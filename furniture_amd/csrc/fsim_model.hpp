@@ -58,6 +58,7 @@ struct DModel {
   const float *body_relpos, *body_relquat, *part_mass;
   const int *arm_qposadr, *arm_dofadr, *grip_qposadr, *grip_dofadr, *eef_siteid, *hand_body;
   const float *arm_initqpos, *grip_initqpos, *qpos0;
+  const float *ik_tab; // control_type "ik": URDF chain of the reference's IK controller, rest pose, base pose (fsim_ik.hpp IKT_*)
   const int *conn_siteid, *conn_partid, *conn_keya, *conn_keyb, *conn_nangle;
   const float *conn_angles;
   const int *part_site_adr, *part_site_num, *part_sites; // all sites living on each part body (bounding boxes)

@@ -48,7 +48,8 @@ DENSE_OVERRIDES = dict(max_episode_steps=150, control_type="impedance", furnitur
                        alignment_project_dist=0.0)
 
 # furniture.py:41-47 (NEW_CONTROLLERS) -> fsim_config_t.control_type: torque-level arm controllers run per physics substep
-CONTROLLER_CODES = {"position_orientation": 2, "position": 3, "joint_impedance": 4, "joint_velocity": 5, "joint_torque": 6}
+CONTROLLER_CODES = {"position_orientation": 2, "position": 3, "joint_impedance": 4, "joint_velocity": 5, "joint_torque": 6,
+                    "ik": 7}  # "ik" (the reference's default, furniture.py:2899-2991): batched DLS solver instead of pybullet
 
 GYM_IDS = {  # furniture/env/__init__.py:19-114
     "IKEACursor-v0": ("FurnitureCursorEnv", dict(furniture_id=0)),
@@ -187,9 +188,9 @@ class FurnitureBatchEnv:
             raise ValueError("unity / record_vid / visual_ob must be False: rendering is outside the accelerated hot path")
         if agent != "Cursor" and cfg.control_type != "impedance" and cfg.control_type not in CONTROLLER_CODES:
             raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
-                                      "controllers %s (ik needs pybullet; the reference's 'torque' path writes an 8-vector into "
-                                      "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
-        if cfg.control_type in CONTROLLER_CODES and (agent != "Sawyer" or dense):
+                                      "controllers / ik %s (the reference's 'torque' path writes an 8-vector into "
+                                      "a 9-actuator ctrl; 'ik_quaternion' is not built)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
+        if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and (agent != "Sawyer" or dense):
             raise NotImplementedError("the arm controllers are built for the Sawyer agent with the sparse reward")
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")

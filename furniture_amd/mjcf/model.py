@@ -222,6 +222,27 @@ def build_model(agent, furniture_name, control_type="impedance", assets_root=Non
     else:
         A["eef_siteid"] = np.zeros(0, np.int32)
         A["hand_bodyid"] = np.zeros(0, np.int32)
+    if agent == "Sawyer":
+        # IK controller tables (control_type "ik"): the pybullet URDF chain (controllers/sawyer_ik_controller.py:112-125), its rest
+        # pose (:196, :263) and the world pose of the MJCF body "base" (pose_in_base_from_name, furniture.py:3380-3396; the base
+        # has no joint above it, so the pose is static)
+        from .urdf_chain import load_chain
+        A.update(load_chain(os.path.join(assets_root, "bullet_data", "sawyer_description", "urdf", "sawyer_arm.urdf")))
+        A["ik_rest"] = np.array([0, -1.18, 0.00, 2.18, 0.00, 0.57, 3.3161])
+        from ..transform_utils import Quaternion
+        b = m.body_names.index("base")
+        pos, quat = np.zeros(3), Quaternion([1, 0, 0, 0])
+        chain = []
+        while b > 0:
+            chain.append(b)
+            b = int(m.body_parentid[b])
+        for b in reversed(chain):
+            pos = pos + quat.rotate(m.body_pos[b])
+            quat = quat * Quaternion(m.body_quat[b])
+        A["ik_base_pos"], A["ik_base_quat"] = np.asarray(pos, dtype=np.float64), np.array(list(quat), dtype=np.float64)
+        # one flat table for the device (csrc/fsim_ik.hpp IKT_*)
+        A["ik_table"] = np.concatenate([A["ik_joint_pos"].reshape(-1), A["ik_joint_quat"].reshape(-1), A["ik_eef_pos"], A["ik_rest"],
+                                        A["ik_base_pos"], A["ik_base_quat"]])
     if agent == "Cursor":
         A["cursor_bodyid"] = np.array([m.body_names.index("cursor0"), m.body_names.index("cursor1")], dtype=np.int32)
         A["cursor_geomid"] = np.array([m.geom_names.index("cursor0"), m.geom_names.index("cursor1")], dtype=np.int32)

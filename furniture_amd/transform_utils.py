@@ -275,3 +275,22 @@ def mat2quat(rmat):
     if q[0] < 0.0:
         q = -q
     return q[[1, 2, 3, 0]]
+
+
+def quat_inverse(q):
+    """xyzw; conjugate / |q|^2 (ref :112-119; doctest: quat_multiply(q, quat_inverse(q)) == [0, 0, 0, 1])."""
+    q = np.asarray(q, dtype=np.float64)
+    return np.array([-q[0], -q[1], -q[2], q[3]]) / np.dot(q, q)
+
+
+def quat2mat(quaternion):
+    """xyzw -> 3x3 (ref :207-229: float32 copy, normalised through sqrt(2 / n))."""
+    q = np.array(quaternion, dtype=np.float32, copy=True)[[3, 0, 1, 2]]
+    n = np.dot(q, q)
+    if n < np.finfo(float).eps * 4.0:
+        return np.identity(3)
+    q *= math.sqrt(2.0 / n)
+    q = np.outer(q, q)
+    return np.array([[1.0 - q[2, 2] - q[3, 3], q[1, 2] - q[3, 0], q[1, 3] + q[2, 0]],
+                     [q[1, 2] + q[3, 0], 1.0 - q[1, 1] - q[3, 3], q[2, 3] - q[1, 0]],
+                     [q[1, 3] - q[2, 0], q[2, 3] + q[1, 0], 1.0 - q[1, 1] - q[2, 2]]])

@@ -37,7 +37,10 @@ typedef struct fsim_config {
   int32_t control_type;       /* 0 impedance (velocity actuators), 1 torque (rejected), and the torque-level arm controllers of
                                  furniture/env/controllers/arm_controller.py run per physics substep (furniture.py:41-47, 3065-3093;
                                  Sawyer, motor-actuated model): 2 position_orientation, 3 position, 4 joint_impedance,
-                                 5 joint_velocity, 6 joint_torque.  Action = [arm command (6|3|7|7|7), grip, connect]. */
+                                 5 joint_velocity, 6 joint_torque.  Action = [arm command (6|3|7|7|7), grip, connect].
+                                 7 ik (furniture.py:2899-2991): action = [dpos 3, rotation 3 (deg / rotate_speed), grip, connect]; a batched
+                                 damped-least-squares solver stands in for pybullet.calculateInverseKinematics (parity unpinned),
+                                 3 closed-loop repeats of 50 substeps per step (action_repeat, furniture.py:172). */
   int32_t n_substeps;         /* int(control_timestep/model_timestep) = 50 (furniture.py:2878) */
   int32_t max_episode_steps;  /* config/furniture.py:163-168 */
   int32_t discrete_grip;      /* furniture_sawyer.py:72-74 */

@@ -111,7 +111,13 @@ class FurnitureEnvOracle:
         self._fail = False
         self._dense = None
         self._ctrl = None
-        if self.cfg.control_type != "impedance":
+        self._ik = self.cfg.control_type == "ik"
+        if self._ik:
+            from oracle import ik as IK
+            assert self.agent == "Sawyer"
+            self._IK = IK
+            self._action_repeat = 3  # furniture.py:172
+        elif self.cfg.control_type != "impedance":
             # _load_controller (F.py:1665-1704) builds one controller per arm at construction; controller.reset() runs only in
             # _reset_internal (F.py:1885-1887), i.e. on the FIRST reset -- the controller state survives later resets.
             from oracle import controllers as C
@@ -259,6 +265,11 @@ class FurnitureEnvOracle:
             self._gravity_comp()
         for _ in range(100):
             self._fs()
+        if self._ik:
+            # F.py:1643-1650: _initial_right_hand_quat = _right_hand_quat (xyzw, hand orientation in the robot base frame);
+            # controller.sync_state(): the IK target position := the IK chain's own forward kinematics at the current joints
+            self._initial_right_hand_quat = self._right_hand_quat()
+            self._ik_target_pos = self._IK.fk(m, sim.data.qpos[m.arm_qposadr])[0]
         self._get_next_subtask()
         # _after_reset
         self._episode_reward = 0
@@ -306,7 +317,7 @@ class FurnitureEnvOracle:
         for a in range(len(self.arms)):
             site = m.eef_siteid[a]
             velp, velr = self.sim.site_vel(site)
-            if getattr(self, "_ctrl", None) is None:  # joint_pos / joint_vel only for impedance / torque (furniture_sawyer.py:112-124)
+            if getattr(self, "_ctrl", None) is None and not getattr(self, "_ik", False):  # joint_pos / joint_vel only for impedance / torque (furniture_sawyer.py:112-124)
                 rs += [d.qpos[m.arm_qposadr[a * nj:(a + 1) * nj]], d.qvel[m.arm_dofadr[a * nj:(a + 1) * nj]]]
             rs += [d.qpos[m.grip_qposadr[2 * a:2 * a + 2]], d.site_xpos[site].copy(),
                    T.convert_quat(d.xquat[m.hand_bodyid[a]], to="xyzw"), velp, velr]
@@ -555,6 +566,39 @@ class FurnitureEnvOracle:
             self.reset()
             self._fail = True
 
+    def _right_hand_quat(self):
+        """F.py:3380-3427: mat2quat of the right_hand orientation in the frame of the body 'base' (data of the last forward pass)."""
+        m, d = self.m, self.sim.data
+        Rb = self._IK.q2m(np.asarray(m.ik_base_quat, float))
+        return T.mat2quat(Rb.T @ d.xmat[int(m.hand_bodyid[0])].reshape(3, 3))
+
+    def _do_ik_step(self, action):
+        """F.py:2899-2991 (Sawyer, control_type 'ik') over oracle/ik.py instead of pybullet.  Note the reference feeds the xyzw
+        quaternion `_initial_right_hand_quat` to euler_to_quat, whose pyquaternion reads it as wxyz (F.py:2917-2919): the same
+        functions are used here in the same way, so the commanded orientation is garbled identically."""
+        IK, m, d = self._IK, self.m, self.sim.data
+        action = np.array(action, dtype=float)
+        action[:3] = action[:3] * self.cfg.move_speed
+        action[:3] = [-action[1], action[0], action[2]]
+        gripper_pos = d.xpos[int(m.hand_bodyid[0])]
+        d_pos = np.clip(action[:3], np.array([-1.5, -1.5, 0.0]) - gripper_pos, np.array([1.5, 1.5, 1.5]) - gripper_pos)  # F.py:170-171, 1252-1258
+        self._initial_right_hand_quat = np.array(T.euler_to_quat(action[3:6] * self.cfg.rotate_speed, self._initial_right_hand_quat))
+        rhq = self._right_hand_quat()
+        d_quat = T.quat_multiply(T.quat_inverse(rhq), self._initial_right_hand_quat)
+        gripper_dis = action[-2]
+        rotation = T.quat2mat(T.quat_multiply(rhq, d_quat))                                  # _make_input (F.py:1332-1343)
+        # SawyerIKController.get_control -> joint_positions_for_eef_command (sawyer_ik_controller.py:51-88, 227-269)
+        self._ik_target_pos = self._ik_target_pos + d_pos * IK.USER_SENSITIVITY
+        target_R = rotation @ IK.rot_z(-np.pi / 2)
+        arm_q = m.arm_qposadr.astype(int)
+        self._ik_q_cmd = IK.solve(m, d.qpos[arm_q], self._ik_target_pos, target_R)
+        for i in range(self._action_repeat):
+            vel = IK.velocities(d.qpos[arm_q], self._ik_q_cmd)
+            ctrl = self._setup_action(np.concatenate([vel, [gripper_dis]]))
+            self._do_simulation(ctrl)
+            if self._fail:
+                break
+
     def _do_controller_step(self, action):
         """F.py:3065-3093 + _pre_action (F.py:1706-1759).  update_model (arm_controller.py:109-136) reads MuJoCo's memory as
         sim.step() left it: poses / Jacobian / mass matrix / qfrc_bias of the forward pass BEFORE the last integration, qpos and
@@ -591,7 +635,9 @@ class FurnitureEnvOracle:
             self._do_simulation(None)
         else:
             connect = a[-1]
-            if self._ctrl is not None:
+            if self._ik:
+                self._do_ik_step(a)
+            elif self._ctrl is not None:
                 self._do_controller_step(a)
             else:
                 ctrl = self._setup_action(a[:-1])

@@ -19,7 +19,7 @@ from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", list(CONTROLLER_CODES))
+@pytest.mark.parametrize("kind", C.TYPES)
 @pytest.mark.parametrize("keep_applied", [True, False])
 def test_controller_steps_match_oracle(kind, keep_applied):
     m = load_compiled("Sawyer", "table_lack_0825", kind)

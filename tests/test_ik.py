@@ -1,0 +1,137 @@
+"""control_type "ik" with a batched damped-least-squares solver in place of pybullet (PARITY UNPINNED for the solver:
+oracle/ik.py header).  CPU: the URDF chain the reference's IK runs on against the MJCF kinematics, solver properties, the env
+flow on the oracle.  GPU: the device IK stage + 3 x 50 substeps against the oracle env."""
+import numpy as np
+import pytest
+import torch
+
+from furniture_amd import transform_utils as T
+from furniture_amd.mjcf.model import load_compiled
+from oracle import ik as IK
+from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+from oracle.oracle_sim import OracleSim
+
+
+@pytest.fixture(scope="module")
+def model():
+    return load_compiled("Sawyer", "table_lack_0825")
+
+
+def test_urdf_chain_equals_mjcf_kinematics(model):
+    """pybullet's sawyer_arm.urdf (link 6 = right_l6) and the MJCF arm are the same chain: the reference relies on it when it turns
+    the commanded right_hand orientation by Rz(-90 deg) into a link-6 target (sawyer_ik_controller.py:248-258; MJCF right_hand =
+    right_l6 . Trans(0, 0, 0.0245) . Rz(+90 deg), robots/sawyer/robot.xml:113-119)."""
+    m = model
+    sim = OracleSim(m)
+    rng = np.random.RandomState(0)
+    Rb, pb, hb = IK.q2m(m.ik_base_quat), m.ik_base_pos, int(m.hand_bodyid[0])
+    for _ in range(5):
+        q = m.arm_initqpos + rng.uniform(-0.7, 0.7, 7)
+        sim.reset()
+        sim.data.qpos[m.arm_qposadr] = q
+        sim.forward()
+        p, R, _, _ = IK.fk(m, q)
+        hand_R = Rb.T @ sim.data.xmat[hb].reshape(3, 3)
+        l6_R = hand_R @ IK.rot_z(-np.pi / 2)
+        l6_p = Rb.T @ (sim.data.xpos[hb] - pb) - l6_R @ np.array([0, 0, 0.0245])
+        assert np.abs(l6_p + l6_R @ m.ik_eef_pos - p).max() < 1e-6   # end effector = CoM frame of right_l6 (getLinkState()[0])
+        assert np.abs(l6_R - R).max() < 1e-5                          # (the MJCF quaternion of right_hand is rounded to 6 digits)
+
+
+def test_solver_reaches_the_target_and_respects_limits(model):
+    m = model
+    rng = np.random.RandomState(1)
+    for _ in range(20):
+        q0 = m.arm_initqpos + rng.uniform(-0.3, 0.3, 7)
+        p0, R0, _, _ = IK.fk(m, q0)
+        tp = p0 + rng.uniform(-0.03, 0.03, 3)          # one env step moves the target by at most move_speed * 0.3
+        w = rng.uniform(-0.2, 0.2, 3)
+        tR = IK.q2m(np.concatenate([[1.0], 0.5 * w])) @ R0
+        q = IK.solve(m, q0, tp, tR)
+        p, R, _, _ = IK.fk(m, q)
+        assert np.abs(p - tp).max() < 1e-6 and np.abs(IK.rotvec(tR @ R.T)).max() < 1e-6
+        assert (q >= IK.IK_LOWER).all() and (q <= IK.IK_UPPER).all()
+        assert np.abs(q - q0).max() < 0.5               # a nearby solution, not a flip of the redundant arm
+    assert np.allclose(IK.velocities([0.0, 0.5, -0.5], [0.1, 0.0, 0.0]), [0.5, -1.0, 1.0])  # -5 (q - q_cmd), clipped to [-1, 1]
+
+
+def test_quaternion_helpers_doctests():
+    """transform_utils.py:112-119 (quat_inverse doctest) and quat2mat on a known rotation."""
+    rng = np.random.RandomState(2)
+    for _ in range(10):
+        q = rng.randn(4)
+        assert np.allclose(T.quat_multiply(q, T.quat_inverse(q)), [0, 0, 0, 1])
+    assert np.allclose(T.quat2mat([0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)]), IK.rot_z(np.pi / 2), atol=1e-6)
+
+
+def test_oracle_env_ik_step_moves_the_hand_where_commanded(model):
+    m = model
+    e = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123, control_type="ik"))
+    ob = e.reset()
+    assert ob["robot_ob"].shape == (15,)   # gripper_qpos 2, eef pos 3, quat 4, velp 3, velr 3 (furniture_sawyer.py:125-153)
+    hb = int(m.hand_bodyid[0])
+    p0 = e.sim.data.xpos[hb].copy()
+    quat0 = ob["robot_ob"][5:9].copy()
+    for _ in range(4):
+        a = np.zeros(8)
+        a[0], a[6] = 1.0, -1.0   # action x -> d_pos = move_speed * [-a1, a0, a2] in the base frame = +x in the world
+        ob, _, _, _ = e.step(a)
+    moved = e.sim.data.xpos[hb] - p0
+    assert 0.08 < moved[0] < 0.16 and abs(moved[1]) < 0.02 and abs(moved[2]) < 0.02  # 4 steps x 0.1 x user_sensitivity 0.3
+    assert min(np.abs(ob["robot_ob"][5:9] - quat0).max(), np.abs(ob["robot_ob"][5:9] + quat0).max()) < 0.1  # orientation held
+
+
+@pytest.mark.gpu
+def test_device_ik_env_matches_oracle(model):
+    from furniture_amd.sim import FSim, INFO_DIM, default_config
+    m, n = model, 2
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset, cfg.control_type = 150, 0, 7
+    sim = FSim(m, n, config=cfg)
+    assert sim.dof_action == 8 and sim.obs_dim == 7 * m.nparts + 15
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10, control_type="ik")) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    sim.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]),
+                         np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)  # fsim_ik.hpp EI_*
+    for i, e in enumerate(envs):
+        assert np.abs(obs[i].cpu().numpy() - e.flat_obs(obs_o[i])).max() < 1e-4
+        assert np.abs(blk[i, :3] - e._ik_target_pos).max() < 1e-5 and np.abs(blk[i, 3:7] - e._initial_right_hand_quat).max() < 1e-5
+    act = torch.zeros((n, 8), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    rng = np.random.RandomState(5)
+    for t in range(4):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        if t == 0:
+            a[:, 3:6] = 0
+        act.copy_(torch.as_tensor(a))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)   # one launch: IK solve + 3 x (P controller, 50 substeps)
+        sim.sync()
+        blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)
+        for i, e in enumerate(envs):
+            ob, r, d_, _ = e.step(a[i].astype(np.float64))
+            assert np.abs(obs[i].cpu().numpy() - e.flat_obs(ob)).max() < 2e-4
+            assert np.abs(blk[i, 7:14] - e._ik_q_cmd).max() < 1e-4        # commanded joint positions
+            assert np.abs(blk[i, :3] - e._ik_target_pos).max() < 1e-5 and np.abs(blk[i, 3:7] - e._initial_right_hand_quat).max() < 1e-5
+            assert abs(float(rew[i]) - r) < 1e-5 and bool(done[i]) == d_
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_default_gym_id_runs_with_ik():
+    """IKEASawyer-v0's defaults (control_type 'ik', swivel_chair_0700; furniture/env/__init__.py:33-43) now construct and step."""
+    from furniture_amd.envs import make
+    env = make("IKEASawyer-v0", unity=False, record_vid=False)
+    assert env.dof == 8
+    ob = env.reset()
+    assert ob["robot_ob"].shape == (15,)
+    ob, r, d, info = env.step(np.array([0.5, 0, 0, 0, 0, 0, -1, 0], dtype=np.float32))
+    assert np.isfinite(ob["robot_ob"]).all() and np.isfinite(ob["object_ob"]).all()
+    env.close()
