@@ -8,6 +8,10 @@ handle and HIP stream; the sub-batches' step kernels are enqueued back to back a
 wave-per-env kernel never sees divergent model sizes inside a launch (no per-lane padding of the physics state).  Only the
 observation slab is padded: rows are ``max_obs_dim`` wide, ``object_ob`` padded to the largest part count, which is the shape
 the RCCL all-gather to the learner moves (``furniture_amd/dist.py``).
+
+With four or more furniture models set ``GPU_MAX_HW_QUEUES`` >= 2 x models in the environment BEFORE the first HIP call: with the
+runtime's default of 4 hardware queues four handles' step kernels ran two at a time (measured); three models
+overlap fine with the default.
 """
 
 from collections import OrderedDict
