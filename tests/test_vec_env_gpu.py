@@ -63,3 +63,35 @@ def test_full_state_snapshot_restores_the_trajectory_bit_exactly():
         assert np.array_equal(o1["object_ob"], o2["object_ob"]) and np.array_equal(o1["robot_ob"], o2["robot_ob"])
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and i1 == i2
     venv.close()
+
+
+@pytest.mark.parametrize("control_type", ["ik", "position_orientation", "joint_impedance"])
+def test_snapshot_replay_with_controller_state(control_type):
+    """The controller / IK bookkeeping (ramp step and goals; ik_robot_target_pos, _initial_right_hand_quat) lives in the env
+    record: a snapshot taken mid-episode replays the following steps bit for bit."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    import torch
+
+    n = 6
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type=control_type,
+                                                            furniture_name="table_lack_0825", max_episode_steps=50, seed=9), auto_reset=False)
+    env.reset()
+    rng = np.random.RandomState(2)
+    acts = rng.uniform(-1, 1, (6, n, env.dof)).astype(np.float32)
+    for t in range(2):
+        env.step(acts[t])
+    snap = {k: v.clone() for k, v in env.get_env_state().items()}
+
+    def run():
+        out = []
+        for t in range(2, 6):
+            ob, rew, done, _ = env.step(acts[t])
+            out.append((ob["object_ob"].clone(), ob["robot_ob"].clone(), rew.clone(), done.clone()))
+        return out
+
+    first = run()
+    env.set_env_state(snap)
+    second = run()
+    for a, b in zip(first, second):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    env.close()
