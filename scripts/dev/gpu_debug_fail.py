@@ -1,7 +1,7 @@
 """Find envs that go unstable on the GPU under random actions and replay them on the CPU oracle (development aid)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, default_config, INFO_DIM

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, default_config, INFO_DIM

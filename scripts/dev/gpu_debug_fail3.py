@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["FSIM_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "furniture_amd", "csrc", "libfsim_prof.so")
 import torch
 from furniture_amd.mjcf.model import load_compiled
