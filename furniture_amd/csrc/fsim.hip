@@ -193,6 +193,8 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
+  hipStream_t queues[FSIM_N_QUEUES] = {nullptr, nullptr, nullptr, nullptr}; // [0] aliases `stream`; the others are created on first use
+  hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
   DModel m{};
   Layout ly{};
@@ -490,6 +492,8 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  for (int q = 1; q < FSIM_N_QUEUES; q++) if (s->queues[q]) { hipStreamSynchronize(s->queues[q]); hipStreamDestroy(s->queues[q]); }
+  if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -613,17 +617,23 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
     HIPCHK(hipMalloc(&s->d_tab_noise, (size_t)s->n_envs * nw * 4 + 16));
     s->n_noise = n_noise;
   }
+  if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+  // rows of envs that are not in flight: safe to write while other envs' step kernels run (asynchronous stepping)
   if (!mask) {
-    HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->stream));
-    if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise, robot_noise, (size_t)s->n_envs * nw * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->xfer));
+    if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise, robot_noise, (size_t)s->n_envs * nw * 4, hipMemcpyHostToDevice, s->xfer));
   } else {
-    for (int e = 0; e < s->n_envs; e++) {
-      if (!mask[e]) continue;
-      HIPCHK(hipMemcpyAsync(s->d_tab_parts + e * pw, part_qpos + e * pw, pw * 4, hipMemcpyHostToDevice, s->stream));
-      if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise + e * nw, robot_noise + e * nw, nw * 4, hipMemcpyHostToDevice, s->stream));
+    for (int e = 0; e < s->n_envs;) { // one copy per run of consecutive masked envs (a full-batch reset is a single run)
+      if (!mask[e]) { e++; continue; }
+      int e1 = e;
+      while (e1 < s->n_envs && mask[e1]) e1++;
+      size_t cnt = (size_t)(e1 - e);
+      HIPCHK(hipMemcpyAsync(s->d_tab_parts + e * pw, part_qpos + e * pw, cnt * pw * 4, hipMemcpyHostToDevice, s->xfer));
+      if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise + e * nw, robot_noise + e * nw, cnt * nw * 4, hipMemcpyHostToDevice, s->xfer));
+      e = e1;
     }
   }
-  HIPCHK(hipStreamSynchronize(s->stream)); // host buffers may be reused by the caller right away
+  HIPCHK(hipStreamSynchronize(s->xfer)); // host buffers may be reused by the caller right away
   return FSIM_OK;
 }
 
@@ -730,6 +740,47 @@ extern "C" int fsim_step(fsim_t *s, const float *action, float *obs, float *rewa
   if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step: auto_reset needs fsim_set_reset_tables");
   if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step: dense_reward needs fsim_set_dense_reward first");
   return launch_env(s, action, obs, reward, done, info, nullptr, 1);
+}
+static int get_queue(fsim *s, int queue, hipStream_t *out) {
+  if (queue < 0 || queue >= FSIM_N_QUEUES) FAIL(FSIM_EINVAL, "queue %d out of range (FSIM_N_QUEUES = %d)", queue, FSIM_N_QUEUES);
+  HIPCHK(hipSetDevice(s->device));
+  if (queue == 0) { *out = s->stream; return FSIM_OK; }
+  if (!s->queues[queue]) HIPCHK(hipStreamCreateWithFlags(&s->queues[queue], hipStreamNonBlocking));
+  *out = s->queues[queue];
+  return FSIM_OK;
+}
+extern "C" int fsim_step_subset(fsim_t *s, int queue, const int32_t *env_ids, int n_ids, const float *action, float *obs, float *reward,
+                                uint8_t *done, int32_t *info, int32_t *cost_keys) {
+  if (!s || !action || !env_ids) FAIL(FSIM_EINVAL, "fsim_step_subset: null handle/action/env_ids");
+  if (n_ids < 0 || n_ids > s->n_envs) FAIL(FSIM_EINVAL, "fsim_step_subset: n_ids %d out of range", n_ids);
+  if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step_subset: auto_reset needs fsim_set_reset_tables");
+  if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step_subset: dense_reward needs fsim_set_dense_reward first");
+  hipStream_t st;
+  if (int rc = get_queue(s, queue, &st)) return rc;
+  if (n_ids == 0) return FSIM_OK;
+  KParams kp = kparams(s, s->cfg.n_substeps, 0);
+  kp.n_envs = n_ids; // grid size; blockIdx -> env through env_ids (the caller lists predicted-expensive envs first)
+  hipLaunchKernelGGL(k_env_step, dim3(n_ids), dim3(64), s->lds_bytes, st, s->d_m, s->d_ly, kp, s->ecfg, s->d_state, action, obs, reward, done, info,
+                     s->d_tab_parts, s->d_tab_noise, s->n_noise, nullptr, 1, reinterpret_cast<int *>(s->d_aux), env_ids, cost_keys ? cost_keys : s->d_cost);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step (subset) launch: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+extern "C" int fsim_queue_query(fsim_t *s, int queue) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  hipStream_t st;
+  if (int rc = get_queue(s, queue, &st)) return rc;
+  hipError_t e = hipStreamQuery(st);
+  if (e == hipSuccess) return 0;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+  FAIL(FSIM_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+}
+extern "C" int fsim_queue_sync(fsim_t *s, int queue) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  hipStream_t st;
+  if (int rc = get_queue(s, queue, &st)) return rc;
+  HIPCHK(hipStreamSynchronize(st));
+  return FSIM_OK;
 }
 extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {
   if (!s) FAIL(FSIM_EINVAL, "null");

@@ -260,8 +260,8 @@ class FurnitureBatchEnv:
     def reset(self):
         self._refill()
         self.sim.reset(None, self._obs)
+        self.sim.sync()  # the reset kernel reads the tables: the next ones may only be uploaded once it has finished
         self._refill()  # tables for the first auto-reset
-        self.sim.sync()
         return self._split(self._obs)
 
     def step_async(self, actions):

@@ -95,6 +95,9 @@ def lib():
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
+        L.fsim_step_subset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+        L.fsim_queue_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.fsim_queue_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.fsim_dense_replay.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
@@ -107,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
-    "fsim_env_block_words",
+    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync",
 ]
 
 
@@ -247,6 +250,20 @@ class FSim:
 
     def step(self, action, obs, reward, done, info):
         self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
+
+    # -- asynchronous stepping (include/fsim.h: fsim_step_subset) ----------------------------------------
+    def step_subset(self, queue, env_ids, n_ids, action, obs, reward, done, info, cost_keys=None):
+        self._chk(lib().fsim_step_subset(self._h, int(queue), env_ids.data_ptr(), int(n_ids), action.data_ptr(), obs.data_ptr(), reward.data_ptr(),
+                                         done.data_ptr(), info.data_ptr(), None if cost_keys is None else cost_keys.data_ptr()))
+
+    def queue_busy(self, queue):
+        rc = lib().fsim_queue_query(self._h, int(queue))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
+    def queue_sync(self, queue):
+        self._chk(lib().fsim_queue_sync(self._h, int(queue)))
 
     def kernel_time_ms(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()

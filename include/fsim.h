@@ -110,7 +110,9 @@ int fsim_env_block_words(const fsim_t *);
 /* Initial placements for the next reset of each env: part poses [n, nparts*7] (pos, quat wxyz) as drawn by
  * the reference's UniformRandomSampler (tasks/placement_sampler.py:138-190) and robot joint noise
  * [n, n_noise, narmjoints] as drawn by _initialize_robot_pos (furniture.py:1761-1779), n_noise = 101.
- * Host pointers; copied asynchronously.  mask: host uint8 [n] or NULL = all. */
+ * Host pointers; copied on a transfer stream of the handle and complete on return.  mask: host uint8 [n] or NULL = all.  The rows
+ * written must not belong to envs with a reset / step in flight (the kernels read the tables); rows of idle envs may be
+ * replaced while other envs are being stepped (asynchronous stepping). */
 int fsim_set_reset_tables(fsim_t *, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise);
 
 /* FurnitureEnv.reset() on the masked envs (device uint8 mask or NULL = all); writes obs if non-NULL. */
@@ -120,6 +122,20 @@ int fsim_reset(fsim_t *, const uint8_t *mask_dev, float *obs_dev);
  * reward [n] float32, done [n] uint8, info [n, info_dim] int32/float bits -- all device pointers.
  * info columns: see FSIM_INFO_* below. */
 int fsim_step(fsim_t *, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev, int32_t *info_dev);
+
+/* Asynchronous stepping (EnvPool-style send / recv): FurnitureEnv.step(action) on the listed envs only.  env_ids: device int32
+ * [n_ids], distinct; every other argument as in fsim_step (full-size [n, ...] buffers indexed by env id -- rows of envs that are
+ * not listed are not touched).  queue selects one of FSIM_N_QUEUES HIP streams of the handle (0 = the stream of fsim_step /
+ * fsim_stream), so that batches of DIFFERENT envs can be in flight at the same time; the caller must not list an env that is still
+ * in flight on another queue.  cost_keys (device int32 [n], or NULL): per-env scheduler key written by the step -- shader time
+ * of the step >> 10, bit 30 = a robot hand is within 10 cm of a part (likely to couple next), -1 = the env will hit its time
+ * limit (and reset inside the launch) next step -- the information a host scheduler needs to batch envs by predicted cost.
+ * Envs are independent: stepping them in subsets, in any order, yields bit-identical per-env trajectories. */
+#define FSIM_N_QUEUES 4
+int fsim_step_subset(fsim_t *, int queue, const int32_t *env_ids_dev, int n_ids, const float *action_dev, float *obs_dev,
+                     float *reward_dev, uint8_t *done_dev, int32_t *info_dev, int32_t *cost_keys_dev);
+int fsim_queue_query(fsim_t *, int queue); /* 0: everything enqueued on the queue has finished, 1: still running, < 0: error */
+int fsim_queue_sync(fsim_t *, int queue);
 
 enum {
   FSIM_INFO_NUM_CONNECTED = 0, FSIM_INFO_SUCCESS = 1, FSIM_INFO_FAIL = 2, FSIM_INFO_LAST_SITE1 = 3,
