@@ -292,47 +292,77 @@ DEV int fs_cone(const float *jar, float Dn, float Dt, float fri, float *f, float
   return 2;
 }
 
-// constraint cost at jar + alpha*jp, and the first/second directional derivatives along jp
-DEV void fs_line_eval(const Ctx &c, float alpha, float *cost, float *d1, float *d2) {
+// Directional derivatives of the elliptic contact cost along jp at jar (what the line search needs), without forming the 3x3
+// cone Hessian: with N = mu jar0, U = fri (jar1, jar2), T = |U| and primes for d/dalpha,
+//   top zone:    0;   bottom zone: quadratic in jar;   middle zone: cost = Dm/2 (N - mu T)^2,
+//   d1 = Dm (N - mu T)(N' - mu T'),  d2 = Dm (N' - mu T')^2 - Dm (N - mu T) mu T'',  T' = U.U'/T,  T'' = (|U'|^2 - T'^2)/T.
+// Identical (up to rounding) to contracting fs_cone's force / Hessian with jp, at a third of the instructions.
+DEV void fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, float fri, float *d1, float *d2) {
+  float mu = fri * sqrtf(Dn / Dt);
+  float U1 = jar[1] * fri, U2 = jar[2] * fri;
+  float N = jar[0] * mu, T = sqrtf(U1 * U1 + U2 * U2);
+  if (N >= mu * T || (T <= 0 && N >= 0)) { *d1 = 0; *d2 = 0; return; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    *d1 = Dn * jar[0] * jp[0] + Dt * (jar[1] * jp[1] + jar[2] * jp[2]);
+    *d2 = Dn * jp[0] * jp[0] + Dt * (jp[1] * jp[1] + jp[2] * jp[2]);
+    return;
+  }
+  float Dm = Dn / fmaxf(mu * mu * (1 + mu * mu), 1e-15f), NT = N - mu * T;
+  float V1 = jp[1] * fri, V2 = jp[2] * fri, rT = 1.0f / T;
+  float Tp = (U1 * V1 + U2 * V2) * rT, Np = jp[0] * mu;
+  float Tpp = (V1 * V1 + V2 * V2 - Tp * Tp) * rT;
+  float w = Np - mu * Tp;
+  *d1 = Dm * NT * w;
+  *d2 = Dm * w * w - Dm * NT * mu * Tpp;
+}
+
+// first / second directional derivatives of the constraint cost along jp at jar + alpha*jp
+DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
   CModel &m = c.m;
   CLayout &ly = c.ly;
   float *L = c.L;
   int nslot = c.I(ly.scal)[SC_NSLOT];
-  float cs = 0, a1 = 0, a2 = 0;
+  float a1 = 0, a2 = 0;
   for (int s = c.lane; s < nslot; s += 64) {
     float *r = L + ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     if (ri[C_DIM] == 1) {
       float j = r[C_JAR] + alpha * r[C_JP];
-      if (j < 0) { cs += 0.5f * r[C_DN] * j * j; a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; }
+      if (j < 0) { a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; }
       continue;
     }
+#ifdef FSIM_LS_FULLCONE
     float jar[3], f[3], H[9], cc;
     for (int a = 0; a < 3; a++) jar[a] = r[C_JAR + a] + alpha * r[C_JP + a];
     int st = fs_cone(jar, r[C_DN], r[C_DT], r[C_MU], f, &cc, H);
     if (!st) continue;
-    cs += cc;
     for (int a = 0; a < 3; a++) {
       a1 -= f[a] * r[C_JP + a];
       for (int b = 0; b < 3; b++) a2 += H[3 * a + b] * r[C_JP + a] * r[C_JP + b];
     }
+#else
+    float jar[3], jp[3], e1, e2;
+    for (int a = 0; a < 3; a++) { jp[a] = r[C_JP + a]; jar[a] = r[C_JAR + a] + alpha * jp[a]; }
+    fs_cone_dir(jar, jp, r[C_DN], r[C_DT], r[C_MU], &e1, &e2);
+    a1 += e1; a2 += e2;
+#endif
   }
   for (int s = c.lane; s < 2 * m.nlim; s += 64) {
     float *r = L + ly.lim + FSIM_LIMW * s;
     if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
     float j = r[LM_JAR] + alpha * r[LM_JP];
-    if (j < 0) { cs += 0.5f * r[LM_D] * j * j; a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; }
+    if (j < 0) { a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; }
   }
   for (int e = c.lane; e < m.neq; e += 64) {
     float *r = L + ly.weld + FSIM_WELDW * e;
     if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
     for (int q = 0; q < 6; q++) {
       float j = r[WD_JAR + q] + alpha * r[WD_JP + q], D = r[WD_D + q];
-      cs += 0.5f * D * j * j; a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
+      a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
     }
   }
-  *cost = wave_sum(cs); *d1 = wave_sum(a1); *d2 = wave_sum(a2);
+  *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
 DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
@@ -802,17 +832,6 @@ DEV float fs_dotv(const Ctx &c, int a, int b) {
   return wave_sum(s);
 }
 
-// total cost at the current (x, Mx, jar)
-DEV float fs_total_cost(const Ctx &c) {
-  CLayout &ly = c.ly;
-  float g = 0;
-  for (int d = c.lane; d < c.m.nv; d += 64) g += c.L[ly.x + d] * (0.5f * c.L[ly.Mx + d] - c.L[ly.smooth + d]);
-  g = wave_sum(g);
-  float cs, d1, d2;
-  fs_line_eval(c, 0.0f, &cs, &d1, &d2);
-  return g + cs;
-}
-
 // Solve for qacc (ly.x) and M*qacc (ly.Mx).
 #ifdef FSIM_PROFILE
 #define FS_SPROF(slot) do { long long t1s_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16 + slot] += (int)((t1s_ - t0s_) >> 4); t0s_ = t1s_; } while (0)
@@ -865,8 +884,11 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     // exact line search: safeguarded Newton on phi'(alpha)
     float lo = 0, hi = -1, alpha = 1, best = 0;
     for (int ls = 0; ls < 20; ls++) {
-      float cc, d1, d2;
-      fs_line_eval(c, alpha, &cc, &d1, &d2);
+      float d1, d2;
+      fs_line_eval(c, alpha, &d1, &d2);
+#ifdef FSIM_PROFILE
+      if (c.lane == 0) { scal[16 + 13] += 1; }
+#endif
       d1 += pg0 + alpha * pMp;
       d2 += pMp;
       best = alpha;
@@ -879,6 +901,9 @@ DEV void fs_solve(const Ctx &c, int coupled) {
       alpha = na;
     }
     alpha = best;
+#ifdef FSIM_PROFILE
+    if (c.lane == 0) { scal[16 + 14] += 1; }
+#endif
     FS_SPROF(27);
 #ifdef FSIM_PROFILE
     if (!isfinite(alpha) && c.lane == 0 && !scal[27]) { scal[27] = 400 + it; scal[28] = scal[21]; }

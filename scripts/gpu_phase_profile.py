@@ -37,6 +37,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         med = np.median(fine, axis=0) / 50
         print("    per-substep kcycles (median env): " + " ".join("%s %.1f" % (n, v / 1e3) for n, v in zip(fn, med)) + " | collide %.1f (geom %.1f broad %.1f narrow %.1f) constraints %.1f" % (np.median(cyc[:, 1]) / 50e3, np.median(cfine[:, 0]) / 50e3, np.median(cfine[:, 1]) / 50e3, np.median(cfine[:, 2]) / 50e3, np.median(cyc[:, 3]) / 50e3))
     if t == 5:
+        print("    line search: evaluations per Newton iteration: all envs %.2f, slow (top 64) %.2f" % (
+            pall[:, 13].sum() / max(1, pall[:, 14].sum()), pall[np.argsort(-tot)[:64], 13].sum() / max(1, pall[np.argsort(-tot)[:64], 14].sum())))
         for e in np.argsort(-tot)[:3]:
             print("    SLOW env %d: Mcyc %.1f it/sub %.2f coupled %.2f | per-substep kcyc: " % (e, tot[e] / 1e6, nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e])) + " ".join("%s %.1f" % (n, v / 50e3) for n, v in zip(fn, fine[e])) + " | collide %.1f constraints %.1f" % (cyc[e, 1] / 50e3, cyc[e, 3] / 50e3))
     if t == 5:
