@@ -650,6 +650,10 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   CModel &m = c.m;
   CLayout &ly = c.ly;
   const float *L = c.L;
+  if (io.info && c.lane == 0) { // the subtask of the state being observed (after an in-kernel auto-reset: the new episode's)
+    io.info[FSIM_INFO_SUBTASK1] = c.I(ly.env)[E_SUBTASK1];
+    io.info[FSIM_INFO_SUBTASK2] = c.I(ly.env)[E_SUBTASK2];
+  }
   // object_ob: body xpos/xquat of every part as left by the last forward pass
   for (int i = c.lane; i < 7 * m.nparts; i += 64) {
     int p = i / 7, k = i % 7, b = GP(m.part_rbody)[p];

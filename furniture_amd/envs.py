@@ -22,7 +22,7 @@ from . import transform_utils as T
 from .mjcf.model import load_compiled
 from .dense import DENSE_COEF_DEFAULTS, pack_dense
 from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DENSE_PHASE, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
-                  INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUCCESS, N_NOISE, default_config)
+                  INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUBTASK1, INFO_SUCCESS, N_NOISE, default_config)
 
 # furniture/config/furniture.py defaults that matter on the hot path (file:line in the reference)
 DEFAULTS = dict(
@@ -240,16 +240,45 @@ class FurnitureBatchEnv:
 
     @property
     def observation_space(self):
-        return spaces.Dict([("object_ob", spaces.Box(-np.inf, np.inf, shape=(7 * self.n_obj,))),
-                            ("robot_ob", spaces.Box(-np.inf, np.inf, shape=(self.sim.obs_dim - 7 * self.n_obj,)))])
+        """furniture.py:215-252 (+ the agent's robot_ob): object_ob holds every part, or only the two parts of the current subtask
+        when object_ob_all is False; subtask_ob adds their (1-based) part ids."""
+        cfg, sp = self.config, []
+        if getattr(cfg, "object_ob", True):
+            sp.append(("object_ob", spaces.Box(-np.inf, np.inf, shape=(7 * self.n_obj if getattr(cfg, "object_ob_all", True) else 14,))))
+        if getattr(cfg, "subtask_ob", False):
+            sp.append(("subtask_ob", spaces.Box(0.0, float(self.n_obj), shape=(2,))))
+        if getattr(cfg, "robot_ob", True):
+            sp.append(("robot_ob", spaces.Box(-np.inf, np.inf, shape=(self.sim.obs_dim - 7 * self.n_obj,))))
+        return spaces.Dict(sp)
 
     @property
     def action_space(self):
         return spaces.Dict([("default", spaces.Box(-1, 1, shape=(self.dof,), dtype=np.float32))])
 
-    def _split(self, flat):
-        k = 7 * self.n_obj
-        return OrderedDict([("object_ob", flat[:, :k]), ("robot_ob", flat[:, k:])])
+    def _split(self, flat, subtask=None):
+        """flat device slab -> the reference's observation dict (furniture.py:1344-1387).  subtask: [n, 2] int tensor of
+        (_subtask_part1, _subtask_part2) for the observed state, None right after a reset (then it is the first weld of the model
+        whose parts are not connected yet, i.e. weld 0: furniture.py:2723-2736)."""
+        cfg, torch = self.config, self.sim.torch
+        k, n = 7 * self.n_obj, flat.shape[0]
+        all_parts, want_sub = getattr(cfg, "object_ob_all", True), getattr(cfg, "subtask_ob", False)
+        if (not all_parts or want_sub) and subtask is None:
+            first = (int(self.model.eq_part1[0]), int(self.model.eq_part2[0])) if self.model.neq else (-1, -1)
+            subtask = torch.tensor([first], dtype=torch.int64, device=flat.device).expand(n, 2)
+        out = OrderedDict()
+        if getattr(cfg, "object_ob", True):
+            if all_parts:
+                out["object_ob"] = flat[:, :k]
+            else:  # parts are visited in index order and kept if they are one of the two; no subtask left -> a 14-zero dummy
+                idx, _ = torch.sort(subtask.long(), dim=1)
+                parts = flat[:, :k].reshape(n, self.n_obj, 7)
+                sel = parts.gather(1, idx.clamp(min=0)[:, :, None].expand(-1, -1, 7)).reshape(n, 14)
+                out["object_ob"] = torch.where((subtask[:, :1] >= 0).expand(-1, 14), sel, torch.zeros_like(sel))
+        if want_sub:
+            out["subtask_ob"] = (subtask + 1).to(flat.dtype)
+        if getattr(cfg, "robot_ob", True):
+            out["robot_ob"] = flat[:, k:]
+        return out
 
     def _refill(self, mask=None):
         if getattr(self, "_table_queue", None) is None:
@@ -287,7 +316,7 @@ class FurnitureBatchEnv:
                      connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
         if self.dense:
             infos["phase_i"] = info[:, INFO_DENSE_PHASE]  # phase + 8 * subtask (furniture_sawyer_dense.py:347)
-        return self._split(self._obs), self._rew, self._done.bool(), infos
+        return self._split(self._obs, info[:, INFO_SUBTASK1:INFO_SUBTASK1 + 2]), self._rew, self._done.bool(), infos
 
     def step(self, actions):
         self.step_async(actions)

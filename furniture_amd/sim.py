@@ -16,7 +16,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 _LIBPATH = os.environ.get("FSIM_LIB", os.path.join(_CSRC, "libfsim.so"))
 _LIB = None
 
-INFO_DIM = 15
+INFO_DIM = 17
+INFO_SUBTASK1, INFO_SUBTASK2 = 15, 16
 INFO_DENSE_PHASE = 13
 INFO_EPISODE_REWARD_F = 14
 DENSE_STATEW = 27  # FSIM_DENSE_STATEW; ED_* of csrc/fsim_dense.hpp (subtask, phase, flags, fine-aligned, 4 x vec3, 11 prev values)

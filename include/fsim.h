@@ -148,7 +148,10 @@ enum {
                                  FSIM_INFO_SUCCESS_REWARD_F carries info["phase_bonus"] and the other *_F columns are 0 */
   FSIM_INFO_EPISODE_REWARD_F = 14, /* float bits: the episode's reward so far incl. this step (step_log["episode_reward"] at done,
                                       furniture.py:468-470) */
-  FSIM_INFO_DIM = 15
+  FSIM_INFO_SUBTASK1 = 15, FSIM_INFO_SUBTASK2 = 16, /* _subtask_part1 / _subtask_part2 of the state the returned observation describes
+                                                       (part indices, -1 = none; furniture.py:2723-2736) -- what object_ob_all=False
+                                                       and subtask_ob=True select / report (furniture.py:1360-1385) */
+  FSIM_INFO_DIM = 17
 };
 
 /* ---- dense-reward env (FurnitureSawyerDenseRewardEnv) -------------------------------------- */

@@ -303,10 +303,17 @@ class FurnitureEnvOracle:
         m, d = self.m, self.sim.data
         ob = {}
         obj = []
+        cfg = getattr(self, "cfg", None)
+        ob_all = getattr(cfg, "object_ob_all", True)
         for i in range(self.nparts):
-            b = m.part_bodyid[i]
-            obj += [d.xpos[b].copy(), d.xquat[b].copy()]
+            if ob_all or i in (self._subtask_part1, self._subtask_part2):   # F.py:1363-1372
+                b = m.part_bodyid[i]
+                obj += [d.xpos[b].copy(), d.xquat[b].copy()]
+        if not ob_all and self._subtask_part1 == -1:
+            obj.append(np.zeros(14))                                         # F.py:1374-1375
         ob["object_ob"] = np.concatenate(obj)
+        if getattr(cfg, "subtask_ob", False):                                # F.py:1382-1385
+            ob["subtask_ob"] = np.array([self._subtask_part1 + 1, self._subtask_part2 + 1])
         if self.agent == "Cursor":
             # furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
             ob["robot_ob"] = np.concatenate([self._cursor_pos(0), self._cursor_pos(1),
@@ -325,7 +332,7 @@ class FurnitureEnvOracle:
         return ob
 
     def flat_obs(self, ob):
-        return np.concatenate([ob["object_ob"], ob["robot_ob"]])
+        return np.concatenate([ob[k] for k in ("object_ob", "subtask_ob", "robot_ob") if k in ob])
 
     # ---- alignment / connect (F.py:847-1153) ------------------------------------------------
     def _is_aligned(self, k1, k2):
