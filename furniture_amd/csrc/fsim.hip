@@ -741,6 +741,11 @@ extern "C" int fsim_step(fsim_t *s, const float *action, float *obs, float *rewa
   if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step: dense_reward needs fsim_set_dense_reward first");
   return launch_env(s, action, obs, reward, done, info, nullptr, 1);
 }
+extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
+  if (!s || n <= 0) FAIL(FSIM_EINVAL, "fsim_set_max_episode_steps: bad arguments");
+  s->cfg.max_episode_steps = n; s->ecfg.max_episode_steps = n; // EnvCfg is passed by value with every launch
+  return FSIM_OK;
+}
 static int get_queue(fsim *s, int queue, hipStream_t *out) {
   if (queue < 0 || queue >= FSIM_N_QUEUES) FAIL(FSIM_EINVAL, "queue %d out of range (FSIM_N_QUEUES = %d)", queue, FSIM_N_QUEUES);
   HIPCHK(hipSetDevice(s->device));

@@ -322,6 +322,11 @@ class FurnitureBatchEnv:
         self.step_async(actions)
         return self.step_wait()
 
+    def set_max_episode_steps(self, max_episode_steps):
+        """furniture.py:312-313 (forwarded by FurnitureGym, furniture_gym.py:46-48)."""
+        self.config.max_episode_steps = int(max_episode_steps)
+        self.sim.set_max_episode_steps(max_episode_steps)
+
     def get_env_state(self):
         """Full snapshot (the reference's {qpos, qvel} plus the weld/mask/group state it omits)."""
         # every field of the per-env record: restoring it reproduces the trajectory bit for bit (qfrc_bias of the last forward
@@ -376,6 +381,17 @@ class _SingleEnv:
 
     def num_subtask(self):
         return self._b.n_obj - 1
+
+    def set_max_episode_steps(self, max_episode_steps):
+        self._max_episode_steps = int(max_episode_steps)
+        self._b.set_max_episode_steps(max_episode_steps)
+
+    def set_subtask(self, subtask, num_connects=None):
+        raise NotImplementedError("set_subtask (pre-assembled starts, furniture.py:204-207) is not part of the accelerated reset")
+
+    def set_init_qpos(self, init_qpos):
+        raise NotImplementedError("set_init_qpos (furniture.py:315-316, applied inside _reset) is not part of the accelerated reset; "
+                                  "use set_env_state after reset()")
 
     def _np(self, ob):
         return OrderedDict((k, v[0].double().cpu().numpy()) for k, v in ob.items())

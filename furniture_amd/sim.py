@@ -96,6 +96,7 @@ def lib():
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
+        L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_step_subset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
         L.fsim_queue_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_queue_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
-    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync",
+    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync", "fsim_set_max_episode_steps",
 ]
 
 
@@ -251,6 +252,10 @@ class FSim:
 
     def step(self, action, obs, reward, done, info):
         self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
+
+    def set_max_episode_steps(self, n):
+        self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))
+        self.cfg.max_episode_steps = int(n)
 
     # -- asynchronous stepping (include/fsim.h: fsim_step_subset) ----------------------------------------
     def step_subset(self, queue, env_ids, n_ids, action, obs, reward, done, info, cost_keys=None):

@@ -123,6 +123,9 @@ int fsim_reset(fsim_t *, const uint8_t *mask_dev, float *obs_dev);
  * info columns: see FSIM_INFO_* below. */
 int fsim_step(fsim_t *, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev, int32_t *info_dev);
 
+/* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
+int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);
+
 /* Asynchronous stepping (EnvPool-style send / recv): FurnitureEnv.step(action) on the listed envs only.  env_ids: device int32
  * [n_ids], distinct; every other argument as in fsim_step (full-size [n, ...] buffers indexed by env id -- rows of envs that are
  * not listed are not touched).  queue selects one of FSIM_N_QUEUES HIP streams of the handle (0 = the stream of fsim_step /

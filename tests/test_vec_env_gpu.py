@@ -95,3 +95,15 @@ def test_snapshot_replay_with_controller_state(control_type):
     for a, b in zip(first, second):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     env.close()
+
+
+def test_set_max_episode_steps_takes_effect():
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+    env = FurnitureSawyerEnv(make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50))
+    env.reset()
+    env.set_max_episode_steps(2)   # FurnitureGym.set_max_episode_steps (furniture_gym.py:46-48)
+    assert env.max_episode_steps == 2
+    _, _, d1, _ = env.step(np.zeros(9, np.float32))
+    _, _, d2, _ = env.step(np.zeros(9, np.float32))
+    assert (d1, d2) == (False, True)
+    env.close()
