@@ -279,8 +279,9 @@ def mat2quat(rmat):
 
 def quat_inverse(q):
     """xyzw; conjugate / |q|^2 (ref :112-119; doctest: quat_multiply(q, quat_inverse(q)) == [0, 0, 0, 1])."""
-    q = np.asarray(q, dtype=np.float64)
-    return np.array([-q[0], -q[1], -q[2], q[3]]) / np.dot(q, q)
+    q = np.asarray(q)
+    conj = np.array((-q[0], -q[1], -q[2], q[3]), dtype=np.float32)  # quat_conjugate down-casts to float32 (ref :99-109, SURVEY Q13)
+    return conj / np.dot(q, q)
 
 
 def quat2mat(quaternion):

@@ -60,7 +60,8 @@ def test_quaternion_helpers_doctests():
     rng = np.random.RandomState(2)
     for _ in range(10):
         q = rng.randn(4)
-        assert np.allclose(T.quat_multiply(q, T.quat_inverse(q)), [0, 0, 0, 1])
+        q /= np.linalg.norm(q)   # the doctest draws a unit quaternion; both functions round through float32
+        assert np.allclose(T.quat_multiply(q, T.quat_inverse(q)), [0, 0, 0, 1], atol=1e-6)
     assert np.allclose(T.quat2mat([0, 0, np.sin(np.pi / 4), np.cos(np.pi / 4)]), IK.rot_z(np.pi / 2), atol=1e-6)
 
 
