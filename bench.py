@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 ENVS_PER_GPU = 4096
 AGENT, FURNITURE = "Sawyer", "table_lack_0825"
 MAX_EPISODE_STEPS = 150
-SEED = 123
+SEED = int(os.environ.get("FSIM_BENCH_SEED", "123"))  # (development: workload-realisation noise; the benchmark seed is 123)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # SURVEY.md section 8(d), fused formulation, fp32: in = state 122 w + per-env mutable model 99 w + action 9 w,
 # out = state 122 w + mutable model 99 w + obs 64 w + reward/done/info ~8 w  -> 523 words per env-step

@@ -41,6 +41,26 @@ struct Emit {
     ri[C_G1] = cg1; ri[C_G2] = cg2;
     ri[C_ACTIVE] = 1;
   }
+  // Batched form for the closed-form primitives that know their contact count up front: ONE LDS atomic per pair instead of one
+  // per contact (a returning LDS atomic is ~100+ cycles of latency on the single wave's critical path), and the contacts of a
+  // pair end up contiguous, in the order MuJoCo lists them.  alloc() returns the first slot (or -1 if none fits) and clips n.
+  DEV int alloc(int &n) const {
+    int *scal_ = c.I(c.ly.scal);
+    int base = atomicAdd(&scal_[SC_NSLOT], n);
+    if (base + n > c.ly.ncon_max) { scal_[SC_OVERFLOW] |= 2; n = max(0, c.ly.ncon_max - base); }
+    return n > 0 ? base : -1;
+  }
+  DEV void write(int slot, float dist, V3 pos, V3 n) const {
+    float *r = c.L + c.ly.con + FSIM_CONW * slot;
+    int *ri = reinterpret_cast<int *>(r);
+    const bool ok = isfinite(dist) && isfinite(pos.x + pos.y + pos.z) && isfinite(n.x + n.y + n.z) && dot(n, n) >= 1e-12f;
+    stv3(r + C_POS, pos);
+    stv3(r + C_FRAME, ok ? n : v3(0, 0, 1));
+    r[C_DIST] = ok ? dist : 1.0f;
+    r[C_INCM] = margin - gap;
+    ri[C_G1] = cg1; ri[C_G2] = cg2;
+    ri[C_ACTIVE] = ok ? 1 : 0; // a degenerate result keeps its slot but never reaches the solver
+  }
 };
 
 // contact frame from the stored unit normal (mju_makeFrame convention: x = n, y = the world y (or z) axis made orthogonal
@@ -87,6 +107,7 @@ DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V
   V3 c0 = colv(bR, 0) * size.x, c1 = colv(bR, 1) * size.y, c2 = colv(bR, 2) * size.z;
   float a = dot(n, c0), b = dot(n, c1), cc = dot(n, c2);
   if (dist0 - fabsf(a) - fabsf(b) - fabsf(cc) > e.margin) return; // deepest corner still above the margin
+#ifdef FSIM_EMIT_PER_CONTACT
   int cnt = 0;
 #pragma unroll 1
   for (int i = 0; i < 8; i++) {
@@ -98,6 +119,31 @@ DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V
     e(cnt, d, cv - n * (0.5f * d) + bp, n);
     if (++cnt >= 4) return;
   }
+#else
+  // pass 1: which corners are kept (the first four, in corner order, that are below the margin and below the centre)
+  int keep = 0, cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float ld = ((i & 1) ? a : -a) + ((i & 2) ? b : -b) + ((i & 4) ? cc : -cc);
+    bool ok = !(dist0 + ld > e.margin || ld > 0) && cnt < 4;
+    keep |= ok ? (1 << i) : 0;
+    cnt += ok ? 1 : 0;
+  }
+  if (!cnt) return;
+  int nw = cnt;
+  const int base = e.alloc(nw);
+  if (base < 0) return;
+  // pass 2: one slot per kept corner
+  int k = 0;
+#pragma unroll 1
+  for (int mm = keep; mm && k < nw; mm &= mm - 1, k++) {
+    int i = __ffs(mm) - 1;
+    float sx = (i & 1) ? 1.0f : -1.0f, sy = (i & 2) ? 1.0f : -1.0f, sz_ = (i & 4) ? 1.0f : -1.0f;
+    float d = dist0 + sx * a + sy * b + sz_ * cc;
+    V3 cv = c0 * sx + c1 * sy + c2 * sz_;
+    e.write(base + k, d, cv - n * (0.5f * d) + bp, n);
+  }
+#endif
 }
 DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &cR, V3 size) {
   V3 n = colv(pR, 2), axis = colv(cR, 2);
