@@ -126,6 +126,7 @@ def main():
     slabs = []
     for g in range(G):
         sl = Slab()
+        sl.index = g
         sl.sim = FSim(m, ng, device=local, config=cfg)
         if args.dense:
             sl.sim.set_dense_reward(*pack_dense(m))
@@ -151,7 +152,7 @@ def main():
             return
         sl.sim.sync()
         sl.inflight = False
-        gather_observations(sl.obs, sl.rew, sl.done)  # RCCL all-gather of the observation slab to the learner
+        gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index)  # ONE RCCL all-gather per slab-step: obs | reward | done packed
         need = sl.info[:, INFO_NEEDS_TABLE]
         if bool(need.any()):  # host-side reference RNG stream for the envs that just consumed their reset table
             mask = need.bool().cpu().numpy()
