@@ -28,7 +28,7 @@ struct EnvCfg {
   int dense, dense_nsub;
   const float *dense_coef, *dense_sub;
   int controller; // CK_* (fsim_ctrl.hpp): torque-level arm controller run before every physics substep, 0 = none
-  int ik;         // control_type "ik" (fsim_ik.hpp)
+  int ik;         // 1: control_type "ik", 2: "ik_quaternion" (fsim_ik.hpp)
 };
 struct EnvIO {
   const float *action;
@@ -43,7 +43,7 @@ struct EnvIO {
 
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
-  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 ? EI_WORDS : 0)));
+  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 || c.control_type == 8 ? EI_WORDS : 0)));
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
@@ -65,8 +65,8 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
     e.dof_action = (e.controller == CK_POS_ORI ? 6 : (e.controller == CK_POS ? 3 : 7)) + 2;
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
   }
-  e.ik = c.control_type == 7;
-  if (e.ik) { e.dof_action = 8; e.obs_dim = 7 * m.nparts + 15 * m.narm; } // furniture_sawyer.py:40-62
+  e.ik = c.control_type == 7 ? 1 : (c.control_type == 8 ? 2 : 0);
+  if (e.ik) { e.dof_action = e.ik == 1 ? 8 : 9; e.obs_dim = 7 * m.nparts + 15 * m.narm; } // furniture_sawyer.py:40-62
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
@@ -811,13 +811,14 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   if (cfg.ik) {
     // _do_ik_step (furniture.py:2911-2924): d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed in env_ik)
     float *K = L + ly.env + E_GROUP + m.nparts;
-    if (c.lane < 7) {
+    const int ng = cfg.ik == 1 ? 6 : 7; // index of the grip entry: [dpos 3, rotation 3 | quaternion 4, grip, connect]
+    if (c.lane <= ng) {
       float v;
       if (c.lane == 0) v = -io.action[1] * cfg.move_speed;
       else if (c.lane == 1) v = io.action[0] * cfg.move_speed;
       else if (c.lane == 2) v = io.action[2] * cfg.move_speed;
-      else if (c.lane < 6) v = io.action[c.lane];
-      else { v = io.action[6]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
+      else if (c.lane < ng) v = io.action[c.lane];
+      else { v = io.action[ng]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
       K[EI_ACT + c.lane] = v;
     }
   } else if (cfg.controller) {
@@ -870,18 +871,14 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     env_stop_selected(c, 1.0f);
   } else if (cfg.ik) {
     SYNC();
-    // the hand pose _do_ik_step reads (gripper_pos for _bounded_d_pos): LDS does not survive the launch, so the body poses are
-    // recomputed at the current state (the reference reads the pass before the last integration: < 1 mm apart, and it only
-    // matters while the workspace bound is active)
-    fs_kinematics(c);
-    env_ik(c, cfg.rotate_speed);
+    env_ik(c, cfg.rotate_speed, cfg.ik);
     const float *K = L + ly.env + E_GROUP + m.nparts;
     for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions
       // get_control's P controller (sawyer_ik_controller.py:75-84), then _setup_action on [velocities, gripper]
       for (int u = c.lane; u < m.nu; u += 64) {
         float a;
         if (u < 7) a = fminf(fmaxf(-5.0f * (L[ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u]), -1.0f), 1.0f);
-        else { a = K[EI_ACT + 6]; if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f); if ((u - 7) & 1) a = -a; }
+        else { a = K[EI_ACT + (cfg.ik == 1 ? 6 : 7)]; if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f); if ((u - 7) & 1) a = -a; }
         L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
       }
       SYNC();
@@ -1013,5 +1010,6 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   SYNC();
   terminal = scal[14];
   if (terminal && cfg.auto_reset) env_reset(c, &cfg, &io); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
+  else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
   env_write_obs(c, cfg, io);
 }

@@ -13,7 +13,8 @@
 
 // per-env block after the group table (env_extra_words)
 enum { EI_TARGET = 0 /* ik_robot_target_pos, base frame */, EI_IQUAT = 3 /* _initial_right_hand_quat, raw 4 numbers */,
-       EI_QCMD = 7 /* commanded_joint_positions */, EI_ACT = 14 /* scaled+permuted d_pos (3), rotation action (3), grip */, EI_WORDS = 22 };
+       EI_QCMD = 7 /* commanded_joint_positions */, EI_ACT = 14 /* scaled+permuted d_pos (3), then ik: rotation action (3), grip | ik_quaternion: quaternion wxyz (4), grip */, EI_HPOS = 22 /* right_hand world position of the last forward pass (what the next step's _bounded_d_pos reads) */,
+       EI_WORDS = 26 };
 // m.ik_tab layout (floats): joint_pos 7x3 | joint_quat 7x4 (wxyz) | eef_pos 3 | rest 7 | base_pos 3 | base_quat 4
 enum { IKT_JPOS = 0, IKT_JQUAT = 21, IKT_EEF = 49, IKT_REST = 52, IKT_BPOS = 59, IKT_BQUAT = 62, IKT_WORDS = 66 };
 #define IK_ITERS 12
@@ -116,28 +117,57 @@ DEV void env_ik_sync(const Ctx &c) {
   if (c.lane == 0) {
     stv3(K + EI_TARGET, f.p); // ik_robot_target_pos := the IK chain's own end-effector position (sync_state :86-99)
     for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = iq[i];
+    stv3(K + EI_HPOS, hp);
+  }
+  SYNC();
+}
+
+// End of a step: what the NEXT _do_ik_step will read from sim.data before any new forward pass -- the hand position (for
+// _bounded_d_pos) and, for ik_quaternion, _right_hand_quat -- i.e. the poses of the last forward pass, one integration old.
+// LDS does not survive the launch, so they are kept in the env record.
+DEV void env_ik_remember(const Ctx &c, int mode) {
+  CModel &m = c.m;
+  float *K = c.L + c.ly.env + E_GROUP + m.nparts;
+  V3 hp; M3 hR;
+  ik_hand_world(c, &hp, &hR);
+  float rh[4];
+  ik_mat2quat_xyzw(mulm(ck_transpose(q2m(qnormalized(ldq(GP(m.ik_tab) + IKT_BQUAT)))), hR), rh);
+  if (c.lane == 0) {
+    stv3(K + EI_HPOS, hp);
+    if (mode == 2) for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = rh[i];
   }
   SYNC();
 }
 
 // get_control(dpos, rotation) (sawyer_ik_controller.py:51-88): new target, solve, store commanded_joint_positions
-__device__ __noinline__ void env_ik(Ctx cv, float rotate_speed) {
+__device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
   FS_REBUILD_CTX(cv);
   CModel &m = c.m;
   float *K = c.L + c.ly.env + E_GROUP + m.nparts;
-  V3 hp; M3 hR;
-  ik_hand_world(c, &hp, &hR);
+  const V3 hp = ldv3(K + EI_HPOS);
   // _bounded_d_pos (furniture.py:1252-1258, limits :170-171)
   V3 a = ldv3(K + EI_ACT);
   V3 dpos = v3(fminf(fmaxf(a.x, -1.5f - hp.x), 1.5f - hp.x), fminf(fmaxf(a.y, -1.5f - hp.y), 1.5f - hp.y), fminf(fmaxf(a.z, 0.0f - hp.z), 1.5f - hp.z));
+  Q4 qi = q4(K[EI_IQUAT], K[EI_IQUAT + 1], K[EI_IQUAT + 2], K[EI_IQUAT + 3]);
+  M3 rot;
+  if (mode == 2) {
+    // control_type "ik_quaternion" (furniture.py:2994-3030): the action carries a quaternion (wxyz, convert_quat -> xyzw) that
+    // _make_input composes with the CURRENT hand orientation: rotation = quat2mat(right_hand_quat (x) action_quat)
+    const float *rh = K + EI_IQUAT; // _right_hand_quat (xyzw) of the last forward pass (env_ik_remember)
+    Q4 q = qmul(q4(rh[3], rh[0], rh[1], rh[2]), q4(K[EI_ACT + 3], K[EI_ACT + 4], K[EI_ACT + 5], K[EI_ACT + 6]));
+    float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    if (n2 < 8.8817842e-16f) { for (int i = 0; i < 9; i++) rot.m[i] = (i & 3) == 0 ? 1.0f : 0.0f; } // quat2mat: n < eps * 4 -> identity
+    else rot = q2m(qnormalized(q));
+  } else {
   // _initial_right_hand_quat = euler_to_quat(action[3:6] * rotate_speed, _initial_right_hand_quat): pyquaternion reads the stored
   // 4 numbers (an xyzw quaternion from mat2quat) as wxyz -- reproduced as is (furniture.py:2917-2919, transform_utils.py:617-630)
   const float d2r = 0.017453292519943295f;
   Q4 qx = axisangle(v3(1, 0, 0), K[EI_ACT + 3] * rotate_speed * d2r), qy = axisangle(v3(0, 1, 0), K[EI_ACT + 4] * rotate_speed * d2r),
      qz = axisangle(v3(0, 0, 1), K[EI_ACT + 5] * rotate_speed * d2r);
-  Q4 qi = qmul(q4(K[EI_IQUAT], K[EI_IQUAT + 1], K[EI_IQUAT + 2], K[EI_IQUAT + 3]), qmul(qz, qmul(qy, qx)));
+  qi = qmul(qi, qmul(qz, qmul(qy, qx)));
   // rotation = quat2mat(right_hand_quat (x) (right_hand_quat^-1 (x) initial)) = quat2mat(initial), the 4 numbers read as xyzw
-  const M3 rot = q2m(qnormalized(q4(qi.z, qi.w, qi.x, qi.y))); // raw (r0, r1, r2, r3) as xyzw -> w = r3 (= qi.z), x = r0 (= qi.w) ...
+  rot = q2m(qnormalized(q4(qi.z, qi.w, qi.x, qi.y))); // raw (r0, r1, r2, r3) as xyzw -> w = r3 (= qi.z), x = r0 (= qi.w) ...
+  }
   // joint_positions_for_eef_command (:227-269): target += dpos * user_sensitivity; orientation . Rz(-90 deg)
   const V3 tp = ldv3(K + EI_TARGET) + dpos * 0.3f;
   M3 Zm; Zm.m[0] = 0; Zm.m[1] = 1; Zm.m[2] = 0; Zm.m[3] = -1; Zm.m[4] = 0; Zm.m[5] = 0; Zm.m[6] = 0; Zm.m[7] = 0; Zm.m[8] = 1; // Rz(-pi/2)
@@ -197,7 +227,7 @@ __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed) {
   }
   if (c.lane == 0) {
     stv3(K + EI_TARGET, tp);
-    K[EI_IQUAT] = qi.w; K[EI_IQUAT + 1] = qi.x; K[EI_IQUAT + 2] = qi.y; K[EI_IQUAT + 3] = qi.z;
+    if (mode != 2) { K[EI_IQUAT] = qi.w; K[EI_IQUAT + 1] = qi.x; K[EI_IQUAT + 2] = qi.y; K[EI_IQUAT + 3] = qi.z; }
 #pragma unroll
     for (int i = 0; i < 7; i++) K[EI_QCMD + i] = q[i];
   }

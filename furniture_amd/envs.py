@@ -49,7 +49,7 @@ DENSE_OVERRIDES = dict(max_episode_steps=150, control_type="impedance", furnitur
 
 # furniture.py:41-47 (NEW_CONTROLLERS) -> fsim_config_t.control_type: torque-level arm controllers run per physics substep
 CONTROLLER_CODES = {"position_orientation": 2, "position": 3, "joint_impedance": 4, "joint_velocity": 5, "joint_torque": 6,
-                    "ik": 7}  # "ik" (the reference's default, furniture.py:2899-2991): batched DLS solver instead of pybullet
+                    "ik": 7, "ik_quaternion": 8}  # "ik" (the reference's default, furniture.py:2899-2991): batched DLS solver instead of pybullet
 
 GYM_IDS = {  # furniture/env/__init__.py:19-114
     "IKEACursor-v0": ("FurnitureCursorEnv", dict(furniture_id=0)),
@@ -189,7 +189,7 @@ class FurnitureBatchEnv:
         if agent != "Cursor" and cfg.control_type != "impedance" and cfg.control_type not in CONTROLLER_CODES:
             raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
                                       "controllers / ik %s (the reference's 'torque' path writes an 8-vector into "
-                                      "a 9-actuator ctrl; 'ik_quaternion' is not built)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
+                                      "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
         if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and (agent != "Sawyer" or dense):
             raise NotImplementedError("the arm controllers are built for the Sawyer agent with the sparse reward")
         if cfg.furn_size_rand != 0:

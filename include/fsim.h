@@ -40,7 +40,9 @@ typedef struct fsim_config {
                                  5 joint_velocity, 6 joint_torque.  Action = [arm command (6|3|7|7|7), grip, connect].
                                  7 ik (furniture.py:2899-2991): action = [dpos 3, rotation 3 (deg / rotate_speed), grip, connect]; a batched
                                  damped-least-squares solver stands in for pybullet.calculateInverseKinematics (parity unpinned),
-                                 3 closed-loop repeats of 50 substeps per step (action_repeat, furniture.py:172). */
+                                 3 closed-loop repeats of 50 substeps per step (action_repeat, furniture.py:172).
+                                 8 ik_quaternion (furniture.py:2994-3063): action = [dpos 3, quaternion wxyz 4, grip, connect], the quaternion
+                                 is composed with the current hand orientation. */
   int32_t n_substeps;         /* int(control_timestep/model_timestep) = 50 (furniture.py:2878) */
   int32_t max_episode_steps;  /* config/furniture.py:163-168 */
   int32_t discrete_grip;      /* furniture_sawyer.py:72-74 */

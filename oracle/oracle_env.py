@@ -111,7 +111,7 @@ class FurnitureEnvOracle:
         self._fail = False
         self._dense = None
         self._ctrl = None
-        self._ik = self.cfg.control_type == "ik"
+        self._ik = self.cfg.control_type in ("ik", "ik_quaternion")
         if self._ik:
             from oracle import ik as IK
             assert self.agent == "Sawyer"
@@ -589,9 +589,12 @@ class FurnitureEnvOracle:
         action[:3] = [-action[1], action[0], action[2]]
         gripper_pos = d.xpos[int(m.hand_bodyid[0])]
         d_pos = np.clip(action[:3], np.array([-1.5, -1.5, 0.0]) - gripper_pos, np.array([1.5, 1.5, 1.5]) - gripper_pos)  # F.py:170-171, 1252-1258
-        self._initial_right_hand_quat = np.array(T.euler_to_quat(action[3:6] * self.cfg.rotate_speed, self._initial_right_hand_quat))
         rhq = self._right_hand_quat()
-        d_quat = T.quat_multiply(T.quat_inverse(rhq), self._initial_right_hand_quat)
+        if self.cfg.control_type == "ik_quaternion":   # F.py:2994-3030: the action's quaternion (wxyz) relative to the current hand
+            d_quat = T.convert_quat(action[3:7])
+        else:
+            self._initial_right_hand_quat = np.array(T.euler_to_quat(action[3:6] * self.cfg.rotate_speed, self._initial_right_hand_quat))
+            d_quat = T.quat_multiply(T.quat_inverse(rhq), self._initial_right_hand_quat)
         gripper_dis = action[-2]
         rotation = T.quat2mat(T.quat_multiply(rhq, d_quat))                                  # _make_input (F.py:1332-1343)
         # SawyerIKController.get_control -> joint_positions_for_eef_command (sawyer_ik_controller.py:51-88, 227-269)

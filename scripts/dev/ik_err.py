@@ -16,7 +16,7 @@ dev = sim.device
 obs = torch.zeros((n, sim.obs_dim), device=dev)
 sim.reset(None, obs); sim.sync()
 print("dof", sim.dof_action, "obs_dim", sim.obs_dim, "reset err", max(np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(obs_o[e])).max() for e in range(n)))
-blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)
+blk = sim.get_state("env_block")["env_block"][:, -26:].cpu().numpy().view(np.float32)
 for e in range(n):
     print(" target dev", blk[e, :3], "oracle", envs[e]._ik_target_pos, "iquat dev", blk[e, 3:7], "oracle", envs[e]._initial_right_hand_quat)
 dof = sim.dof_action
@@ -27,7 +27,7 @@ for t in range(5):
     if t < 2: a[:, 3:6] = 0
     act.copy_(torch.as_tensor(a)); torch.cuda.synchronize()
     sim.step(act, obs, rew, done, info); sim.sync()
-    blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)
+    blk = sim.get_state("env_block")["env_block"][:, -26:].cpu().numpy().view(np.float32)
     for e in range(n):
         ob, r, d_, _ = envs[e].step(a[e].astype(np.float64))
         d = np.abs(obs[e].cpu().numpy() - envs[e].flat_obs(ob))

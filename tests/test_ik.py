@@ -83,14 +83,16 @@ def test_oracle_env_ik_step_moves_the_hand_where_commanded(model):
 
 
 @pytest.mark.gpu
-def test_device_ik_env_matches_oracle(model):
+@pytest.mark.parametrize("ctype", ["ik", "ik_quaternion"])
+def test_device_ik_env_matches_oracle(model, ctype):
     from furniture_amd.sim import FSim, INFO_DIM, default_config
     m, n = model, 2
+    dof = 8 if ctype == "ik" else 9
     cfg = default_config()
-    cfg.max_episode_steps, cfg.auto_reset, cfg.control_type = 150, 0, 7
+    cfg.max_episode_steps, cfg.auto_reset, cfg.control_type = 150, 0, (7 if ctype == "ik" else 8)
     sim = FSim(m, n, config=cfg)
-    assert sim.dof_action == 8 and sim.obs_dim == 7 * m.nparts + 15
-    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10, control_type="ik")) for i in range(n)]
+    assert sim.dof_action == dof and sim.obs_dim == 7 * m.nparts + 15
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10, control_type=ctype)) for i in range(n)]
     obs_o = [e.reset() for e in envs]
     sim.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]),
                          np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
@@ -98,29 +100,34 @@ def test_device_ik_env_matches_oracle(model):
     obs = torch.zeros((n, sim.obs_dim), device=dev)
     sim.reset(None, obs)
     sim.sync()
-    blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)  # fsim_ik.hpp EI_*
+    blk = sim.get_state("env_block")["env_block"][:, -26:].cpu().numpy().view(np.float32)  # fsim_ik.hpp EI_*
     for i, e in enumerate(envs):
         assert np.abs(obs[i].cpu().numpy() - e.flat_obs(obs_o[i])).max() < 1e-4
         assert np.abs(blk[i, :3] - e._ik_target_pos).max() < 1e-5 and np.abs(blk[i, 3:7] - e._initial_right_hand_quat).max() < 1e-5
-    act = torch.zeros((n, 8), device=dev)
+    act = torch.zeros((n, dof), device=dev)
     rew = torch.zeros(n, device=dev)
     done = torch.zeros(n, dtype=torch.uint8, device=dev)
     info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
     rng = np.random.RandomState(5)
     for t in range(4):
-        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
-        if t == 0:
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
+        if ctype == "ik_quaternion":   # a small rotation relative to the current hand orientation (wxyz, not normalised)
+            a[:, 3] = 1.0
+            a[:, 4:7] *= 0.05
+        elif t == 0:
             a[:, 3:6] = 0
         act.copy_(torch.as_tensor(a))
         torch.cuda.synchronize()
         sim.step(act, obs, rew, done, info)   # one launch: IK solve + 3 x (P controller, 50 substeps)
         sim.sync()
-        blk = sim.get_state("env_block")["env_block"][:, -22:].cpu().numpy().view(np.float32)
+        blk = sim.get_state("env_block")["env_block"][:, -26:].cpu().numpy().view(np.float32)
         for i, e in enumerate(envs):
             ob, r, d_, _ = e.step(a[i].astype(np.float64))
             assert np.abs(obs[i].cpu().numpy() - e.flat_obs(ob)).max() < 2e-4
             assert np.abs(blk[i, 7:14] - e._ik_q_cmd).max() < 1e-4        # commanded joint positions
-            assert np.abs(blk[i, :3] - e._ik_target_pos).max() < 1e-5 and np.abs(blk[i, 3:7] - e._initial_right_hand_quat).max() < 1e-5
+            assert np.abs(blk[i, :3] - e._ik_target_pos).max() < 1e-5
+            if ctype == "ik":
+                assert np.abs(blk[i, 3:7] - e._initial_right_hand_quat).max() < 1e-5
             assert abs(float(rew[i]) - r) < 1e-5 and bool(done[i]) == d_
     sim.close()
 
