@@ -97,3 +97,24 @@ def rot_z(angle):
 def velocities(q, q_cmd):
     """get_control's P controller (:75-84)."""
     return np.clip(-5.0 * (np.asarray(q) - np.asarray(q_cmd)), -1.0, 1.0)
+
+
+def preprocess(control_type, action, move_speed, rotate_speed, hand_pos, right_hand_quat, initial_quat):
+    """FurnitureEnv._do_ik_step up to the controller call (furniture.py:2911-2924 for "ik", :2999-3027 for "ik_quaternion") and
+    _make_input (:1332-1343): -> (d_pos, rotation 3x3, new _initial_right_hand_quat, gripper action).  The reference hands the xyzw
+    quaternion _initial_right_hand_quat to euler_to_quat, whose pyquaternion reads it as wxyz: the same functions are used here in
+    the same way (pinned by tests/golden/controllers.npz, ikstep_*)."""
+    from furniture_amd import transform_utils as T
+    action = np.array(action, dtype=float)
+    action[:3] = action[:3] * move_speed
+    action[:3] = [-action[1], action[0], action[2]]
+    hand_pos = np.asarray(hand_pos, float)
+    d_pos = np.clip(action[:3], np.array([-1.5, -1.5, 0.0]) - hand_pos, np.array([1.5, 1.5, 1.5]) - hand_pos)  # :170-171, 1252-1258
+    if control_type == "ik_quaternion":
+        d_quat = T.convert_quat(action[3:7])
+        new_initial = np.asarray(initial_quat, float)
+    else:
+        new_initial = np.array(T.euler_to_quat(action[3:6] * rotate_speed, initial_quat))
+        d_quat = T.quat_multiply(T.quat_inverse(right_hand_quat), new_initial)
+    rotation = T.quat2mat(T.quat_multiply(right_hand_quat, d_quat))
+    return d_pos, rotation, new_initial, action[-2]

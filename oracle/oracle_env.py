@@ -584,19 +584,9 @@ class FurnitureEnvOracle:
         quaternion `_initial_right_hand_quat` to euler_to_quat, whose pyquaternion reads it as wxyz (F.py:2917-2919): the same
         functions are used here in the same way, so the commanded orientation is garbled identically."""
         IK, m, d = self._IK, self.m, self.sim.data
-        action = np.array(action, dtype=float)
-        action[:3] = action[:3] * self.cfg.move_speed
-        action[:3] = [-action[1], action[0], action[2]]
-        gripper_pos = d.xpos[int(m.hand_bodyid[0])]
-        d_pos = np.clip(action[:3], np.array([-1.5, -1.5, 0.0]) - gripper_pos, np.array([1.5, 1.5, 1.5]) - gripper_pos)  # F.py:170-171, 1252-1258
-        rhq = self._right_hand_quat()
-        if self.cfg.control_type == "ik_quaternion":   # F.py:2994-3030: the action's quaternion (wxyz) relative to the current hand
-            d_quat = T.convert_quat(action[3:7])
-        else:
-            self._initial_right_hand_quat = np.array(T.euler_to_quat(action[3:6] * self.cfg.rotate_speed, self._initial_right_hand_quat))
-            d_quat = T.quat_multiply(T.quat_inverse(rhq), self._initial_right_hand_quat)
-        gripper_dis = action[-2]
-        rotation = T.quat2mat(T.quat_multiply(rhq, d_quat))                                  # _make_input (F.py:1332-1343)
+        d_pos, rotation, self._initial_right_hand_quat, gripper_dis = IK.preprocess(
+            self.cfg.control_type, action, self.cfg.move_speed, self.cfg.rotate_speed, d.xpos[int(m.hand_bodyid[0])],
+            self._right_hand_quat(), self._initial_right_hand_quat)
         # SawyerIKController.get_control -> joint_positions_for_eef_command (sawyer_ik_controller.py:51-88, 227-269)
         self._ik_target_pos = self._ik_target_pos + d_pos * IK.USER_SENSITIVITY
         target_R = rotation @ IK.rot_z(-np.pi / 2)

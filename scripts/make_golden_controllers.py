@@ -228,6 +228,56 @@ def main():
         out[k + "_bias"], out[k + "_in"] = np.array([bias0] + biases), np.array([in0] + ins)
         out[k + "_calls"] = np.array(sim.calls)
         out[k + "_ctrlrange"] = sim.model.actuator_ctrlrange
+    # ---- FurnitureEnv._do_ik_step (furniture.py:2899-2991 / 2994-3063) on a fake self: what reaches the IK controller --------------
+    # pyquaternion is absent here: the reference's transform_utils gets furniture_amd.transform_utils.Quaternion (a restatement of
+    # pyquaternion's constructor / product / iteration semantics) under the name it imports, so that euler_to_quat is the
+    # reference's own code.  Pinned: action scaling + permutation, _bounded_d_pos, the accumulation of _initial_right_hand_quat
+    # (an xyzw quaternion handed to pyquaternion, which reads wxyz), d_quat, _make_input's rotation, the three closed-loop repeats.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from furniture_amd.transform_utils import Quaternion as OurQuaternion
+    import furniture.env.transform_utils as RT
+    RT.Quaternion = OurQuaternion
+    for ctype in ("ik", "ik_quaternion"):
+        rec = dict(act=[], hand_pos=[], rhq=[], init_in=[], dpos=[], rot=[], init_out=[], low=[], nsim=[])
+        for t in range(24):
+            env = types.SimpleNamespace()
+            env._control_type, env._agent_type, env._arms = ctype, "Sawyer", ["right"]
+            env._move_speed, env._rotate_speed, env._action_repeat, env._record_demo = 0.1, 22.5, 3, False
+            env._min_gripper_pos, env._max_gripper_pos = np.array([-1.5, -1.5, 0.0]), np.array([1.5, 1.5, 1.5])
+            hand_pos = rng.uniform(-0.5, 0.5, 3) + np.array([0.0, 0.2, 0.6 if t % 4 else 0.03])  # near the z = 0 bound at times
+            rhq = RT.mat2quat(rand_rot(rng).astype(np.float32))
+            init_q = RT.mat2quat(rand_rot(rng).astype(np.float32))
+            env._right_hand_quat, env._initial_right_hand_quat = rhq, init_q.copy()
+            env.sim = types.SimpleNamespace(data=types.SimpleNamespace(get_body_xpos=lambda name, hp=hand_pos: hp))
+            env._bounded_d_pos = types.MethodType(F.FurnitureEnv._bounded_d_pos, env)
+            env._make_input = types.MethodType(F.FurnitureEnv._make_input, env)
+            calls = dict(ctrl=[], low=[], nsim=0)
+            vel_seq = [rng.uniform(-1, 1, 7) for _ in range(3)]
+
+            def get_control(dpos=None, rotation=None, calls=calls, vel_seq=vel_seq):
+                if dpos is not None:
+                    calls["dpos"], calls["rot"] = np.array(dpos, dtype=float), np.array(rotation, dtype=float)
+                return vel_seq[len(calls["ctrl"])]
+
+            def setup_action(a, calls=calls):
+                calls["low"].append(np.array(a, dtype=float))
+                calls["ctrl"].append(1)
+                return a
+
+            def do_sim(ctrl, calls=calls):
+                calls["nsim"] += 1
+
+            env._controller = types.SimpleNamespace(get_control=get_control)
+            env._setup_action, env._do_simulation = setup_action, do_sim
+            a = rng.uniform(-1, 1, 8 if ctype == "ik" else 9)
+            a[-2] = -1.0 if a[-2] < 0 else 1.0
+            F.FurnitureEnv._do_ik_step(env, a.copy())
+            rec["act"].append(a); rec["hand_pos"].append(hand_pos); rec["rhq"].append(rhq); rec["init_in"].append(init_q)
+            rec["dpos"].append(calls["dpos"]); rec["rot"].append(calls["rot"]); rec["init_out"].append(np.array(env._initial_right_hand_quat, dtype=float))
+            rec["low"].append(np.array(calls["low"])); rec["nsim"].append(calls["nsim"])
+            rec.setdefault("vel", []).append(np.array(vel_seq))
+        for k, v in rec.items():
+            out["ikstep_%s_%s" % (ctype, k)] = np.array(v)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB", len(out), "arrays")
 
