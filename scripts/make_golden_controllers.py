@@ -278,6 +278,75 @@ def main():
             rec.setdefault("vel", []).append(np.array(vel_seq))
         for k, v in rec.items():
             out["ikstep_%s_%s" % (ctype, k)] = np.array(v)
+    # ---- SawyerIKController (controllers/sawyer_ik_controller.py) around a fake pybullet: everything but the IK solve itself ---------
+    # The fake `p` keeps the joint states the controller writes (resetJointState), answers getLinkState(robot, 6) with the
+    # centre-of-mass frame of right_l6 from the compiled model's URDF chain (oracle/ik.fk, itself checked against the MJCF
+    # kinematics) on a base at (0, 0, 0.9) as loadURDF places it, records every calculateInverseKinematics call and answers it with a
+    # joint vector we choose.  Pinned: sync_state's initial target, target += dpos * user_sensitivity, the Rz(-90 deg) orientation
+    # convention, the base -> world target conversion, 20 solver calls with the rest-pose / limit arguments, the P controller.
+    _m2q = RT.mat2quat  # np.array(rmat, dtype=float32, copy=False) raises under numpy >= 2 for float64 input; numpy 1.x (which the
+    RT.mat2quat = lambda rmat, precise=False: _m2q(np.asarray(rmat, dtype=np.float32), precise)  # reference ran on) silently copies
+    import furniture.env.controllers.sawyer_ik_controller as SIK
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle import ik as OIK
+    cm = load_compiled("Sawyer", "table_lack_0825")
+
+    class FakeBullet:
+        DIRECT, POSITION_CONTROL = 0, 1
+
+        def __init__(self):
+            self.q = np.zeros(7)
+            self.calls = []
+            self.answer = None
+
+        def connect(self, *a, **k): return 0
+        def resetSimulation(self, *a, **k): pass
+        def loadURDF(self, path, base, useFixedBase=1):
+            self.base = np.array(base, dtype=float)
+            self.urdf = path
+            return 7
+        def setRealTimeSimulation(self, *a, **k): pass
+        def resetJointState(self, robot, i, v, *a): self.q[i] = v
+        def getBasePositionAndOrientation(self, robot): return (tuple(self.base), (0.0, 0.0, 0.0, 1.0))
+        def getLinkState(self, robot, link):
+            assert link == 6
+            pos, R, _, _ = OIK.fk(cm, self.q)
+            return (tuple(pos + self.base), tuple(RT.mat2quat(R.astype(np.float32))))
+        def calculateInverseKinematics(self, robot, link, pos, **kw):
+            self.calls.append(dict(link=link, pos=np.array(pos, dtype=float), orn=np.array(kw["targetOrientation"], dtype=float),
+                                   rest=np.array(kw["restPoses"], dtype=float), lower=np.array(kw.get("lowerLimits", [])),
+                                   upper=np.array(kw.get("upperLimits", [])), damping=np.array(kw["jointDamping"])))
+            return list(self.answer)
+
+    fb = FakeBullet()
+    SIK.p = fb
+    jpos = [cm.arm_initqpos.copy()]
+    ctl = SIK.SawyerIKController(bullet_data_path="/x", robot_jpos_getter=lambda: jpos[0])
+    out["sik_urdf"] = np.array(fb.urdf)
+    out["sik_sync_target"] = np.array(ctl.ik_robot_target_pos, dtype=float)
+    out["sik_base"] = fb.base
+    recs = dict(q=[], dpos=[], rot=[], answer=[], target_after=[], call_pos=[], call_orn=[], ncalls=[], vel=[], vel2=[], q2=[])
+    for t in range(12):
+        jpos[0] = cm.arm_initqpos + rng.uniform(-0.3, 0.3, 7)
+        dpos, rot = rng.uniform(-0.1, 0.1, 3), rand_rot(rng).astype(np.float32)
+        fb.answer = jpos[0] + rng.uniform(-0.4, 0.4, 7)
+        fb.calls = []
+        vel = ctl.get_control(dpos=dpos.copy(), rotation=rot.copy())
+        jpos.append(None)
+        q2 = jpos[0] + rng.uniform(-0.05, 0.05, 7)
+        q_first = jpos[0].copy()
+        jpos[0] = q2
+        vel2 = ctl.get_control()   # closed-loop repeat: no new target
+        recs["q"].append(q_first); recs["dpos"].append(dpos); recs["rot"].append(rot.astype(float)); recs["answer"].append(fb.answer.copy())
+        recs["target_after"].append(np.array(ctl.ik_robot_target_pos, dtype=float)); recs["call_pos"].append(fb.calls[0]["pos"]); recs["call_orn"].append(fb.calls[0]["orn"])
+        recs["ncalls"].append(len(fb.calls)); recs["vel"].append(np.array(vel)); recs["vel2"].append(np.array(vel2)); recs["q2"].append(q2)
+        if t == 0:
+            out["sik_rest"], out["sik_lower"], out["sik_upper"], out["sik_damping"] = fb.calls[0]["rest"], fb.calls[0]["lower"], fb.calls[0]["upper"], fb.calls[0]["damping"]
+            out["sik_link"] = np.array(fb.calls[0]["link"])
+        jpos = [jpos[0]]
+    for k, v in recs.items():
+        out["sik_" + k] = np.array(v)
+    out["sik_user_sensitivity"] = np.array(ctl.user_sensitivity)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB", len(out), "arrays")
 
