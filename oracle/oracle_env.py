@@ -538,6 +538,16 @@ class FurnitureEnvOracle:
             out.append((L, R, Fl))
         return out
 
+    def _connect_scan(self):
+        """F.py:1290-1330: per arm, the first part (in part order) touched by both fingers is tried; a successful connect ends
+        the scan, a failed one only ends this arm's (quirk Q4)."""
+        for (L, R, _) in self._touch_sets():
+            for i in range(self.nparts):
+                if i in L and i in R:
+                    if self._try_connect(i):
+                        return
+                    break
+
     def _setup_action(self, action):
         m = self.m
         if self.cfg.rescale_actions:
@@ -643,15 +653,7 @@ class FurnitureEnvOracle:
                 ctrl = self._setup_action(a[:-1])
                 self._do_simulation(ctrl)
             if connect > 0:
-                for (L, R, _) in self._touch_sets():
-                    hit = False
-                    for i in range(self.nparts):
-                        if i in L and i in R:
-                            res = self._try_connect(i)
-                            hit = True
-                            break
-                    if hit and res:
-                        break
+                self._connect_scan()
         if self._connected_body1 is not None:
             self.sim.forward()
             self._move_objects_target(self._connected_body1, self._connected_body1_pos, self._connected_body1_quat, self._gravity_compensation)
