@@ -671,19 +671,24 @@ class FurnitureEnvOracle:
             done = done or d2
         else:
             reward, info = self._compute_reward(action)
-        # _after_step
+        fail = self._fail
+        done, penalty = self._after_step(reward, done)
+        info.update(num_connected=self._num_connected, success=int(self._success), fail=int(fail), site1=self._site1_id,
+                    site2=self._site2_id, episode_length=self._episode_length, connected_this_step=int(self._connected))
+        return ob, reward + penalty, done, info
+
+    def _after_step(self, reward, done):
+        """F.py:451-480: episode counters, time limit by EQUALITY (quirk Q9), failure -> terminal with a one-shot penalty.
+        -> (terminal, penalty); step_log's episode_reward is _episode_reward + penalty."""
         self._episode_reward += reward
         self._episode_length += 1
         penalty = 0
-        fail = self._fail
         if self._episode_length == self.cfg.max_episode_steps or self._fail:
             done = True
             if self._fail:
                 self._fail = False
                 penalty = -self.cfg.unstable_penalty_coef
-        info.update(num_connected=self._num_connected, success=int(self._success), fail=int(fail), site1=self._site1_id,
-                    site2=self._site2_id, episode_length=self._episode_length, connected_this_step=int(self._connected))
-        return ob, reward + penalty, done, info
+        return done, penalty
 
     def _compute_reward(self, ac):
         touch = pick = 0.0

@@ -82,6 +82,23 @@ def main():
         out[agent + "_contacts"], out[agent + "_script"] = np.array(cons), np.array(scripts)
         out[agent + "_tried"], out[agent + "_nsim"] = np.array(tried), np.array(nsim)
         out[agent + "_connect"] = np.array(out[agent + "_connect"])
+    # ---- FurnitureEnv._after_step (furniture.py:451-480): counters, equality time limit, failure penalty, terminal step_log ------
+    env = types.SimpleNamespace(_episode_reward=0.0, _episode_length=0, _max_episode_steps=7, _fail=False, _success=False, _num_connected=0,
+                                _episode_time=0.0, _config=types.SimpleNamespace(unstable_penalty_coef=100), get_env_state=lambda: {})
+    rows = []
+    for t in range(60):
+        reward = float(rng.uniform(-1, 1))
+        terminal_in = bool(rng.rand() < 0.1)
+        env._fail = bool(rng.rand() < 0.1)
+        env._success = bool(rng.rand() < 0.1)
+        env._num_connected = int(rng.randint(0, 4))
+        fail_in = env._fail
+        term, log, pen = F.FurnitureEnv._after_step(env, reward, terminal_in, {})
+        rows.append([reward, terminal_in, fail_in, term, pen, env._episode_length, env._episode_reward, log.get("episode_reward", np.nan),
+                     log.get("episode_length", -1), log.get("episode_unstable", np.nan), env._fail])
+        if term:  # _after_reset (furniture.py:336-346)
+            env._episode_reward, env._episode_length = 0.0, 0
+    out["after_step"] = np.array(rows, dtype=float)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB")
 
