@@ -99,6 +99,53 @@ def main():
         if term:  # _after_reset (furniture.py:336-346)
             env._episode_reward, env._episode_length = 0.0, 0
     out["after_step"] = np.array(rows, dtype=float)
+    # ---- call traces of _do_simulation (furniture.py:2857-2897) and of _step's post-connect block (:405-449) -------------------------
+    T_TOK = ["setctrl", "forward", "step", "stop1", "stop0", "reset", "fail", "move_target", "get_obs", "scan"]
+    out["trace_tokens"] = np.array(T_TOK)
+
+    def fake(agent, log, selected=(None, None), groups=None, raise_at=None):
+        env = types.SimpleNamespace()
+        env._agent_type, env._control_type = agent, "impedance"
+        env._control_timestep, env._model_timestep, env._cur_time = 0.1, 0.002, 0.0
+        env._object_names = ["p0", "p1", "p2", "p3"]
+        env._cursor_selected = list(selected)
+        grp = groups or {n: i for i, n in enumerate(env._object_names)}
+        env._find_group = lambda n: grp[n]
+        env._stop_object = lambda n, gravity=1: log.append("stop%d" % gravity)
+
+        class Ctrl:
+            def __setitem__(self, k, v): log.append("setctrl")
+        count = dict(n=0)
+
+        def step():
+            count["n"] += 1
+            if raise_at is not None and count["n"] == raise_at:
+                raise RuntimeError("unstable")
+            log.append("step")
+        env.sim = types.SimpleNamespace(data=types.SimpleNamespace(ctrl=Ctrl()), forward=lambda: log.append("forward"), step=step)
+        env.set_init_qpos = lambda q: None
+        env.reset = lambda: log.append("reset")
+        env._fail = False
+        return env
+
+    traces = {}
+    log = []; e = fake("Sawyer", log); F.FurnitureEnv._do_simulation(e, np.zeros(9)); traces["dosim_sawyer"] = log
+    log = []; e = fake("Cursor", log, selected=("p1", None), groups={"p0": 0, "p1": 1, "p2": 1, "p3": 3}); F.FurnitureEnv._do_simulation(e, None); traces["dosim_cursor"] = log
+    log = []; e = fake("Sawyer", log, raise_at=7); F.FurnitureEnv._do_simulation(e, np.zeros(9)); traces["dosim_unstable"] = log + (["fail"] if e._fail else [])
+    # _step: Sawyer, a connect happened inside _step_continuous
+    log = []
+    e = fake("Sawyer", log)
+    e._connected_body1, e._connected_body1_pos, e._connected_body1_quat, e._gravity_compensation = "p0", np.zeros(3), np.array([1.0, 0, 0, 0]), 0
+    e._step_continuous = lambda a: log.append("scan")
+    e._move_objects_target = lambda *a: log.append("move_target")
+    e._get_obs = lambda: (log.append("get_obs"), {})[1]
+    e._num_connected, e._success_num_conn, e._success = 4, 4, False
+    ob, rew, done, info = F.FurnitureEnv._step(e, np.zeros(9))
+    traces["step_postconnect"] = log
+    out["step_postconnect_result"] = np.array([rew, float(done), float(e._success), float(e._connected_body1 is None)])
+    for k, v in traces.items():
+        out["trace_" + k] = np.array([T_TOK.index(t) for t in v], dtype=np.int16)
+        print(k, len(v), v[:6], "...", v[-3:])
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB")
 
