@@ -55,7 +55,6 @@ def test_async_trajectories_equal_sync():
 
 
 def test_subset_step_leaves_other_rows_untouched():
-    from furniture_amd.sim import INFO_DIM
     n = 16
     b = FurnitureBatchEnv("Sawyer", n, config=_cfg())
     b.reset()

@@ -1,7 +1,6 @@
 """BASELINE configs 3 and 4 at their full single-GPU sizes (8192 envs Sawyer + swivel_chair_0700; 4096 envs Baxter +
 desk_mikael_1064): size-independent properties -- finite observations, unit quaternions, time-limit terminations with in-kernel
 auto-reset, run-to-run bit determinism, and invariance of an env's trajectory to its position in the batch."""
-import numpy as np
 import pytest
 import torch
 
