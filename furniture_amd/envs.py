@@ -194,6 +194,13 @@ class FurnitureBatchEnv:
             raise NotImplementedError("the arm controllers are built for the Sawyer agent with the sparse reward")
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
+        # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them
+        for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect)"),
+                          ("no_collision", "furniture.py:1919-1924"), ("fix_init", "furniture.py:1516-1521"), ("assembled", "furniture.py:1503, 1526"),
+                          ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325"),
+                          ("preassembled", "furniture.py:1492-1557")):
+            if getattr(cfg, flag, None):
+                raise NotImplementedError("config.%s (%s) is not part of the accelerated path" % (flag, ref))
         names = furniture_names()
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg

@@ -59,3 +59,12 @@ def test_obs_options_match_oracle_env():
             for k in ("object_ob", "subtask_ob", "robot_ob"):
                 assert np.abs(ob[k][i].cpu().numpy() - o[k]).max() < 5e-4, k
     env.close()
+
+
+@pytest.mark.parametrize("flag", ["reset_robot_after_attach", "no_collision", "fix_init", "assembled", "record_demo"])
+def test_unsupported_reference_options_fail_loudly(flag):
+    """Options of furniture/config/furniture.py that change the reset / connect flow and are not built raise before any device work
+    (no silent ignore); checked on CPU: the guard sits ahead of the FSim construction."""
+    with pytest.raises(NotImplementedError, match=flag):
+        FurnitureBatchEnv("Sawyer", 1, config=make_config(unity=False, record_vid=False, control_type="impedance",
+                                                          furniture_name="table_lack_0825", **{flag: True}))
