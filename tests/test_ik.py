@@ -143,3 +143,39 @@ def test_default_gym_id_runs_with_ik():
     ob, r, d, info = env.step(np.array([0.5, 0, 0, 0, 0, 0, -1, 0], dtype=np.float32))
     assert np.isfinite(ob["robot_ob"]).all() and np.isfinite(ob["object_ob"]).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_device_ik_tracks_an_end_effector_path(model):
+    """Task-level validation of the stand-in solver ('validate by task success, not trajectories'): 64 envs follow a
+    commanded square path (+x, +z, -x, -z in the world, 8 steps a side) under control_type 'ik'.  The hand must end each side
+    within 1.5 cm of where the accumulated command puts it (move_speed 0.1 x user_sensitivity 0.3 = 3 cm per step), keep its
+    orientation within 6 degrees, and return to the start within 2 cm -- for every env of the batch."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    n = 64
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="ik", furniture_name="table_lack_0825",
+                                                            max_episode_steps=500, seed=7), auto_reset=False)
+    ob = env.reset()
+    eef0 = ob["robot_ob"][:, 2:5].clone()
+    quat0 = ob["robot_ob"][:, 5:9].clone()
+    a = torch.zeros((n, 8), device=env.sim.device)
+    a[:, 6], a[:, 7] = -1.0, -1.0
+    # action axes -> world: d_pos(base) = move_speed * [-a1, a0, a2], and the Sawyer base is yawed -90 deg: world x <- a0, world z <- a2
+    sides = [(0, +1.0, 0), (2, +1.0, 2), (0, -1.0, 0), (2, -1.0, 2)]
+    expect = eef0.clone()
+    for comp, sign, world_axis in sides:
+        for _ in range(8):
+            a[:, :6] = 0
+            a[:, comp] = sign
+            ob, _, done, _ = env.step(a)
+        a[:, :6] = 0
+        for _ in range(3):   # let the P controller settle on the last target
+            ob, _, _, _ = env.step(a)
+        expect[:, world_axis] += sign * 8 * 0.1 * 0.3
+        eef = ob["robot_ob"][:, 2:5]
+        assert float((eef - expect).abs().max()) < 0.015, (comp, sign, float((eef - expect).abs().max()))
+        q = ob["robot_ob"][:, 5:9]
+        cosang = (q * quat0).sum(dim=1).abs().clamp(max=1.0)
+        assert float(torch.rad2deg(2 * torch.acos(cosang)).max()) < 6.0
+    assert float((ob["robot_ob"][:, 2:5] - eef0).abs().max()) < 0.02 and not bool(done.any())
+    env.close()
