@@ -179,3 +179,75 @@ def test_device_ik_tracks_an_end_effector_path(model):
         assert float(torch.rad2deg(2 * torch.acos(cosang)).max()) < 6.0
     assert float((ob["robot_ob"][:, 2:5] - eef0).abs().max()) < 0.02 and not bool(done.any())
     env.close()
+
+
+def _scripted_pick(step_fn, get_obs, n, n_obj):
+    """Observation-only scripted policy under control_type 'ik_quaternion': point the gripper straight down with the fingers
+    across leg 0, move above it, descend, close, lift.  step_fn(actions [n, 9]) -> reward [n]; get_obs() -> (object_ob, robot_ob)."""
+    from oracle import ik as IK
+
+    def hand_R(q_xyzw):
+        return IK.q2m(np.array([q_xyzw[3], q_xyzw[0], q_xyzw[1], q_xyzw[2]]))
+    Rt = np.array([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]])  # hand z -> world -z, finger axis (hand y) -> world y
+    total_reward = np.zeros(n)
+    obj, rob = get_obs()
+    leg = obj[:, 0:3].copy()
+
+    def phase(steps, z, grip):
+        nonlocal total_reward
+        for _ in range(steps):
+            obj, rob = get_obs()
+            a = np.zeros((n, 9), dtype=np.float32)
+            for i in range(n):
+                R = hand_R(rob[i, 5:9])
+                E = R.T @ Rt
+                w = 0.5 * np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])
+                nw = np.linalg.norm(w)
+                th = min(np.arcsin(min(1.0, nw)), 0.15)
+                ax = w / (nw + 1e-12)
+                a[i, 3], a[i, 4:7] = np.cos(th / 2), ax * np.sin(th / 2)
+                if z is not None:
+                    a[i, :3] = np.clip((np.array([leg[i, 0], leg[i, 1], z]) - rob[i, 2:5]) / 0.03 * 0.5, -1, 1)
+            a[:, 7], a[:, 8] = grip, -1.0
+            total_reward += step_fn(a)
+    phase(25, None, -1.0)     # orient
+    phase(30, 0.12, -1.0)     # above the leg
+    phase(30, 0.028, -1.0)    # descend: finger tips straddle the 3 cm leg
+    phase(8, 0.028, 1.0)      # close
+    phase(30, 0.15, 1.0)      # lift
+    obj, rob = get_obs()
+    return obj[:, 2], total_reward
+
+
+def test_scripted_pick_on_the_oracle_env(model):
+    """The same policy on the fp64 oracle env (CPU): leg 0 ends ~12 cm above the floor, touch + pick rewards are paid."""
+    e = FurnitureEnvOracle(model, OracleConfig(max_episode_steps=500, seed=123, control_type="ik_quaternion"))
+    last = {"ob": e.reset()}
+
+    def step_fn(a):
+        ob, r, d, _ = e.step(a[0].astype(np.float64))
+        last["ob"] = ob
+        return np.array([r])
+    z, rew = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts)
+    assert z[0] > 0.08 and rew[0] > 100.0   # touch_reward 10 + pick_reward 100 - control penalties
+
+
+@pytest.mark.gpu
+def test_scripted_pick_on_the_device(model):
+    """Task success on the HIP path: 16 envs (different placements), observation-only scripted pick under ik_quaternion.
+    At least three quarters of the envs (the open-loop script has no re-grasp; 14 of 16 when written) pay the touch + pick
+    rewards and hold leg 0 ~12 cm above the floor at the end; env 0 (the oracle test's seed) is one of them."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    n = 16
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="ik_quaternion",
+                                                            furniture_name="table_lack_0825", max_episode_steps=500, seed=123), auto_reset=False)
+    last = {"ob": env.reset()}
+
+    def step_fn(a):
+        ob, r, d, _ = env.step(a)
+        last["ob"] = ob
+        return r.cpu().numpy()
+    z, rew = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy()), n, model.nparts)
+    ok = (z > 0.08) & (rew > 100.0)
+    assert ok.sum() >= (3 * n) // 4 and ok[0], (z.round(3), rew.round(1))
+    env.close()
