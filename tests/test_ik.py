@@ -181,42 +181,67 @@ def test_device_ik_tracks_an_end_effector_path(model):
     env.close()
 
 
-def _scripted_pick(step_fn, get_obs, n, n_obj):
+def _scripted_pick(step_fn, get_obs, n, n_obj, model=None, attach=False):
     """Observation-only scripted policy under control_type 'ik_quaternion': point the gripper straight down with the fingers
-    across leg 0, move above it, descend, close, lift.  step_fn(actions [n, 9]) -> reward [n]; get_obs() -> (object_ob, robot_ob)."""
+    across leg 0, move above it, descend, close, lift; with attach=True: turn the hand a quarter turn about the finger axis so that
+    the leg hangs vertically with its connector down, carry it over the nearest connector of the (upside-down) table top and send
+    connect.  step_fn(actions [n, 9]) -> (reward [n], num_connected [n]); get_obs() -> (object_ob, robot_ob)."""
     from oracle import ik as IK
 
-    def hand_R(q_xyzw):
-        return IK.q2m(np.array([q_xyzw[3], q_xyzw[0], q_xyzw[1], q_xyzw[2]]))
+    def Rq(q_wxyz):
+        return IK.q2m(np.asarray(q_wxyz, dtype=float))
     Rt = np.array([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]])  # hand z -> world -z, finger axis (hand y) -> world y
-    total_reward = np.zeros(n)
+    total_reward, ncon = np.zeros(n), np.zeros(n, dtype=int)
     obj, rob = get_obs()
     leg = obj[:, 0:3].copy()
 
-    def phase(steps, z, grip):
-        nonlocal total_reward
+    def phase(steps, target_R, target_fn, grip, connect=-1.0, maxrot=0.15):
+        nonlocal total_reward, ncon
         for _ in range(steps):
             obj, rob = get_obs()
             a = np.zeros((n, 9), dtype=np.float32)
             for i in range(n):
-                R = hand_R(rob[i, 5:9])
-                E = R.T @ Rt
+                R = Rq([rob[i, 8], rob[i, 5], rob[i, 6], rob[i, 7]])   # eef_quat is xyzw
+                E = R.T @ target_R
                 w = 0.5 * np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])
                 nw = np.linalg.norm(w)
-                th = min(np.arcsin(min(1.0, nw)), 0.15)
-                ax = w / (nw + 1e-12)
-                a[i, 3], a[i, 4:7] = np.cos(th / 2), ax * np.sin(th / 2)
-                if z is not None:
-                    a[i, :3] = np.clip((np.array([leg[i, 0], leg[i, 1], z]) - rob[i, 2:5]) / 0.03 * 0.5, -1, 1)
-            a[:, 7], a[:, 8] = grip, -1.0
-            total_reward += step_fn(a)
-    phase(25, None, -1.0)     # orient
-    phase(30, 0.12, -1.0)     # above the leg
-    phase(30, 0.028, -1.0)    # descend: finger tips straddle the 3 cm leg
-    phase(8, 0.028, 1.0)      # close
-    phase(30, 0.15, 1.0)      # lift
+                ang = np.arcsin(min(1.0, nw))
+                if np.trace(E) < 1.0 and nw < 0.9:
+                    ang = np.pi - ang                                   # more than a quarter turn to go
+                th = min(ang, maxrot)
+                a[i, 3], a[i, 4:7] = np.cos(th / 2), w / (nw + 1e-12) * np.sin(th / 2)
+                tgt = target_fn(i, obj, rob)
+                if tgt is not None:
+                    a[i, :3] = np.clip((tgt - rob[i, 2:5]) / 0.03 * 0.5, -1, 1)
+            a[:, 7], a[:, 8] = grip, connect
+            r, nc = step_fn(a)
+            total_reward += r
+            ncon = np.maximum(ncon, nc)
+    at = lambda z: (lambda i, obj, rob: np.array([leg[i, 0], leg[i, 1], z]))
+    phase(25, Rt, lambda i, obj, rob: None, -1.0)     # orient
+    phase(30, Rt, at(0.12), -1.0)                     # above the leg
+    phase(30, Rt, at(0.028), -1.0)                    # descend: finger tips straddle the 3 cm leg
+    phase(8, Rt, at(0.028), 1.0)                      # close
+    if not attach:
+        phase(30, Rt, at(0.15), 1.0)                  # lift
+        obj, rob = get_obs()
+        return obj[:, 2], total_reward, ncon
+    phase(30, Rt, at(0.25), 1.0)                      # lift high enough for the leg to hang vertically
+    Rt2 = np.array([[0, 0, 1.0], [0, 1.0, 0], [-1.0, 0, 0]]) @ Rt   # +90 deg about world y: the leg's +x end (its connector) -> down
+    phase(40, Rt2, at(0.25), 1.0, maxrot=0.08)
+    m = model
+    s_leg, s_tab = int(m.conn_siteid[0]), int(m.conn_siteid[6])
+    assert int(m.site_bodyid[s_leg]) == int(m.part_bodyid[0]) and int(m.site_bodyid[s_tab]) == int(m.part_bodyid[4])
+    tab = obj[:, 28:35].copy()                        # the table top has not moved: its connector is the carry target
+    tab_conn = np.stack([tab[i, :3] + Rq(tab[i, 3:7]) @ m.site_pos[s_tab] for i in range(n)])
+
+    def over_table(i, obj, rob):
+        leg_conn = obj[i, 0:3] + Rq(obj[i, 3:7]) @ m.site_pos[s_leg]
+        return tab_conn[i] + np.array([0, 0, 0.03]) + (rob[i, 2:5] - leg_conn)
+    phase(50, Rt2, over_table, 1.0, maxrot=0.08)
+    phase(5, Rt2, over_table, 1.0, connect=1.0, maxrot=0.08)   # connect > 0 while both fingers hold the leg -> _try_connect
     obj, rob = get_obs()
-    return obj[:, 2], total_reward
+    return obj[:, 2], total_reward, ncon
 
 
 def test_scripted_pick_on_the_oracle_env(model):
@@ -225,11 +250,26 @@ def test_scripted_pick_on_the_oracle_env(model):
     last = {"ob": e.reset()}
 
     def step_fn(a):
-        ob, r, d, _ = e.step(a[0].astype(np.float64))
+        ob, r, d, info = e.step(a[0].astype(np.float64))
         last["ob"] = ob
-        return np.array([r])
-    z, rew = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts)
+        return np.array([r]), np.array([info["num_connected"]])
+    get = lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None])
+    z, rew, _ = _scripted_pick(step_fn, get, 1, model.nparts)
     assert z[0] > 0.08 and rew[0] > 100.0   # touch_reward 10 + pick_reward 100 - control penalties
+
+
+def test_scripted_attach_on_the_oracle_env(model):
+    """Pick leg 0, hang it vertically, carry it over a table connector, connect: the weld of the first subtask becomes active, the
+    leg and the table top share a group, success_reward is paid (furniture.py:847-924, 926-1042)."""
+    e = FurnitureEnvOracle(model, OracleConfig(max_episode_steps=1000, seed=123, control_type="ik_quaternion"))
+    last = {"ob": e.reset()}
+
+    def step_fn(a):
+        ob, r, d, info = e.step(a[0].astype(np.float64))
+        last["ob"] = ob
+        return np.array([r]), np.array([info["num_connected"]])
+    z, rew, ncon = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts, model, attach=True)
+    assert ncon[0] == 1 and rew[0] > 200.0 and e.sim.model.eq_active[0] == 1 and e._find_group(0) == e._find_group(4)
 
 
 @pytest.mark.gpu
@@ -244,10 +284,39 @@ def test_scripted_pick_on_the_device(model):
     last = {"ob": env.reset()}
 
     def step_fn(a):
-        ob, r, d, _ = env.step(a)
+        ob, r, d, info = env.step(a)
         last["ob"] = ob
-        return r.cpu().numpy()
-    z, rew = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy()), n, model.nparts)
+        return r.cpu().numpy(), info["num_connected"].cpu().numpy()
+    get = lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy())
+    z, rew, _ = _scripted_pick(step_fn, get, n, model.nparts)
     ok = (z > 0.08) & (rew > 100.0)
     assert ok.sum() >= (3 * n) // 4 and ok[0], (z.round(3), rew.round(1))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_scripted_attach_on_the_device(model):
+    """The whole first subtask on the HIP path under IK control: pick leg 0, hang it vertically, carry it over a connector of
+    the table top, connect -- num_connected becomes 1, the weld is active and the two parts share a group (bit-exact integers),
+    success_reward is paid.  8 placements; the open-loop script has no retries, so three quarters must succeed, env 0 (the
+    oracle test's seed) among them."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    n = 8
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="ik_quaternion",
+                                                            furniture_name="table_lack_0825", max_episode_steps=1000, seed=123), auto_reset=False)
+    last = {"ob": env.reset()}
+
+    def step_fn(a):
+        ob, r, d, info = env.step(a)
+        last["ob"] = ob
+        return r.cpu().numpy(), info["num_connected"].cpu().numpy()
+    get = lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy())
+    z, rew, ncon = _scripted_pick(step_fn, get, n, model.nparts, model, attach=True)
+    st = env.sim.get_state("eq_active", "group")
+    ok = (ncon == 1) & (rew > 200.0) & (st["eq_active"][:, 0].cpu().numpy() == 1)
+    grp = st["group"].cpu().numpy()
+    print("scripted attach on the device: %d of %d placements connected" % (int(ok.sum()), n))
+    assert ok.sum() >= (3 * n) // 4 and ok[0], (ncon, rew.round(1))
+    for i in np.nonzero(ok)[0]:
+        assert grp[i, 0] == 4 or grp[i, 4] == grp[i, 0] or grp[i, grp[i, 0]] == grp[i, 4]  # leg 0 and the table top in one group
     env.close()
