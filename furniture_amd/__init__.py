@@ -11,6 +11,7 @@ Only the path named in BASELINE.json's north_star lives here:
 * ``async_env`` EnvPool-style send / recv over fsim_step_subset
 * ``dense``     tables of the dense 8-phase reward
 * ``dist``      env sharding + the per-step RCCL observation all-gather
+* ``scripted``  scripted pick-and-attach policy under ik_quaternion (scenario generator, cf. furniture_sawyer_gen.py)
 * ``transform_utils`` quaternion helpers the env logic needs
 
 The product path never imports anything from ``oracle/``.

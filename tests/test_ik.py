@@ -182,66 +182,18 @@ def test_device_ik_tracks_an_end_effector_path(model):
 
 
 def _scripted_pick(step_fn, get_obs, n, n_obj, model=None, attach=False):
-    """Observation-only scripted policy under control_type 'ik_quaternion': point the gripper straight down with the fingers
-    across leg 0, move above it, descend, close, lift; with attach=True: turn the hand a quarter turn about the finger axis so that
-    the leg hangs vertically with its connector down, carry it over the nearest connector of the (upside-down) table top and send
-    connect.  step_fn(actions [n, 9]) -> (reward [n], num_connected [n]); get_obs() -> (object_ob, robot_ob)."""
-    from oracle import ik as IK
+    """furniture_amd.scripted.PickAndAttach driven through (step_fn, get_obs) adapters: -> (leg 0 height, summed reward, num_connected)."""
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.scripted import PickAndAttach
+    pol = PickAndAttach(model if model is not None else load_compiled("Sawyer", "table_lack_0825"), n, attach=attach)
 
-    def Rq(q_wxyz):
-        return IK.q2m(np.asarray(q_wxyz, dtype=float))
-    Rt = np.array([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]])  # hand z -> world -z, finger axis (hand y) -> world y
-    total_reward, ncon = np.zeros(n), np.zeros(n, dtype=int)
-    obj, rob = get_obs()
-    leg = obj[:, 0:3].copy()
-
-    def phase(steps, target_R, target_fn, grip, connect=-1.0, maxrot=0.15):
-        nonlocal total_reward, ncon
-        for _ in range(steps):
-            obj, rob = get_obs()
-            a = np.zeros((n, 9), dtype=np.float32)
-            for i in range(n):
-                R = Rq([rob[i, 8], rob[i, 5], rob[i, 6], rob[i, 7]])   # eef_quat is xyzw
-                E = R.T @ target_R
-                w = 0.5 * np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])
-                nw = np.linalg.norm(w)
-                ang = np.arcsin(min(1.0, nw))
-                if np.trace(E) < 1.0 and nw < 0.9:
-                    ang = np.pi - ang                                   # more than a quarter turn to go
-                th = min(ang, maxrot)
-                a[i, 3], a[i, 4:7] = np.cos(th / 2), w / (nw + 1e-12) * np.sin(th / 2)
-                tgt = target_fn(i, obj, rob)
-                if tgt is not None:
-                    a[i, :3] = np.clip((tgt - rob[i, 2:5]) / 0.03 * 0.5, -1, 1)
-            a[:, 7], a[:, 8] = grip, connect
-            r, nc = step_fn(a)
-            total_reward += r
-            ncon = np.maximum(ncon, nc)
-    at = lambda z: (lambda i, obj, rob: np.array([leg[i, 0], leg[i, 1], z]))
-    phase(25, Rt, lambda i, obj, rob: None, -1.0)     # orient
-    phase(30, Rt, at(0.12), -1.0)                     # above the leg
-    phase(30, Rt, at(0.028), -1.0)                    # descend: finger tips straddle the 3 cm leg
-    phase(8, Rt, at(0.028), 1.0)                      # close
-    if not attach:
-        phase(30, Rt, at(0.15), 1.0)                  # lift
+    def step(a):
+        r, nc = step_fn(a)
         obj, rob = get_obs()
-        return obj[:, 2], total_reward, ncon
-    phase(30, Rt, at(0.25), 1.0)                      # lift high enough for the leg to hang vertically
-    Rt2 = np.array([[0, 0, 1.0], [0, 1.0, 0], [-1.0, 0, 0]]) @ Rt   # +90 deg about world y: the leg's +x end (its connector) -> down
-    phase(40, Rt2, at(0.25), 1.0, maxrot=0.08)
-    m = model
-    s_leg, s_tab = int(m.conn_siteid[0]), int(m.conn_siteid[6])
-    assert int(m.site_bodyid[s_leg]) == int(m.part_bodyid[0]) and int(m.site_bodyid[s_tab]) == int(m.part_bodyid[4])
-    tab = obj[:, 28:35].copy()                        # the table top has not moved: its connector is the carry target
-    tab_conn = np.stack([tab[i, :3] + Rq(tab[i, 3:7]) @ m.site_pos[s_tab] for i in range(n)])
-
-    def over_table(i, obj, rob):
-        leg_conn = obj[i, 0:3] + Rq(obj[i, 3:7]) @ m.site_pos[s_leg]
-        return tab_conn[i] + np.array([0, 0, 0.03]) + (rob[i, 2:5] - leg_conn)
-    phase(50, Rt2, over_table, 1.0, maxrot=0.08)
-    phase(5, Rt2, over_table, 1.0, connect=1.0, maxrot=0.08)   # connect > 0 while both fingers hold the leg -> _try_connect
+        return {"object_ob": obj, "robot_ob": rob}, r, None, {"num_connected": nc}
     obj, rob = get_obs()
-    return obj[:, 2], total_reward, ncon
+    total, ncon, ob = pol.run(step, {"object_ob": obj, "robot_ob": rob})
+    return np.asarray(ob["object_ob"])[:, 2], total, ncon
 
 
 def test_scripted_pick_on_the_oracle_env(model):
