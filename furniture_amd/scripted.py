@@ -17,10 +17,15 @@ QUARTER_TURN_Y = np.array([[0, 0, 1.0], [0, 1.0, 0], [-1.0, 0, 0]])      # +90 d
 
 
 def _rot(q_wxyz):
-    w, x, y, z = np.asarray(q_wxyz, dtype=float) / np.linalg.norm(q_wxyz)
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    """[..., 4] wxyz -> [..., 3, 3] (batched)"""
+    q = np.asarray(q_wxyz, dtype=float)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z); R[..., 0, 1] = 2 * (x * y - w * z); R[..., 0, 2] = 2 * (x * z + w * y)
+    R[..., 1, 0] = 2 * (x * y + w * z); R[..., 1, 1] = 1 - 2 * (x * x + z * z); R[..., 1, 2] = 2 * (y * z - w * x)
+    R[..., 2, 0] = 2 * (x * z - w * y); R[..., 2, 1] = 2 * (y * z + w * x); R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
 
 
 def _to_numpy(x):
@@ -37,19 +42,21 @@ class PickAndAttach:
         assert int(model.site_bodyid[self.s_leg]) == int(model.part_bodyid[leg]) and int(model.site_bodyid[self.s_tab]) == int(model.part_bodyid[table])
 
     def _action(self, obj, rob, target_R, target, grip, connect, maxrot):
-        a = np.zeros((self.n, 9), dtype=np.float32)
-        for i in range(self.n):
-            R = _rot([rob[i, 8], rob[i, 5], rob[i, 6], rob[i, 7]])          # eef_quat is xyzw (furniture_sawyer.py:138-140)
-            E = R.T @ target_R                                             # remaining rotation, in the hand frame
-            w = 0.5 * np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])
-            nw = np.linalg.norm(w)
-            ang = np.arcsin(min(1.0, nw))
-            if np.trace(E) < 1.0 and nw < 0.9:
-                ang = np.pi - ang
-            th = min(ang, maxrot)
-            a[i, 3], a[i, 4:7] = np.cos(th / 2), w / (nw + 1e-12) * np.sin(th / 2)  # quaternion (wxyz) relative to the hand
-            if target is not None:
-                a[i, :3] = np.clip((target(i, obj, rob) - rob[i, 2:5]) / 0.03 * 0.5, -1, 1)  # 3 cm of target per unit action
+        """Vectorised over the batch: orientation servo in the hand frame + proportional position set-point."""
+        n = self.n
+        a = np.zeros((n, 9), dtype=np.float32)
+        R = _rot(rob[:, [8, 5, 6, 7]])                                     # eef_quat is xyzw (furniture_sawyer.py:138-140)
+        E = np.einsum("nji,jk->nik", R, target_R)                          # R^T . target: remaining rotation, in the hand frame
+        w = 0.5 * np.stack([E[:, 2, 1] - E[:, 1, 2], E[:, 0, 2] - E[:, 2, 0], E[:, 1, 0] - E[:, 0, 1]], axis=1)
+        nw = np.linalg.norm(w, axis=1)
+        ang = np.arcsin(np.minimum(1.0, nw))
+        far = (np.trace(E, axis1=1, axis2=2) < 1.0) & (nw < 0.9)
+        ang = np.where(far, np.pi - ang, ang)
+        th = np.minimum(ang, maxrot)
+        a[:, 3] = np.cos(th / 2)                                           # quaternion (wxyz) relative to the hand
+        a[:, 4:7] = w / (nw[:, None] + 1e-12) * np.sin(th / 2)[:, None]
+        if target is not None:
+            a[:, :3] = np.clip((target(obj, rob) - rob[:, 2:5]) / 0.03 * 0.5, -1, 1)  # 3 cm of target per unit action
         a[:, 7], a[:, 8] = grip, connect
         return a
 
@@ -70,7 +77,7 @@ class PickAndAttach:
                 state["ob"] = ob2
                 total += _to_numpy(rew).reshape(self.n)
                 ncon = np.maximum(ncon, _to_numpy(info["num_connected"]).reshape(self.n).astype(int))
-        at = lambda z: (lambda i, obj, rob: np.array([leg0[i, 0], leg0[i, 1], z]))
+        at = lambda z: (lambda obj, rob: np.concatenate([leg0[:, :2], np.full((self.n, 1), z)], axis=1))
         phase(25, GRIPPER_DOWN, None, -1.0)
         phase(30, GRIPPER_DOWN, at(0.12), -1.0)
         phase(30, GRIPPER_DOWN, at(0.028), -1.0)       # finger tips straddle the 3 cm leg
@@ -83,11 +90,11 @@ class PickAndAttach:
         phase(40, turned, at(0.25), 1.0, maxrot=0.08)
         to = 7 * self.table
         tab = obj[:, to:to + 7].copy()                 # the table top has not moved
-        tab_conn = np.stack([tab[i, :3] + _rot(tab[i, 3:7]) @ m.site_pos[self.s_tab] for i in range(self.n)])
+        tab_conn = tab[:, :3] + _rot(tab[:, 3:7]) @ m.site_pos[self.s_tab]
 
-        def over_table(i, obj, rob):
-            leg_conn = obj[i, lo:lo + 3] + _rot(obj[i, lo + 3:lo + 7]) @ m.site_pos[self.s_leg]
-            return tab_conn[i] + np.array([0, 0, 0.03]) + (rob[i, 2:5] - leg_conn)
+        def over_table(obj, rob):
+            leg_conn = obj[:, lo:lo + 3] + _rot(obj[:, lo + 3:lo + 7]) @ m.site_pos[self.s_leg]
+            return tab_conn + np.array([0, 0, 0.03]) + (rob[:, 2:5] - leg_conn)
         phase(50, turned, over_table, 1.0, maxrot=0.08)
         phase(5, turned, over_table, 1.0, connect=1.0, maxrot=0.08)   # connect > 0 while both fingers hold the leg
         return total, ncon, state["ob"]
