@@ -334,7 +334,13 @@ static int build_model(fsim *s) {
   LI(arm_qposadr, "arm_qposadr"); LI(arm_dofadr, "arm_dofadr"); LI(grip_qposadr, "grip_qposadr"); LI(grip_dofadr, "grip_dofadr");
   LI(eef_siteid, "eef_siteid"); LI(hand_body, "hand_bodyid");
   LF(arm_initqpos, "arm_initqpos"); LF(grip_initqpos, "grip_initqpos"); LF(qpos0, "qpos0");
-  { std::vector<float> v_; blob_f(s->blob, "ik_table", v_); if (v_.size() != IKT_WORDS) v_.assign(IKT_WORDS, 0.0f); s->has_ik = v_[IKT_BQUAT] != 0.0f || v_[IKT_BQUAT + 3] != 0.0f; ar.add(&s->m.ik_tab, v_); }
+  { // IK chain table(s): IKT_ARM floats per arm + IKT_TAIL (fsim_ik.hpp); models without one get zeros and refuse control_type 7 / 8
+    std::vector<float> v_; blob_f(s->blob, "ik_table", v_);
+    const size_t want = (size_t)IKT_ARM * std::max(m.narm, 1) + IKT_TAIL;
+    s->has_ik = m.narm > 0 && v_.size() == want;
+    if (!s->has_ik) v_.assign(want, 0.0f);
+    ar.add(&s->m.ik_tab, v_);
+  }
   { std::vector<int> v; blob_i(s->blob, "arm_qposadr", v); m.narmj = (int)v.size(); blob_i(s->blob, "grip_qposadr", v); m.ngripj = (int)v.size(); }
   LI(conn_siteid, "conn_siteid"); LI(conn_partid, "conn_partid"); LI(conn_keya, "conn_keya"); LI(conn_keyb, "conn_keyb"); LI(conn_nangle, "conn_nangle");
   LF(conn_angles, "conn_angles");
@@ -424,7 +430,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
-  if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent != 0 || s->cfg.dense_reward || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer agent, sparse reward, on a model compiled with the IK chain table"); }
+  if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || s->cfg.dense_reward || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, sparse reward, on a model compiled with the IK chain table"); }
   if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built; the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl", cfg ? cfg->control_type : 0); }
   if (env_controller_kind(s->cfg)) {
     if (s->m.agent != 0 || s->cfg.dense_reward) { delete s; FAIL(FSIM_EINVAL, "arm controllers (control_type 2..6) are built for the Sawyer agent, sparse reward"); }

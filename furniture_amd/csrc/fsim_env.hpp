@@ -43,7 +43,7 @@ struct EnvIO {
 
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
-  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 || c.control_type == 8 ? EI_WORDS : 0)));
+  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 || c.control_type == 8 ? EI_WORDS * m.narm : 0)));
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
@@ -66,7 +66,10 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
   }
   e.ik = c.control_type == 7 ? 1 : (c.control_type == 8 ? 2 : 0);
-  if (e.ik) { e.dof_action = e.ik == 1 ? 8 : 9; e.obs_dim = 7 * m.nparts + 15 * m.narm; } // furniture_sawyer.py:40-62
+  if (e.ik) { // [per arm: dpos 3, rotation 3 | quaternion 4] + one grip per arm + connect (furniture_sawyer.py:52-64, furniture_baxter.py:26-37)
+    e.dof_action = m.narm * (3 + (e.ik == 1 ? 3 : 4)) + m.narm + 1;
+    e.obs_dim = 7 * m.nparts + 15 * m.narm;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
@@ -809,17 +812,20 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
   float connect = io.action[dof - 1];
   if (cfg.ik) {
-    // _do_ik_step (furniture.py:2911-2924): d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed in env_ik)
-    float *K = L + ly.env + E_GROUP + m.nparts;
-    const int ng = cfg.ik == 1 ? 6 : 7; // index of the grip entry: [dpos 3, rotation 3 | quaternion 4, grip, connect]
-    if (c.lane <= ng) {
+    // _do_ik_step (furniture.py:2911-2958, 2999-3018): per arm d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed
+    // in env_ik); the grips follow the arm commands, the last entry is connect.  Block layout per arm: EI_ACT + [dpos 3, rot 3|4, grip]
+    const int nrot = cfg.ik == 1 ? 3 : 4, stride = 3 + nrot;
+    for (int t = c.lane; t < m.narm * (stride + 1); t += 64) {
+      const int arm = t / (stride + 1), k = t % (stride + 1);
+      float *K = L + ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+      const float *aa = io.action + arm * stride;
       float v;
-      if (c.lane == 0) v = -io.action[1] * cfg.move_speed;
-      else if (c.lane == 1) v = io.action[0] * cfg.move_speed;
-      else if (c.lane == 2) v = io.action[2] * cfg.move_speed;
-      else if (c.lane < ng) v = io.action[c.lane];
-      else { v = io.action[ng]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
-      K[EI_ACT + c.lane] = v;
+      if (k == 0) v = -aa[1] * cfg.move_speed;
+      else if (k == 1) v = aa[0] * cfg.move_speed;
+      else if (k == 2) v = aa[2] * cfg.move_speed;
+      else if (k < stride) v = aa[k];
+      else { v = io.action[m.narm * stride + arm]; if (cfg.discrete_grip && cfg.agent == 0) v = v < 0 ? -1.0f : 1.0f; } // furniture_sawyer.py:72-74
+      K[EI_ACT + k] = v;
     }
   } else if (cfg.controller) {
     // FurnitureSawyerEnv._step discretises the grip (furniture_sawyer.py:72-74); _do_controller_step scales the first three
@@ -872,13 +878,22 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   } else if (cfg.ik) {
     SYNC();
     env_ik(c, cfg.rotate_speed, cfg.ik);
-    const float *K = L + ly.env + E_GROUP + m.nparts;
+    const float *K0 = L + ly.env + E_GROUP + m.nparts;
+    const float pgain = GP(m.ik_tab)[IKT_ARM * m.narm + IKT_GAIN];
+    const int ng = 3 + (cfg.ik == 1 ? 3 : 4); // offset of the grip entry inside EI_ACT
     for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions
-      // get_control's P controller (sawyer_ik_controller.py:75-84), then _setup_action on [velocities, gripper]
+      // get_control's P controller (sawyer_ik_controller.py:75-84, baxter_ik_controller.py:86-95), then _setup_action on [velocities, grips]
       for (int u = c.lane; u < m.nu; u += 64) {
         float a;
-        if (u < 7) a = fminf(fmaxf(-5.0f * (L[ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u]), -1.0f), 1.0f);
-        else { a = K[EI_ACT + (cfg.ik == 1 ? 6 : 7)]; if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f); if ((u - 7) & 1) a = -a; }
+        if (u < m.narmj) {
+          const float *K = K0 + EI_WORDS * (u / 7);
+          a = fminf(fmaxf(-pgain * (L[ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u % 7]), -1.0f), 1.0f);
+        } else {
+          const float *K = K0 + EI_WORDS * ((u - m.narmj) >> 1);
+          a = K[EI_ACT + ng];
+          if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
+          if ((u - m.narmj) & 1) a = -a;
+        }
         L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
       }
       SYNC();

@@ -15,8 +15,10 @@
 enum { EI_TARGET = 0 /* ik_robot_target_pos, base frame */, EI_IQUAT = 3 /* _initial_right_hand_quat, raw 4 numbers */,
        EI_QCMD = 7 /* commanded_joint_positions */, EI_ACT = 14 /* scaled+permuted d_pos (3), then ik: rotation action (3), grip | ik_quaternion: quaternion wxyz (4), grip */, EI_HPOS = 22 /* right_hand world position of the last forward pass (what the next step's _bounded_d_pos reads) */,
        EI_WORDS = 26 };
-// m.ik_tab layout (floats): joint_pos 7x3 | joint_quat 7x4 (wxyz) | eef_pos 3 | rest 7 | base_pos 3 | base_quat 4
-enum { IKT_JPOS = 0, IKT_JQUAT = 21, IKT_EEF = 49, IKT_REST = 52, IKT_BPOS = 59, IKT_BQUAT = 62, IKT_WORDS = 66 };
+// m.ik_tab layout (floats), per arm (stride IKT_ARM): joint_pos 7x3 | joint_quat 7x4 (wxyz) | eef_pos 3 | eef_quat 4 | rest 7 | lower 7 |
+// upper 7; after the last arm: base_pos 3 | base_quat 4 | user_sensitivity | P gain | rest mode (0 table, 1 current joints) | Rz(-90) flag
+enum { IKT_JPOS = 0, IKT_JQUAT = 21, IKT_EEF = 49, IKT_EEFQ = 52, IKT_REST = 56, IKT_LOWER = 63, IKT_UPPER = 70, IKT_ARM = 77,
+       IKT_BPOS = 0, IKT_BQUAT = 3, IKT_SENS = 7, IKT_GAIN = 8, IKT_RESTMODE = 9, IKT_RZ = 10, IKT_TAIL = 11 };
 #define IK_ITERS 12
 #define IK_TAIL 4
 #define IK_DAMP2 (0.05f * 0.05f)
@@ -24,21 +26,21 @@ enum { IKT_JPOS = 0, IKT_JQUAT = 21, IKT_EEF = 49, IKT_REST = 52, IKT_BPOS = 59,
 
 struct IkFk { V3 p; M3 R; V3 o[7], z[7]; };
 // forward kinematics of the URDF chain: child = parent . Trans(xyz) . Rot(rpy) . Rz(q_i); end effector = CoM frame of link 6
-DEV void ik_fk(CModel &m, const float *q, IkFk &f) {
+template <class TP> DEV void ik_fk(TP tab, const float *q, IkFk &f) {
   M3 R; for (int i = 0; i < 9; i++) R.m[i] = (i & 3) == 0 ? 1.0f : 0.0f;
   V3 p = v3(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 7; i++) {
-    p = p + mulv(R, ldv3(GP(m.ik_tab) + IKT_JPOS + 3 * i));
-    R = mulm(R, q2m(qnormalized(ldq(GP(m.ik_tab) + IKT_JQUAT + 4 * i))));
+    p = p + mulv(R, ldv3(tab + IKT_JPOS + 3 * i));
+    R = mulm(R, q2m(qnormalized(ldq(tab + IKT_JQUAT + 4 * i))));
     f.o[i] = p; f.z[i] = colv(R, 2);
     float s, cq;
     sincosf(q[i], &s, &cq);
     M3 Z; Z.m[0] = cq; Z.m[1] = -s; Z.m[2] = 0; Z.m[3] = s; Z.m[4] = cq; Z.m[5] = 0; Z.m[6] = 0; Z.m[7] = 0; Z.m[8] = 1;
     R = mulm(R, Z);
   }
-  f.p = p + mulv(R, ldv3(GP(m.ik_tab) + IKT_EEF));
-  f.R = R;
+  f.p = p + mulv(R, ldv3(tab + IKT_EEF));
+  f.R = mulm(R, q2m(qnormalized(ldq(tab + IKT_EEFQ)))); // (identity for Sawyer: the product is then exact)
 }
 // axis * angle of a rotation matrix
 DEV V3 ik_rotvec(const M3 &R) {
@@ -82,9 +84,9 @@ DEV void ik_solve6(const float *A, float *b) {
   }
 }
 // hand (right_hand body) pose of the last forward pass
-DEV void ik_hand_world(const Ctx &c, V3 *pos, M3 *R) {
+DEV void ik_hand_world(const Ctx &c, int arm, V3 *pos, M3 *R) {
   CModel &m = c.m;
-  const int hb = GP(m.hand_body)[0], rb = GP(m.body_red)[hb];
+  const int hb = GP(m.hand_body)[arm], rb = GP(m.body_red)[hb];
   const M3 Rb = ldm3(c.L + c.ly.xmat + 9 * rb);
   *pos = ldv3(c.L + c.ly.xpos + 3 * rb) + mulv(Rb, ldv3(GP(m.body_relpos) + 3 * hb));
   *R = mulm(Rb, q2m(qnormalized(ldq(GP(m.body_relquat) + 4 * hb))));
@@ -100,24 +102,27 @@ DEV void ik_mat2quat_xyzw(const M3 &R, float *q) {
   q[0] = x; q[1] = y; q[2] = z; q[3] = w;
 }
 
-// end of _reset (furniture.py:1643-1650): _initial_right_hand_quat = _right_hand_quat; controller.sync_state()
+// end of _reset (furniture.py:1643-1650): _initial_<arm>_hand_quat = _<arm>_hand_quat; controller.sync_state()
 DEV void env_ik_sync(const Ctx &c) {
   CModel &m = c.m;
-  float *K = c.L + c.ly.env + E_GROUP + m.nparts;
-  V3 hp; M3 hR;
-  ik_hand_world(c, &hp, &hR);
-  M3 Rb = q2m(qnormalized(ldq(GP(m.ik_tab) + IKT_BQUAT)));
-  float iq[4];
-  ik_mat2quat_xyzw(mulm(ck_transpose(Rb), hR), iq); // hand orientation in the frame of body "base" (furniture.py:3380-3427)
-  float q[7];
+  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
+  for (int arm = 0; arm < m.narm; arm++) {
+    float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+    V3 hp; M3 hR;
+    ik_hand_world(c, arm, &hp, &hR);
+    float iq[4];
+    ik_mat2quat_xyzw(mulm(RbT, hR), iq); // hand orientation in the frame of body "base" (furniture.py:3380-3457)
+    float q[7];
 #pragma unroll
-  for (int i = 0; i < 7; i++) q[i] = c.L[c.ly.qpos + GP(m.arm_qposadr)[i]];
-  IkFk f;
-  ik_fk(m, q, f);
-  if (c.lane == 0) {
-    stv3(K + EI_TARGET, f.p); // ik_robot_target_pos := the IK chain's own end-effector position (sync_state :86-99)
-    for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = iq[i];
-    stv3(K + EI_HPOS, hp);
+    for (int i = 0; i < 7; i++) q[i] = c.L[c.ly.qpos + GP(m.arm_qposadr)[7 * arm + i]];
+    IkFk f;
+    ik_fk(GP(m.ik_tab) + IKT_ARM * arm, q, f);
+    if (c.lane == 0) {
+      stv3(K + EI_TARGET, f.p); // ik_robot_target_pos := the IK chain's own end-effector position (sync_state)
+      for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = iq[i];
+      stv3(K + EI_HPOS, hp);
+    }
   }
   SYNC();
 }
@@ -127,14 +132,18 @@ DEV void env_ik_sync(const Ctx &c) {
 // LDS does not survive the launch, so they are kept in the env record.
 DEV void env_ik_remember(const Ctx &c, int mode) {
   CModel &m = c.m;
-  float *K = c.L + c.ly.env + E_GROUP + m.nparts;
-  V3 hp; M3 hR;
-  ik_hand_world(c, &hp, &hR);
-  float rh[4];
-  ik_mat2quat_xyzw(mulm(ck_transpose(q2m(qnormalized(ldq(GP(m.ik_tab) + IKT_BQUAT)))), hR), rh);
-  if (c.lane == 0) {
-    stv3(K + EI_HPOS, hp);
-    if (mode == 2) for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = rh[i];
+  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
+  for (int arm = 0; arm < m.narm; arm++) {
+    float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+    V3 hp; M3 hR;
+    ik_hand_world(c, arm, &hp, &hR);
+    float rh[4];
+    ik_mat2quat_xyzw(mulm(RbT, hR), rh);
+    if (c.lane == 0) {
+      stv3(K + EI_HPOS, hp);
+      if (mode == 2) for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = rh[i];
+    }
   }
   SYNC();
 }
@@ -143,7 +152,13 @@ DEV void env_ik_remember(const Ctx &c, int mode) {
 __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
   FS_REBUILD_CTX(cv);
   CModel &m = c.m;
-  float *K = c.L + c.ly.env + E_GROUP + m.nparts;
+  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const float sens = tail[IKT_SENS];
+  const bool rest_current = tail[IKT_RESTMODE] != 0.0f, rz = tail[IKT_RZ] != 0.0f;
+#pragma unroll 1
+  for (int arm = 0; arm < m.narm; arm++) {
+  const auto tab = GP(m.ik_tab) + IKT_ARM * arm;
+  float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
   const V3 hp = ldv3(K + EI_HPOS);
   // _bounded_d_pos (furniture.py:1252-1258, limits :170-171)
   V3 a = ldv3(K + EI_ACT);
@@ -169,17 +184,19 @@ __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
   rot = q2m(qnormalized(q4(qi.z, qi.w, qi.x, qi.y))); // raw (r0, r1, r2, r3) as xyzw -> w = r3 (= qi.z), x = r0 (= qi.w) ...
   }
   // joint_positions_for_eef_command (:227-269): target += dpos * user_sensitivity; orientation . Rz(-90 deg)
-  const V3 tp = ldv3(K + EI_TARGET) + dpos * 0.3f;
-  M3 Zm; Zm.m[0] = 0; Zm.m[1] = 1; Zm.m[2] = 0; Zm.m[3] = -1; Zm.m[4] = 0; Zm.m[5] = 0; Zm.m[6] = 0; Zm.m[7] = 0; Zm.m[8] = 1; // Rz(-pi/2)
-  const M3 tR = mulm(rot, Zm);
-  float q[7];
+  const V3 tp = ldv3(K + EI_TARGET) + dpos * sens;
+  M3 tR = rot;
+  if (rz) { // Sawyer: the commanded hand orientation . Rz(-90 deg) is the target of link right_l6 (sawyer_ik_controller.py:248-254)
+    M3 Zm; Zm.m[0] = 0; Zm.m[1] = 1; Zm.m[2] = 0; Zm.m[3] = -1; Zm.m[4] = 0; Zm.m[5] = 0; Zm.m[6] = 0; Zm.m[7] = 0; Zm.m[8] = 1;
+    tR = mulm(rot, Zm);
+  }
+  float q[7], q0[7], lo[7], hi[7];
 #pragma unroll
-  for (int i = 0; i < 7; i++) q[i] = c.L[c.ly.qpos + GP(m.arm_qposadr)[i]];
-  const float lo[7] = {-3.05f, -3.82f, -3.05f, -3.05f, -2.98f, -2.98f, -4.71f}, hi[7] = {3.05f, 2.28f, 3.05f, 3.05f, 2.98f, 2.98f, 4.71f};
+  for (int i = 0; i < 7; i++) { q[i] = q0[i] = c.L[c.ly.qpos + GP(m.arm_qposadr)[7 * arm + i]]; lo[i] = tab[IKT_LOWER + i]; hi[i] = tab[IKT_UPPER + i]; }
 #pragma unroll 1
   for (int it = 0; it < IK_ITERS; it++) {
     IkFk f;
-    ik_fk(m, q, f);
+    ik_fk(tab, q, f);
     V3 ep = tp - f.p, er = ik_rotvec(mulm(tR, ck_transpose(f.R)));
     float J[6][7];
 #pragma unroll
@@ -209,7 +226,7 @@ __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
     if (it < IK_ITERS - IK_TAIL) { // null-space pull towards rest_poses (:263), projected with the same damped inverse
       float n[7], y2[6];
 #pragma unroll
-      for (int i = 0; i < 7; i++) n[i] = IK_NULL_GAIN * (GP(m.ik_tab)[IKT_REST + i] - q[i]);
+      for (int i = 0; i < 7; i++) n[i] = IK_NULL_GAIN * ((rest_current ? q0[i] : tab[IKT_REST + i]) - q[i]); // Baxter rests at the current joints (:321)
 #pragma unroll
       for (int r = 0; r < 6; r++) { float s = 0;
 #pragma unroll
@@ -231,5 +248,6 @@ __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
 #pragma unroll
     for (int i = 0; i < 7; i++) K[EI_QCMD + i] = q[i];
   }
+  } // arm
   SYNC();
 }

@@ -190,8 +190,10 @@ class FurnitureBatchEnv:
             raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
                                       "controllers / ik %s (the reference's 'torque' path writes an 8-vector into "
                                       "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
-        if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and (agent != "Sawyer" or dense):
-            raise NotImplementedError("the arm controllers are built for the Sawyer agent with the sparse reward")
+        if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and dense:
+            raise NotImplementedError("the dense-reward env runs with control_type 'impedance' (config/furniture_sawyer_dense.py:7)")
+        if agent == "Baxter" and cfg.control_type in CONTROLLER_CODES and cfg.control_type not in ("ik", "ik_quaternion"):
+            raise NotImplementedError("the torque-level arm controllers are built for Sawyer (the reference's Baxter path mis-indexes ctrl)")
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them

@@ -222,27 +222,51 @@ def build_model(agent, furniture_name, control_type="impedance", assets_root=Non
     else:
         A["eef_siteid"] = np.zeros(0, np.int32)
         A["hand_bodyid"] = np.zeros(0, np.int32)
-    if agent == "Sawyer":
-        # IK controller tables (control_type "ik"): the pybullet URDF chain (controllers/sawyer_ik_controller.py:112-125), its rest
-        # pose (:196, :263) and the world pose of the MJCF body "base" (pose_in_base_from_name, furniture.py:3380-3396; the base
-        # has no joint above it, so the pose is static)
-        from .urdf_chain import load_chain
-        A.update(load_chain(os.path.join(assets_root, "bullet_data", "sawyer_description", "urdf", "sawyer_arm.urdf")))
-        A["ik_rest"] = np.array([0, -1.18, 0.00, 2.18, 0.00, 0.57, 3.3161])
+    if agent in ("Sawyer", "Baxter"):
+        # IK controller tables (control_type "ik" / "ik_quaternion"): the pybullet URDF chain(s) the reference's IK controller solves
+        # on, per arm (controllers/sawyer_ik_controller.py:112-125, baxter_ik_controller.py:118-137), its rest pose / limits / gains,
+        # and the world pose of the MJCF body "base" (pose_in_base_from_name, furniture.py:3380-3396; no joint above it: static)
+        from .urdf_chain import load_chain, load_tree_chain
         from ..transform_utils import Quaternion
-        b = m.body_names.index("base")
+        bd = os.path.join(assets_root, "bullet_data")
+        if agent == "Sawyer":
+            c = load_chain(os.path.join(bd, "sawyer_description", "urdf", "sawyer_arm.urdf"))
+            chains = [dict(joint_pos=c["ik_joint_pos"], joint_quat=c["ik_joint_quat"], eef_pos=c["ik_eef_pos"], eef_quat=np.array([1.0, 0, 0, 0]),
+                           rest=np.array([0, -1.18, 0.00, 2.18, 0.00, 0.57, 3.3161]),                            # :196, :263
+                           lower=np.array([-3.05, -3.82, -3.05, -3.05, -2.98, -2.98, -4.71]),                      # :207
+                           upper=np.array([3.05, 2.28, 3.05, 3.05, 2.98, 2.98, 4.71]))]                            # :208
+            # user_sensitivity (:47), P gain (:82), rest pose: fixed (0) / current joints (1), Rz(-90 deg) end-effector convention (:248-254)
+            params = np.array([0.3, 5.0, 0.0, 1.0])
+        else:
+            urdf = os.path.join(bd, "baxter_description", "urdf", "baxter_mod.urdf")
+            chains = []
+            for eff, act in ((27, [13, 14, 15, 16, 17, 19, 20]), (45, [31, 32, 33, 34, 35, 37, 38])):  # baxter_ik_controller.py:124-137
+                c = load_tree_chain(urdf, eff, act)
+                chains.append(dict(joint_pos=c["joint_pos"], joint_quat=c["joint_quat"], eef_pos=c["eef_pos"], eef_quat=c["eef_quat"],
+                                   rest=np.zeros(7), lower=c["limits"][:, 0], upper=c["limits"][:, 1]))  # lower / upper: getJointInfo (:146-152)
+            params = np.array([1.0, 2.0, 1.0, 0.0])  # user_sensitivity (:43), P gain -2 (:92), rest = current joints (:321), no Rz convention
+        A["ik_joint_pos"] = np.concatenate([c["joint_pos"] for c in chains])          # [narm * 7, 3]
+        A["ik_joint_quat"] = np.concatenate([c["joint_quat"] for c in chains])        # [narm * 7, 4] wxyz
+        A["ik_eef_pos"] = np.stack([c["eef_pos"] for c in chains])                    # [narm, 3]
+        A["ik_eef_quat"] = np.stack([c["eef_quat"] for c in chains])                  # [narm, 4]
+        A["ik_rest"] = np.stack([c["rest"] for c in chains])
+        A["ik_lower"], A["ik_upper"] = np.stack([c["lower"] for c in chains]), np.stack([c["upper"] for c in chains])
+        A["ik_params"] = params
+        b_ = m.body_names.index("base")
         pos, quat = np.zeros(3), Quaternion([1, 0, 0, 0])
-        chain = []
-        while b > 0:
-            chain.append(b)
-            b = int(m.body_parentid[b])
-        for b in reversed(chain):
-            pos = pos + quat.rotate(m.body_pos[b])
-            quat = quat * Quaternion(m.body_quat[b])
+        up = []
+        while b_ > 0:
+            up.append(b_)
+            b_ = int(m.body_parentid[b_])
+        for b_ in reversed(up):
+            pos = pos + quat.rotate(m.body_pos[b_])
+            quat = quat * Quaternion(m.body_quat[b_])
         A["ik_base_pos"], A["ik_base_quat"] = np.asarray(pos, dtype=np.float64), np.array(list(quat), dtype=np.float64)
-        # one flat table for the device (csrc/fsim_ik.hpp IKT_*)
-        A["ik_table"] = np.concatenate([A["ik_joint_pos"].reshape(-1), A["ik_joint_quat"].reshape(-1), A["ik_eef_pos"], A["ik_rest"],
-                                        A["ik_base_pos"], A["ik_base_quat"]])
+        # one flat table for the device (csrc/fsim_ik.hpp IKT_*): per arm [joint_pos 21 | joint_quat 28 | eef_pos 3 | eef_quat 4 | rest 7 |
+        # lower 7 | upper 7] = 77 floats, then [base_pos 3 | base_quat 4 | params 4]
+        blocks = [np.concatenate([c["joint_pos"].reshape(-1), c["joint_quat"].reshape(-1), c["eef_pos"], c["eef_quat"], c["rest"], c["lower"], c["upper"]])
+                  for c in chains]
+        A["ik_table"] = np.concatenate(blocks + [A["ik_base_pos"], A["ik_base_quat"], params])
     if agent == "Cursor":
         A["cursor_bodyid"] = np.array([m.body_names.index("cursor0"), m.body_names.index("cursor1")], dtype=np.int32)
         A["cursor_geomid"] = np.array([m.geom_names.index("cursor0"), m.geom_names.index("cursor1")], dtype=np.int32)

@@ -43,19 +43,22 @@ def q2m(q):  # wxyz -> 3x3
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
-def fk(model, q):
-    """Pose of the end-effector frame (CoM frame of right_l6) in the arm base frame, plus joint origins and axes.
-    URDF joint: child = parent . Trans(xyz) . Rot(rpy) . Rz(q_i)."""
+def fk(model, q, arm=0):
+    """Pose of the end-effector frame (CoM frame of the IK chain's end link: right_l6 for Sawyer, right / left_gripper for Baxter) in
+    the robot base frame, plus joint origins and axes.  URDF joint: child = parent . Trans(xyz) . Rot(rpy) . Rz(q_i); fixed joints
+    are folded into the following joint's origin (furniture_amd/mjcf/urdf_chain.py)."""
     R, p = np.eye(3), np.zeros(3)
     origins, axes = [], []
+    jp, jq = model.ik_joint_pos[7 * arm:7 * arm + 7], model.ik_joint_quat[7 * arm:7 * arm + 7]
     for i in range(7):
-        p = p + R @ model.ik_joint_pos[i]
-        R = R @ q2m(model.ik_joint_quat[i])
+        p = p + R @ jp[i]
+        R = R @ q2m(jq[i])
         origins.append(p.copy())
         axes.append(R[:, 2].copy())
         c, s = np.cos(q[i]), np.sin(q[i])
         R = R @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
-    return p + R @ model.ik_eef_pos, R, np.array(origins), np.array(axes)
+    eq = np.asarray(model.ik_eef_quat, float).reshape(-1, 4)[arm]
+    return p + R @ np.asarray(model.ik_eef_pos, float).reshape(-1, 3)[arm], R @ q2m(eq), np.array(origins), np.array(axes)
 
 
 def rotvec(R):
@@ -68,12 +71,15 @@ def rotvec(R):
     return v * (np.arctan2(s, c) / s)
 
 
-def solve(model, q0, target_pos, target_R, iters=IK_ITERS):
-    """joint_positions_for_eef_command's inner solve: from the current joints to the target pose (both in the base frame)."""
+def solve(model, q0, target_pos, target_R, iters=IK_ITERS, arm=0, rest=None):
+    """joint_positions_for_eef_command's inner solve: from the current joints to the target pose (both in the base frame).
+    rest: the rest pose handed to the solver (Sawyer: a fixed pose; Baxter: the current joints, baxter_ik_controller.py:321)."""
     q = np.array(q0, dtype=float)
-    rest = np.asarray(model.ik_rest, float)
+    rest = np.asarray(model.ik_rest, float).reshape(-1, 7)[arm] if rest is None else np.asarray(rest, float)
+    lower = np.asarray(getattr(model, "ik_lower", IK_LOWER), float).reshape(-1, 7)[arm]
+    upper = np.asarray(getattr(model, "ik_upper", IK_UPPER), float).reshape(-1, 7)[arm]
     for k in range(iters):
-        p, R, o, z = fk(model, q)
+        p, R, o, z = fk(model, q, arm)
         e = np.concatenate([target_pos - p, rotvec(target_R @ R.T)])
         J = np.zeros((6, 7))
         for i in range(7):
@@ -85,7 +91,7 @@ def solve(model, q0, target_pos, target_R, iters=IK_ITERS):
         if k < iters - IK_TAIL:
             n = IK_NULL_GAIN * (rest - q)
             dq = dq + n - J.T @ np.linalg.solve(A, J @ n)
-        q = np.clip(q + dq, IK_LOWER, IK_UPPER)
+        q = np.clip(q + dq, lower, upper)
     return q
 
 
@@ -94,27 +100,38 @@ def rot_z(angle):
     return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
 
 
-def velocities(q, q_cmd):
-    """get_control's P controller (:75-84)."""
-    return np.clip(-5.0 * (np.asarray(q) - np.asarray(q_cmd)), -1.0, 1.0)
+def velocities(q, q_cmd, gain=5.0):
+    """get_control's P controller (sawyer_ik_controller.py:75-84: -5 delta; baxter_ik_controller.py:86-95: -2 delta), clipped to +-1."""
+    return np.clip(-gain * (np.asarray(q) - np.asarray(q_cmd)), -1.0, 1.0)
 
 
-def preprocess(control_type, action, move_speed, rotate_speed, hand_pos, right_hand_quat, initial_quat):
-    """FurnitureEnv._do_ik_step up to the controller call (furniture.py:2911-2924 for "ik", :2999-3027 for "ik_quaternion") and
-    _make_input (:1332-1343): -> (d_pos, rotation 3x3, new _initial_right_hand_quat, gripper action).  The reference hands the xyzw
-    quaternion _initial_right_hand_quat to euler_to_quat, whose pyquaternion reads it as wxyz: the same functions are used here in
-    the same way (pinned by tests/golden/controllers.npz, ikstep_*)."""
+def arm_action_slices(agent, control_type, arm):
+    """Where an arm's command sits in the env action (furniture.py:2911-2958, 2994-3018): -> (dpos slice, rotation slice, grip index
+    from the END of the action).  Sawyer: [dpos 3, rot 3 | quat 4, grip, connect]; Baxter: [right dpos, rot, left dpos, rot, grip_r,
+    grip_l, connect]."""
+    nrot = 3 if control_type == "ik" else 4
+    narm = 1 if agent == "Sawyer" else 2
+    o = arm * (3 + nrot)
+    return slice(o, o + 3), slice(o + 3, o + 3 + nrot), -(1 + narm) + arm
+
+
+def preprocess(control_type, action, move_speed, rotate_speed, hand_pos, right_hand_quat, initial_quat, agent="Sawyer", arm=0):
+    """FurnitureEnv._do_ik_step up to the controller call (furniture.py:2911-2958 for "ik", :2999-3027 for "ik_quaternion") and
+    _make_input (:1332-1343), for one arm: -> (d_pos, rotation 3x3, new _initial_<arm>_hand_quat, gripper action).  The reference
+    hands the xyzw quaternion _initial_right_hand_quat to euler_to_quat, whose pyquaternion reads it as wxyz: the same functions are
+    used here in the same way (pinned by tests/golden/controllers.npz, ikstep_*)."""
     from furniture_amd import transform_utils as T
     action = np.array(action, dtype=float)
-    action[:3] = action[:3] * move_speed
-    action[:3] = [-action[1], action[0], action[2]]
+    sp, sr, ig = arm_action_slices(agent, control_type, arm)
+    dp = action[sp] * move_speed
+    dp = np.array([-dp[1], dp[0], dp[2]])
     hand_pos = np.asarray(hand_pos, float)
-    d_pos = np.clip(action[:3], np.array([-1.5, -1.5, 0.0]) - hand_pos, np.array([1.5, 1.5, 1.5]) - hand_pos)  # :170-171, 1252-1258
+    d_pos = np.clip(dp, np.array([-1.5, -1.5, 0.0]) - hand_pos, np.array([1.5, 1.5, 1.5]) - hand_pos)  # :170-171, 1252-1258
     if control_type == "ik_quaternion":
-        d_quat = T.convert_quat(action[3:7])
+        d_quat = T.convert_quat(action[sr])
         new_initial = np.asarray(initial_quat, float)
     else:
-        new_initial = np.array(T.euler_to_quat(action[3:6] * rotate_speed, initial_quat))
+        new_initial = np.array(T.euler_to_quat(action[sr] * rotate_speed, initial_quat))
         d_quat = T.quat_multiply(T.quat_inverse(right_hand_quat), new_initial)
     rotation = T.quat2mat(T.quat_multiply(right_hand_quat, d_quat))
-    return d_pos, rotation, new_initial, action[-2]
+    return d_pos, rotation, new_initial, action[ig]

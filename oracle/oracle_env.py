@@ -114,7 +114,7 @@ class FurnitureEnvOracle:
         self._ik = self.cfg.control_type in ("ik", "ik_quaternion")
         if self._ik:
             from oracle import ik as IK
-            assert self.agent == "Sawyer"
+            assert self.agent in ("Sawyer", "Baxter")
             self._IK = IK
             self._action_repeat = 3  # furniture.py:172
         elif self.cfg.control_type != "impedance":
@@ -268,8 +268,10 @@ class FurnitureEnvOracle:
         if self._ik:
             # F.py:1643-1650: _initial_right_hand_quat = _right_hand_quat (xyzw, hand orientation in the robot base frame);
             # controller.sync_state(): the IK target position := the IK chain's own forward kinematics at the current joints
-            self._initial_right_hand_quat = self._right_hand_quat()
-            self._ik_target_pos = self._IK.fk(m, sim.data.qpos[m.arm_qposadr])[0]
+            na = len(self.arms)
+            self._initial_hand_quat = [self._hand_quat(a) for a in range(na)]
+            self._ik_tp = [self._IK.fk(m, sim.data.qpos[m.arm_qposadr[7 * a:7 * a + 7]], a)[0] for a in range(na)]
+            self._initial_right_hand_quat, self._ik_target_pos = self._initial_hand_quat[0], self._ik_tp[0]
         self._get_next_subtask()
         # _after_reset
         self._episode_reward = 0
@@ -583,28 +585,40 @@ class FurnitureEnvOracle:
             self.reset()
             self._fail = True
 
-    def _right_hand_quat(self):
-        """F.py:3380-3427: mat2quat of the right_hand orientation in the frame of the body 'base' (data of the last forward pass)."""
+    def _hand_quat(self, arm=0):
+        """F.py:3380-3457: mat2quat of the <arm>_hand orientation in the frame of the body 'base' (data of the last forward pass)."""
         m, d = self.m, self.sim.data
         Rb = self._IK.q2m(np.asarray(m.ik_base_quat, float))
-        return T.mat2quat(Rb.T @ d.xmat[int(m.hand_bodyid[0])].reshape(3, 3))
+        return T.mat2quat(Rb.T @ d.xmat[int(m.hand_bodyid[arm])].reshape(3, 3))
+
+    def _right_hand_quat(self):
+        return self._hand_quat(0)
 
     def _do_ik_step(self, action):
-        """F.py:2899-2991 (Sawyer, control_type 'ik') over oracle/ik.py instead of pybullet.  Note the reference feeds the xyzw
-        quaternion `_initial_right_hand_quat` to euler_to_quat, whose pyquaternion reads it as wxyz (F.py:2917-2919): the same
-        functions are used here in the same way, so the commanded orientation is garbled identically."""
+        """F.py:2899-3063 (control_type 'ik' / 'ik_quaternion', Sawyer and Baxter) over oracle/ik.py instead of pybullet.  Note the
+        reference feeds the xyzw quaternion `_initial_<arm>_hand_quat` to euler_to_quat, whose pyquaternion reads it as wxyz
+        (F.py:2917-2919): the same functions are used here in the same way, so the commanded orientation is garbled identically."""
         IK, m, d = self._IK, self.m, self.sim.data
-        d_pos, rotation, self._initial_right_hand_quat, gripper_dis = IK.preprocess(
-            self.cfg.control_type, action, self.cfg.move_speed, self.cfg.rotate_speed, d.xpos[int(m.hand_bodyid[0])],
-            self._right_hand_quat(), self._initial_right_hand_quat)
-        # SawyerIKController.get_control -> joint_positions_for_eef_command (sawyer_ik_controller.py:51-88, 227-269)
-        self._ik_target_pos = self._ik_target_pos + d_pos * IK.USER_SENSITIVITY
-        target_R = rotation @ IK.rot_z(-np.pi / 2)
+        sens, gain, rest_current, rz = [float(v) for v in m.ik_params]
+        na = len(self.arms)
+        grips, qcmd = [], []
+        for a in range(na):
+            d_pos, rotation, self._initial_hand_quat[a], g = IK.preprocess(
+                self.cfg.control_type, action, self.cfg.move_speed, self.cfg.rotate_speed, d.xpos[int(m.hand_bodyid[a])],
+                self._hand_quat(a), self._initial_hand_quat[a], self.agent, a)
+            grips.append(g)
+            # <Robot>IKController.get_control -> joint_positions_for_eef_command (sawyer_ik_controller.py:51-88, 227-269;
+            # baxter_ik_controller.py:47-100, 296-333): the target moves by dpos * user_sensitivity in the base frame
+            self._ik_tp[a] = self._ik_tp[a] + d_pos * sens
+            target_R = rotation @ IK.rot_z(-np.pi / 2) if rz else rotation
+            qa = d.qpos[m.arm_qposadr[7 * a:7 * a + 7].astype(int)]
+            qcmd.append(IK.solve(m, qa, self._ik_tp[a], target_R, arm=a, rest=qa.copy() if rest_current else None))
+        self._ik_q_cmd = np.concatenate(qcmd)
+        self._initial_right_hand_quat, self._ik_target_pos = self._initial_hand_quat[0], self._ik_tp[0]
         arm_q = m.arm_qposadr.astype(int)
-        self._ik_q_cmd = IK.solve(m, d.qpos[arm_q], self._ik_target_pos, target_R)
         for i in range(self._action_repeat):
-            vel = IK.velocities(d.qpos[arm_q], self._ik_q_cmd)
-            ctrl = self._setup_action(np.concatenate([vel, [gripper_dis]]))
+            vel = IK.velocities(d.qpos[arm_q], self._ik_q_cmd, gain)
+            ctrl = self._setup_action(np.concatenate([vel, grips]))
             self._do_simulation(ctrl)
             if self._fail:
                 break

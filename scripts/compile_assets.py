@@ -15,7 +15,9 @@ from furniture_amd.mjcf import assemble, model  # noqa: E402
 DEFAULT = [
     ("Sawyer", "table_lack_0825"), ("Sawyer", "swivel_chair_0700"), ("Sawyer", "toy_table"),
     ("Sawyer", "chair_agne_0007"), ("Sawyer", "shelf_ivar_0678"), ("Baxter", "desk_mikael_1064"),
-    ("Baxter", "table_lack_0825"), ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"), ("Cursor", "swivel_chair_0700"),
+    ("Baxter", "table_lack_0825"), ("Baxter", "bench_bjoderna_0208"),  # furniture id 1: IKEABaxter-v0's default (furniture/env/__init__.py:47-57)
+    ("Cursor", "bed_dalselv_0270"),  # furniture id 0: IKEACursor-v0's default (furniture/env/__init__.py:19-29)
+    ("Cursor", "toy_table"), ("Cursor", "table_lack_0825"), ("Cursor", "swivel_chair_0700"),
     # motor-actuated robot (robot_torque.xml) for the torque-level arm controllers (furniture.py:1893)
     ("Sawyer", "table_lack_0825", "joint_torque"), ("Sawyer", "swivel_chair_0700", "joint_torque"),
 ]

@@ -34,7 +34,7 @@ def test_urdf_chain_equals_mjcf_kinematics(model):
         hand_R = Rb.T @ sim.data.xmat[hb].reshape(3, 3)
         l6_R = hand_R @ IK.rot_z(-np.pi / 2)
         l6_p = Rb.T @ (sim.data.xpos[hb] - pb) - l6_R @ np.array([0, 0, 0.0245])
-        assert np.abs(l6_p + l6_R @ m.ik_eef_pos - p).max() < 1e-6   # end effector = CoM frame of right_l6 (getLinkState()[0])
+        assert np.abs(l6_p + l6_R @ m.ik_eef_pos[0] - p).max() < 1e-6   # end effector = CoM frame of right_l6 (getLinkState()[0])
         assert np.abs(l6_R - R).max() < 1e-5                          # (the MJCF quaternion of right_hand is rounded to 6 digits)
 
 
@@ -271,4 +271,106 @@ def test_scripted_attach_on_the_device(model):
     assert ok.sum() >= (3 * n) // 4 and ok[0], (ncon, rew.round(1))
     for i in np.nonzero(ok)[0]:
         assert grp[i, 0] == 4 or grp[i, 4] == grp[i, 0] or grp[i, grp[i, 0]] == grp[i, 4]  # leg 0 and the table top in one group
+    env.close()
+
+
+def test_pybullet_joint_order_reproduces_the_reference_constants():
+    """baxter_ik_controller.py:124-137 hard-codes pybullet indices (effectors 27 / 45, arm joints 13-17, 19, 20 / 31-35, 37, 38): the
+    depth-first joint order of the URDF tree gives exactly those, and the resulting chains equal the MJCF kinematics (the URDF
+    gripper frame is the MJCF hand frame moved 2.5 cm along its z axis, both arms, any configuration)."""
+    m = load_compiled("Baxter", "desk_mikael_1064")
+    assert m.ik_joint_pos.shape == (14, 3) and m.ik_params.tolist() == [1.0, 2.0, 1.0, 0.0]
+    sim = OracleSim(m)
+    rng = np.random.RandomState(3)
+    Rb, pb = IK.q2m(m.ik_base_quat), m.ik_base_pos
+    for _ in range(3):
+        q = m.arm_initqpos + rng.uniform(-0.5, 0.5, 14)
+        sim.reset()
+        sim.data.qpos[m.arm_qposadr] = q
+        sim.forward()
+        for arm in range(2):
+            p, R, _, _ = IK.fk(m, q[7 * arm:7 * arm + 7], arm)
+            hb = int(m.hand_bodyid[arm])
+            hand_R = Rb.T @ sim.data.xmat[hb].reshape(3, 3)
+            hand_p = Rb.T @ (sim.data.xpos[hb] - pb)
+            assert np.abs(hand_R.T @ R - np.eye(3)).max() < 1e-5
+            assert np.abs(hand_R.T @ (p - hand_p) - np.array([0, 0, 0.025])).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ctype", ["ik", "ik_quaternion"])
+def test_device_baxter_ik_matches_oracle(ctype):
+    """Bimanual Baxter under IK control (IKEABaxter-v0's default control type): two chains, user_sensitivity 1, P gain 2, rest pose =
+    current joints, no Rz convention -- device vs the fp64 oracle env."""
+    from furniture_amd.sim import FSim, INFO_DIM, default_config
+    m, n = load_compiled("Baxter", "desk_mikael_1064"), 2
+    dof = 15 if ctype == "ik" else 17
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset, cfg.control_type = 150, 0, (7 if ctype == "ik" else 8)
+    sim = FSim(m, n, config=cfg)
+    assert sim.dof_action == dof and sim.obs_dim == 7 * m.nparts + 30
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10, control_type=ctype)) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    sim.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]),
+                         np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    for i, e in enumerate(envs):
+        assert np.abs(obs[i].cpu().numpy() - e.flat_obs(obs_o[i])).max() < 1e-4
+    act = torch.zeros((n, dof), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    rng = np.random.RandomState(8)
+    for t in range(3):
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
+        if ctype == "ik_quaternion":
+            for arm in range(2):
+                a[:, 7 * arm + 3] = 1.0
+                a[:, 7 * arm + 4:7 * arm + 7] *= 0.05
+        else:  # moderate rotation commands: a target a quarter turn away per step leaves the damped solve ill-conditioned in fp32
+            a[:, 3:6] *= 0.0 if t == 0 else 0.25
+            a[:, 9:12] *= 0.0 if t == 0 else 0.25
+        act.copy_(torch.as_tensor(a))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        blk = sim.get_state("env_block")["env_block"][:, -52:].cpu().numpy().view(np.float32)   # two EI blocks of 26 words
+        for i, e in enumerate(envs):
+            ob, r, d_, _ = e.step(a[i].astype(np.float64))
+            assert np.abs(obs[i].cpu().numpy() - e.flat_obs(ob)).max() < 3e-4
+            for arm in range(2):
+                assert np.abs(blk[i, 26 * arm + 7:26 * arm + 14] - e._ik_q_cmd[7 * arm:7 * arm + 7]).max() < 1e-4
+                assert np.abs(blk[i, 26 * arm:26 * arm + 3] - e._ik_tp[arm]).max() < 1e-5
+            assert abs(float(rew[i]) - r) < 1e-5 and bool(done[i]) == d_
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_default_baxter_gym_id_runs_with_ik():
+    """IKEABaxter-v0's defaults (control_type 'ik', furniture_id 1; furniture/env/__init__.py:47-57)."""
+    from furniture_amd.envs import furniture_names, make
+    from furniture_amd.mjcf.model import _COMPILED_DIR
+    import os
+    name = furniture_names()[1]
+    if not os.path.exists(os.path.join(_COMPILED_DIR, "Baxter__%s__vel.npz" % name)):
+        pytest.skip("the default Baxter furniture (%s) is not among the shipped compiled models" % name)
+    env = make("IKEABaxter-v0", unity=False, record_vid=False)
+    assert env.dof == 15
+    ob = env.reset()
+    ob, r, d, info = env.step(np.zeros(15, dtype=np.float32))
+    assert ob["robot_ob"].shape == (30,) and np.isfinite(ob["robot_ob"]).all()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_default_cursor_gym_id_runs():
+    """IKEACursor-v0's defaults (furniture_id 0 = bed_dalselv_0270; furniture/env/__init__.py:19-29)."""
+    from furniture_amd.envs import make
+    env = make("IKEACursor-v0", unity=False, record_vid=False)
+    ob = env.reset()
+    ob, r, d, info = env.step(np.zeros(15, dtype=np.float32))
+    assert np.isfinite(ob["object_ob"]).all() and ob["robot_ob"].shape == (8,)
     env.close()
