@@ -278,6 +278,48 @@ def main():
             rec.setdefault("vel", []).append(np.array(vel_seq))
         for k, v in rec.items():
             out["ikstep_%s_%s" % (ctype, k)] = np.array(v)
+    # ---- the same for Baxter (two arms: furniture.py:2925-2958, 3000-3018; get_control(right, left)) -----------------------------------
+    for ctype in ("ik", "ik_quaternion"):
+        rec = dict(act=[], hand_pos=[], rhq=[], init_in=[], dpos=[], rot=[], init_out=[], low=[], nsim=[], vel=[])
+        for t in range(16):
+            env = types.SimpleNamespace()
+            env._control_type, env._agent_type, env._arms = ctype, "Baxter", ["right", "left"]
+            env._move_speed, env._rotate_speed, env._action_repeat, env._record_demo = 0.1, 22.5, 3, False
+            env._min_gripper_pos, env._max_gripper_pos = np.array([-1.5, -1.5, 0.0]), np.array([1.5, 1.5, 1.5])
+            hp = {"right_hand": rng.uniform(-0.5, 0.5, 3) + np.array([0.0, 0.2, 0.6]), "left_hand": rng.uniform(-0.5, 0.5, 3) + np.array([0.0, 0.2, 0.02])}
+            rhq = [RT.mat2quat(rand_rot(rng).astype(np.float32)) for _ in range(2)]
+            init_q = [RT.mat2quat(rand_rot(rng).astype(np.float32)) for _ in range(2)]
+            env._right_hand_quat, env._left_hand_quat = rhq
+            env._initial_right_hand_quat, env._initial_left_hand_quat = init_q[0].copy(), init_q[1].copy()
+            env.sim = types.SimpleNamespace(data=types.SimpleNamespace(get_body_xpos=lambda name, hp=hp: hp[name]))
+            env._bounded_d_pos = types.MethodType(F.FurnitureEnv._bounded_d_pos, env)
+            env._make_input = types.MethodType(F.FurnitureEnv._make_input, env)
+            calls = dict(ctrl=[], low=[], nsim=0)
+            vel_seq = [rng.uniform(-1, 1, 14) for _ in range(3)]
+
+            def get_control(right=None, left=None, calls=calls, vel_seq=vel_seq):
+                if right is not None:
+                    calls["dpos"] = np.array([right["dpos"], left["dpos"]], dtype=float)
+                    calls["rot"] = np.array([right["rotation"], left["rotation"]], dtype=float)
+                return vel_seq[len(calls["ctrl"])]
+
+            def setup_action(a, calls=calls):
+                calls["low"].append(np.array(a, dtype=float))
+                calls["ctrl"].append(1)
+                return a
+
+            env._controller = types.SimpleNamespace(get_control=get_control)
+            env._setup_action = setup_action
+            env._do_simulation = lambda ctrl, calls=calls: calls.__setitem__("nsim", calls["nsim"] + 1)
+            a = rng.uniform(-1, 1, 15 if ctype == "ik" else 17)
+            F.FurnitureEnv._do_ik_step(env, a.copy())
+            rec["act"].append(a); rec["hand_pos"].append([hp["right_hand"], hp["left_hand"]]); rec["rhq"].append(rhq); rec["init_in"].append(init_q)
+            rec["dpos"].append(calls["dpos"]); rec["rot"].append(calls["rot"])
+            rec["init_out"].append([np.array(env._initial_right_hand_quat, dtype=float), np.array(env._initial_left_hand_quat, dtype=float)])
+            rec["low"].append(np.array(calls["low"])); rec["nsim"].append(calls["nsim"]); rec["vel"].append(np.array(vel_seq))
+        for k, v in rec.items():
+            out["ikstep_baxter_%s_%s" % (ctype, k)] = np.array(v)
+
     # ---- SawyerIKController (controllers/sawyer_ik_controller.py) around a fake pybullet: everything but the IK solve itself ---------
     # The fake `p` keeps the joint states the controller writes (resetJointState), answers getLinkState(robot, 6) with the
     # centre-of-mass frame of right_l6 from the compiled model's URDF chain (oracle/ik.fk, itself checked against the MJCF
