@@ -389,6 +389,71 @@ def main():
     for k, v in recs.items():
         out["sik_" + k] = np.array(v)
     out["sik_user_sensitivity"] = np.array(ctl.user_sensitivity)
+
+    # ---- BaxterIKController on a fake pybullet (48 joints, 15 movable: head_pan + 2 x 7) ------------------------------------------------
+    import furniture.env.controllers.baxter_ik_controller as BIK
+    import xml.etree.ElementTree as ET
+    from furniture_amd.mjcf.urdf_chain import pybullet_joint_order
+    cb = load_compiled("Baxter", "desk_mikael_1064")
+    urdf_order = pybullet_joint_order(ET.parse("/root/reference/furniture/env/models/assets/bullet_data/baxter_description/urdf/baxter_mod.urdf").getroot())
+
+    class FakeBaxterBullet:
+        DIRECT, POSITION_CONTROL = 0, 1
+
+        def __init__(self):
+            self.state = np.zeros(len(urdf_order))
+            self.calls, self.answers = [], None
+
+        def connect(self, *a, **k): return 0
+        def resetSimulation(self, *a, **k): pass
+        def loadURDF(self, path, base, useFixedBase=1):
+            self.base, self.urdf = np.array(base, dtype=float), path
+            return 3
+        def setRealTimeSimulation(self, *a, **k): pass
+        def getNumJoints(self, robot): return len(urdf_order)
+        def getJointInfo(self, robot, i):
+            j = urdf_order[i]
+            mov = j.get("type") != "fixed"
+            lim = j.find("limit")
+            lo, hi = (float(lim.get("lower")), float(lim.get("upper"))) if (mov and lim is not None) else (0.0, -1.0)
+            return (i, j.get("name").encode(), 0 if mov else 4, (7 + i) if mov else -1, (6 + i) if mov else -1, 0, 0.0, 0.0, lo, hi, 0.0, 0.0)
+        def getJointState(self, robot, i): return (self.state[i], 0.0, (0,) * 6, 0.0)
+        def resetJointState(self, robot, i, v, *a): self.state[i] = v
+        def getBasePositionAndOrientation(self, robot): return (tuple(self.base), (0.0, 0.0, 0.0, 1.0))
+        def getLinkState(self, robot, link):
+            arm = {27: 0, 45: 1}[link]
+            act = [13, 14, 15, 16, 17, 19, 20] if arm == 0 else [31, 32, 33, 34, 35, 37, 38]
+            pos, R, _, _ = OIK.fk(cb, self.state[act], arm)
+            return (tuple(pos + self.base), tuple(RT.mat2quat(R.astype(np.float32))))
+        def calculateInverseKinematics(self, robot, link, pos, **kw):
+            self.calls.append(dict(link=link, pos=np.array(pos, dtype=float), orn=np.array(kw["targetOrientation"], dtype=float), rest=np.array(kw["restPoses"], dtype=float),
+                                   lower=np.array(kw["lowerLimits"]), upper=np.array(kw["upperLimits"]), damping=np.array(kw["jointDamping"])))
+            return list(self.answers[0 if link == 27 else 1])
+
+    fbb = FakeBaxterBullet()
+    BIK.p = fbb
+    jb = [cb.arm_initqpos.copy()]
+    bctl = BIK.BaxterIKController(bullet_data_path="/x", robot_jpos_getter=lambda: jb[0])
+    out["bik_urdf"], out["bik_base"] = np.array(fbb.urdf), fbb.base
+    out["bik_sync_target"] = np.array([bctl.ik_robot_target_pos_right, bctl.ik_robot_target_pos_left], dtype=float)
+    out["bik_lower"], out["bik_upper"] = np.array(bctl.lower), np.array(bctl.upper)
+    brec = dict(q=[], dpos=[], rot=[], answer=[], target_after=[], call_pos=[], call_orn=[], call_rest=[], ncalls=[], vel=[], links=[])
+    for t in range(8):
+        jb[0] = cb.arm_initqpos + rng.uniform(-0.3, 0.3, 14)
+        dpos = rng.uniform(-0.1, 0.1, (2, 3))
+        rot = np.stack([rand_rot(rng).astype(np.float32) for _ in range(2)])
+        ans = rng.uniform(-0.5, 0.5, (2, 15))
+        fbb.answers, fbb.calls = ans, []
+        vel = bctl.get_control(right=dict(dpos=dpos[0].copy(), rotation=rot[0].copy()), left=dict(dpos=dpos[1].copy(), rotation=rot[1].copy()))
+        brec["q"].append(jb[0].copy()); brec["dpos"].append(dpos); brec["rot"].append(rot.astype(float)); brec["answer"].append(ans)
+        brec["target_after"].append(np.array([bctl.ik_robot_target_pos_right, bctl.ik_robot_target_pos_left], dtype=float))
+        brec["call_pos"].append([fbb.calls[0]["pos"], fbb.calls[1]["pos"]]); brec["call_orn"].append([fbb.calls[0]["orn"], fbb.calls[1]["orn"]])
+        brec["call_rest"].append([fbb.calls[0]["rest"], fbb.calls[1]["rest"]]); brec["ncalls"].append(len(fbb.calls)); brec["vel"].append(np.array(vel))
+        brec["links"].append([fbb.calls[0]["link"], fbb.calls[1]["link"]])
+    for k, v in brec.items():
+        out["bik_" + k] = np.array(v)
+    out["bik_user_sensitivity"] = np.array(bctl.user_sensitivity)
+    out["bik_actual"] = np.array(bctl.actual)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB", len(out), "arrays")
 
