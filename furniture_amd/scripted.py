@@ -1,18 +1,21 @@
-"""Scripted pick-and-attach policy for Sawyer + table_lack_0825 under ``control_type="ik_quaternion"`` -- a scenario generator
-in the spirit of the reference's ``furniture/env/furniture_sawyer_gen.py`` (phase-based scripted demonstrations), reduced to the
-first assembly subtask and written against the observation dict only (+ the connector-site tables of the compiled model):
+"""Scripted assembly policy for Sawyer + table_lack_0825 under ``control_type="ik_quaternion"`` -- a scenario generator in the
+spirit of the reference's ``furniture/env/furniture_sawyer_gen.py`` (phase-based scripted demonstrations), written against the
+observation dict only (+ the connector-site tables of the compiled model).  Per leg:
 
-  orient (gripper down, fingers across leg 0) -> above the leg -> descend -> close -> lift -> quarter turn about the finger axis
-  (the leg hangs vertically, connector down) -> carry over the nearest table connector -> connect
+  orient (gripper down, fingers across the leg) -> above the leg -> descend -> close -> lift -> quarter turn about the finger axis
+  (the leg hangs vertically, connector down) -> carry over the nearest free table connector -> connect -> release, back off
 
-It is open loop per phase (fixed step counts, proportional set-points), so some placements fail; on the device 7 of 8 random
-placements complete the subtask (tests/test_ik.py).  Works on anything with the batched interface:
-``step(actions [n, 9]) -> (ob dict, reward, done, info)`` with ``ob["object_ob"] [n, 7 * parts]`` and ``ob["robot_ob"] [n, 15]``.
+``run(legs=(0, 3, 1, 2))`` assembles the whole table (num_connected 4 = success).  Phases are closed loop on the end-effector
+position (a phase ends when every env of the batch is within tolerance of its set-point, with a step cap) and each env asks to connect
+on its own schedule; there is no re-grasp, so some placements fail a leg (tests/test_ik.py states the measured rates).  Works on
+anything with the batched interface: ``step(actions [n, 9]) -> (ob dict, reward, done, info)`` with ``ob["object_ob"] [n, 7 * parts]``
+and ``ob["robot_ob"] [n, 15]``.
 """
 
 import numpy as np
 
 GRIPPER_DOWN = np.array([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]])       # hand z -> world -z, finger axis (hand y) -> world y
+FULL_TABLE = (0, 3, 1, 2)                                                # near pair first, then the far pair
 QUARTER_TURN_Y = np.array([[0, 0, 1.0], [0, 1.0, 0], [-1.0, 0, 0]])      # +90 deg about world y: the leg's +x end -> down
 
 
@@ -35,13 +38,13 @@ def _to_numpy(x):
 class PickAndAttach:
     """policy = PickAndAttach(model, n); for a in policy.actions(ob): ob, ... = env.step(a); policy.observe(ob)."""
 
-    def __init__(self, model, n, leg=0, table=4, leg_conn=0, table_conn=6, attach=True):
-        self.m, self.n, self.attach = model, n, attach
+    def __init__(self, model, n, leg=0, table=4, leg_conn=0, table_conn=6, attach=True, gain=0.3):
+        self.m, self.n, self.attach, self.gain = model, n, attach, gain
         self.leg, self.table = leg, table
         self.s_leg, self.s_tab = int(model.conn_siteid[leg_conn]), int(model.conn_siteid[table_conn])
         assert int(model.site_bodyid[self.s_leg]) == int(model.part_bodyid[leg]) and int(model.site_bodyid[self.s_tab]) == int(model.part_bodyid[table])
 
-    def _action(self, obj, rob, target_R, target, grip, connect, maxrot):
+    def _action(self, obj, rob, target_R, target, grip, connect, maxrot, speed=1.0):
         """Vectorised over the batch: orientation servo in the hand frame + proportional position set-point."""
         n = self.n
         a = np.zeros((n, 9), dtype=np.float32)
@@ -56,45 +59,80 @@ class PickAndAttach:
         a[:, 3] = np.cos(th / 2)                                           # quaternion (wxyz) relative to the hand
         a[:, 4:7] = w / (nw[:, None] + 1e-12) * np.sin(th / 2)[:, None]
         if target is not None:
-            a[:, :3] = np.clip((target(obj, rob) - rob[:, 2:5]) / 0.03 * 0.5, -1, 1)  # 3 cm of target per unit action
+            a[:, :3] = np.clip((target(obj, rob) - rob[:, 2:5]) / 0.03 * self.gain, -speed, speed)  # 3 cm of target per unit action
         a[:, 7], a[:, 8] = grip, connect
         return a
 
-    def run(self, step, ob):
-        """Drive the batched env through the script.  step(actions) -> (ob, reward, done, info).  Returns
-        (summed reward [n], max num_connected [n], final ob)."""
-        lo, m = 7 * self.leg, self.m
-        obj, rob = _to_numpy(ob["object_ob"]), _to_numpy(ob["robot_ob"])
-        leg0 = obj[:, lo:lo + 3].copy()
-        total, ncon = np.zeros(self.n), np.zeros(self.n, dtype=int)
+    def run(self, step, ob, legs=None):
+        """Drive the batched env through the script.  step(actions) -> (ob, reward, done, info).  legs: which legs to attach, in order
+        (default: leg 0 only; FULL_TABLE = (0, 3, 1, 2) takes the two legs next to the robot first, then the far pair).  Each leg goes
+        to the free connector of the table top nearest to it.  Returns (summed reward [n], max num_connected [n], final ob)."""
+        m, n = self.m, self.n
+        legs = [self.leg] if legs is None else list(legs)
+        total, ncon = np.zeros(n), np.zeros(n, dtype=int)
         state = {"ob": ob}
-
-        def phase(steps, target_R, target, grip, connect=-1.0, maxrot=0.15):
-            nonlocal total, ncon
-            for _ in range(steps):
-                obj, rob = _to_numpy(state["ob"]["object_ob"]), _to_numpy(state["ob"]["robot_ob"])
-                ob2, rew, done, info = step(self._action(obj, rob, target_R, target, grip, connect, maxrot))
-                state["ob"] = ob2
-                total += _to_numpy(rew).reshape(self.n)
-                ncon = np.maximum(ncon, _to_numpy(info["num_connected"]).reshape(self.n).astype(int))
-        at = lambda z: (lambda obj, rob: np.concatenate([leg0[:, :2], np.full((self.n, 1), z)], axis=1))
-        phase(25, GRIPPER_DOWN, None, -1.0)
-        phase(30, GRIPPER_DOWN, at(0.12), -1.0)
-        phase(30, GRIPPER_DOWN, at(0.028), -1.0)       # finger tips straddle the 3 cm leg
-        phase(8, GRIPPER_DOWN, at(0.028), 1.0)         # close
-        if not self.attach:
-            phase(30, GRIPPER_DOWN, at(0.15), 1.0)
-            return total, ncon, state["ob"]
-        phase(30, GRIPPER_DOWN, at(0.25), 1.0)         # high enough for the 26 cm leg to hang vertically
-        turned = QUARTER_TURN_Y @ GRIPPER_DOWN
-        phase(40, turned, at(0.25), 1.0, maxrot=0.08)
         to = 7 * self.table
-        tab = obj[:, to:to + 7].copy()                 # the table top has not moved
-        tab_conn = tab[:, :3] + _rot(tab[:, 3:7]) @ m.site_pos[self.s_tab]
+        table_conns = [k for k in range(len(m.conn_siteid)) if int(m.conn_partid[k]) == self.table]
+        used = np.zeros((n, len(table_conns)), dtype=bool)
 
-        def over_table(obj, rob):
-            leg_conn = obj[:, lo:lo + 3] + _rot(obj[:, lo + 3:lo + 7]) @ m.site_pos[self.s_leg]
-            return tab_conn + np.array([0, 0, 0.03]) + (rob[:, 2:5] - leg_conn)
-        phase(50, turned, over_table, 1.0, maxrot=0.08)
-        phase(5, turned, over_table, 1.0, connect=1.0, maxrot=0.08)   # connect > 0 while both fingers hold the leg
+        def phase(steps, target_R, target, grip, connect=-1.0, maxrot=0.15, tol=None, speed=1.0, connect_within=None):
+            """`steps` env steps, or -- with tol -- until every env's end effector is within tol of its set-point (at most 3 x steps).
+            connect_within: every env asks to connect on the steps on which it is within that distance of its set-point, and the phase
+            ends when all envs have one more connection than at its start."""
+            nonlocal total, ncon
+            n0 = ncon.copy()
+            for k in range(steps if tol is None and connect_within is None else 3 * steps):
+                obj, rob = _to_numpy(state["ob"]["object_ob"]), _to_numpy(state["ob"]["robot_ob"])
+                err = np.abs(target(obj, rob) - rob[:, 2:5]).max(axis=1) if target is not None else np.zeros(n)
+                if tol is not None and k >= 3 and err.max() < tol:
+                    break
+                if connect_within is not None:
+                    if (ncon > n0).all():
+                        break
+                    connect = np.where((err < connect_within) & (ncon == n0), 1.0, -1.0)
+                ob2, rew, done, info = step(self._action(obj, rob, target_R, target, grip, connect, maxrot, speed))
+                state["ob"] = ob2
+                total += _to_numpy(rew).reshape(n)
+                ncon = np.maximum(ncon, _to_numpy(info["num_connected"]).reshape(n).astype(int))
+        turned = QUARTER_TURN_Y @ GRIPPER_DOWN
+        for li, leg in enumerate(legs):
+            lo = 7 * leg
+            s_leg = int(m.conn_siteid[[k for k in range(len(m.conn_siteid)) if int(m.conn_partid[k]) == leg][0]])
+            obj, rob = _to_numpy(state["ob"]["object_ob"]), _to_numpy(state["ob"]["robot_ob"])
+            leg0 = obj[:, lo:lo + 3].copy()
+            at = lambda z, leg0=leg0: (lambda obj, rob: np.concatenate([leg0[:, :2], np.full((n, 1), z)], axis=1))
+            if li:   # coming from the previous attach: release, back off, go up, turn the gripper down again
+                phase(10, turned, None, -1.0)
+                here = _to_numpy(state["ob"]["robot_ob"])[:, 2:5].copy()
+                phase(20, turned, lambda obj, rob: here + np.array([0.12, 0.0, 0.08]), -1.0, tol=0.01)
+                phase(30, GRIPPER_DOWN, lambda obj, rob: np.concatenate([here[:, :2] + np.array([0.12, 0.0]), np.full((n, 1), 0.45)], axis=1), -1.0, tol=0.01)
+                phase(45, GRIPPER_DOWN, at(0.45), -1.0, tol=0.008)
+            else:
+                phase(25, GRIPPER_DOWN, None, -1.0)
+            phase(30, GRIPPER_DOWN, at(0.12), -1.0, tol=0.003)
+            phase(12, GRIPPER_DOWN, at(0.034), -1.0, tol=0.003, speed=0.4)   # finger tips straddle the 3 cm leg, just off the floor
+            phase(8, GRIPPER_DOWN, at(0.034), 1.0)         # close
+            if not self.attach:
+                phase(30, GRIPPER_DOWN, at(0.15), 1.0)
+                return total, ncon, state["ob"]
+            high = 0.25 if len(legs) == 1 else 0.5         # with a leg already standing on the table, carry above it
+            phase(30 if high < 0.3 else 40, GRIPPER_DOWN, at(high), 1.0, tol=0.01)
+            phase(40 if high < 0.3 else 45, turned, at(high), 1.0, maxrot=0.08)
+            obj = _to_numpy(state["ob"]["object_ob"])
+            tab = obj[:, to:to + 7].copy()                 # where the table top is now
+            conn_pos = np.stack([tab[:, :3] + _rot(tab[:, 3:7]) @ m.site_pos[int(m.conn_siteid[k])] for k in table_conns], axis=1)  # [n, 4, 3]
+            dist = np.linalg.norm(conn_pos - leg0[:, None, :], axis=2) + 1e3 * used
+            pick = dist.argmin(axis=1)
+            used[np.arange(n), pick] = True
+            tab_conn = conn_pos[np.arange(n), pick]
+
+            def over_table(dz):
+                def f(obj, rob):
+                    leg_conn = obj[:, lo:lo + 3] + _rot(obj[:, lo + 3:lo + 7]) @ m.site_pos[s_leg]
+                    return tab_conn + np.array([0, 0, dz]) + (rob[:, 2:5] - leg_conn)
+                return f
+            if high > 0.3:
+                phase(60, turned, over_table(0.30), 1.0, maxrot=0.08, tol=0.01)
+            phase(50, turned, over_table(0.03), 1.0, maxrot=0.08, tol=0.02)
+            phase(20, turned, over_table(0.03), 1.0, maxrot=0.08, connect_within=0.008)   # connect > 0 while both fingers hold the leg
         return total, ncon, state["ob"]

@@ -181,7 +181,7 @@ def test_device_ik_tracks_an_end_effector_path(model):
     env.close()
 
 
-def _scripted_pick(step_fn, get_obs, n, n_obj, model=None, attach=False):
+def _scripted_pick(step_fn, get_obs, n, n_obj, model=None, attach=False, legs=None):
     """furniture_amd.scripted.PickAndAttach driven through (step_fn, get_obs) adapters: -> (leg 0 height, summed reward, num_connected)."""
     from furniture_amd.mjcf.model import load_compiled
     from furniture_amd.scripted import PickAndAttach
@@ -192,7 +192,7 @@ def _scripted_pick(step_fn, get_obs, n, n_obj, model=None, attach=False):
         obj, rob = get_obs()
         return {"object_ob": obj, "robot_ob": rob}, r, None, {"num_connected": nc}
     obj, rob = get_obs()
-    total, ncon, ob = pol.run(step, {"object_ob": obj, "robot_ob": rob})
+    total, ncon, ob = pol.run(step, {"object_ob": obj, "robot_ob": rob}, legs=legs)
     return np.asarray(ob["object_ob"])[:, 2], total, ncon
 
 
@@ -222,6 +222,89 @@ def test_scripted_attach_on_the_oracle_env(model):
         return np.array([r]), np.array([info["num_connected"]])
     z, rew, ncon = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts, model, attach=True)
     assert ncon[0] == 1 and rew[0] > 200.0 and e.sim.model.eq_active[0] == 1 and e._find_group(0) == e._find_group(4)
+
+
+def test_scripted_two_leg_assembly_on_the_oracle_env(model):
+    """Two subtasks in one episode: leg 0, release, back off, leg 3 -- each to the free table connector nearest to it.  Both welds
+    active, both legs in the table top's group, success_reward paid twice."""
+    e = FurnitureEnvOracle(model, OracleConfig(max_episode_steps=2000, seed=123, control_type="ik_quaternion"))
+    last = {"ob": e.reset()}
+
+    def step_fn(a):
+        ob, r, d, info = e.step(a[0].astype(np.float64))
+        last["ob"] = ob
+        return np.array([r]), np.array([info["num_connected"]])
+    z, rew, ncon = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts, model,
+                                  attach=True, legs=(0, 3))
+    assert ncon[0] == 2 and rew[0] > 400.0 and e._find_group(0) == e._find_group(4) == e._find_group(3)
+    assert int(np.sum(e.sim.model.eq_active)) == 2
+
+
+def test_scripted_full_assembly_on_the_oracle_env(model):
+    """All four legs of table_lack_0825, one episode, observation-only policy under ik_quaternion: num_connected reaches 4, every part
+    is in one group, the episode ends with success (furniture.py:470-480: done when all parts are connected)."""
+    from furniture_amd.scripted import FULL_TABLE
+    e = FurnitureEnvOracle(model, OracleConfig(max_episode_steps=4000, seed=123, control_type="ik_quaternion"))
+    last = {"ob": e.reset(), "done": False}
+
+    def step_fn(a):
+        ob, r, d, info = e.step(a[0].astype(np.float64))
+        last["ob"], last["done"] = ob, d
+        return np.array([r]), np.array([info["num_connected"]])
+    z, rew, ncon = _scripted_pick(step_fn, lambda: (last["ob"]["object_ob"][None], last["ob"]["robot_ob"][None]), 1, model.nparts, model,
+                                  attach=True, legs=FULL_TABLE)
+    assert ncon[0] == 4 and rew[0] > 800.0 and len({e._find_group(i) for i in range(5)}) == 1 and last["done"]
+    assert int(np.sum(e.sim.model.eq_active)) == 4
+
+
+@pytest.mark.gpu
+def test_scripted_full_assembly_on_the_device(model):
+    """The whole table on the HIP path, 8 placements, no retries in the script: at least half of the envs finish all four subtasks
+    (5 of 6 on the fp64 oracle env when written), every env at least two; an env that finishes reports done, and num_connected is
+    what the welds say."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.scripted import FULL_TABLE
+    n = 8
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="ik_quaternion",
+                                                            furniture_name="table_lack_0825", max_episode_steps=6000, seed=123), auto_reset=False)
+    last = {"ob": env.reset(), "done": None}
+
+    def step_fn(a):
+        ob, r, d, info = env.step(a)
+        last["ob"] = ob
+        last["done"] = d.cpu().numpy().astype(bool) if last["done"] is None else (last["done"] | d.cpu().numpy().astype(bool))
+        return r.cpu().numpy(), info["num_connected"].cpu().numpy()
+    get = lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy())
+    z, rew, ncon = _scripted_pick(step_fn, get, n, model.nparts, model, attach=True, legs=FULL_TABLE)
+    act = env.sim.get_state("eq_active")["eq_active"].cpu().numpy()
+    print("full scripted assembly on the device: num_connected", ncon.tolist(), "reward", rew.round(0).tolist(), "done", last["done"].tolist())
+    assert (ncon >= 2).all() and (ncon == 4).sum() >= n // 2, (ncon, rew.round(1))
+    assert ((ncon == 4) == last["done"]).all() and (act.sum(axis=1) >= np.minimum(ncon, 4)).all()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_scripted_two_leg_assembly_on_the_device(model):
+    """The two-leg episode on the HIP path, 8 placements: at least five finish both subtasks (no retries in the script), every env
+    attaches at least the first leg or fails it cleanly (num_connected is what the welds and groups say)."""
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    n = 8
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="ik_quaternion",
+                                                            furniture_name="table_lack_0825", max_episode_steps=3000, seed=123), auto_reset=False)
+    last = {"ob": env.reset()}
+
+    def step_fn(a):
+        ob, r, d, info = env.step(a)
+        last["ob"] = ob
+        return r.cpu().numpy(), info["num_connected"].cpu().numpy()
+    get = lambda: (last["ob"]["object_ob"].cpu().numpy(), last["ob"]["robot_ob"].cpu().numpy())
+    z, rew, ncon = _scripted_pick(step_fn, get, n, model.nparts, model, attach=True, legs=(0, 3))
+    st = env.sim.get_state("eq_active", "group")
+    act = st["eq_active"].cpu().numpy()
+    print("two-leg scripted assembly on the device: num_connected", ncon.tolist(), "reward", rew.round(0).tolist())
+    assert (act.sum(axis=1) == ncon).all()
+    assert (ncon == 2).sum() >= 5 and ((ncon == 2) <= (rew > 400.0)).all(), (ncon, rew.round(1))
+    env.close()
 
 
 @pytest.mark.gpu
