@@ -359,6 +359,7 @@ static void build_layout(fsim *s, int ncon_max) {
   ly.qpos = take(m.nq); ly.qvel = take(m.nv); ly.qaccws = take(m.nv); ly.qfrcbias = take(m.nv); ly.ctrl = take(m.nu);
   ly.qfrcapp = take(m.nv); ly.xfrc = take(6 * m.nparts); ly.eqdata = take(7 * m.neq); ly.eqactive = take(m.neq);
   ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg));
+  ly.eik = ly.env + E_GROUP + m.nparts + (s->cfg.dense_reward ? ED_WORDS : 0);
   o = (o + 3) / 4 * 4;
   ly.stride = o;
   // LDS-only
@@ -430,7 +431,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
-  if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || s->cfg.dense_reward || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, sparse reward, on a model compiled with the IK chain table"); }
+  if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, on a model compiled with the IK chain table"); }
   if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built; the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl", cfg ? cfg->control_type : 0); }
   if (env_controller_kind(s->cfg)) {
     if (s->m.agent != 0 || s->cfg.dense_reward) { delete s; FAIL(FSIM_EINVAL, "arm controllers (control_type 2..6) are built for the Sawyer agent, sparse reward"); }

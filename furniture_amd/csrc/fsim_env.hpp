@@ -43,7 +43,8 @@ struct EnvIO {
 
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
-  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS : (env_controller_kind(c) ? EK_WORDS : (c.control_type == 7 || c.control_type == 8 ? EI_WORDS * m.narm : 0)));
+  const int ik = (c.control_type == 7 || c.control_type == 8) ? EI_WORDS * m.narm : 0;  // the dense-reward env may run under IK control: [dense | ik]
+  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS + ik : (env_controller_kind(c) ? EK_WORDS : ik));
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
@@ -817,7 +818,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     const int nrot = cfg.ik == 1 ? 3 : 4, stride = 3 + nrot;
     for (int t = c.lane; t < m.narm * (stride + 1); t += 64) {
       const int arm = t / (stride + 1), k = t % (stride + 1);
-      float *K = L + ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+      float *K = L + ly.eik + EI_WORDS * arm;
       const float *aa = io.action + arm * stride;
       float v;
       if (k == 0) v = -aa[1] * cfg.move_speed;
@@ -878,7 +879,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   } else if (cfg.ik) {
     SYNC();
     env_ik(c, cfg.rotate_speed, cfg.ik);
-    const float *K0 = L + ly.env + E_GROUP + m.nparts;
+    const float *K0 = L + ly.eik;
     const float pgain = GP(m.ik_tab)[IKT_ARM * m.narm + IKT_GAIN];
     const int ng = 3 + (cfg.ik == 1 ? 3 : 4); // offset of the grip entry inside EI_ACT
     for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions

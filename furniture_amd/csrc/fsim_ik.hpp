@@ -108,7 +108,7 @@ DEV void env_ik_sync(const Ctx &c) {
   const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
   const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
   for (int arm = 0; arm < m.narm; arm++) {
-    float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+    float *K = c.L + c.ly.eik + EI_WORDS * arm;
     V3 hp; M3 hR;
     ik_hand_world(c, arm, &hp, &hR);
     float iq[4];
@@ -135,7 +135,7 @@ DEV void env_ik_remember(const Ctx &c, int mode) {
   const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
   const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
   for (int arm = 0; arm < m.narm; arm++) {
-    float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+    float *K = c.L + c.ly.eik + EI_WORDS * arm;
     V3 hp; M3 hR;
     ik_hand_world(c, arm, &hp, &hR);
     float rh[4];
@@ -158,7 +158,7 @@ __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
 #pragma unroll 1
   for (int arm = 0; arm < m.narm; arm++) {
   const auto tab = GP(m.ik_tab) + IKT_ARM * arm;
-  float *K = c.L + c.ly.env + E_GROUP + m.nparts + EI_WORDS * arm;
+  float *K = c.L + c.ly.eik + EI_WORDS * arm;
   const V3 hp = ldv3(K + EI_HPOS);
   // _bounded_d_pos (furniture.py:1252-1258, limits :170-171)
   V3 a = ldv3(K + EI_ACT);

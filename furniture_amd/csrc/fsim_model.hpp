@@ -66,7 +66,7 @@ struct DModel {
 
 // word offsets inside one env record (HBM) == start of the LDS image
 struct Layout {
-  int qpos, qvel, qaccws, qfrcbias, ctrl, qfrcapp, xfrc, eqdata, eqactive, contype, conaff, env, stride;
+  int qpos, qvel, qaccws, qfrcbias, ctrl, qfrcapp, xfrc, eqdata, eqactive, contype, conaff, env, eik, stride;  // eik: first word of the IK blocks inside the env record (after the dense block, if any)
   // LDS-only work arrays (word offsets from LDS base)
   int xpos, xquat, xmat, xanchor, xaxis, xipos, com;
   int cinert, crb, cdofdot, cvel, cacc, cfrc, H; // H aliases cinert..cfrc

@@ -190,8 +190,8 @@ class FurnitureBatchEnv:
             raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
                                       "controllers / ik %s (the reference's 'torque' path writes an 8-vector into "
                                       "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
-        if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and dense:
-            raise NotImplementedError("the dense-reward env runs with control_type 'impedance' (config/furniture_sawyer_dense.py:7)")
+        if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and dense and cfg.control_type not in ("ik", "ik_quaternion"):
+            raise NotImplementedError("the dense-reward env runs with control_type 'impedance' (config/furniture_sawyer_dense.py:7) or ik / ik_quaternion")
         if agent == "Baxter" and cfg.control_type in CONTROLLER_CODES and cfg.control_type not in ("ik", "ik_quaternion"):
             raise NotImplementedError("the torque-level arm controllers are built for Sawyer (the reference's Baxter path mis-indexes ctrl)")
         if cfg.furn_size_rand != 0:

@@ -38,8 +38,8 @@ def _to_numpy(x):
 class PickAndAttach:
     """policy = PickAndAttach(model, n); for a in policy.actions(ob): ob, ... = env.step(a); policy.observe(ob)."""
 
-    def __init__(self, model, n, leg=0, table=4, leg_conn=0, table_conn=6, attach=True, gain=0.3):
-        self.m, self.n, self.attach, self.gain = model, n, attach, gain
+    def __init__(self, model, n, leg=0, table=4, leg_conn=0, table_conn=6, attach=True, gain=0.3, hover=0.03):
+        self.m, self.n, self.attach, self.gain, self.hover = model, n, attach, gain, hover   # hover: connector gap at which connect is sent
         self.leg, self.table = leg, table
         self.s_leg, self.s_tab = int(model.conn_siteid[leg_conn]), int(model.conn_siteid[table_conn])
         assert int(model.site_bodyid[self.s_leg]) == int(model.part_bodyid[leg]) and int(model.site_bodyid[self.s_tab]) == int(model.part_bodyid[table])
@@ -63,10 +63,11 @@ class PickAndAttach:
         a[:, 7], a[:, 8] = grip, connect
         return a
 
-    def run(self, step, ob, legs=None):
+    def run(self, step, ob, legs=None, table_connectors=None):
         """Drive the batched env through the script.  step(actions) -> (ob, reward, done, info).  legs: which legs to attach, in order
         (default: leg 0 only; FULL_TABLE = (0, 3, 1, 2) takes the two legs next to the robot first, then the far pair).  Each leg goes
-        to the free connector of the table top nearest to it.  Returns (summed reward [n], max num_connected [n], final ob)."""
+        to the free connector of the table top nearest to it, or -- table_connectors: one connector index (the model's conn_* tables) per
+        leg -- to the one a recipe prescribes (the dense-reward env ends the episode on any other, furniture_sawyer_dense.py).  Returns (summed reward [n], max num_connected [n], final ob)."""
         m, n = self.m, self.n
         legs = [self.leg] if legs is None else list(legs)
         total, ncon = np.zeros(n), np.zeros(n, dtype=int)
@@ -122,7 +123,7 @@ class PickAndAttach:
             tab = obj[:, to:to + 7].copy()                 # where the table top is now
             conn_pos = np.stack([tab[:, :3] + _rot(tab[:, 3:7]) @ m.site_pos[int(m.conn_siteid[k])] for k in table_conns], axis=1)  # [n, 4, 3]
             dist = np.linalg.norm(conn_pos - leg0[:, None, :], axis=2) + 1e3 * used
-            pick = dist.argmin(axis=1)
+            pick = dist.argmin(axis=1) if table_connectors is None else np.full(n, table_conns.index(int(table_connectors[li])))
             used[np.arange(n), pick] = True
             tab_conn = conn_pos[np.arange(n), pick]
 
@@ -133,6 +134,6 @@ class PickAndAttach:
                 return f
             if high > 0.3:
                 phase(60, turned, over_table(0.30), 1.0, maxrot=0.08, tol=0.01)
-            phase(50, turned, over_table(0.03), 1.0, maxrot=0.08, tol=0.02)
-            phase(20, turned, over_table(0.03), 1.0, maxrot=0.08, connect_within=0.008)   # connect > 0 while both fingers hold the leg
+            phase(50, turned, over_table(self.hover), 1.0, maxrot=0.08, tol=0.02)
+            phase(20, turned, over_table(self.hover), 1.0, maxrot=0.08, connect_within=0.008)   # connect > 0 while both fingers hold the leg
         return total, ncon, state["ob"]
