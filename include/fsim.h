@@ -58,7 +58,8 @@ typedef struct fsim_config {
   float furn_xyz_rand, furn_rot_rand, agent_xyz_rand;
   float move_speed, rotate_speed, cursor_boundary; /* Cursor agent: config/furniture.py move_speed 0.05? see furniture_cursor.py; degrees per step; workspace half-extent */
   int32_t dense_reward;       /* 1: FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py): the 8-phase reward replaces the sparse
-                                 one; the tables must be uploaded with fsim_set_dense_reward before the first reset.  Sawyer only. */
+                                 one; the tables must be uploaded with fsim_set_dense_reward before the first reset.  Sawyer only; control_type 0
+                                 (impedance, the reference's dense config) or 7 / 8 (ik / ik_quaternion). */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
