@@ -221,7 +221,7 @@ def main():
                                    "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
-                       "physics_substeps_per_s": value * 50, "obs_finite": finite,
+                       "physics_substeps_per_s": value * 50, "obs_finite": finite, "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

@@ -7,6 +7,7 @@
 // every XCD keeps its own L2 copy of the (tens of KB) model and no cross-XCD coherence is needed.
 #include "../../include/fsim.h"
 #include "fsim_env.hpp"
+#include "fsim_spec.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -36,59 +37,57 @@ __device__ __forceinline__ void store_record(float *rec, const float *L, int n, 
   for (int i = lane; i < n; i += 64) rec[i] = L[i];
 }
 
-__global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
+template <class Ctx> __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
-  CLayout &ly = *(CLayout *)lp;
   int env = blockIdx.x, lane = threadIdx.x;
   if (env >= kp.n_envs) return;
-  float *rec = state + (size_t)env * ly.stride;
-  load_record(L, rec, ly.stride, lane);
-  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + ly.scal)[i] = 0;
+  const Ctx c(L, m, *(CLayout *)lp, lane, kp.newton_maxit, kp.newton_tol);
+  float *rec = state + (size_t)env * c.ly.stride;
+  load_record(L, rec, c.ly.stride, lane);
+  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   SYNC();
-  Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   fs_load_cache(c);
   if (kp.mode == 1) fs_substeps(c, 1, 1);
   else fs_substeps(c, kp.n_substeps, 0);
   // aux: [qacc nv][xpos 3nr][xquat 4nr][ncon, niter, overflow, bad][contact geoms 2*ncon_max]
   if (aux) {
-    float *a = aux + (size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max);
-    for (int d = lane; d < m.nv; d += 64) a[d] = L[ly.x + d];
-    for (int i = lane; i < 3 * m.nr; i += 64) a[m.nv + i] = L[ly.xpos + i];
-    for (int i = lane; i < 4 * m.nr; i += 64) a[m.nv + 3 * m.nr + i] = L[ly.xquat + i];
-    int *ai = reinterpret_cast<int *>(a + m.nv + 7 * m.nr);
-    const int *scal = reinterpret_cast<const int *>(L + ly.scal);
+    float *a = aux + (size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max);
+    for (int d = lane; d < c.D.nv; d += 64) a[d] = L[c.ly.x + d];
+    for (int i = lane; i < 3 * c.D.nr; i += 64) a[c.D.nv + i] = L[c.ly.xpos + i];
+    for (int i = lane; i < 4 * c.D.nr; i += 64) a[c.D.nv + 3 * c.D.nr + i] = L[c.ly.xquat + i];
+    int *ai = reinterpret_cast<int *>(a + c.D.nv + 7 * c.D.nr);
+    const int *scal = reinterpret_cast<const int *>(L + c.ly.scal);
     if (lane == 0) { ai[0] = scal[SC_NCON]; ai[1] = scal[SC_NITER]; ai[2] = scal[SC_OVERFLOW]; ai[3] = scal[SC_BAD]; }
     // ordered list of (geom1, geom2) original ids of listed contacts
     if (lane == 0) {
       int n = 0, nslot = scal[SC_NSLOT];
       for (int s = 0; s < nslot; s++) {
-        const int *ri = reinterpret_cast<const int *>(L + ly.con + FSIM_CONW * s);
+        const int *ri = reinterpret_cast<const int *>(L + c.ly.con + FSIM_CONW * s);
         if (ri[C_ACTIVE]) { ai[4 + 2 * n] = m.cg_orig[ri[C_G1]]; ai[4 + 2 * n + 1] = m.cg_orig[ri[C_G2]]; n++; }
       }
-      for (; n < ly.ncon_max; n++) { ai[4 + 2 * n] = -1; ai[4 + 2 * n + 1] = -1; }
+      for (; n < c.ly.ncon_max; n++) { ai[4 + 2 * n] = -1; ai[4 + 2 * n + 1] = -1; }
     }
   }
   SYNC();
-  store_record(rec, L, ly.stride, lane);
+  store_record(rec, L, c.ly.stride, lane);
 }
 
-__global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
+template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
                                                  const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
-  CLayout &ly = *(CLayout *)lp;
   long long t_entry = clock64();
   int lane = threadIdx.x;
   if ((int)blockIdx.x >= kp.n_envs) return;
   // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
   int env = order ? order[blockIdx.x] : (int)blockIdx.x;
-  float *rec = state + (size_t)env * ly.stride;
-  load_record(L, rec, ly.stride, lane);
-  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + ly.scal)[i] = 0;
+  const Ctx c(L, m, *(CLayout *)lp, lane, kp.newton_maxit, kp.newton_tol);
+  float *rec = state + (size_t)env * c.ly.stride;
+  load_record(L, rec, c.ly.stride, lane);
+  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   SYNC();
-  Ctx c(L, m, ly, lane, kp.newton_maxit, kp.newton_tol);
   fs_load_cache(c);
   EnvIO io;
   io.action = action ? action + (size_t)env * cfg.dof_action : nullptr;
@@ -96,8 +95,8 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
   io.reward = reward ? reward + env : nullptr;
   io.done = done ? done + env : nullptr;
   io.info = info ? info + (size_t)env * FSIM_INFO_DIM : nullptr;
-  io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * m.nparts : nullptr;
-  io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * m.narmj : nullptr;
+  io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
+  io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * c.D.narmj : nullptr;
   io.n_noise = n_noise;
   io.cost = cost ? cost + env : nullptr;
   io.t0 = t_entry;
@@ -105,9 +104,9 @@ __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layo
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   SYNC();
 #ifdef FSIM_PROFILE
-  if (prof && lane < 48) prof[(size_t)env * (m.nv + 7 * m.nr + 4 + 2 * ly.ncon_max) + lane] = reinterpret_cast<int *>(L + ly.scal)[16 + lane];
+  if (prof && lane < 48) prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + lane] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
 #endif
-  store_record(rec, L, ly.stride, lane);
+  store_record(rec, L, c.ly.stride, lane);
 }
 
 // Longest-job-first launch order.  An env-step's cost varies 5x with its contact state (robot gripping a part =>
@@ -190,6 +189,12 @@ __global__ void k_expand_bodies(const float *aux, int auxstride, int nv, int nr,
 // ------------------------------------------------------------------------------------------ host
 struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_t off; };
 
+// ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
+typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
+typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, EnvCfg, float *, const float *, float *, float *, uint8_t *, int *, const float *,
+                          const float *, int, const uint8_t *, int, int *, const int *, int *);
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; };
+
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
@@ -210,6 +215,7 @@ struct fsim {
   int n_noise = 0;
   int auxstride = 0, lds_bytes = 0;
   std::vector<char> blob;
+  KernelSet ks{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double acc_ms = 0;
   int acc_n = 0;
@@ -351,67 +357,30 @@ static int build_model(fsim *s) {
   return FSIM_OK;
 }
 
-static void build_layout(fsim *s, int ncon_max) {
+static LayoutIn layout_in(const fsim *s, int ncon_max) {
   const DModel &m = s->m;
-  Layout &ly = s->ly;
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += n; return r; };
-  ly.qpos = take(m.nq); ly.qvel = take(m.nv); ly.qaccws = take(m.nv); ly.qfrcbias = take(m.nv); ly.ctrl = take(m.nu);
-  ly.qfrcapp = take(m.nv); ly.xfrc = take(6 * m.nparts); ly.eqdata = take(7 * m.neq); ly.eqactive = take(m.neq);
-  ly.contype = take(m.ncg); ly.conaff = take(m.ncg); ly.env = take(E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg));
-  ly.eik = ly.env + E_GROUP + m.nparts + (s->cfg.dense_reward ? ED_WORDS : 0);
-  o = (o + 3) / 4 * 4;
-  ly.stride = o;
-  // LDS-only
-  ly.xpos = take(3 * m.nr); ly.xquat = take(4 * m.nr); ly.xmat = take(9 * m.nr);
-  ly.xipos = take(3 * m.nr); ly.com = take(3 * m.ntree);
-  ly.cvel = take(6 * m.nr); // read by constraint assembly AND by the observation (site velocities): never aliased
-  int hstart = o;
-  ly.cinert = take(10 * m.nr); ly.crb = take(10 * m.nr); ly.cdofdot = take(6 * m.nv); ly.cacc = take(6 * m.nr); ly.cfrc = take(6 * m.nr);
-  // joint anchors / axes are only live between kinematics and the motion-axis computation: they sit in the unused cacc slot
-  ly.xanchor = ly.cacc; ly.xaxis = ly.cacc + 3 * m.nr;
-  // H (Newton Hessian, packed lower triangle) is only live inside fs_solve, after the rigid-body temporaries
-  // above are dead, so it aliases them.
-  int nH = m.nv * (m.nv + 1) / 2;
-  ly.H = hstart;
-  if (hstart + nH > o) o = hstart + nH;
-  ly.cdof = take(6 * m.nv);
-  { // M lives in the tree-packed triangle layout of k_tmap (dense lower triangle per kinematic tree)
-    std::vector<int> tn; blob_i(s->blob, "tree_dofnum", tn);
-    int w = 0; for (int n_ : tn) w += n_ * (n_ + 1) / 2;
-    ly.M = take(w);
-  } ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
-  ly.smooth = take(m.nv); ly.asmooth = ly.smooth; ly.x = take(m.nv); ly.Mx = take(m.nv); ly.grad = take(m.nv); ly.p = take(m.nv); ly.Mp = take(m.nv);
-  ly.gpos = take(3 * m.ncg); ly.gmat = take(9 * m.ncg);
-  {
-    int need = 21 * m.nr + 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
-    ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * m.nr;
-    if (need < 12 * m.nr) need = 12 * m.nr;
-    if (need > 12 * m.ncg) take(need - 12 * m.ncg);
-    // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
-    ly.W = ly.gpos; ly.G = ly.gpos + 6 * m.nr;
+  LayoutIn in{};
+  in.nq = m.nq; in.nv = m.nv; in.nu = m.nu; in.nr = m.nr; in.ntree = m.ntree; in.ncg = m.ncg; in.nparts = m.nparts; in.neq = m.neq;
+  in.nlim = m.nlim; in.nM = m.nM;
+  std::vector<int> tn, ca, cl;
+  blob_i(s->blob, "tree_dofnum", tn); blob_i(s->blob, "r_chainadr", ca); blob_i(s->blob, "r_chainlen", cl);
+  for (int n_ : tn) in.Mwords += n_ * (n_ + 1) / 2;
+  for (size_t b = 0; b < ca.size(); b++) in.nchain = std::max(in.nchain, ca[b] + cl[b]);
+  in.env_words = E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg);
+  in.eik_rel = s->cfg.dense_reward ? ED_WORDS : 0;
+  in.ncon_max = ncon_max;
+  return in;
+}
+
+static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, sizeof(Dims)) == 0; }
+static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
+static KernelSet pick_kernels(const Dims &d, const LayoutIn &in) {
+  if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>}; }
+    FSIM_SPEC_LIST(FS_TRY)
+#undef FS_TRY
   }
-  ly.surv = take(FSIM_MAXSURV);
-  ly.con = take(FSIM_CONW * ncon_max); ly.weld = take(FSIM_WELDW * m.neq); ly.lim = take(FSIM_LIMW * 2 * m.nlim);
-  ly.scal = take(SC_WORDS); ly.hmap = take(2 * m.nv);
-  // LDS model cache
-  {
-    std::vector<int> ca, cl;
-    blob_i(s->blob, "r_chainadr", ca); blob_i(s->blob, "r_chainlen", cl);
-    int nchain = 0;
-    for (size_t b = 0; b < ca.size(); b++) nchain = std::max(nchain, ca[b] + cl[b]);
-    ly.k_begin = o;
-    ly.k_dof_parent = take(m.nv); ly.k_r_submask = take(m.nr); ly.k_dof_rbody = take(m.nv); ly.k_dof_tree = take(m.nv);
-    ly.k_r_parent = take(m.nr); ly.k_r_jtype = take(m.nr); ly.k_r_qposadr = take(m.nr); ly.k_r_dofadr = take(m.nr); ly.k_r_chain = take(m.nr);
-    ly.k_r_tree = take(m.nr); ly.k_r_chainadr = take(m.nr); ly.k_r_chainlen = take(m.nr); ly.k_r_ancmask = 0; ly.k_chain_dofs = take(nchain);
-    ly.k_tree_dofadr = take(m.ntree); ly.k_tree_dofnum = take(m.ntree); ly.k_tree_bodyadr = take(m.ntree); ly.k_tree_bodynum = take(m.ntree);
-    ly.k_M_ij = take(m.nM);
-    ly.k_r_pos = ly.k_r_quat = ly.k_r_jpos = ly.k_r_jaxis = ly.k_r_ipos = ly.k_r_inertia = 0; // not cached
-    ly.k_r_mass = take(m.nr); ly.k_dof_damping = take(m.nv); ly.k_dof_armature = take(m.nv); ly.k_tmap = take(2 * m.nv);
-    ly.k_end = o;
-  }
-  ly.lds_words = o;
-  ly.ncon_max = ncon_max;
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -440,12 +409,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   }
   if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
   if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
-  build_layout(s, ncon_max);
+  const LayoutIn lin = layout_in(s, ncon_max);
+  s->ly = make_layout(lin);
+  s->ks = pick_kernels(s->m, lin);
   s->lds_bytes = s->ly.lds_words * 4;
   if (const char *e = getenv("FSIM_LDS_PAD")) s->lds_bytes += atoi(e); // development: lower the occupancy on purpose
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
   size_t sbytes = (size_t)n_envs * s->ly.stride * 4;
@@ -480,10 +451,10 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   }
   if (getenv("FSIM_VERBOSE")) {
     int nb = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_env_step), 64, s->lds_bytes);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step), 64, s->lds_bytes);
     hipFuncAttributes fa;
-    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_env_step));
-    fprintf(stderr, "[fsim] lds_bytes=%d stride_words=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu ncon_max=%d\n", s->lds_bytes, s->ly.stride, nb,
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step));
+    fprintf(stderr, "[fsim] kernel=%s lds_bytes=%d stride_words=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu ncon_max=%d\n", s->ks.name, s->lds_bytes, s->ly.stride, nb,
             fa.numRegs, (size_t)fa.localSizeBytes, s->ly.ncon_max);
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
@@ -517,6 +488,7 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
   return FSIM_OK;
 }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
+extern "C" const char *fsim_kernel_variant(const fsim_t *s) { return s && s->ks.name ? s->ks.name : ""; }
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
@@ -539,14 +511,14 @@ static void timing_collect(fsim *s) {
 extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
   if (!s || nsub < 0) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
+  hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
   return FSIM_OK;
 }
 extern "C" int fsim_physics_forward(fsim_t *s) {
   if (!s) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
+  hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
   return FSIM_OK;
 }
@@ -650,7 +622,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   bool sched = do_step && s->lpt;
   if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
   timing_begin(s);
-  hipLaunchKernelGGL(k_env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
+  hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
                      sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr);
   hipError_t e = hipGetLastError();
@@ -772,7 +744,7 @@ extern "C" int fsim_step_subset(fsim_t *s, int queue, const int32_t *env_ids, in
   if (n_ids == 0) return FSIM_OK;
   KParams kp = kparams(s, s->cfg.n_substeps, 0);
   kp.n_envs = n_ids; // grid size; blockIdx -> env through env_ids (the caller lists predicted-expensive envs first)
-  hipLaunchKernelGGL(k_env_step, dim3(n_ids), dim3(64), s->lds_bytes, st, s->d_m, s->d_ly, kp, s->ecfg, s->d_state, action, obs, reward, done, info,
+  hipLaunchKernelGGL(s->ks.env_step, dim3(n_ids), dim3(64), s->lds_bytes, st, s->d_m, s->d_ly, kp, s->ecfg, s->d_state, action, obs, reward, done, info,
                      s->d_tab_parts, s->d_tab_noise, s->n_noise, nullptr, 1, reinterpret_cast<int *>(s->d_aux), env_ids, cost_keys ? cost_keys : s->d_cost);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step (subset) launch: %s", hipGetErrorString(e));

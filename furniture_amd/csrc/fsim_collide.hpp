@@ -15,7 +15,7 @@ enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
 
-struct Emit {
+template <class Ctx> struct Emit {
   const Ctx &c;
   int maxn, cg1, cg2;
   float margin, gap;
@@ -73,7 +73,7 @@ DEV void fs_frame(const float *r, V3 &x, V3 &y, V3 &z) {
 }
 
 // lane = slot: unit normal and the geom pair's parameters
-DEV void fs_finish_contacts(const Ctx &c) {
+template <class Ctx> DEV void fs_finish_contacts(const Ctx &c) {
   CModel &m = c.m;
   int nslot = min(c.I(c.ly.scal)[SC_NSLOT], c.ly.ncon_max);
   for (int s = c.lane; s < nslot; s += 64) {
@@ -93,13 +93,13 @@ DEV void fs_finish_contacts(const Ctx &c) {
 }
 
 // ---- narrow phase primitives ---------------------------------------------------------------
-DEV void np_plane_sphere(const Emit &e, V3 pp, const M3 &pR, V3 sp, float r) {
+template <class Emit> DEV void np_plane_sphere(const Emit &e, V3 pp, const M3 &pR, V3 sp, float r) {
   V3 n = colv(pR, 2);
   float dist = dot(sp - pp, n) - r;
   if (dist > e.margin) return;
   e(0, dist, sp - n * (r + 0.5f * dist), n);
 }
-DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V3 size) {
+template <class Emit> DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V3 size) {
   // corner i = bp +- c0 +- c1 +- c2 (scaled box axes); its height over the plane is dist0 +- a +- b +- cc, so the
   // eight depth tests cost three adds each and the corner itself is only formed for the (<= 4) contacts that are kept
   V3 n = colv(pR, 2);
@@ -145,7 +145,7 @@ DEV void np_plane_box(const Emit &e, V3 pp, const M3 &pR, V3 bp, const M3 &bR, V
   }
 #endif
 }
-DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &cR, V3 size) {
+template <class Emit> DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &cR, V3 size) {
   V3 n = colv(pR, 2), axis = colv(cR, 2);
   float prjaxis = dot(n, axis);
   if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
@@ -179,14 +179,14 @@ DEV void np_plane_cylinder(const Emit &e, V3 pp, const M3 &pR, V3 cp, const M3 &
     e(cnt++, d, cp - v1 + axis - vec * 0.5f - n * (0.5f * d), n);
   }
 }
-DEV void np_sphere_sphere(const Emit &e, V3 p1, float r1, V3 p2, float r2) {
+template <class Emit> DEV void np_sphere_sphere(const Emit &e, V3 p1, float r1, V3 p2, float r2) {
   V3 d = p2 - p1;
   float len = norm(d), dist = len - r1 - r2;
   if (dist > e.margin) return;
   V3 n = len < 1e-15f ? v3(1, 0, 0) : d * (1.0f / len);
   e(0, dist, p1 + n * (r1 + 0.5f * dist), n);
 }
-DEV void np_sphere_local(const Emit &e, V3 sp, float r, const M3 &oR, V3 cl, V3 q, bool inside, V3 od, float pen) {
+template <class Emit> DEV void np_sphere_local(const Emit &e, V3 sp, float r, const M3 &oR, V3 cl, V3 q, bool inside, V3 od, float pen) {
   V3 nl;
   float dist;
   if (!inside) { float d; nl = normalized(q - cl, &d); dist = d - r; }
@@ -195,7 +195,7 @@ DEV void np_sphere_local(const Emit &e, V3 sp, float r, const M3 &oR, V3 cl, V3 
   V3 n = mulv(oR, nl);
   e(0, dist, sp + n * (r + 0.5f * dist), n);
 }
-DEV void np_sphere_box(const Emit &e, V3 sp, float r, V3 bp, const M3 &bR, V3 size) {
+template <class Emit> DEV void np_sphere_box(const Emit &e, V3 sp, float r, V3 bp, const M3 &bR, V3 size) {
   V3 cl = multv(bR, sp - bp);
   V3 q = v3(fminf(fmaxf(cl.x, -size.x), size.x), fminf(fmaxf(cl.y, -size.y), size.y), fminf(fmaxf(cl.z, -size.z), size.z));
   bool inside = (q.x == cl.x) && (q.y == cl.y) && (q.z == cl.z);
@@ -211,7 +211,7 @@ DEV void np_sphere_box(const Emit &e, V3 sp, float r, V3 bp, const M3 &bR, V3 si
   }
   np_sphere_local(e, sp, r, bR, cl, q, inside, od, pen);
 }
-DEV void np_sphere_cylinder(const Emit &e, V3 sp, float r, V3 cp, const M3 &cR, V3 size) {
+template <class Emit> DEV void np_sphere_cylinder(const Emit &e, V3 sp, float r, V3 cp, const M3 &cR, V3 size) {
   V3 cl = multv(cR, sp - cp);
   float rho = sqrtf(cl.x * cl.x + cl.y * cl.y), rc = size.x, h = size.y;
   bool inside = (rho <= rc) && (fabsf(cl.z) <= h);
@@ -236,7 +236,7 @@ DEV float sz(V3 s, int k) { return comp(s, k); }
 //   reference face rectangle  (x) incident face quad, both projected on the reference face:
 //   manifold = {quad vertices inside the rectangle} + {quad edge x rectangle side crossings} + {rectangle corners
 //   strictly inside the quad}  (the vertex set of the clipped polygon, <= 8 points, no polygon buffers needed).
-DEV void np_box_box(const Emit &e, V3 p1, const M3 &R1, V3 s1, V3 p2, const M3 &R2, V3 s2) {
+template <class Emit> DEV void np_box_box(const Emit &e, V3 p1, const M3 &R1, V3 s1, V3 p2, const M3 &R2, V3 s2) {
   const V3 A0 = colv(R1, 0), A1 = colv(R1, 1), A2 = colv(R1, 2), B0 = colv(R2, 0), B1 = colv(R2, 1), B2 = colv(R2, 2);
   const V3 d = p2 - p1;
   const float margin = e.margin;
@@ -428,7 +428,7 @@ DEV V3 np_support(const Shape &s, V3 dir) {
 }
 struct Sup { V3 v, a, b; };
 DEV Sup np_msup(const Shape &A, const Shape &B, V3 dir) { Sup s; s.a = np_support(A, -dir); s.b = np_support(B, dir); s.v = s.b - s.a; return s; }
-DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
+template <class Emit> DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
   Sup v0, v1, v2, v3_, v4;
   v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
   if (dot(v0.v, v0.v) < 1e-20f) v0.v.x = 1e-5f;
@@ -498,44 +498,43 @@ DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
 #else
 #define FS_CPROF(slot) do { } while (0)
 #endif
-DEV void fs_collide(const Ctx &c) {
+template <class Ctx> DEV void fs_collide(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int *scal = c.I(ly.scal);
+  int *scal = c.I(c.ly.scal);
 #ifdef FSIM_PROFILE
   long long t0c_ = clock64();
 #endif
-  for (int g = c.lane; g < m.ncg; g += 64) {
+  for (int g = c.lane; g < c.D.ncg; g += 64) {
     int b = m.cg_body[g];
-    M3 Rb = ldm3(L + ly.xmat + 9 * b);
-    V3 gp = ldv3(L + ly.xpos + 3 * b) + mulv(Rb, ldv3(GP(m.cg_pos) + 3 * g));
-    if (m.agent == 2) { // cursor boxes are world geoms whose body_pos the env rewrites (furniture.py:3139)
+    M3 Rb = ldm3(L + c.ly.xmat + 9 * b);
+    V3 gp = ldv3(L + c.ly.xpos + 3 * b) + mulv(Rb, ldv3(GP(m.cg_pos) + 3 * g));
+    if (c.D.agent == 2) { // cursor boxes are world geoms whose body_pos the env rewrites (furniture.py:3139)
       int cm = m.cg_cursor[g];
-      if (cm) { int k = (cm & 1) ? 0 : 1; gp = gp + ldv3(L + ly.env + E_GROUP + m.nparts + EC_POS + 3 * k) - ldv3(GP(m.cursor_pos0) + 3 * k); }
+      if (cm) { int k = (cm & 1) ? 0 : 1; gp = gp + ldv3(L + c.ly.env + E_GROUP + c.D.nparts + EC_POS + 3 * k) - ldv3(GP(m.cursor_pos0) + 3 * k); }
     }
-    stv3(L + ly.gpos + 3 * g, gp);
-    stm3(L + ly.gmat + 9 * g, mulm(Rb, ldm3(GP(m.cg_mat) + 9 * g)));
+    stv3(L + c.ly.gpos + 3 * g, gp);
+    stm3(L + c.ly.gmat + 9 * g, mulm(Rb, ldm3(GP(m.cg_mat) + 9 * g)));
   }
   SYNC();
   FS_CPROF(29);
   // broadphase + ordered compaction
   int nsurv = 0;
-  int *surv = c.I(ly.surv);
-  const int *ctype = c.I(ly.contype), *caff = c.I(ly.conaff);
-  for (int p0 = 0; p0 < m.ncp; p0 += 64) {
+  int *surv = c.I(c.ly.surv);
+  const int *ctype = c.I(c.ly.contype), *caff = c.I(c.ly.conaff);
+  for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
     int p = p0 + c.lane;
     bool pass = false;
-    if (p < m.ncp) {
+    if (p < c.D.ncp) {
       // one 64-byte record per pair (g1 g2 pt types | margin gap r1 r2 | size1 | size2): no dependent table lookups
       const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
       const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
       const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
       if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
         const float margin = q1.x, r1 = q1.z, r2 = q1.w;
-        V3 d = ldv3(L + ly.gpos + 3 * g2) - ldv3(L + ly.gpos + 3 * g1);
+        V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
         if (t1 == GT_PLANE) {
-          V3 n = v3(L[ly.gmat + 9 * g1 + 2], L[ly.gmat + 9 * g1 + 5], L[ly.gmat + 9 * g1 + 8]);
+          V3 n = v3(L[c.ly.gmat + 9 * g1 + 2], L[c.ly.gmat + 9 * g1 + 5], L[c.ly.gmat + 9 * g1 + 8]);
           pass = dot(d, n) <= r2 + margin;
         } else {
           float bound = r1 + r2 + margin;
@@ -550,7 +549,7 @@ DEV void fs_collide(const Ctx &c) {
               float ro = (side ? r2 : r1) + margin;              // other geom's radius
               if (!pass || (ty != GT_BOX && ty != GT_CYLINDER)) continue;
               V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
-              const float *R = L + ly.gmat + 9 * gs;
+              const float *R = L + c.ly.gmat + 9 * gs;
               V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
               const f4_t qs = GPC<f4_t>(m.pair_rec)[4 * p + (side ? 2 : 3)];
               V3 sz_ = v3(qs.x, qs.y, qs.z);
@@ -585,9 +584,9 @@ DEV void fs_collide(const Ctx &c) {
                  q3 = GPC<f4_t>(m.pair_rec)[4 * p + 3];
     const int g1 = q0.x, g2 = q0.y, pt = q0.z;
     const float margin = q1.x, gap = q1.y;
-    Emit e(c, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
-    V3 p1 = ldv3(L + ly.gpos + 3 * g1), p2 = ldv3(L + ly.gpos + 3 * g2);
-    M3 R1 = ldm3(L + ly.gmat + 9 * g1), R2 = ldm3(L + ly.gmat + 9 * g2);
+    Emit<Ctx> e(c, FS_PAIR_MAXCON[pt], g1, g2, margin, gap);
+    V3 p1 = ldv3(L + c.ly.gpos + 3 * g1), p2 = ldv3(L + c.ly.gpos + 3 * g2);
+    M3 R1 = ldm3(L + c.ly.gmat + 9 * g1), R2 = ldm3(L + c.ly.gmat + 9 * g2);
     V3 s1 = v3(q2.x, q2.y, q2.z), s2 = v3(q3.x, q3.y, q3.z);
 #ifdef FSIM_NPPROF
     // development: run the pair types one after the other so that each type's path length can be timed on its own
@@ -644,7 +643,7 @@ DEV void fs_collide(const Ctx &c) {
   }
   SYNC();
   fs_finish_contacts(c);
-  if (c.lane == 0 && scal[SC_NSLOT] > ly.ncon_max) scal[SC_NSLOT] = ly.ncon_max;
+  if (c.lane == 0 && scal[SC_NSLOT] > c.ly.ncon_max) scal[SC_NSLOT] = c.ly.ncon_max;
   SYNC();
   FS_CPROF(31);
 }

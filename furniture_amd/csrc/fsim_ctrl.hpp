@@ -79,26 +79,25 @@ DEV M3 ck_pinv_sym3(const M3 &A) {
 }
 
 // entry (i, j) of the arm block of M (tree-packed lower triangle, k_tmap)
-DEV float ck_M(const Ctx &c, int i, int j) {
+template <class Ctx> DEV float ck_M(const Ctx &c, int i, int j) {
   int di = GP(c.m.arm_dofadr)[i], dj = GP(c.m.arm_dofadr)[j];
   return c.L[c.ly.M + fs_hidx(c, c.ly.k_tmap, max(di, dj), min(di, dj))];
 }
 
 // _pre_action for the (single, Sawyer) arm: writes ctrl[0..6] (motors) and ctrl[7..8] (fingers)
-DEV void fs_controller(const Ctx &c, int policy_step) {
+template <class Ctx> DEV void fs_controller(const Ctx &c, int policy_step) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  float *K = L + ly.env + E_GROUP + m.nparts;
+  float *K = L + c.ly.env + E_GROUP + c.D.nparts;
   int *Ki = reinterpret_cast<int *>(K);
   const int kind = Ki[EK_KIND];
-  float *S = L + ly.H; // scratch: [0,42) J rows, [42,84) M^-1 J' rows, [84,102) the two 3x3 blocks, [102,108) wrench, [108,115) joint torques
-  const float N = floorf(0.2f * 20.0f / m.timestep); // ramp_ratio * control_freq / timestep (arm_controller.py:114): 2000
+  float *S = L + c.ly.H; // scratch: [0,42) J rows, [42,84) M^-1 J' rows, [84,102) the two 3x3 blocks, [102,108) wrench, [108,115) joint torques
+  const float N = floorf(0.2f * 20.0f / c.D.timestep); // ramp_ratio * control_freq / timestep (arm_controller.py:114): 2000
   const int k = c.lane;
   const bool jl = k < CK_NJ;
   const int dk = jl ? GP(m.arm_dofadr)[k] : 0;
-  const float qk = jl ? L[ly.qpos + GP(m.arm_qposadr)[k]] : 0.0f;
-  float qdk = jl ? L[ly.qvel + dk] : 0.0f;
+  const float qk = jl ? L[c.ly.qpos + GP(m.arm_qposadr)[k]] : 0.0f;
+  float qdk = jl ? L[c.ly.qvel + dk] : 0.0f;
   const int step0 = policy_step ? 0 : Ki[EK_STEP];
   float tau = 0.0f;
   if (kind >= CK_JOINT_IMP) {
@@ -127,7 +126,7 @@ DEV void fs_controller(const Ctx &c, int policy_step) {
       const float kp = k < 4 ? 55.0f : (k == 4 ? 30.0f : (k == 5 ? 15.5f : 5.5f)); // (kp_max + kp_min) / 2, damping (2 + 0) / 2 = 1
       const float kv = 2.0f * sqrtf(kp);
       float n2 = 0;
-      for (int j = 0; j < CK_NJ; j++) { float v = L[ly.qvel + GP(m.arm_dofadr)[j]]; n2 += v * v; }
+      for (int j = 0; j < CK_NJ; j++) { float v = L[c.ly.qvel + GP(m.arm_dofadr)[j]]; n2 += v * v; }
       const float nrm = sqrtf(n2);
       if (nrm > 7.0f) qdk = qdk / (nrm * 7.0f); // :485-487
       if (jl) S[108 + k] = kp * (lg - qk) - kv * qdk;
@@ -137,11 +136,11 @@ DEV void fs_controller(const Ctx &c, int policy_step) {
   } else {
     // ---- cartesian kinds
     const int hb = GP(m.hand_body)[0], rb = GP(m.body_red)[hb];
-    const M3 Rb = ldm3(L + ly.xmat + 9 * rb);
-    const V3 pos = ldv3(L + ly.xpos + 3 * rb) + mulv(Rb, ldv3(GP(m.body_relpos) + 3 * hb));
+    const M3 Rb = ldm3(L + c.ly.xmat + 9 * rb);
+    const V3 pos = ldv3(L + c.ly.xpos + 3 * rb) + mulv(Rb, ldv3(GP(m.body_relpos) + 3 * hb));
     const M3 R = mulm(Rb, q2m(qnormalized(ldq(GP(m.body_relquat) + 4 * hb))));
     if (jl) {
-      V3 jp = fs_col(c, dk, pos), jr = ldv3(L + ly.cdof + 6 * dk);
+      V3 jp = fs_col(c, dk, pos), jr = ldv3(L + c.ly.cdof + 6 * dk);
       S[0 * 7 + k] = jp.x; S[1 * 7 + k] = jp.y; S[2 * 7 + k] = jp.z; S[3 * 7 + k] = jr.x; S[4 * 7 + k] = jr.y; S[5 * 7 + k] = jr.z;
     }
     SYNC();
@@ -198,7 +197,7 @@ DEV void fs_controller(const Ctx &c, int policy_step) {
     if (k == 0) {
       V3 velp = v3(0, 0, 0), velr = v3(0, 0, 0); // body_xvelp / body_xvelr = jac . qvel
       for (int j = 0; j < CK_NJ; j++) {
-        float v = L[ly.qvel + GP(m.arm_dofadr)[j]];
+        float v = L[c.ly.qvel + GP(m.arm_dofadr)[j]];
         velp = velp + v3(S[j], S[7 + j], S[14 + j]) * v;
         velr = velr + v3(S[21 + j], S[28 + j], S[35 + j]) * v;
       }
@@ -249,11 +248,11 @@ DEV void fs_controller(const Ctx &c, int policy_step) {
   SYNC();
   if (k == 0) Ki[EK_STEP] = ((float)step0 < N - 1.0f) ? step0 + 1 : step0;
   // ctrl[arm] = qfrc_bias[arm] + torques (furniture.py:1756-1758; the bias of the same stale forward pass)
-  if (jl) L[ly.ctrl + k] = L[ly.qfrcbias + dk] + tau;
+  if (jl) L[c.ly.ctrl + k] = L[c.ly.qfrcbias + dk] + tau;
   // gripper: format_action 1 -> [g, -g], bias + weight * a from actuator_ctrlrange, not clipped (furniture.py:1722-1737)
   if (k >= CK_NJ && k < CK_NJ + 2) {
     float g = K[EK_ACT + 7];
-    L[ly.ctrl + k] = GP(m.ctrl_bias)[k] + GP(m.ctrl_weight)[k] * (k == CK_NJ ? g : -g);
+    L[c.ly.ctrl + k] = GP(m.ctrl_bias)[k] + GP(m.ctrl_weight)[k] * (k == CK_NJ ? g : -g);
   }
   SYNC();
 }

@@ -74,7 +74,7 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
 }
 
 // ---------------------------------------------------------------------------------------------------- physics wrappers
-DEV void fs_touch_flags(const Ctx &c) {
+template <class Ctx> DEV void fs_touch_flags(const Ctx &c) {
   // who touches whom, from the contact list of this forward pass (data.contact[0:ncon])
   CModel &m = c.m;
   int *scal = c.I(c.ly.scal);
@@ -91,7 +91,7 @@ DEV void fs_touch_flags(const Ctx &c) {
       if (part < 0) continue;
       int role = m.cg_fingerrole[ga];
       // bits: arm*16 + part  (nparts <= 16, narm <= 2)
-      for (int arm = 0; arm < m.narm; arm++) {
+      for (int arm = 0; arm < c.D.narm; arm++) {
         if (role & (1 << (2 * arm))) atomicOr(&scal[SC_TOUCHL], 1 << (16 * arm + part));
         if (role & (1 << (2 * arm + 1))) atomicOr(&scal[SC_TOUCHR], 1 << (16 * arm + part));
       }
@@ -102,7 +102,7 @@ DEV void fs_touch_flags(const Ctx &c) {
 }
 
 // One forward pass (inlined exactly once, into fs_substeps below).
-DEV void fs_forward_body(const Ctx &c) {
+template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
 #ifdef FSIM_PROFILE
   // per-phase shader-clock accounting (development builds only): scal[16..] = cycles of
   // {kinematics+inertia+crb+factor, collide, velocity+smooth, constraints, solve}, then counters
@@ -112,8 +112,8 @@ DEV void fs_forward_body(const Ctx &c) {
 #define FS_PROF(slot) do { } while (0)
 #endif
   fs_kinematics(c);
-  if (c.m.agent == 2 && c.lane < 6) { // data.xpos of the cursor bodies follows model.body_pos at every forward pass
-    float *ec = c.L + c.ly.env + E_GROUP + c.m.nparts;
+  if (c.D.agent == 2 && c.lane < 6) { // data.xpos of the cursor bodies follows model.body_pos at every forward pass
+    float *ec = c.L + c.ly.env + E_GROUP + c.D.nparts;
     ec[EC_XPOS + c.lane] = ec[EC_POS + c.lane];
   }
   FS_PROF(16);
@@ -137,7 +137,7 @@ DEV void fs_forward_body(const Ctx &c) {
 #ifdef FSIM_PROFILE
   {
     int bad_ = 0;
-    for (int d = c.lane; d < c.m.nv; d += 64) bad_ |= !isfinite(c.L[c.ly.asmooth + d]) | (!isfinite(c.L[c.ly.qfrcbias + d]) << 1);
+    for (int d = c.lane; d < c.D.nv; d += 64) bad_ |= !isfinite(c.L[c.ly.asmooth + d]) | (!isfinite(c.L[c.ly.qfrcbias + d]) << 1);
     int ns_ = c.I(c.ly.scal)[SC_NSLOT];
     for (int s_ = c.lane; s_ < ns_; s_ += 64) { const float *r_ = c.L + c.ly.con + FSIM_CONW * s_; if (c.I(c.ly.con + FSIM_CONW * s_)[C_ACTIVE] == 1) bad_ |= (!isfinite(r_[C_AREF] + r_[C_AREF + 1] + r_[C_AREF + 2] + r_[C_DN]) << 2) | ((fabsf(r_[C_POS]) + fabsf(r_[C_POS + 1]) + fabsf(r_[C_POS + 2]) > 100.f) << 3); }
     bad_ = wave_or(bad_);
@@ -155,7 +155,7 @@ DEV void fs_forward_body(const Ctx &c) {
     if (sc_[SC_NSURV] > sc_[52]) sc_[52] = sc_[SC_NSURV];
   }
 #endif
-  if (c.m.agent == 2) {
+  if (c.D.agent == 2) {
     // parts named in a contact with cursor K (on_collision, furniture.py:3290-3310): kept in the env block because the
     // env reads data.contact of the PREVIOUS step when it selects (and LDS does not survive the launch)
     int t0m = 0, t1m = 0;
@@ -168,11 +168,11 @@ DEV void fs_forward_body(const Ctx &c) {
       if (cm & 2) t1m |= pm;
     }
     t0m = wave_or(t0m); t1m = wave_or(t1m);
-    if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.m.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
+    if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.D.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
   }
   // instability guard (mj_checkAcc analogue): NaN / huge accelerations
   int bad = 0;
-  for (int d = c.lane; d < c.m.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }
+  for (int d = c.lane; d < c.D.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }
   bad = wave_or(bad);
   if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
   SYNC();
@@ -187,7 +187,7 @@ DEV void fs_forward_body(const Ctx &c) {
 //   CTRL (separate instantiation, so the default path's code and register allocation are untouched): the torque-level arm
 //   controller runs before every substep (_do_controller_step, furniture.py:3065-3093); pass -1 is the sim.forward() that
 //   precedes the loop, whose results the first _pre_action reads.
-template <bool CTRL> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
+template <bool CTRL, class Ctx> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
   FS_REBUILD_CTX(cv);
   const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
   if (mode & 1) {
@@ -204,9 +204,9 @@ template <bool CTRL> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, 
     fs_integrate_body(c);
   }
 }
-DEV void fs_substeps(const Ctx &c, int n, int mode) { fs_substeps_t<false>(c, n, mode); }
-DEV void fs_forward(const Ctx &c) { fs_substeps(c, 1, 1); }
-DEV void fs_step(const Ctx &c) { fs_substeps(c, 1, 0); }
+template <class Ctx> DEV void fs_substeps(const Ctx &c, int n, int mode) { fs_substeps_t<false>(c, n, mode); }
+template <class Ctx> DEV void fs_forward(const Ctx &c) { fs_substeps(c, 1, 1); }
+template <class Ctx> DEV void fs_step(const Ctx &c) { fs_substeps(c, 1, 0); }
 
 // ---------------------------------------------------------------------------------------------------- helpers (lane-0 scalar code)
 DEV int env_find(int *grp, int i) {
@@ -215,7 +215,7 @@ DEV int env_find(int *grp, int i) {
   while (grp[i] != r) { int n = grp[i]; grp[i] = r; i = n; }
   return r;
 }
-DEV void env_site_pose(const Ctx &c, int site, V3 *pos, Q4 *quat, M3 *mat) {
+template <class Ctx> DEV void env_site_pose(const Ctx &c, int site, V3 *pos, Q4 *quat, M3 *mat) {
   CModel &m = c.m;
   int b = GP(m.s_body)[site];
   Q4 qb = ldq(c.L + c.ly.xquat + 4 * b);
@@ -246,15 +246,15 @@ DEV void env_ttq(V3 bp, Q4 bq, V3 p, Q4 q, Q4 target, V3 *np_, Q4 *nq) {
   *np_ = qrot(qnormalized(rel), p - bp) + bp;
   *nq = qmul(rel, q);
 }
-DEV void env_stop_part(const Ctx &c, int part, float gravity) {
+template <class Ctx> DEV void env_stop_part(const Ctx &c, int part, float gravity) {
   CModel &m = c.m;
   float *x = c.L + c.ly.xfrc + 6 * part;
-  x[0] = 0; x[1] = 0; x[2] = -gravity * m.gravity[2] * GP(m.part_mass)[part]; x[3] = 0; x[4] = 0; x[5] = 0;
+  x[0] = 0; x[1] = 0; x[2] = -gravity * c.D.gravity[2] * GP(m.part_mass)[part]; x[3] = 0; x[4] = 0; x[5] = 0;
   int d = GP(m.part_dofadr)[part];
   for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = 0; c.L[c.ly.qfrcapp + d + k] = 0; }
 }
 // _move_objects_translation_quat (furniture.py:1163-1176): rigidly re-pose the whole weld group of `part`
-DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float gravity) {
+template <class Ctx> DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float gravity) {
   CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   float *qp = c.L + c.ly.qpos;
@@ -262,7 +262,7 @@ DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float
   V3 bp = ldv3(qp + a0);
   Q4 bq = ldq(qp + a0 + 3);
   int g = env_find(grp, part);
-  for (int i = 0; i < m.nparts; i++) {
+  for (int i = 0; i < c.D.nparts; i++) {
     if (env_find(grp, i) != g) continue;
     int a = GP(m.part_qposadr)[i];
     V3 np_; Q4 nq;
@@ -273,12 +273,12 @@ DEV void env_move_group(const Ctx &c, int part, V3 translation, Q4 target, float
   }
 }
 // site bounding box of a weld group, min/max initialised with 0 (quirk Q1, furniture.py:747-769)
-DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
+template <class Ctx> DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
   CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   int g = env_find(grp, part);
   V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
-  for (int i = 0; i < m.nparts; i++) {
+  for (int i = 0; i < c.D.nparts; i++) {
     if (env_find(grp, i) != g) continue;
     for (int k = 0; k < GP(m.part_site_num)[i]; k++) {
       V3 p; env_site_pose(c, GP(m.part_sites)[GP(m.part_site_adr)[i] + k], &p, nullptr, nullptr);
@@ -289,19 +289,19 @@ DEV void env_bbox(const Ctx &c, int part, V3 *mn, V3 *mx) {
   *mn = lo; *mx = hi;
 }
 
-DEV void env_next_subtask(const Ctx &c) {
+template <class Ctx> DEV void env_next_subtask(const Ctx &c) {
   CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
   E[E_SUBTASK1] = -1; E[E_SUBTASK2] = -1;
-  for (int i = 0; i < m.neq; i++) {
+  for (int i = 0; i < c.D.neq; i++) {
     int p1 = GP(m.eq_part1)[i], p2 = GP(m.eq_part2)[i];
     if (env_find(grp, p1) != env_find(grp, p2)) { E[E_SUBTASK1] = p1; E[E_SUBTASK2] = p2; return; }
   }
 }
 
 // _is_aligned (furniture.py:1057-1153) for connector indices k1,k2; writes the target quaternion on success paths
-DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
+template <class Ctx> DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
   CModel &m = c.m;
   V3 p1, p2; M3 R1, R2;
   env_site_pose(c, GP(m.conn_siteid)[k1], &p1, nullptr, &R1);
@@ -337,7 +337,7 @@ DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
 }
 
 // sensor values of the dense reward from the poses of the last forward pass (furniture_sawyer_dense.py:222-271)
-struct DenseSimP {
+template <class Ctx> struct DenseSimP {
   const Ctx &c;
   const EnvCfg &cfg;
   DEV void obs(int st, DObs &o) const {
@@ -366,10 +366,10 @@ struct DenseSimP {
     return env_is_aligned(c, cfg, (int)T[DS_K_LEG], (int)T[DS_K_TABLE]);
   }
 };
-DEV float *env_edense(const Ctx &c) { return c.L + c.ly.env + E_GROUP + c.m.nparts; }
+template <class Ctx> DEV float *env_edense(const Ctx &c) { return c.L + c.ly.env + E_GROUP + c.D.nparts; }
 
 // ---------------------------------------------------------------------------------------------------- connect
-DEV int env_ecur(const Ctx &c) { return c.ly.env + E_GROUP + c.m.nparts; }
+template <class Ctx> DEV int env_ecur(const Ctx &c) { return c.ly.env + E_GROUP + c.D.nparts; }
 
 // euler_to_quat(rotation_deg, quat) = quat * (qz * qy * qx)   (transform_utils.py:617-630)
 DEV Q4 env_euler_quat(V3 deg, Q4 q) {
@@ -394,12 +394,12 @@ DEV Q4 env_slerp(Q4 q0, Q4 q1, float fraction) {
 }
 
 // _stop_selected_objects (furniture.py:771-779): every part in a selected group is frozen with gravity compensation
-DEV void env_stop_selected(const Ctx &c, float gravity) {
+template <class Ctx> DEV void env_stop_selected(const Ctx &c, float gravity) {
   CModel &m = c.m;
   if (c.lane == 0) {
     int *grp = c.I(c.ly.env + E_GROUP);
     const int *ec = c.I(env_ecur(c));
-    for (int i = 0; i < m.nparts; i++) {
+    for (int i = 0; i < c.D.nparts; i++) {
       int g = env_find(grp, i);
       for (int k = 0; k < 2; k++)
         if (ec[EC_SEL + k] && env_find(grp, ec[EC_SEL + k] - 1) == g) { env_stop_part(c, i, gravity); break; }
@@ -411,13 +411,13 @@ DEV void env_stop_selected(const Ctx &c, float gravity) {
 // _move_rotate_object (furniture.py:708-745): rigidly rotate the weld group of `part` by rot_deg about the part and shift
 // it by `move`, validate with one forward+step and the site bounding box (_is_inside), undo the poses if it left the
 // workspace.  returns (wave-uniform) 1 if the move was kept.
-DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) {
+template <class Ctx> DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) {
   CModel &m = c.m;
   int *grp = c.I(c.ly.env + E_GROUP);
   int *scal = c.I(c.ly.scal);
   // old part poses stay in registers (lane i keeps word i of the [nparts][7] pose table) so the move can be undone
   float keep[2] = {0, 0};
-  for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * m.nparts) keep[r] = c.L[c.ly.qpos + GP(m.part_qposadr)[i / 7] + i % 7]; }
+  for (int r = 0; r < 2; r++) { int i = c.lane + 64 * r; if (i < 7 * c.D.nparts) keep[r] = c.L[c.ly.qpos + GP(m.part_qposadr)[i / 7] + i % 7]; }
   SYNC();
   if (c.lane == 0) {
     int g = env_find(grp, part);
@@ -425,7 +425,7 @@ DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) 
     Q4 bq = ldq(c.L + c.ly.qpos + a0 + 3);
     V3 bp = ldv3(c.L + c.ly.qpos + a0);
     Q4 target = env_euler_quat(rot_deg, bq);
-    for (int i = 0; i < m.nparts; i++) {
+    for (int i = 0; i < c.D.nparts; i++) {
       if (env_find(grp, i) != g) continue;
       int a = GP(m.part_qposadr)[i];
       V3 np_; Q4 nq;
@@ -448,7 +448,7 @@ DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) 
     int g = scal[13];
     for (int r = 0; r < 2; r++) {
       int i = c.lane + 64 * r;
-      if (i < 7 * m.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + GP(m.part_qposadr)[pi] + i % 7] = keep[r]; }
+      if (i < 7 * c.D.nparts) { int pi = i / 7; if (env_find(grp, pi) == g) c.L[c.ly.qpos + GP(m.part_qposadr)[pi] + i % 7] = keep[r]; }
     }
     SYNC();
   }
@@ -457,7 +457,7 @@ DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3 rot_deg, float bnd) 
 
 // _try_connect(part1, part2) (furniture.py:926-1042).  part2 < 0: any part (the arm agents).  returns (wave-uniform) 1 if a
 // connection was made; with num_connect_steps > 0 (Cursor) an aligned pair is first approached over that many calls.
-DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
+template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
   CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
@@ -465,19 +465,19 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
   // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
   if (c.lane == 0) {
     int found1 = -1, found2 = -1;
-    bool weld_ok = m.neq > 0 && m.nconn > 0;
+    bool weld_ok = c.D.neq > 0 && c.D.nconn > 0;
     int g1 = env_find(grp, part1), g2 = part2 >= 0 ? env_find(grp, part2) : -1;
     if (weld_ok && part2 >= 0) { // some <weld> must join two bodies of group(part1) U group(part2) (activity is not checked)
       weld_ok = false;
-      for (int i = 0; i < m.neq && !weld_ok; i++) {
+      for (int i = 0; i < c.D.neq && !weld_ok; i++) {
         int ga = env_find(grp, GP(m.eq_part1)[i]), gb = env_find(grp, GP(m.eq_part2)[i]);
         weld_ok = (ga == g1 || ga == g2) && (gb == g1 || gb == g2);
       }
     }
     if (weld_ok) {
-      for (int k1 = 0; k1 < m.nconn && found1 < 0; k1++) {
+      for (int k1 = 0; k1 < c.D.nconn && found1 < 0; k1++) {
         if (env_find(grp, GP(m.conn_partid)[k1]) != g1) continue;
-        for (int k2 = 0; k2 < m.nconn; k2++) {
+        for (int k2 = 0; k2 < c.D.nconn; k2++) {
           if (g2 >= 0 && env_find(grp, GP(m.conn_partid)[k2]) != g2) continue;
           if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
           if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
@@ -527,7 +527,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     E[E_SITE1] = GP(m.conn_siteid)[k1]; E[E_SITE2] = GP(m.conn_siteid)[k2];
     int gA = env_find(grp, pA), gB = env_find(grp, pB);
     int *ct = c.I(c.ly.contype), *ca = c.I(c.ly.conaff);
-    for (int g = 0; g < m.ncg; g++) {
+    for (int g = 0; g < c.D.ncg; g++) {
       int p = m.cg_partid[g];
       if (p < 0) continue;
       int gp = env_find(grp, p);
@@ -549,7 +549,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     }
   }
   SYNC();
-  if (m.agent == 2) env_stop_selected(c, 1.0f);
+  if (c.D.agent == 2) env_stop_selected(c, 1.0f);
   fs_step(c);
   if (c.lane == 0) {
     V3 mn1, mx1, mn2, mx2;
@@ -564,11 +564,11 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
     env_move_rotate(c, pA, v3(0, 0, -mz), v3(0, 0, 0), cfg.cursor_boundary);
     env_move_rotate(c, pB, v3(0, 0, -mz), v3(0, 0, 0), cfg.cursor_boundary);
   }
-  if (m.agent == 2) env_stop_selected(c, 1.0f);
+  if (c.D.agent == 2) env_stop_selected(c, 1.0f);
   fs_step(c);
   if (c.lane == 0) {
     // _activate_weld(body1, body2)
-    for (int i = 0; i < m.neq; i++) {
+    for (int i = 0; i < c.D.neq; i++) {
       int p1 = GP(m.eq_part1)[i], p2 = GP(m.eq_part2)[i];
       if ((p1 == pA || p1 == pB) && (p2 == pA || p2 == pB)) {
         int a1 = GP(m.part_qposadr)[p1], a2 = GP(m.part_qposadr)[p2];
@@ -582,7 +582,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
         grp[r1] = r2;
       }
     }
-    if (m.agent == 2) c.I(env_ecur(c))[EC_SEL + 1] = 0; // furniture.py:914-915
+    if (c.D.agent == 2) c.I(env_ecur(c))[EC_SEL + 1] = 0; // furniture.py:914-915
     E[E_NUM_CONNECTED] += 1;
     E[E_CONNECTED_THIS_STEP] = 1;
     E[E_CONNBODY1] = pA + 1;
@@ -596,7 +596,7 @@ DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
 
 // ---------------------------------------------------------------------------------------------------- Cursor agent
 // _step_discrete (furniture.py:800-845) + helpers _move_cursor / _select_object (furniture.py:700-798, 3290-3310).
-DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
+template <class Ctx> DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
   CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
@@ -631,7 +631,7 @@ DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
     if (c.lane == 0 && select && eci[EC_SEL + k] == 0) {
       // _select_object: first part (in part order) not in an already selected group that touches this cursor
       int hit = 0;
-      for (int i = 0; i < m.nparts && !hit; i++) {
+      for (int i = 0; i < c.D.nparts && !hit; i++) {
         int g = env_find(grp, i);
         bool taken = false;
         for (int q = 0; q < 2; q++) if (eci[EC_SEL + q] && env_find(grp, eci[EC_SEL + q] - 1) == g) taken = true;
@@ -649,49 +649,48 @@ DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cfg, const float *a) {
 }
 
 // ---------------------------------------------------------------------------------------------------- observation / reward
-DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   if (!io.obs) return;
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   const float *L = c.L;
   if (io.info && c.lane == 0) { // the subtask of the state being observed (after an in-kernel auto-reset: the new episode's)
-    io.info[FSIM_INFO_SUBTASK1] = c.I(ly.env)[E_SUBTASK1];
-    io.info[FSIM_INFO_SUBTASK2] = c.I(ly.env)[E_SUBTASK2];
+    io.info[FSIM_INFO_SUBTASK1] = c.I(c.ly.env)[E_SUBTASK1];
+    io.info[FSIM_INFO_SUBTASK2] = c.I(c.ly.env)[E_SUBTASK2];
   }
   // object_ob: body xpos/xquat of every part as left by the last forward pass
-  for (int i = c.lane; i < 7 * m.nparts; i += 64) {
+  for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
     int p = i / 7, k = i % 7, b = GP(m.part_rbody)[p];
-    io.obs[i] = k < 3 ? L[ly.xpos + 3 * b + k] : L[ly.xquat + 4 * b + k - 3];
+    io.obs[i] = k < 3 ? L[c.ly.xpos + 3 * b + k] : L[c.ly.xquat + 4 * b + k - 3];
   }
-  int base = 7 * m.nparts;
+  int base = 7 * c.D.nparts;
   // data.site_xvelp / site_xvelr in mujoco_py are jac(site) . qvel: the Jacobian of the LAST forward pass (one integration
   // old after sim.step()) times the CURRENT qvel -- not mj_objectVelocity's cvel of that pass.
-  if (m.narm) fs_body_spatial(c, ly.qvel);
-  if (m.agent == 2) { // furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
-    const float *ec = L + ly.env + E_GROUP + m.nparts;
+  if (c.D.narm) fs_body_spatial(c, c.ly.qvel);
+  if (c.D.agent == 2) { // furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
+    const float *ec = L + c.ly.env + E_GROUP + c.D.nparts;
     if (c.lane < 6) io.obs[base + c.lane] = ec[EC_XPOS + c.lane];
     if (c.lane < 2) io.obs[base + 6 + c.lane] = reinterpret_cast<const int *>(ec)[EC_SEL + c.lane] ? 1.0f : 0.0f;
   }
-  for (int arm = 0; arm < m.narm; arm++) {
-    const int njm = m.narmj / m.narm;
+  for (int arm = 0; arm < c.D.narm; arm++) {
+    const int njm = c.D.narmj / c.D.narm;
     // joint_pos / joint_vel are part of robot_ob for impedance / torque only (furniture_sawyer.py:112-124)
     const int nj = (cfg.controller || cfg.ik) ? 0 : njm;
     float *o = io.obs + base + (2 * nj + 15) * arm;
     for (int k = c.lane; k < nj; k += 64) {
-      o[k] = L[ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
-      o[nj + k] = L[ly.qvel + GP(m.arm_dofadr)[arm * njm + k]];
+      o[k] = L[c.ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
+      o[nj + k] = L[c.ly.qvel + GP(m.arm_dofadr)[arm * njm + k]];
     }
-    if (c.lane < 2) o[2 * nj + c.lane] = L[ly.qpos + GP(m.grip_qposadr)[2 * arm + c.lane]];
+    if (c.lane < 2) o[2 * nj + c.lane] = L[c.ly.qpos + GP(m.grip_qposadr)[2 * arm + c.lane]];
     if (c.lane == 0) {
       int site = GP(m.eef_siteid)[arm];
       V3 sp; env_site_pose(c, site, &sp, nullptr, nullptr);
       stv3(o + 2 * nj + 2, sp);
       int hb = GP(m.hand_body)[arm], rb = GP(m.body_red)[hb];
-      Q4 q = qmul(ldq(L + ly.xquat + 4 * rb), ldq(GP(m.body_relquat) + 4 * hb));
+      Q4 q = qmul(ldq(L + c.ly.xquat + 4 * rb), ldq(GP(m.body_relquat) + 4 * hb));
       o[2 * nj + 5] = q.x; o[2 * nj + 6] = q.y; o[2 * nj + 7] = q.z; o[2 * nj + 8] = q.w;
       int sb = GP(m.s_body)[site];
-      S6 v = lds6(L + ly.W + 6 * sb);
-      V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + ly.com + 3 * KI(r_tree, sb))) : v3(0, 0, 0);
+      S6 v = lds6(L + c.ly.W + 6 * sb);
+      V3 vp = sb ? v.l + cross(v.a, sp - ldv3(L + c.ly.com + 3 * KI(r_tree, sb))) : v3(0, 0, 0);
       stv3(o + 2 * nj + 9, vp);
       stv3(o + 2 * nj + 12, sb ? v.a : v3(0, 0, 0));
     }
@@ -699,36 +698,36 @@ DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
 }
 
 // ---------------------------------------------------------------------------------------------------- reset
-DEV void env_gravity_comp(const Ctx &c) {
+template <class Ctx> DEV void env_gravity_comp(const Ctx &c) {
   CModel &m = c.m;
-  for (int k = c.lane; k < m.narmj; k += 64) c.L[c.ly.qfrcapp + GP(m.arm_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.arm_dofadr)[k]];
-  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qfrcapp + GP(m.grip_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.grip_dofadr)[k]];
+  for (int k = c.lane; k < c.D.narmj; k += 64) c.L[c.ly.qfrcapp + GP(m.arm_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.arm_dofadr)[k]];
+  for (int k = c.lane; k < c.D.ngripj; k += 64) c.L[c.ly.qfrcapp + GP(m.grip_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.grip_dofadr)[k]];
   SYNC();
 }
-DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw, float move_speed) {
+template <class Ctx> DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw, float move_speed) {
   CModel &m = c.m;
-  if (m.agent == 2 && c.lane < 2) { // furniture.py:1763-1768: cursors at x = -+0.2, half a move step above the floor
-    float *p = c.L + c.ly.env + E_GROUP + m.nparts + EC_POS + 3 * c.lane;
+  if (c.D.agent == 2 && c.lane < 2) { // furniture.py:1763-1768: cursors at x = -+0.2, half a move step above the floor
+    float *p = c.L + c.ly.env + E_GROUP + c.D.nparts + EC_POS + 3 * c.lane;
     p[0] = c.lane ? 0.2f : -0.2f; p[1] = 0.0f; p[2] = move_speed * 0.5f;
   }
-  for (int k = c.lane; k < m.narmj; k += 64) {
-    float noise = io.tab_noise ? io.tab_noise[(size_t)min(draw, io.n_noise - 1) * m.narmj + k] : 0.0f;
+  for (int k = c.lane; k < c.D.narmj; k += 64) {
+    float noise = io.tab_noise ? io.tab_noise[(size_t)min(draw, io.n_noise - 1) * c.D.narmj + k] : 0.0f;
     c.L[c.ly.qpos + GP(m.arm_qposadr)[k]] = GP(m.arm_initqpos)[k] + noise;
   }
-  for (int k = c.lane; k < m.ngripj; k += 64) c.L[c.ly.qpos + GP(m.grip_qposadr)[k]] = GP(m.grip_initqpos)[k];
+  for (int k = c.lane; k < c.D.ngripj; k += 64) c.L[c.ly.qpos + GP(m.grip_qposadr)[k]] = GP(m.grip_initqpos)[k];
   SYNC();
 }
-DEV void env_settle_parts(const Ctx &c) {
+template <class Ctx> DEV void env_settle_parts(const Ctx &c) {
   CModel &m = c.m;
   for (int o = 0; o < 10; o++) {
-    if (c.lane == 0) for (int p = 0; p < m.nparts; p++) env_stop_part(c, p, 0.0f);
+    if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
     SYNC();
     for (int i = 0; i < 10; i++) {
       fs_step(c);
       // _slow_objects: gravity compensation + clip |qvel| <= 0.2
-      for (int p = c.lane; p < m.nparts; p += 64) {
+      for (int p = c.lane; p < c.D.nparts; p += 64) {
         float *x = c.L + c.ly.xfrc + 6 * p;
-        x[0] = 0; x[1] = 0; x[2] = -m.gravity[2] * GP(m.part_mass)[p]; x[3] = 0; x[4] = 0; x[5] = 0;
+        x[0] = 0; x[1] = 0; x[2] = -c.D.gravity[2] * GP(m.part_mass)[p]; x[3] = 0; x[4] = 0; x[5] = 0;
         int d = GP(m.part_dofadr)[p];
         for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = fminf(fmaxf(c.L[c.ly.qvel + d + k], -0.2f), 0.2f); c.L[c.ly.qfrcapp + d + k] = 0; }
       }
@@ -737,64 +736,63 @@ DEV void env_settle_parts(const Ctx &c) {
   }
 }
 
-__device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *iop) {
+template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *iop) {
   FS_REBUILD_CTX(cv);
   const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp));
   const EnvIO io = *iop;
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int *E = c.I(ly.env);
+  int *E = c.I(c.ly.env);
   // sim.reset()
-  for (int i = c.lane; i < m.nq; i += 64) L[ly.qpos + i] = GP(m.qpos0)[i];
-  for (int i = c.lane; i < m.nv; i += 64) { L[ly.qvel + i] = 0; L[ly.qaccws + i] = 0; L[ly.qfrcbias + i] = 0; L[ly.qfrcapp + i] = 0; }
-  for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
-  for (int i = c.lane; i < 6 * m.nparts; i += 64) L[ly.xfrc + i] = 0;
+  for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = GP(m.qpos0)[i];
+  for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qvel + i] = 0; L[c.ly.qaccws + i] = 0; L[c.ly.qfrcbias + i] = 0; L[c.ly.qfrcapp + i] = 0; }
+  for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
+  for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
   // robot collision off, part colliders on (furniture.py:1441-1461)
-  for (int g = c.lane; g < m.ncg; g += 64) {
+  for (int g = c.lane; g < c.D.ncg; g += 64) {
     int ct = m.cg_contype0[g], ca = m.cg_conaffinity0[g];
     if (m.cg_isrobot[g]) { ct = 0; ca = 0; }
     if (m.cg_ispartcol[g]) { ct = 1; ca = 1; }
-    c.I(ly.contype)[g] = ct; c.I(ly.conaff)[g] = ca;
+    c.I(c.ly.contype)[g] = ct; c.I(c.ly.conaff)[g] = ca;
   }
-  for (int e = c.lane; e < m.neq; e += 64) { c.I(ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
+  for (int e = c.lane; e < c.D.neq; e += 64) { c.I(c.ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[c.ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
   int episodes = E[E_EPISODE_COUNT];
   SYNC();
   for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
-  for (int p = c.lane; p < m.nparts; p += 64) E[E_GROUP + p] = p;
-  if (m.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + m.nparts + i] = 0;
+  for (int p = c.lane; p < c.D.nparts; p += 64) E[E_GROUP + p] = p;
+  if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
   SYNC();
   if (c.lane == 0) { E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; }
   // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
-  for (int i = c.lane; i < 7 * m.nparts; i += 64) {
+  for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
     int p = i / 7, k = i % 7;
-    if (io.tab_parts) L[ly.qpos + GP(m.part_qposadr)[p] + k] = io.tab_parts[i];
+    if (io.tab_parts) L[c.ly.qpos + GP(m.part_qposadr)[p] + k] = io.tab_parts[i];
   }
   SYNC();
   env_settle_parts(c);
   if (cfg.has_recipe) env_settle_parts(c);
   {
-    if (m.narm > 0) env_gravity_comp(c);
+    if (c.D.narm > 0) env_gravity_comp(c);
     env_init_robot(c, io, 0, cfg.move_speed);
     fs_step(c);
-    for (int g = c.lane; g < m.ncg; g += 64)
-      if (m.cg_isrobot[g]) { c.I(ly.contype)[g] = m.cg_contype0[g]; c.I(ly.conaff)[g] = m.cg_conaffinity0[g]; }
+    for (int g = c.lane; g < c.D.ncg; g += 64)
+      if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
     SYNC();
-    if (m.narm > 0) env_gravity_comp(c);
+    if (c.D.narm > 0) env_gravity_comp(c);
     for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k, cfg.move_speed); fs_step(c); }
   }
-  for (int i = c.lane; i < m.nu; i += 64) L[ly.ctrl + i] = 0;
-  for (int i = c.lane; i < m.nv; i += 64) { L[ly.qfrcapp + i] = 0; L[ly.qaccws + i] = 0; }
-  for (int i = c.lane; i < 6 * m.nparts; i += 64) L[ly.xfrc + i] = 0;
+  for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
+  for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qfrcapp + i] = 0; L[c.ly.qaccws + i] = 0; }
+  for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
   SYNC();
   fs_forward(c);
-  if (m.narm > 0) env_gravity_comp(c);
+  if (c.D.narm > 0) env_gravity_comp(c);
   for (int k = 0; k < 100; k++) fs_step(c);
   if (cfg.ik) env_ik_sync(c); // furniture.py:1643-1650
   if (c.lane == 0) {
     env_next_subtask(c);
     if (cfg.dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
-      DenseSimP dp{c, cfg};
+      DenseSimP<Ctx> dp{c, cfg};
       dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, 0);
     }
   }
@@ -802,12 +800,11 @@ __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *
 }
 
 // ---------------------------------------------------------------------------------------------------- step
-DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int *E = c.I(ly.env);
-  int *scal = c.I(ly.scal);
+  int *E = c.I(c.ly.env);
+  int *scal = c.I(c.ly.scal);
   int dof = cfg.dof_action;
   // _before_step + action plumbing
   if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
@@ -816,22 +813,22 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     // _do_ik_step (furniture.py:2911-2958, 2999-3018): per arm d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed
     // in env_ik); the grips follow the arm commands, the last entry is connect.  Block layout per arm: EI_ACT + [dpos 3, rot 3|4, grip]
     const int nrot = cfg.ik == 1 ? 3 : 4, stride = 3 + nrot;
-    for (int t = c.lane; t < m.narm * (stride + 1); t += 64) {
+    for (int t = c.lane; t < c.D.narm * (stride + 1); t += 64) {
       const int arm = t / (stride + 1), k = t % (stride + 1);
-      float *K = L + ly.eik + EI_WORDS * arm;
+      float *K = L + c.ly.eik + EI_WORDS * arm;
       const float *aa = io.action + arm * stride;
       float v;
       if (k == 0) v = -aa[1] * cfg.move_speed;
       else if (k == 1) v = aa[0] * cfg.move_speed;
       else if (k == 2) v = aa[2] * cfg.move_speed;
       else if (k < stride) v = aa[k];
-      else { v = io.action[m.narm * stride + arm]; if (cfg.discrete_grip && cfg.agent == 0) v = v < 0 ? -1.0f : 1.0f; } // furniture_sawyer.py:72-74
+      else { v = io.action[c.D.narm * stride + arm]; if (cfg.discrete_grip && cfg.agent == 0) v = v < 0 ? -1.0f : 1.0f; } // furniture_sawyer.py:72-74
       K[EI_ACT + k] = v;
     }
   } else if (cfg.controller) {
     // FurnitureSawyerEnv._step discretises the grip (furniture_sawyer.py:72-74); _do_controller_step scales the first three
     // entries by move_speed and permutes them [-a1, a0, a2] whatever the controller kind (furniture.py:3069-3071)
-    float *K = L + ly.env + E_GROUP + m.nparts;
+    float *K = L + c.ly.env + E_GROUP + c.D.nparts;
     const int cd = dof - 2;
     if (c.lane < 8) {
       float v = 0;
@@ -845,28 +842,28 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     if (c.lane == 0) reinterpret_cast<int *>(K)[EK_KIND] = cfg.controller;
   } else
   // _setup_action (impedance): clip, gripper 1 -> 2, rescale to ctrlrange, stale gravity compensation
-  for (int u = c.lane; u < m.nu; u += 64) {
+  for (int u = c.lane; u < c.D.nu; u += 64) {
     float a;
-    if (u < m.narmj) a = io.action[u];
+    if (u < c.D.narmj) a = io.action[u];
     else {
-      int gi = (u - m.narmj) >> 1;
-      a = io.action[m.narmj + gi];
+      int gi = (u - c.D.narmj) >> 1;
+      a = io.action[c.D.narmj + gi];
       if (cfg.discrete_grip && cfg.agent == 0) a = a < 0 ? -1.0f : 1.0f; // furniture_sawyer.py:72-74
       if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
-      if ((u - m.narmj) & 1) a = -a; // format_action: [g, -g]
+      if ((u - c.D.narmj) & 1) a = -a; // format_action: [g, -g]
     }
-    if (u < m.narmj && cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
-    L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
+    if (u < c.D.narmj && cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
+    L[c.ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
   }
   SYNC();
-  if (m.agent == 2) {
+  if (c.D.agent == 2) {
     // FurnitureCursorEnv._step: _step_discrete(a) then _do_simulation(None) (furniture_cursor.py:59-70, furniture.py:2857-2897)
     connect = 0; // the arm agents' finger scan below does not apply
     env_cursor_discrete(c, cfg, io.action);
     if (c.lane == 0) { // parts in a selected group float (gravity compensated), the others are only stopped
       int *grp = E + E_GROUP;
       const int *eci = c.I(env_ecur(c));
-      for (int i = 0; i < m.nparts; i++) {
+      for (int i = 0; i < c.D.nparts; i++) {
         int g = env_find(grp, i);
         bool sel = false;
         for (int q = 0; q < 2; q++) if (eci[EC_SEL + q] && env_find(grp, eci[EC_SEL + q] - 1) == g) sel = true;
@@ -879,23 +876,23 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   } else if (cfg.ik) {
     SYNC();
     env_ik(c, cfg.rotate_speed, cfg.ik);
-    const float *K0 = L + ly.eik;
-    const float pgain = GP(m.ik_tab)[IKT_ARM * m.narm + IKT_GAIN];
+    const float *K0 = L + c.ly.eik;
+    const float pgain = GP(m.ik_tab)[IKT_ARM * c.D.narm + IKT_GAIN];
     const int ng = 3 + (cfg.ik == 1 ? 3 : 4); // offset of the grip entry inside EI_ACT
     for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions
       // get_control's P controller (sawyer_ik_controller.py:75-84, baxter_ik_controller.py:86-95), then _setup_action on [velocities, grips]
-      for (int u = c.lane; u < m.nu; u += 64) {
+      for (int u = c.lane; u < c.D.nu; u += 64) {
         float a;
-        if (u < m.narmj) {
+        if (u < c.D.narmj) {
           const float *K = K0 + EI_WORDS * (u / 7);
-          a = fminf(fmaxf(-pgain * (L[ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u % 7]), -1.0f), 1.0f);
+          a = fminf(fmaxf(-pgain * (L[c.ly.qpos + GP(m.arm_qposadr)[u]] - K[EI_QCMD + u % 7]), -1.0f), 1.0f);
         } else {
-          const float *K = K0 + EI_WORDS * ((u - m.narmj) >> 1);
+          const float *K = K0 + EI_WORDS * ((u - c.D.narmj) >> 1);
           a = K[EI_ACT + ng];
           if (cfg.rescale_actions) a = fminf(fmaxf(a, -1.0f), 1.0f);
-          if ((u - m.narmj) & 1) a = -a;
+          if ((u - c.D.narmj) & 1) a = -a;
         }
-        L[ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
+        L[c.ly.ctrl + u] = cfg.rescale_actions ? GP(m.ctrl_bias)[u] + GP(m.ctrl_weight)[u] * a : a;
       }
       SYNC();
       env_gravity_comp(c);
@@ -921,7 +918,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   } else if (connect > 0) {
     // finger-touch scan -> first part (in part order) pinched by both fingers of an arm -> _try_connect
     int done_connect = 0;
-    for (int arm = 0; arm < m.narm && !done_connect; arm++) {
+    for (int arm = 0; arm < c.D.narm && !done_connect; arm++) {
       int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
       if (!both) continue;
       int part = __ffs(both) - 1;
@@ -933,9 +930,9 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     fs_forward(c);
     if (c.lane == 0) {
       int pA = E[E_CONNBODY1] - 1;
-      V3 tp = ldv3(L + ly.env + E_CB1_POS);
-      Q4 tq = ldq(L + ly.env + E_CB1_QUAT);
-      env_move_group(c, pA, tp - ldv3(L + ly.qpos + GP(m.part_qposadr)[pA]), tq, cfg.gravity_comp ? 1.0f : 0.0f);
+      V3 tp = ldv3(L + c.ly.env + E_CB1_POS);
+      Q4 tq = ldq(L + c.ly.env + E_CB1_QUAT);
+      env_move_group(c, pA, tp - ldv3(L + c.ly.qpos + GP(m.part_qposadr)[pA]), tq, cfg.gravity_comp ? 1.0f : 0.0f);
       E[E_CONNBODY1] = 0;
     }
     SYNC();
@@ -947,19 +944,19 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   {
     float s2 = 0;
     for (int k = c.lane; k < dof; k += 64) s2 += io.action[k] * io.action[k];
-    ctrl_pen = m.agent == 2 ? 0.0f : -cfg.ctrl_penalty_coef * wave_sum(s2); // (wave_sum is evaluated by all lanes either way)
+    ctrl_pen = c.D.agent == 2 ? 0.0f : -cfg.ctrl_penalty_coef * wave_sum(s2); // (wave_sum is evaluated by all lanes either way)
   }
   int success = 0, terminal = 0;
   // scheduler hint: is a robot hand within 10 cm of a furniture part's collision geom?  (an env about to enter robot-part
   // contact is the expensive kind next step even if this step was cheap)
   int near = 0;
   if (io.cost) {
-    for (int g = c.lane; g < m.ncg; g += 64) {
+    for (int g = c.lane; g < c.D.ncg; g += 64) {
       if (!m.cg_ispartcol[g]) continue;
       int b = m.cg_body[g];
-      V3 ctr = ldv3(L + ly.xpos + 3 * b) + mulv(ldm3(L + ly.xmat + 9 * b), ldv3(GP(m.cg_pos) + 3 * g));
-      for (int arm = 0; arm < m.narm; arm++) {
-        V3 hp = ldv3(L + ly.xpos + 3 * GP(m.body_red)[GP(m.hand_body)[arm]]);
+      V3 ctr = ldv3(L + c.ly.xpos + 3 * b) + mulv(ldm3(L + c.ly.xmat + 9 * b), ldv3(GP(m.cg_pos) + 3 * g));
+      for (int arm = 0; arm < c.D.narm; arm++) {
+        V3 hp = ldv3(L + c.ly.xpos + 3 * GP(m.body_red)[GP(m.hand_body)[arm]]);
         if (norm(ctr - hp) - GP(m.cg_rbound)[g] < 0.10f) near = 1;
       }
     }
@@ -967,9 +964,9 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   }
   float penalty = 0, dense_rew = 0;
   if (c.lane == 0) {
-    for (int arm = 0; arm < m.narm; arm++) {
+    for (int arm = 0; arm < c.D.narm; arm++) {
       int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
-      for (int p = 0; p < m.nparts; p++) {
+      for (int p = 0; p < c.D.nparts; p++) {
         if (!((both >> p) & 1)) continue;
         if (!((E[E_TOUCHED] >> p) & 1)) { E[E_TOUCHED] |= 1 << p; touch_rew += cfg.touch_reward; }
         if (!((scal[SC_TOUCHF] >> p) & 1) && !((E[E_PICKED] >> p) & 1)) { E[E_PICKED] |= 1 << p; pick_rew += cfg.pick_reward; }
@@ -977,13 +974,13 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
     }
     succ_rew = cfg.success_reward * (float)(E[E_NUM_CONNECTED] - E[E_PREV_NUM_CONNECTED]);
     E[E_PREV_NUM_CONNECTED] = E[E_NUM_CONNECTED];
-    if (E[E_NUM_CONNECTED] == m.nparts - 1 && m.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
+    if (E[E_NUM_CONNECTED] == c.D.nparts - 1 && c.D.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
     terminal = success;
     int dense_phase = 0;
     if (cfg.dense) {
       // FurnitureSawyerEnv._step (furniture_sawyer.py:76-79): the dense _compute_reward replaces the reward and owns _success;
       // done = (all parts connected) or its own done
-      DenseSimP dp{c, cfg};
+      DenseSimP<Ctx> dp{c, cfg};
       DenseOut d = dense_compute(env_edense(c), cfg.dense_coef, cfg.dense_sub, cfg.dense_nsub, dp, io.action, dof, E[E_CONNECTED_THIS_STEP] != 0);
       success = d.success; E[E_SUCCESS] = success;
       terminal = terminal || d.done;
@@ -999,7 +996,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       if (fail) { E[E_FAIL] = 0; penalty = -cfg.unstable_penalty_coef; }
     }
     float rew = cfg.dense ? dense_rew + penalty : succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
-    L[ly.env + E_EPISODE_REWARD] += rew;
+    L[c.ly.env + E_EPISODE_REWARD] += rew;
     if (io.reward) *io.reward = rew;
     if (io.done) *io.done = (uint8_t)terminal;
     if (io.info) {
@@ -1011,7 +1008,7 @@ DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
       io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
       io.info[FSIM_INFO_DENSE_PHASE] = dense_phase;
-      io.info[FSIM_INFO_EPISODE_REWARD_F] = __float_as_int(L[ly.env + E_EPISODE_REWARD]);
+      io.info[FSIM_INFO_EPISODE_REWARD_F] = __float_as_int(L[c.ly.env + E_EPISODE_REWARD]);
     }
     scal[14] = terminal;
     if (io.cost) {

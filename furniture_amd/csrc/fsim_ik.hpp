@@ -84,7 +84,7 @@ DEV void ik_solve6(const float *A, float *b) {
   }
 }
 // hand (right_hand body) pose of the last forward pass
-DEV void ik_hand_world(const Ctx &c, int arm, V3 *pos, M3 *R) {
+template <class Ctx> DEV void ik_hand_world(const Ctx &c, int arm, V3 *pos, M3 *R) {
   CModel &m = c.m;
   const int hb = GP(m.hand_body)[arm], rb = GP(m.body_red)[hb];
   const M3 Rb = ldm3(c.L + c.ly.xmat + 9 * rb);
@@ -103,11 +103,11 @@ DEV void ik_mat2quat_xyzw(const M3 &R, float *q) {
 }
 
 // end of _reset (furniture.py:1643-1650): _initial_<arm>_hand_quat = _<arm>_hand_quat; controller.sync_state()
-DEV void env_ik_sync(const Ctx &c) {
+template <class Ctx> DEV void env_ik_sync(const Ctx &c) {
   CModel &m = c.m;
-  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const auto tail = GP(m.ik_tab) + IKT_ARM * c.D.narm;
   const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
-  for (int arm = 0; arm < m.narm; arm++) {
+  for (int arm = 0; arm < c.D.narm; arm++) {
     float *K = c.L + c.ly.eik + EI_WORDS * arm;
     V3 hp; M3 hR;
     ik_hand_world(c, arm, &hp, &hR);
@@ -130,11 +130,11 @@ DEV void env_ik_sync(const Ctx &c) {
 // End of a step: what the NEXT _do_ik_step will read from sim.data before any new forward pass -- the hand position (for
 // _bounded_d_pos) and, for ik_quaternion, _right_hand_quat -- i.e. the poses of the last forward pass, one integration old.
 // LDS does not survive the launch, so they are kept in the env record.
-DEV void env_ik_remember(const Ctx &c, int mode) {
+template <class Ctx> DEV void env_ik_remember(const Ctx &c, int mode) {
   CModel &m = c.m;
-  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const auto tail = GP(m.ik_tab) + IKT_ARM * c.D.narm;
   const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
-  for (int arm = 0; arm < m.narm; arm++) {
+  for (int arm = 0; arm < c.D.narm; arm++) {
     float *K = c.L + c.ly.eik + EI_WORDS * arm;
     V3 hp; M3 hR;
     ik_hand_world(c, arm, &hp, &hR);
@@ -149,14 +149,14 @@ DEV void env_ik_remember(const Ctx &c, int mode) {
 }
 
 // get_control(dpos, rotation) (sawyer_ik_controller.py:51-88): new target, solve, store commanded_joint_positions
-__device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
+template <class Ctx> __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
   FS_REBUILD_CTX(cv);
   CModel &m = c.m;
-  const auto tail = GP(m.ik_tab) + IKT_ARM * m.narm;
+  const auto tail = GP(m.ik_tab) + IKT_ARM * c.D.narm;
   const float sens = tail[IKT_SENS];
   const bool rest_current = tail[IKT_RESTMODE] != 0.0f, rz = tail[IKT_RZ] != 0.0f;
 #pragma unroll 1
-  for (int arm = 0; arm < m.narm; arm++) {
+  for (int arm = 0; arm < c.D.narm; arm++) {
   const auto tab = GP(m.ik_tab) + IKT_ARM * arm;
   float *K = c.L + c.ly.eik + EI_WORDS * arm;
   const V3 hp = ldv3(K + EI_HPOS);

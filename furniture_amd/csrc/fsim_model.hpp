@@ -19,10 +19,16 @@ enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
 enum { PT_PLANE_SPHERE = 0, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL };
 
-struct DModel {
+// Dimensions and scalar options of a model.  The generic kernels read them at run time (scalar loads from the DModel
+// in constant memory); the kernels specialised for one (agent, furniture, config) carry them as compile-time constants
+// (fsim_spec.hpp), which turns every layout offset into an instruction immediate and every `lane < n` loop into a test.
+struct Dims {
   int nq, nv, nu, nr, ntree, ncg, ncp, nsite, neq, nparts, nM, maxdepth, nconn, narm, nlim, nbody, ngeom, agent;
   int narmj, ngripj;
   float timestep, gravity[3], impratio, meaninertia_scale;
+};
+
+struct DModel : Dims {
   // reduced bodies
   const int *r_parent, *r_jtype, *r_qposadr, *r_dofadr, *r_dofnum, *r_depth, *r_tree, *r_chainadr, *r_chainlen, *r_ancmask;
   const float *r_pos, *r_quat, *r_jaxis, *r_jpos, *r_mass, *r_ipos, *r_inertia;
@@ -92,12 +98,6 @@ enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4,
        SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 80,
        SC_HWORDS = FSIM_SC_BASE + 96, SC_TWORDS = FSIM_SC_BASE + 97, SC_WORDS = FSIM_SC_BASE + 100 };
 
-// Device code reaches the (read-only, launch-constant) model and layout structs through the CONSTANT address space:
-// their fields then come in by scalar loads (s_load_dword through the scalar cache, hoistable and CSE-able across
-// stores) instead of flat vector loads that tick both memory counters and serialise behind every LDS wait.
-typedef const __attribute__((address_space(4))) DModel CModel;
-typedef const __attribute__((address_space(4))) Layout CLayout;
-
 // env-logic block (word offsets relative to Layout::env)
 enum {
   E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL, E_TERMINAL,
@@ -112,3 +112,77 @@ enum { EC_SEL = 0 /* 2 ints: selected part + 1, 0 = none */, EC_POS = 2 /* model
        EC_XPOS = 8 /* data.xpos of the cursors = EC_POS as of the last forward pass */,
        EC_P2Q0 = 14 /* gradual connect (furniture.py:993-1034): part pose at connect step 0 */, EC_BODY_POS = 21, EC_BODY_ROT = 24,
        EC_TOUCH = 28 /* 2 ints: parts in contact with cursor K at the last forward pass */, EC_WORDS = 30 };
+
+#define FSIM_NPAIR 4 // body-pair cross blocks assembled per Hessian pass (fsim_solver.hpp)
+
+// Everything the LDS layout depends on (host: from the model blob + config; specialised kernels: compile-time constants)
+struct LayoutIn {
+  int nq, nv, nu, nr, ntree, ncg, nparts, neq, nlim, nM;
+  int Mwords;    // sum over kinematic trees of n (n + 1) / 2: the tree-packed lower triangles of M
+  int nchain;    // entries of chain_dofs
+  int env_words; // env-logic block of the record: E_FIXED_WORDS + nparts + agent / reward / controller extras
+  int eik_rel;   // offset of the IK blocks behind the group table (the dense block, if any, comes first)
+  int ncon_max;
+};
+
+// One function for host and device: fsim_create calls it at run time, fsim_spec.hpp at compile time.
+constexpr Layout make_layout(const LayoutIn &in) {
+  Layout ly{};
+  int o = 0;
+#define TAKE(field, n) do { ly.field = o; o += (n); } while (0)
+  TAKE(qpos, in.nq); TAKE(qvel, in.nv); TAKE(qaccws, in.nv); TAKE(qfrcbias, in.nv); TAKE(ctrl, in.nu);
+  TAKE(qfrcapp, in.nv); TAKE(xfrc, 6 * in.nparts); TAKE(eqdata, 7 * in.neq); TAKE(eqactive, in.neq);
+  TAKE(contype, in.ncg); TAKE(conaff, in.ncg); TAKE(env, in.env_words);
+  ly.eik = ly.env + E_GROUP + in.nparts + in.eik_rel;
+  o = (o + 3) / 4 * 4;
+  ly.stride = o;
+  // LDS-only
+  TAKE(xpos, 3 * in.nr); TAKE(xquat, 4 * in.nr); TAKE(xmat, 9 * in.nr); TAKE(xipos, 3 * in.nr); TAKE(com, 3 * in.ntree);
+  TAKE(cvel, 6 * in.nr); // read by constraint assembly AND by the observation (site velocities): never aliased
+  const int hstart = o;
+  TAKE(cinert, 10 * in.nr); TAKE(crb, 10 * in.nr); TAKE(cdofdot, 6 * in.nv); TAKE(cacc, 6 * in.nr); TAKE(cfrc, 6 * in.nr);
+  // joint anchors / axes are only live between kinematics and the motion-axis computation: they sit in the unused cacc slot
+  ly.xanchor = ly.cacc; ly.xaxis = ly.cacc + 3 * in.nr;
+  // H (Newton Hessian, packed lower triangle) is only live inside fs_solve, after the rigid-body temporaries above are
+  // dead, so it aliases them.
+  const int nH = in.nv * (in.nv + 1) / 2;
+  ly.H = hstart;
+  if (hstart + nH > o) o = hstart + nH;
+  TAKE(cdof, 6 * in.nv);
+  TAKE(M, in.Mwords); // tree-packed triangle layout of k_tmap (dense lower triangle per kinematic tree)
+  ly.LD = ly.M; ly.Dinv = ly.M; ly.LDh = ly.M; ly.Dhinv = ly.M;
+  TAKE(smooth, in.nv); ly.asmooth = ly.smooth; TAKE(x, in.nv); TAKE(Mx, in.nv); TAKE(grad, in.nv); TAKE(p, in.nv); TAKE(Mp, in.nv);
+  TAKE(gpos, 3 * in.ncg); TAKE(gmat, 9 * in.ncg);
+  {
+    int need = 21 * in.nr + 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
+    ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * in.nr;
+    if (need < 12 * in.nr) need = 12 * in.nr;
+    if (need > 12 * in.ncg) o += need - 12 * in.ncg;
+    // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
+    ly.W = ly.gpos; ly.G = ly.gpos + 6 * in.nr;
+  }
+  TAKE(surv, FSIM_MAXSURV);
+  TAKE(con, FSIM_CONW * in.ncon_max); TAKE(weld, FSIM_WELDW * in.neq); TAKE(lim, FSIM_LIMW * 2 * in.nlim);
+  TAKE(scal, SC_WORDS); TAKE(hmap, 2 * in.nv);
+  // LDS model cache
+  ly.k_begin = o;
+  TAKE(k_dof_parent, in.nv); TAKE(k_r_submask, in.nr); TAKE(k_dof_rbody, in.nv); TAKE(k_dof_tree, in.nv);
+  TAKE(k_r_parent, in.nr); TAKE(k_r_jtype, in.nr); TAKE(k_r_qposadr, in.nr); TAKE(k_r_dofadr, in.nr); TAKE(k_r_chain, in.nr);
+  TAKE(k_r_tree, in.nr); TAKE(k_r_chainadr, in.nr); TAKE(k_r_chainlen, in.nr); ly.k_r_ancmask = 0; TAKE(k_chain_dofs, in.nchain);
+  TAKE(k_tree_dofadr, in.ntree); TAKE(k_tree_dofnum, in.ntree); TAKE(k_tree_bodyadr, in.ntree); TAKE(k_tree_bodynum, in.ntree);
+  TAKE(k_M_ij, in.nM);
+  ly.k_r_pos = 0; ly.k_r_quat = 0; ly.k_r_jpos = 0; ly.k_r_jaxis = 0; ly.k_r_ipos = 0; ly.k_r_inertia = 0; // not cached
+  TAKE(k_r_mass, in.nr); TAKE(k_dof_damping, in.nv); TAKE(k_dof_armature, in.nv); TAKE(k_tmap, 2 * in.nv);
+  ly.k_end = o;
+#undef TAKE
+  ly.lds_words = o;
+  ly.ncon_max = in.ncon_max;
+  return ly;
+}
+
+// Device code reaches the (read-only, launch-constant) model and layout structs through the CONSTANT address space:
+// their fields then come in by scalar loads (s_load_dword through the scalar cache, hoistable and CSE-able across
+// stores) instead of flat vector loads that tick both memory counters and serialise behind every LDS wait.
+typedef const __attribute__((address_space(4))) DModel CModel;
+typedef const __attribute__((address_space(4))) Layout CLayout;
+

@@ -18,15 +18,34 @@
 #define SYNC() __syncthreads()
 #endif
 
-struct Ctx {
+// The per-wave context.  Two flavours with the same member names, so the physics / solver / env code is written once as
+// templates over the context type:
+//   GenCtx  -- layout offsets and model dimensions are run-time values (scalar loads from constant memory): any model;
+//   SpecCtx -- they are compile-time constants of the specialisation S (fsim_spec.hpp): offsets become instruction
+//              immediates, `for (i = lane; i < n; i += 64)` loops become a single test, no SGPRs are spent on the layout.
+struct GenCtx {
   float *L;          // LDS base (state image followed by work arrays)
-  CModel &m;
-  CLayout &ly;
+  CModel &m;         // model tables (pointers)
+  CLayout &ly;       // LDS / record layout
+  CModel &D;         // dimensions + scalar options (the Dims base of the same struct)
   int lane;
   int newton_maxit;
   float newton_tol;
-  __device__ Ctx(float *L_, CModel &m_, CLayout &ly_, int lane_, int it, float tol)
-      : L(L_), m(m_), ly(ly_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
+  __device__ GenCtx(float *L_, CModel &m_, CLayout &ly_, int lane_, int it, float tol)
+      : L(L_), m(m_), ly(ly_), D(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
+  DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
+};
+template <class S> struct SpecCtx {
+  float *L;
+  CModel &m;
+  static constexpr Layout ly = S::ly;
+  static constexpr Dims D = S::D;
+  int lane;
+  int newton_maxit;
+  float newton_tol;
+  __device__ SpecCtx(float *L_, CModel &m_, CLayout &, int lane_, int it, float tol)
+      : L(L_), m(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
+  __device__ SpecCtx(float *L_, CModel &m_, int lane_, int it, float tol) : L(L_), m(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
 };
 
@@ -36,12 +55,18 @@ template <class T> DEV T *fs_uniform_ptr(T *p) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (T *)(((unsigned long long)hi << 32) | lo);
 }
-#define FS_REBUILD_CTX(cv)                                                                                      \
-  extern __shared__ float fs_lds_[];                                                                            \
-  CModel &m_u_ = *fs_uniform_ptr(&(cv).m);                                                                      \
-  CLayout &ly_u_ = *fs_uniform_ptr(&(cv).ly);                                                                   \
-  Ctx c(fs_lds_, m_u_, ly_u_, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((cv).newton_maxit),              \
-        __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((cv).newton_tol))))
+DEV GenCtx fs_rebuild(const GenCtx &cv, float *lds) {
+  return GenCtx(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+}
+template <class S> DEV SpecCtx<S> fs_rebuild(const SpecCtx<S> &cv, float *lds) {
+  CModel &mu = *fs_uniform_ptr(&cv.m);
+  return SpecCtx<S>(lds, mu, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                    __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+}
+#define FS_REBUILD_CTX(cv)            \
+  extern __shared__ float fs_lds_[];  \
+  const Ctx c = fs_rebuild(cv, fs_lds_)
 
 
 #define KI(field, idx) (c.I(c.ly.k_##field)[idx])
@@ -52,16 +77,16 @@ template <class T> DEV T *fs_uniform_ptr(T *p) {
 #define KFP(field) (c.L + c.ly.k_##field)
 
 // copy the hot model tables HBM -> LDS (once per kernel launch; the 50 substeps then never leave the CU for them)
-DEV void fs_load_cache(const Ctx &c) {
+template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
   CModel &m = c.m;
-  int nb = m.nr, nv = m.nv, nchain = 0;
+  int nb = c.D.nr, nv = c.D.nv, nchain = 0;
   for (int b = 0; b < nb; b++) nchain = max(nchain, GP(m.r_chainadr)[b] + GP(m.r_chainlen)[b]);
 #define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
 #define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
   CPI(dof_parent, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
   CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_tree, nb);
   CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(chain_dofs, nchain);
-  CPI(tree_dofadr, m.ntree); CPI(tree_dofnum, m.ntree); CPI(tree_bodyadr, m.ntree); CPI(tree_bodynum, m.ntree);
+  CPI(tree_dofadr, c.D.ntree); CPI(tree_dofnum, c.D.ntree); CPI(tree_bodyadr, c.D.ntree); CPI(tree_bodynum, c.D.ntree);
   // (body-frame constants r_pos/r_quat/r_jpos/r_jaxis/r_ipos/r_inertia are read once per substep by lane-per-body
   //  passes: they stay in HBM/L2 and their 330 words of LDS buy an extra workgroup per CU instead)
   CPF(r_mass, nb); CPF(dof_damping, nv); CPF(dof_armature, nv);
@@ -88,107 +113,105 @@ DEV void fs_load_cache(const Ctx &c) {
   SYNC();
   // M entry e -> (i, j, packed index in the tree-packed triangle); the entries of M that are structurally zero
   // (two branches of one tree) are zeroed once here and never written again
-  for (int e = c.lane; e < m.nM; e += 64) {
+  for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = GP(m.M_i)[e], j = GP(m.M_j)[e];
     int pidx = (c.I(c.ly.k_tmap)[i] & 0xfff) + ((c.I(c.ly.k_tmap)[j] >> 12) & 63);
     c.I(c.ly.k_M_ij)[e] = (pidx << 16) | (i << 8) | j;
   }
   {
     int w = 0;
-    for (int u = 0; u < m.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
+    for (int u = 0; u < c.D.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     for (int k = c.lane; k < w; k += 64) c.L[c.ly.M + k] = 0.0f;
   }
   if (c.lane == 0) {
     int w = 0;
-    for (int u = 0; u < m.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
+    for (int u = 0; u < c.D.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     c.I(c.ly.scal)[SC_TWORDS] = w; // packed size of the tree-block system
   }
   SYNC();
 }
 
 // ------------------------------------------------------------------------------------------ P1
-DEV void fs_kinematics(const Ctx &c) {
+template <class Ctx> DEV void fs_kinematics(const Ctx &c) {
   // Three passes.  (A) lane = body: joint transform relative to the parent frame (trig, quaternion products) -- parallel;
   // (B) lane = tree: compose parent * local down the chain with the parent pose held in registers -- the only serial
   // part, ~40 instructions per body for the 8-deep Sawyer chain; (C) lane = body: rotation matrix, joint anchor / axis
   // and inertial-frame origin in world coordinates -- parallel.
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  for (int b = c.lane; b < m.nr; b += 64) {
-    if (b == 0) { stv3(L + ly.xpos, v3(0, 0, 0)); stq(L + ly.xquat, q4(1, 0, 0, 0)); continue; }
+  for (int b = c.lane; b < c.D.nr; b += 64) {
+    if (b == 0) { stv3(L + c.ly.xpos, v3(0, 0, 0)); stq(L + c.ly.xquat, q4(1, 0, 0, 0)); continue; }
     int jt = KI(r_jtype, b), qa = KI(r_qposadr, b);
     V3 pl, al, axl = v3(0, 0, 1);
     Q4 ql;
     if (jt == JT_FREE) {
-      const float *q = L + ly.qpos + qa;
+      const float *q = L + c.ly.qpos + qa;
       pl = ldv3(q);
       ql = qnormalized(ldq(q + 3));
-      stq(L + ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
+      stq(L + c.ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
       al = pl;
     } else {
       Q4 q0 = ldq(GP(m.r_quat) + 4 * b);
       V3 p0 = ldv3(GP(m.r_pos) + 3 * b), jpos = ldv3(GP(m.r_jpos) + 3 * b), jax = ldv3(GP(m.r_jaxis) + 3 * b);
       al = p0 + qrot(q0, jpos);
       axl = qrot(q0, jax);
-      float q = L[ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
+      float q = L[c.ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
       if (jt == JT_SLIDE) { ql = q0; pl = p0 + axl * q; }
       else { ql = qmul(q0, axisangle(jax, q)); pl = al - qrot(ql, jpos); }
     }
-    stv3(L + ly.xpos + 3 * b, pl); stq(L + ly.xquat + 4 * b, ql);
-    stv3(L + ly.xanchor + 3 * b, al); stv3(L + ly.xaxis + 3 * b, axl);
+    stv3(L + c.ly.xpos + 3 * b, pl); stq(L + c.ly.xquat + 4 * b, ql);
+    stv3(L + c.ly.xanchor + 3 * b, al); stv3(L + c.ly.xaxis + 3 * b, axl);
   }
   SYNC();
-  for (int t = c.lane; t < m.ntree; t += 64) {
+  for (int t = c.lane; t < c.D.ntree; t += 64) {
     int b0 = KI(tree_bodyadr, t), nbod = KI(tree_bodynum, t);
     int pid = 0;
     V3 ppos = v3(0, 0, 0);
     Q4 pquat = q4(1, 0, 0, 0);
     for (int b = b0; b < b0 + nbod; b++) {
       int p = KI(r_parent, b);
-      if (p != pid) { ppos = ldv3(L + ly.xpos + 3 * p); pquat = ldq(L + ly.xquat + 4 * p); pid = p; } // branch: parent already final
-      V3 pos = ppos + qrot(pquat, ldv3(L + ly.xpos + 3 * b));
-      Q4 quat = qnormalized(qmul(pquat, ldq(L + ly.xquat + 4 * b)));
-      stv3(L + ly.xpos + 3 * b, pos); stq(L + ly.xquat + 4 * b, quat);
+      if (p != pid) { ppos = ldv3(L + c.ly.xpos + 3 * p); pquat = ldq(L + c.ly.xquat + 4 * p); pid = p; } // branch: parent already final
+      V3 pos = ppos + qrot(pquat, ldv3(L + c.ly.xpos + 3 * b));
+      Q4 quat = qnormalized(qmul(pquat, ldq(L + c.ly.xquat + 4 * b)));
+      stv3(L + c.ly.xpos + 3 * b, pos); stq(L + c.ly.xquat + 4 * b, quat);
       pid = b; ppos = pos; pquat = quat;
     }
   }
   SYNC();
-  for (int b = c.lane; b < m.nr; b += 64) {
-    M3 R = q2m(ldq(L + ly.xquat + 4 * b));
-    stm3(L + ly.xmat + 9 * b, R);
-    stv3(L + ly.xipos + 3 * b, ldv3(L + ly.xpos + 3 * b) + mulv(R, ldv3(GP(m.r_ipos) + 3 * b)));
+  for (int b = c.lane; b < c.D.nr; b += 64) {
+    M3 R = q2m(ldq(L + c.ly.xquat + 4 * b));
+    stm3(L + c.ly.xmat + 9 * b, R);
+    stv3(L + c.ly.xipos + 3 * b, ldv3(L + c.ly.xpos + 3 * b) + mulv(R, ldv3(GP(m.r_ipos) + 3 * b)));
     if (b > 0) { // joint anchor / axis were left in the parent frame by pass A
       int p = KI(r_parent, b);
-      V3 pp = ldv3(L + ly.xpos + 3 * p);
-      Q4 pq = ldq(L + ly.xquat + 4 * p);
-      stv3(L + ly.xanchor + 3 * b, pp + qrot(pq, ldv3(L + ly.xanchor + 3 * b)));
-      stv3(L + ly.xaxis + 3 * b, qrot(pq, ldv3(L + ly.xaxis + 3 * b)));
+      V3 pp = ldv3(L + c.ly.xpos + 3 * p);
+      Q4 pq = ldq(L + c.ly.xquat + 4 * p);
+      stv3(L + c.ly.xanchor + 3 * b, pp + qrot(pq, ldv3(L + c.ly.xanchor + 3 * b)));
+      stv3(L + c.ly.xaxis + 3 * b, qrot(pq, ldv3(L + c.ly.xaxis + 3 * b)));
     }
   }
   SYNC();
 }
 
 // per-tree centre of mass, body inertias about it, motion axes (mj_comPos)
-DEV void fs_com_inertia(const Ctx &c) {
+template <class Ctx> DEV void fs_com_inertia(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  for (int t = c.lane; t < m.ntree; t += 64) {
+  for (int t = c.lane; t < c.D.ntree; t += 64) {
     V3 s = v3(0, 0, 0);
     float tot = 0;
     for (int b = KI(tree_bodyadr, t); b < KI(tree_bodyadr, t) + KI(tree_bodynum, t); b++) {
       float ms = KF(r_mass, b);
-      s = s + ms * ldv3(L + ly.xipos + 3 * b);
+      s = s + ms * ldv3(L + c.ly.xipos + 3 * b);
       tot += ms;
     }
-    stv3(L + ly.com + 3 * t, tot > 0 ? s * (1.0f / tot) : ldv3(L + ly.xpos + 3 * KI(tree_bodyadr, t)));
+    stv3(L + c.ly.com + 3 * t, tot > 0 ? s * (1.0f / tot) : ldv3(L + c.ly.xpos + 3 * KI(tree_bodyadr, t)));
   }
   SYNC();
-  for (int b = c.lane; b < m.nr; b += 64) {
-    float *I = L + ly.cinert + 10 * b;
+  for (int b = c.lane; b < c.D.nr; b += 64) {
+    float *I = L + c.ly.cinert + 10 * b;
     if (b == 0) { for (int k = 0; k < 10; k++) I[k] = 0; continue; }
-    M3 R = ldm3(L + ly.xmat + 9 * b);
+    M3 R = ldm3(L + c.ly.xmat + 9 * b);
     auto ib = GP(m.r_inertia) + 6 * b; // xx yy zz xy xz yz in body frame
     M3 Ib;
     Ib.m[0] = ib[0]; Ib.m[4] = ib[1]; Ib.m[8] = ib[2]; Ib.m[1] = Ib.m[3] = ib[3]; Ib.m[2] = Ib.m[6] = ib[4]; Ib.m[5] = Ib.m[7] = ib[5];
@@ -201,62 +224,61 @@ DEV void fs_com_inertia(const Ctx &c) {
       w[e] = T.m[3 * i] * R.m[3 * j] + T.m[3 * i + 1] * R.m[3 * j + 1] + T.m[3 * i + 2] * R.m[3 * j + 2];
     }
     float ms = KF(r_mass, b);
-    V3 d = ldv3(L + ly.xipos + 3 * b) - ldv3(L + ly.com + 3 * KI(r_tree, b));
+    V3 d = ldv3(L + c.ly.xipos + 3 * b) - ldv3(L + c.ly.com + 3 * KI(r_tree, b));
     float dd = dot(d, d);
     I[0] = w[0] + ms * (dd - d.x * d.x); I[1] = w[1] + ms * (dd - d.y * d.y); I[2] = w[2] + ms * (dd - d.z * d.z);
     I[3] = w[3] - ms * d.x * d.y; I[4] = w[4] - ms * d.x * d.z; I[5] = w[5] - ms * d.y * d.z;
     I[6] = ms * d.x; I[7] = ms * d.y; I[8] = ms * d.z; I[9] = ms;
   }
-  for (int d = c.lane; d < m.nv; d += 64) {
+  for (int d = c.lane; d < c.D.nv; d += 64) {
     int b = KI(dof_rbody, d), jt = KI(r_jtype, b), k = d - KI(r_dofadr, b);
-    V3 com = ldv3(L + ly.com + 3 * KI(r_tree, b));
+    V3 com = ldv3(L + c.ly.com + 3 * KI(r_tree, b));
     S6 s;
     if (jt == JT_FREE) {
       if (k < 3) { s.a = v3(0, 0, 0); s.l = v3(k == 0, k == 1, k == 2); }
       else {
-        M3 R = ldm3(L + ly.xmat + 9 * b);
+        M3 R = ldm3(L + c.ly.xmat + 9 * b);
         s.a = colv(R, k - 3);
-        s.l = cross(s.a, com - ldv3(L + ly.xpos + 3 * b));
+        s.l = cross(s.a, com - ldv3(L + c.ly.xpos + 3 * b));
       }
-    } else if (jt == JT_SLIDE) { s.a = v3(0, 0, 0); s.l = ldv3(L + ly.xaxis + 3 * b); }
-    else { s.a = ldv3(L + ly.xaxis + 3 * b); s.l = cross(s.a, com - ldv3(L + ly.xanchor + 3 * b)); }
-    sts6(L + ly.cdof + 6 * d, s);
+    } else if (jt == JT_SLIDE) { s.a = v3(0, 0, 0); s.l = ldv3(L + c.ly.xaxis + 3 * b); }
+    else { s.a = ldv3(L + c.ly.xaxis + 3 * b); s.l = cross(s.a, com - ldv3(L + c.ly.xanchor + 3 * b)); }
+    sts6(L + c.ly.cdof + 6 * d, s);
   }
   SYNC();
 }
 
 // ------------------------------------------------------------------------------------------ P2
-DEV void fs_crb_factor(const Ctx &c) {
+template <class Ctx> DEV void fs_crb_factor(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
   // composite inertia: sum over descendants (no serial tree pass: each lane scans the body list)
-  for (int b = c.lane; b < m.nr; b += 64) {
+  for (int b = c.lane; b < c.D.nr; b += 64) {
     float acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
     for (int mm = KI(r_submask, b); mm; mm &= mm - 1) {
-      const float *I = L + ly.cinert + 10 * (__ffs(mm) - 1);
+      const float *I = L + c.ly.cinert + 10 * (__ffs(mm) - 1);
       for (int k = 0; k < 10; k++) acc[k] += I[k];
     }
-    for (int k = 0; k < 10; k++) L[ly.crb + 10 * b + k] = acc[k];
+    for (int k = 0; k < 10; k++) L[c.ly.crb + 10 * b + k] = acc[k];
   }
   SYNC();
-  for (int e = c.lane; e < m.nM; e += 64) {
+  for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = KM_I(e), j = KM_J(e);
-    S6 f = inert_mul(L + ly.crb + 10 * KI(dof_rbody, i), lds6(L + ly.cdof + 6 * i));
-    float v = dot6(lds6(L + ly.cdof + 6 * j), f);
+    S6 f = inert_mul(L + c.ly.crb + 10 * KI(dof_rbody, i), lds6(L + c.ly.cdof + 6 * i));
+    float v = dot6(lds6(L + c.ly.cdof + 6 * j), f);
     if (i == j) v += KF(dof_armature, i);
-    L[ly.M + KM_P(e)] = v;
+    L[c.ly.M + KM_P(e)] = v;
   }
   SYNC();
 }
 
 // y = M v.  M is a dense packed lower triangle per kinematic tree (layout of k_tmap), so lane = dof gathers its row
 // with computed addresses: no index loads, no atomics, one barrier.
-DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
+template <class Ctx> DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   CModel &m = c.m;
   float *L = c.L;
-  for (int i = c.lane; i < m.nv; i += 64) {
+  for (int i = c.lane; i < c.D.nv; i += 64) {
     const int w = c.I(c.ly.k_tmap)[i];
     const int li = (w >> 12) & 63, n = (w >> 18) & 127, a = (w >> 25) & 63; // local index, tree size, first dof
     const int rowi = w & 0xfff, tb = rowi - li * (li + 1) / 2;
@@ -270,79 +292,77 @@ DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
 }
 
 // ------------------------------------------------------------------------------------------ P5/P6
-DEV void fs_velocity_bias(const Ctx &c) {
+template <class Ctx> DEV void fs_velocity_bias(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
   // cdof_dot: velocity of everything *before* the dof in the chain, crossed with the axis
-  for (int d = c.lane; d < m.nv; d += 64) {
+  for (int d = c.lane; d < c.D.nv; d += 64) {
     int b = KI(dof_rbody, d), jt = KI(r_jtype, b), k = d - KI(r_dofadr, b);
     S6 v = s6zero();
     if (jt == JT_FREE) {
-      if (k >= 3) for (int t = 0; t < 3; t++) { int dd = KI(r_dofadr, b) + t; v = v + lds6(L + ly.cdof + 6 * dd) * L[ly.qvel + dd]; }
+      if (k >= 3) for (int t = 0; t < 3; t++) { int dd = KI(r_dofadr, b) + t; v = v + lds6(L + c.ly.cdof + 6 * dd) * L[c.ly.qvel + dd]; }
     } else {
-      for (int a = KI(dof_parent, d); a >= 0; a = KI(dof_parent, a)) v = v + lds6(L + ly.cdof + 6 * a) * L[ly.qvel + a];
+      for (int a = KI(dof_parent, d); a >= 0; a = KI(dof_parent, a)) v = v + lds6(L + c.ly.cdof + 6 * a) * L[c.ly.qvel + a];
     }
-    S6 sd = (jt == JT_FREE && k < 3) ? s6zero() : cross_motion(v, lds6(L + ly.cdof + 6 * d));
-    sts6(L + ly.cdofdot + 6 * d, sd);
+    S6 sd = (jt == JT_FREE && k < 3) ? s6zero() : cross_motion(v, lds6(L + c.ly.cdof + 6 * d));
+    sts6(L + c.ly.cdofdot + 6 * d, sd);
   }
   SYNC();
-  for (int b = c.lane; b < m.nr; b += 64) {
+  for (int b = c.lane; b < c.D.nr; b += 64) {
     S6 v = s6zero(), a = s6zero();
-    a.l = v3(-m.gravity[0], -m.gravity[1], -m.gravity[2]);
+    a.l = v3(-c.D.gravity[0], -c.D.gravity[1], -c.D.gravity[2]);
     {
       const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
       for (int mm = ch & 0x3ffffff; mm; mm &= mm - 1) {
         int d = base + __ffs(mm) - 1;
-        float qd = L[ly.qvel + d];
-        v = v + lds6(L + ly.cdof + 6 * d) * qd;
-        a = a + lds6(L + ly.cdofdot + 6 * d) * qd;
+        float qd = L[c.ly.qvel + d];
+        v = v + lds6(L + c.ly.cdof + 6 * d) * qd;
+        a = a + lds6(L + c.ly.cdofdot + 6 * d) * qd;
       }
     }
-    sts6(L + ly.cvel + 6 * b, v);
+    sts6(L + c.ly.cvel + 6 * b, v);
     S6 f = s6zero();
     if (b > 0) {
-      const float *I = L + ly.cinert + 10 * b;
+      const float *I = L + c.ly.cinert + 10 * b;
       f = inert_mul(I, a) + cross_force(v, inert_mul(I, v));
     }
-    sts6(L + ly.cfrc + 6 * b, f);
+    sts6(L + c.ly.cfrc + 6 * b, f);
   }
   SYNC();
-  for (int d = c.lane; d < m.nv; d += 64) {
+  for (int d = c.lane; d < c.D.nv; d += 64) {
     int bd = KI(dof_rbody, d);
-    S6 s = lds6(L + ly.cdof + 6 * d);
+    S6 s = lds6(L + c.ly.cdof + 6 * d);
     float acc = 0;
-    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + ly.cfrc + 6 * (__ffs(mm) - 1)));
-    L[ly.qfrcbias + d] = acc;
+    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + c.ly.cfrc + 6 * (__ffs(mm) - 1)));
+    L[c.ly.qfrcbias + d] = acc;
   }
   SYNC();
 }
 
-DEV void fs_smooth(const Ctx &c) {
+template <class Ctx> DEV void fs_smooth(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  for (int d = c.lane; d < m.nv; d += 64)
-    L[ly.smooth + d] = -KF(dof_damping, d) * L[ly.qvel + d] - L[ly.qfrcbias + d] + L[ly.qfrcapp + d];
+  for (int d = c.lane; d < c.D.nv; d += 64)
+    L[c.ly.smooth + d] = -KF(dof_damping, d) * L[c.ly.qvel + d] - L[c.ly.qfrcbias + d] + L[c.ly.qfrcapp + d];
   SYNC();
-  for (int u = c.lane; u < m.nu; u += 64) {
-    float ct = L[ly.ctrl + u];
+  for (int u = c.lane; u < c.D.nu; u += 64) {
+    float ct = L[c.ly.ctrl + u];
     if (GP(m.act_ctrllimited)[u]) ct = fminf(fmaxf(ct, GP(m.act_ctrlrange)[2 * u]), GP(m.act_ctrlrange)[2 * u + 1]);
     float g = GP(m.act_gear)[u];
-    float len = L[ly.qpos + GP(m.act_qpos)[u]] * g, vel = L[ly.qvel + GP(m.act_dof)[u]] * g;
+    float len = L[c.ly.qpos + GP(m.act_qpos)[u]] * g, vel = L[c.ly.qvel + GP(m.act_dof)[u]] * g;
     float f = GP(m.act_gain)[u] * ct + GP(m.act_bias)[3 * u] + GP(m.act_bias)[3 * u + 1] * len + GP(m.act_bias)[3 * u + 2] * vel;
     if (GP(m.act_forcelimited)[u]) f = fminf(fmaxf(f, GP(m.act_forcerange)[2 * u]), GP(m.act_forcerange)[2 * u + 1]);
-    atomicAdd(L + ly.smooth + GP(m.act_dof)[u], f * g);
+    atomicAdd(L + c.ly.smooth + GP(m.act_dof)[u], f * g);
   }
-  for (int p = c.lane; p < m.nparts; p += 64) {
-    const float *F = L + ly.xfrc + 6 * p;
+  for (int p = c.lane; p < c.D.nparts; p += 64) {
+    const float *F = L + c.ly.xfrc + 6 * p;
     V3 f = ldv3(F), t = ldv3(F + 3);
     if (f.x != 0 || f.y != 0 || f.z != 0 || t.x != 0 || t.y != 0 || t.z != 0) {
       int b = GP(m.part_rbody)[p], d = GP(m.part_dofadr)[p];
-      M3 R = ldm3(L + ly.xmat + 9 * b);
-      V3 tq = multv(R, t + cross(ldv3(L + ly.xipos + 3 * b) - ldv3(L + ly.xpos + 3 * b), f));
-      atomicAdd(L + ly.smooth + d, f.x); atomicAdd(L + ly.smooth + d + 1, f.y); atomicAdd(L + ly.smooth + d + 2, f.z);
-      atomicAdd(L + ly.smooth + d + 3, tq.x); atomicAdd(L + ly.smooth + d + 4, tq.y); atomicAdd(L + ly.smooth + d + 5, tq.z);
+      M3 R = ldm3(L + c.ly.xmat + 9 * b);
+      V3 tq = multv(R, t + cross(ldv3(L + c.ly.xipos + 3 * b) - ldv3(L + c.ly.xpos + 3 * b), f));
+      atomicAdd(L + c.ly.smooth + d, f.x); atomicAdd(L + c.ly.smooth + d + 1, f.y); atomicAdd(L + c.ly.smooth + d + 2, f.z);
+      atomicAdd(L + c.ly.smooth + d + 3, tq.x); atomicAdd(L + c.ly.smooth + d + 4, tq.y); atomicAdd(L + c.ly.smooth + d + 5, tq.z);
     }
   }
   SYNC();

@@ -44,8 +44,8 @@ template <class P1, class P2> DEV float fs_impedance(P1 solref, P2 solimp, float
 }
 
 // bt = body | tree << 8 (contact slots store it that way; fs_bt builds it for other callers)
-DEV int fs_bt(const Ctx &c, int b) { return b | (KI(r_tree, b) << 8); }
-DEV V3 fs_ptvel(const Ctx &c, int off, int bt, V3 p) {
+template <class Ctx> DEV int fs_bt(const Ctx &c, int b) { return b | (KI(r_tree, b) << 8); }
+template <class Ctx> DEV V3 fs_ptvel(const Ctx &c, int off, int bt, V3 p) {
   const int b = bt & 255;
   if (b == 0) return v3(0, 0, 0);
   S6 w = lds6(c.L + off + 6 * b);
@@ -53,17 +53,16 @@ DEV V3 fs_ptvel(const Ctx &c, int off, int bt, V3 p) {
 }
 
 // returns 1 if any constraint couples two kinematic trees
-DEV int fs_make_constraints(const Ctx &c) {
+template <class Ctx> DEV int fs_make_constraints(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int nslot = c.I(ly.scal)[SC_NSLOT];
+  int nslot = c.I(c.ly.scal)[SC_NSLOT];
   int coupled = 0, ncon = 0;
-  int *adj = c.I(ly.scal) + SC_ADJ; // tree adjacency bitmasks (islands for the block Cholesky)
-  if (c.lane < m.ntree) adj[c.lane] = 1 << c.lane;
+  int *adj = c.I(c.ly.scal) + SC_ADJ; // tree adjacency bitmasks (islands for the block Cholesky)
+  if (c.lane < c.D.ntree) adj[c.lane] = 1 << c.lane;
   SYNC();
   for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + ly.con + FSIM_CONW * s;
+    float *r = L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     ncon++;
@@ -71,16 +70,16 @@ DEV int fs_make_constraints(const Ctx &c) {
     float dist = r[C_DIST], incm = r[C_INCM];
     if (dist >= incm) { ri[C_ACTIVE] = 2; continue; }
     V3 pos = ldv3(r + C_POS);
-    V3 vrel = fs_ptvel(c, ly.cvel, bt2, pos) - fs_ptvel(c, ly.cvel, bt1, pos);
+    V3 vrel = fs_ptvel(c, c.ly.cvel, bt2, pos) - fs_ptvel(c, c.ly.cvel, bt1, pos);
     float mix = GP(m.cg_solmix)[g1] / (GP(m.cg_solmix)[g1] + GP(m.cg_solmix)[g2]);
     float sr[2], si[5];
     for (int i = 0; i < 2; i++) sr[i] = mix * GP(m.cg_solref)[2 * g1 + i] + (1 - mix) * GP(m.cg_solref)[2 * g2 + i];
     for (int i = 0; i < 5; i++) si[i] = mix * GP(m.cg_solimp)[5 * g1 + i] + (1 - mix) * GP(m.cg_solimp)[5 * g2 + i];
     float k, b;
-    float imp = fs_impedance(sr, si, dist - incm, m.timestep, &k, &b);
+    float imp = fs_impedance(sr, si, dist - incm, c.D.timestep, &k, &b);
     float R = fmaxf((1 - imp) / imp * (GP(m.cg_invweight)[g1] + GP(m.cg_invweight)[g2]), 1e-15f);
     r[C_DN] = 1.0f / R;
-    r[C_DT] = fmaxf(m.impratio, 1e-15f) / R;
+    r[C_DT] = fmaxf(c.D.impratio, 1e-15f) / R;
     V3 fx, fy, fz;
     fs_frame(r, fx, fy, fz);
     r[C_AREF] = -b * dot(fx, vrel) - k * imp * (dist - incm);
@@ -91,28 +90,28 @@ DEV int fs_make_constraints(const Ctx &c) {
       if (t1 != t2) { coupled = 1; atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
     }
   }
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-    float *r = L + ly.lim + FSIM_LIMW * s;
+  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+    float *r = L + c.ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     int li = s >> 1, side = s & 1, d = GP(m.lim_dof)[li];
-    float q = L[ly.qpos + GP(m.dof_qposadr)[d]];
+    float q = L[c.ly.qpos + GP(m.dof_qposadr)[d]];
     float dist = side ? GP(m.lim_range)[2 * li + 1] - q : q - GP(m.lim_range)[2 * li];
     float mg = GP(m.lim_margin)[li];
     int act = dist < mg;
     ri[LM_ACTIVE] = act;
     if (!act) continue;
     float sign = side ? -1.0f : 1.0f, k, b;
-    float imp = fs_impedance(GP(m.lim_solref) + 2 * li, GP(m.lim_solimp) + 5 * li, dist - mg, m.timestep, &k, &b);
+    float imp = fs_impedance(GP(m.lim_solref) + 2 * li, GP(m.lim_solimp) + 5 * li, dist - mg, c.D.timestep, &k, &b);
     float R = fmaxf((1 - imp) / imp * GP(m.dof_invweight0)[d], 1e-15f);
     r[LM_D] = 1.0f / R;
-    r[LM_AREF] = -b * sign * L[ly.qvel + d] - k * imp * (dist - mg);
+    r[LM_AREF] = -b * sign * L[c.ly.qvel + d] - k * imp * (dist - mg);
     r[LM_SIGN] = sign;
     ri[LM_DOF] = d;
   }
-  for (int e = c.lane; e < m.neq; e += 64) {
-    float *r = L + ly.weld + FSIM_WELDW * e;
+  for (int e = c.lane; e < c.D.neq; e += 64) {
+    float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
-    int act = c.I(ly.eqactive)[e];
+    int act = c.I(c.ly.eqactive)[e];
     ri[WD_ACTIVE] = act;
     if (!act) continue;
     coupled = 1;
@@ -121,12 +120,12 @@ DEV int fs_make_constraints(const Ctx &c) {
       int t1 = KI(r_tree, b1), t2 = KI(r_tree, b2);
       if (t1 != t2) { atomicOr(&adj[t1], 1 << t2); atomicOr(&adj[t2], 1 << t1); }
     }
-    const float *data = L + ly.eqdata + 7 * e;
-    M3 R1 = ldm3(L + ly.xmat + 9 * b1);
-    V3 p0 = ldv3(L + ly.xpos + 3 * b1) + mulv(R1, ldv3(data));
-    V3 x2 = ldv3(L + ly.xpos + 3 * b2);
-    Q4 qd = qmul(ldq(L + ly.xquat + 4 * b1), ldq(data + 3));
-    Q4 q2c = qconj(ldq(L + ly.xquat + 4 * b2));
+    const float *data = L + c.ly.eqdata + 7 * e;
+    M3 R1 = ldm3(L + c.ly.xmat + 9 * b1);
+    V3 p0 = ldv3(L + c.ly.xpos + 3 * b1) + mulv(R1, ldv3(data));
+    V3 x2 = ldv3(L + c.ly.xpos + 3 * b2);
+    Q4 qd = qmul(ldq(L + c.ly.xquat + 4 * b1), ldq(data + 3));
+    Q4 q2c = qconj(ldq(L + c.ly.xquat + 4 * b2));
     Q4 qe = qmul(q2c, qd);
     float cpos[6];
     V3 dp = p0 - x2;
@@ -137,13 +136,13 @@ DEV int fs_make_constraints(const Ctx &c) {
       Q4 t = qmul(qmul(q2c, w), qd);
       r[WD_C + 0 * 3 + a] = 0.5f * t.x; r[WD_C + 1 * 3 + a] = 0.5f * t.y; r[WD_C + 2 * 3 + a] = 0.5f * t.z;
     }
-    V3 jt = fs_ptvel(c, ly.cvel, fs_bt(c, b1), p0) - fs_ptvel(c, ly.cvel, fs_bt(c, b2), x2);
-    V3 dw = lds6(L + ly.cvel + 6 * b1).a - lds6(L + ly.cvel + 6 * b2).a;
+    V3 jt = fs_ptvel(c, c.ly.cvel, fs_bt(c, b1), p0) - fs_ptvel(c, c.ly.cvel, fs_bt(c, b2), x2);
+    V3 dw = lds6(L + c.ly.cvel + 6 * b1).a - lds6(L + c.ly.cvel + 6 * b2).a;
     float jv[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
     for (int q = 0; q < 3; q++) jv[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
     for (int q = 0; q < 6; q++) {
       float k, b;
-      float imp = fs_impedance(GP(m.eq_solref) + 2 * e, GP(m.eq_solimp) + 5 * e, cpos[q], m.timestep, &k, &b);
+      float imp = fs_impedance(GP(m.eq_solref) + 2 * e, GP(m.eq_solimp) + 5 * e, cpos[q], c.D.timestep, &k, &b);
       float R = fmaxf((1 - imp) / imp * GP(m.eq_invweight)[2 * e + (q >= 3)], 1e-15f);
       r[WD_D + q] = 1.0f / R;
       r[WD_AREF + q] = -b * jv[q] - k * imp * cpos[q];
@@ -153,14 +152,14 @@ DEV int fs_make_constraints(const Ctx &c) {
   }
   int any = wave_or(coupled);
   int tot = (int)wave_sum((float)ncon);
-  if (c.lane == 0) c.I(ly.scal)[SC_NCON] = tot;
+  if (c.lane == 0) c.I(c.ly.scal)[SC_NCON] = tot;
   SYNC();
-  int *scal_ = c.I(ly.scal);
+  int *scal_ = c.I(c.ly.scal);
   // the island structure rarely changes between substeps: keep last substep's closure + map when the adjacency is the same
-  bool changed = c.lane < m.ntree && adj[c.lane] != scal_[SC_PADJ + c.lane];
+  bool changed = c.lane < c.D.ntree && adj[c.lane] != scal_[SC_PADJ + c.lane];
   if (!__ballot(changed)) return any;
-  if (c.lane < m.ntree) scal_[SC_PADJ + c.lane] = adj[c.lane];
-  if (c.lane < m.ntree) { // transitive closure of the (<= 16 node) tree graph
+  if (c.lane < c.D.ntree) scal_[SC_PADJ + c.lane] = adj[c.lane];
+  if (c.lane < c.D.ntree) { // transitive closure of the (<= 16 node) tree graph
     int reach = adj[c.lane], prev;
     do {
       prev = reach;
@@ -173,9 +172,9 @@ DEV int fs_make_constraints(const Ctx &c) {
   // island => every island owns a contiguous range of "solver lanes" and a dense packed lower triangle in H.
   const int *isl = scal_ + SC_ISL;
   int *tmp = scal_ + SC_TMP; // [0..16) first lane of tree, [16..32) island size, [32..48) island H base
-  if (c.lane < m.ntree) {
+  if (c.lane < c.D.ntree) {
     int t = c.lane, my = isl[t], rep = __ffs(my) - 1, lanebase = 0, nI = 0;
-    for (int u = 0; u < m.ntree; u++) {
+    for (int u = 0; u < c.D.ntree; u++) {
       int ru = __ffs(isl[u]) - 1, nu = KI(tree_dofnum, u);
       if (ru < rep || (ru == rep && u < t)) lanebase += nu;
       if ((my >> u) & 1) nI += nu;
@@ -183,9 +182,9 @@ DEV int fs_make_constraints(const Ctx &c) {
     tmp[t] = lanebase; tmp[16 + t] = nI;
   }
   SYNC();
-  if (c.lane < m.ntree) {
+  if (c.lane < c.D.ntree) {
     int t = c.lane, rep = __ffs(isl[t]) - 1, hb = 0, tot = 0;
-    for (int u = 0; u < m.ntree; u++) {
+    for (int u = 0; u < c.D.ntree; u++) {
       if (__ffs(isl[u]) - 1 != u) continue; // u is not an island representative
       int n = tmp[16 + u], w = n * (n + 1) / 2;
       if (u < rep) hb += w;
@@ -196,12 +195,12 @@ DEV int fs_make_constraints(const Ctx &c) {
   }
   SYNC();
   {
-    int *hm = c.I(ly.hmap);
-    for (int i = c.lane; i < m.nv; i += 64) {
+    int *hm = c.I(c.ly.hmap);
+    for (int i = c.lane; i < c.D.nv; i += 64) {
       int t = KI(dof_tree, i), rep = __ffs(isl[t]) - 1, ib = tmp[rep];
       int l = tmp[t] - ib + i - KI(tree_dofadr, t);
       hm[i] = (tmp[32 + t] + l * (l + 1) / 2) | (l << 12) | (tmp[16 + t] << 18) | (ib << 25);
-      hm[m.nv + ib + l] = i;
+      hm[c.D.nv + ib + l] = i;
     }
   }
   SYNC();
@@ -209,10 +208,10 @@ DEV int fs_make_constraints(const Ctx &c) {
 }
 
 // W_b = sum_{d in chain(b)} cdof_d * vec_d
-DEV void fs_body_spatial(const Ctx &c, int off_vec) {
+template <class Ctx> DEV void fs_body_spatial(const Ctx &c, int off_vec) {
   CModel &m = c.m;
   float *L = c.L;
-  for (int b = c.lane; b < m.nr; b += 64) {
+  for (int b = c.lane; b < c.D.nr; b += 64) {
     S6 w = s6zero();
     {
       const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
@@ -224,17 +223,16 @@ DEV void fs_body_spatial(const Ctx &c, int off_vec) {
 }
 
 // rec[dst..] = J * vec (- aref if sub_aref), using W from fs_body_spatial(vec)
-DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
+template <class Ctx> DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int nslot = c.I(ly.scal)[SC_NSLOT];
+  int nslot = c.I(c.ly.scal)[SC_NSLOT];
   for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + ly.con + FSIM_CONW * s;
+    float *r = L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     V3 pos = ldv3(r + C_POS);
-    V3 rel = fs_ptvel(c, ly.W, ri[C_B2], pos) - fs_ptvel(c, ly.W, ri[C_B1], pos);
+    V3 rel = fs_ptvel(c, c.ly.W, ri[C_B2], pos) - fs_ptvel(c, c.ly.W, ri[C_B1], pos);
     int dst = to_jar ? C_JAR : C_JP;
     V3 fx, fy, fz;
     fs_frame(r, fx, fy, fz);
@@ -242,20 +240,20 @@ DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
     r[dst + 1] = dot(fy, rel) - (to_jar ? r[C_AREF + 1] : 0.0f);
     r[dst + 2] = dot(fz, rel) - (to_jar ? r[C_AREF + 2] : 0.0f);
   }
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-    float *r = L + ly.lim + FSIM_LIMW * s;
+  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+    float *r = L + c.ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[LM_ACTIVE]) continue;
     float v = r[LM_SIGN] * L[off_vec + ri[LM_DOF]];
     if (to_jar) r[LM_JAR] = v - r[LM_AREF]; else r[LM_JP] = v;
   }
-  for (int e = c.lane; e < m.neq; e += 64) {
-    float *r = L + ly.weld + FSIM_WELDW * e;
+  for (int e = c.lane; e < c.D.neq; e += 64) {
+    float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[WD_ACTIVE]) continue;
     int b1 = ri[WD_B1], b2 = ri[WD_B2];
-    V3 jt = fs_ptvel(c, ly.W, fs_bt(c, b1), ldv3(r + WD_P0)) - fs_ptvel(c, ly.W, fs_bt(c, b2), ldv3(r + WD_X2));
-    V3 dw = lds6(L + ly.W + 6 * b1).a - lds6(L + ly.W + 6 * b2).a;
+    V3 jt = fs_ptvel(c, c.ly.W, fs_bt(c, b1), ldv3(r + WD_P0)) - fs_ptvel(c, c.ly.W, fs_bt(c, b2), ldv3(r + WD_X2));
+    V3 dw = lds6(L + c.ly.W + 6 * b1).a - lds6(L + c.ly.W + 6 * b2).a;
     int dst = to_jar ? WD_JAR : WD_JP;
     float v[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
     for (int q = 0; q < 3; q++) v[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
@@ -317,14 +315,13 @@ DEV void fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, floa
 }
 
 // first / second directional derivatives of the constraint cost along jp at jar + alpha*jp
-DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
+template <class Ctx> DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int nslot = c.I(ly.scal)[SC_NSLOT];
+  int nslot = c.I(c.ly.scal)[SC_NSLOT];
   float a1 = 0, a2 = 0;
   for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + ly.con + FSIM_CONW * s;
+    float *r = L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     if (ri[C_DIM] == 1) {
@@ -348,14 +345,14 @@ DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
     a1 += e1; a2 += e2;
 #endif
   }
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-    float *r = L + ly.lim + FSIM_LIMW * s;
+  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+    float *r = L + c.ly.lim + FSIM_LIMW * s;
     if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
     float j = r[LM_JAR] + alpha * r[LM_JP];
     if (j < 0) { a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; }
   }
-  for (int e = c.lane; e < m.neq; e += 64) {
-    float *r = L + ly.weld + FSIM_WELDW * e;
+  for (int e = c.lane; e < c.D.neq; e += 64) {
+    float *r = L + c.ly.weld + FSIM_WELDW * e;
     if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
     for (int q = 0; q < 6; q++) {
       float j = r[WD_JAR + q] + alpha * r[WD_JP + q], D = r[WD_D + q];
@@ -365,7 +362,7 @@ DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
   *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
-DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
+template <class Ctx> DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
   const int b = bt & 255;
   if (b == 0) return;
   float *G = c.L + c.ly.G + 6 * b;
@@ -379,19 +376,18 @@ DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3 T, float sign) {
 // cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
 struct SlotK { bool on; float K[6]; };
 
-DEV SlotK fs_gradient(const Ctx &c) {
+template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
   SlotK sk;
   sk.on = false;
   for (int q = 0; q < 6; q++) sk.K[q] = 0;
-  for (int i = c.lane; i < 6 * m.nr; i += 64) L[ly.G + i] = 0;
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.grad + d] = L[ly.Mx + d] - L[ly.smooth + d];
+  for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
   SYNC();
-  int nslot = c.I(ly.scal)[SC_NSLOT];
+  int nslot = c.I(c.ly.scal)[SC_NSLOT];
   for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + ly.con + FSIM_CONW * s;
+    float *r = L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     float f[3] = {0, 0, 0}, cc, Hc[9];
@@ -416,14 +412,14 @@ DEV SlotK fs_gradient(const Ctx &c) {
     fs_add_wrench(c, ri[C_B2], pos, F, v3(0, 0, 0), 1.0f);
     fs_add_wrench(c, ri[C_B1], pos, F, v3(0, 0, 0), -1.0f);
   }
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-    float *r = L + ly.lim + FSIM_LIMW * s;
+  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+    float *r = L + c.ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
-    atomicAdd(L + ly.grad + ri[LM_DOF], r[LM_SIGN] * r[LM_D] * r[LM_JAR]); // -sign*f, f = -D*jar
+    atomicAdd(L + c.ly.grad + ri[LM_DOF], r[LM_SIGN] * r[LM_D] * r[LM_JAR]); // -sign*f, f = -D*jar
   }
-  for (int e = c.lane; e < m.neq; e += 64) {
-    float *r = L + ly.weld + FSIM_WELDW * e;
+  for (int e = c.lane; e < c.D.neq; e += 64) {
+    float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[WD_ACTIVE]) continue;
     float f[6];
@@ -435,12 +431,12 @@ DEV SlotK fs_gradient(const Ctx &c) {
     fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T, -1.0f);
   }
   SYNC();
-  for (int d = c.lane; d < m.nv; d += 64) {
+  for (int d = c.lane; d < c.D.nv; d += 64) {
     int bd = KI(dof_rbody, d);
-    S6 s = lds6(L + ly.cdof + 6 * d);
+    S6 s = lds6(L + c.ly.cdof + 6 * d);
     float acc = 0;
-    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + ly.G + 6 * (__ffs(mm) - 1)));
-    L[ly.grad + d] -= acc;
+    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + c.ly.G + 6 * (__ffs(mm) - 1)));
+    L[c.ly.grad + d] -= acc;
   }
   SYNC();
   return sk;
@@ -449,11 +445,11 @@ DEV SlotK fs_gradient(const Ctx &c) {
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
 // map word of dof i: packed row base (12 bits) | local index (6) | island size (7) | first solver lane (6); [nv + lane] = dof of a solver lane
-DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return (A[i] & 0xfff) + ((A[j] >> 12) & 63); }
+template <class Ctx> DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return (A[i] & 0xfff) + ((A[j] >> 12) & 63); }
 
 // column of J for chain entry: value of row-space functional on dof d.  For a contact the three rows are
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
-DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
+template <class Ctx> DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
   S6 s = lds6(c.L + c.ly.cdof + 6 * d);
   return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(dof_tree, d)));
 }
@@ -470,33 +466,32 @@ DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   a contact between two moving bodies (lo, hi) additionally adds -cdof_d1' X cdof_d2, X = P_lo' K P_hi, on
 //   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
-DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
+template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  const int nH = c.I(ly.scal)[SC_HWORDS]; // packed island triangles
-  const int hm = ly.hmap;
-  float *A = L + ly.hA;                    // [nr][21]: aa(xx,xy,xz,yy,yz,zz) al(9, row = ang comp) ll(xx,xy,xz,yy,yz,zz)
-  float *X = L + ly.hP;                    // [NPAIR][36] cross blocks, row = lo's spatial comp, col = hi's
-  int *pmeta = c.I(ly.hP + 36 * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
+  const int nH = c.I(c.ly.scal)[SC_HWORDS]; // packed island triangles
+  const int hm = c.ly.hmap;
+  float *A = L + c.ly.hA;                    // [nr][21]: aa(xx,xy,xz,yy,yz,zz) al(9, row = ang comp) ll(xx,xy,xz,yy,yz,zz)
+  float *X = L + c.ly.hP;                    // [NPAIR][36] cross blocks, row = lo's spatial comp, col = hi's
+  int *pmeta = c.I(c.ly.hP + 36 * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
 #ifdef FSIM_PROFILE
   long long th_ = clock64();
-#define FS_HPROF(slot) do { long long t1h_ = clock64(); if (c.lane == 0) c.I(ly.scal)[slot] += (int)((t1h_ - th_) >> 4); th_ = t1h_; } while (0)
+#define FS_HPROF(slot) do { long long t1h_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[slot] += (int)((t1h_ - th_) >> 4); th_ = t1h_; } while (0)
 #else
 #define FS_HPROF(slot) do { } while (0)
 #endif
-  for (int i = c.lane; i < nH; i += 64) L[ly.H + i] = 0;
-  for (int i = c.lane; i < 21 * m.nr; i += 64) A[i] = 0;
+  for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
+  for (int i = c.lane; i < 21 * c.D.nr; i += 64) A[i] = 0;
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
-  const int nslot = c.I(ly.scal)[SC_NSLOT];
+  const int nslot = c.I(c.ly.scal)[SC_NSLOT];
   const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
   int blo = 0, bhi = 0, tlo = 0, thi = 0;
   float K[6];
   for (int q = 0; q < 6; q++) K[q] = sk.K[q];
   V3 pos = v3(0, 0, 0);
   if (on) {
-    const float *r = L + ly.con + FSIM_CONW * c.lane;
+    const float *r = L + c.ly.con + FSIM_CONW * c.lane;
     const int *ri = reinterpret_cast<const int *>(r);
     pos = ldv3(r + C_POS);
     const int wb1 = ri[C_B1], wb2 = ri[C_B2]; // body | tree << 8
@@ -511,7 +506,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
     for (int side = 0; side < 2; side++) {
       int b = side ? bhi : blo;
       if (b == 0) continue;
-      V3 rr = pos - ldv3(L + ly.com + 3 * (side ? thi : tlo));
+      V3 rr = pos - ldv3(L + c.ly.com + 3 * (side ? thi : tlo));
       // G[:, c] = rr x K[:, c]  (K symmetric: column c = row c); stored by rows G_a = (G[a][0], G[a][1], G[a][2])
       V3 c0 = cross(rr, K0), c1 = cross(rr, K1), c2 = cross(rr, K2);
       V3 G0 = v3(c0.x, c1.x, c2.x), G1 = v3(c0.y, c1.y, c2.y), G2 = v3(c0.z, c1.z, c2.z);
@@ -536,7 +531,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
     // lane-per-(body, component) bitmask sums with register staging 25, register-carried chain with prefetch 28 --
     // this code is bound by instruction count, not by the LDS round trips.)
     if (c.lane < 21)
-      for (int b = m.nr - 1; b >= 1; b--) {
+      for (int b = c.D.nr - 1; b >= 1; b--) {
         int p = KI(r_parent, b);
         if (p > 0) A[21 * p + c.lane] += A[21 * b + c.lane];
       }
@@ -544,10 +539,10 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
   }
   FS_HPROF(49);
   // ---- tree blocks on M's pattern: lane = M entry
-  for (int e = c.lane; e < m.nM; e += 64) {
+  for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = KM_I(e), j = KM_J(e);
     const float *Ab = A + 21 * KI(dof_rbody, i);
-    S6 si = lds6(L + ly.cdof + 6 * i), sj = lds6(L + ly.cdof + 6 * j);
+    S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
     // t = A * sj
     V3 ta = v3(Ab[0] * sj.a.x + Ab[1] * sj.a.y + Ab[2] * sj.a.z + Ab[6] * sj.l.x + Ab[7] * sj.l.y + Ab[8] * sj.l.z,
                Ab[1] * sj.a.x + Ab[3] * sj.a.y + Ab[4] * sj.a.z + Ab[9] * sj.l.x + Ab[10] * sj.l.y + Ab[11] * sj.l.z,
@@ -555,7 +550,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
     V3 tl = v3(Ab[6] * sj.a.x + Ab[9] * sj.a.y + Ab[12] * sj.a.z + Ab[15] * sj.l.x + Ab[16] * sj.l.y + Ab[17] * sj.l.z,
                Ab[7] * sj.a.x + Ab[10] * sj.a.y + Ab[13] * sj.a.z + Ab[16] * sj.l.x + Ab[18] * sj.l.y + Ab[19] * sj.l.z,
                Ab[8] * sj.a.x + Ab[11] * sj.a.y + Ab[14] * sj.a.z + Ab[17] * sj.l.x + Ab[19] * sj.l.y + Ab[20] * sj.l.z);
-    L[ly.H + fs_hidx(c, hm, i, j)] = L[ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
+    L[c.ly.H + fs_hidx(c, hm, i, j)] = L[c.ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
   }
   SYNC();
   FS_HPROF(50);
@@ -601,7 +596,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
       int e1 = (int)(((float)rem + 0.5f) / (float)nhi), e2 = rem - e1 * nhi;
       int d1 = KI(chain_dofs, KI(r_chainadr, lo) + e1), d2 = KI(chain_dofs, KI(r_chainadr, hi) + e2);
       const float *Xp = X + 36 * q;
-      const float *s1 = L + ly.cdof + 6 * d1, *s2 = L + ly.cdof + 6 * d2;
+      const float *s1 = L + c.ly.cdof + 6 * d1, *s2 = L + c.ly.cdof + 6 * d2;
       float v = 0;
 #pragma unroll
       for (int rr = 0; rr < 6; rr++) {
@@ -611,19 +606,19 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
         v += s1[rr] * t;
       }
       if (d1 == d2) v *= 2.0f;
-      atomicAdd(L + ly.H + fs_hidx(c, hm, max(d1, d2), min(d1, d2)), -v);
+      atomicAdd(L + c.ly.H + fs_hidx(c, hm, max(d1, d2), min(d1, d2)), -v);
     }
     SYNC();
   }
   FS_HPROF(53);
-  for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-    float *r = L + ly.lim + FSIM_LIMW * s;
+  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+    float *r = L + c.ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
-    atomicAdd(L + ly.H + fs_hidx(c, hm, ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
+    atomicAdd(L + c.ly.H + fs_hidx(c, hm, ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
   }
-  for (int e = c.lane; e < m.neq; e += 64) {
-    float *r = L + ly.weld + FSIM_WELDW * e;
+  for (int e = c.lane; e < c.D.neq; e += 64) {
+    float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[WD_ACTIVE]) continue;
     int b1 = ri[WD_B1], b2 = ri[WD_B2];
@@ -634,7 +629,7 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
       int d1 = f1 ? KI(chain_dofs, a1 + e1) : KI(chain_dofs, a2 + e1 - n1);
       float sg1 = f1 ? 1.0f : -1.0f;
       V3 t1 = fs_col(c, d1, f1 ? p0 : x2) * sg1;
-      V3 w1 = lds6(L + ly.cdof + 6 * d1).a * sg1;
+      V3 w1 = lds6(L + c.ly.cdof + 6 * d1).a * sg1;
       float j1[6] = {t1.x, t1.y, t1.z, 0, 0, 0};
       for (int q = 0; q < 3; q++) j1[3 + q] = r[WD_C + 3 * q] * w1.x + r[WD_C + 3 * q + 1] * w1.y + r[WD_C + 3 * q + 2] * w1.z;
       for (int q = 0; q < 6; q++) j1[q] *= r[WD_D + q];
@@ -644,10 +639,10 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
         if (d2 > d1) continue;
         float sg2 = f2 ? 1.0f : -1.0f;
         V3 t2 = fs_col(c, d2, f2 ? p0 : x2) * sg2;
-        V3 w2 = lds6(L + ly.cdof + 6 * d2).a * sg2;
+        V3 w2 = lds6(L + c.ly.cdof + 6 * d2).a * sg2;
         float v = j1[0] * t2.x + j1[1] * t2.y + j1[2] * t2.z;
         for (int q = 0; q < 3; q++) v += j1[3 + q] * (r[WD_C + 3 * q] * w2.x + r[WD_C + 3 * q + 1] * w2.y + r[WD_C + 3 * q + 2] * w2.z);
-        atomicAdd(L + ly.H + fs_hidx(c, hm, d1, d2), v);
+        atomicAdd(L + c.ly.H + fs_hidx(c, hm, d1, d2), v);
       }
     }
   }
@@ -666,12 +661,10 @@ DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
 // sequential depth is the largest island (9 for a free Sawyer, 15 when it grips one part), and a step costs
 // 2 * (island size - jj) instructions with no LDS round trip in the dependency chain.  Only the back substitution
 // reads the factor by columns, from a copy written once to LDS.
-template <int NLOC>
-DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
-  CLayout &ly = c.ly;
+template <int NLOC, class Ctx> DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   float *L = c.L;
-  float *H = L + ly.H;
-  const int nv = c.m.nv;
+  float *H = L + c.ly.H;
+  const int nv = c.D.nv;
   const bool row = c.lane < nv;
   const int i = row ? c.I(mp)[nv + c.lane] : 0;
   const int B = row ? c.I(mp)[i] : 0;
@@ -688,7 +681,7 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
   for (int k = 0; k < NLOC; k++) Lr[k] = (row && k <= l) ? H[rowb + k] : 0.0f;
   int bad = 0;
   float mydinv = 0.0f;
-  float b = row ? -L[ly.grad + i] : 0.0f; // right-hand side; forward substitution rides along with the factorisation
+  float b = row ? -L[c.ly.grad + i] : 0.0f; // right-hand side; forward substitution rides along with the factorisation
   FS_CHPROF(48);
 #pragma unroll
   for (int jj = 0; jj < NLOC; jj++) {
@@ -697,7 +690,7 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
       const float ci = (l >= jj) ? Lr[jj] : 0.0f;
 #ifdef FSIM_CHOL_STAGE
       { // column jj through a 64-word LDS staging buffer (ping-pong p / Mp): one write + one batch of broadcast reads
-        float *cb = L + ((jj & 1) ? ly.Mp : ly.p);
+        float *cb = L + ((jj & 1) ? c.ly.Mp : c.ly.p);
         if (row) cb[c.lane] = ci;
         SYNC();
         const float *cI = cb + ib;
@@ -756,7 +749,7 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
     float pj = __shfl(b * mydinv, ib, 64);
     if (0 < nI && l == 0) b = pj;
   }
-  if (row) L[ly.p + i] = b;
+  if (row) L[c.ly.p + i] = b;
   SYNC();
   FS_CHPROF(53);
   return !wave_or(bad);
@@ -764,11 +757,10 @@ DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
 
 // islands larger than 32 dofs (e.g. the fully welded table plus the robot): same algorithm with the factor left in LDS,
 // left-looking, no unrolling -- slow path, kept small on purpose
-DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
-  CLayout &ly = c.ly;
+template <class Ctx> DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
   float *L = c.L;
-  float *H = L + ly.H;
-  const int nv = c.m.nv;
+  float *H = L + c.ly.H;
+  const int nv = c.D.nv;
   const bool row = c.lane < nv;
   const int i = row ? c.I(mp)[nv + c.lane] : 0;
   const int B = row ? c.I(mp)[i] : 0;
@@ -795,7 +787,7 @@ DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
     }
     SYNC();
   }
-  float b = row ? -L[ly.grad + i] : 0.0f;
+  float b = row ? -L[c.ly.grad + i] : 0.0f;
 #pragma unroll 1
   for (int jj = 0; jj < steps; jj++) {
     float yj = __shfl(b * mydinv, ib + jj, 64);
@@ -806,14 +798,14 @@ DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
     float pj = __shfl(b * mydinv, ib + jj, 64);
     if (jj < nI) { if (l == jj) b = pj; else if (l < jj) b -= H[hI + jj * (jj + 1) / 2 + l] * pj; }
   }
-  if (row) L[ly.p + i] = b;
+  if (row) L[c.ly.p + i] = b;
   SYNC();
   return !wave_or(bad);
 }
 
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
-DEV bool fs_chol_solve(const Ctx &c, int mp) {
-  const int nv = c.m.nv;
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
+  const int nv = c.D.nv;
   int nI = c.lane < nv ? (c.I(mp)[c.lane] >> 18) & 127 : 0;
   const int steps = (int)wave_max((float)nI);
 #ifdef FSIM_PROFILE
@@ -826,39 +818,38 @@ DEV bool fs_chol_solve(const Ctx &c, int mp) {
   return fs_chol_lds(c, mp, steps);
 }
 
-DEV float fs_dotv(const Ctx &c, int a, int b) {
+template <class Ctx> DEV float fs_dotv(const Ctx &c, int a, int b) {
   float s = 0;
-  for (int d = c.lane; d < c.m.nv; d += 64) s += c.L[a + d] * c.L[b + d];
+  for (int d = c.lane; d < c.D.nv; d += 64) s += c.L[a + d] * c.L[b + d];
   return wave_sum(s);
 }
 
-// Solve for qacc (ly.x) and M*qacc (ly.Mx).
+// Solve for qacc (c.ly.x) and M*qacc (c.ly.Mx).
 #ifdef FSIM_PROFILE
 #define FS_SPROF(slot) do { long long t1s_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16 + slot] += (int)((t1s_ - t0s_) >> 4); t0s_ = t1s_; } while (0)
 #else
 #define FS_SPROF(slot) do { } while (0)
 #endif
-DEV void fs_solve(const Ctx &c, int coupled) {
+template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
 #ifdef FSIM_PROFILE
   long long t0s_ = clock64();
 #endif
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  int *scal = c.I(ly.scal);
+  int *scal = c.I(c.ly.scal);
   int nslot = scal[SC_NSLOT];
   // Start from the previous step's acceleration (qacc_warmstart).  Unconstrained envs take the same path: with no
   // active slot the first Newton step (H = M, alpha = 1) is exactly M^-1 qfrc_smooth, so M is never factored on its own.
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.x + d] = L[ly.qaccws + d];
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.x + d] = L[c.ly.qaccws + d];
   SYNC();
-  fs_mulM(c, ly.Mx, ly.x);
-  fs_body_spatial(c, ly.x);
-  fs_jdot(c, ly.x, true);
-  float scale = m.meaninertia_scale;
+  fs_mulM(c, c.ly.Mx, c.ly.x);
+  fs_body_spatial(c, c.ly.x);
+  fs_jdot(c, c.ly.x, true);
+  float scale = c.D.meaninertia_scale;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
     const SlotK sk = fs_gradient(c);
-    float gn = sqrtf(fs_dotv(c, ly.grad, ly.grad));
+    float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
     FS_SPROF(23);
 #ifdef FSIM_PROFILE
     if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
@@ -866,19 +857,19 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     if (scale * gn < c.newton_tol) break;
     fs_hessian(c, sk);
     FS_SPROF(24);
-    bool ok = fs_chol_solve(c, ly.hmap);
+    bool ok = fs_chol_solve(c, c.ly.hmap);
     FS_SPROF(25);
 #ifdef FSIM_PROFILE
     if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
 #endif
     if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
-    float dphi0 = fs_dotv(c, ly.p, ly.grad); // phi'(0) along the Newton direction (= -g' H^-1 g < 0)
-    fs_mulM(c, ly.Mp, ly.p);
-    fs_body_spatial(c, ly.p);
-    fs_jdot(c, ly.p, false);
-    float pMp = fs_dotv(c, ly.p, ly.Mp);
+    float dphi0 = fs_dotv(c, c.ly.p, c.ly.grad); // phi'(0) along the Newton direction (= -g' H^-1 g < 0)
+    fs_mulM(c, c.ly.Mp, c.ly.p);
+    fs_body_spatial(c, c.ly.p);
+    fs_jdot(c, c.ly.p, false);
+    float pMp = fs_dotv(c, c.ly.p, c.ly.Mp);
     float pg0 = 0;
-    for (int d = c.lane; d < m.nv; d += 64) pg0 += L[ly.p + d] * (L[ly.Mx + d] - L[ly.smooth + d]);
+    for (int d = c.lane; d < c.D.nv; d += 64) pg0 += L[c.ly.p + d] * (L[c.ly.Mx + d] - L[c.ly.smooth + d]);
     pg0 = wave_sum(pg0);
     FS_SPROF(26);
     // exact line search: safeguarded Newton on phi'(alpha)
@@ -909,18 +900,18 @@ DEV void fs_solve(const Ctx &c, int coupled) {
     if (!isfinite(alpha) && c.lane == 0 && !scal[27]) { scal[27] = 400 + it; scal[28] = scal[21]; }
     if (!isfinite(pMp) && c.lane == 0 && !scal[27]) { scal[27] = 500 + it; scal[28] = scal[21]; }
 #endif
-    for (int d = c.lane; d < m.nv; d += 64) { L[ly.x + d] += alpha * L[ly.p + d]; L[ly.Mx + d] += alpha * L[ly.Mp + d]; }
+    for (int d = c.lane; d < c.D.nv; d += 64) { L[c.ly.x + d] += alpha * L[c.ly.p + d]; L[c.ly.Mx + d] += alpha * L[c.ly.Mp + d]; }
     for (int s = c.lane; s < nslot; s += 64) {
-      float *r = L + ly.con + FSIM_CONW * s;
+      float *r = L + c.ly.con + FSIM_CONW * s;
       if (reinterpret_cast<int *>(r)[C_ACTIVE] != 1) continue;
       for (int a = 0; a < 3; a++) r[C_JAR + a] += alpha * r[C_JP + a];
     }
-    for (int s = c.lane; s < 2 * m.nlim; s += 64) {
-      float *r = L + ly.lim + FSIM_LIMW * s;
+    for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
+      float *r = L + c.ly.lim + FSIM_LIMW * s;
       if (reinterpret_cast<int *>(r)[LM_ACTIVE]) r[LM_JAR] += alpha * r[LM_JP];
     }
-    for (int e = c.lane; e < m.neq; e += 64) {
-      float *r = L + ly.weld + FSIM_WELDW * e;
+    for (int e = c.lane; e < c.D.neq; e += 64) {
+      float *r = L + c.ly.weld + FSIM_WELDW * e;
       if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
     }
     SYNC();
@@ -937,37 +928,36 @@ DEV void fs_solve(const Ctx &c, int coupled) {
 }
 
 // ------------------------------------------------------------------------------------------ P8
-// qacc in ly.x, M*qacc in ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
-DEV void fs_integrate_body(const Ctx &c) {
+// qacc in c.ly.x, M*qacc in c.ly.Mx (valid).  Semi-implicit Euler with implicit joint damping.
+template <class Ctx> DEV void fs_integrate_body(const Ctx &c) {
   CModel &m = c.m;
-  CLayout &ly = c.ly;
   float *L = c.L;
-  float h = m.timestep;
+  float h = c.D.timestep;
   // (M + h D) a' = M a : the same lane-per-row block Cholesky as the Newton step, on H = M + h diag(damping)
-  int nH = c.I(ly.scal)[SC_TWORDS];
-  for (int d = c.lane; d < m.nv; d += 64) { L[ly.qaccws + d] = L[ly.x + d]; L[ly.grad + d] = -L[ly.Mx + d]; }
-  for (int k = c.lane; k < nH; k += 64) L[ly.H + k] = L[ly.M + k]; // same tree-packed layout
+  int nH = c.I(c.ly.scal)[SC_TWORDS];
+  for (int d = c.lane; d < c.D.nv; d += 64) { L[c.ly.qaccws + d] = L[c.ly.x + d]; L[c.ly.grad + d] = -L[c.ly.Mx + d]; }
+  for (int k = c.lane; k < nH; k += 64) L[c.ly.H + k] = L[c.ly.M + k]; // same tree-packed layout
   SYNC();
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.H + fs_hidx(c, ly.k_tmap, d, d)] += h * KF(dof_damping, d);
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.H + fs_hidx(c, c.ly.k_tmap, d, d)] += h * KF(dof_damping, d);
   SYNC();
-  fs_chol_solve(c, ly.k_tmap);
-  for (int d = c.lane; d < m.nv; d += 64) L[ly.qvel + d] += h * L[ly.p + d];
+  fs_chol_solve(c, c.ly.k_tmap);
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.qvel + d] += h * L[c.ly.p + d];
   SYNC();
-  for (int b = c.lane; b < m.nr; b += 64) {
+  for (int b = c.lane; b < c.D.nr; b += 64) {
     if (b == 0) continue;
     int jt = KI(r_jtype, b), qa = KI(r_qposadr, b), d = KI(r_dofadr, b);
     if (jt == JT_FREE) {
-      for (int k = 0; k < 3; k++) L[ly.qpos + qa + k] += h * L[ly.qvel + d + k];
-      V3 w = ldv3(L + ly.qvel + d + 3);
+      for (int k = 0; k < 3; k++) L[c.ly.qpos + qa + k] += h * L[c.ly.qvel + d + k];
+      V3 w = ldv3(L + c.ly.qvel + d + 3);
       float wn;
       V3 ax = normalized(w, &wn);
       float ang = wn * h;
       if (ang > 0) {
-        Q4 q = qnormalized(qmul(ldq(L + ly.qpos + qa + 3), axisangle(ax, ang)));
-        stq(L + ly.qpos + qa + 3, q);
+        Q4 q = qnormalized(qmul(ldq(L + c.ly.qpos + qa + 3), axisangle(ax, ang)));
+        stq(L + c.ly.qpos + qa + 3, q);
       }
     } else
-      L[ly.qpos + qa] += h * L[ly.qvel + d];
+      L[c.ly.qpos + qa] += h * L[c.ly.qvel + d];
   }
   SYNC();
 }

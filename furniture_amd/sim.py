@@ -93,6 +93,8 @@ def lib():
         L.fsim_set_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
         L.fsim_env_block_words.argtypes = [ctypes.c_void_p]
+        L.fsim_kernel_variant.argtypes = [ctypes.c_void_p]
+        L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
@@ -112,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
-    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync", "fsim_set_max_episode_steps",
+    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync", "fsim_set_max_episode_steps", "fsim_kernel_variant",
 ]
 
 
@@ -166,6 +168,7 @@ class FSim:
         self._chk(lib().fsim_dims(self._h, *[ctypes.byref(x) for x in d]))
         self.nq, self.nv, self.nu, self.dof_action, self.obs_dim, self.info_dim, self.stride = [x.value for x in d]
         self.max_contacts = lib().fsim_max_contacts(self._h)
+        self.kernel_variant = lib().fsim_kernel_variant(self._h).decode()
         self.env_block_words = lib().fsim_env_block_words(self._h)
         st = ctypes.c_void_p()
         self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))

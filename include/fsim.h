@@ -107,6 +107,9 @@ typedef struct fsim_state_ptrs {
 int fsim_get_state(fsim_t *, const fsim_state_ptrs_t *dst);
 int fsim_set_state(fsim_t *, const fsim_state_ptrs_t *src);
 int fsim_max_contacts(const fsim_t *);
+/* Which step kernel the handle runs: "generic" (run-time layout, any model) or the name of a kernel specialised at build
+ * time for this (agent, furniture, config) -- same arithmetic, layout offsets as instruction immediates (csrc/fsim_spec.hpp). */
+const char *fsim_kernel_variant(const fsim_t *);
 int fsim_env_block_words(const fsim_t *);
 
 /* ---- the env hot path ------------------------------------------------------------------- */
