@@ -12,7 +12,7 @@
 #define FSIM_MAXANG 8
 #define FSIM_CONW 25     // words per contact slot: 24 used + 1 pad -- an ODD stride spreads lane = slot accesses over all 64 LDS banks (24 would hit 8)
 #define FSIM_WELDW 44    // words per weld record
-#define FSIM_LIMW 9      // words per joint-limit record (7 used; odd stride, see FSIM_CONW)
+#define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
 #define FSIM_MAXSURV 48  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
@@ -79,7 +79,7 @@ struct Layout {
   int cdof, M, LD, Dinv, LDh, Dhinv;
   int smooth, asmooth, x, Mx, grad, p, Mp;
   int gpos, gmat, surv, con, weld, lim, W, G, scal;
-  int hmap;   // [3][nv] per-substep island map of the Newton system: row base | (local idx, island size, first lane) | lane -> dof
+  int hmap;   // per-substep island map of the Newton system (FSIM_MAPW(nv) words, format at fs_build_map in fsim_solver.hpp)
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int lds_words, ncon_max;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
@@ -95,8 +95,8 @@ struct Layout {
 #define FSIM_SC_BASE 16
 #endif
 enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8,
-       SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 80,
-       SC_HWORDS = FSIM_SC_BASE + 96, SC_TWORDS = FSIM_SC_BASE + 97, SC_WORDS = FSIM_SC_BASE + 100 };
+       SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 64,
+       SC_HWORDS = FSIM_SC_BASE + 80, SC_TWORDS = FSIM_SC_BASE + 81, SC_WORDS = FSIM_SC_BASE + 84 };
 
 // env-logic block (word offsets relative to Layout::env)
 enum {
@@ -114,6 +114,8 @@ enum { EC_SEL = 0 /* 2 ints: selected part + 1, 0 = none */, EC_POS = 2 /* model
        EC_TOUCH = 28 /* 2 ints: parts in contact with cursor K at the last forward pass */, EC_WORDS = 30 };
 
 #define FSIM_NPAIR 4 // body-pair cross blocks assembled per Hessian pass (fsim_solver.hpp)
+// island / tree map of a block-diagonal SPD system: [nv] dof words, [64] lane words, [16] tail (fs_build_map, fsim_solver.hpp)
+#define FSIM_MAPW(nv) ((nv) + 64 + 16)
 
 // Everything the LDS layout depends on (host: from the model blob + config; specialised kernels: compile-time constants)
 struct LayoutIn {
@@ -163,16 +165,16 @@ constexpr Layout make_layout(const LayoutIn &in) {
   }
   TAKE(surv, FSIM_MAXSURV);
   TAKE(con, FSIM_CONW * in.ncon_max); TAKE(weld, FSIM_WELDW * in.neq); TAKE(lim, FSIM_LIMW * 2 * in.nlim);
-  TAKE(scal, SC_WORDS); TAKE(hmap, 2 * in.nv);
+  TAKE(scal, SC_WORDS); TAKE(hmap, FSIM_MAPW(in.nv));
   // LDS model cache
   ly.k_begin = o;
-  TAKE(k_dof_parent, in.nv); TAKE(k_r_submask, in.nr); TAKE(k_dof_rbody, in.nv); TAKE(k_dof_tree, in.nv);
+  TAKE(k_dof_parent, in.nv); TAKE(k_r_submask, in.nr); TAKE(k_dof_rbody, in.nv); ly.k_dof_tree = 0; // (dof -> tree goes through dof_rbody, r_tree)
   TAKE(k_r_parent, in.nr); TAKE(k_r_jtype, in.nr); TAKE(k_r_qposadr, in.nr); TAKE(k_r_dofadr, in.nr); TAKE(k_r_chain, in.nr);
   TAKE(k_r_tree, in.nr); TAKE(k_r_chainadr, in.nr); TAKE(k_r_chainlen, in.nr); ly.k_r_ancmask = 0; TAKE(k_chain_dofs, in.nchain);
   TAKE(k_tree_dofadr, in.ntree); TAKE(k_tree_dofnum, in.ntree); TAKE(k_tree_bodyadr, in.ntree); TAKE(k_tree_bodynum, in.ntree);
   TAKE(k_M_ij, in.nM);
   ly.k_r_pos = 0; ly.k_r_quat = 0; ly.k_r_jpos = 0; ly.k_r_jaxis = 0; ly.k_r_ipos = 0; ly.k_r_inertia = 0; // not cached
-  TAKE(k_r_mass, in.nr); TAKE(k_dof_damping, in.nv); TAKE(k_dof_armature, in.nv); TAKE(k_tmap, 2 * in.nv);
+  TAKE(k_r_mass, in.nr); TAKE(k_dof_damping, in.nv); TAKE(k_dof_armature, in.nv); TAKE(k_tmap, FSIM_MAPW(in.nv));
   ly.k_end = o;
 #undef TAKE
   ly.lds_words = o;

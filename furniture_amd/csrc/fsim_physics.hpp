@@ -76,6 +76,71 @@ template <class S> DEV SpecCtx<S> fs_rebuild(const SpecCtx<S> &cv, float *lds) {
 #define KF(field, idx) (c.L[c.ly.k_##field + (idx)])
 #define KFP(field) (c.L + c.ly.k_##field)
 
+// ---- map of a block-diagonal SPD system over "islands" (sets of kinematic trees): Layout::hmap (Newton Hessian, islands
+// = trees joined by an active constraint, rebuilt when the adjacency changes) and Layout::k_tmap (M + h D of the
+// integrator, islands = trees, built once per launch).  Words, relative to `mp`:
+//   [0, nv)        per dof:  row base in the packed triangles (12 bits) | local index l in its island (6) << 12 |
+//                            island size nI (7) << 18 | solver lane (6) << 25
+//   [nv, nv + 64)  per lane: byte 0 = dof this lane owns in the ROW phase (0xff none), byte 1 = dof it owns in the BIG phase,
+//                            byte 2 = number of occupied positions in the lane's 16-lane row
+//   [nv + 64, +16) tail:     [0] row-phase steps (largest row fill), [1] number of big islands, [2 + 2b], [3 + 2b] = first
+//                            lane and size of big island b (b < 6), [14] largest big island
+// Islands of <= 16 dofs are packed into the four 16-lane DPP rows of the wave (several islands may share a row: they are
+// factored as one block-diagonal matrix); the factorisation then needs no LDS traffic at all -- the pivot row travels by
+// `row_newbcast` DPP moves.  Larger islands (a robot holding two parts, Baxter's 19-dof tree) get a contiguous lane range
+// and are factored one after the other with v_readlane broadcasts.  (fs_chol_solve, fsim_solver.hpp)
+enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP = 6 };
+template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl, int hwords_slot) {
+  const int nv = c.D.nv, ntree = c.D.ntree;
+  int *scal_ = c.I(c.ly.scal);
+  int *tmp = scal_ + SC_TMP; // [t] = local offset of tree t in its island | island size << 8 | (rep only: first lane << 16 | big << 24); [16 + t] = island H base
+  int *hm = c.I(mp);
+  int *tail = hm + nv + 64;
+  if (c.lane < ntree) {
+    int t = c.lane, my = isl[t], loc = 0, nI = 0;
+    for (int u = 0; u < ntree; u++) {
+      int nu = KI(tree_dofnum, u);
+      if ((my >> u) & 1) { nI += nu; if (u < t) loc += nu; }
+    }
+    tmp[t] = loc | (nI << 8);
+  }
+  SYNC();
+  if (c.lane == 0) {
+    // islands in the order of their lowest tree: H base, then a lane range.  Small islands go to the least-filled row that
+    // still has room (keeps the row phase short: 9 | 6+6 | 6+6 | 6 for a free Sawyer + table_lack), the others (and any small
+    // island that no row can take) become "big".
+    int fill[4] = {0, 0, 0, 0}, hb = 0, sb = 0, nbig = 0, maxbig = 0;
+    for (int u = 0; u < ntree; u++) {
+      if (__ffs(isl[u]) - 1 != u) continue;
+      const int n = (tmp[u] >> 8) & 255;
+      tmp[16 + u] = hb;
+      hb += n * (n + 1) / 2;
+      int row = -1;
+      if (n <= 16) for (int r = 0; r < 4; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
+      int lane0;
+      if (row >= 0) { lane0 = 16 * row + fill[row]; fill[row] += n; }
+      else { lane0 = sb; if (nbig < MAP_BIGCAP) { tail[MAP_BIG0 + 2 * nbig] = sb; tail[MAP_BIG0 + 2 * nbig + 1] = n; } nbig++; sb += n; maxbig = max(maxbig, n); }
+      tmp[u] |= (lane0 << 16) | ((row < 0 ? 1 : 0) << 24);
+    }
+    tail[MAP_RSTEPS] = max(max(fill[0], fill[1]), max(fill[2], fill[3]));
+    tail[MAP_NBIG] = nbig;
+    tail[MAP_MAXBIG] = nbig > MAP_BIGCAP ? 99 : maxbig; // (more big islands than the table holds: LDS fallback handles them all)
+    tail[15] = fill[0] | (fill[1] << 8) | (fill[2] << 16) | (fill[3] << 24);
+    scal_[hwords_slot] = hb;
+  }
+  SYNC();
+  hm[nv + c.lane] = 0xffff | (((tail[15] >> (8 * (c.lane >> 4))) & 255) << 16);
+  SYNC();
+  for (int i = c.lane; i < nv; i += 64) {
+    const int t = KI(r_tree, KI(dof_rbody, i)), rep = __ffs(isl[t]) - 1;
+    const int nI = (tmp[rep] >> 8) & 255, l = (tmp[t] & 255) + i - KI(tree_dofadr, t), lane = ((tmp[rep] >> 16) & 63) + l;
+    hm[i] = (tmp[16 + rep] + l * (l + 1) / 2) | (l << 12) | (nI << 18) | (lane << 25);
+    const bool big = (tmp[rep] >> 24) & 1;
+    reinterpret_cast<unsigned char *>(hm + nv)[4 * lane + (big ? 1 : 0)] = (unsigned char)i;
+  }
+  SYNC();
+}
+
 // copy the hot model tables HBM -> LDS (once per kernel launch; the 50 substeps then never leave the CU for them)
 template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
   CModel &m = c.m;
@@ -83,7 +148,7 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
   for (int b = 0; b < nb; b++) nchain = max(nchain, GP(m.r_chainadr)[b] + GP(m.r_chainlen)[b]);
 #define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
 #define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
-  CPI(dof_parent, nv); CPI(dof_rbody, nv); CPI(dof_tree, nv);
+  CPI(dof_parent, nv); CPI(dof_rbody, nv);
   CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_tree, nb);
   CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(chain_dofs, nchain);
   CPI(tree_dofadr, c.D.ntree); CPI(tree_dofnum, c.D.ntree); CPI(tree_bodyadr, c.D.ntree); CPI(tree_bodynum, c.D.ntree);
@@ -102,15 +167,12 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
     c.I(c.ly.k_r_submask)[b] = sub;
     c.I(c.ly.k_r_chain)[b] = (base << 26) | ch;
   }
-  // static "tree map" of a block-diagonal-by-tree system (M + h*D in fs_integrate): same format as the per-substep
-  // island map (Layout::hmap), see fs_hidx / fs_chol_solve
-  for (int i = c.lane; i < nv; i += 64) {
-    int t = GP(m.dof_tree)[i], adr = GP(m.tree_dofadr)[t], num = GP(m.tree_dofnum)[t], l = i - adr, base = 0;
-    for (int u = 0; u < t; u++) base += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
-    c.I(c.ly.k_tmap)[i] = (base + l * (l + 1) / 2) | (l << 12) | (num << 18) | (adr << 25);
-    c.I(c.ly.k_tmap)[nv + i] = i;
-  }
   SYNC();
+  // static "tree map" of the block-diagonal-by-tree system M + h*D of fs_integrate (islands = trees): same format as the
+  // per-substep island map of the Newton system; also fixes the tree-packed triangle layout of M itself
+  if (c.lane < c.D.ntree) c.I(c.ly.scal)[SC_ISL + c.lane] = 1 << c.lane;
+  SYNC();
+  fs_build_map(c, c.ly.k_tmap, c.I(c.ly.scal) + SC_ISL, SC_TWORDS);
   // M entry e -> (i, j, packed index in the tree-packed triangle); the entries of M that are structurally zero
   // (two branches of one tree) are zeroed once here and never written again
   for (int e = c.lane; e < c.D.nM; e += 64) {
@@ -122,11 +184,6 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
     int w = 0;
     for (int u = 0; u < c.D.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
     for (int k = c.lane; k < w; k += 64) c.L[c.ly.M + k] = 0.0f;
-  }
-  if (c.lane == 0) {
-    int w = 0;
-    for (int u = 0; u < c.D.ntree; u++) w += GP(m.tree_dofnum)[u] * (GP(m.tree_dofnum)[u] + 1) / 2;
-    c.I(c.ly.scal)[SC_TWORDS] = w; // packed size of the tree-block system
   }
   SYNC();
 }
@@ -280,7 +337,7 @@ template <class Ctx> DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   float *L = c.L;
   for (int i = c.lane; i < c.D.nv; i += 64) {
     const int w = c.I(c.ly.k_tmap)[i];
-    const int li = (w >> 12) & 63, n = (w >> 18) & 127, a = (w >> 25) & 63; // local index, tree size, first dof
+    const int li = (w >> 12) & 63, n = (w >> 18) & 127, a = i - li; // local index, tree size, first dof
     const int rowi = w & 0xfff, tb = rowi - li * (li + 1) / 2;
     const float *Mt = L + c.ly.M;
     float acc = 0;

@@ -168,42 +168,7 @@ template <class Ctx> DEV int fs_make_constraints(const Ctx &c) {
     scal_[SC_ISL + c.lane] = reach;
   }
   SYNC();
-  // Island map of the Newton system (Layout::hmap): islands ordered by their lowest tree, trees ascending inside an
-  // island => every island owns a contiguous range of "solver lanes" and a dense packed lower triangle in H.
-  const int *isl = scal_ + SC_ISL;
-  int *tmp = scal_ + SC_TMP; // [0..16) first lane of tree, [16..32) island size, [32..48) island H base
-  if (c.lane < c.D.ntree) {
-    int t = c.lane, my = isl[t], rep = __ffs(my) - 1, lanebase = 0, nI = 0;
-    for (int u = 0; u < c.D.ntree; u++) {
-      int ru = __ffs(isl[u]) - 1, nu = KI(tree_dofnum, u);
-      if (ru < rep || (ru == rep && u < t)) lanebase += nu;
-      if ((my >> u) & 1) nI += nu;
-    }
-    tmp[t] = lanebase; tmp[16 + t] = nI;
-  }
-  SYNC();
-  if (c.lane < c.D.ntree) {
-    int t = c.lane, rep = __ffs(isl[t]) - 1, hb = 0, tot = 0;
-    for (int u = 0; u < c.D.ntree; u++) {
-      if (__ffs(isl[u]) - 1 != u) continue; // u is not an island representative
-      int n = tmp[16 + u], w = n * (n + 1) / 2;
-      if (u < rep) hb += w;
-      tot += w;
-    }
-    tmp[32 + t] = hb;
-    if (t == 0) scal_[SC_HWORDS] = tot;
-  }
-  SYNC();
-  {
-    int *hm = c.I(c.ly.hmap);
-    for (int i = c.lane; i < c.D.nv; i += 64) {
-      int t = KI(dof_tree, i), rep = __ffs(isl[t]) - 1, ib = tmp[rep];
-      int l = tmp[t] - ib + i - KI(tree_dofadr, t);
-      hm[i] = (tmp[32 + t] + l * (l + 1) / 2) | (l << 12) | (tmp[16 + t] << 18) | (ib << 25);
-      hm[c.D.nv + ib + l] = i;
-    }
-  }
-  SYNC();
+  fs_build_map(c, c.ly.hmap, scal_ + SC_ISL, SC_HWORDS);
   return any;
 }
 
@@ -451,7 +416,7 @@ template <class Ctx> DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
 template <class Ctx> DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
   S6 s = lds6(c.L + c.ly.cdof + 6 * d);
-  return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(dof_tree, d)));
+  return s.l + cross(s.a, pos - ldv3(c.L + c.ly.com + 3 * KI(r_tree, KI(dof_rbody, d))));
 }
 
 #ifndef FSIM_LS_TOL
@@ -653,119 +618,107 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
 // Island Cholesky + solve: p <- -H^-1 grad.  returns false if not SPD.
 //
 // H is block diagonal over "islands" (sets of kinematic trees joined by an active constraint; a lone tree is its own
-// island).  The map at `mp` (fs_make_constraints for the Newton system, fs_load_cache for the per-tree M + hD system)
-// gives every island a contiguous range of solver lanes and a dense packed lower triangle in LDS.  Solver lane
-// = one row.  The factor lives in REGISTERS (row l of an island in Lr[0..l]); the factorisation is right-looking:
-// at step jj every island scales its column jj and applies the rank-1 update of its trailing rows, the column
-// travelling between lanes with ds_bpermute (source lane = island base + k).  All islands advance together, so the
-// sequential depth is the largest island (9 for a free Sawyer, 15 when it grips one part), and a step costs
-// 2 * (island size - jj) instructions with no LDS round trip in the dependency chain.  Only the back substitution
-// reads the factor by columns, from a copy written once to LDS.
-template <int NLOC, class Ctx> DEV bool fs_chol_regs(const Ctx &c, int mp, int steps) {
-  float *L = c.L;
-  float *H = L + c.ly.H;
-  const int nv = c.D.nv;
-  const bool row = c.lane < nv;
-  const int i = row ? c.I(mp)[nv + c.lane] : 0;
-  const int B = row ? c.I(mp)[i] : 0;
-  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, ib = (B >> 25) & 63;
-  const int rowb = B & 0xfff;
-#ifdef FSIM_PROFILE
-  long long tq_ = clock64();
-#define FS_CHPROF(slot) do { } while (0)
-#else
-#define FS_CHPROF(slot) do { } while (0)
-#endif
-  float Lr[NLOC];
+// island); the map at `mp` (fs_build_map) gives every dof a solver lane.  A solver lane holds its FULL symmetric row in
+// registers and the factorisation is right-looking on the symmetric trailing matrix: at pivot j every lane below j needs
+// (a) its own entry A[l][j] -- already in its registers -- and (b) the pivot ROW A[j][k], k > j, which by symmetry is the
+// pivot column: one broadcast of lane j's register k per k.  No transposition, no LDS, no cross-lane dependency beyond
+// that broadcast:
+//   * row phase  -- islands of <= 16 dofs sit in the wave's four 16-lane DPP rows (several islands per row = one block-
+//                   diagonal matrix) and the broadcast is a `row_newbcast:j` DPP move: four rows are factored at once,
+//                   sequential depth = the fullest row (12 for a free Sawyer + five parts, 15 when it grips one);
+//   * big phase  -- an island of 17..32 dofs owns a contiguous lane range and the broadcast is v_readlane from lane
+//                   (first + j); big islands are factored one after the other;
+//   * beyond 32 dofs (all parts welded to the arm) the factor stays in LDS: fs_chol_lds.
+// Forward substitution rides along with the factorisation; the back substitution reads L[j][l] = A[l][j] / L[l][l] from
+// the lane's OWN registers (lane l stopped updating its row at step l), so it needs one broadcast per step as well.
+template <int J> DEV float fs_rowbc(float v) { // value of lane J of the caller's 16-lane row, in every lane of that row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, true));
+}
+struct RowBcast { // row phase: lane `pos` of each 16-lane row (DPP row_newbcast)
+  template <int J> DEV float get(float v) const { return fs_rowbc<J>(v); }
+};
+struct LaneBcast { // big phase: lane first + J of the wave (v_readlane, wave-uniform source)
+  int first;
+  template <int J> DEV float get(float v) const { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), first + J)); }
+};
+
+// One phase: every lane owns row `l` (position `pos` in its group, which starts at position pos - l) of a symmetric matrix
+// whose group has `fill` occupied positions; steps = largest fill in the wave (uniform).  A[q] = row entries by position.
+template <int NLOC, int JJ, class BC> struct FsCholStep {
+  DEV static void fwd(float (&A)[NLOC], float &b, float &mydinv, int &bad, const int pos, const int fill, const int steps, const BC &bc) {
+    if (JJ < steps) {
+      float d = bc.template get<JJ>(A[JJ]);
+      const bool act = JJ < fill;
+      if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+      const float rinv = act ? rsqrtf(d) : 0.0f;
+      // forward substitution, column form: y_j = b_j / L_jj, then b_l -= L[l][j] y_j below the pivot
+      const float yj = bc.template get<JJ>(b * rinv);
+      const float lij = A[JJ] * rinv; // L[l][j] for pos > j
+      if (pos == JJ) { mydinv = rinv; b = yj; }
+      const bool below = pos > JJ;
+      if (below) b -= lij * yj;
+      const float w = below ? -lij * rinv : 0.0f; // A[l][k] -= L[l][j] L[k][j] = A[l][j] A[j][k] / d
 #pragma unroll
-  for (int k = 0; k < NLOC; k++) Lr[k] = (row && k <= l) ? H[rowb + k] : 0.0f;
-  int bad = 0;
-  float mydinv = 0.0f;
-  float b = row ? -L[c.ly.grad + i] : 0.0f; // right-hand side; forward substitution rides along with the factorisation
-  FS_CHPROF(48);
-#pragma unroll
-  for (int jj = 0; jj < NLOC; jj++) {
-    if (jj < steps) {
-      const bool act = jj < nI;
-      const float ci = (l >= jj) ? Lr[jj] : 0.0f;
-#ifdef FSIM_CHOL_STAGE
-      { // column jj through a 64-word LDS staging buffer (ping-pong p / Mp): one write + one batch of broadcast reads
-        float *cb = L + ((jj & 1) ? c.ly.Mp : c.ly.p);
-        if (row) cb[c.lane] = ci;
-        SYNC();
-        const float *cI = cb + ib;
-        float d = cI[jj];
-        if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
-        const float rp = act ? 1.0f / d : 0.0f, rinv = act ? rsqrtf(d) : 0.0f;
-        const float t = ci * rp;
-        Lr[jj] = ci * rinv;
-        if (l == jj) mydinv = rinv;
-        const float yj = __shfl(b * rinv, ib + jj, 64);
-        if (act) b = (l == jj) ? yj : (l > jj ? b - ci * rinv * yj : b);
-#pragma unroll
-        for (int k = jj + 1; k < NLOC; k++) {
-          if ((k & 7) == ((jj + 1) & 7) && k >= steps) break;
-          Lr[k] -= t * cI[k];
-        }
+      for (int k = JJ + 1; k < NLOC; k++) {
+        if (((k - JJ - 1) & 3) == 0 && k >= steps) break;
+        A[k] = __builtin_fmaf(w, bc.template get<JJ>(A[k]), A[k]);
       }
-#else
-      {
-        float d = __shfl(ci, ib + jj, 64);
-        if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
-        const float rinv = act ? rsqrtf(d) : 0.0f;
-        const float lij = ci * rinv;
-        Lr[jj] = lij;
-        if (l == jj) mydinv = rinv;
-        // forward substitution, column form: y_jj = b_jj / L_jj, then b_l -= L[l][jj] * y_jj for the rows below
-        const float yj = __shfl(b * rinv, ib + jj, 64);
-        if (act) b = (l == jj) ? yj : (l > jj ? b - lij * yj : b);
-#pragma unroll
-        for (int k = jj + 1; k < NLOC; k++) {
-          if ((k & 7) == ((jj + 1) & 7) && k >= steps) break;
-          Lr[k] -= lij * __shfl(lij, ib + k, 64);
-        }
-      }
-#endif
+      FsCholStep<NLOC, JJ + 1, BC>::fwd(A, b, mydinv, bad, pos, fill, steps, bc);
     }
   }
-  FS_CHPROF(49);
-  FS_CHPROF(50);
-  // backward: L' p = y, column access through LDS
+  // backward: L' p = y.  L[j][l] = A[l][j] * dinv_l for l < j (lane l's row as it was when l was the pivot)
+  DEV static void bwd(const float (&A)[NLOC], float &b, const float mydinv, const int pos, const int steps, const BC &bc) {
+    constexpr int J = NLOC - 1 - JJ;
+    if (J < steps) {
+      const float pj = bc.template get<J>(b * mydinv);
+      if (pos == J) b = pj;
+      if (pos < J) b -= A[J] * mydinv * pj;
+    }
+    FsCholStep<NLOC, JJ + 1, BC>::bwd(A, b, mydinv, pos, steps, bc);
+  }
+};
+template <int NLOC, class BC> struct FsCholStep<NLOC, NLOC, BC> {
+  DEV static void fwd(float (&)[NLOC], float &, float &, int &, const int, const int, const int, const BC &) {}
+  DEV static void bwd(const float (&)[NLOC], float &, const float, const int, const int, const BC &) {}
+};
+
+// dof: the dof this lane owns in this phase (< 0: none); pos / fill / steps as above; writes p[dof].  returns the lane's bad flag
+template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int mp, const int dof, const int pos, const int fill, const int steps, const BC &bc) {
+  float *L = c.L;
+  const float *H = L + c.ly.H;
+  const bool row = dof >= 0;
+  const int B = row ? c.I(mp)[dof] : 0;
+  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
+  const int p0 = pos - l; // first position of the lane's island inside its group
+  float A[NLOC];
 #pragma unroll
-  for (int k = 0; k < NLOC; k++) if (k < steps && row && k <= l) H[rowb + k] = Lr[k];
-  SYNC();
-  const int hI = rowb - l * (l + 1) / 2;
-  // the column entries do not depend on the running solution: they are fetched (clamped address) ahead of the shuffle
-  // that carries the dependency, two steps per trip
-  int jj = steps - 1;
-  for (; jj >= 1; jj -= 2) {
-    const float h0 = H[hI + jj * (jj + 1) / 2 + min(l, jj)], h1 = H[hI + (jj - 1) * jj / 2 + min(l, jj - 1)];
-    float pj = __shfl(b * mydinv, ib + jj, 64);
-    if (jj < nI) b = (l == jj) ? pj : (l < jj ? b - h0 * pj : b);
-    pj = __shfl(b * mydinv, ib + jj - 1, 64);
-    if (jj - 1 < nI) b = (l == jj - 1) ? pj : (l < jj - 1 ? b - h1 * pj : b);
+  for (int q = 0; q < NLOC; q++) {
+    const int lq = q - p0;
+    const bool ok = row && q < steps && lq >= 0 && lq < nI;
+    const int hi = max(l, lq), lo = min(l, lq);
+    A[q] = ok ? H[hI + hi * (hi + 1) / 2 + lo] : 0.0f;
   }
-  if (jj == 0) {
-    float pj = __shfl(b * mydinv, ib, 64);
-    if (0 < nI && l == 0) b = pj;
-  }
-  if (row) L[c.ly.p + i] = b;
-  SYNC();
-  FS_CHPROF(53);
-  return !wave_or(bad);
+  float b = row ? -L[c.ly.grad + dof] : 0.0f, mydinv = 0.0f;
+  int bad = 0;
+  FsCholStep<NLOC, 0, BC>::fwd(A, b, mydinv, bad, pos, row ? fill : 0, steps, bc);
+  FsCholStep<NLOC, 0, BC>::bwd(A, b, mydinv, pos, steps, bc);
+  if (row) L[c.ly.p + dof] = b;
+  return bad;
 }
 
-// islands larger than 32 dofs (e.g. the fully welded table plus the robot): same algorithm with the factor left in LDS,
-// left-looking, no unrolling -- slow path, kept small on purpose
-template <class Ctx> DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
+// islands larger than 32 dofs (e.g. the fully welded table plus the robot): the factor stays in LDS, left-looking, lane = row
+// of a big-phase lane range, all such islands together -- slow path, kept small on purpose
+template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
   float *L = c.L;
   float *H = L + c.ly.H;
   const int nv = c.D.nv;
-  const bool row = c.lane < nv;
-  const int i = row ? c.I(mp)[nv + c.lane] : 0;
+  const int dofb = (c.I(mp)[nv + c.lane] >> 8) & 255;
+  const bool row = dofb != 255;
+  const int i = row ? dofb : 0;
   const int B = row ? c.I(mp)[i] : 0;
-  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, ib = (B >> 25) & 63;
+  const int l = (B >> 12) & 63, nI = row ? (B >> 18) & 127 : 0, ib = c.lane - l;
   const int rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
+  const int steps = (int)wave_max((float)nI);
   int bad = 0;
   float mydinv = 0.0f;
 #pragma unroll 1
@@ -799,23 +752,40 @@ template <class Ctx> DEV bool fs_chol_lds(const Ctx &c, int mp, int steps) {
     if (jj < nI) { if (l == jj) b = pj; else if (l < jj) b -= H[hI + jj * (jj + 1) / 2 + l] * pj; }
   }
   if (row) L[c.ly.p + i] = b;
-  SYNC();
-  return !wave_or(bad);
+  return bad;
 }
 
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
 template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int nv = c.D.nv;
-  int nI = c.lane < nv ? (c.I(mp)[c.lane] >> 18) & 127 : 0;
-  const int steps = (int)wave_max((float)nI);
-#ifdef FSIM_PROFILE
-  if (0 && c.lane == 0) { c.I(c.ly.scal)[48] += steps; c.I(c.ly.scal)[49] += 1; c.I(c.ly.scal)[50] = max(c.I(c.ly.scal)[50], steps); }
-#endif
-  if (steps <= 10) return fs_chol_regs<10>(c, mp, steps); // free Sawyer (9) / Baxter arm trees, free parts (6)
-  if (steps <= 16) return fs_chol_regs<16>(c, mp, steps);
-  if (steps <= 24) return fs_chol_regs<24>(c, mp, steps); // robot + two parts (21): the common size of a gripping env
-  if (steps <= 32) return fs_chol_regs<32>(c, mp, steps);
-  return fs_chol_lds(c, mp, steps);
+  const int *tail = c.I(mp) + nv + 64;
+  const int lw = c.I(mp)[nv + c.lane];
+  const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
+  int bad = 0;
+  if (rsteps > 0) {
+    const int dofr = lw & 255, fill = (lw >> 16) & 255;
+    const int dof = dofr == 255 ? -1 : dofr;
+    if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, fill, rsteps, RowBcast());
+    else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, fill, rsteps, RowBcast());
+  }
+  if (nbig > 0) {
+    const int maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
+    if (maxbig > 32) bad |= fs_chol_lds(c, mp);
+    else {
+      const int dofb = (lw >> 8) & 255;
+#pragma unroll 1
+      for (int q = 0; q < nbig; q++) {
+        const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
+        const bool mine = c.lane >= first && c.lane < first + n && dofb != 255;
+        const int dof = mine ? dofb : -1;
+        LaneBcast bc; bc.first = first;
+        if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, n, bc);
+        else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, n, bc);
+      }
+    }
+  }
+  SYNC();
+  return !wave_or(bad);
 }
 
 template <class Ctx> DEV float fs_dotv(const Ctx &c, int a, int b) {

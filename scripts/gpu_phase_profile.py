@@ -8,7 +8,7 @@ from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, default_config, INFO_DIM
 from furniture_amd.envs import ResetTableSampler, make_config
 m = load_compiled("Sawyer", "table_lack_0825")
-N = 4096
+N = int(os.environ.get("FSIM_PROF_N", "4096"))
 cfg = default_config(); cfg.max_episode_steps = 150; cfg.solver_tolerance = float(os.environ.get('FSIM_TOL', '1e-6'))
 sim = FSim(m, N, config=cfg)
 sampler = ResetTableSampler(m, make_config(), 123, 0, N)
