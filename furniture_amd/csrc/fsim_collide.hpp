@@ -518,19 +518,26 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
   }
   SYNC();
   FS_CPROF(29);
-  // broadphase + ordered compaction
-  int nsurv = 0;
+  // broadphase + ordered compaction, two stages so that the expensive test only runs on the few pairs that need it (a
+  // wave pays for a branch as soon as ONE lane takes it):
+  //   stage 1, all candidate pairs, 64 per pass: collision masks + bounding spheres (plane: signed distance) -> list A
+  //            (kept in the contact-slot area, which is dead until the narrow phase emits);
+  //   stage 2, list A: exact point-to-solid distance for flat / long shapes -> the survivor list of the narrow phase.
+  // Both compactions are ballot-ordered, so survivors (hence contacts) stay in candidate-pair order.
   int *surv = c.I(c.ly.surv);
+  int *listA = c.I(c.ly.con);
+  const int capA = FSIM_CONW * c.ly.ncon_max;
   const int *ctype = c.I(c.ly.contype), *caff = c.I(c.ly.conaff);
+  int nA = 0;
   for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
     int p = p0 + c.lane;
     bool pass = false;
     if (p < c.D.ncp) {
       // one 64-byte record per pair (g1 g2 pt types | margin gap r1 r2 | size1 | size2): no dependent table lookups
       const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
-      const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
-      const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
+      const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255;
       if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
+        const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
         const float margin = q1.x, r1 = q1.z, r2 = q1.w;
         V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
         if (t1 == GT_PLANE) {
@@ -539,31 +546,52 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
         } else {
           float bound = r1 + r2 + margin;
           pass = dot(d, d) <= bound * bound;
-          // second, tighter test for flat / long shapes (a 0.64 x 0.24 x 0.04 table top has a 0.34 m bounding sphere):
-          // distance from the OTHER geom's centre to this box / cylinder (exact point-solid distance) must be within the
-          // other geom's bounding radius.  Conservative: never rejects a pair that can touch.
-          if (pass) {
+        }
+      }
+    }
+    unsigned long long mask = __ballot(pass);
+    int idx = nA + __popcll(mask & ((1ull << c.lane) - 1ull));
+    if (pass && idx < capA) listA[idx] = p;
+    nA += __popcll(mask);
+  }
+  if (nA > capA) { nA = capA; if (c.lane == 0) scal[SC_OVERFLOW] |= 1; }
+  SYNC();
+  int nsurv = 0;
+  for (int i0 = 0; i0 < nA; i0 += 64) {
+    const int i = i0 + c.lane;
+    bool pass = false;
+    int p = 0;
+    if (i < nA) {
+      p = listA[i];
+      const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
+      const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
+      pass = true;
+      // tighter test for flat / long shapes (a 0.64 x 0.24 x 0.04 table top has a 0.34 m bounding sphere): the distance from
+      // the OTHER geom's centre to this box / cylinder (exact point-solid distance) must be within the other geom's
+      // bounding radius.  Conservative: never rejects a pair that can touch.
+      if (t1 != GT_PLANE && (t1 == GT_BOX || t1 == GT_CYLINDER || t2 == GT_BOX || t2 == GT_CYLINDER)) {
+        const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
+        const float margin = q1.x, r1 = q1.z, r2 = q1.w;
+        V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
 #pragma unroll
-            for (int side = 0; side < 2; side++) {
-              int gs = side ? g1 : g2, ty = side ? t1 : t2;       // solid tested
-              float ro = (side ? r2 : r1) + margin;              // other geom's radius
-              if (!pass || (ty != GT_BOX && ty != GT_CYLINDER)) continue;
-              V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
-              const float *R = L + c.ly.gmat + 9 * gs;
-              V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
-              const f4_t qs = GPC<f4_t>(m.pair_rec)[4 * p + (side ? 2 : 3)];
-              V3 sz_ = v3(qs.x, qs.y, qs.z);
-              float dist2;
-              if (ty == GT_BOX) {
-                V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
-                dist2 = dot(e, e);
-              } else {
-                float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz_.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz_.y, 0.0f);
-                dist2 = er * er + ez * ez;
-              }
-              if (dist2 > ro * ro) pass = false;
-            }
+        for (int side = 0; side < 2; side++) {
+          int gs = side ? g1 : g2, ty = side ? t1 : t2;       // solid tested
+          float ro = (side ? r2 : r1) + margin;              // other geom's radius
+          if (!pass || (ty != GT_BOX && ty != GT_CYLINDER)) continue;
+          V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
+          const float *R = L + c.ly.gmat + 9 * gs;
+          V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
+          const f4_t qs = GPC<f4_t>(m.pair_rec)[4 * p + (side ? 2 : 3)];
+          V3 sz_ = v3(qs.x, qs.y, qs.z);
+          float dist2;
+          if (ty == GT_BOX) {
+            V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
+            dist2 = dot(e, e);
+          } else {
+            float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz_.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz_.y, 0.0f);
+            dist2 = er * er + ez * ez;
           }
+          if (dist2 > ro * ro) pass = false;
         }
       }
     }

@@ -260,15 +260,15 @@ DEV int fs_cone(const float *jar, float Dn, float Dt, float fri, float *f, float
 //   top zone:    0;   bottom zone: quadratic in jar;   middle zone: cost = Dm/2 (N - mu T)^2,
 //   d1 = Dm (N - mu T)(N' - mu T'),  d2 = Dm (N' - mu T')^2 - Dm (N - mu T) mu T'',  T' = U.U'/T,  T'' = (|U'|^2 - T'^2)/T.
 // Identical (up to rounding) to contracting fs_cone's force / Hessian with jp, at a third of the instructions.
-DEV void fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, float fri, float *d1, float *d2) {
+DEV int fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, float fri, float *d1, float *d2) {
   float mu = fri * sqrtf(Dn / Dt);
   float U1 = jar[1] * fri, U2 = jar[2] * fri;
   float N = jar[0] * mu, T = sqrtf(U1 * U1 + U2 * U2);
-  if (N >= mu * T || (T <= 0 && N >= 0)) { *d1 = 0; *d2 = 0; return; }
+  if (N >= mu * T || (T <= 0 && N >= 0)) { *d1 = 0; *d2 = 0; return 0; }
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
     *d1 = Dn * jar[0] * jp[0] + Dt * (jar[1] * jp[1] + jar[2] * jp[2]);
     *d2 = Dn * jp[0] * jp[0] + Dt * (jp[1] * jp[1] + jp[2] * jp[2]);
-    return;
+    return 1;
   }
   float Dm = Dn / fmaxf(mu * mu * (1 + mu * mu), 1e-15f), NT = N - mu * T;
   float V1 = jp[1] * fri, V2 = jp[2] * fri, rT = 1.0f / T;
@@ -277,44 +277,38 @@ DEV void fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, floa
   float w = Np - mu * Tp;
   *d1 = Dm * NT * w;
   *d2 = Dm * w * w - Dm * NT * mu * Tpp;
+  return 2;
 }
 
 // first / second directional derivatives of the constraint cost along jp at jar + alpha*jp
-template <class Ctx> DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2) {
+// zone: per-lane record of which piece of the piecewise cost this lane's contact slot (bits 0-1: 0 top / 1 bottom / 2 middle)
+// and joint-limit record (bit 2: active) were in when the gradient was taken; *nonquad: some lane's slot / limit is now in another
+// piece than at `zone`, or on the cone surface (the only non-quadratic piece)
+template <class Ctx> DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2, int zone, bool *nonquad) {
   CModel &m = c.m;
   float *L = c.L;
   int nslot = c.I(c.ly.scal)[SC_NSLOT];
   float a1 = 0, a2 = 0;
+  int zc = 0, zl = 0; // this lane's contact zone / limit activity at alpha (slot = lane: ncon_max <= 64)
   for (int s = c.lane; s < nslot; s += 64) {
     float *r = L + c.ly.con + FSIM_CONW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (ri[C_ACTIVE] != 1) continue;
     if (ri[C_DIM] == 1) {
       float j = r[C_JAR] + alpha * r[C_JP];
-      if (j < 0) { a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; }
+      if (j < 0) { a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; zc = 1; }
       continue;
     }
-#ifdef FSIM_LS_FULLCONE
-    float jar[3], f[3], H[9], cc;
-    for (int a = 0; a < 3; a++) jar[a] = r[C_JAR + a] + alpha * r[C_JP + a];
-    int st = fs_cone(jar, r[C_DN], r[C_DT], r[C_MU], f, &cc, H);
-    if (!st) continue;
-    for (int a = 0; a < 3; a++) {
-      a1 -= f[a] * r[C_JP + a];
-      for (int b = 0; b < 3; b++) a2 += H[3 * a + b] * r[C_JP + a] * r[C_JP + b];
-    }
-#else
     float jar[3], jp[3], e1, e2;
     for (int a = 0; a < 3; a++) { jp[a] = r[C_JP + a]; jar[a] = r[C_JAR + a] + alpha * jp[a]; }
-    fs_cone_dir(jar, jp, r[C_DN], r[C_DT], r[C_MU], &e1, &e2);
+    zc = fs_cone_dir(jar, jp, r[C_DN], r[C_DT], r[C_MU], &e1, &e2);
     a1 += e1; a2 += e2;
-#endif
   }
   for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
     float *r = L + c.ly.lim + FSIM_LIMW * s;
     if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
     float j = r[LM_JAR] + alpha * r[LM_JP];
-    if (j < 0) { a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; }
+    if (j < 0) { a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; zl = 1; }
   }
   for (int e = c.lane; e < c.D.neq; e += 64) {
     float *r = L + c.ly.weld + FSIM_WELDW * e;
@@ -324,6 +318,7 @@ template <class Ctx> DEV void fs_line_eval(const Ctx &c, float alpha, float *d1,
       a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
     }
   }
+  *nonquad = __ballot(zc == 2 || zc != (zone & 3) || zl != ((zone >> 2) & 1)) != 0 || 2 * c.D.nlim > 64;
   *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
@@ -339,13 +334,14 @@ template <class Ctx> DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3
 // grad = Mx - qfrc_smooth - J' f(jar)
 // What the gradient pass already knows about this lane's contact slot and the Hessian pass needs again: whether the
 // cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
-struct SlotK { bool on; float K[6]; };
+struct SlotK { bool on; int zone; float K[6]; }; // zone: see fs_line_eval
 
 template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
   CModel &m = c.m;
   float *L = c.L;
   SlotK sk;
   sk.on = false;
+  sk.zone = 0;
   for (int q = 0; q < 6; q++) sk.K[q] = 0;
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
@@ -362,7 +358,8 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
       if (on) f[0] = -r[C_DN] * r[C_JAR];
       for (int q = 0; q < 9; q++) Hc[q] = 0;
       Hc[0] = r[C_DN];
-    } else on = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc) != 0;
+      sk.zone = on ? 1 : 0;
+    } else { sk.zone = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc); on = sk.zone != 0; }
     if (!on) continue; // top zone: zero force, zero Hessian
     V3 fx, fy, fz;
     fs_frame(r, fx, fy, fz);
@@ -381,6 +378,7 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
     float *r = L + c.ly.lim + FSIM_LIMW * s;
     int *ri = reinterpret_cast<int *>(r);
     if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
+    sk.zone |= 4;
     atomicAdd(L + c.ly.grad + ri[LM_DOF], r[LM_SIGN] * r[LM_D] * r[LM_JAR]); // -sign*f, f = -D*jar
   }
   for (int e = c.lane; e < c.D.neq; e += 64) {
@@ -761,6 +759,9 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
   const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
+#ifdef FSIM_PROFILE
+  if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[55] += rsteps; ps_[56] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[57] += nbig; ps_[58] += 1; }
+#endif
   int bad = 0;
   if (rsteps > 0) {
     const int dofr = lw & 255, fill = (lw >> 16) & 255;
@@ -844,15 +845,20 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     FS_SPROF(26);
     // exact line search: safeguarded Newton on phi'(alpha)
     float lo = 0, hi = -1, alpha = 1, best = 0;
+    bool nonquad = true; // the full step alpha = 1 stayed on one quadratic piece of the cost? (set by the first evaluation)
+    int nls = 0;
     for (int ls = 0; ls < 20; ls++) {
       float d1, d2;
-      fs_line_eval(c, alpha, &d1, &d2);
+      bool nq;
+      fs_line_eval(c, alpha, &d1, &d2, sk.zone, &nq);
+      if (ls == 0) nonquad = nq;
 #ifdef FSIM_PROFILE
       if (c.lane == 0) { scal[16 + 13] += 1; }
 #endif
       d1 += pg0 + alpha * pMp;
       d2 += pMp;
       best = alpha;
+      nls = ls;
       if (fabsf(d1) <= FSIM_LS_TOL * fabsf(dphi0) + 1e-30f) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
       float na = alpha - d1 / fmaxf(d2, 1e-30f);
@@ -892,6 +898,10 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     FS_SPROF(28);
     float improvement = scale * 0.5f * alpha * fmaxf(-dphi0, 0.0f);
     if (improvement < c.newton_tol) { it++; break; }
+    // The full Newton step was accepted at the first trial and every constraint stayed in the quadratic piece it was in when
+    // H was assembled: x is the exact minimiser of that piece, the new gradient is zero up to rounding.  Evaluating it (a
+    // full J'f pass, a quarter of an uncoupled env's solve) could only confirm that -- the iteration ends here.
+    if (!nonquad && nls == 0 && alpha == 1.0f) { it++; break; }
   }
   if (c.lane == 0) scal[SC_NITER] = it;
   SYNC();
