@@ -151,8 +151,6 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
     int *sc_ = c.I(c.ly.scal);
     sc_[21] += 1; sc_[22] += sc_[SC_NITER]; sc_[23] += coupled; sc_[24] += sc_[SC_NSURV]; sc_[25] += sc_[SC_NSLOT];
     if (sc_[SC_NITER] > sc_[26]) sc_[26] = sc_[SC_NITER];
-    if (sc_[SC_NSLOT] > sc_[51]) sc_[51] = sc_[SC_NSLOT];
-    if (sc_[SC_NSURV] > sc_[52]) sc_[52] = sc_[SC_NSURV];
   }
 #endif
   if (c.D.agent == 2) {

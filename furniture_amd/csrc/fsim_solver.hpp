@@ -704,6 +704,87 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
   return bad;
 }
 
+// ---- big phase on the matrix cores: one island of 17..31 dofs as a 32 x 32 symmetric tile in the accumulator layout of
+// v_mfma_f32_32x32x2_f32 (lane = column j = lane % 32, half h = lane / 32; register v holds row 8 (v / 4) + 4 h + v % 4).
+// Row 31 / column 31 carry the right-hand side, so the forward substitution IS the elimination.  At pivot p the scaled pivot
+// row u (one register, lanes of one half, columns > p) is both MFMA operands: D -= u u' is ONE instruction for the whole
+// trailing matrix (fp32 MFMA = an fmaf chain, bit-exact fp32), where the readlane path issues 2.5 instructions per
+// (pivot, column) pair.  A wave issues one instruction per ~5 cycles whatever it is, so the 21-dof island of a gripping
+// env drops from ~1100 to ~550 issued instructions per factorisation + solve.  Columns <= p are masked out of u, so
+// row p and column p keep S^(p)[p][.] = L[.][p] / rinv_p for the back substitution, which is column oriented: lane i
+// accumulates sum_j S[j][i] x_j from its OWN registers (one accumulator per half), x_p travels by v_readlane.
+typedef float fs_f16v __attribute__((ext_vector_type(16)));
+template <int P> struct FsMfmaStep {
+  static constexpr int VP = 4 * (P >> 3) + (P & 3), HP = (P >> 2) & 1;
+  static constexpr unsigned long long COLS_GT = ((0xffffffffull << (P + 1)) & 0xffffffffull) << (32 * HP); // half HP, columns > P
+  static constexpr unsigned long long COLS_LT = ((1ull << P) - 1ull) << (32 * HP);                          // half HP, columns < P
+  DEV static void fwd(fs_f16v &D, float &myrinv, int &bad, const int n, const int lane) {
+    if (P < n) {
+      float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VP]), 32 * HP + P));
+      if (!(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+      const float rinv = rsqrtf(d);
+      const float u = ((COLS_GT >> lane) & 1ull) ? D[VP] * rinv : 0.0f;
+      if ((lane & 31) == P) myrinv = rinv;
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u, -u, D, 0, 0, 0);
+      FsMfmaStep<P + 1>::fwd(D, myrinv, bad, n, lane);
+    }
+  }
+  DEV static void bwd(const fs_f16v &D, const float myrinv, float &acc, float &res, const int n, const int lane) {
+    constexpr int Q = 30 - P; // pivots 30 .. 0
+    constexpr int VQ = 4 * (Q >> 3) + (Q & 3), HQ = (Q >> 2) & 1;
+    constexpr unsigned long long LT = ((1ull << Q) - 1ull) << (32 * HQ);
+    if (Q < n) {
+      const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VQ]), 32 * HQ + 31));
+      const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q));
+      const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q + 32));
+      const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrinv), Q));
+      const float xq = r * r * (sy - t0 - t1);
+      if ((LT >> lane) & 1ull) acc = __builtin_fmaf(D[VQ], xq, acc);
+      if (lane == Q) res = xq;
+    }
+    FsMfmaStep<P + 1>::bwd(D, myrinv, acc, res, n, lane);
+  }
+};
+template <> struct FsMfmaStep<31> {
+  DEV static void fwd(fs_f16v &, float &, int &, const int, const int) {}
+  DEV static void bwd(const fs_f16v &, const float, float &, float &, const int, const int) {}
+};
+// first: first big-phase lane of the island, n: its size (17..31).  returns the bad flag (uniform)
+// (a real function: its 16-register accumulator tile must not weigh on the register allocation of the substep loop, and
+//  only the rare env with a big island ever calls it)
+template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, int mp_, int first_, int n_) {
+  FS_REBUILD_CTX(cv);
+  const int mp = __builtin_amdgcn_readfirstlane(mp_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_);
+  float *L = c.L;
+  const float *H = L + c.ly.H;
+  const int nv = c.D.nv;
+  float *rhs = L + c.ly.hA; // 32 words of scratch: the Hessian body blocks (>= 21 nr + 160 words) are dead once H is assembled
+  const int k = c.lane & 31, h = c.lane >> 5;
+  int dofk = 0;
+  if (c.lane < 32) {
+    dofk = k < n ? (c.I(mp)[nv + first + k] >> 8) & 255 : 0;
+    rhs[k] = k < n ? -L[c.ly.grad + dofk] : 0.0f;
+  }
+  const int hI = __builtin_amdgcn_readfirstlane(c.I(mp)[(c.I(mp)[nv + first] >> 8) & 255] & 0xfff); // packed base of the island (its first dof has l = 0)
+  SYNC();
+  fs_f16v D;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+    const int hi = max(i, k), lo = min(i, k);
+    float e = 0.0f;
+    if (hi < n) e = H[hI + hi * (hi + 1) / 2 + lo];
+    else if (hi == 31 && lo < n) e = rhs[lo];
+    D[v] = e;
+  }
+  float myrinv = 0.0f, acc = 0.0f, res = 0.0f;
+  int bad = 0;
+  FsMfmaStep<0>::fwd(D, myrinv, bad, n, c.lane);
+  FsMfmaStep<0>::bwd(D, myrinv, acc, res, n, c.lane);
+  if (c.lane < n) L[c.ly.p + dofk] = res;
+  return bad;
+}
+
 // islands larger than 32 dofs (e.g. the fully welded table plus the robot): the factor stays in LDS, left-looking, lane = row
 // of a big-phase lane range, all such islands together -- slow path, kept small on purpose
 template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
@@ -760,7 +841,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int lw = c.I(mp)[nv + c.lane];
   const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
 #ifdef FSIM_PROFILE
-  if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[55] += rsteps; ps_[56] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[57] += nbig; ps_[58] += 1; }
+  if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += nbig > 0; }
 #endif
   int bad = 0;
   if (rsteps > 0) {
@@ -779,9 +860,14 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
         const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
         const bool mine = c.lane >= first && c.lane < first + n && dofb != 255;
         const int dof = mine ? dofb : -1;
+#ifdef FSIM_CHOL_READLANE
         LaneBcast bc; bc.first = first;
         if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, n, bc);
         else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, n, bc);
+#else
+        if (n <= 31) bad |= fs_chol_mfma(c, mp, first, n);
+        else { LaneBcast bc; bc.first = first; bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, n, bc); }
+#endif
       }
     }
   }
