@@ -155,7 +155,10 @@ def main():
         gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index)  # ONE RCCL all-gather per slab-step: obs | reward | done packed
         need = sl.info[:, INFO_NEEDS_TABLE]
         if bool(need.any()):  # host-side reference RNG stream for the envs that just consumed their reset table
-            mask = need.bool().cpu().numpy()
+            need = need.cpu().numpy()
+            mask = need > 0
+            if (need > 1).any():  # an unstable env: the reference draws twice (reset inside step() + the worker's reset)
+                sl.tables.take(need > 1)
             p, nz = sl.tables.take(mask)
             sl.sim.set_reset_tables(p, nz, mask=mask)
 

@@ -8,7 +8,6 @@ Only the path named in BASELINE.json's north_star lives here:
 * ``envs``      host-side mirror of the reference's gym.Env surface (batched env, single-env classes, gym ids)
 * ``vec_env``   SubprocVecEnv-shaped wrapper (numpy in / out, per-env infos)
 * ``mixed``     mixed-furniture batch (BASELINE config 5)
-* ``async_env`` EnvPool-style send / recv over fsim_step_subset
 * ``dense``     tables of the dense 8-phase reward
 * ``dist``      env sharding + the per-step RCCL observation all-gather
 * ``scripted``  scripted pick-and-attach policy under ik_quaternion (scenario generator, cf. furniture_sawyer_gen.py)

@@ -198,7 +198,6 @@ struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; };
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
-  hipStream_t queues[FSIM_N_QUEUES] = {nullptr, nullptr, nullptr, nullptr}; // [0] aliases `stream`; the others are created on first use
   hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
   DModel m{};
@@ -219,7 +218,7 @@ struct fsim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double acc_ms = 0;
   int acc_n = 0;
-  bool timing_pending = false;
+  bool timing_pending = false, timing = false; // HIP-event timing of the step kernel: off until fsim_kernel_time_ms is first called
   int nbody = 0, ngeom = 0;
 };
 
@@ -470,7 +469,6 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  for (int q = 1; q < FSIM_N_QUEUES; q++) if (s->queues[q]) { hipStreamSynchronize(s->queues[q]); hipStreamDestroy(s->queues[q]); }
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -618,15 +616,15 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
 
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
-  timing_collect(s);
+  if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
-  timing_begin(s);
+  if (s->timing) timing_begin(s);
   hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
                      sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr);
   hipError_t e = hipGetLastError();
-  timing_end(s);
+  if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
   return FSIM_OK;
 }
@@ -708,6 +706,135 @@ extern "C" int fsim_dense_replay(int device, const float *coef, int ncoef, const
   return FSIM_OK;
 }
 
+// ---- env-logic replay hooks: the DEVICE functions of the connector state machine fed with recorded inputs, so that the
+// golden vectors the reference's own methods produced (tests/golden/env_logic.npz, step_scan.npz) are checked against the
+// code that runs inside fsim_step -- not only against the CPU restatement.
+__global__ void k_replay_is_aligned(AlignCfg cfg, int n, const float *p1, const float *R1, const float *p2, const float *R2, const int *nang,
+                                    const float *angles, int *out_ok, float *out_tq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float tq[4] = {__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
+  bool ok = env_is_aligned_core(ldv3(p1 + 3 * i), ldm3(R1 + 9 * i), ldv3(p2 + 3 * i), ldm3(R2 + 9 * i), nang[i], angles + 4 * i, cfg, tq);
+  out_ok[i] = ok ? 1 : 0;
+  for (int k = 0; k < 4; k++) out_tq[4 * i + k] = tq[k];
+}
+extern "C" int fsim_replay_is_aligned(int device, float pos_dist, float rot_up, float rot_fwd, float proj_dist, int n, const float *p1, const float *R1,
+                                      const float *p2, const float *R2, const int32_t *nang, const float *angles, int32_t *out_ok, float *out_tq) {
+  if (n < 1 || !p1 || !R1 || !p2 || !R2 || !nang || !angles || !out_ok || !out_tq) FAIL(FSIM_EINVAL, "fsim_replay_is_aligned: bad args");
+  HIPCHK(hipSetDevice(device));
+  float *d = nullptr;
+  const size_t w = (size_t)n * (3 + 9 + 3 + 9 + 1 + 4 + 1 + 4);
+  HIPCHK(hipMalloc(&d, w * 4));
+  float *dp1 = d, *dR1 = dp1 + 3 * n, *dp2 = dR1 + 9 * n, *dR2 = dp2 + 3 * n, *dang = dR2 + 9 * n, *dtq = dang + 4 * n;
+  int *dn = reinterpret_cast<int *>(dtq + 4 * n), *dok = dn + n;
+  hipMemcpy(dp1, p1, 12 * n, hipMemcpyHostToDevice); hipMemcpy(dR1, R1, 36 * n, hipMemcpyHostToDevice);
+  hipMemcpy(dp2, p2, 12 * n, hipMemcpyHostToDevice); hipMemcpy(dR2, R2, 36 * n, hipMemcpyHostToDevice);
+  hipMemcpy(dang, angles, 16 * n, hipMemcpyHostToDevice); hipMemcpy(dn, nang, 4 * n, hipMemcpyHostToDevice);
+  AlignCfg ac; ac.pos_dist = pos_dist; ac.rot_up = rot_up; ac.rot_fwd = rot_fwd; ac.proj_dist = proj_dist;
+  hipLaunchKernelGGL(k_replay_is_aligned, dim3((n + 63) / 64), dim3(64), 0, 0, ac, n, dp1, dR1, dp2, dR2, dn, dang, dok, dtq);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out_ok, dok, 4 * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_tq, dtq, 16 * n, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "fsim_replay_is_aligned: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+
+// one workgroup per trial, on the handle's model and record layout: the env block (group table, used-site bits, connect step)
+// comes from the caller, the alignment test is a recorded truth table [nconn][nconn]
+__global__ __launch_bounds__(64) void k_replay_try_connect(const DModel *mp, const Layout *lp, int num_connect_steps, const int *part12, const int *group,
+                                                         const int *used, const unsigned char *aligned, const int *step_in, int *out) {
+  extern __shared__ float L[];
+  CModel &m = *(CModel *)mp;
+  const GenCtx c(L, m, *(CLayout *)lp, threadIdx.x, 0, 0.0f);
+  const int t = blockIdx.x, nconn = c.D.nconn;
+  int *E = c.I(c.ly.env);
+  for (int i = threadIdx.x; i < E_FIXED_WORDS + c.D.nparts; i += 64) E[i] = 0;
+  SYNC();
+  if (threadIdx.x == 0) {
+    for (int p = 0; p < c.D.nparts; p++) E[E_GROUP + p] = group[t * c.D.nparts + p];
+    for (int k = 0; k < nconn; k++) if (used[t * nconn + k]) E[E_CONNSITES0 + (k >> 5)] |= 1 << (k & 31);
+    E[E_CONNECT_STEP] = step_in[t];
+    const unsigned char *al = aligned + (size_t)t * nconn * nconn;
+    int f1, f2;
+    const bool searched = env_connect_search(c, part12[2 * t], part12[2 * t + 1], [&](int k1, int k2) { return al[k1 * nconn + k2] != 0; }, &f1, &f2);
+    const int approach = env_connect_decide(E, num_connect_steps, searched, f1);
+    out[5 * t] = f1; out[5 * t + 1] = f2; out[5 * t + 2] = (!approach && f1 >= 0) ? 1 : 0; // returns True only when it connects
+    out[5 * t + 3] = E[E_CONNECT_STEP]; out[5 * t + 4] = (approach && f2 >= 0) ? m.conn_partid[f2] : -1;
+  }
+}
+extern "C" int fsim_replay_try_connect(fsim_t *s, int n, int num_connect_steps, const int32_t *part12, const int32_t *group, const int32_t *used,
+                                       const uint8_t *aligned, const int32_t *step_in, int32_t *out) {
+  if (!s || n < 1 || !part12 || !group || !used || !aligned || !step_in || !out) FAIL(FSIM_EINVAL, "fsim_replay_try_connect: bad args");
+  HIPCHK(hipSetDevice(s->device));
+  const int np = s->m.nparts, nc = s->m.nconn;
+  int *d = nullptr; unsigned char *da = nullptr;
+  HIPCHK(hipMalloc(&d, (size_t)n * (2 + np + nc + 1 + 5) * 4)); HIPCHK(hipMalloc(&da, (size_t)n * nc * nc + 4));
+  int *d12 = d, *dg = d12 + 2 * n, *du = dg + (size_t)n * np, *ds = du + (size_t)n * nc, *dout = ds + n;
+  hipMemcpy(d12, part12, 8 * n, hipMemcpyHostToDevice); hipMemcpy(dg, group, (size_t)4 * n * np, hipMemcpyHostToDevice);
+  hipMemcpy(du, used, (size_t)4 * n * nc, hipMemcpyHostToDevice); hipMemcpy(ds, step_in, 4 * n, hipMemcpyHostToDevice);
+  hipMemcpy(da, aligned, (size_t)n * nc * nc, hipMemcpyHostToDevice);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_replay_try_connect), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  hipLaunchKernelGGL(k_replay_try_connect, dim3(n), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, num_connect_steps, d12, dg, du, da, ds, dout);
+  hipError_t e = hipStreamSynchronize(s->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)20 * n, hipMemcpyDeviceToHost);
+  hipFree(d); hipFree(da);
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "fsim_replay_try_connect: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+
+// contact lists (colliding-geom indices) -> fs_touch_flags -> env_finger_scan with scripted try_connect outcomes: which parts
+// are tried, in which order
+__global__ __launch_bounds__(64) void k_replay_touch_scan(const DModel *mp, const Layout *lp, int maxc, const int *ncon, const int *geoms, const unsigned char *script,
+                                                        int *out_masks, int *out_tried) {
+  extern __shared__ float L[];
+  CModel &m = *(CModel *)mp;
+  const GenCtx c(L, m, *(CLayout *)lp, threadIdx.x, 0, 0.0f);
+  const int t = blockIdx.x;
+  int *scal = c.I(c.ly.scal);
+  const int n = min(ncon[t], c.ly.ncon_max);
+  for (int sl = threadIdx.x; sl < n; sl += 64) {
+    int *ri = c.I(c.ly.con + FSIM_CONW * sl);
+    ri[C_ACTIVE] = 1; ri[C_G1] = geoms[(t * maxc + sl) * 2]; ri[C_G2] = geoms[(t * maxc + sl) * 2 + 1];
+  }
+  if (threadIdx.x == 0) scal[SC_NSLOT] = n;
+  SYNC();
+  fs_touch_flags(c);
+  int ntried = 0;
+  env_finger_scan(c.D.narm, scal, [&](int part) {
+    if (threadIdx.x == 0) out_tried[4 * t + ntried] = part;
+    int r = script[4 * t + ntried] ? 1 : 0;
+    ntried++;
+    return r;
+  });
+  if (threadIdx.x == 0) {
+    for (int k = ntried; k < 4; k++) out_tried[4 * t + k] = -1;
+    out_masks[3 * t] = scal[SC_TOUCHL]; out_masks[3 * t + 1] = scal[SC_TOUCHR]; out_masks[3 * t + 2] = scal[SC_TOUCHF];
+  }
+}
+extern "C" int fsim_replay_touch_scan(fsim_t *s, int n, int maxc, const int32_t *ncon, const int32_t *geoms, const uint8_t *script, int32_t *out_masks,
+                                      int32_t *out_tried) {
+  if (!s || n < 1 || maxc < 1 || !ncon || !geoms || !script || !out_masks || !out_tried) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: bad args");
+  HIPCHK(hipSetDevice(s->device));
+  for (int t = 0; t < n; t++) {
+    if (ncon[t] < 0 || ncon[t] > maxc) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: ncon[%d] out of range", t);
+    for (int k = 0; k < 2 * ncon[t]; k++) if (geoms[(size_t)t * maxc * 2 + k] < 0 || geoms[(size_t)t * maxc * 2 + k] >= s->m.ncg) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: geom index out of range (colliding-geom indices expected)");
+  }
+  int *d = nullptr; unsigned char *dsc = nullptr;
+  HIPCHK(hipMalloc(&d, (size_t)n * (1 + 2 * maxc + 3 + 4) * 4)); HIPCHK(hipMalloc(&dsc, (size_t)4 * n));
+  int *dn = d, *dg = dn + n, *dm = dg + (size_t)2 * n * maxc, *dt = dm + 3 * n;
+  hipMemcpy(dn, ncon, 4 * n, hipMemcpyHostToDevice); hipMemcpy(dg, geoms, (size_t)8 * n * maxc, hipMemcpyHostToDevice);
+  hipMemcpy(dsc, script, (size_t)4 * n, hipMemcpyHostToDevice);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_replay_touch_scan), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+  hipLaunchKernelGGL(k_replay_touch_scan, dim3(n), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, maxc, dn, dg, dsc, dm, dt);
+  hipError_t e = hipStreamSynchronize(s->stream);
+  if (e == hipSuccess) e = hipMemcpy(out_masks, dm, (size_t)12 * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_tried, dt, (size_t)16 * n, hipMemcpyDeviceToHost);
+  hipFree(d); hipFree(dsc);
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "fsim_replay_touch_scan: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+
 extern "C" int fsim_reset(fsim_t *s, const uint8_t *mask_dev, float *obs_dev) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (!s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: call fsim_set_reset_tables first");
@@ -725,49 +852,9 @@ extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   s->cfg.max_episode_steps = n; s->ecfg.max_episode_steps = n; // EnvCfg is passed by value with every launch
   return FSIM_OK;
 }
-static int get_queue(fsim *s, int queue, hipStream_t *out) {
-  if (queue < 0 || queue >= FSIM_N_QUEUES) FAIL(FSIM_EINVAL, "queue %d out of range (FSIM_N_QUEUES = %d)", queue, FSIM_N_QUEUES);
-  HIPCHK(hipSetDevice(s->device));
-  if (queue == 0) { *out = s->stream; return FSIM_OK; }
-  if (!s->queues[queue]) HIPCHK(hipStreamCreateWithFlags(&s->queues[queue], hipStreamNonBlocking));
-  *out = s->queues[queue];
-  return FSIM_OK;
-}
-extern "C" int fsim_step_subset(fsim_t *s, int queue, const int32_t *env_ids, int n_ids, const float *action, float *obs, float *reward,
-                                uint8_t *done, int32_t *info, int32_t *cost_keys) {
-  if (!s || !action || !env_ids) FAIL(FSIM_EINVAL, "fsim_step_subset: null handle/action/env_ids");
-  if (n_ids < 0 || n_ids > s->n_envs) FAIL(FSIM_EINVAL, "fsim_step_subset: n_ids %d out of range", n_ids);
-  if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step_subset: auto_reset needs fsim_set_reset_tables");
-  if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step_subset: dense_reward needs fsim_set_dense_reward first");
-  hipStream_t st;
-  if (int rc = get_queue(s, queue, &st)) return rc;
-  if (n_ids == 0) return FSIM_OK;
-  KParams kp = kparams(s, s->cfg.n_substeps, 0);
-  kp.n_envs = n_ids; // grid size; blockIdx -> env through env_ids (the caller lists predicted-expensive envs first)
-  hipLaunchKernelGGL(s->ks.env_step, dim3(n_ids), dim3(64), s->lds_bytes, st, s->d_m, s->d_ly, kp, s->ecfg, s->d_state, action, obs, reward, done, info,
-                     s->d_tab_parts, s->d_tab_noise, s->n_noise, nullptr, 1, reinterpret_cast<int *>(s->d_aux), env_ids, cost_keys ? cost_keys : s->d_cost);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step (subset) launch: %s", hipGetErrorString(e));
-  return FSIM_OK;
-}
-extern "C" int fsim_queue_query(fsim_t *s, int queue) {
-  if (!s) FAIL(FSIM_EINVAL, "null");
-  hipStream_t st;
-  if (int rc = get_queue(s, queue, &st)) return rc;
-  hipError_t e = hipStreamQuery(st);
-  if (e == hipSuccess) return 0;
-  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
-  FAIL(FSIM_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
-}
-extern "C" int fsim_queue_sync(fsim_t *s, int queue) {
-  if (!s) FAIL(FSIM_EINVAL, "null");
-  hipStream_t st;
-  if (int rc = get_queue(s, queue, &st)) return rc;
-  HIPCHK(hipStreamSynchronize(st));
-  return FSIM_OK;
-}
 extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {
   if (!s) FAIL(FSIM_EINVAL, "null");
+  s->timing = true;
   timing_collect(s);
   if (avg_ms) *avg_ms = s->acc_n ? s->acc_ms / s->acc_n : 0.0;
   if (n) *n = s->acc_n;

@@ -168,9 +168,11 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
     t0m = wave_or(t0m); t1m = wave_or(t1m);
     if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.D.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
   }
-  // instability guard (mj_checkAcc analogue): NaN / huge accelerations
+  // instability guard (mj_checkPos / mj_checkVel / mj_checkAcc: NaN, Inf or a value beyond 1e10 in qpos, qvel or qacc -- the
+  // warnings mujoco_py turns into the MujocoException that _do_simulation catches, furniture.py:2889-2897)
   int bad = 0;
-  for (int d = c.lane; d < c.D.nv; d += 64) { float a = c.L[c.ly.x + d]; bad |= !(fabsf(a) < 1e10f); }
+  for (int d = c.lane; d < c.D.nv; d += 64) { float a = c.L[c.ly.x + d], v = c.L[c.ly.qvel + d]; bad |= !(fabsf(a) < 1e10f) | !(fabsf(v) < 1e10f); }
+  for (int d = c.lane; d < c.D.nq; d += 64) { float q = c.L[c.ly.qpos + d]; bad |= !(fabsf(q) < 1e10f); }
   bad = wave_or(bad);
   if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
   SYNC();
@@ -298,20 +300,17 @@ template <class Ctx> DEV void env_next_subtask(const Ctx &c) {
   }
 }
 
-// _is_aligned (furniture.py:1057-1153) for connector indices k1,k2; writes the target quaternion on success paths
-template <class Ctx> DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
-  CModel &m = c.m;
-  V3 p1, p2; M3 R1, R2;
-  env_site_pose(c, GP(m.conn_siteid)[k1], &p1, nullptr, &R1);
-  env_site_pose(c, GP(m.conn_siteid)[k2], &p2, nullptr, &R2);
+// _is_aligned (furniture.py:1057-1153) on two site poses (world position, rotation matrix), the allowed forward angles of the
+// first site (na == 0: any) and the thresholds; writes the target quaternion on the same paths as the reference.  Separate
+// from the pose gathering so that the reference's golden vectors can be fed to it directly (fsim_replay_is_aligned).
+struct AlignCfg { float pos_dist, rot_up, rot_fwd, proj_dist; };
+template <class AngP> DEV bool env_is_aligned_core(V3 p1, const M3 &R1, V3 p2, const M3 &R2, int na, AngP angles, const AlignCfg &cfg, float *tq) {
   V3 up1 = colv(R1, 2), up2 = colv(R2, 2), f1 = colv(R1, 1), f2 = colv(R2, 1);
   float pos_dist = norm(p1 - p2);
   float rot_up = env_cos(up1, up2);
   float proj12 = dot(up1, (p2 - p1) * (1.0f / norm(p2 - p1)));
   float proj21 = dot(up2, (p1 - p2) * (1.0f / norm(p1 - p2)));
   bool fwd_ok;
-  int na = GP(m.conn_nangle)[k1];
-  float *tq = c.L + c.ly.env + E_TARGET_QUAT;
   if (na == 0) {
     fwd_ok = true;
     float cs = env_cos(f1, f2);
@@ -324,7 +323,7 @@ template <class Ctx> DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, in
     fwd_ok = false;
     V3 k = normalized(up1);
     for (int a = 0; a < na; a++) {
-      float ang = GP(m.conn_angles)[FSIM_MAXANG * k1 + a] / 180.0f * 3.14159265358979f;
+      float ang = angles[a] / 180.0f * 3.14159265358979f;
       V3 fr = cosf(ang) * f1 + sinf(ang) * cross(k, f1);
       if (env_cos(fr, f2) > cfg.rot_fwd) { fwd_ok = true; stq(tq, env_lookat(up1, fr)); break; }
     }
@@ -332,6 +331,16 @@ template <class Ctx> DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, in
   if (pos_dist < cfg.pos_dist && rot_up > cfg.rot_up && fwd_ok && fabsf(proj12) > cfg.proj_dist && fabsf(proj21) > cfg.proj_dist) return true;
   if (pos_dist < cfg.pos_dist / 2 && rot_up > cfg.rot_up && fwd_ok) return true;
   return false;
+}
+// for connector indices k1, k2 of the env's model, on the poses of the last forward pass
+template <class Ctx> DEV bool env_is_aligned(const Ctx &c, const EnvCfg &cfg, int k1, int k2) {
+  CModel &m = c.m;
+  V3 p1, p2; M3 R1, R2;
+  env_site_pose(c, GP(m.conn_siteid)[k1], &p1, nullptr, &R1);
+  env_site_pose(c, GP(m.conn_siteid)[k2], &p2, nullptr, &R2);
+  AlignCfg ac;
+  ac.pos_dist = cfg.pos_dist; ac.rot_up = cfg.rot_up; ac.rot_fwd = cfg.rot_fwd; ac.proj_dist = cfg.proj_dist;
+  return env_is_aligned_core(p1, R1, p2, R2, GP(m.conn_nangle)[k1], GP(m.conn_angles) + FSIM_MAXANG * k1, ac, c.L + c.ly.env + E_TARGET_QUAT);
 }
 
 // sensor values of the dense reward from the poses of the last forward pass (furniture_sawyer_dense.py:222-271)
@@ -453,6 +462,71 @@ template <class Ctx> DEV int env_move_rotate(const Ctx &c, int part, V3 move, V3
   return inside;
 }
 
+// The search of _try_connect (furniture.py:946-991), lane-0 scalar code: the first (site1 on group(part1), site2 on group(part2)
+// or on any part) in connector order that is unused, name-matched and aligned.  `aligned(k1, k2)` is the alignment test --
+// env_is_aligned in the env, a recorded truth table in fsim_replay_try_connect.
+// returns false where the reference returns early (furniture.py:964-973: a group without connector sites, or no <weld> between
+// the two groups) -- those paths leave _connect_step untouched
+template <class Ctx, class AlignedFn> DEV bool env_connect_search(const Ctx &c, int part1, int part2, AlignedFn aligned, int *f1, int *f2) {
+  CModel &m = c.m;
+  int *E = c.I(c.ly.env);
+  int *grp = E + E_GROUP;
+  int found1 = -1, found2 = -1;
+  *f1 = -1; *f2 = -1;
+  int g1 = env_find(grp, part1), g2 = part2 >= 0 ? env_find(grp, part2) : -1;
+  int n1 = 0, n2 = 0;
+  for (int k = 0; k < c.D.nconn; k++) {
+    int gk = env_find(grp, GP(m.conn_partid)[k]);
+    n1 += gk == g1; n2 += g2 < 0 || gk == g2;
+  }
+  if (n1 == 0 || n2 == 0) return false;
+  bool weld_ok = c.D.neq > 0;
+  if (weld_ok && part2 >= 0) { // some <weld> must join two bodies of group(part1) U group(part2) (activity is not checked)
+    weld_ok = false;
+    for (int i = 0; i < c.D.neq && !weld_ok; i++) {
+      int ga = env_find(grp, GP(m.eq_part1)[i]), gb = env_find(grp, GP(m.eq_part2)[i]);
+      weld_ok = (ga == g1 || ga == g2) && (gb == g1 || gb == g2);
+    }
+  }
+  if (!weld_ok) return false;
+  {
+    for (int k1 = 0; k1 < c.D.nconn && found1 < 0; k1++) {
+      if (env_find(grp, GP(m.conn_partid)[k1]) != g1) continue;
+      for (int k2 = 0; k2 < c.D.nconn; k2++) {
+        if (g2 >= 0 && env_find(grp, GP(m.conn_partid)[k2]) != g2) continue;
+        if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
+        if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
+        int a1 = GP(m.conn_keya)[k1], b1 = GP(m.conn_keyb)[k1], a2 = GP(m.conn_keya)[k2], b2 = GP(m.conn_keyb)[k2];
+        bool match = (b1 < 0 || b2 < 0) ? (b1 < 0 && b2 < 0 && a1 == a2) : (a1 == b2 && b1 == a2);
+        if (!match) continue;
+        if (aligned(k1, k2)) { found1 = k1; found2 = k2; break; }
+      }
+    }
+  }
+  *f1 = found1; *f2 = found2;
+  return true;
+}
+// _connect_step bookkeeping (furniture.py:993-1040): 1 = approach the aligned pose by one increment (found pair, counter below
+// num_connect_steps; the counter is advanced), 0 = connect now if a pair was found (the counter restarts)
+DEV int env_connect_decide(int *E, int num_connect_steps, bool searched, int found1) {
+  if (!searched) return 0; // the reference returned before touching the counter
+  if (found1 >= 0 && E[E_CONNECT_STEP] < num_connect_steps) { E[E_CONNECT_STEP] += 1; return 1; }
+  E[E_CONNECT_STEP] = 0;
+  return 0;
+}
+// finger-touch connect scan of _step_continuous (furniture.py:1290-1330) on the touch masks of the last forward pass: per arm the
+// first part (in part order) touched by BOTH fingers is tried; a successful attempt ends the scan (quirk Q4).  try_connect(part)
+// returns wave-uniform 1 if a connection was made.
+template <class TryFn> DEV void env_finger_scan(int narm, const int *scal, TryFn try_connect) {
+  int done_connect = 0;
+  for (int arm = 0; arm < narm && !done_connect; arm++) {
+    int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
+    if (!both) continue;
+    int part = __ffs(both) - 1;
+    done_connect = try_connect(part); // break after the first pinched part either way
+  }
+}
+
 // _try_connect(part1, part2) (furniture.py:926-1042).  part2 < 0: any part (the arm agents).  returns (wave-uniform) 1 if a
 // connection was made; with num_connect_steps > 0 (Cursor) an aligned pair is first approached over that many calls.
 template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
@@ -462,33 +536,11 @@ template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, in
   int *scal = c.I(c.ly.scal);
   // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
   if (c.lane == 0) {
-    int found1 = -1, found2 = -1;
-    bool weld_ok = c.D.neq > 0 && c.D.nconn > 0;
-    int g1 = env_find(grp, part1), g2 = part2 >= 0 ? env_find(grp, part2) : -1;
-    if (weld_ok && part2 >= 0) { // some <weld> must join two bodies of group(part1) U group(part2) (activity is not checked)
-      weld_ok = false;
-      for (int i = 0; i < c.D.neq && !weld_ok; i++) {
-        int ga = env_find(grp, GP(m.eq_part1)[i]), gb = env_find(grp, GP(m.eq_part2)[i]);
-        weld_ok = (ga == g1 || ga == g2) && (gb == g1 || gb == g2);
-      }
-    }
-    if (weld_ok) {
-      for (int k1 = 0; k1 < c.D.nconn && found1 < 0; k1++) {
-        if (env_find(grp, GP(m.conn_partid)[k1]) != g1) continue;
-        for (int k2 = 0; k2 < c.D.nconn; k2++) {
-          if (g2 >= 0 && env_find(grp, GP(m.conn_partid)[k2]) != g2) continue;
-          if ((E[E_CONNSITES0 + (k1 >> 5)] >> (k1 & 31)) & 1) continue;
-          if ((E[E_CONNSITES0 + (k2 >> 5)] >> (k2 & 31)) & 1) continue;
-          int a1 = GP(m.conn_keya)[k1], b1 = GP(m.conn_keyb)[k1], a2 = GP(m.conn_keya)[k2], b2 = GP(m.conn_keyb)[k2];
-          bool match = (b1 < 0 || b2 < 0) ? (b1 < 0 && b2 < 0 && a1 == a2) : (a1 == b2 && b1 == a2);
-          if (!match) continue;
-          if (env_is_aligned(c, cfg, k1, k2)) { found1 = k1; found2 = k2; break; }
-        }
-      }
-    }
-    if (found1 >= 0 && E[E_CONNECT_STEP] < cfg.num_connect_steps) {
+    int found1, found2;
+    const bool searched = env_connect_search(c, part1, part2, [&](int k1, int k2) { return env_is_aligned(c, cfg, k1, k2); }, &found1, &found2);
+    if (env_connect_decide(E, cfg.num_connect_steps, searched, found1) == 1) {
       // approach phase (furniture.py:993-1034): slerp / lerp part2's group towards the aligned pose, one increment per call
-      const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP];
+      const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP] - 1; // (already advanced by env_connect_decide)
       float *ec = c.L + env_ecur(c);
       int p2 = GP(m.conn_partid)[found2], a = GP(m.part_qposadr)[p2];
       V3 p2p = ldv3(c.L + c.ly.qpos + a); Q4 p2q = ldq(c.L + c.ly.qpos + a + 3);
@@ -507,10 +559,7 @@ template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, in
       V3 npos = p0 + (bpos - p0) * x;
       Q4 nrot = env_slerp(q0, brot, (float)(step + 1) / n);
       env_move_group(c, p2, npos - p2p, nrot, 1.0f);
-      E[E_CONNECT_STEP] = step + 1;
       found1 = -1;
-    } else {
-      E[E_CONNECT_STEP] = 0;
     }
     scal[9] = found1; scal[10] = found2;
   }
@@ -908,20 +957,19 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   }
   int bad = scal[SC_BAD] & 2;
   if (bad) {
-    // unstable simulation: reset inside step(), flag the failure (furniture.py:2889-2897)
-    env_reset(c, &cfg, &io);
-    if (c.lane == 0) { E[E_FAIL] = 1; scal[SC_BAD] = 0; }
+    // unstable simulation: reset inside step(), flag the failure (furniture.py:2889-2897).  Under auto_reset the step is
+    // terminal and the env is reset again right below (the vec-env worker's reset, subproc_vec_env.py:16-20): the first reset
+    // would leave nothing behind but ONE consumed pass of the env's reset-time RNG stream, so it is not executed -- the info
+    // block tells the host to drop one draw instead (FSIM_INFO_NEEDS_TABLE = 2).  (The dense reward is computed on the reset
+    // state by the reference, so the dense env keeps the in-step reset and its stream runs one draw behind after a failure.)
+    const bool skip_reset = cfg.auto_reset && !cfg.dense;
+    if (!skip_reset) env_reset(c, &cfg, &io);
+    if (c.lane == 0) { E[E_FAIL] = skip_reset ? 2 : 1; scal[SC_BAD] = 0; if (skip_reset) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; } }
     SYNC();
-    fs_substeps(c, 1, 3);
+    if (!skip_reset) fs_substeps(c, 1, 3);
   } else if (connect > 0) {
     // finger-touch scan -> first part (in part order) pinched by both fingers of an arm -> _try_connect
-    int done_connect = 0;
-    for (int arm = 0; arm < c.D.narm && !done_connect; arm++) {
-      int both = (scal[SC_TOUCHL] >> (16 * arm)) & (scal[SC_TOUCHR] >> (16 * arm)) & 0xffff;
-      if (!both) continue;
-      int part = __ffs(both) - 1;
-      done_connect = env_try_connect(c, cfg, part, -1); // break after the first pinched part either way (quirk Q4)
-    }
+    env_finger_scan(c.D.narm, scal, [&](int part) { return env_try_connect(c, cfg, part, -1); });
   }
   // post-connect re-pose of body1's (merged) group (furniture.py:426-436)
   if (E[E_CONNBODY1] > 0) {
@@ -998,10 +1046,10 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     if (io.reward) *io.reward = rew;
     if (io.done) *io.done = (uint8_t)terminal;
     if (io.info) {
-      io.info[FSIM_INFO_NUM_CONNECTED] = E[E_NUM_CONNECTED]; io.info[FSIM_INFO_SUCCESS] = success; io.info[FSIM_INFO_FAIL] = fail;
+      io.info[FSIM_INFO_NUM_CONNECTED] = E[E_NUM_CONNECTED]; io.info[FSIM_INFO_SUCCESS] = success; io.info[FSIM_INFO_FAIL] = fail ? 1 : 0;
       io.info[FSIM_INFO_LAST_SITE1] = E[E_SITE1]; io.info[FSIM_INFO_LAST_SITE2] = E[E_SITE2];
       io.info[FSIM_INFO_EPISODE_LENGTH] = E[E_EPISODE_LENGTH]; io.info[FSIM_INFO_CONNECTED_THIS_STEP] = E[E_CONNECTED_THIS_STEP];
-      io.info[FSIM_INFO_NEEDS_TABLE] = (terminal && cfg.auto_reset) ? 1 : 0;
+      io.info[FSIM_INFO_NEEDS_TABLE] = (terminal && cfg.auto_reset) ? (fail == 2 ? 2 : 1) : 0; // 2: drop one draw first (see the unstable branch)
       io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
       io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];

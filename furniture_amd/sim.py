@@ -94,14 +94,14 @@ def lib():
         L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
         L.fsim_env_block_words.argtypes = [ctypes.c_void_p]
         L.fsim_kernel_variant.argtypes = [ctypes.c_void_p]
+        L.fsim_replay_is_aligned.argtypes = [ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 8
+        L.fsim_replay_try_connect.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+        L.fsim_replay_touch_scan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        L.fsim_step_subset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
-        L.fsim_queue_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        L.fsim_queue_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.fsim_dense_replay.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
@@ -114,7 +114,8 @@ EXPORTED_SYMBOLS = [
     "fsim_last_error", "fsim_default_config", "fsim_create", "fsim_destroy", "fsim_dims", "fsim_stream", "fsim_sync",
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
-    "fsim_env_block_words", "fsim_step_subset", "fsim_queue_query", "fsim_queue_sync", "fsim_set_max_episode_steps", "fsim_kernel_variant",
+    "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
+    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan",
 ]
 
 
@@ -143,6 +144,20 @@ def dense_replay(coef, subtasks, n_pre, obs0, obs, ac, connected, device=0):
     if rc:
         raise FsimError("fsim_dense_replay rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
     return rew, flags
+
+
+def replay_is_aligned(p1, R1, p2, R2, nang, angles, pos_dist=0.1, rot_up=0.9, rot_fwd=0.9, proj_dist=0.3, device=0):
+    """The device's _is_aligned on recorded site poses (include/fsim.h: fsim_replay_is_aligned) -> (ok [n] bool, target_quat [n, 4])."""
+    f = lambda a, sh: np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(sh))
+    n = len(nang)
+    p1, R1, p2, R2, ang = f(p1, (n, 3)), f(R1, (n, 9)), f(p2, (n, 3)), f(R2, (n, 9)), f(angles, (n, 4))
+    na = np.ascontiguousarray(np.asarray(nang, dtype=np.int32))
+    ok, tq = np.zeros(n, dtype=np.int32), np.zeros((n, 4), dtype=np.float32)
+    rc = lib().fsim_replay_is_aligned(int(device), pos_dist, rot_up, rot_fwd, proj_dist, n, p1.ctypes.data, R1.ctypes.data, p2.ctypes.data,
+                                      R2.ctypes.data, na.ctypes.data, ang.ctypes.data, ok.ctypes.data, tq.ctypes.data)
+    if rc != 0:
+        raise FsimError("fsim_replay_is_aligned rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
+    return ok.astype(bool), tq
 
 
 class FSim:
@@ -213,9 +228,12 @@ class FSim:
         out, p = {}, StatePtrs()
         for n in names:
             dim, kind = shapes[n]
+            # zero-filled (geom_contype / geom_conaffinity only receive their colliding-geom entries); the fill runs on torch's
+            # stream, the copies on the handle's: the synchronize below orders them
             t = torch.zeros((self.n_envs, dim), dtype=torch.float32 if kind == "f" else torch.int32, device=self.device)
             out[n] = t
             setattr(p, n, t.data_ptr() if dim else None)
+        torch.cuda.current_stream(self.device).synchronize()
         self._chk(lib().fsim_get_state(self._h, ctypes.byref(p)))
         self.sync()
         return out
@@ -260,19 +278,25 @@ class FSim:
         self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))
         self.cfg.max_episode_steps = int(n)
 
-    # -- asynchronous stepping (include/fsim.h: fsim_step_subset) ----------------------------------------
-    def step_subset(self, queue, env_ids, n_ids, action, obs, reward, done, info, cost_keys=None):
-        self._chk(lib().fsim_step_subset(self._h, int(queue), env_ids.data_ptr(), int(n_ids), action.data_ptr(), obs.data_ptr(), reward.data_ptr(),
-                                         done.data_ptr(), info.data_ptr(), None if cost_keys is None else cost_keys.data_ptr()))
+    # -- env-logic replay hooks (include/fsim.h: fsim_replay_*) ------------------------------------------
+    def replay_try_connect(self, part12, group, used, aligned, step_in, num_connect_steps):
+        i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+        part12, group, used, step_in = i32(part12), i32(group), i32(used), i32(step_in)
+        al = np.ascontiguousarray(np.asarray(aligned, dtype=np.uint8))
+        n = len(step_in)
+        out = np.zeros((n, 5), dtype=np.int32)
+        self._chk(lib().fsim_replay_try_connect(self._h, n, int(num_connect_steps), part12.ctypes.data, group.ctypes.data, used.ctypes.data,
+                                                al.ctypes.data, step_in.ctypes.data, out.ctypes.data))
+        return out
 
-    def queue_busy(self, queue):
-        rc = lib().fsim_queue_query(self._h, int(queue))
-        if rc < 0:
-            self._chk(rc)
-        return rc == 1
-
-    def queue_sync(self, queue):
-        self._chk(lib().fsim_queue_sync(self._h, int(queue)))
+    def replay_touch_scan(self, ncon, geoms, script):
+        i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+        ncon, geoms = i32(ncon), i32(geoms)
+        sc = np.ascontiguousarray(np.asarray(script, dtype=np.uint8))
+        n, maxc = len(ncon), geoms.shape[1]
+        masks, tried = np.zeros((n, 3), dtype=np.int32), np.zeros((n, 4), dtype=np.int32)
+        self._chk(lib().fsim_replay_touch_scan(self._h, n, maxc, ncon.ctypes.data, geoms.ctypes.data, sc.ctypes.data, masks.ctypes.data, tried.ctypes.data))
+        return masks, tried
 
     def kernel_time_ms(self):
         ms, n = ctypes.c_double(), ctypes.c_int32()

@@ -92,6 +92,8 @@ typedef struct fsim_state_ptrs {
   float *eq_data /* [n, neq*7] */;
   int32_t *eq_active /* [n, neq] */, *geom_contype /* [n, ngeom] */, *geom_conaffinity /* [n, ngeom] */;
   int32_t *group /* [n, nparts] */;
+  /* The `out only` fields below are results of the last fsim_physics_step / fsim_physics_forward launch: fsim_step and
+   * fsim_reset do NOT refresh them (their forward passes live and die inside the fused kernel). */
   float *qacc /* out only */, *xpos /* out only: [n, nbody*3] */, *xquat /* out only: [n, nbody*4] */;
   int32_t *ncon /* out only: [n] */, *contact_geoms /* out only: [n, max_contacts*2], -1 padded */;
   int32_t *solver_iters /* out only: [n] Newton iterations of the last substep */;
@@ -132,24 +134,12 @@ int fsim_step(fsim_t *, const float *action_dev, float *obs_dev, float *reward_d
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);
 
-/* Asynchronous stepping (EnvPool-style send / recv): FurnitureEnv.step(action) on the listed envs only.  env_ids: device int32
- * [n_ids], distinct; every other argument as in fsim_step (full-size [n, ...] buffers indexed by env id -- rows of envs that are
- * not listed are not touched).  queue selects one of FSIM_N_QUEUES HIP streams of the handle (0 = the stream of fsim_step /
- * fsim_stream), so that batches of DIFFERENT envs can be in flight at the same time; the caller must not list an env that is still
- * in flight on another queue.  cost_keys (device int32 [n], or NULL): per-env scheduler key written by the step -- shader time
- * of the step >> 10, bit 30 = a robot hand is within 10 cm of a part (likely to couple next), -1 = the env will hit its time
- * limit (and reset inside the launch) next step -- the information a host scheduler needs to batch envs by predicted cost.
- * Envs are independent: stepping them in subsets, in any order, yields bit-identical per-env trajectories. */
-#define FSIM_N_QUEUES 4
-int fsim_step_subset(fsim_t *, int queue, const int32_t *env_ids_dev, int n_ids, const float *action_dev, float *obs_dev,
-                     float *reward_dev, uint8_t *done_dev, int32_t *info_dev, int32_t *cost_keys_dev);
-int fsim_queue_query(fsim_t *, int queue); /* 0: everything enqueued on the queue has finished, 1: still running, < 0: error */
-int fsim_queue_sync(fsim_t *, int queue);
-
 enum {
   FSIM_INFO_NUM_CONNECTED = 0, FSIM_INFO_SUCCESS = 1, FSIM_INFO_FAIL = 2, FSIM_INFO_LAST_SITE1 = 3,
   FSIM_INFO_LAST_SITE2 = 4, FSIM_INFO_EPISODE_LENGTH = 5, FSIM_INFO_CONNECTED_THIS_STEP = 6,
-  FSIM_INFO_NEEDS_TABLE = 7, /* env consumed its reset table this step */
+  FSIM_INFO_NEEDS_TABLE = 7, /* env consumed its reset table this step: upload the next one (fsim_set_reset_tables with a mask).
+                              * 2 = after DROPPING one pass of the env's reset-time RNG stream: an unstable simulation resets inside
+                              * step() (furniture.py:2889-2897) and the vec-env worker resets again; only the second reset is run */
   FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
   FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
   FSIM_INFO_OVERFLOW = 12, /* bit 0: broadphase survivor list truncated, bit 1: contact slots exhausted (contacts dropped) in this step */
@@ -178,8 +168,32 @@ int fsim_dense_replay(int device, const float *coef, int ncoef, const float *sub
                       const float *obs, const float *ac, int dof, const uint8_t *connected, int T, float *out_reward,
                       int32_t *out_flags);
 
-/* timing helper for bench.py: average device time (ms) of the last fsim_step kernel launches, measured with
- * HIP events on the handle's stream; resets the accumulator. */
+/* ---- env-logic replay (parity hooks, like fsim_dense_replay): the device functions of the connector state machine that run
+ * inside fsim_step, fed with recorded inputs so that the reference's golden vectors can be checked against them directly.
+ * Host pointers; synchronous.
+ *   fsim_replay_is_aligned   FurnitureEnv._is_aligned (furniture.py:1057-1153) on n site-pose pairs: p [n][3], R [n][9] row-major
+ *                            world rotation of the site, nang [n] allowed forward angles of site 1 (0 = any), angles [n][4] degrees;
+ *                            out_ok [n], out_tq [n][4] = _target_connector_xquat (wxyz; NaN where the reference leaves it unset).
+ *   fsim_replay_try_connect  the search + _connect_step bookkeeping of _try_connect (furniture.py:926-1042) on the handle's connector /
+ *                            weld tables: part12 [n][2] (part2 = -1: any), group [n][nparts] union-find parent table, used [n][nconn]
+ *                            connected-site flags, aligned [n][nconn][nconn] recorded outcome of _is_aligned per connector pair,
+ *                            step_in [n]; out [n][5] = connector index 1, connector index 2 (-1: none), return value, _connect_step
+ *                            after the call, part moved by the approach phase (-1: none).
+ *   fsim_replay_touch_scan   finger-touch masks (furniture.py:500-513, 1298-1322) + the connect scan of _step_continuous
+ *                            (furniture.py:1290-1330) on n contact lists: ncon [n], geoms [n][maxc][2] COLLIDING-geom indices,
+ *                            script [n][4] outcome of the k-th _try_connect; out_masks [n][3] = left / right finger touch bits
+ *                            (arm * 16 + part), floor touch bits; out_tried [n][4] parts tried in order, -1 padded. */
+int fsim_replay_is_aligned(int device, float pos_dist, float rot_up, float rot_fwd, float proj_dist, int n, const float *p1, const float *R1,
+                           const float *p2, const float *R2, const int32_t *nang, const float *angles, int32_t *out_ok, float *out_tq);
+int fsim_replay_try_connect(fsim_t *, int n, int num_connect_steps, const int32_t *part12, const int32_t *group, const int32_t *used,
+                            const uint8_t *aligned, const int32_t *step_in, int32_t *out);
+int fsim_replay_touch_scan(fsim_t *, int n, int maxc, const int32_t *ncon, const int32_t *geoms, const uint8_t *script, int32_t *out_masks,
+                           int32_t *out_tried);
+
+/* timing helper for bench.py: average device time (ms) of the fsim_step kernel launches since the previous call, measured with
+ * HIP events on the handle's stream; resets the accumulator.  Timing is OFF until the first call (which returns n = 0): while
+ * it is on, each fsim_step / fsim_reset first waits for the end event of the handle's previous launch, i.e. a launch is then
+ * no longer fully asynchronous with respect to the one before it. */
 int fsim_kernel_time_ms(fsim_t *, double *avg_ms, int32_t *n_launches);
 
 #ifdef __cplusplus

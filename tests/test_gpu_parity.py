@@ -486,3 +486,79 @@ def test_thousand_env_steps_within_1e4_of_oracle(sawyer_lack):
     assert not bool(done[0]) and not d
     print("1000 env steps: worst observation error %.2e" % worst)
     sim.close()
+
+
+def test_second_reset_continues_the_reference_rng_stream(sawyer_lack):
+    """Every reset() consumes exactly one pass of the env's reset-time RNG stream (seed + i, furniture/env/base.py:77): a table
+    uploaded ahead for an auto-reset that has not happened yet is the NEXT draw and must not be dropped.  Single-env class
+    (auto_reset off) and batched env (auto_reset on), three resets each, against the oracle env's consecutive resets."""
+    from furniture_amd.envs import FurnitureBatchEnv, FurnitureSawyerEnv, make_config
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50, seed=321)
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=321, solver_tolerance=1e-10))
+    want = [orc.flat_obs(orc.reset())[:35] for _ in range(3)]
+    assert np.abs(want[0] - want[1]).max() > 1e-3  # the placements differ from draw to draw
+    env = FurnitureSawyerEnv(make_config(**kw))
+    for k in range(3):
+        ob = env.reset()
+        assert np.abs(ob["object_ob"] - want[k]).max() < 2e-4, k
+        env.step(np.zeros(9, dtype=np.float32))
+    env.close()
+    benv = FurnitureBatchEnv("Sawyer", 2, config=make_config(**kw))
+    for k in range(3):
+        ob = benv.reset()
+        assert np.abs(ob["object_ob"][0].cpu().numpy() - want[k]).max() < 2e-4, k
+        benv.step(np.zeros((2, 9), dtype=np.float32))
+    benv.close()
+
+
+@pytest.mark.parametrize("auto_reset", [0, 1])
+def test_unstable_simulation_fails_the_step_and_resets(sawyer_lack, auto_reset):
+    """_do_simulation's exception path (furniture.py:2889-2897) + _after_step (furniture.py:463-467): a state that blows the solver
+    up (huge velocity) => fail flag, -unstable_penalty_coef reward, terminal step, and an observation of a freshly reset episode.
+    With auto_reset the in-step reset is folded into the worker's reset and the host is told to drop one RNG draw (needs_table = 2)."""
+    from furniture_amd.sim import INFO_EPISODE_LENGTH, INFO_FAIL, INFO_NEEDS_TABLE
+    m = sawyer_lack
+    n = 4
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset = 100, auto_reset
+    sim = FSim(m, n, config=cfg)
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=100, seed=50 + i, solver_tolerance=1e-10)) for i in range(n)]
+    for e in envs:
+        e.reset()
+    tabs = (np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]), np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    sim.set_reset_tables(*tabs)
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    obs0 = obs.clone()
+    sim.set_reset_tables(*tabs)  # the same placement again: the post-failure observation is then known
+    st = sim.get_state("qvel")
+    qv = st["qvel"].clone()
+    qv[1] = float("nan")            # env 1: NaN velocity
+    qv[2, m.part_dofadr[0]] = 1e12  # env 2: a part at 1e12 m/s
+    sim.set_state(qvel=qv)
+    act = torch.zeros((n, 9), device=dev)
+    sim.step(act, obs, rew, done, info)
+    sim.sync()
+    inf = info.cpu().numpy()
+    assert list(inf[:, INFO_FAIL]) == [0, 1, 1, 0]
+    assert list(done.cpu().numpy()) == [0, 1, 1, 0]
+    assert np.allclose(rew.cpu().numpy(), [0, -100, -100, 0], atol=1e-6)
+    assert torch.isfinite(obs).all()
+    for e in (1, 2):  # observation of a fresh episode from the same table = the first reset's observation ...
+        d = np.abs(obs[e].cpu().numpy() - obs0[e].cpu().numpy())
+        assert d[:35].max() < 2e-4
+        # ... except that the reference's in-step reset is followed by one more forward pass before _get_obs (the step goes on),
+        # so the end-effector pose is one integration step newer than in reset()'s own observation
+        assert d[35:].max() < (2e-4 if auto_reset else 5e-3)
+    assert list(inf[:, INFO_NEEDS_TABLE]) == ([0, 2, 2, 0] if auto_reset else [0, 0, 0, 0])
+    assert list(inf[:, INFO_EPISODE_LENGTH]) == [1, 1, 1, 1]
+    # the failed envs carry on: next step is an ordinary first step of the new episode
+    sim.step(act, obs, rew, done, info)
+    sim.sync()
+    assert torch.isfinite(obs).all() and list(done.cpu().numpy()) == [0, 0, 0, 0] and list(info[:, INFO_FAIL].cpu().numpy()) == [0, 0, 0, 0]
+    sim.close()
