@@ -4,7 +4,8 @@ Workload = BASELINE config 2: FurnitureSawyerEnv + table_lack_0825, control_type
 U(-1,1)^9 random actions (fps.py protocol), max_episode_steps=150 with in-kernel auto-reset, fp32 state.
 One "step" = one FurnitureEnv.step() on every env = 50 physics substeps + connector logic + obs + reward.
 
-    python bench.py --gpus 1 --steps 150 --warmup 2
+    python bench.py                      # SURVEY 8(d) protocol: 100 warm-up + 1000 timed steps (>= 6 full-batch resets inside)
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `value` is the whole-job aggregate; inputs are resident in HBM when the timed region
@@ -67,8 +68,8 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
     ap.add_argument("--control-type", default="impedance", help="(exploration only) a torque-level arm controller, e.g. position_orientation")
+    ap.add_argument("--obs-bf16", action="store_true", help="store the observation slab as bfloat16 (BASELINE config 2's narrow slab; state stays fp32)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
@@ -90,7 +92,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run (also with one rank)
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -104,6 +107,7 @@ def main():
     cfg = default_config()
     cfg.max_episode_steps = MAX_EPISODE_STEPS
     cfg.auto_reset = 1
+    cfg.obs_bf16 = 1 if args.obs_bf16 else 0
     if args.control_type != "impedance":
         from furniture_amd.envs import CONTROLLER_CODES
         cfg.control_type = CONTROLLER_CODES[args.control_type]
@@ -133,7 +137,7 @@ def main():
         dev = sl.sim.device
         sl.tables = ResetTableQueue(ResetTableSampler(m, ecfg, SEED, lo + g * ng, ng))  # reference RNG stream, drawn one reset ahead
         sl.sim.set_reset_tables(*sl.tables.take())
-        sl.obs = torch.zeros((ng, sl.sim.obs_dim), device=dev)
+        sl.obs = torch.zeros((ng, sl.sim.obs_dim), device=dev, dtype=torch.bfloat16 if args.obs_bf16 else torch.float32)
         sl.rew = torch.zeros(ng, device=dev)
         sl.done = torch.zeros(ng, dtype=torch.uint8, device=dev)
         sl.info = torch.zeros((ng, INFO_DIM), dtype=torch.int32, device=dev)
@@ -141,6 +145,7 @@ def main():
         sl.gen = torch.Generator(device=dev)
         sl.gen.manual_seed(SEED + rank * 64 + g)
         sl.inflight = False
+        sl.pg = dist.new_group() if distributed else None  # one RCCL communicator (= one internal stream) per slab
         sl.sim.reset(None, sl.obs)
         sl.sim.sync()
         sl.sim.set_reset_tables(*sl.tables.take())  # tables for the first auto-reset
@@ -150,9 +155,8 @@ def main():
     def wait(sl):
         if not sl.inflight:
             return
-        sl.sim.sync()
+        sl.sim.sync()  # the handle's stream: step kernel + the gather chained behind it
         sl.inflight = False
-        gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index)  # ONE RCCL all-gather per slab-step: obs | reward | done packed
         need = sl.info[:, INFO_NEEDS_TABLE]
         if bool(need.any()):  # host-side reference RNG stream for the envs that just consumed their reset table
             need = need.cpu().numpy()
@@ -166,6 +170,9 @@ def main():
         sl.act.uniform_(-1, 1, generator=sl.gen)
         torch.cuda.current_stream(dev).synchronize()
         sl.sim.step(sl.act, sl.obs, sl.rew, sl.done, sl.info)
+        # ONE RCCL all-gather per slab-step (obs | reward | done packed), enqueued on the handle's stream right behind the step
+        # kernel: no host synchronisation between the two
+        sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
         sl.inflight = True
 
     def one_step():
@@ -182,7 +189,7 @@ def main():
     drain()
     for sl in slabs:
         sl.sim.kernel_time_ms()  # reset the accumulators
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -190,13 +197,13 @@ def main():
         one_step()
     drain()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
     kt = [sl.sim.kernel_time_ms() for sl in slabs]
     klaunches = sum(k[1] for k in kt)
     kms = sum(k[0] * k[1] for k in kt) / max(1, klaunches)
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -207,12 +214,15 @@ def main():
         total_env_steps = world * n * args.steps
         value = total_env_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * ng / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        traffic, traffic_note = None, None
-        try:  # HBM bytes measured offline with rocprofv3 --pmc (bench.py cannot profile itself); see profiles/hbm_traffic.json
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                tj = json.load(f)
-            traffic = tj["bytes_per_env_step"] * ng
-            traffic_note = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), %d B per env-step x %d envs per launch" % (tj["bytes_per_env_step"], ng)
+        # What the counters say about this kernel (rocprofv3 --pmc passes of the same workload, scripts/profile_round.sh; bench.py
+        # cannot profile itself).  HBM traffic feeds the contract's roofline object; the rest says what actually binds.
+        traffic, traffic_note, pmc = None, None, {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pmc = json.load(f)
+            traffic = pmc["bytes_per_env_step"] * ng
+            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, %s), %d B per env-step x %d envs per launch"
+                            % (pmc.get("source", "profiles/"), pmc["bytes_per_env_step"], ng))
         except Exception:
             pass
         line = {
@@ -224,13 +234,26 @@ def main():
                                    "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
-                       "physics_substeps_per_s": value * 50, "obs_finite": finite, "kernel_variant": slabs[0].sim.kernel_variant,
+                       "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_env_step", "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
-                         "note": "fused 50-substep step keeps state in LDS: the kernel is VALU/LDS-latency bound, HBM fraction is ~0 by design"},
+                         "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
+                         # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
+                         # wave issues at most one instruction per ~5 cycles (scripts/dev/micro: 5.0 cycles per dependent-distance-4
+                         # v_fma at 1-2 waves per SIMD), so an env-step costs ~5 cycles x instructions + LDS waits
+                         "binding": {"bound": "per-wave instruction issue + LDS wait (not HBM, not MFMA)",
+                                     "valu_util": pmc.get("valu_issue_util"), "valu_util_def": "VALU wave-instructions per SIMD per cycle over the launch (peak ~1)",
+                                     "waves_per_simd": pmc.get("waves_per_simd"), "waves_per_simd_limit": 2,
+                                     "wait_frac": pmc.get("wait_frac"), "issue_frac": pmc.get("issue_frac"),
+                                     "insts_per_env_step": pmc.get("insts_per_env_step"), "valu_insts_per_env_step": pmc.get("valu_insts_per_env_step"),
+                                     "wave_cycles_per_env_step": pmc.get("wave_cycles_per_env_step"),
+                                     "algorithmic_flops_per_env_step": [1.5e6, 5.5e6],
+                                     "fp32_vector_peak_tflops": 157.3,
+                                     "achieved_tflops_algorithmic": [1.5e6 * value / 1e12, 5.5e6 * value / 1e12],
+                                     "source": pmc.get("source")}},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
@@ -238,7 +261,7 @@ def main():
     for sl in slabs:
         sl.tables.close()
         sl.sim.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

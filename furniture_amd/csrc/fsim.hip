@@ -75,7 +75,8 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_physics(const DM
 
 template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
-                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost) {
+                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost,
+                                                 const float *init_state, const uint8_t *init_mask) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
@@ -91,13 +92,14 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
   fs_load_cache(c);
   EnvIO io;
   io.action = action ? action + (size_t)env * cfg.dof_action : nullptr;
-  io.obs = obs ? obs + (size_t)env * cfg.obs_dim : nullptr;
+  io.obs = obs ? reinterpret_cast<float *>(reinterpret_cast<char *>(obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4)) : nullptr;
   io.reward = reward ? reward + env : nullptr;
   io.done = done ? done + env : nullptr;
   io.info = info ? info + (size_t)env * FSIM_INFO_DIM : nullptr;
   io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
   io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * c.D.narmj : nullptr;
   io.n_noise = n_noise;
+  io.init_state = (init_state && init_mask && init_mask[env]) ? init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
   io.cost = cost ? cost + env : nullptr;
   io.t0 = t_entry;
   if (do_step) env_step(c, cfg, io);
@@ -192,7 +194,7 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, EnvCfg, float *, const float *, float *, float *, uint8_t *, int *, const float *,
-                          const float *, int, const uint8_t *, int, int *, const int *, int *);
+                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *);
 struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; };
 
 struct fsim {
@@ -209,6 +211,8 @@ struct fsim {
   Layout *d_ly = nullptr;
   float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
   int *d_cost = nullptr, *d_order = nullptr; // longest-job-first scheduling (k_schedule)
+  float *d_init = nullptr;       // set_init_qpos: [n][nq + nv] state the masked envs' resets start from
+  uint8_t *d_init_mask = nullptr;
   float *d_dense = nullptr; // dense-reward tables: DC_WORDS coefficients, then nsub rows of DS_WORDS
   bool lpt = true;
   int n_noise = 0;
@@ -457,6 +461,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
             fa.numRegs, (size_t)fa.localSizeBytes, s->ly.ncon_max);
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
+  if (s->ecfg.obs_dim > 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4) { int od = s->ecfg.obs_dim; delete s; FAIL(FSIM_ENOMEM, "obs_dim %d exceeds the LDS staging area of the observation (%d words)", od, 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4); }
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
   HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout)));
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
@@ -470,7 +475,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -614,6 +619,31 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
   return FSIM_OK;
 }
 
+extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  const int n = s->n_envs, nq = s->m.nq, nv = s->m.nv, w = nq + nv;
+  if (!s->d_init) {
+    HIPCHK(hipMalloc(&s->d_init, (size_t)n * w * 4)); HIPCHK(hipMalloc(&s->d_init_mask, n));
+    HIPCHK(hipMemset(s->d_init_mask, 0, n));
+  }
+  if (!qpos) { // set_init_qpos(None)
+    if (!mask) HIPCHK(hipMemset(s->d_init_mask, 0, n));
+    else for (int e = 0; e < n; e++) if (mask[e]) HIPCHK(hipMemset(s->d_init_mask + e, 0, 1));
+    return FSIM_OK;
+  }
+  if (!qvel) FAIL(FSIM_EINVAL, "fsim_set_init_state: qvel missing");
+  std::vector<float> row(w);
+  for (int e = 0; e < n; e++) {
+    if (mask && !mask[e]) continue;
+    memcpy(row.data(), qpos + (size_t)e * nq, (size_t)nq * 4); memcpy(row.data() + nq, qvel + (size_t)e * nv, (size_t)nv * 4);
+    HIPCHK(hipMemcpy(s->d_init + (size_t)e * w, row.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->d_init_mask + e, 1, 1));
+  }
+  return FSIM_OK;
+}
+
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
   if (s->timing) timing_collect(s);
@@ -622,7 +652,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (s->timing) timing_begin(s);
   hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
-                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr);
+                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr, s->d_init, s->d_init_mask);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
@@ -835,17 +865,17 @@ extern "C" int fsim_replay_touch_scan(fsim_t *s, int n, int maxc, const int32_t 
   return FSIM_OK;
 }
 
-extern "C" int fsim_reset(fsim_t *s, const uint8_t *mask_dev, float *obs_dev) {
+extern "C" int fsim_reset(fsim_t *s, const uint8_t *mask_dev, void *obs_dev) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (!s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: call fsim_set_reset_tables first");
   if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_reset: dense_reward needs fsim_set_dense_reward first");
-  return launch_env(s, nullptr, obs_dev, nullptr, nullptr, nullptr, mask_dev, 0);
+  return launch_env(s, nullptr, static_cast<float *>(obs_dev), nullptr, nullptr, nullptr, mask_dev, 0);
 }
-extern "C" int fsim_step(fsim_t *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info) {
+extern "C" int fsim_step(fsim_t *s, const float *action, void *obs, float *reward, uint8_t *done, int32_t *info) {
   if (!s || !action) FAIL(FSIM_EINVAL, "fsim_step: null handle/action");
   if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step: auto_reset needs fsim_set_reset_tables");
   if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step: dense_reward needs fsim_set_dense_reward first");
-  return launch_env(s, action, obs, reward, done, info, nullptr, 1);
+  return launch_env(s, action, static_cast<float *>(obs), reward, done, info, nullptr, 1);
 }
 extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   if (!s || n <= 0) FAIL(FSIM_EINVAL, "fsim_set_max_episode_steps: bad arguments");

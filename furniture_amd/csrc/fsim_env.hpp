@@ -29,6 +29,7 @@ struct EnvCfg {
   const float *dense_coef, *dense_sub;
   int controller; // CK_* (fsim_ctrl.hpp): torque-level arm controller run before every physics substep, 0 = none
   int ik;         // 1: control_type "ik", 2: "ik_quaternion" (fsim_ik.hpp)
+  int obs_bf16;   // the caller's observation slab is bfloat16 (fsim_config_t::obs_bf16)
 };
 struct EnvIO {
   const float *action;
@@ -36,6 +37,7 @@ struct EnvIO {
   uint8_t *done;
   int *info;
   const float *tab_parts, *tab_noise;
+  const float *init_state; // set_init_qpos (furniture.py:315-316): [nq + nv] state this env's resets start from, or null
   int n_noise;
   int *cost;      // scheduler key written by env_step (shader cycles >> 10 of the step just taken, -1 = will time out next step)
   long long t0;   // shader clock at kernel entry
@@ -67,6 +69,7 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
   }
   e.ik = c.control_type == 7 ? 1 : (c.control_type == 8 ? 2 : 0);
+  e.obs_bf16 = c.obs_bf16 ? 1 : 0;
   if (e.ik) { // [per arm: dpos 3, rotation 3 | quaternion 4] + one grip per arm + connect (furniture_sawyer.py:52-64, furniture_baxter.py:26-37)
     e.dof_action = m.narm * (3 + (e.ik == 1 ? 3 : 4)) + m.narm + 1;
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
@@ -700,6 +703,9 @@ template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, con
   if (!io.obs) return;
   CModel &m = c.m;
   const float *L = c.L;
+  // the observation is assembled in LDS (the Hessian pair-block area: dead outside fs_hessian) and stored in one coalesced pass,
+  // as float32 or -- fsim_config_t::obs_bf16 -- as bfloat16
+  float *ob = c.L + c.ly.hP;
   if (io.info && c.lane == 0) { // the subtask of the state being observed (after an in-kernel auto-reset: the new episode's)
     io.info[FSIM_INFO_SUBTASK1] = c.I(c.ly.env)[E_SUBTASK1];
     io.info[FSIM_INFO_SUBTASK2] = c.I(c.ly.env)[E_SUBTASK2];
@@ -707,7 +713,7 @@ template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, con
   // object_ob: body xpos/xquat of every part as left by the last forward pass
   for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
     int p = i / 7, k = i % 7, b = GP(m.part_rbody)[p];
-    io.obs[i] = k < 3 ? L[c.ly.xpos + 3 * b + k] : L[c.ly.xquat + 4 * b + k - 3];
+    ob[i] = k < 3 ? L[c.ly.xpos + 3 * b + k] : L[c.ly.xquat + 4 * b + k - 3];
   }
   int base = 7 * c.D.nparts;
   // data.site_xvelp / site_xvelr in mujoco_py are jac(site) . qvel: the Jacobian of the LAST forward pass (one integration
@@ -715,14 +721,14 @@ template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, con
   if (c.D.narm) fs_body_spatial(c, c.ly.qvel);
   if (c.D.agent == 2) { // furniture_cursor.py:88-109: [cursor0 pos, cursor1 pos, selected0, selected1]
     const float *ec = L + c.ly.env + E_GROUP + c.D.nparts;
-    if (c.lane < 6) io.obs[base + c.lane] = ec[EC_XPOS + c.lane];
-    if (c.lane < 2) io.obs[base + 6 + c.lane] = reinterpret_cast<const int *>(ec)[EC_SEL + c.lane] ? 1.0f : 0.0f;
+    if (c.lane < 6) ob[base + c.lane] = ec[EC_XPOS + c.lane];
+    if (c.lane < 2) ob[base + 6 + c.lane] = reinterpret_cast<const int *>(ec)[EC_SEL + c.lane] ? 1.0f : 0.0f;
   }
   for (int arm = 0; arm < c.D.narm; arm++) {
     const int njm = c.D.narmj / c.D.narm;
     // joint_pos / joint_vel are part of robot_ob for impedance / torque only (furniture_sawyer.py:112-124)
     const int nj = (cfg.controller || cfg.ik) ? 0 : njm;
-    float *o = io.obs + base + (2 * nj + 15) * arm;
+    float *o = ob + base + (2 * nj + 15) * arm;
     for (int k = c.lane; k < nj; k += 64) {
       o[k] = L[c.ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
       o[nj + k] = L[c.ly.qvel + GP(m.arm_dofadr)[arm * njm + k]];
@@ -742,6 +748,15 @@ template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, con
       stv3(o + 2 * nj + 12, sb ? v.a : v3(0, 0, 0));
     }
   }
+  SYNC();
+  if (cfg.obs_bf16) {
+    unsigned short *o16 = reinterpret_cast<unsigned short *>(io.obs);
+    for (int i = c.lane; i < cfg.obs_dim; i += 64) {
+      const unsigned u = __float_as_uint(ob[i]);
+      o16[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); // round to nearest even (finite values; NaN stays NaN)
+    }
+  } else
+    for (int i = c.lane; i < cfg.obs_dim; i += 64) io.obs[i] = ob[i];
 }
 
 // ---------------------------------------------------------------------------------------------------- reset
@@ -810,6 +825,18 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
   if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
   SYNC();
   if (c.lane == 0) { E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; }
+  if (io.init_state) {
+    // set_init_qpos (furniture.py:1505-1519, 1568-1569, 1617-1618): set_env_state(given state) replaces placement, settling and the
+    // robot initialisation (no RNG draw is consumed); robot collision on; the reference's forward passes in between do not change
+    // qpos / qvel, the common tail below starts with one
+    if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
+    SYNC();
+    for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = io.init_state[i];
+    for (int i = c.lane; i < c.D.nv; i += 64) L[c.ly.qvel + i] = io.init_state[c.D.nq + i];
+    for (int g = c.lane; g < c.D.ncg; g += 64)
+      if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
+    SYNC();
+  } else {
   // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
   for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
     int p = i / 7, k = i % 7;
@@ -827,6 +854,7 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
     SYNC();
     if (c.D.narm > 0) env_gravity_comp(c);
     for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k, cfg.move_speed); fs_step(c); }
+  }
   }
   for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
   for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qfrcapp + i] = 0; L[c.ly.qaccws + i] = 0; }

@@ -17,19 +17,29 @@ def shard_range(rank, world_size, envs_per_rank):
     return rank * envs_per_rank, (rank + 1) * envs_per_rank
 
 
-def gather_observations(obs, reward, done, tag=0):
+def gather_observations(obs, reward, done, tag=0, stream=None, group=None):
     """All ranks contribute [n, d] / [n] / [n]; every rank gets the [world*n, ...] tensors in global env order.  The returned
-    tensors are views of a persistent receive buffer (one per ``tag``): valid until the next call with the same tag and shapes."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    tensors are views of a persistent receive buffer (one per ``tag``): valid until the next call with the same tag and shapes.
+
+    stream: the HIP stream the producing fsim_step was enqueued on (``FSim.torch_stream``).  The packing copies and the
+    collective are then enqueued BEHIND the step kernel on that stream -- no host synchronisation between step and gather
+    (SURVEY.md section 8e); the caller synchronises the stream once, when it needs the result.  group: the process group to
+    gather over -- RCCL runs all collectives of one communicator on one internal stream, so env slabs that are stepped
+    pipelined on separate streams need a communicator each (``dist.new_group()``), or slab B's gather queues behind slab A's
+    step kernel.  Without a process group (single process) the inputs are returned as they are."""
+    if not (dist.is_available() and dist.is_initialized()):
         return obs, reward, done
-    w = dist.get_world_size()
+    if stream is not None and obs.is_cuda:
+        with torch.cuda.stream(stream):
+            return gather_observations(obs, reward, done, tag=tag, group=group)
+    w = dist.get_world_size(group)
     n, d = obs.shape
     if obs.dtype != torch.float32 or reward.dtype != torch.float32:
         out = []
         for t in (obs, reward, done):  # generic path: one collective per field
             t = t.contiguous()
             g = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(g, t)
+            dist.all_gather_into_tensor(g, t, group=group)
             out.append(g)
         return tuple(out)
     key = (obs.device, n, d, w, tag)
@@ -40,5 +50,5 @@ def gather_observations(obs, reward, done, tag=0):
     send[:, :d] = obs
     send[:, d] = reward
     send[:, d + 1] = done
-    dist.all_gather_into_tensor(recv, send)
+    dist.all_gather_into_tensor(recv, send, group=group)
     return recv[:, :d], recv[:, d], recv[:, d + 1].to(done.dtype)

@@ -22,7 +22,8 @@ from . import transform_utils as T
 from .mjcf.model import load_compiled
 from .dense import DENSE_COEF_DEFAULTS, pack_dense
 from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DENSE_PHASE, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
-                  INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUBTASK1, INFO_SUCCESS, N_NOISE, default_config)
+                  INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUBTASK1, INFO_SUCCESS, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F,
+                  INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F, N_NOISE, default_config)
 
 # furniture/config/furniture.py defaults that matter on the hot path (file:line in the reference)
 DEFAULTS = dict(
@@ -85,6 +86,7 @@ class ResetTableSampler:
         idx = [first_env_index + i for i in range(n_envs)] if env_indices is None else [int(i) for i in env_indices]
         assert len(idx) == n_envs
         self.rngs = [np.random.RandomState(seed + i) for i in idx]
+        self.hist = [[] for _ in idx]  # RNG states before each of the last draws (rng_handover rolls unconsumed draws back)
         self.narm = len(model.arm_qposadr)
 
     def _placement(self, rng):
@@ -122,6 +124,7 @@ class ResetTableSampler:
         for i, rng in enumerate(self.rngs):
             if mask is not None and not mask[i]:
                 continue
+            self.hist[i] = self.hist[i][-2:] + [rng.get_state()]
             parts[i] = self._placement(rng).reshape(-1)
             if self.narm:
                 a = self.cfg.agent_xyz_rand
@@ -171,9 +174,10 @@ _AGENT_OF = {"FurnitureSawyerEnv": "Sawyer", "FurnitureBaxterEnv": "Baxter", "Fu
 class FurnitureBatchEnv:
     """n_envs copies of FurnitureEnv on one GPU.  Observations / rewards / dones are torch tensors on the device."""
 
-    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, dense=False, env_indices=None, **kw):
+    def __init__(self, agent, num_envs, config=None, device=0, first_env_index=0, auto_reset=True, dense=False, env_indices=None, obs_bf16=False, **kw):
         """dense=True: FurnitureSawyerDenseRewardEnv semantics (furniture_sawyer_dense.py) -- the config then carries the
-        config/furniture_sawyer_dense.py overrides and, optionally, any of its reward coefficients."""
+        config/furniture_sawyer_dense.py overrides and, optionally, any of its reward coefficients.
+        obs_bf16=True: the observation slab is stored (and returned) as bfloat16 -- state and arithmetic stay float32."""
         cfg = config if config is not None else make_config(**(DENSE_OVERRIDES if dense else {}))
         for k, v in kw.items():
             setattr(cfg, k, v)
@@ -230,6 +234,7 @@ class FurnitureBatchEnv:
         if getattr(cfg, "solver_tolerance", None) is not None:
             c.solver_tolerance = float(cfg.solver_tolerance)
         c.dense_reward = 1 if dense else 0
+        c.obs_bf16 = 1 if obs_bf16 else 0
         self.dense = bool(dense)
         self.sim = FSim(self.model, num_envs, device=device, config=c)
         if dense:
@@ -239,7 +244,7 @@ class FurnitureBatchEnv:
         self.num_envs = num_envs
         torch = self.sim.torch
         dev = self.sim.device
-        self._obs = torch.zeros((num_envs, self.sim.obs_dim), dtype=torch.float32, device=dev)
+        self._obs = torch.zeros((num_envs, self.sim.obs_dim), dtype=torch.bfloat16 if obs_bf16 else torch.float32, device=dev)
         self._rew = torch.zeros(num_envs, dtype=torch.float32, device=dev)
         self._done = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
         self._info = torch.zeros((num_envs, INFO_DIM), dtype=torch.int32, device=dev)
@@ -311,7 +316,23 @@ class FurnitureBatchEnv:
         else:
             self._tables_fresh[np.asarray(mask, dtype=bool)] = True
 
+    def set_init_qpos(self, init_qpos):
+        """furniture.py:315-316: every following reset starts from this {qpos, qvel} state (get_env_state's format; [dim] or
+        [n_envs, dim]) instead of a sampled placement; None switches back.  Such resets take no draw from the RNG stream."""
+        self._init_qpos = init_qpos
+        if init_qpos is None:
+            self.sim.set_init_state(None)
+        else:
+            as_np = lambda v: v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            self.sim.set_init_state(as_np(init_qpos["qpos"]), as_np(init_qpos["qvel"]))
+
     def reset(self):
+        if getattr(self, "_init_qpos", None) is not None:
+            if not self._tables_fresh.all():  # (the kernel insists on tables being present; these are not consumed)
+                self._refill(None if not self._tables_fresh.any() else ~self._tables_fresh)
+            self.sim.reset(None, self._obs)
+            self.sim.sync()
+            return self._split(self._obs)
         # one table = one pass of the reference's reset-time RNG stream: a table that is on the device but was never
         # consumed (uploaded for an auto-reset that did not happen yet) IS the next draw of that env and is used as is
         stale = ~self._tables_fresh
@@ -323,6 +344,21 @@ class FurnitureBatchEnv:
         if self._auto_reset:
             self._refill()  # tables for the first auto-reset
         return self._split(self._obs)
+
+    def rng_handover(self):
+        """The per-env RandomState objects positioned at the first draw no reset has consumed yet (tables drawn ahead -- one in
+        the host queue, possibly one on the device -- are rolled back): what a rebuilt env (reset(furniture_id)) continues from,
+        as the reference keeps ONE self._rng across furniture switches (furniture.py:72, 318-334)."""
+        q = getattr(self, "_table_queue", None)
+        if q is not None:
+            q.close()
+            self._table_queue = None
+        for i, rng in enumerate(self._sampler.rngs):
+            back = (1 if q is not None else 0) + int(self._tables_fresh[i])
+            hist = self._sampler.hist[i]
+            if back:
+                rng.set_state(hist[-back])
+        return self._sampler.rngs
 
     def step_async(self, actions):
         torch = self.sim.torch
@@ -349,6 +385,9 @@ class FurnitureBatchEnv:
                      connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
         if self.dense:
             infos["phase_i"] = info[:, INFO_DENSE_PHASE]  # phase + 8 * subtask (furniture_sawyer_dense.py:347)
+        else:  # the reward terms _compute_reward reports (furniture.py:535-540); float bits in the int32 info block
+            fl = info[:, INFO_SUCCESS_REWARD_F:INFO_CTRL_PENALTY_F + 1].view(self.sim.torch.float32)
+            infos.update(success_reward=fl[:, 0], touch_reward=fl[:, 1], pick_reward=fl[:, 2], ctrl_penalty=fl[:, 3])
         return self._split(self._obs, info[:, INFO_SUBTASK1:INFO_SUBTASK1 + 2]), self._rew, self._done.bool(), infos
 
     def step(self, actions):
@@ -423,15 +462,25 @@ class _SingleEnv:
         raise NotImplementedError("set_subtask (pre-assembled starts, furniture.py:204-207) is not part of the accelerated reset")
 
     def set_init_qpos(self, init_qpos):
-        raise NotImplementedError("set_init_qpos (furniture.py:315-316, applied inside _reset) is not part of the accelerated reset; "
-                                  "use set_env_state after reset()")
+        """furniture.py:315-316: {qpos, qvel} as returned by get_env_state(), or None"""
+        self._b.set_init_qpos(init_qpos)
 
     def _np(self, ob):
         return OrderedDict((k, v[0].double().cpu().numpy()) for k, v in ob.items())
 
     def reset(self, furniture_id=None, background=None):
         if furniture_id is not None and self._b.furniture_name != furniture_names()[furniture_id]:
-            raise NotImplementedError("changing furniture_id on reset: construct a new env instead")
+            # furniture.py:318-334: a new furniture id rebuilds the model (here: a new handle for the other compiled model); the
+            # env's RNG stream carries on where the old furniture left it
+            old = self._b
+            cfg = old.config
+            cfg.furniture_id, cfg.furniture_name = int(furniture_id), None
+            rngs = old.rng_handover()
+            dev = old.sim.device.index or 0
+            old.close()
+            self._b = FurnitureBatchEnv(self._agent, 1, config=cfg, device=dev, auto_reset=False, dense=self._dense)
+            self._b._sampler.rngs = rngs
+            self._b._sampler.hist = [[] for _ in rngs]
         return self._np(self._b.reset())
 
     def step(self, action):
@@ -441,7 +490,7 @@ class _SingleEnv:
             action = np.concatenate([action[k] for k in self.action_space.spaces.keys()])
         # single-env semantics: no auto-reset inside step (the caller resets, as with the reference's gym.Env)
         ob, rew, done, info = self._b.step(np.asarray(action, dtype=np.float32)[None])
-        return self._np(ob), float(rew[0]), bool(done[0]), {k: int(v[0]) for k, v in info.items()}
+        return self._np(ob), float(rew[0]), bool(done[0]), {k: (float(v[0]) if v.dtype.is_floating_point else int(v[0])) for k, v in info.items()}
 
     def get_env_state(self):
         s = self._b.get_env_state()

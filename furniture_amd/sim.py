@@ -40,7 +40,7 @@ class FsimConfig(ctypes.Structure):
         ("touch_reward", ctypes.c_float), ("pick_reward", ctypes.c_float),
         ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
         ("move_speed", ctypes.c_float), ("rotate_speed", ctypes.c_float), ("cursor_boundary", ctypes.c_float),
-        ("dense_reward", ctypes.c_int32),
+        ("dense_reward", ctypes.c_int32), ("obs_bf16", ctypes.c_int32),
     ]
 
 
@@ -100,6 +100,7 @@ def lib():
         L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_set_init_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
@@ -115,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan",
+    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state",
 ]
 
 
@@ -184,6 +185,11 @@ class FSim:
         self.nq, self.nv, self.nu, self.dof_action, self.obs_dim, self.info_dim, self.stride = [x.value for x in d]
         self.max_contacts = lib().fsim_max_contacts(self._h)
         self.kernel_variant = lib().fsim_kernel_variant(self._h).decode()
+        st = ctypes.c_void_p()
+        self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
+        # the handle's HIP stream as a torch stream: work enqueued under `with torch.cuda.stream(sim.torch_stream)` (an RCCL
+        # collective, a copy) runs behind the step kernel without a host synchronisation
+        self.torch_stream = torch.cuda.ExternalStream(st.value, device=self.device)
         self.env_block_words = lib().fsim_env_block_words(self._h)
         st = ctypes.c_void_p()
         self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
@@ -267,6 +273,16 @@ class FSim:
         mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self._chk(lib().fsim_set_reset_tables(self._h, None if mk is None else mk.ctypes.data, pq.ctypes.data,
                                               None if rn is None else rn.ctypes.data, n_noise))
+
+    def set_init_state(self, qpos=None, qvel=None, mask=None):
+        """set_init_qpos for the masked envs (None = all); qpos None clears it (include/fsim.h: fsim_set_init_state)"""
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+        if qpos is None:
+            self._chk(lib().fsim_set_init_state(self._h, None if mk is None else mk.ctypes.data, None, None))
+            return
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(qpos, dtype=np.float32).reshape(-1, self.nq), (self.n_envs, self.nq)))
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(qvel, dtype=np.float32).reshape(-1, self.nv), (self.n_envs, self.nv)))
+        self._chk(lib().fsim_set_init_state(self._h, None if mk is None else mk.ctypes.data, q.ctypes.data, v.ctypes.data))
 
     def reset(self, mask=None, obs=None):
         self._chk(lib().fsim_reset(self._h, None if mask is None else mask.data_ptr(), None if obs is None else obs.data_ptr()))

@@ -60,6 +60,9 @@ typedef struct fsim_config {
   int32_t dense_reward;       /* 1: FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py): the 8-phase reward replaces the sparse
                                  one; the tables must be uploaded with fsim_set_dense_reward before the first reset.  Sawyer only; control_type 0
                                  (impedance, the reference's dense config) or 7 / 8 (ik / ik_quaternion). */
+  int32_t obs_bf16;           /* 1: the observation slab handed to fsim_step / fsim_reset is bfloat16 [n, obs_dim] (round to nearest even) --
+                                 half the bytes of the per-step all-gather to the learner (BASELINE config 2).  State, reward and the whole
+                                 computation stay float32; only the store of the finished observation is narrowed. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -124,12 +127,19 @@ int fsim_env_block_words(const fsim_t *);
 int fsim_set_reset_tables(fsim_t *, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise);
 
 /* FurnitureEnv.reset() on the masked envs (device uint8 mask or NULL = all); writes obs if non-NULL. */
-int fsim_reset(fsim_t *, const uint8_t *mask_dev, float *obs_dev);
+/* FurnitureEnv.set_init_qpos (furniture.py:315-316; applied inside _reset, :1505-1519, 1568, 1617): the resets of the masked envs
+ * (host uint8 [n], NULL = all) start from the given state -- qpos [n][nq], qvel [n][nv], host float32 (the format of
+ * get_env_state) -- instead of sampling a placement, settling the parts and initialising the robot; no reset table is consumed.
+ * qpos = NULL: back to sampled resets (set_init_qpos(None)). */
+int fsim_set_init_state(fsim_t *, const uint8_t *mask, const float *qpos, const float *qvel);
+
+int fsim_reset(fsim_t *, const uint8_t *mask_dev, void *obs_dev /* float32 | bfloat16, as fsim_step */);
 
 /* FurnitureEnv.step(action) on every env.  action [n, dof_action] float32, obs [n, obs_dim] float32,
  * reward [n] float32, done [n] uint8, info [n, info_dim] int32/float bits -- all device pointers.
  * info columns: see FSIM_INFO_* below. */
-int fsim_step(fsim_t *, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev, int32_t *info_dev);
+int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bfloat16 with cfg.obs_bf16 */, float *reward_dev, uint8_t *done_dev,
+              int32_t *info_dev);
 
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);

@@ -207,6 +207,10 @@ class FurnitureEnvOracle:
             for k, x in enumerate((-0.2, 0.2)):
                 self.sim.model.body_pos[self.m.cursor_bodyid[k]] = [x, 0.0, self.cfg.move_speed / 2]
 
+    def set_init_qpos(self, init_qpos):
+        """F.py:315-316: {qpos, qvel} (get_env_state's format) or None"""
+        self._init_qpos = init_qpos
+
     def reset(self):
         m, sim = self.m, self.sim
         self.reset_draws = {"noise": []}
@@ -235,25 +239,39 @@ class FurnitureEnvOracle:
         self._picked = [False] * self.nparts
         sim.model.eq_active[:] = 0
         sim.model.eq_data[:] = m.eq_data0
-        # placement (init_pos is sampled on first reset and re-sampled afterwards: fix_init=False)
-        pos, quat = sample_placement(self._rng, m, self.cfg)
-        self.reset_draws["part_qpos"] = np.array([np.concatenate([pos[i], quat[i]]) for i in range(self.nparts)])
-        for i in range(self.nparts):
-            self._set_part_qpos(i, pos[i], quat[i])
-        self._settle()
-        if self._has_recipe:
+        init = getattr(self, "_init_qpos", None)
+        if init is not None:
+            # F.py:1505-1519, 1568-1569, 1617-1618 (set_init_qpos): the given state replaces placement, settling and the robot
+            # initialisation -- no draw is taken from the RNG stream; set_env_state + forward, twice, then the common tail
+            for _ in range(2):
+                for i in range(self.nparts):
+                    self._stop_object(i, gravity=0)
+                sim.data.qpos[:] = init["qpos"]
+                sim.data.qvel[:] = init["qvel"]
+                sim.data.ctrl[:] = 0
+                sim.model.geom_contype[robot] = ct0[robot]
+                sim.model.geom_conaffinity[robot] = ca0[robot]
+                sim.forward()
+        else:
+            # placement (init_pos is sampled on first reset and re-sampled afterwards: fix_init=False)
+            pos, quat = sample_placement(self._rng, m, self.cfg)
+            self.reset_draws["part_qpos"] = np.array([np.concatenate([pos[i], quat[i]]) for i in range(self.nparts)])
+            for i in range(self.nparts):
+                self._set_part_qpos(i, pos[i], quat[i])
             self._settle()
-        if self.agent != "Cursor":
-            self._gravity_comp()
-        self._initialize_robot_pos()
-        self._fs()
-        sim.model.geom_contype[robot] = ct0[robot]
-        sim.model.geom_conaffinity[robot] = ca0[robot]
-        if self.agent != "Cursor":
-            self._gravity_comp()
-        for _ in range(100):
+            if self._has_recipe:
+                self._settle()
+            if self.agent != "Cursor":
+                self._gravity_comp()
             self._initialize_robot_pos()
             self._fs()
+            sim.model.geom_contype[robot] = ct0[robot]
+            sim.model.geom_conaffinity[robot] = ca0[robot]
+            if self.agent != "Cursor":
+                self._gravity_comp()
+            for _ in range(100):
+                self._initialize_robot_pos()
+                self._fs()
         sim.data.ctrl[:] = 0
         sim.data.qfrc_applied[:] = 0
         sim.data.xfrc_applied[:] = 0

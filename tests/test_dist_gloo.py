@@ -57,3 +57,48 @@ def test_two_process_gather():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def _env_worker(rank, world, port, q):
+    """real env observations: the CPU oracle env stands in for the device (same seeding rule: global env i <- seed + i)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Sawyer", "table_lack_0825")
+    per = 2
+
+    def run(i):
+        env = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=20, seed=123 + i))
+        env.reset()
+        ob, rew, done, _ = env.step(np.random.RandomState(1000 + i).uniform(-1, 1, 9))
+        return env.flat_obs(ob), rew, done
+
+    lo, hi = shard_range(rank, world, per)
+    mine = [run(i) for i in range(lo, hi)]
+    obs = torch.as_tensor(np.stack([x[0] for x in mine])).float()
+    rew = torch.as_tensor([x[1] for x in mine]).float()
+    done = torch.as_tensor([int(x[2]) for x in mine]).to(torch.uint8)
+    g_obs, g_rew, g_done = gather_observations(obs, rew, done)
+    if rank == 0:  # the one-process batch of the same global envs: bit-identical per env
+        whole = [run(i) for i in range(world * per)]
+        assert np.array_equal(g_obs.numpy(), np.stack([x[0] for x in whole]).astype(np.float32))
+        assert np.array_equal(g_rew.numpy(), np.asarray([x[1] for x in whole], dtype=np.float32))
+        assert g_done.tolist() == [int(x[2]) for x in whole]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_one_rank_and_two_rank_batches_are_identical_per_env():
+    """SURVEY 8(e): env i -> rank i // envs_per_rank, seed 123 + i, so the gathered observation / reward / done slab does not depend
+    on the number of ranks: 2 ranks x 2 oracle envs (reset + one random-action step) against the same 4 envs in one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_env_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(2)) == [0, 1]

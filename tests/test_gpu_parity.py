@@ -562,3 +562,56 @@ def test_unstable_simulation_fails_the_step_and_resets(sawyer_lack, auto_reset):
     sim.sync()
     assert torch.isfinite(obs).all() and list(done.cpu().numpy()) == [0, 0, 0, 0] and list(info[:, INFO_FAIL].cpu().numpy()) == [0, 0, 0, 0]
     sim.close()
+
+
+def test_set_init_qpos_resets_from_the_given_state(sawyer_lack):
+    """set_init_qpos (furniture.py:315-316, used inside _reset :1505-1519, 1568, 1617): the reset starts from a given {qpos, qvel}
+    instead of a sampled placement and consumes no RNG draw; set_init_qpos(None) goes back to the sampled stream where it was."""
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50, seed=77)
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=77, solver_tolerance=1e-10))
+    env = FurnitureSawyerEnv(make_config(**kw))
+    o0 = orc.flat_obs(orc.reset())
+    d0 = env.reset()
+    assert np.abs(np.concatenate([d0["object_ob"], d0["robot_ob"]]) - o0).max() < 2e-4
+    # a state to start from: the oracle's post-reset state with two parts moved and the arm bent
+    init = dict(qpos=orc.sim.data.qpos.copy(), qvel=np.zeros(sawyer_lack.nv))
+    init["qpos"][sawyer_lack.part_qposadr[1]:sawyer_lack.part_qposadr[1] + 2] += [0.07, -0.05]
+    init["qpos"][sawyer_lack.part_qposadr[3] + 2] += 0.05
+    init["qpos"][sawyer_lack.arm_qposadr[1]] -= 0.2
+    orc.set_init_qpos(init)
+    env.set_init_qpos(init)
+    for _ in range(2):  # the same state every time
+        o1 = orc.flat_obs(orc.reset())
+        d1 = env.reset()
+        assert np.abs(np.concatenate([d1["object_ob"], d1["robot_ob"]]) - o1).max() < 2e-4
+    assert np.abs(o1[:35] - o0[:35]).max() > 0.03
+    orc.set_init_qpos(None)
+    env.set_init_qpos(None)
+    o2 = orc.flat_obs(orc.reset())  # the second draw of the stream (the init-state resets took none)
+    d2 = env.reset()
+    assert np.abs(np.concatenate([d2["object_ob"], d2["robot_ob"]]) - o2).max() < 2e-4
+    env.close()
+
+
+def test_reset_with_another_furniture_id_swaps_the_model_and_keeps_the_rng_stream(sawyer_lack):
+    """reset(furniture_id) (furniture.py:318-334): the env rebuilds for the other furniture; the reset-time RNG stream is the
+    env's one self._rng and carries on across the switch."""
+    from furniture_amd.envs import FurnitureSawyerEnv, furniture_names, make_config
+    names = furniture_names()
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50, seed=9)
+    env = FurnitureSawyerEnv(make_config(**kw))
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=9, solver_tolerance=1e-10))
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert np.abs(np.concatenate([d["object_ob"], d["robot_ob"]]) - o).max() < 2e-4
+    m2 = load_compiled("Sawyer", "swivel_chair_0700")
+    orc2 = FurnitureEnvOracle(m2, OracleConfig(max_episode_steps=50, seed=9, solver_tolerance=1e-10))
+    orc2._rng = orc._rng  # one stream
+    o2 = orc2.flat_obs(orc2.reset())
+    d2 = env.reset(furniture_id=names.index("swivel_chair_0700"))
+    assert d2["object_ob"].shape == (7 * m2.nparts,)
+    assert np.abs(np.concatenate([d2["object_ob"], d2["robot_ob"]]) - o2).max() < 2e-4
+    ob, rew, done, info = env.step(np.zeros(9, dtype=np.float32))
+    assert np.isfinite(ob["robot_ob"]).all() and "touch_reward" in info and info["ctrl_penalty"] == 0.0
+    env.close()

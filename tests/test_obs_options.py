@@ -68,3 +68,27 @@ def test_unsupported_reference_options_fail_loudly(flag):
     with pytest.raises(NotImplementedError, match=flag):
         FurnitureBatchEnv("Sawyer", 1, config=make_config(unity=False, record_vid=False, control_type="impedance",
                                                           furniture_name="table_lack_0825", **{flag: True}))
+
+
+@pytest.mark.gpu
+def test_bf16_observation_slab_is_the_rounded_f32_one():
+    """fsim_config_t.obs_bf16 (BASELINE config 2's narrow observation slab; SURVEY 8b `void* obs f32|bf16`): same state, same
+    arithmetic, the finished observation stored as bfloat16 with round-to-nearest-even -- i.e. exactly torch's f32 -> bf16 cast
+    of the float32 slab, after a reset and after steps; reward / done are unaffected."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=150, seed=5)
+    a = FurnitureBatchEnv("Sawyer", 16, config=make_config(**kw))
+    b = FurnitureBatchEnv("Sawyer", 16, config=make_config(**kw), obs_bf16=True)
+    oa, ob = a.reset(), b.reset()
+    assert ob["object_ob"].dtype == torch.bfloat16 and ob["robot_ob"].shape == oa["robot_ob"].shape
+    rng = np.random.RandomState(0)
+    for t in range(4):
+        for k in oa:
+            assert torch.equal(oa[k].to(torch.bfloat16), ob[k]), (t, k)
+        act = rng.uniform(-1, 1, (16, 9)).astype(np.float32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+    a.close()
+    b.close()
