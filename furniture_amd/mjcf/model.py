@@ -308,7 +308,10 @@ def build_model(agent, furniture_name, control_type="impedance", assets_root=Non
         A["ctrl_bias"], A["ctrl_weight"] = np.zeros(0), np.zeros(0)
 
     from .reduce import reduce_model
-    A.update(reduce_model(A))
+    A["geom_names_list"] = list(m.geom_names)  # (names for reduce_model's diagnostics; not stored)
+    red = reduce_model(A)
+    del A["geom_names_list"]
+    A.update(red)
     A["flags"] = np.array([1 if info["recipe_path"] is not None else 0], dtype=np.int32)
 
     ndof_action = {"Sawyer": 9, "Baxter": 17, "Cursor": 15}[agent]

@@ -88,3 +88,16 @@ def test_shipped_tables_match_fresh_compile(have_reference):
     assert set(fresh.arrays) == set(shipped.arrays)
     for k in fresh.arrays:
         assert np.array_equal(np.asarray(fresh.arrays[k]), np.asarray(shipped.arrays[k])), k
+
+
+def test_unsupported_collider_pairs_fail_the_compilation(have_reference, monkeypatch):
+    """A primitive pair without a narrow-phase routine (Baxter's pedestal capsule, robots/baxter/robot.xml:61) is either waived BY
+    NAME with a stated reason (reduce.WAIVED_COLLIDERS) or fails the model compilation -- never dropped silently."""
+    if not have_reference:
+        pytest.skip("needs the reference's MJCF assets")
+    from furniture_amd.mjcf import reduce
+    from furniture_amd.mjcf.model import build_model
+    build_model("Baxter", "desk_mikael_1064")  # waived by name: compiles
+    monkeypatch.setattr(reduce, "WAIVED_COLLIDERS", set())
+    with pytest.raises(NotImplementedError, match="pedestal_2_collision"):
+        build_model("Baxter", "desk_mikael_1064")
