@@ -672,3 +672,5 @@ void osim_full_M(osim_t *s, double *M) { memcpy(M, s->M, sizeof(double) * s->m.n
 void osim_set_solver(osim_t *s, int it, double tol) { s->solver_iters = it; s->solver_tol = tol; }
 void osim_set_solver_kind(osim_t *s, int kind) { s->solver_kind = kind; }
 int osim_last_solver_iters(osim_t *s) { return s->last_iters; }
+/* signed distance of listed contact i (< 0: penetration), as data.contact[i].dist */
+double osim_contact_dist(osim_t *s, int i) { return (i >= 0 && i < s->ncon) ? s->contact[i].dist : 0.0; }

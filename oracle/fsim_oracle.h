@@ -44,6 +44,7 @@ void osim_full_M(osim_t *, double *M_nvxnv);
 /* solver knobs: iterations, tolerance (<=0: fixed iterations), order (0 canonical) */
 void osim_set_solver(osim_t *, int iterations, double tolerance);
 int osim_last_solver_iters(osim_t *);
+double osim_contact_dist(osim_t *, int i);
 void osim_set_solver_kind(osim_t *, int kind); /* 0 = PGS (dual), 1 = Newton (primal, MuJoCo default) */
 
 #ifdef __cplusplus

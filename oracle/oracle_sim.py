@@ -48,6 +48,8 @@ def lib():
         L.osim_set_solver_kind.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.osim_last_solver_iters.argtypes = [ctypes.c_void_p]
         L.osim_last_solver_iters.restype = ctypes.c_int
+        L.osim_contact_dist.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.osim_contact_dist.restype = ctypes.c_double
         _LIB = L
     return _LIB
 
@@ -126,6 +128,10 @@ class OracleSim:
     def contacts(self):
         n = self.ncon
         return list(zip(self._cg1[:n].tolist(), self._cg2[:n].tolist()))
+
+    def contact_dists(self):
+        """data.contact[i].dist of the listed contacts (< 0: penetration)"""
+        return [lib().osim_contact_dist(self._h, i) for i in range(self.ncon)]
 
     def site_vel(self, site_id):
         """data.site_xvelp[site], data.site_xvelr[site] as mujoco_py computes them: jac(site) . qvel, i.e. the Jacobian
