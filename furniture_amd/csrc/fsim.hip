@@ -291,6 +291,7 @@ static int build_model(fsim *s) {
   if (m.nv > 64) FAIL(FSIM_ENOMEM, "nv=%d > 64: the lane-per-row Newton factorisation supports at most 64 dofs", m.nv);
   if (m.nr > 31) FAIL(FSIM_ENOMEM, "more than 31 moving bodies");
   if (m.ncp > 65535) FAIL(FSIM_ENOMEM, "too many candidate pairs");
+  if (m.ncg > 255) FAIL(FSIM_ENOMEM, "more than 255 colliding geoms (broadphase records hold 8-bit geom indices)");
   LI(r_parent, "r_parent"); LI(r_jtype, "r_jtype"); LI(r_qposadr, "r_qposadr"); LI(r_dofadr, "r_dofadr"); LI(r_dofnum, "r_dofnum");
   LI(r_depth, "r_depth"); LI(r_tree, "r_tree"); LI(r_chainadr, "r_chainadr"); LI(r_chainlen, "r_chainlen"); LI(r_ancmask, "r_ancmask");
   LF(r_pos, "r_pos"); LF(r_quat, "r_quat"); LF(r_jaxis, "r_jaxis"); LF(r_jpos, "r_jpos"); LF(r_mass, "r_mass"); LF(r_ipos, "r_ipos");
@@ -323,6 +324,15 @@ static int build_model(fsim *s) {
       for (int k = 0; k < 3; k++) { r[8 + k] = sz_[3 * g1 + k]; r[12 + k] = sz_[3 * g2 + k]; }
     }
     ar.add(&s->m.pair_rec, rec);
+    std::vector<int> bp((size_t)2 * std::max(m.ncp, 1), 0);
+    for (int p = 0; p < m.ncp; p++) {
+      int g1 = cp_[3 * p], g2 = cp_[3 * p + 1];
+      const bool plane = ty_[g1] == GT_PLANE;
+      const float margin = std::max(mg_[g1], mg_[g2]), bound = plane ? rb_[g2] + margin : rb_[g1] + rb_[g2] + margin;
+      bp[2 * p] = g1 | (g2 << 8) | ((plane ? 1 : 0) << 16);
+      memcpy(&bp[2 * p + 1], &bound, 4);
+    }
+    ar.add(&s->m.pair_bp, bp);
   }
   LI(s_body, "s_body"); LF(s_pos, "s_pos"); LF(s_quat, "s_quat");
   {

@@ -529,30 +529,29 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
   const int capA = FSIM_CONW * c.ly.ncon_max;
   const int *ctype = c.I(c.ly.contype), *caff = c.I(c.ly.conaff);
   int nA = 0;
-  for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
-    int p = p0 + c.lane;
-    bool pass = false;
-    if (p < c.D.ncp) {
-      // one 64-byte record per pair (g1 g2 pt types | margin gap r1 r2 | size1 | size2): no dependent table lookups
-      const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
-      const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255;
-      if ((ctype[g1] & caff[g2]) || (ctype[g2] & caff[g1])) {
-        const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
-        const float margin = q1.x, r1 = q1.z, r2 = q1.w;
-        V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
-        if (t1 == GT_PLANE) {
-          V3 n = v3(L[c.ly.gmat + 9 * g1 + 2], L[c.ly.gmat + 9 * g1 + 5], L[c.ly.gmat + 9 * g1 + 8]);
-          pass = dot(d, n) <= r2 + margin;
-        } else {
-          float bound = r1 + r2 + margin;
-          pass = dot(d, d) <= bound * bound;
-        }
-      }
+  {
+    // stage 1 is latency, not arithmetic: per pass ONE 8-byte record per lane (fetched a pass ahead) and ONE batch of LDS reads
+    // issued unconditionally (masks, both centres, the plane normal) -- no load waits behind a branch
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const int last = c.D.ncp - 1;
+    i2_t rec = GPC<i2_t>(m.pair_bp)[min(c.lane, last)];
+    for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
+      const int p = p0 + c.lane;
+      const i2_t cur = rec;
+      if (p0 + 64 < c.D.ncp) rec = GPC<i2_t>(m.pair_bp)[min(p + 64, last)];
+      const int g1 = cur.x & 255, g2 = (cur.x >> 8) & 255;
+      const bool plane = (cur.x >> 16) & 1;
+      const float bound = __int_as_float(cur.y);
+      const int ct1 = ctype[g1], ca1 = caff[g1], ct2 = ctype[g2], ca2 = caff[g2];
+      const V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
+      const V3 n = v3(L[c.ly.gmat + 9 * g1 + 2], L[c.ly.gmat + 9 * g1 + 5], L[c.ly.gmat + 9 * g1 + 8]);
+      const bool near = plane ? dot(d, n) <= bound : dot(d, d) <= bound * bound;
+      const bool pass = p <= last && ((ct1 & ca2) | (ct2 & ca1)) != 0 && near;
+      unsigned long long mask = __ballot(pass);
+      int idx = nA + __popcll(mask & ((1ull << c.lane) - 1ull));
+      if (pass && idx < capA) listA[idx] = p;
+      nA += __popcll(mask);
     }
-    unsigned long long mask = __ballot(pass);
-    int idx = nA + __popcll(mask & ((1ull << c.lane) - 1ull));
-    if (pass && idx < capA) listA[idx] = p;
-    nA += __popcll(mask);
   }
   if (nA > capA) { nA = capA; if (c.lane == 0) scal[SC_OVERFLOW] |= 1; }
   SYNC();
@@ -561,37 +560,33 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
     const int i = i0 + c.lane;
     bool pass = false;
     int p = 0;
-    if (i < nA) {
-      p = listA[i];
+    {
+      // the whole 64-byte pair record and both geom poses are fetched up front (one global + one LDS round trip for the pass)
+      p = listA[min(i, max(nA - 1, 0))];
       const i4_t q0 = GPC<i4_t>(m.pair_rec)[4 * p];
+      const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1], q2 = GPC<f4_t>(m.pair_rec)[4 * p + 2], q3 = GPC<f4_t>(m.pair_rec)[4 * p + 3];
       const int g1 = q0.x, g2 = q0.y, t1 = q0.w & 255, t2 = q0.w >> 8;
-      pass = true;
+      const float margin = q1.x, r1 = q1.z, r2 = q1.w;
+      const V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
+      const M3 Ra = ldm3(L + c.ly.gmat + 9 * g1), Rb = ldm3(L + c.ly.gmat + 9 * g2);
+      pass = i < nA;
       // tighter test for flat / long shapes (a 0.64 x 0.24 x 0.04 table top has a 0.34 m bounding sphere): the distance from
       // the OTHER geom's centre to this box / cylinder (exact point-solid distance) must be within the other geom's
       // bounding radius.  Conservative: never rejects a pair that can touch.
-      if (t1 != GT_PLANE && (t1 == GT_BOX || t1 == GT_CYLINDER || t2 == GT_BOX || t2 == GT_CYLINDER)) {
-        const f4_t q1 = GPC<f4_t>(m.pair_rec)[4 * p + 1];
-        const float margin = q1.x, r1 = q1.z, r2 = q1.w;
-        V3 d = ldv3(L + c.ly.gpos + 3 * g2) - ldv3(L + c.ly.gpos + 3 * g1);
+      if (t1 != GT_PLANE) {
 #pragma unroll
         for (int side = 0; side < 2; side++) {
-          int gs = side ? g1 : g2, ty = side ? t1 : t2;       // solid tested
-          float ro = (side ? r2 : r1) + margin;              // other geom's radius
-          if (!pass || (ty != GT_BOX && ty != GT_CYLINDER)) continue;
-          V3 dw = side ? -d : d;                             // centre(solid) - centre(other)
-          const float *R = L + c.ly.gmat + 9 * gs;
-          V3 cl = v3(-(R[0] * dw.x + R[3] * dw.y + R[6] * dw.z), -(R[1] * dw.x + R[4] * dw.y + R[7] * dw.z), -(R[2] * dw.x + R[5] * dw.y + R[8] * dw.z));
-          const f4_t qs = GPC<f4_t>(m.pair_rec)[4 * p + (side ? 2 : 3)];
-          V3 sz_ = v3(qs.x, qs.y, qs.z);
-          float dist2;
-          if (ty == GT_BOX) {
-            V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
-            dist2 = dot(e, e);
-          } else {
-            float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz_.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz_.y, 0.0f);
-            dist2 = er * er + ez * ez;
-          }
-          if (dist2 > ro * ro) pass = false;
+          const int ty = side ? t1 : t2;                       // solid tested
+          const float ro = (side ? r2 : r1) + margin;         // other geom's radius
+          const V3 dw = side ? -d : d;                        // centre(solid) - centre(other)
+          const M3 &R = side ? Ra : Rb;
+          const V3 cl = v3(-(R.m[0] * dw.x + R.m[3] * dw.y + R.m[6] * dw.z), -(R.m[1] * dw.x + R.m[4] * dw.y + R.m[7] * dw.z), -(R.m[2] * dw.x + R.m[5] * dw.y + R.m[8] * dw.z));
+          const f4_t qs = side ? q2 : q3;
+          const V3 sz_ = v3(qs.x, qs.y, qs.z);
+          const V3 e = v3(fmaxf(fabsf(cl.x) - sz_.x, 0.0f), fmaxf(fabsf(cl.y) - sz_.y, 0.0f), fmaxf(fabsf(cl.z) - sz_.z, 0.0f));
+          const float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz_.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz_.y, 0.0f);
+          const float dist2 = ty == GT_BOX ? dot(e, e) : er * er + ez * ez;
+          if ((ty == GT_BOX || ty == GT_CYLINDER) && dist2 > ro * ro) pass = false;
         }
       }
     }

@@ -49,6 +49,9 @@ struct DModel : Dims {
   // [ncp][16] one 64-byte record per candidate pair with everything the broad/narrow phase needs from the two geoms:
   // g1 g2 pairtype (type1 | type2 << 8) | margin gap rbound1 rbound2 | size1 xyz - | size2 xyz -   (built by fsim_create)
   const float *pair_rec;
+  // [ncp][2] broadphase stage-1 record: g1 | g2 << 8 | (geom 1 is a plane) << 16, then the float bound the centre distance (plane:
+  // the signed distance of geom 2's centre) is tested against: r1 + r2 + margin (plane: r2 + margin)
+  const int *pair_bp;
   // sites
   const int *s_body;
   const float *s_pos, *s_quat;
