@@ -190,61 +190,63 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
 
 // ------------------------------------------------------------------------------------------ P1
 template <class Ctx> DEV void fs_kinematics(const Ctx &c) {
-  // Three passes.  (A) lane = body: joint transform relative to the parent frame (trig, quaternion products) -- parallel;
-  // (B) lane = tree: compose parent * local down the chain with the parent pose held in registers -- the only serial
-  // part, ~40 instructions per body for the 8-deep Sawyer chain; (C) lane = body: rotation matrix, joint anchor / axis
-  // and inertial-frame origin in world coordinates -- parallel.
+  // lane = body from start to end, poses in registers.  (A) joint transform relative to the parent frame; (B) world poses by
+  // pointer doubling up the kinematic tree: every body holds its pose relative to an ancestor and in each round composes it with
+  // that ancestor's own record and jumps to the ancestor's ancestor -- ceil(log2(depth)) rounds of (one LDS write, one LDS read)
+  // instead of a serial walk down the 8-deep Sawyer chain (which was 9 x three dependent LDS round trips on one lane while 63
+  // idled: half of this stage); (C) rotation matrix, joint anchor / axis and inertial-frame origin in world coordinates.
   CModel &m = c.m;
   float *L = c.L;
-  for (int b = c.lane; b < c.D.nr; b += 64) {
-    if (b == 0) { stv3(L + c.ly.xpos, v3(0, 0, 0)); stq(L + c.ly.xquat, q4(1, 0, 0, 0)); continue; }
-    int jt = KI(r_jtype, b), qa = KI(r_qposadr, b);
-    V3 pl, al, axl = v3(0, 0, 1);
-    Q4 ql;
+  int *ancs = c.I(c.ly.surv); // (the broadphase survivor list: dead until fs_collide)
+  const int b = c.lane;
+  const bool on = b < c.D.nr && b > 0;
+  const int bb = on ? b : 0;
+  // every load this stage needs from global memory, issued first (one round trip)
+  const Q4 q0 = ldq(GP(m.r_quat) + 4 * bb);
+  const V3 p0 = ldv3(GP(m.r_pos) + 3 * bb), jpos = ldv3(GP(m.r_jpos) + 3 * bb), jax = ldv3(GP(m.r_jaxis) + 3 * bb), ipos = ldv3(GP(m.r_ipos) + 3 * bb);
+  const int jt = KI(r_jtype, bb), qa = KI(r_qposadr, bb), parent = KI(r_parent, bb);
+  V3 P = v3(0, 0, 0), al = v3(0, 0, 0), axl = v3(0, 0, 1);
+  Q4 Q = q4(1, 0, 0, 0);
+  if (on) {
     if (jt == JT_FREE) {
       const float *q = L + c.ly.qpos + qa;
-      pl = ldv3(q);
-      ql = qnormalized(ldq(q + 3));
-      stq(L + c.ly.qpos + qa + 3, ql); // MuJoCo normalises the stored quaternion in place
-      al = pl;
+      P = ldv3(q);
+      Q = qnormalized(ldq(q + 3));
+      stq(L + c.ly.qpos + qa + 3, Q); // MuJoCo normalises the stored quaternion in place
+      al = P;
     } else {
-      Q4 q0 = ldq(GP(m.r_quat) + 4 * b);
-      V3 p0 = ldv3(GP(m.r_pos) + 3 * b), jpos = ldv3(GP(m.r_jpos) + 3 * b), jax = ldv3(GP(m.r_jaxis) + 3 * b);
       al = p0 + qrot(q0, jpos);
       axl = qrot(q0, jax);
-      float q = L[c.ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
-      if (jt == JT_SLIDE) { ql = q0; pl = p0 + axl * q; }
-      else { ql = qmul(q0, axisangle(jax, q)); pl = al - qrot(ql, jpos); }
-    }
-    stv3(L + c.ly.xpos + 3 * b, pl); stq(L + c.ly.xquat + 4 * b, ql);
-    stv3(L + c.ly.xanchor + 3 * b, al); stv3(L + c.ly.xaxis + 3 * b, axl);
-  }
-  SYNC();
-  for (int t = c.lane; t < c.D.ntree; t += 64) {
-    int b0 = KI(tree_bodyadr, t), nbod = KI(tree_bodynum, t);
-    int pid = 0;
-    V3 ppos = v3(0, 0, 0);
-    Q4 pquat = q4(1, 0, 0, 0);
-    for (int b = b0; b < b0 + nbod; b++) {
-      int p = KI(r_parent, b);
-      if (p != pid) { ppos = ldv3(L + c.ly.xpos + 3 * p); pquat = ldq(L + c.ly.xquat + 4 * p); pid = p; } // branch: parent already final
-      V3 pos = ppos + qrot(pquat, ldv3(L + c.ly.xpos + 3 * b));
-      Q4 quat = qnormalized(qmul(pquat, ldq(L + c.ly.xquat + 4 * b)));
-      stv3(L + c.ly.xpos + 3 * b, pos); stq(L + c.ly.xquat + 4 * b, quat);
-      pid = b; ppos = pos; pquat = quat;
+      const float q = L[c.ly.qpos + qa]; // joint reference positions are zero in every in-scope model (checked by the compiler)
+      if (jt == JT_SLIDE) { Q = q0; P = p0 + axl * q; }
+      else { Q = qmul(q0, axisangle(jax, q)); P = al - qrot(Q, jpos); }
     }
   }
+  int anc = on ? parent : 0;
+  for (int span = 1; span < c.D.maxdepth; span <<= 1) {
+    if (b < c.D.nr) { stv3(L + c.ly.xpos + 3 * b, P); stq(L + c.ly.xquat + 4 * b, Q); ancs[b] = anc; }
+    SYNC();
+    if (anc > 0) {
+      const V3 pa = ldv3(L + c.ly.xpos + 3 * anc);
+      const Q4 qa_ = ldq(L + c.ly.xquat + 4 * anc);
+      const int na = ancs[anc];
+      P = pa + qrot(qa_, P);
+      Q = qnormalized(qmul(qa_, Q));
+      anc = na;
+    }
+    SYNC();
+  }
+  if (b < c.D.nr) { stv3(L + c.ly.xpos + 3 * b, P); stq(L + c.ly.xquat + 4 * b, Q); }
   SYNC();
-  for (int b = c.lane; b < c.D.nr; b += 64) {
-    M3 R = q2m(ldq(L + c.ly.xquat + 4 * b));
+  if (b < c.D.nr) {
+    const M3 R = q2m(Q);
     stm3(L + c.ly.xmat + 9 * b, R);
-    stv3(L + c.ly.xipos + 3 * b, ldv3(L + c.ly.xpos + 3 * b) + mulv(R, ldv3(GP(m.r_ipos) + 3 * b)));
-    if (b > 0) { // joint anchor / axis were left in the parent frame by pass A
-      int p = KI(r_parent, b);
-      V3 pp = ldv3(L + c.ly.xpos + 3 * p);
-      Q4 pq = ldq(L + c.ly.xquat + 4 * p);
-      stv3(L + c.ly.xanchor + 3 * b, pp + qrot(pq, ldv3(L + c.ly.xanchor + 3 * b)));
-      stv3(L + c.ly.xaxis + 3 * b, qrot(pq, ldv3(L + c.ly.xaxis + 3 * b)));
+    stv3(L + c.ly.xipos + 3 * b, P + mulv(R, ipos));
+    if (b > 0) { // joint anchor / axis are in the parent frame
+      const V3 pp = ldv3(L + c.ly.xpos + 3 * parent);
+      const Q4 pq = ldq(L + c.ly.xquat + 4 * parent);
+      stv3(L + c.ly.xanchor + 3 * b, pp + qrot(pq, al));
+      stv3(L + c.ly.xaxis + 3 * b, qrot(pq, axl));
     }
   }
   SYNC();
@@ -350,47 +352,76 @@ template <class Ctx> DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
 
 // ------------------------------------------------------------------------------------------ P5/P6
 template <class Ctx> DEV void fs_velocity_bias(const Ctx &c) {
+  // Body velocities and RNE bias accelerations without walking the chains: all spatial vectors of a tree share one reference
+  // point (its CoM), so  v_b = sum_{i in chain(b)} u_i  with u_i = (joint i's motion axes) * qvel, and the velocity-product
+  // acceleration  a_b + g = sum_i cdof_dot_i qvel_i = sum_{j before i} u_j x u_i  (x = spatial motion cross product, bilinear).
+  // Segments of a chain therefore combine as (U, C) o (U', C') = (U + U', C + C' + U x U'), an associative rule: lane = body
+  // and ceil(log2(depth)) pointer-doubling rounds replace the per-dof pointer chase up the chain plus the per-body walk down it.
   CModel &m = c.m;
   float *L = c.L;
-  // cdof_dot: velocity of everything *before* the dof in the chain, crossed with the axis
-  for (int d = c.lane; d < c.D.nv; d += 64) {
-    int b = KI(dof_rbody, d), jt = KI(r_jtype, b), k = d - KI(r_dofadr, b);
-    S6 v = s6zero();
+  int *ancs = c.I(c.ly.surv);             // (broadphase survivor list: dead here)
+  float *SU = L + c.ly.cacc, *SC = L + c.ly.cfrc; // round scratch: cacc is free (anchors / axes were consumed by fs_com_inertia)
+  const int b = c.lane;
+  const bool on = b < c.D.nr && b > 0;
+  const int bb = on ? b : 0;
+  const int jt = KI(r_jtype, bb), da = KI(r_dofadr, bb), parent = KI(r_parent, bb);
+  S6 u = s6zero(), cc = s6zero();
+  if (on) {
     if (jt == JT_FREE) {
-      if (k >= 3) for (int t = 0; t < 3; t++) { int dd = KI(r_dofadr, b) + t; v = v + lds6(L + c.ly.cdof + 6 * dd) * L[c.ly.qvel + dd]; }
-    } else {
-      for (int a = KI(dof_parent, d); a >= 0; a = KI(dof_parent, a)) v = v + lds6(L + c.ly.cdof + 6 * a) * L[c.ly.qvel + a];
-    }
-    S6 sd = (jt == JT_FREE && k < 3) ? s6zero() : cross_motion(v, lds6(L + c.ly.cdof + 6 * d));
-    sts6(L + c.ly.cdofdot + 6 * d, sd);
-  }
-  SYNC();
-  for (int b = c.lane; b < c.D.nr; b += 64) {
-    S6 v = s6zero(), a = s6zero();
-    a.l = v3(-c.D.gravity[0], -c.D.gravity[1], -c.D.gravity[2]);
-    {
-      const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
-      for (int mm = ch & 0x3ffffff; mm; mm &= mm - 1) {
-        int d = base + __ffs(mm) - 1;
-        float qd = L[c.ly.qvel + d];
-        v = v + lds6(L + c.ly.cdof + 6 * d) * qd;
-        a = a + lds6(L + c.ly.cdofdot + 6 * d) * qd;
+      S6 vt = s6zero();
+#pragma unroll
+      for (int t = 0; t < 3; t++) vt = vt + lds6(L + c.ly.cdof + 6 * (da + t)) * L[c.ly.qvel + da + t];
+      u = vt;
+#pragma unroll
+      for (int k = 3; k < 6; k++) {
+        const S6 sk = lds6(L + c.ly.cdof + 6 * (da + k));
+        const float qd = L[c.ly.qvel + da + k];
+        u = u + sk * qd;
+        cc = cc + cross_motion(vt, sk) * qd;
       }
+    } else
+      u = lds6(L + c.ly.cdof + 6 * da) * L[c.ly.qvel + da];
+  }
+  int anc = on ? parent : 0;
+  for (int span = 1; span < c.D.maxdepth; span <<= 1) {
+    if (b < c.D.nr) { sts6(SU + 6 * b, u); sts6(SC + 6 * b, cc); ancs[b] = anc; }
+    SYNC();
+    if (anc > 0) {
+      const S6 ua = lds6(SU + 6 * anc), ca = lds6(SC + 6 * anc);
+      const int na = ancs[anc];
+      cc = ca + cc + cross_motion(ua, u);
+      u = ua + u;
+      anc = na;
     }
-    sts6(L + c.ly.cvel + 6 * b, v);
+    SYNC();
+  }
+  if (b < c.D.nr) {
+    S6 a = cc;
+    a.l = a.l + v3(-c.D.gravity[0], -c.D.gravity[1], -c.D.gravity[2]);
+    sts6(L + c.ly.cvel + 6 * b, u);
     S6 f = s6zero();
     if (b > 0) {
       const float *I = L + c.ly.cinert + 10 * b;
-      f = inert_mul(I, a) + cross_force(v, inert_mul(I, v));
+      f = inert_mul(I, a) + cross_force(u, inert_mul(I, u));
     }
     sts6(L + c.ly.cfrc + 6 * b, f);
   }
   SYNC();
   for (int d = c.lane; d < c.D.nv; d += 64) {
-    int bd = KI(dof_rbody, d);
-    S6 s = lds6(L + c.ly.cdof + 6 * d);
+    const int bd = KI(dof_rbody, d);
+    const S6 s_ = lds6(L + c.ly.cdof + 6 * d);
     float acc = 0;
-    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + c.ly.cfrc + 6 * (__ffs(mm) - 1)));
+    // two subtree bodies per trip, the second one predicated (its address falls back to the first): the loads of a trip are
+    // independent, so a 9-body subtree costs 5 LDS round trips instead of 9
+    for (int mm = KI(r_submask, bd); mm;) {
+      const int b0 = __ffs(mm) - 1;
+      mm &= mm - 1;
+      const bool two = mm != 0;
+      const int b1 = two ? __ffs(mm) - 1 : b0;
+      mm &= mm - 1;
+      const S6 f0 = lds6(L + c.ly.cfrc + 6 * b0), f1 = lds6(L + c.ly.cfrc + 6 * b1);
+      acc += dot6(s_, f0) + (two ? dot6(s_, f1) : 0.0f);
+    }
     L[c.ly.qfrcbias + d] = acc;
   }
   SYNC();
