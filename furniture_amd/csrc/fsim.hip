@@ -302,6 +302,7 @@ static int build_model(fsim *s) {
   LF(dof_armature, "dof_armature"); LF(dof_damping, "dof_damping"); LF(dof_invweight0, "dof_invweight0");
   LI(lim_dof, "lim_dof"); LF(lim_range, "lim_range"); LF(lim_margin, "lim_margin"); LF(lim_solref, "lim_solref"); LF(lim_solimp, "lim_solimp");
   { std::vector<int> v; blob_i(s->blob, "lim_dof", v); m.nlim = (int)v.size(); }
+  if (2 * m.nlim > 64) FAIL(FSIM_ENOMEM, "%d limited joints: the Newton solve keeps one joint-limit record per lane (2 per joint, <= 64)", m.nlim);
   LI(cg_body, "cg_body"); LI(cg_type, "cg_type"); LI(cg_condim, "cg_condim"); LI(cg_partid, "cg_partid"); LI(cg_fingerrole, "cg_fingerrole");
   LI(cg_isfloor, "cg_isfloor"); LI(cg_isrobot, "cg_isrobot"); LI(cg_ispartcol, "cg_ispartcol"); LI(cg_orig, "cg_orig");
   LI(cg_contype0, "cg_contype0"); LI(cg_conaffinity0, "cg_conaffinity0");

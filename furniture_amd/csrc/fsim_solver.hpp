@@ -187,44 +187,82 @@ template <class Ctx> DEV void fs_body_spatial(const Ctx &c, int off_vec) {
   SYNC();
 }
 
-// rec[dst..] = J * vec (- aref if sub_aref), using W from fs_body_spatial(vec)
-template <class Ctx> DEV void fs_jdot(const Ctx &c, int off_vec, bool to_jar) {
-  CModel &m = c.m;
+// ---- the Newton solve keeps this lane's constraint records in REGISTERS: lane = contact slot (ncon_max <= 64) and lane =
+// joint-limit record (2 nlim <= 64, checked by fsim_create).  The records are read from LDS once per solve (one round trip) and
+// every pass of the iteration -- J v, the cone forces, the line-search evaluations, the update -- runs on registers: those passes
+// used to re-read 10-20 words per slot behind `if (active)` branches, i.e. several dependent LDS round trips each, which is
+// what a single wavefront per env pays for most (a wave issues ~1 instruction per 5 cycles and waits ~100 for every dependent
+// LDS access).  Welds (rare: only after a connect) stay in LDS behind one wave-uniform flag.
+struct SolSlot {
+  bool act, dim1;          // contact slot is an active constraint / is frictionless (condim 1)
+  int bt1, bt2;            // body | tree << 8 of the two geoms
+  V3 r1, r2, fx, fy, fz;   // contact point relative to the CoM of body 1's / body 2's tree, and the contact frame (x = normal)
+  int tb;                  // (wave-uniform) bitmask of the moving bodies that carry an active contact or weld
+  float mu, dn, dt;
+  float aref[3], jar[3], jp[3];
+  bool lact;               // joint-limit record is active
+  int ldof;
+  float ld, laref, lsign, ljar, ljp;
+  bool anyweld;            // (wave-uniform) some weld is active
+};
+template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
   float *L = c.L;
-  int nslot = c.I(c.ly.scal)[SC_NSLOT];
-  for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + c.ly.con + FSIM_CONW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (ri[C_ACTIVE] != 1) continue;
-    V3 pos = ldv3(r + C_POS);
-    V3 rel = fs_ptvel(c, c.ly.W, ri[C_B2], pos) - fs_ptvel(c, c.ly.W, ri[C_B1], pos);
-    int dst = to_jar ? C_JAR : C_JP;
-    V3 fx, fy, fz;
-    fs_frame(r, fx, fy, fz);
-    r[dst] = dot(fx, rel) - (to_jar ? r[C_AREF] : 0.0f);
-    r[dst + 1] = dot(fy, rel) - (to_jar ? r[C_AREF + 1] : 0.0f);
-    r[dst + 2] = dot(fz, rel) - (to_jar ? r[C_AREF + 2] : 0.0f);
+  SolSlot S;
+  const int nslot = c.I(c.ly.scal)[SC_NSLOT];
+  const int sc = min(c.lane, c.ly.ncon_max - 1), sl = min(c.lane, max(2 * c.D.nlim - 1, 0));
+  const float *r = L + c.ly.con + FSIM_CONW * sc;
+  const int *ri = reinterpret_cast<const int *>(r);
+  S.act = c.lane < nslot && ri[C_ACTIVE] == 1;
+  S.dim1 = ri[C_DIM] == 1;
+  S.bt1 = S.act ? ri[C_B1] : 0; S.bt2 = S.act ? ri[C_B2] : 0;
+  {
+    const V3 pos = ldv3(r + C_POS);
+    S.r1 = pos - ldv3(L + c.ly.com + 3 * (S.bt1 >> 8)); S.r2 = pos - ldv3(L + c.ly.com + 3 * (S.bt2 >> 8));
   }
-  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
-    float *r = L + c.ly.lim + FSIM_LIMW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (!ri[LM_ACTIVE]) continue;
-    float v = r[LM_SIGN] * L[off_vec + ri[LM_DOF]];
-    if (to_jar) r[LM_JAR] = v - r[LM_AREF]; else r[LM_JP] = v;
+  S.mu = r[C_MU]; S.dn = r[C_DN]; S.dt = r[C_DT];
+  for (int a = 0; a < 3; a++) { S.aref[a] = r[C_AREF + a]; S.jar[a] = 0; S.jp[a] = 0; }
+  fs_frame(r, S.fx, S.fy, S.fz);
+  const float *q = L + c.ly.lim + FSIM_LIMW * sl;
+  const int *qi = reinterpret_cast<const int *>(q);
+  S.lact = c.lane < 2 * c.D.nlim && qi[LM_ACTIVE] != 0;
+  S.ldof = qi[LM_DOF]; S.ld = q[LM_D]; S.laref = q[LM_AREF]; S.lsign = q[LM_SIGN]; S.ljar = 0; S.ljp = 0;
+  if (!S.lact) S.ldof = 0;
+  int aw = 0, tb = S.act ? ((1 << (S.bt1 & 255)) | (1 << (S.bt2 & 255))) : 0;
+  for (int e = c.lane; e < c.D.neq; e += 64)
+    if (c.I(c.ly.eqactive)[e]) { aw = 1; tb |= (1 << GP(c.m.eq_rbody1)[e]) | (1 << GP(c.m.eq_rbody2)[e]); }
+  S.anyweld = __ballot(aw != 0) != 0;
+  S.tb = wave_or(tb) & ~1;
+  return S;
+}
+
+// S.jar (to_jar: minus aref) or S.jp = J * vec, using W from fs_body_spatial(vec)
+template <class Ctx> DEV void fs_jdot(const Ctx &c, SolSlot &S, int off_vec, bool to_jar) {
+  float *L = c.L;
+  {
+    // (unconditional loads: inactive lanes read body 0 / valid addresses and drop the result)
+    const S6 w1 = lds6(L + c.ly.W + 6 * (S.bt1 & 255)), w2 = lds6(L + c.ly.W + 6 * (S.bt2 & 255)); // (body 0's W is zero)
+    const V3 rel = (w2.l + cross(w2.a, S.r2)) - (w1.l + cross(w1.a, S.r1));
+    const float v0 = dot(S.fx, rel), v1 = dot(S.fy, rel), v2 = dot(S.fz, rel);
+    if (to_jar) { S.jar[0] = v0 - S.aref[0]; S.jar[1] = v1 - S.aref[1]; S.jar[2] = v2 - S.aref[2]; }
+    else { S.jp[0] = v0; S.jp[1] = v1; S.jp[2] = v2; }
+    const float lv = S.lsign * L[off_vec + S.ldof];
+    if (to_jar) S.ljar = lv - S.laref; else S.ljp = lv;
   }
-  for (int e = c.lane; e < c.D.neq; e += 64) {
-    float *r = L + c.ly.weld + FSIM_WELDW * e;
-    int *ri = reinterpret_cast<int *>(r);
-    if (!ri[WD_ACTIVE]) continue;
-    int b1 = ri[WD_B1], b2 = ri[WD_B2];
-    V3 jt = fs_ptvel(c, c.ly.W, fs_bt(c, b1), ldv3(r + WD_P0)) - fs_ptvel(c, c.ly.W, fs_bt(c, b2), ldv3(r + WD_X2));
-    V3 dw = lds6(L + c.ly.W + 6 * b1).a - lds6(L + c.ly.W + 6 * b2).a;
-    int dst = to_jar ? WD_JAR : WD_JP;
-    float v[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
-    for (int q = 0; q < 3; q++) v[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
-    for (int q = 0; q < 6; q++) r[dst + q] = v[q] - (to_jar ? r[WD_AREF + q] : 0.0f);
+  if (S.anyweld) {
+    for (int e = c.lane; e < c.D.neq; e += 64) {
+      float *r = L + c.ly.weld + FSIM_WELDW * e;
+      int *ri = reinterpret_cast<int *>(r);
+      if (!ri[WD_ACTIVE]) continue;
+      int b1 = ri[WD_B1], b2 = ri[WD_B2];
+      V3 jt = fs_ptvel(c, c.ly.W, fs_bt(c, b1), ldv3(r + WD_P0)) - fs_ptvel(c, c.ly.W, fs_bt(c, b2), ldv3(r + WD_X2));
+      V3 dw = lds6(L + c.ly.W + 6 * b1).a - lds6(L + c.ly.W + 6 * b2).a;
+      int dst = to_jar ? WD_JAR : WD_JP;
+      float v[6] = {jt.x, jt.y, jt.z, 0, 0, 0};
+      for (int q = 0; q < 3; q++) v[3 + q] = r[WD_C + 3 * q] * dw.x + r[WD_C + 3 * q + 1] * dw.y + r[WD_C + 3 * q + 2] * dw.z;
+      for (int q = 0; q < 6; q++) r[dst + q] = v[q] - (to_jar ? r[WD_AREF + q] : 0.0f);
+    }
+    SYNC();
   }
-  SYNC();
 }
 
 // elliptic contact block: force, cost, (optional) 3x3 Hessian w.r.t. jar.  returns state 0/1/2
@@ -284,41 +322,35 @@ DEV int fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, float
 // zone: per-lane record of which piece of the piecewise cost this lane's contact slot (bits 0-1: 0 top / 1 bottom / 2 middle)
 // and joint-limit record (bit 2: active) were in when the gradient was taken; *nonquad: some lane's slot / limit is now in another
 // piece than at `zone`, or on the cone surface (the only non-quadratic piece)
-template <class Ctx> DEV void fs_line_eval(const Ctx &c, float alpha, float *d1, float *d2, int zone, bool *nonquad) {
-  CModel &m = c.m;
+template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float alpha, float *d1, float *d2, int zone, bool *nonquad) {
   float *L = c.L;
-  int nslot = c.I(c.ly.scal)[SC_NSLOT];
   float a1 = 0, a2 = 0;
-  int zc = 0, zl = 0; // this lane's contact zone / limit activity at alpha (slot = lane: ncon_max <= 64)
-  for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + c.ly.con + FSIM_CONW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (ri[C_ACTIVE] != 1) continue;
-    if (ri[C_DIM] == 1) {
-      float j = r[C_JAR] + alpha * r[C_JP];
-      if (j < 0) { a1 += r[C_DN] * j * r[C_JP]; a2 += r[C_DN] * r[C_JP] * r[C_JP]; zc = 1; }
-      continue;
-    }
-    float jar[3], jp[3], e1, e2;
-    for (int a = 0; a < 3; a++) { jp[a] = r[C_JP + a]; jar[a] = r[C_JAR + a] + alpha * jp[a]; }
-    zc = fs_cone_dir(jar, jp, r[C_DN], r[C_DT], r[C_MU], &e1, &e2);
-    a1 += e1; a2 += e2;
-  }
-  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
-    float *r = L + c.ly.lim + FSIM_LIMW * s;
-    if (!reinterpret_cast<int *>(r)[LM_ACTIVE]) continue;
-    float j = r[LM_JAR] + alpha * r[LM_JP];
-    if (j < 0) { a1 += r[LM_D] * j * r[LM_JP]; a2 += r[LM_D] * r[LM_JP] * r[LM_JP]; zl = 1; }
-  }
-  for (int e = c.lane; e < c.D.neq; e += 64) {
-    float *r = L + c.ly.weld + FSIM_WELDW * e;
-    if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
-    for (int q = 0; q < 6; q++) {
-      float j = r[WD_JAR + q] + alpha * r[WD_JP + q], D = r[WD_D + q];
-      a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
+  int zc = 0, zl = 0; // this lane's contact zone / limit activity at alpha
+  if (S.act) {
+    if (S.dim1) {
+      float j = S.jar[0] + alpha * S.jp[0];
+      if (j < 0) { a1 += S.dn * j * S.jp[0]; a2 += S.dn * S.jp[0] * S.jp[0]; zc = 1; }
+    } else {
+      float jar[3], e1, e2;
+      for (int a = 0; a < 3; a++) jar[a] = S.jar[a] + alpha * S.jp[a];
+      zc = fs_cone_dir(jar, S.jp, S.dn, S.dt, S.mu, &e1, &e2);
+      a1 += e1; a2 += e2;
     }
   }
-  *nonquad = __ballot(zc == 2 || zc != (zone & 3) || zl != ((zone >> 2) & 1)) != 0 || 2 * c.D.nlim > 64;
+  if (S.lact) {
+    float j = S.ljar + alpha * S.ljp;
+    if (j < 0) { a1 += S.ld * j * S.ljp; a2 += S.ld * S.ljp * S.ljp; zl = 1; }
+  }
+  if (S.anyweld)
+    for (int e = c.lane; e < c.D.neq; e += 64) {
+      float *r = L + c.ly.weld + FSIM_WELDW * e;
+      if (!reinterpret_cast<int *>(r)[WD_ACTIVE]) continue;
+      for (int q = 0; q < 6; q++) {
+        float j = r[WD_JAR + q] + alpha * r[WD_JP + q], D = r[WD_D + q];
+        a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
+      }
+    }
+  *nonquad = __ballot(zc == 2 || zc != (zone & 3) || zl != ((zone >> 2) & 1)) != 0;
   *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
@@ -330,14 +362,22 @@ template <class Ctx> DEV void fs_add_wrench(const Ctx &c, int bt, V3 p, V3 F, V3
   atomicAdd(G + 0, mo.x); atomicAdd(G + 1, mo.y); atomicAdd(G + 2, mo.z);
   atomicAdd(G + 3, sign * F.x); atomicAdd(G + 4, sign * F.y); atomicAdd(G + 5, sign * F.z);
 }
+// (r: application point relative to the tree's CoM)
+template <class Ctx> DEV void fs_add_wrench_r(const Ctx &c, int bt, V3 r, V3 F, float sign) {
+  const int b = bt & 255;
+  if (b == 0) return;
+  float *G = c.L + c.ly.G + 6 * b;
+  const V3 mo = cross(r, F) * sign;
+  atomicAdd(G + 0, mo.x); atomicAdd(G + 1, mo.y); atomicAdd(G + 2, mo.z);
+  atomicAdd(G + 3, sign * F.x); atomicAdd(G + 4, sign * F.y); atomicAdd(G + 5, sign * F.z);
+}
 
 // grad = Mx - qfrc_smooth - J' f(jar)
 // What the gradient pass already knows about this lane's contact slot and the Hessian pass needs again: whether the
 // cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
 struct SlotK { bool on; int zone; float K[6]; }; // zone: see fs_line_eval
 
-template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
-  CModel &m = c.m;
+template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S) {
   float *L = c.L;
   SlotK sk;
   sk.on = false;
@@ -346,59 +386,60 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c) {
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
   SYNC();
-  int nslot = c.I(c.ly.scal)[SC_NSLOT];
-  for (int s = c.lane; s < nslot; s += 64) {
-    float *r = L + c.ly.con + FSIM_CONW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (ri[C_ACTIVE] != 1) continue;
+  if (S.act) {
     float f[3] = {0, 0, 0}, cc, Hc[9];
     bool on;
-    if (ri[C_DIM] == 1) {
-      on = r[C_JAR] < 0;
-      if (on) f[0] = -r[C_DN] * r[C_JAR];
+    if (S.dim1) {
+      on = S.jar[0] < 0;
+      if (on) f[0] = -S.dn * S.jar[0];
       for (int q = 0; q < 9; q++) Hc[q] = 0;
-      Hc[0] = r[C_DN];
+      Hc[0] = S.dn;
       sk.zone = on ? 1 : 0;
-    } else { sk.zone = fs_cone(r + C_JAR, r[C_DN], r[C_DT], r[C_MU], f, &cc, Hc); on = sk.zone != 0; }
-    if (!on) continue; // top zone: zero force, zero Hessian
-    V3 fx, fy, fz;
-    fs_frame(r, fx, fy, fz);
-    {
+    } else { sk.zone = fs_cone(S.jar, S.dn, S.dt, S.mu, f, &cc, Hc); on = sk.zone != 0; }
+    if (on) { // (top zone: zero force, zero Hessian)
+      const V3 fx = S.fx, fy = S.fy, fz = S.fz;
       V3 w0 = fx * Hc[0] + fy * Hc[1] + fz * Hc[2], w1 = fx * Hc[3] + fy * Hc[4] + fz * Hc[5], w2 = fx * Hc[6] + fy * Hc[7] + fz * Hc[8];
       sk.on = true;
       sk.K[0] = fx.x * w0.x + fy.x * w1.x + fz.x * w2.x; sk.K[1] = fx.x * w0.y + fy.x * w1.y + fz.x * w2.y; sk.K[2] = fx.x * w0.z + fy.x * w1.z + fz.x * w2.z;
       sk.K[3] = fx.y * w0.y + fy.y * w1.y + fz.y * w2.y; sk.K[4] = fx.y * w0.z + fy.y * w1.z + fz.y * w2.z; sk.K[5] = fx.z * w0.z + fy.z * w1.z + fz.z * w2.z;
+      const V3 F = fx * f[0] + fy * f[1] + fz * f[2];
+      fs_add_wrench_r(c, S.bt2, S.r2, F, 1.0f);
+      fs_add_wrench_r(c, S.bt1, S.r1, F, -1.0f);
     }
-    V3 F = fx * f[0] + fy * f[1] + fz * f[2];
-    V3 pos = ldv3(r + C_POS);
-    fs_add_wrench(c, ri[C_B2], pos, F, v3(0, 0, 0), 1.0f);
-    fs_add_wrench(c, ri[C_B1], pos, F, v3(0, 0, 0), -1.0f);
   }
-  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
-    float *r = L + c.ly.lim + FSIM_LIMW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
+  if (S.lact && S.ljar < 0) {
     sk.zone |= 4;
-    atomicAdd(L + c.ly.grad + ri[LM_DOF], r[LM_SIGN] * r[LM_D] * r[LM_JAR]); // -sign*f, f = -D*jar
+    atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar); // -sign*f, f = -D*jar
   }
-  for (int e = c.lane; e < c.D.neq; e += 64) {
-    float *r = L + c.ly.weld + FSIM_WELDW * e;
-    int *ri = reinterpret_cast<int *>(r);
-    if (!ri[WD_ACTIVE]) continue;
-    float f[6];
-    for (int q = 0; q < 6; q++) f[q] = -r[WD_D + q] * r[WD_JAR + q];
-    V3 F = v3(f[0], f[1], f[2]);
-    V3 T = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
-              r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
-    fs_add_wrench(c, fs_bt(c, ri[WD_B1]), ldv3(r + WD_P0), F, T, 1.0f);
-    fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T, -1.0f);
-  }
+  if (S.anyweld)
+    for (int e = c.lane; e < c.D.neq; e += 64) {
+      float *r = L + c.ly.weld + FSIM_WELDW * e;
+      int *ri = reinterpret_cast<int *>(r);
+      if (!ri[WD_ACTIVE]) continue;
+      float f[6];
+      for (int q = 0; q < 6; q++) f[q] = -r[WD_D + q] * r[WD_JAR + q];
+      V3 F = v3(f[0], f[1], f[2]);
+      V3 T = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
+                r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
+      fs_add_wrench(c, fs_bt(c, ri[WD_B1]), ldv3(r + WD_P0), F, T, 1.0f);
+      fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T, -1.0f);
+    }
   SYNC();
   for (int d = c.lane; d < c.D.nv; d += 64) {
-    int bd = KI(dof_rbody, d);
-    S6 s = lds6(L + c.ly.cdof + 6 * d);
+    const int bd = KI(dof_rbody, d);
+    const S6 s_ = lds6(L + c.ly.cdof + 6 * d);
     float acc = 0;
-    for (int mm = KI(r_submask, bd); mm; mm &= mm - 1) acc += dot6(s, lds6(L + c.ly.G + 6 * (__ffs(mm) - 1)));
+    // only the bodies that carry a constraint hold a wrench (a free arm's dofs skip the walk); two bodies per trip, the second
+    // predicated, so that a trip's loads are independent
+    for (int mm = KI(r_submask, bd) & S.tb; mm;) {
+      const int b0 = __ffs(mm) - 1;
+      mm &= mm - 1;
+      const bool two = mm != 0;
+      const int b1 = two ? __ffs(mm) - 1 : b0;
+      mm &= mm - 1;
+      const S6 g0 = lds6(L + c.ly.G + 6 * b0), g1 = lds6(L + c.ly.G + 6 * b1);
+      acc += dot6(s_, g0) + (two ? dot6(s_, g1) : 0.0f);
+    }
     L[c.ly.grad + d] -= acc;
   }
   SYNC();
@@ -429,7 +470,7 @@ template <class Ctx> DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   a contact between two moving bodies (lo, hi) additionally adds -cdof_d1' X cdof_d2, X = P_lo' K P_hi, on
 //   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
-template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
+template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const SolSlot &S) {
   CModel &m = c.m;
   float *L = c.L;
   const int nH = c.I(c.ly.scal)[SC_HWORDS]; // packed island triangles
@@ -447,19 +488,16 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
   for (int i = c.lane; i < 21 * c.D.nr; i += 64) A[i] = 0;
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
-  const int nslot = c.I(c.ly.scal)[SC_NSLOT];
   const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
   int blo = 0, bhi = 0, tlo = 0, thi = 0;
   float K[6];
   for (int q = 0; q < 6; q++) K[q] = sk.K[q];
-  V3 pos = v3(0, 0, 0);
-  if (on) {
-    const float *r = L + c.ly.con + FSIM_CONW * c.lane;
-    const int *ri = reinterpret_cast<const int *>(r);
-    pos = ldv3(r + C_POS);
-    const int wb1 = ri[C_B1], wb2 = ri[C_B2]; // body | tree << 8
-    const int wl = (wb1 & 255) <= (wb2 & 255) ? wb1 : wb2, wh = (wb1 & 255) <= (wb2 & 255) ? wb2 : wb1;
+  V3 rlo_ = v3(0, 0, 0), rhi_ = rlo_;
+  if (on) { // (this lane's slot record is in registers: SolSlot)
+    const bool first_lo = (S.bt1 & 255) <= (S.bt2 & 255);
+    const int wl = first_lo ? S.bt1 : S.bt2, wh = first_lo ? S.bt2 : S.bt1;
     blo = wl & 255; bhi = wh & 255; tlo = wl >> 8; thi = wh >> 8;
+    rlo_ = first_lo ? S.r1 : S.r2; rhi_ = first_lo ? S.r2 : S.r1;
   }
   // rows of K, G = [r]x K (ang-lin block), and the diagonal blocks
   const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
@@ -469,7 +507,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
     for (int side = 0; side < 2; side++) {
       int b = side ? bhi : blo;
       if (b == 0) continue;
-      V3 rr = pos - ldv3(L + c.ly.com + 3 * (side ? thi : tlo));
+      V3 rr = side ? rhi_ : rlo_;
       // G[:, c] = rr x K[:, c]  (K symmetric: column c = row c); stored by rows G_a = (G[a][0], G[a][1], G[a][2])
       V3 c0 = cross(rr, K0), c1 = cross(rr, K1), c2 = cross(rr, K2);
       V3 G0 = v3(c0.x, c1.x, c2.x), G1 = v3(c0.y, c1.y, c2.y), G2 = v3(c0.z, c1.z, c2.z);
@@ -574,12 +612,8 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk) {
     SYNC();
   }
   FS_HPROF(53);
-  for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
-    float *r = L + c.ly.lim + FSIM_LIMW * s;
-    int *ri = reinterpret_cast<int *>(r);
-    if (!ri[LM_ACTIVE] || r[LM_JAR] >= 0) continue;
-    atomicAdd(L + c.ly.H + fs_hidx(c, hm, ri[LM_DOF], ri[LM_DOF]), r[LM_D]);
-  }
+  if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
+  if (S.anyweld)
   for (int e = c.lane; e < c.D.neq; e += 64) {
     float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
@@ -899,35 +933,32 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   // active slot the first Newton step (H = M, alpha = 1) is exactly M^-1 qfrc_smooth, so M is never factored on its own.
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.x + d] = L[c.ly.qaccws + d];
   SYNC();
+  SolSlot S = fs_load_slots(c);
   fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
-  fs_jdot(c, c.ly.x, true);
+  fs_jdot(c, S, c.ly.x, true);
   float scale = c.D.meaninertia_scale;
   int it = 0;
   for (; it < c.newton_maxit; it++) {
-    const SlotK sk = fs_gradient(c);
+    const SlotK sk = fs_gradient(c, S);
     float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
     FS_SPROF(23);
-#ifdef FSIM_PROFILE
-    if (!isfinite(gn) && c.lane == 0 && !scal[27]) { scal[27] = 100 + it; scal[28] = scal[21]; }
-#endif
     if (scale * gn < c.newton_tol) break;
-    fs_hessian(c, sk);
+    fs_hessian(c, sk, S);
     FS_SPROF(24);
     bool ok = fs_chol_solve(c, c.ly.hmap);
     FS_SPROF(25);
-#ifdef FSIM_PROFILE
-    if (!ok && c.lane == 0 && !scal[27]) { scal[27] = 300 + it; scal[28] = scal[21]; }
-#endif
     if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
-    float dphi0 = fs_dotv(c, c.ly.p, c.ly.grad); // phi'(0) along the Newton direction (= -g' H^-1 g < 0)
     fs_mulM(c, c.ly.Mp, c.ly.p);
     fs_body_spatial(c, c.ly.p);
-    fs_jdot(c, c.ly.p, false);
-    float pMp = fs_dotv(c, c.ly.p, c.ly.Mp);
-    float pg0 = 0;
-    for (int d = c.lane; d < c.D.nv; d += 64) pg0 += L[c.ly.p + d] * (L[c.ly.Mx + d] - L[c.ly.smooth + d]);
-    pg0 = wave_sum(pg0);
+    fs_jdot(c, S, c.ly.p, false);
+    // phi'(0) along the Newton direction (= -g' H^-1 g < 0), p'Mp and p'(Mx - smooth) in one pass over the dofs
+    float dphi0 = 0, pMp = 0, pg0 = 0;
+    for (int d = c.lane; d < c.D.nv; d += 64) {
+      const float pd = L[c.ly.p + d];
+      dphi0 += pd * L[c.ly.grad + d]; pMp += pd * L[c.ly.Mp + d]; pg0 += pd * (L[c.ly.Mx + d] - L[c.ly.smooth + d]);
+    }
+    dphi0 = wave_sum(dphi0); pMp = wave_sum(pMp); pg0 = wave_sum(pg0);
     FS_SPROF(26);
     // exact line search: safeguarded Newton on phi'(alpha)
     float lo = 0, hi = -1, alpha = 1, best = 0;
@@ -936,7 +967,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     for (int ls = 0; ls < 20; ls++) {
       float d1, d2;
       bool nq;
-      fs_line_eval(c, alpha, &d1, &d2, sk.zone, &nq);
+      fs_line_eval(c, S, alpha, &d1, &d2, sk.zone, &nq);
       if (ls == 0) nonquad = nq;
 #ifdef FSIM_PROFILE
       if (c.lane == 0) { scal[16 + 13] += 1; }
@@ -958,24 +989,14 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     if (c.lane == 0) { scal[16 + 14] += 1; }
 #endif
     FS_SPROF(27);
-#ifdef FSIM_PROFILE
-    if (!isfinite(alpha) && c.lane == 0 && !scal[27]) { scal[27] = 400 + it; scal[28] = scal[21]; }
-    if (!isfinite(pMp) && c.lane == 0 && !scal[27]) { scal[27] = 500 + it; scal[28] = scal[21]; }
-#endif
     for (int d = c.lane; d < c.D.nv; d += 64) { L[c.ly.x + d] += alpha * L[c.ly.p + d]; L[c.ly.Mx + d] += alpha * L[c.ly.Mp + d]; }
-    for (int s = c.lane; s < nslot; s += 64) {
-      float *r = L + c.ly.con + FSIM_CONW * s;
-      if (reinterpret_cast<int *>(r)[C_ACTIVE] != 1) continue;
-      for (int a = 0; a < 3; a++) r[C_JAR + a] += alpha * r[C_JP + a];
-    }
-    for (int s = c.lane; s < 2 * c.D.nlim; s += 64) {
-      float *r = L + c.ly.lim + FSIM_LIMW * s;
-      if (reinterpret_cast<int *>(r)[LM_ACTIVE]) r[LM_JAR] += alpha * r[LM_JP];
-    }
-    for (int e = c.lane; e < c.D.neq; e += 64) {
-      float *r = L + c.ly.weld + FSIM_WELDW * e;
-      if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
-    }
+    for (int a = 0; a < 3; a++) S.jar[a] += alpha * S.jp[a];
+    S.ljar += alpha * S.ljp;
+    if (S.anyweld)
+      for (int e = c.lane; e < c.D.neq; e += 64) {
+        float *r = L + c.ly.weld + FSIM_WELDW * e;
+        if (reinterpret_cast<int *>(r)[WD_ACTIVE]) for (int q = 0; q < 6; q++) r[WD_JAR + q] += alpha * r[WD_JP + q];
+      }
     SYNC();
     // MuJoCo's second stopping rule: scaled cost improvement of the step below tolerance.  The improvement is taken
     // from the line-search model, phi(0) - phi(alpha) = -1/2 alpha phi'(0) at an exact minimiser of a (piecewise)
