@@ -674,68 +674,89 @@ struct LaneBcast { // big phase: lane first + J of the wave (v_readlane, wave-un
   template <int J> DEV float get(float v) const { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), first + J)); }
 };
 
-// One phase: every lane owns row `l` (position `pos` in its group, which starts at position pos - l) of a symmetric matrix
-// whose group has `fill` occupied positions; steps = largest fill in the wave (uniform).  A[q] = row entries by position.
+// One phase: every lane owns row `l` (position `pos` in its group, which starts at position pos - l) of a symmetric matrix;
+// steps = largest group fill in the wave (uniform).  A[q] = row entries by position.  Unoccupied positions carry a unit
+// diagonal (set by the caller), so no per-step "is this pivot live" predicate exists; the lane-role tests (pivot / below /
+// above) are single-use compares against `pos` -- kept that way on purpose: when the forward and the backward sweep shared
+// them the compiler held 2 x NLOC lane masks in SGPR pairs, spilled them to VGPR lanes and a third of this routine's
+// instructions were v_readlane reloads of masks.
+typedef float fs_f2 __attribute__((ext_vector_type(2)));
+// (the row lives in NLOC / 2 two-float vectors so that the trailing update is v_pk_fma_f32 on register pairs the allocator keeps
+//  aligned -- with a plain float array the SLP-packed update paid 2.5 v_mov per packed FMA to build the pairs)
+#define FS_ROW(A, k) ((A)[(k) >> 1][(k) & 1])
 template <int NLOC, int JJ, class BC> struct FsCholStep {
-  DEV static void fwd(float (&A)[NLOC], float &b, float &mydinv, int &bad, const int pos, const int fill, const int steps, const BC &bc) {
+  DEV static void fwd(fs_f2 (&A)[NLOC / 2], float &b, float &mydinv, float &dmin, const int pos, const int steps, const BC &bc) {
     if (JJ < steps) {
-      float d = bc.template get<JJ>(A[JJ]);
-      const bool act = JJ < fill;
-      if (act && !(d > 1e-30f)) { bad = 1; d = 1e-30f; }
-      const float rinv = act ? rsqrtf(d) : 0.0f;
+      const float ajj = FS_ROW(A, JJ);
+      const float d = bc.template get<JJ>(ajj);
+      dmin = fminf(dmin, d);
+      const float rinv = rsqrtf(fmaxf(d, 1e-30f));
       // forward substitution, column form: y_j = b_j / L_jj, then b_l -= L[l][j] y_j below the pivot
       const float yj = bc.template get<JJ>(b * rinv);
-      const float lij = A[JJ] * rinv; // L[l][j] for pos > j
-      if (pos == JJ) { mydinv = rinv; b = yj; }
-      const bool below = pos > JJ;
-      if (below) b -= lij * yj;
+      const float lij = ajj * rinv; // L[l][j] for pos > j
+      int pj = pos;
+      asm volatile("" : "+v"(pj) : "v"(yj)); // (ties this step's lane-role compares to this step: see the note above)
+      const bool below = pj > JJ;
+      b = pj == JJ ? yj : b;
+      mydinv = pj == JJ ? rinv : mydinv;
+      b = below ? __builtin_fmaf(-lij, yj, b) : b;
       const float w = below ? -lij * rinv : 0.0f; // A[l][k] -= L[l][j] L[k][j] = A[l][j] A[j][k] / d
-#pragma unroll
-      for (int k = JJ + 1; k < NLOC; k++) {
-        if (((k - JJ - 1) & 3) == 0 && k >= steps) break;
-        A[k] = __builtin_fmaf(w, bc.template get<JJ>(A[k]), A[k]);
+      const fs_f2 w2 = {w, w};
+      if ((JJ + 1) & 1) { // odd first column: scalar
+        if (JJ + 1 < NLOC) FS_ROW(A, JJ + 1) = __builtin_fmaf(w, bc.template get<JJ>(FS_ROW(A, JJ + 1)), FS_ROW(A, JJ + 1));
       }
-      FsCholStep<NLOC, JJ + 1, BC>::fwd(A, b, mydinv, bad, pos, fill, steps, bc);
+#pragma unroll
+      for (int kk = (JJ + 2) >> 1; kk < NLOC / 2; kk++) {
+        if (((kk - ((JJ + 2) >> 1)) & 1) == 0 && 2 * kk >= steps) break;
+        const fs_f2 t = {bc.template get<JJ>(A[kk].x), bc.template get<JJ>(A[kk].y)};
+        A[kk] = __builtin_elementwise_fma(w2, t, A[kk]);
+      }
+      FsCholStep<NLOC, JJ + 1, BC>::fwd(A, b, mydinv, dmin, pos, steps, bc);
     }
   }
   // backward: L' p = y.  L[j][l] = A[l][j] * dinv_l for l < j (lane l's row as it was when l was the pivot)
-  DEV static void bwd(const float (&A)[NLOC], float &b, const float mydinv, const int pos, const int steps, const BC &bc) {
+  DEV static void bwd(const fs_f2 (&A)[NLOC / 2], float &b, const float mydinv, const int pos, const int steps, const BC &bc) {
     constexpr int J = NLOC - 1 - JJ;
     if (J < steps) {
       const float pj = bc.template get<J>(b * mydinv);
-      if (pos == J) b = pj;
-      if (pos < J) b -= A[J] * mydinv * pj;
+      int pk = pos;
+      asm volatile("" : "+v"(pk) : "v"(pj));
+      b = pk == J ? pj : b;
+      b = pk < J ? __builtin_fmaf(-FS_ROW(A, J) * mydinv, pj, b) : b;
     }
     FsCholStep<NLOC, JJ + 1, BC>::bwd(A, b, mydinv, pos, steps, bc);
   }
 };
 template <int NLOC, class BC> struct FsCholStep<NLOC, NLOC, BC> {
-  DEV static void fwd(float (&)[NLOC], float &, float &, int &, const int, const int, const int, const BC &) {}
-  DEV static void bwd(const float (&)[NLOC], float &, const float, const int, const int, const BC &) {}
+  DEV static void fwd(fs_f2 (&)[NLOC / 2], float &, float &, float &, const int, const int, const BC &) {}
+  DEV static void bwd(const fs_f2 (&)[NLOC / 2], float &, const float, const int, const int, const BC &) {}
 };
 
-// dof: the dof this lane owns in this phase (< 0: none); pos / fill / steps as above; writes p[dof].  returns the lane's bad flag
-template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int mp, const int dof, const int pos, const int fill, const int steps, const BC &bc) {
+// dof: the dof this lane owns in this phase (< 0: none); pos / steps as above; writes p[dof].  returns the lane's bad flag
+template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int mp, const int dof, const int pos, const int steps, const BC &bc) {
+  static_assert(NLOC % 2 == 0, "rows are stored as float pairs");
   float *L = c.L;
   const float *H = L + c.ly.H;
   const bool row = dof >= 0;
   const int B = row ? c.I(mp)[dof] : 0;
   const int l = (B >> 12) & 63, nI = (B >> 18) & 127, rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
   const int p0 = pos - l; // first position of the lane's island inside its group
-  float A[NLOC];
+  fs_f2 A[NLOC / 2];
 #pragma unroll
   for (int q = 0; q < NLOC; q++) {
     const int lq = q - p0;
     const bool ok = row && q < steps && lq >= 0 && lq < nI;
     const int hi = max(l, lq), lo = min(l, lq);
-    A[q] = ok ? H[hI + hi * (hi + 1) / 2 + lo] : 0.0f;
+    const float e = ok ? H[hI + hi * (hi + 1) / 2 + lo] : 0.0f;
+    FS_ROW(A, q) = (!row && q == pos) ? 1.0f : e; // a lane without a dof: unit diagonal, zero row
   }
-  float b = row ? -L[c.ly.grad + dof] : 0.0f, mydinv = 0.0f;
-  int bad = 0;
-  FsCholStep<NLOC, 0, BC>::fwd(A, b, mydinv, bad, pos, row ? fill : 0, steps, bc);
-  FsCholStep<NLOC, 0, BC>::bwd(A, b, mydinv, pos, steps, bc);
+  float b = row ? -L[c.ly.grad + dof] : 0.0f, mydinv = 0.0f, dmin = 1.0f;
+  FsCholStep<NLOC, 0, BC>::fwd(A, b, mydinv, dmin, pos, steps, bc);
+  int pos2 = pos;
+  asm volatile("" : "+v"(pos2)); // (the backward sweep derives its lane roles afresh: see FsCholStep)
+  FsCholStep<NLOC, 0, BC>::bwd(A, b, mydinv, pos2, steps, bc);
   if (row) L[c.ly.p + dof] = b;
-  return bad;
+  return !(dmin > 1e-30f); // a non-positive (or NaN) pivot anywhere in this lane's group
 }
 
 // ---- big phase on the matrix cores: one island of 17..31 dofs as a 32 x 32 symmetric tile in the accumulator layout of
@@ -750,37 +771,36 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
 typedef float fs_f16v __attribute__((ext_vector_type(16)));
 template <int P> struct FsMfmaStep {
   static constexpr int VP = 4 * (P >> 3) + (P & 3), HP = (P >> 2) & 1;
-  static constexpr unsigned long long COLS_GT = ((0xffffffffull << (P + 1)) & 0xffffffffull) << (32 * HP); // half HP, columns > P
-  static constexpr unsigned long long COLS_LT = ((1ull << P) - 1ull) << (32 * HP);                          // half HP, columns < P
-  DEV static void fwd(fs_f16v &D, float &myrinv, int &bad, const int n, const int lane) {
+  DEV static void fwd(fs_f16v &D, float &myrinv, float &dmin, const int n, const int lane) {
     if (P < n) {
-      float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VP]), 32 * HP + P));
-      if (!(d > 1e-30f)) { bad = 1; d = 1e-30f; }
-      const float rinv = rsqrtf(d);
-      const float u = ((COLS_GT >> lane) & 1ull) ? D[VP] * rinv : 0.0f;
-      if ((lane & 31) == P) myrinv = rinv;
+      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VP]), 32 * HP + P));
+      dmin = fminf(dmin, d);
+      const float rinv = rsqrtf(fmaxf(d, 1e-30f));
+      // lanes of half HP with column > P: one unsigned range test
+      const bool cols = (unsigned)(lane - (32 * HP + P + 1)) < (unsigned)(31 - P);
+      const float u = cols ? D[VP] * rinv : 0.0f;
+      myrinv = (lane & 31) == P ? rinv : myrinv;
       D = __builtin_amdgcn_mfma_f32_32x32x2f32(u, -u, D, 0, 0, 0);
-      FsMfmaStep<P + 1>::fwd(D, myrinv, bad, n, lane);
+      FsMfmaStep<P + 1>::fwd(D, myrinv, dmin, n, lane);
     }
   }
   DEV static void bwd(const fs_f16v &D, const float myrinv, float &acc, float &res, const int n, const int lane) {
     constexpr int Q = 30 - P; // pivots 30 .. 0
     constexpr int VQ = 4 * (Q >> 3) + (Q & 3), HQ = (Q >> 2) & 1;
-    constexpr unsigned long long LT = ((1ull << Q) - 1ull) << (32 * HQ);
     if (Q < n) {
       const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VQ]), 32 * HQ + 31));
       const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q));
       const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q + 32));
       const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrinv), Q));
       const float xq = r * r * (sy - t0 - t1);
-      if ((LT >> lane) & 1ull) acc = __builtin_fmaf(D[VQ], xq, acc);
-      if (lane == Q) res = xq;
+      acc = (unsigned)(lane - 32 * HQ) < (unsigned)Q ? __builtin_fmaf(D[VQ], xq, acc) : acc; // half HQ, columns < Q
+      res = lane == Q ? xq : res;
     }
     FsMfmaStep<P + 1>::bwd(D, myrinv, acc, res, n, lane);
   }
 };
 template <> struct FsMfmaStep<31> {
-  DEV static void fwd(fs_f16v &, float &, int &, const int, const int) {}
+  DEV static void fwd(fs_f16v &, float &, float &, const int, const int) {}
   DEV static void bwd(const fs_f16v &, const float, float &, float &, const int, const int) {}
 };
 // first: first big-phase lane of the island, n: its size (17..31).  returns the bad flag (uniform)
@@ -811,12 +831,11 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, int mp_, i
     else if (hi == 31 && lo < n) e = rhs[lo];
     D[v] = e;
   }
-  float myrinv = 0.0f, acc = 0.0f, res = 0.0f;
-  int bad = 0;
-  FsMfmaStep<0>::fwd(D, myrinv, bad, n, c.lane);
+  float myrinv = 0.0f, acc = 0.0f, res = 0.0f, dmin = 1.0f;
+  FsMfmaStep<0>::fwd(D, myrinv, dmin, n, c.lane);
   FsMfmaStep<0>::bwd(D, myrinv, acc, res, n, c.lane);
   if (c.lane < n) L[c.ly.p + dofk] = res;
-  return bad;
+  return !(dmin > 1e-30f);
 }
 
 // islands larger than 32 dofs (e.g. the fully welded table plus the robot): the factor stays in LDS, left-looking, lane = row
@@ -879,10 +898,10 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
 #endif
   int bad = 0;
   if (rsteps > 0) {
-    const int dofr = lw & 255, fill = (lw >> 16) & 255;
+    const int dofr = lw & 255;
     const int dof = dofr == 255 ? -1 : dofr;
-    if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, fill, rsteps, RowBcast());
-    else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, fill, rsteps, RowBcast());
+    if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+    else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   }
   if (nbig > 0) {
     const int maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
@@ -896,11 +915,11 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
         const int dof = mine ? dofb : -1;
 #ifdef FSIM_CHOL_READLANE
         LaneBcast bc; bc.first = first;
-        if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, n, bc);
-        else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, n, bc);
+        if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, bc);
+        else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc);
 #else
         if (n <= 31) bad |= fs_chol_mfma(c, mp, first, n);
-        else { LaneBcast bc; bc.first = first; bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, n, bc); }
+        else { LaneBcast bc; bc.first = first; bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc); }
 #endif
       }
     }
