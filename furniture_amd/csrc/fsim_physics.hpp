@@ -69,6 +69,16 @@ template <class S> DEV SpecCtx<S> fs_rebuild(const SpecCtx<S> &cv, float *lds) {
   const Ctx c = fs_rebuild(cv, fs_lds_)
 
 
+// Walk the set bits of a mask three per trip: i0 is valid, i1 / i2 fall back to i0 with their flag cleared.  A loop with a
+// run-time trip count pays one dependent LDS round trip per iteration (a wave has no other work to hide it); three independent
+// element loads per trip cut a 9-element walk from 9 round trips to 3.
+#define FS_BITS3(mm, i0, i1, i2, h1, h2)             \
+  const int i0 = __ffs(mm) - 1; mm &= mm - 1;        \
+  const bool h1 = mm != 0;                           \
+  const int i1 = h1 ? __ffs(mm) - 1 : i0; mm &= mm - 1; \
+  const bool h2 = mm != 0;                           \
+  const int i2 = h2 ? __ffs(mm) - 1 : i0; mm &= mm - 1
+
 #define KI(field, idx) (c.I(c.ly.k_##field)[idx])
 #define KM_I(e) ((c.I(c.ly.k_M_ij)[e] >> 8) & 255)
 #define KM_J(e) (c.I(c.ly.k_M_ij)[e] & 255)
@@ -315,9 +325,11 @@ template <class Ctx> DEV void fs_crb_factor(const Ctx &c) {
   for (int b = c.lane; b < c.D.nr; b += 64) {
     float acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
-    for (int mm = KI(r_submask, b); mm; mm &= mm - 1) {
-      const float *I = L + c.ly.cinert + 10 * (__ffs(mm) - 1);
-      for (int k = 0; k < 10; k++) acc[k] += I[k];
+    for (int mm = KI(r_submask, b); mm;) {
+      FS_BITS3(mm, b0, b1, b2, h1, h2);
+      const float *I0 = L + c.ly.cinert + 10 * b0, *I1 = L + c.ly.cinert + 10 * b1, *I2 = L + c.ly.cinert + 10 * b2;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { const float x0 = I0[k], x1 = I1[k], x2 = I2[k]; acc[k] += x0 + (h1 ? x1 : 0.0f) + (h2 ? x2 : 0.0f); }
     }
     for (int k = 0; k < 10; k++) L[c.ly.crb + 10 * b + k] = acc[k];
   }
@@ -343,8 +355,19 @@ template <class Ctx> DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
     const int rowi = w & 0xfff, tb = rowi - li * (li + 1) / 2;
     const float *Mt = L + c.ly.M;
     float acc = 0;
-    for (int lj = 0; lj <= li; lj++) acc += Mt[rowi + lj] * L[off_v + a + lj];
-    for (int lj = li + 1; lj < n; lj++) acc += Mt[tb + lj * (lj + 1) / 2 + li] * L[off_v + a + lj];
+    // one walk over the row (left of the diagonal: the packed row itself, right of it: column li of the later rows), three
+    // independent entries per trip
+    for (int lj0 = 0; lj0 < n; lj0 += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int lj = lj0 + u;
+        const bool ok = lj < n;
+        const int ljc = ok ? lj : li;
+        const int adr = ljc <= li ? rowi + ljc : tb + ljc * (ljc + 1) / 2 + li;
+        const float mv = Mt[adr] * L[off_v + a + ljc];
+        acc += ok ? mv : 0.0f;
+      }
+    }
     L[off_y + i] = acc;
   }
   SYNC();

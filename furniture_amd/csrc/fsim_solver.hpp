@@ -180,7 +180,13 @@ template <class Ctx> DEV void fs_body_spatial(const Ctx &c, int off_vec) {
     S6 w = s6zero();
     {
       const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
-      for (int mm = ch & 0x3ffffff; mm; mm &= mm - 1) { int d = base + __ffs(mm) - 1; w = w + lds6(L + c.ly.cdof + 6 * d) * L[off_vec + d]; }
+      for (int mm = ch & 0x3ffffff; mm;) {
+        FS_BITS3(mm, e0, e1, e2, h1, h2);
+        const int d0 = base + e0, d1 = base + e1, d2 = base + e2;
+        const S6 s0 = lds6(L + c.ly.cdof + 6 * d0), s1 = lds6(L + c.ly.cdof + 6 * d1), s2 = lds6(L + c.ly.cdof + 6 * d2);
+        const float v0 = L[off_vec + d0], l1 = L[off_vec + d1], l2 = L[off_vec + d2], v1 = h1 ? l1 : 0.0f, v2 = h2 ? l2 : 0.0f;
+        w = w + s0 * v0 + s1 * v1 + s2 * v2;
+      }
     }
     sts6(L + c.ly.W + 6 * b, w);
   }
