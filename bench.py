@@ -141,7 +141,6 @@ def main():
         sl.rew = torch.zeros(ng, device=dev)
         sl.done = torch.zeros(ng, dtype=torch.uint8, device=dev)
         sl.info = torch.zeros((ng, INFO_DIM), dtype=torch.int32, device=dev)
-        sl.act = torch.empty((ng, sl.sim.dof_action), device=dev)
         sl.gen = torch.Generator(device=dev)
         sl.gen.manual_seed(SEED + rank * 64 + g)
         sl.inflight = False
@@ -157,19 +156,26 @@ def main():
             return
         sl.sim.sync()  # the handle's stream: step kernel + the gather chained behind it
         sl.inflight = False
-        need = sl.info[:, INFO_NEEDS_TABLE]
-        if bool(need.any()):  # host-side reference RNG stream for the envs that just consumed their reset table
-            need = need.cpu().numpy()
+        if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
+            need = sl.info[:, INFO_NEEDS_TABLE].cpu().numpy()
             mask = need > 0
             if (need > 1).any():  # an unstable env: the reference draws twice (reset inside step() + the worker's reset)
                 sl.tables.take(need > 1)
             p, nz = sl.tables.take(mask)
             sl.sim.set_reset_tables(p, nz, mask=mask)
 
+    # U(-1,1) actions of every step, generated on the device BEFORE the timed region (the contract: inputs resident in HBM when
+    # the clock starts) -- one slab-step's actions are a [ng, dof] slice; no torch kernel is launched inside the loop, where it
+    # would queue behind the step kernels' waves for up to a millisecond
+    total_steps = args.warmup + args.steps
+    for sl in slabs:
+        sl.actions = torch.empty((total_steps, ng, sl.sim.dof_action), device=dev).uniform_(-1, 1, generator=sl.gen)
+        sl.t = 0
+    torch.cuda.synchronize(dev)
+
     def launch(sl):
-        sl.act.uniform_(-1, 1, generator=sl.gen)
-        torch.cuda.current_stream(dev).synchronize()
-        sl.sim.step(sl.act, sl.obs, sl.rew, sl.done, sl.info)
+        sl.sim.step(sl.actions[sl.t], sl.obs, sl.rew, sl.done, sl.info)
+        sl.t += 1
         # ONE RCCL all-gather per slab-step (obs | reward | done packed), enqueued on the handle's stream right behind the step
         # kernel: no host synchronisation between the two
         sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)

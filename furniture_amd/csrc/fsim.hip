@@ -76,7 +76,7 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_physics(const DM
 template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
                                                  const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost,
-                                                 const float *init_state, const uint8_t *init_mask) {
+                                                 const float *init_state, const uint8_t *init_mask, int *nreset) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
@@ -99,6 +99,7 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
   io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
   io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * c.D.narmj : nullptr;
   io.n_noise = n_noise;
+  io.nreset = nreset;
   io.init_state = (init_state && init_mask && init_mask[env]) ? init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
   io.cost = cost ? cost + env : nullptr;
   io.t0 = t_entry;
@@ -194,7 +195,7 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, EnvCfg, float *, const float *, float *, float *, uint8_t *, int *, const float *,
-                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *);
+                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *, int *);
 struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; };
 
 struct fsim {
@@ -211,6 +212,7 @@ struct fsim {
   Layout *d_ly = nullptr;
   float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
   int *d_cost = nullptr, *d_order = nullptr; // longest-job-first scheduling (k_schedule)
+  int *d_nreset = nullptr, *h_nreset = nullptr; // envs that consumed their reset table in the last step launch (device counter, pinned host copy)
   float *d_init = nullptr;       // set_init_qpos: [n][nq + nv] state the masked envs' resets start from
   uint8_t *d_init_mask = nullptr;
   float *d_dense = nullptr; // dense-reward tables: DC_WORDS coefficients, then nsub rows of DS_WORDS
@@ -440,6 +442,8 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemsetAsync(s->d_aux, 0, (size_t)n_envs * s->auxstride * 4, s->stream));
   HIPCHK(hipMalloc(&s->d_cost, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_order, (size_t)n_envs * 4));
   HIPCHK(hipMemsetAsync(s->d_cost, 0, (size_t)n_envs * 4, s->stream));
+  HIPCHK(hipMalloc(&s->d_nreset, 4)); HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->h_nreset), 4, hipHostMallocDefault));
+  *s->h_nreset = 0;
   s->lpt = !getenv("FSIM_NO_LPT");
   // initial record: qpos0, default masks, weld data, env block zero
   {
@@ -486,7 +490,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask); hipFree(s->d_nreset); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -501,6 +505,7 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
   if (info_dim) *info_dim = FSIM_INFO_DIM; if (stride) *stride = s->ly.stride;
   return FSIM_OK;
 }
+extern "C" int fsim_tables_needed(const fsim_t *s) { return s && s->h_nreset ? *s->h_nreset : 0; }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
 extern "C" const char *fsim_kernel_variant(const fsim_t *s) { return s && s->ks.name ? s->ks.name : ""; }
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
@@ -659,11 +664,13 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   HIPCHK(hipSetDevice(s->device));
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
+  if (do_step) hipMemsetAsync(s->d_nreset, 0, 4, s->stream);
   if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
   if (s->timing) timing_begin(s);
   hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
-                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr, s->d_init, s->d_init_mask);
+                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr, s->d_init, s->d_init_mask, do_step ? s->d_nreset : nullptr);
+  if (do_step) hipMemcpyAsync(s->h_nreset, s->d_nreset, 4, hipMemcpyDeviceToHost, s->stream);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

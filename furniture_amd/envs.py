@@ -374,9 +374,8 @@ class FurnitureBatchEnv:
     def step_wait(self):
         self.sim.sync()
         if self.refill_tables_every_step:
-            need = self._info[:, INFO_NEEDS_TABLE]
-            if bool(need.any()):
-                need = need.cpu().numpy()
+            if self.sim.tables_needed():
+                need = self._info[:, INFO_NEEDS_TABLE].cpu().numpy()
                 self._tables_fresh[need > 0] = False
                 self._refill(need > 0, skip=need > 1)
         info = self._info

@@ -94,6 +94,7 @@ def lib():
         L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
         L.fsim_env_block_words.argtypes = [ctypes.c_void_p]
         L.fsim_kernel_variant.argtypes = [ctypes.c_void_p]
+        L.fsim_tables_needed.argtypes = [ctypes.c_void_p]
         L.fsim_replay_is_aligned.argtypes = [ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 8
         L.fsim_replay_try_connect.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
         L.fsim_replay_touch_scan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
@@ -116,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state",
+    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed",
 ]
 
 
@@ -289,6 +290,10 @@ class FSim:
 
     def step(self, action, obs, reward, done, info):
         self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
+
+    def tables_needed(self):
+        """envs that consumed their reset table in the last step (valid after sync())"""
+        return int(lib().fsim_tables_needed(self._h))
 
     def set_max_episode_steps(self, n):
         self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))

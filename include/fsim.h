@@ -141,6 +141,10 @@ int fsim_reset(fsim_t *, const uint8_t *mask_dev, void *obs_dev /* float32 | bfl
 int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bfloat16 with cfg.obs_bf16 */, float *reward_dev, uint8_t *done_dev,
               int32_t *info_dev);
 
+/* Number of envs whose FSIM_INFO_NEEDS_TABLE is set by the last fsim_step, valid once that step has completed (fsim_sync): lets the
+ * host skip the scan of the info block on the (many) steps in which no episode ended. */
+int fsim_tables_needed(const fsim_t *);
+
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);
 
