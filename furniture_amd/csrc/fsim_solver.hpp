@@ -812,9 +812,13 @@ template <> struct FsMfmaStep<31> {
 // first: first big-phase lane of the island, n: its size (17..31).  returns the bad flag (uniform)
 // (a real function: its 16-register accumulator tile must not weigh on the register allocation of the substep loop, and
 //  only the rare env with a big island ever calls it)
+#ifdef FSIM_MFMA_INLINE
+template <class Ctx> DEV int fs_chol_mfma(const Ctx &c, int mp, int first, int n) {
+#else
 template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, int mp_, int first_, int n_) {
   FS_REBUILD_CTX(cv);
   const int mp = __builtin_amdgcn_readfirstlane(mp_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_);
+#endif
   float *L = c.L;
   const float *H = L + c.ly.H;
   const int nv = c.D.nv;
