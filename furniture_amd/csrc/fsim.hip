@@ -442,8 +442,11 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemsetAsync(s->d_aux, 0, (size_t)n_envs * s->auxstride * 4, s->stream));
   HIPCHK(hipMalloc(&s->d_cost, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_order, (size_t)n_envs * 4));
   HIPCHK(hipMemsetAsync(s->d_cost, 0, (size_t)n_envs * 4, s->stream));
-  HIPCHK(hipMalloc(&s->d_nreset, 4)); HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->h_nreset), 4, hipHostMallocDefault));
+  // counter in pinned host memory the kernel increments in place (system-scope atomic, only when an episode ends): no copy or
+  // memset kernel queues behind the step kernel's waves
+  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->h_nreset), 64, hipHostMallocMapped));
   *s->h_nreset = 0;
+  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_nreset), s->h_nreset, 0));
   s->lpt = !getenv("FSIM_NO_LPT");
   // initial record: qpos0, default masks, weld data, env block zero
   {
@@ -490,7 +493,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask); hipFree(s->d_nreset); if (s->h_nreset) hipHostFree(s->h_nreset);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -664,13 +667,12 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   HIPCHK(hipSetDevice(s->device));
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
-  if (do_step) hipMemsetAsync(s->d_nreset, 0, 4, s->stream);
+  if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
   if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
   if (s->timing) timing_begin(s);
   hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
                      sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr, s->d_init, s->d_init_mask, do_step ? s->d_nreset : nullptr);
-  if (do_step) hipMemcpyAsync(s->h_nreset, s->d_nreset, 4, hipMemcpyDeviceToHost, s->stream);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

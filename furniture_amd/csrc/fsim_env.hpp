@@ -1079,7 +1079,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       io.info[FSIM_INFO_LAST_SITE1] = E[E_SITE1]; io.info[FSIM_INFO_LAST_SITE2] = E[E_SITE2];
       io.info[FSIM_INFO_EPISODE_LENGTH] = E[E_EPISODE_LENGTH]; io.info[FSIM_INFO_CONNECTED_THIS_STEP] = E[E_CONNECTED_THIS_STEP];
       io.info[FSIM_INFO_NEEDS_TABLE] = (terminal && cfg.auto_reset) ? (fail == 2 ? 2 : 1) : 0; // 2: drop one draw first (see the unstable branch)
-      if (terminal && cfg.auto_reset && io.nreset) atomicAdd(io.nreset, 1);
+      if (terminal && cfg.auto_reset && io.nreset) __hip_atomic_fetch_add(io.nreset, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
       io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
