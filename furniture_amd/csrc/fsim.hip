@@ -107,6 +107,16 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   SYNC();
 #ifdef FSIM_PROFILE
+#ifdef FSIM_TIMELINE
+  // development: when and where this workgroup ran (scripts/dev/timeline.py: how many are resident at a time)
+  if (lane == 0) {
+    int *ps_ = reinterpret_cast<int *>(L + c.ly.scal);
+    ps_[53] = (int)((t_entry >> 6) & 0x7fffffff); ps_[54] = (int)((clock64() >> 6) & 0x7fffffff);
+    ps_[50] = (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID, 32 bits
+    int xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ps_[49] = xcc;
+  }
+  SYNC();
+#endif
   if (prof && lane < 48) prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + lane] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
 #endif
   store_record(rec, L, c.ly.stride, lane);

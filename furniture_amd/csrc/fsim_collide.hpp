@@ -8,10 +8,11 @@
 #pragma once
 #include "fsim_physics.hpp"
 
-// contact slot (FSIM_CONW = 24 words).  Only the normal is stored; the tangents are rebuilt where needed (fs_frame).
+// contact slot (FSIM_CONW: 18 words + 1 pad).  Only the normal is stored; the tangents are rebuilt where needed (fs_frame);
+// J*a and J*p of the Newton solve live in registers (SolSlot).
 // C_DIST / C_INCM are consumed by fs_make_constraints before it writes C_AREF + 1 / + 2 over them.
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2 = 10, C_G1 = 11, C_G2 = 12, C_AREF = 13,
-       C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17, C_JAR = 18, C_JP = 21 };
+       C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17 };
 
 __constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
 

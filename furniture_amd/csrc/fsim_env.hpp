@@ -172,6 +172,9 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
     t0m = wave_or(t0m); t1m = wave_or(t1m);
     if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.D.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
   }
+#ifdef FSIM_TIMELINE
+  long long tg0_ = clock64();
+#endif
   // instability guard (mj_checkPos / mj_checkVel / mj_checkAcc: NaN, Inf or a value beyond 1e10 in qpos, qvel or qacc -- the
   // warnings mujoco_py turns into the MujocoException that _do_simulation catches, furniture.py:2889-2897)
   int bad = 0;
@@ -180,6 +183,9 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
   bad = wave_or(bad);
   if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
   SYNC();
+#ifdef FSIM_TIMELINE
+  { long long tg1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[18] += (int)((tg1_ - tg0_) >> 4); }
+#endif
 }
 
 // The ONE out-of-line physics routine: n x (forward [+ finger-touch scan on the last pass] + integrate), or a single
@@ -205,7 +211,13 @@ template <bool CTRL, class Ctx> __device__ __noinline__ void fs_substeps_t(Ctx c
     fs_forward_body(c);
     if (CTRL && s < 0) continue;
     if ((mode & 2) && s == n - 1) fs_touch_flags(c);
+#ifdef FSIM_TIMELINE
+    long long ti0_ = clock64();
+#endif
     fs_integrate_body(c);
+#ifdef FSIM_TIMELINE
+    { long long ti1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16] += (int)((ti1_ - ti0_) >> 4); }
+#endif
   }
 }
 template <class Ctx> DEV void fs_substeps(const Ctx &c, int n, int mode) { fs_substeps_t<false>(c, n, mode); }
@@ -981,8 +993,15 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     fs_substeps_t<true>(c, cfg.n_substeps, 2);
   } else {
     env_gravity_comp(c);
+#ifdef FSIM_TIMELINE
+    long long tl0_ = clock64();
+    if (c.lane == 0) scal[48] = (int)((tl0_ - io.t0) >> 4);
+#endif
     // _do_simulation: n_substeps x sim.step()
     fs_substeps(c, cfg.n_substeps, 2);
+#ifdef FSIM_TIMELINE
+    { long long tl1_ = clock64(); if (c.lane == 0) { scal[51] = (int)((tl1_ - tl0_) >> 4); scal[52] = (int)(tl1_ >> 4); } }
+#endif
   }
   int bad = scal[SC_BAD] & 2;
   if (bad) {
@@ -1101,4 +1120,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   if (terminal && cfg.auto_reset) env_reset(c, &cfg, &io); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
   else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
   env_write_obs(c, cfg, io);
+#ifdef FSIM_TIMELINE
+  if (c.lane == 0) scal[52] = (int)(clock64() >> 4) - scal[52];
+#endif
 }

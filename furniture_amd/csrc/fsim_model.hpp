@@ -10,7 +10,8 @@
 #include <stdint.h>
 
 #define FSIM_MAXANG 8
-#define FSIM_CONW 25     // words per contact slot: 24 used + 1 pad -- an ODD stride spreads lane = slot accesses over all 64 LDS banks (24 would hit 8)
+#define FSIM_CONW 19     // words per contact slot: 18 used + 1 pad -- an ODD stride spreads lane = slot accesses over all 64 LDS banks (18 would hit 32)
+#define FSIM_PCAP 192    // body-pair projection items cached per substep (fs_pair_cache; a gripper holding a part that touches another: 132)
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
 #define FSIM_MAXSURV 48  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
@@ -84,6 +85,7 @@ struct Layout {
   int gpos, gmat, surv, con, weld, lim, W, G, scal;
   int hmap;   // per-substep island map of the Newton system (FSIM_MAPW(nv) words, format at fs_build_map in fsim_solver.hpp)
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
+  int pitem;  // [FSIM_PCAP] body-pair projection items of this substep (fs_pair_cache)
   int lds_words, ncon_max;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
   int k_dof_parent, k_r_submask, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_chain, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
@@ -166,7 +168,7 @@ constexpr Layout make_layout(const LayoutIn &in) {
     // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
     ly.W = ly.gpos; ly.G = ly.gpos + 6 * in.nr;
   }
-  TAKE(surv, FSIM_MAXSURV);
+  TAKE(surv, FSIM_MAXSURV); TAKE(pitem, FSIM_PCAP);
   TAKE(con, FSIM_CONW * in.ncon_max); TAKE(weld, FSIM_WELDW * in.neq); TAKE(lim, FSIM_LIMW * 2 * in.nlim);
   TAKE(scal, SC_WORDS); TAKE(hmap, FSIM_MAPW(in.nv));
   // LDS model cache

@@ -210,6 +210,7 @@ struct SolSlot {
   int ldof;
   float ld, laref, lsign, ljar, ljp;
   bool anyweld;            // (wave-uniform) some weld is active
+  int pid, npc, ptot;      // body-pair cache (fs_pair_cache): this slot's pair block (-1 none), pairs (wave-uniform; -1 = not cached), items
 };
 template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
   float *L = c.L;
@@ -238,7 +239,58 @@ template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
     if (c.I(c.ly.eqactive)[e]) { aw = 1; tb |= (1 << GP(c.m.eq_rbody1)[e]) | (1 << GP(c.m.eq_rbody2)[e]); }
   S.anyweld = __ballot(aw != 0) != 0;
   S.tb = wave_or(tb) & ~1;
+  S.pid = -1; S.npc = 0; S.ptot = 0;
   return S;
+}
+
+// ---- body-pair cache.  A contact between two MOVING bodies (lo, hi) adds a cross block on chain(lo) x chain(hi) to the Newton
+// Hessian (fs_hessian).  Which pairs exist, which slot feeds which pair block and the (pair, dof, dof) triple of every entry
+// to project depend on the contact list only, i.e. they are fixed for the substep, while fs_hessian runs once per Newton
+// iteration (5-6 times per substep when a gripper holds a part): the leader election, the chain-length prefix sums and the
+// item -> (pair, e1, e2) -> (d1, d2) decoding cost five dependent LDS round trips per 64 items and iteration.  Built once per
+// solve: S.pid per slot and one word per item (pair | d1 << 8 | d2 << 16) in Layout::pitem.  More than FSIM_NPAIR pairs or FSIM_PCAP items: S.npc = -1, fs_hessian takes
+// its multi-pass path.
+template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
+  const int b1 = S.bt1 & 255, b2 = S.bt2 & 255, blo = min(b1, b2), bhi = max(b1, b2);
+  const bool haskey = S.act && blo != 0 && bhi != blo;
+  unsigned long long pending = __ballot(haskey);
+  if (!pending) return; // (uniform) no moving-moving contact: nothing to do
+  const int key = blo * 256 + bhi;
+  int *pitem = c.I(c.ly.pitem);
+  int np = 0, total = 0;
+  int plo[FSIM_NPAIR], phi_[FSIM_NPAIR], pbase[FSIM_NPAIR + 1]; // wave-uniform
+  for (int q = 0; q < FSIM_NPAIR; q++) { plo[q] = 0; phi_[q] = 0; pbase[q] = 0x7fffffff; }
+  pbase[FSIM_NPAIR] = 0x7fffffff;
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < FSIM_NPAIR + 1; q++) {
+    if (!pending) break;
+    if (q == FSIM_NPAIR) { ok = false; break; }
+    const int leader = __ffsll((long long)pending) - 1;
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const bool mt = haskey && key == k;
+    if (mt) S.pid = q;
+    plo[q] = k >> 8; phi_[q] = k & 255; pbase[q] = total;
+    total += KI(r_chainlen, k >> 8) * KI(r_chainlen, k & 255);
+    pending &= ~__ballot(mt);
+    np = q + 1;
+  }
+  total = __builtin_amdgcn_readfirstlane(total);
+  if (!ok || total > FSIM_PCAP) { S.pid = -1; S.npc = -1; return; }
+  S.npc = np; S.ptot = total;
+  for (int it = c.lane; it < total; it += 64) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < FSIM_NPAIR; t++) q += it >= pbase[t]; // (unused pairs: base = INT_MAX)
+    int lo = plo[0], hi = phi_[0], base = pbase[0];
+#pragma unroll
+    for (int t = 1; t < FSIM_NPAIR; t++) if (q == t) { lo = plo[t]; hi = phi_[t]; base = pbase[t]; }
+    const int rem = it - base, nhi = KI(r_chainlen, hi);
+    const int e1 = (int)(((float)rem + 0.5f) / (float)nhi), e2 = rem - e1 * nhi;
+    const int d1 = KI(chain_dofs, KI(r_chainadr, lo) + e1), d2 = KI(chain_dofs, KI(r_chainadr, hi) + e2);
+    pitem[it] = q | (d1 << 8) | (d2 << 16);
+  }
+  // (no barrier: fs_hessian's first barrier orders these stores before its item loop)
 }
 
 // S.jar (to_jar: minus aref) or S.jp = J * vec, using W from fs_body_spatial(vec)
@@ -484,7 +536,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
   float *A = L + c.ly.hA;                    // [nr][21]: aa(xx,xy,xz,yy,yz,zz) al(9, row = ang comp) ll(xx,xy,xz,yy,yz,zz)
   float *X = L + c.ly.hP;                    // [NPAIR][36] cross blocks, row = lo's spatial comp, col = hi's
   int *pmeta = c.I(c.ly.hP + 36 * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
-#ifdef FSIM_PROFILE
+#if defined(FSIM_PROFILE) && !defined(FSIM_NPPROF) && !defined(FSIM_CHOLPROF) && !defined(FSIM_TIMELINE) // (those reuse these profile slots)
   long long th_ = clock64();
 #define FS_HPROF(slot) do { long long t1h_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[slot] += (int)((t1h_ - th_) >> 4); th_ = t1h_; } while (0)
 #else
@@ -492,6 +544,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
 #endif
   for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
   for (int i = c.lane; i < 21 * c.D.nr; i += 64) A[i] = 0;
+  if (S.npc > 0) for (int i = c.lane; i < 36 * S.npc; i += 64) X[i] = 0; // cached pairs: the blocks are filled with the body blocks below
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
   const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
@@ -508,6 +561,17 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
   // rows of K, G = [r]x K (ang-lin block), and the diagonal blocks
   const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
   V3 Glo0 = v3(0, 0, 0), Glo1 = Glo0, Glo2 = Glo0, rhi = Glo0;
+  // X = [[Glo * Rhi, Glo], [K * Rhi, K]],  v' * Rhi = v' * (-[rhi]x) = (rhi x v)'  row-wise
+#define FS_ADD_X(Xp_) do {                                                                                                  \
+    float *Xp = (Xp_);                                                                                                      \
+    V3 x0 = cross(rhi, Glo0), x1 = cross(rhi, Glo1), x2 = cross(rhi, Glo2), y0 = cross(rhi, K0), y1 = cross(rhi, K1), y2 = cross(rhi, K2); \
+    atomicAdd(Xp + 0, x0.x); atomicAdd(Xp + 1, x0.y); atomicAdd(Xp + 2, x0.z); atomicAdd(Xp + 3, Glo0.x); atomicAdd(Xp + 4, Glo0.y); atomicAdd(Xp + 5, Glo0.z); \
+    atomicAdd(Xp + 6, x1.x); atomicAdd(Xp + 7, x1.y); atomicAdd(Xp + 8, x1.z); atomicAdd(Xp + 9, Glo1.x); atomicAdd(Xp + 10, Glo1.y); atomicAdd(Xp + 11, Glo1.z); \
+    atomicAdd(Xp + 12, x2.x); atomicAdd(Xp + 13, x2.y); atomicAdd(Xp + 14, x2.z); atomicAdd(Xp + 15, Glo2.x); atomicAdd(Xp + 16, Glo2.y); atomicAdd(Xp + 17, Glo2.z); \
+    atomicAdd(Xp + 18, y0.x); atomicAdd(Xp + 19, y0.y); atomicAdd(Xp + 20, y0.z); atomicAdd(Xp + 21, K0.x); atomicAdd(Xp + 22, K0.y); atomicAdd(Xp + 23, K0.z); \
+    atomicAdd(Xp + 24, y1.x); atomicAdd(Xp + 25, y1.y); atomicAdd(Xp + 26, y1.z); atomicAdd(Xp + 27, K1.x); atomicAdd(Xp + 28, K1.y); atomicAdd(Xp + 29, K1.z); \
+    atomicAdd(Xp + 30, y2.x); atomicAdd(Xp + 31, y2.y); atomicAdd(Xp + 32, y2.z); atomicAdd(Xp + 33, K2.x); atomicAdd(Xp + 34, K2.y); atomicAdd(Xp + 35, K2.z); \
+  } while (0)
   if (on) {
 #pragma unroll
     for (int side = 0; side < 2; side++) {
@@ -526,6 +590,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
       atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]);
       if (side == 0) { Glo0 = G0; Glo1 = G1; Glo2 = G2; } else rhi = rr;
     }
+    if (S.pid >= 0) FS_ADD_X(X + 36 * S.pid); // cached pair block of this slot (zeroed above)
   }
   FS_HPROF(48);
   // the subtree sums are only needed when a non-root body (a robot link beyond the base) carries a contact block
@@ -561,7 +626,34 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
   }
   SYNC();
   FS_HPROF(50);
-  // ---- body-pair cross blocks, FSIM_NPAIR distinct pairs per pass
+  // ---- body-pair cross blocks: -cdof_d1' X cdof_d2 on chain(lo) x chain(hi), one lane per entry
+#define FS_PAIR_ITEM(q_, d1_, d2_) do {                                                   \
+    const float *Xq = X + 36 * (q_);                                                      \
+    const float *s1 = L + c.ly.cdof + 6 * (d1_), *s2 = L + c.ly.cdof + 6 * (d2_);        \
+    float v = 0;                                                                          \
+    _Pragma("unroll") for (int rr = 0; rr < 6; rr++) {                                    \
+      float t = 0;                                                                        \
+      _Pragma("unroll") for (int cc = 0; cc < 6; cc++) t += Xq[6 * rr + cc] * s2[cc];     \
+      v += s1[rr] * t;                                                                    \
+    }                                                                                     \
+    if ((d1_) == (d2_)) v *= 2.0f;                                                        \
+    atomicAdd(L + c.ly.H + fs_hidx(c, hm, max((d1_), (d2_)), min((d1_), (d2_))), -v);     \
+  } while (0)
+  if (S.npc > 0) {
+    // cached (fs_pair_cache): the blocks were filled with the body blocks; a pair none of whose contacts is in an active cone
+    // zone is skipped -- its dofs may lie in different islands, where fs_hidx means nothing
+    int pairon = 0;
+#pragma unroll
+    for (int q = 0; q < FSIM_NPAIR; q++) pairon |= (__ballot(on && S.pid == q) != 0) << q;
+    if (pairon) {
+      const int *pitem = c.I(c.ly.pitem);
+      for (int it = c.lane; it < S.ptot; it += 64) {
+        const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = w >> 16;
+        if ((pairon >> q) & 1) FS_PAIR_ITEM(q, d1, d2);
+      }
+    }
+  } else if (S.npc < 0) {
+  // more pairs / items than the cache holds: FSIM_NPAIR distinct pairs per pass, elected and decoded on the fly
   bool haskey = on && blo != 0 && bhi != blo;
   const int key = blo * 256 + bhi;
   unsigned long long pending = __ballot(haskey);
@@ -581,18 +673,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
     }
     for (int i = c.lane; i < 36 * np; i += 64) X[i] = 0;
     SYNC();
-    if (pid >= 0) {
-      // X = [[Glo * Rhi, Glo], [K * Rhi, K]],  v' * Rhi = v' * (-[rhi]x) = (rhi x v)'  row-wise
-      float *Xp = X + 36 * pid;
-      V3 x0 = cross(rhi, Glo0), x1 = cross(rhi, Glo1), x2 = cross(rhi, Glo2), y0 = cross(rhi, K0), y1 = cross(rhi, K1), y2 = cross(rhi, K2);
-      atomicAdd(Xp + 0, x0.x); atomicAdd(Xp + 1, x0.y); atomicAdd(Xp + 2, x0.z); atomicAdd(Xp + 3, Glo0.x); atomicAdd(Xp + 4, Glo0.y); atomicAdd(Xp + 5, Glo0.z);
-      atomicAdd(Xp + 6, x1.x); atomicAdd(Xp + 7, x1.y); atomicAdd(Xp + 8, x1.z); atomicAdd(Xp + 9, Glo1.x); atomicAdd(Xp + 10, Glo1.y); atomicAdd(Xp + 11, Glo1.z);
-      atomicAdd(Xp + 12, x2.x); atomicAdd(Xp + 13, x2.y); atomicAdd(Xp + 14, x2.z); atomicAdd(Xp + 15, Glo2.x); atomicAdd(Xp + 16, Glo2.y); atomicAdd(Xp + 17, Glo2.z);
-      atomicAdd(Xp + 18, y0.x); atomicAdd(Xp + 19, y0.y); atomicAdd(Xp + 20, y0.z); atomicAdd(Xp + 21, K0.x); atomicAdd(Xp + 22, K0.y); atomicAdd(Xp + 23, K0.z);
-      atomicAdd(Xp + 24, y1.x); atomicAdd(Xp + 25, y1.y); atomicAdd(Xp + 26, y1.z); atomicAdd(Xp + 27, K1.x); atomicAdd(Xp + 28, K1.y); atomicAdd(Xp + 29, K1.z);
-      atomicAdd(Xp + 30, y2.x); atomicAdd(Xp + 31, y2.y); atomicAdd(Xp + 32, y2.z); atomicAdd(Xp + 33, K2.x); atomicAdd(Xp + 34, K2.y); atomicAdd(Xp + 35, K2.z);
-      haskey = false;
-    }
+    if (pid >= 0) { FS_ADD_X(X + 36 * pid); haskey = false; }
     SYNC();
     for (int it = c.lane; it < total; it += 64) {
       int q = 0;
@@ -602,21 +683,13 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
       int nhi = KI(r_chainlen, hi);
       int e1 = (int)(((float)rem + 0.5f) / (float)nhi), e2 = rem - e1 * nhi;
       int d1 = KI(chain_dofs, KI(r_chainadr, lo) + e1), d2 = KI(chain_dofs, KI(r_chainadr, hi) + e2);
-      const float *Xp = X + 36 * q;
-      const float *s1 = L + c.ly.cdof + 6 * d1, *s2 = L + c.ly.cdof + 6 * d2;
-      float v = 0;
-#pragma unroll
-      for (int rr = 0; rr < 6; rr++) {
-        float t = 0;
-#pragma unroll
-        for (int cc = 0; cc < 6; cc++) t += Xp[6 * rr + cc] * s2[cc];
-        v += s1[rr] * t;
-      }
-      if (d1 == d2) v *= 2.0f;
-      atomicAdd(L + c.ly.H + fs_hidx(c, hm, max(d1, d2), min(d1, d2)), -v);
+      FS_PAIR_ITEM(q, d1, d2);
     }
     SYNC();
   }
+  }
+#undef FS_PAIR_ITEM
+#undef FS_ADD_X
   FS_HPROF(53);
   if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
   if (S.anyweld)
@@ -748,13 +821,29 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
   const int l = (B >> 12) & 63, nI = (B >> 18) & 127, rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
   const int p0 = pos - l; // first position of the lane's island inside its group
   fs_f2 A[NLOC / 2];
+  {
+    // entry (l, lq) of the island's packed triangle, lq = q - p0: tri(max) + min.  Unconditional loads on an unclamped index
+    // (at worst 15 words below the island's base, inside the LDS image) and a selection afterwards: behind `ok ? load : 0`
+    // every entry became an exec-masked block of ~20 instructions
+    float e[NLOC];
+    const int triL = l * (l + 1) / 2;
+    int lq = -p0, triQ = p0 * (p0 - 1) / 2; // tri(lq) for lq = -p0 (only used once lq >= l >= 0)
 #pragma unroll
-  for (int q = 0; q < NLOC; q++) {
-    const int lq = q - p0;
-    const bool ok = row && q < steps && lq >= 0 && lq < nI;
-    const int hi = max(l, lq), lo = min(l, lq);
-    const float e = ok ? H[hI + hi * (hi + 1) / 2 + lo] : 0.0f;
-    FS_ROW(A, q) = (!row && q == pos) ? 1.0f : e; // a lane without a dof: unit diagonal, zero row
+    for (int q = 0; q < NLOC; q++) {
+      e[q] = H[hI + (l >= lq ? triL + lq : triQ + l)];
+      lq++; triQ += lq;
+    }
+    if (NLOC == 12)
+      asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
+    else
+#pragma unroll
+      for (int q0 = 0; q0 < NLOC; q0 += 8)
+        asm volatile("" : "+v"(e[q0]), "+v"(e[q0 + 1]), "+v"(e[q0 + 2]), "+v"(e[q0 + 3]), "+v"(e[q0 + 4]), "+v"(e[q0 + 5]), "+v"(e[q0 + 6]), "+v"(e[q0 + 7]));
+#pragma unroll
+    for (int q = 0; q < NLOC; q++) {
+      const bool ok = row && q < steps && (unsigned)(q - p0) < (unsigned)nI;
+      FS_ROW(A, q) = (!row && q == pos) ? 1.0f : (ok ? e[q] : 0.0f); // a lane without a dof: unit diagonal, zero row
+    }
   }
   float b = row ? -L[c.ly.grad + dof] : 0.0f, mydinv = 0.0f, dmin = 1.0f;
   FsCholStep<NLOC, 0, BC>::fwd(A, b, mydinv, dmin, pos, steps, bc);
@@ -777,17 +866,37 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
 typedef float fs_f16v __attribute__((ext_vector_type(16)));
 template <int P> struct FsMfmaStep {
   static constexpr int VP = 4 * (P >> 3) + (P & 3), HP = (P >> 2) & 1;
+  // forward: pivots P and P + 1 (P even: both rows sit in the same half, registers VP and VP + 1) with ONE MFMA -- the
+  // instruction contracts over K = 2 (lanes 0..31 carry k = 0, lanes 32..63 k = 1), so it applies two rank-1 updates at once.
+  // Row P + 1 after pivot P's update is formed ahead of the MFMA on the vector ALU (one broadcast + one FMA: the same fmaf the
+  // matrix core performs), pivot P + 1's scaled row follows from it, v_permlane32_swap moves it to the other half of the
+  // operand register.  One MFMA latency (64 cycles + the 17-cycle read-after-MFMA gap) per TWO pivots.
   DEV static void fwd(fs_f16v &D, float &myrinv, float &dmin, const int n, const int lane) {
+    static_assert((P & 1) == 0, "pivots are taken in pairs");
     if (P < n) {
-      const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VP]), 32 * HP + P));
-      dmin = fminf(dmin, d);
-      const float rinv = rsqrtf(fmaxf(d, 1e-30f));
+      const float d0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VP]), 32 * HP + P));
+      dmin = fminf(dmin, d0);
+      const float r0 = rsqrtf(fmaxf(d0, 1e-30f));
       // lanes of half HP with column > P: one unsigned range test
-      const bool cols = (unsigned)(lane - (32 * HP + P + 1)) < (unsigned)(31 - P);
-      const float u = cols ? D[VP] * rinv : 0.0f;
-      myrinv = (lane & 31) == P ? rinv : myrinv;
-      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u, -u, D, 0, 0, 0);
-      FsMfmaStep<P + 1>::fwd(D, myrinv, dmin, n, lane);
+      const bool cols0 = (unsigned)(lane - (32 * HP + P + 1)) < (unsigned)(31 - P);
+      const float u0 = cols0 ? D[VP] * r0 : 0.0f;
+      myrinv = (lane & 31) == P ? r0 : myrinv;
+      float A = u0;
+      if (P + 1 < 31) {
+        const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u0), 32 * HP + P + 1)); // L[P + 1][P]
+        const float row1 = __builtin_fmaf(-m, u0, D[VP + 1]); // row P + 1 after pivot P (columns > P; the others are not used)
+        const float d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row1), 32 * HP + P + 1));
+        dmin = fminf(dmin, P + 1 < n ? d1 : 1.0f); // (n odd: row n is empty, d1 = 0, u1 = 0)
+        const float r1 = rsqrtf(fmaxf(d1, 1e-30f));
+        const bool cols1 = (unsigned)(lane - (32 * HP + P + 2)) < (unsigned)(30 - P);
+        const float u1 = cols1 ? row1 * r1 : 0.0f;
+        myrinv = (lane & 31) == P + 1 ? r1 : myrinv;
+        // u0, u1 are zero outside half HP: swapping u0's upper with u1's lower half leaves [U0 | U1] in one of the two results
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);
+        A = __uint_as_float(sw[HP]);
+      }
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(A, -A, D, 0, 0, 0);
+      FsMfmaStep<P + 2>::fwd(D, myrinv, dmin, n, lane);
     }
   }
   DEV static void bwd(const fs_f16v &D, const float myrinv, float &acc, float &res, const int n, const int lane) {
@@ -797,8 +906,8 @@ template <int P> struct FsMfmaStep {
       const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[VQ]), 32 * HQ + 31));
       const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q));
       const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), Q + 32));
-      const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrinv), Q));
-      const float xq = r * r * (sy - t0 - t1);
+      const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myrinv), Q)); // (the caller passes 1 / d_Q = rinv_Q^2)
+      const float xq = r2 * (sy - t0 - t1);
       acc = (unsigned)(lane - 32 * HQ) < (unsigned)Q ? __builtin_fmaf(D[VQ], xq, acc) : acc; // half HQ, columns < Q
       res = lane == Q ? xq : res;
     }
@@ -806,44 +915,68 @@ template <int P> struct FsMfmaStep {
   }
 };
 template <> struct FsMfmaStep<31> {
-  DEV static void fwd(fs_f16v &, float &, float &, const int, const int) {}
   DEV static void bwd(const fs_f16v &, const float, float &, float &, const int, const int) {}
+};
+template <> struct FsMfmaStep<32> {
+  DEV static void fwd(fs_f16v &, float &, float &, const int, const int) {}
 };
 // first: first big-phase lane of the island, n: its size (17..31).  returns the bad flag (uniform)
 // (a real function: its 16-register accumulator tile must not weigh on the register allocation of the substep loop, and
 //  only the rare env with a big island ever calls it)
-#ifdef FSIM_MFMA_INLINE
-template <class Ctx> DEV int fs_chol_mfma(const Ctx &c, int mp, int first, int n) {
-#else
-template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, int mp_, int first_, int n_) {
-  FS_REBUILD_CTX(cv);
+// (the LDS base travels as a 32-bit LDS address: naming the dynamic-LDS symbol inside a non-kernel function costs a table lookup
+//  -- s_getpc + s_load + wait, ~400 cycles -- at every use the compiler does not merge)
+typedef __attribute__((address_space(3))) float fs_lds_f;
+template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_) {
+  float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
+  const Ctx c = fs_rebuild(cv, lds_);
   const int mp = __builtin_amdgcn_readfirstlane(mp_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_);
-#endif
   float *L = c.L;
   const float *H = L + c.ly.H;
   const int nv = c.D.nv;
   float *rhs = L + c.ly.hA; // 32 words of scratch: the Hessian body blocks (>= 21 nr + 160 words) are dead once H is assembled
   const int k = c.lane & 31, h = c.lane >> 5;
-  int dofk = 0;
-  if (c.lane < 32) {
-    dofk = k < n ? (c.I(mp)[nv + first + k] >> 8) & 255 : 0;
-    rhs[k] = k < n ? -L[c.ly.grad + dofk] : 0.0f;
-  }
-  const int hI = __builtin_amdgcn_readfirstlane(c.I(mp)[(c.I(mp)[nv + first] >> 8) & 255] & 0xfff); // packed base of the island (its first dof has l = 0)
+  // every load below is unconditional on a clamped index and the selection follows: behind `if` the 32 reads of the tile
+  // became 32 exec-masked blocks with a wait each
+  const int lw = c.I(mp)[nv + first + min(k, n - 1)];
+  const int dofk = (lw >> 8) & 255;
+  const float gk = L[c.ly.grad + dofk];
+  const int hI = __builtin_amdgcn_readfirstlane(c.I(mp)[__builtin_amdgcn_readfirstlane(dofk)] & 0xfff); // packed base of the island (its first dof -- lane 0's -- has l = 0)
+  if (c.lane < 32) rhs[k] = k < n ? -gk : 0.0f;
   SYNC();
   fs_f16v D;
+  float eH[16], eR[16];
+  // element (i, k) of the packed lower triangle: tri(max) + min.  The index is NOT clamped for rows / columns outside the
+  // island: hI + 527 words is inside the LDS image whatever follows H, and the selection below drops what was read
+  const int triK = k * (k + 1) / 2;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int i0 = 8 * (v >> 2) + (v & 3), i = i0 + 4 * h;
+    const int triI = h ? (i0 + 4) * (i0 + 5) / 2 : i0 * (i0 + 1) / 2;
+    eH[v] = H[hI + (i >= k ? triI + k : triK + i)];
+    eR[v] = rhs[i]; // column 31 (lanes 31 and 63): the right-hand side.  (row 31 is never read: zero)
+  }
+  // (pins the 32 loads where they are: the compiler otherwise sinks each of them into the branch of the selection below)
+  asm volatile("" : "+v"(eH[0]), "+v"(eH[1]), "+v"(eH[2]), "+v"(eH[3]), "+v"(eH[4]), "+v"(eH[5]), "+v"(eH[6]), "+v"(eH[7]),
+                    "+v"(eH[8]), "+v"(eH[9]), "+v"(eH[10]), "+v"(eH[11]), "+v"(eH[12]), "+v"(eH[13]), "+v"(eH[14]), "+v"(eH[15]));
+  asm volatile("" : "+v"(eR[0]), "+v"(eR[1]), "+v"(eR[2]), "+v"(eR[3]), "+v"(eR[4]), "+v"(eR[5]), "+v"(eR[6]), "+v"(eR[7]),
+                    "+v"(eR[8]), "+v"(eR[9]), "+v"(eR[10]), "+v"(eR[11]), "+v"(eR[12]), "+v"(eR[13]), "+v"(eR[14]), "+v"(eR[15]));
 #pragma unroll
   for (int v = 0; v < 16; v++) {
     const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-    const int hi = max(i, k), lo = min(i, k);
-    float e = 0.0f;
-    if (hi < n) e = H[hI + hi * (hi + 1) / 2 + lo];
-    else if (hi == 31 && lo < n) e = rhs[lo];
-    D[v] = e;
+    D[v] = max(i, k) < n ? eH[v] : ((k == 31 && i < n) ? eR[v] : 0.0f);
   }
   float myrinv = 0.0f, acc = 0.0f, res = 0.0f, dmin = 1.0f;
+#ifdef FSIM_CHOLPROF
+  long long tm0_ = clock64();
+#endif
   FsMfmaStep<0>::fwd(D, myrinv, dmin, n, c.lane);
-  FsMfmaStep<0>::bwd(D, myrinv, acc, res, n, c.lane);
+#ifdef FSIM_CHOLPROF
+  { long long tm1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[50] += (int)((tm1_ - tm0_) >> 4); tm0_ = tm1_; }
+#endif
+  FsMfmaStep<0>::bwd(D, myrinv * myrinv, acc, res, n, c.lane);
+#ifdef FSIM_CHOLPROF
+  { long long tm1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[53] += (int)((tm1_ - tm0_) >> 4); }
+#endif
   if (c.lane < n) L[c.ly.p + dofk] = res;
   return !(dmin > 1e-30f);
 }
@@ -907,12 +1040,19 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += nbig > 0; }
 #endif
   int bad = 0;
+#ifdef FSIM_CHOLPROF
+  long long tc_ = clock64();
+#define FS_CHPROF(slot) do { long long t1c_ = clock64(); if (c.lane == 0 && mp == c.ly.hmap) c.I(c.ly.scal)[slot] += (int)((t1c_ - tc_) >> 4); tc_ = t1c_; } while (0)
+#else
+#define FS_CHPROF(slot) do { } while (0)
+#endif
   if (rsteps > 0) {
     const int dofr = lw & 255;
     const int dof = dofr == 255 ? -1 : dofr;
     if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
     else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   }
+  FS_CHPROF(48);
   if (nbig > 0) {
     const int maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
     if (maxbig > 32) bad |= fs_chol_lds(c, mp);
@@ -928,12 +1068,13 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
         if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, bc);
         else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc);
 #else
-        if (n <= 31) bad |= fs_chol_mfma(c, mp, first, n);
+        if (n <= 31) bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
         else { LaneBcast bc; bc.first = first; bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc); }
 #endif
       }
     }
   }
+  FS_CHPROF(49);
   SYNC();
   return !wave_or(bad);
 }
@@ -963,6 +1104,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.x + d] = L[c.ly.qaccws + d];
   SYNC();
   SolSlot S = fs_load_slots(c);
+  fs_pair_cache(c, S);
   fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
   fs_jdot(c, S, c.ly.x, true);
