@@ -11,7 +11,9 @@
 
 #define FSIM_MAXANG 8
 #define FSIM_CONW 19     // words per contact slot: 18 used + 1 pad -- an ODD stride spreads lane = slot accesses over all 64 LDS banks (18 would hit 32)
-#define FSIM_PCAP 192    // body-pair projection items cached per substep (fs_pair_cache; a gripper holding a part that touches another: 132)
+#define FSIM_PCAP 192    // words of the body-pair cache (fs_pair_cache): FSIM_PCAP - FSIM_YCAP projection items (a gripper holding a part that touches another: 132) + FSIM_YCAP column items
+#define FSIM_YCAP 36     // (pair, dof of the higher body's chain) items: FSIM_NPAIR pairs x chains of <= FSIM_XW / 6 dofs
+#define FSIM_XW 54       // words per body-pair block: the 6 x 6 cross block X, overwritten by Y = X * cdof (6 x chain length <= 9)
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
 #define FSIM_MAXSURV 48  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
@@ -161,7 +163,7 @@ constexpr Layout make_layout(const LayoutIn &in) {
   TAKE(smooth, in.nv); ly.asmooth = ly.smooth; TAKE(x, in.nv); TAKE(Mx, in.nv); TAKE(grad, in.nv); TAKE(p, in.nv); TAKE(Mp, in.nv);
   TAKE(gpos, 3 * in.ncg); TAKE(gmat, 9 * in.ncg);
   {
-    int need = 21 * in.nr + 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
+    int need = 21 * in.nr + FSIM_XW * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
     ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * in.nr;
     if (need < 12 * in.nr) need = 12 * in.nr;
     if (need > 12 * in.ncg) o += need - 12 * in.ncg;

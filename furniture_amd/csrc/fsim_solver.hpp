@@ -210,7 +210,7 @@ struct SolSlot {
   int ldof;
   float ld, laref, lsign, ljar, ljp;
   bool anyweld;            // (wave-uniform) some weld is active
-  int pid, npc, ptot;      // body-pair cache (fs_pair_cache): this slot's pair block (-1 none), pairs (wave-uniform; -1 = not cached), items
+  int pid, npc, ptot, nye; // body-pair cache (fs_pair_cache): this slot's pair block (-1 none), pairs (wave-uniform; -1 = not cached), items, column items
 };
 template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
   float *L = c.L;
@@ -239,17 +239,20 @@ template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
     if (c.I(c.ly.eqactive)[e]) { aw = 1; tb |= (1 << GP(c.m.eq_rbody1)[e]) | (1 << GP(c.m.eq_rbody2)[e]); }
   S.anyweld = __ballot(aw != 0) != 0;
   S.tb = wave_or(tb) & ~1;
-  S.pid = -1; S.npc = 0; S.ptot = 0;
+  S.pid = -1; S.npc = 0; S.ptot = 0; S.nye = 0;
   return S;
 }
 
-// ---- body-pair cache.  A contact between two MOVING bodies (lo, hi) adds a cross block on chain(lo) x chain(hi) to the Newton
-// Hessian (fs_hessian).  Which pairs exist, which slot feeds which pair block and the (pair, dof, dof) triple of every entry
-// to project depend on the contact list only, i.e. they are fixed for the substep, while fs_hessian runs once per Newton
-// iteration (5-6 times per substep when a gripper holds a part): the leader election, the chain-length prefix sums and the
-// item -> (pair, e1, e2) -> (d1, d2) decoding cost five dependent LDS round trips per 64 items and iteration.  Built once per
-// solve: S.pid per slot and one word per item (pair | d1 << 8 | d2 << 16) in Layout::pitem.  More than FSIM_NPAIR pairs or FSIM_PCAP items: S.npc = -1, fs_hessian takes
-// its multi-pass path.
+// ---- body-pair cache.  A contact between two MOVING bodies (lo, hi) adds the cross block -cdof_d1' X cdof_d2 on
+// chain(lo) x chain(hi) to the Newton Hessian (fs_hessian).  Which pairs exist, which slot feeds which pair block and the
+// (pair, dof, dof) triple of every entry depend on the contact list only, i.e. they are fixed for the substep, while fs_hessian
+// runs once per Newton iteration (5-6 times per substep when a gripper holds a part): the leader election, the chain-length
+// prefix sums and the item -> (pair, e1, e2) -> (d1, d2) decoding cost five dependent LDS round trips per 64 items and
+// iteration.  Built once per solve: S.pid per slot; one word per entry (pair | d1 << 8 | d2 << 16 | column << 24) in
+// Layout::pitem[0 .. ptot); one word per column of Y = X * cdof(chain(hi)) (pair | d2 << 8 | column << 16) in
+// pitem[FSIM_PCAP - FSIM_YCAP ..).  The projection then runs in two stages: Y (36 FMAs per column, <= 36 columns), then
+// 6 FMAs per entry instead of 42.  More than FSIM_NPAIR pairs, a chain longer than FSIM_XW / 6 or more entries than fit:
+// S.npc = -1 and fs_hessian takes its multi-pass path.
 template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
   const int b1 = S.bt1 & 255, b2 = S.bt2 & 255, blo = min(b1, b2), bhi = max(b1, b2);
   const bool haskey = S.act && blo != 0 && bhi != blo;
@@ -257,10 +260,9 @@ template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
   if (!pending) return; // (uniform) no moving-moving contact: nothing to do
   const int key = blo * 256 + bhi;
   int *pitem = c.I(c.ly.pitem);
-  int np = 0, total = 0;
-  int plo[FSIM_NPAIR], phi_[FSIM_NPAIR], pbase[FSIM_NPAIR + 1]; // wave-uniform
-  for (int q = 0; q < FSIM_NPAIR; q++) { plo[q] = 0; phi_[q] = 0; pbase[q] = 0x7fffffff; }
-  pbase[FSIM_NPAIR] = 0x7fffffff;
+  int np = 0, total = 0, ycols = 0;
+  int plo[FSIM_NPAIR], phi_[FSIM_NPAIR], pbase[FSIM_NPAIR], ybase[FSIM_NPAIR]; // wave-uniform
+  for (int q = 0; q < FSIM_NPAIR; q++) { plo[q] = 0; phi_[q] = 0; pbase[q] = 0x7fffffff; ybase[q] = 0x7fffffff; }
   bool ok = true;
 #pragma unroll
   for (int q = 0; q < FSIM_NPAIR + 1; q++) {
@@ -270,14 +272,16 @@ template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
     const int k = __builtin_amdgcn_readlane(key, leader);
     const bool mt = haskey && key == k;
     if (mt) S.pid = q;
-    plo[q] = k >> 8; phi_[q] = k & 255; pbase[q] = total;
-    total += KI(r_chainlen, k >> 8) * KI(r_chainlen, k & 255);
+    const int nlo = KI(r_chainlen, k >> 8), nhi = KI(r_chainlen, k & 255);
+    plo[q] = k >> 8; phi_[q] = k & 255; pbase[q] = total; ybase[q] = ycols;
+    total += nlo * nhi; ycols += nhi;
+    ok = ok && 6 * nhi <= FSIM_XW;
     pending &= ~__ballot(mt);
     np = q + 1;
   }
-  total = __builtin_amdgcn_readfirstlane(total);
-  if (!ok || total > FSIM_PCAP) { S.pid = -1; S.npc = -1; return; }
-  S.npc = np; S.ptot = total;
+  total = __builtin_amdgcn_readfirstlane(total); ycols = __builtin_amdgcn_readfirstlane(ycols);
+  if (!__builtin_amdgcn_readfirstlane(ok) || total > FSIM_PCAP - FSIM_YCAP || ycols > FSIM_YCAP) { S.pid = -1; S.npc = -1; return; }
+  S.npc = np; S.ptot = total; S.nye = ycols;
   for (int it = c.lane; it < total; it += 64) {
     int q = 0;
 #pragma unroll
@@ -288,9 +292,19 @@ template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
     const int rem = it - base, nhi = KI(r_chainlen, hi);
     const int e1 = (int)(((float)rem + 0.5f) / (float)nhi), e2 = rem - e1 * nhi;
     const int d1 = KI(chain_dofs, KI(r_chainadr, lo) + e1), d2 = KI(chain_dofs, KI(r_chainadr, hi) + e2);
-    pitem[it] = q | (d1 << 8) | (d2 << 16);
+    pitem[it] = q | (d1 << 8) | (d2 << 16) | (e2 << 24);
   }
-  // (no barrier: fs_hessian's first barrier orders these stores before its item loop)
+  if (c.lane < ycols) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < FSIM_NPAIR; t++) q += c.lane >= ybase[t];
+    int hi = phi_[0], base = ybase[0];
+#pragma unroll
+    for (int t = 1; t < FSIM_NPAIR; t++) if (q == t) { hi = phi_[t]; base = ybase[t]; }
+    const int e2 = c.lane - base;
+    pitem[FSIM_PCAP - FSIM_YCAP + c.lane] = q | (KI(chain_dofs, KI(r_chainadr, hi) + e2) << 8) | (e2 << 16);
+  }
+  // (no barrier: fs_hessian's first barrier orders these stores before its loads)
 }
 
 // S.jar (to_jar: minus aref) or S.jp = J * vec, using W from fs_body_spatial(vec)
@@ -534,8 +548,8 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
   const int nH = c.I(c.ly.scal)[SC_HWORDS]; // packed island triangles
   const int hm = c.ly.hmap;
   float *A = L + c.ly.hA;                    // [nr][21]: aa(xx,xy,xz,yy,yz,zz) al(9, row = ang comp) ll(xx,xy,xz,yy,yz,zz)
-  float *X = L + c.ly.hP;                    // [NPAIR][36] cross blocks, row = lo's spatial comp, col = hi's
-  int *pmeta = c.I(c.ly.hP + 36 * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
+  float *X = L + c.ly.hP;                    // [NPAIR][FSIM_XW] cross blocks (first 36 words), row = lo's spatial comp, col = hi's
+  int *pmeta = c.I(c.ly.hP + FSIM_XW * FSIM_NPAIR); // lo[NPAIR], hi[NPAIR], base[NPAIR + 1]
 #if defined(FSIM_PROFILE) && !defined(FSIM_NPPROF) && !defined(FSIM_CHOLPROF) && !defined(FSIM_TIMELINE) // (those reuse these profile slots)
   long long th_ = clock64();
 #define FS_HPROF(slot) do { long long t1h_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[slot] += (int)((t1h_ - th_) >> 4); th_ = t1h_; } while (0)
@@ -544,7 +558,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
 #endif
   for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
   for (int i = c.lane; i < 21 * c.D.nr; i += 64) A[i] = 0;
-  if (S.npc > 0) for (int i = c.lane; i < 36 * S.npc; i += 64) X[i] = 0; // cached pairs: the blocks are filled with the body blocks below
+  if (S.npc > 0) for (int i = c.lane; i < FSIM_XW * S.npc; i += 64) X[i] = 0; // cached pairs: the blocks are filled with the body blocks below
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
   const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
@@ -590,12 +604,40 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
       atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]);
       if (side == 0) { Glo0 = G0; Glo1 = G1; Glo2 = G2; } else rhi = rr;
     }
-    if (S.pid >= 0) FS_ADD_X(X + 36 * S.pid); // cached pair block of this slot (zeroed above)
+    if (S.pid >= 0) FS_ADD_X(X + FSIM_XW * S.pid); // cached pair block of this slot (zeroed above)
   }
   FS_HPROF(48);
   // the subtree sums are only needed when a non-root body (a robot link beyond the base) carries a contact block
   const bool deep = on && ((blo > 0 && KI(r_parent, blo) > 0) || (bhi > 0 && KI(r_parent, bhi) > 0));
   SYNC();
+  // cached pairs, stage 1: Y_q = X_q * cdof(chain(hi_q)), one lane per column, written over X_q
+  int pairon = 0;
+  if (S.npc > 0) {
+#pragma unroll
+    for (int q = 0; q < FSIM_NPAIR; q++) pairon |= (__ballot(on && S.pid == q) != 0) << q;
+    // (a pair none of whose contacts is in an active cone zone is skipped: its dofs may lie in different islands, where
+    //  fs_hidx means nothing)
+    if (pairon) {
+      const int w = c.I(c.ly.pitem)[FSIM_PCAP - FSIM_YCAP + min(c.lane, S.nye - 1)]; // (lanes beyond the last column redo it and store nothing)
+      const int q = w & 255, d2 = (w >> 8) & 255, e2 = w >> 16;
+      const float *Xq = X + FSIM_XW * q;
+      const float *s2 = L + c.ly.cdof + 6 * d2;
+      float y[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+        float t = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) t += Xq[6 * rr + cc] * s2[cc];
+        y[rr] = t;
+      }
+      SYNC(); // every column has read X before the first one overwrites it
+      if (c.lane < S.nye) {
+        float *Yq = X + FSIM_XW * q + 6 * e2;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) Yq[rr] = y[rr];
+      }
+    }
+  }
   // ---- composite blocks: children are numbered after their parents
   if (__ballot(deep)) {
     // lane = component: a lane only ever touches its own component of every block, so the child -> parent chain needs
@@ -640,16 +682,19 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
     atomicAdd(L + c.ly.H + fs_hidx(c, hm, max((d1_), (d2_)), min((d1_), (d2_))), -v);     \
   } while (0)
   if (S.npc > 0) {
-    // cached (fs_pair_cache): the blocks were filled with the body blocks; a pair none of whose contacts is in an active cone
-    // zone is skipped -- its dofs may lie in different islands, where fs_hidx means nothing
-    int pairon = 0;
-#pragma unroll
-    for (int q = 0; q < FSIM_NPAIR; q++) pairon |= (__ballot(on && S.pid == q) != 0) << q;
+    // cached pairs, stage 2: entry (d1, d2) += -cdof_d1 . Y_q[:, column of d2]   (Y was written before the last barrier)
     if (pairon) {
       const int *pitem = c.I(c.ly.pitem);
       for (int it = c.lane; it < S.ptot; it += 64) {
-        const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = w >> 16;
-        if ((pairon >> q) & 1) FS_PAIR_ITEM(q, d1, d2);
+        const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = (w >> 16) & 255, e2 = w >> 24;
+        const float *Yq = X + FSIM_XW * q + 6 * e2;
+        const float *s1 = L + c.ly.cdof + 6 * d1;
+        float v = 0;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) v += s1[rr] * Yq[rr];
+        if (d1 == d2) v *= 2.0f;
+        const int hx = fs_hidx(c, hm, max(d1, d2), min(d1, d2));
+        if ((pairon >> q) & 1) atomicAdd(L + c.ly.H + hx, -v);
       }
     }
   } else if (S.npc < 0) {
@@ -1105,6 +1150,9 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   SYNC();
   SolSlot S = fs_load_slots(c);
   fs_pair_cache(c, S);
+#ifdef FSIM_PROFILE
+  if (c.lane == 0) scal[52] += ((S.npc < 0) << 16) + ((S.npc > 0) << 24); // solves whose body pairs did not fit the cache / did
+#endif
   fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
   fs_jdot(c, S, c.ly.x, true);

@@ -60,8 +60,10 @@ def build(force=False, verbose=False):
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fsim.h"))
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(s) <= os.path.getmtime(_LIBPATH) for s in srcs):
         return _LIBPATH
+    # (max-ilp: one wavefront per env has no other wave to hide latency behind, so the machine scheduler is asked to interleave
+    #  independent chains rather than to minimise register pressure; +1.5 % on the benchmark, same register / scratch budget)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", _LIBPATH, os.path.join(_CSRC, "fsim.hip")]
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", _LIBPATH, os.path.join(_CSRC, "fsim.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
