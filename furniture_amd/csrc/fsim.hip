@@ -226,6 +226,7 @@ struct fsim {
   float *d_init = nullptr;       // set_init_qpos: [n][nq + nv] state the masked envs' resets start from
   uint8_t *d_init_mask = nullptr;
   float *d_dense = nullptr; // dense-reward tables: DC_WORDS coefficients, then nsub rows of DS_WORDS
+  int *d_pre = nullptr;     // pre-assembled starts: [n_pre][3] (EnvCfg::pre_tab)
   bool lpt = true;
   int n_noise = 0;
   int auxstride = 0, lds_bytes = 0;
@@ -503,7 +504,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -650,6 +651,7 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
 
 extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) {
   if (!s) FAIL(FSIM_EINVAL, "null");
+  if (s->ecfg.n_pre > 0 && qpos) FAIL(FSIM_EINVAL, "fsim_set_init_state: not combined with pre-assembled starts (fsim_set_preassembled)");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   const int n = s->n_envs, nq = s->m.nq, nv = s->m.nv, w = nq + nv;
@@ -906,6 +908,34 @@ extern "C" int fsim_step(fsim_t *s, const float *action, void *obs, float *rewar
   if (s->cfg.auto_reset && !s->d_tab_parts) FAIL(FSIM_EINVAL, "fsim_step: auto_reset needs fsim_set_reset_tables");
   if (s->cfg.dense_reward && !s->d_dense) FAIL(FSIM_EINVAL, "fsim_step: dense_reward needs fsim_set_dense_reward first");
   return launch_env(s, action, static_cast<float *>(obs), reward, done, info, nullptr, 1);
+}
+extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
+  if (!s || n_pre < 0 || n_pre > 16 || (n_pre > 0 && !ids)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: bad arguments");
+  const bool recipe = s->ecfg.has_recipe != 0;
+  if (n_pre > 0 && s->d_init) FAIL(FSIM_EINVAL, "fsim_set_preassembled: not combined with fsim_set_init_state");
+  if (n_pre > 0 && recipe && (!conn_pairs || !angles)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: this furniture has a recipe: pass the connector pair and angle of every listed recipe step");
+  std::vector<int> tab(3 * (size_t)n_pre, 0);
+  for (int i = 0; i < n_pre; i++) {
+    if (recipe) {
+      const int k1 = conn_pairs[2 * i], k2 = conn_pairs[2 * i + 1];
+      if (k1 < 0 || k1 >= s->m.nconn || k2 < 0 || k2 >= s->m.nconn) FAIL(FSIM_EINVAL, "fsim_set_preassembled: connector index out of range in row %d", i);
+      tab[3 * i] = k1; tab[3 * i + 1] = k2; memcpy(&tab[3 * i + 2], &angles[i], 4);
+    } else {
+      if (ids[i] < 0 || ids[i] >= s->m.neq) FAIL(FSIM_EINVAL, "fsim_set_preassembled: weld id %d out of range (%d welds)", ids[i], s->m.neq);
+      tab[3 * i] = ids[i];
+    }
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->d_pre) { hipFree(s->d_pre); s->d_pre = nullptr; }
+  if (n_pre > 0) {
+    HIPCHK(hipMalloc(&s->d_pre, tab.size() * 4));
+    HIPCHK(hipMemcpy(s->d_pre, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
+  s->ecfg.n_pre = n_pre; s->ecfg.pre_mode = recipe ? 1 : 0; s->ecfg.pre_tab = s->d_pre;
+  // _success_num_conn (furniture.py:1476-1481)
+  s->ecfg.success_num_conn = num_connects >= 0 ? num_connects + n_pre : s->m.nparts - 1;
+  return FSIM_OK;
 }
 extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   if (!s || n <= 0) FAIL(FSIM_EINVAL, "fsim_set_max_episode_steps: bad arguments");

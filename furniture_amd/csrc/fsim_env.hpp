@@ -30,6 +30,11 @@ struct EnvCfg {
   int controller; // CK_* (fsim_ctrl.hpp): torque-level arm controller run before every physics substep, 0 = none
   int ik;         // 1: control_type "ik", 2: "ik_quaternion" (fsim_ik.hpp)
   int obs_bf16;   // the caller's observation slab is bfloat16 (fsim_config_t::obs_bf16)
+  // pre-assembled starts (furniture.py:163, 204-207, 1476-1503, 1542-1566; fsim_set_preassembled)
+  int n_pre, pre_mode;      // pre_mode 0: pre_tab rows = {weld id, -, -} (no recipe: welds switched on, groups merged);
+                            //          1: rows = {connector of the recipe's site2, connector of its site1, angle bits or NaN} (_connect per row)
+  const int *pre_tab;       // [n_pre][3], device memory
+  int success_num_conn;     // _success_num_conn (furniture.py:1476-1481)
 };
 struct EnvIO {
   const float *action;
@@ -71,6 +76,7 @@ static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel 
   }
   e.ik = c.control_type == 7 ? 1 : (c.control_type == 8 ? 2 : 0);
   e.obs_bf16 = c.obs_bf16 ? 1 : 0;
+  e.n_pre = 0; e.pre_mode = 0; e.pre_tab = nullptr; e.success_num_conn = m.nparts - 1;
   if (e.ik) { // [per arm: dpos 3, rotation 3 | quaternion 4] + one grip per arm + connect (furniture_sawyer.py:52-64, furniture_baxter.py:26-37)
     e.dof_action = m.narm * (3 + (e.ik == 1 ? 3 : 4)) + m.narm + 1;
     e.obs_dim = 7 * m.nparts + 15 * m.narm;
@@ -545,44 +551,12 @@ template <class TryFn> DEV void env_finger_scan(int narm, const int *scal, TryFn
 
 // _try_connect(part1, part2) (furniture.py:926-1042).  part2 < 0: any part (the arm agents).  returns (wave-uniform) 1 if a
 // connection was made; with num_connect_steps > 0 (Cursor) an aligned pair is first approached over that many calls.
-template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
+// _connect(site1, site2) (furniture.py:847-925) for connector indices k1, k2; the target orientation is in E_TARGET_QUAT
+template <class Ctx> DEV void env_connect(const Ctx &c, const EnvCfg &cfg, int k1, int k2, bool auto_align) {
   CModel &m = c.m;
   int *E = c.I(c.ly.env);
   int *grp = E + E_GROUP;
   int *scal = c.I(c.ly.scal);
-  // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
-  if (c.lane == 0) {
-    int found1, found2;
-    const bool searched = env_connect_search(c, part1, part2, [&](int k1, int k2) { return env_is_aligned(c, cfg, k1, k2); }, &found1, &found2);
-    if (env_connect_decide(E, cfg.num_connect_steps, searched, found1) == 1) {
-      // approach phase (furniture.py:993-1034): slerp / lerp part2's group towards the aligned pose, one increment per call
-      const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP] - 1; // (already advanced by env_connect_decide)
-      float *ec = c.L + env_ecur(c);
-      int p2 = GP(m.conn_partid)[found2], a = GP(m.part_qposadr)[p2];
-      V3 p2p = ldv3(c.L + c.ly.qpos + a); Q4 p2q = ldq(c.L + c.ly.qpos + a + 3);
-      if (step == 0) {
-        V3 s1p, s2p; Q4 s2q;
-        env_site_pose(c, GP(m.conn_siteid)[found1], &s1p, nullptr, nullptr);
-        env_site_pose(c, GP(m.conn_siteid)[found2], &s2p, &s2q, nullptr);
-        V3 bpos; Q4 brot;
-        env_ttq(s2p, s2q, p2p, p2q, ldq(c.L + c.ly.env + E_TARGET_QUAT), &bpos, &brot);
-        bpos = bpos + (s1p - s2p);
-        stv3(ec + EC_P2Q0, p2p); stq(ec + EC_P2Q0 + 3, p2q); stv3(ec + EC_BODY_POS, bpos); stq(ec + EC_BODY_ROT, brot);
-      }
-      V3 p0 = ldv3(ec + EC_P2Q0), bpos = ldv3(ec + EC_BODY_POS);
-      Q4 q0 = ldq(ec + EC_P2Q0 + 3), brot = ldq(ec + EC_BODY_ROT);
-      float lo = 1.0f / n, x = n > 1 ? lo + (0.9f - lo) * step / (n - 1) : lo; // np.linspace(1/n, 0.9, n)[step]
-      V3 npos = p0 + (bpos - p0) * x;
-      Q4 nrot = env_slerp(q0, brot, (float)(step + 1) / n);
-      env_move_group(c, p2, npos - p2p, nrot, 1.0f);
-      found1 = -1;
-    }
-    scal[9] = found1; scal[10] = found2;
-  }
-  SYNC();
-  int k1 = scal[9], k2 = scal[10];
-  if (k1 < 0) return 0;
-  // ---- _connect(site1, site2)
   int pA = GP(m.conn_partid)[k1], pB = GP(m.conn_partid)[k2];
   if (c.lane == 0) {
     E[E_CONNSITES0 + (k1 >> 5)] |= 1 << (k1 & 31);
@@ -596,7 +570,7 @@ template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, in
       int gp = env_find(grp, p);
       if ((gp == gA || gp == gB) && ct[g] != 0) { ct[g] = (1 << 30) - 1 - (1 << (gA + 1)); ca[g] = 1 << (gA + 1); }
     }
-    if (cfg.auto_align) {
+    if (auto_align) {
       // _align_connectors -> _move_site_to_target(site2, [site1 pos, target quat])
       V3 s1p, s2p; Q4 s2q;
       env_site_pose(c, GP(m.conn_siteid)[k1], &s1p, nullptr, nullptr);
@@ -654,6 +628,66 @@ template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, in
     env_next_subtask(c);
   }
   SYNC();
+}
+
+// _project_connector_quat(connector1, connector2, angle) (furniture.py:1201-1222): connector2's orientation when aligned
+// with connector1 -- the target of _is_aligned without its thresholds.  Lane 0, on the poses of the last forward pass.
+template <class Ctx> DEV void env_project_connector_quat(const Ctx &c, int k1, int k2, bool has_angle, float angle_deg) {
+  CModel &m = c.m;
+  V3 p1, p2; M3 R1, R2;
+  env_site_pose(c, GP(m.conn_siteid)[k1], &p1, nullptr, &R1);
+  env_site_pose(c, GP(m.conn_siteid)[k2], &p2, nullptr, &R2);
+  const V3 up1 = colv(R1, 2), f1 = colv(R1, 1), f2 = colv(R2, 1), k = normalized(up1);
+  V3 fr;
+  if (!has_angle) {
+    const float cs = env_cos(f1, f2), sn = sqrtf(1 - cs * cs);
+    const V3 rp = cs * f1 + sn * cross(k, f1), rn = cs * f1 - sn * cross(k, f1);
+    fr = env_cos(rp, f2) > env_cos(rn, f2) ? rp : rn;
+  } else {
+    const float ang = angle_deg / 180.0f * 3.14159265358979f;
+    fr = cosf(ang) * f1 + sinf(ang) * cross(k, f1);
+  }
+  stq(c.L + c.ly.env + E_TARGET_QUAT, env_lookat(up1, fr));
+}
+
+template <class Ctx> DEV int env_try_connect(const Ctx &c, const EnvCfg &cfg, int part1, int part2) {
+  CModel &m = c.m;
+  int *E = c.I(c.ly.env);
+  int *grp = E + E_GROUP;
+  int *scal = c.I(c.ly.scal);
+  // ---- lane 0: search the first aligned (site1, site2) pair in site-id order
+  if (c.lane == 0) {
+    int found1, found2;
+    const bool searched = env_connect_search(c, part1, part2, [&](int k1, int k2) { return env_is_aligned(c, cfg, k1, k2); }, &found1, &found2);
+    if (env_connect_decide(E, cfg.num_connect_steps, searched, found1) == 1) {
+      // approach phase (furniture.py:993-1034): slerp / lerp part2's group towards the aligned pose, one increment per call
+      const int n = cfg.num_connect_steps, step = E[E_CONNECT_STEP] - 1; // (already advanced by env_connect_decide)
+      float *ec = c.L + env_ecur(c);
+      int p2 = GP(m.conn_partid)[found2], a = GP(m.part_qposadr)[p2];
+      V3 p2p = ldv3(c.L + c.ly.qpos + a); Q4 p2q = ldq(c.L + c.ly.qpos + a + 3);
+      if (step == 0) {
+        V3 s1p, s2p; Q4 s2q;
+        env_site_pose(c, GP(m.conn_siteid)[found1], &s1p, nullptr, nullptr);
+        env_site_pose(c, GP(m.conn_siteid)[found2], &s2p, &s2q, nullptr);
+        V3 bpos; Q4 brot;
+        env_ttq(s2p, s2q, p2p, p2q, ldq(c.L + c.ly.env + E_TARGET_QUAT), &bpos, &brot);
+        bpos = bpos + (s1p - s2p);
+        stv3(ec + EC_P2Q0, p2p); stq(ec + EC_P2Q0 + 3, p2q); stv3(ec + EC_BODY_POS, bpos); stq(ec + EC_BODY_ROT, brot);
+      }
+      V3 p0 = ldv3(ec + EC_P2Q0), bpos = ldv3(ec + EC_BODY_POS);
+      Q4 q0 = ldq(ec + EC_P2Q0 + 3), brot = ldq(ec + EC_BODY_ROT);
+      float lo = 1.0f / n, x = n > 1 ? lo + (0.9f - lo) * step / (n - 1) : lo; // np.linspace(1/n, 0.9, n)[step]
+      V3 npos = p0 + (bpos - p0) * x;
+      Q4 nrot = env_slerp(q0, brot, (float)(step + 1) / n);
+      env_move_group(c, p2, npos - p2p, nrot, 1.0f);
+      found1 = -1;
+    }
+    scal[9] = found1; scal[10] = found2;
+  }
+  SYNC();
+  int k1 = scal[9], k2 = scal[10];
+  if (k1 < 0) return 0;
+  env_connect(c, cfg, k1, k2, cfg.auto_align != 0);
   return 1;
 }
 
@@ -837,7 +871,18 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
   for (int p = c.lane; p < c.D.nparts; p += 64) E[E_GROUP + p] = p;
   if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
   SYNC();
-  if (c.lane == 0) { E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; }
+  if (c.lane == 0) {
+    E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1;
+    if (cfg.n_pre > 0 && cfg.pre_mode == 0) // no recipe: the listed welds are switched on, their groups merged (furniture.py:1493-1501)
+      for (int i = 0; i < cfg.n_pre; i++) {
+        const int e = GP(cfg.pre_tab)[3 * i];
+        c.I(c.ly.eqactive)[e] = 1;
+        int *grp = E + E_GROUP;
+        const int r1 = env_find(grp, GP(m.eq_part1)[e]), r2 = env_find(grp, GP(m.eq_part2)[e]);
+        grp[r1] = r2;
+      }
+  }
+  SYNC();
   if (io.init_state) {
     // set_init_qpos (furniture.py:1505-1519, 1568-1569, 1617-1618): set_env_state(given state) replaces placement, settling and the
     // robot initialisation (no RNG draw is consumed); robot collision on; the reference's forward passes in between do not change
@@ -857,7 +902,20 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
   }
   SYNC();
   env_settle_parts(c);
-  if (cfg.has_recipe) env_settle_parts(c);
+  if (cfg.has_recipe) {
+    // pre-assembled recipe steps (furniture.py:1542-1557): _connect(site2, site1) with the recipe's angle, latches cleared
+    if (cfg.pre_mode == 1)
+      for (int i = 0; i < cfg.n_pre; i++) {
+        const int k1 = GP(cfg.pre_tab)[3 * i], k2 = GP(cfg.pre_tab)[3 * i + 1];
+        const float ang = __int_as_float(GP(cfg.pre_tab)[3 * i + 2]);
+        if (c.lane == 0) env_project_connector_quat(c, k1, k2, ang == ang, ang);
+        SYNC();
+        env_connect(c, cfg, k1, k2, true);
+        if (c.lane == 0) { E[E_CONNECTED_THIS_STEP] = 0; E[E_CONNBODY1] = 0; }
+        SYNC();
+      }
+    env_settle_parts(c);
+  }
   {
     if (c.D.narm > 0) env_gravity_comp(c);
     env_init_robot(c, io, 0, cfg.move_speed);
@@ -881,7 +939,7 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
     env_next_subtask(c);
     if (cfg.dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
       DenseSimP<Ctx> dp{c, cfg};
-      dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, 0);
+      dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, cfg.n_pre);
     }
   }
   SYNC();
@@ -1068,14 +1126,14 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     }
     succ_rew = cfg.success_reward * (float)(E[E_NUM_CONNECTED] - E[E_PREV_NUM_CONNECTED]);
     E[E_PREV_NUM_CONNECTED] = E[E_NUM_CONNECTED];
-    if (E[E_NUM_CONNECTED] == c.D.nparts - 1 && c.D.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
+    if (E[E_NUM_CONNECTED] == cfg.success_num_conn && c.D.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
     terminal = success;
     int dense_phase = 0;
     if (cfg.dense) {
       // FurnitureSawyerEnv._step (furniture_sawyer.py:76-79): the dense _compute_reward replaces the reward and owns _success;
       // done = (all parts connected) or its own done
       DenseSimP<Ctx> dp{c, cfg};
-      DenseOut d = dense_compute(env_edense(c), cfg.dense_coef, cfg.dense_sub, cfg.dense_nsub, dp, io.action, dof, E[E_CONNECTED_THIS_STEP] != 0);
+      DenseOut d = dense_compute(env_edense(c), cfg.dense_coef, cfg.dense_sub, min(cfg.dense_nsub, cfg.success_num_conn), dp, io.action, dof, E[E_CONNECTED_THIS_STEP] != 0);
       success = d.success; E[E_SUCCESS] = success;
       terminal = terminal || d.done;
       dense_phase = d.phase_info;

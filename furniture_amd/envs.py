@@ -186,8 +186,8 @@ class FurnitureBatchEnv:
                 raise ValueError("the dense-reward env exists for the Sawyer agent only")
             if not getattr(cfg, "diff_rew", True):
                 raise NotImplementedError("diff_rew=False: the reference itself fails in grasp_leg (furniture_sawyer_dense.py:668)")
-            if getattr(cfg, "phase_ob", False) or getattr(cfg, "preassembled", None):
-                raise NotImplementedError("phase_ob / preassembled are not part of the accelerated dense-reward path")
+            if getattr(cfg, "phase_ob", False):
+                raise NotImplementedError("phase_ob is not part of the accelerated dense-reward path")
         if cfg.unity or cfg.record_vid:
             # the reference's defaults (config/furniture.py:21-23, 146-148) would launch the Unity binary / a video writer;
             # neither changes what reset()/step() return, so the accelerated env accepts the flags and switches them off
@@ -210,8 +210,7 @@ class FurnitureBatchEnv:
         # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them
         for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect)"),
                           ("no_collision", "furniture.py:1919-1924"), ("fix_init", "furniture.py:1516-1521"), ("assembled", "furniture.py:1503, 1526"),
-                          ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325"),
-                          ("preassembled", "furniture.py:1492-1557")):
+                          ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325")):
             if getattr(cfg, flag, None):
                 raise NotImplementedError("config.%s (%s) is not part of the accelerated path" % (flag, ref))
         names = furniture_names()
@@ -241,6 +240,9 @@ class FurnitureBatchEnv:
             coef = {k: float(getattr(cfg, k)) for k, _ in DENSE_COEF_DEFAULTS
                     if k not in ("z_finedist", "griptip_site", "grip_site") and getattr(cfg, k, None) is not None}
             self.sim.set_dense_reward(*pack_dense(self.model, coef))
+        self._num_connects = getattr(cfg, "num_connects", None)
+        if getattr(cfg, "preassembled", None) or self._num_connects is not None:  # config.preassembled / num_connects (furniture.py:163, 1476-1503)
+            self.sim.set_preassembled(list(getattr(cfg, "preassembled", None) or []), self._num_connects)
         self.num_envs = num_envs
         torch = self.sim.torch
         dev = self.sim.device
@@ -315,6 +317,17 @@ class FurnitureBatchEnv:
             self._tables_fresh[:] = True
         else:
             self._tables_fresh[np.asarray(mask, dtype=bool)] = True
+
+    def set_subtask(self, subtask, num_connects=None):
+        """furniture.py:204-207: the following resets start with recipe steps (weld ids, for a furniture without a recipe)
+        0 .. subtask-1 already assembled; num_connects as in config.num_connects (success after that many further connects)."""
+        self.config.preassembled = list(range(int(subtask)))
+        self._num_connects = num_connects
+        self.sim.set_preassembled(self.config.preassembled, num_connects)
+
+    def num_subtask(self):
+        """furniture.py:209-213"""
+        return self._num_connects if self._num_connects is not None else self.n_obj - 1
 
     def set_init_qpos(self, init_qpos):
         """furniture.py:315-316: every following reset starts from this {qpos, qvel} state (get_env_state's format; [dim] or
@@ -451,14 +464,15 @@ class _SingleEnv:
         return self._max_episode_steps
 
     def num_subtask(self):
-        return self._b.n_obj - 1
+        return self._b.num_subtask()
 
     def set_max_episode_steps(self, max_episode_steps):
         self._max_episode_steps = int(max_episode_steps)
         self._b.set_max_episode_steps(max_episode_steps)
 
     def set_subtask(self, subtask, num_connects=None):
-        raise NotImplementedError("set_subtask (pre-assembled starts, furniture.py:204-207) is not part of the accelerated reset")
+        """furniture.py:204-207"""
+        self._b.set_subtask(subtask, num_connects)
 
     def set_init_qpos(self, init_qpos):
         """furniture.py:315-316: {qpos, qvel} as returned by get_env_state(), or None"""

@@ -108,6 +108,7 @@ def lib():
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_kernel_time_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.fsim_set_preassembled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_dense_replay.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
@@ -119,8 +120,26 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed",
+    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled",
 ]
+
+
+def preassembled_rows(model, preassembled):
+    """(ids, connector pairs, angles) of fsim_set_preassembled for the reference's `preassembled` list.  With a recipe, row i holds
+    the connector-table indices of site_recipe[i]'s site2 and site1 -- the reset calls _connect(site2_id, site1_id)
+    (furniture.py:1546-1554) -- and the recipe's angle (NaN: none)."""
+    ids = np.ascontiguousarray([int(x) for x in preassembled], dtype=np.int32)
+    if not model.meta.get("has_recipe"):
+        return ids, None, None
+    sites = list(model.meta["site_names"])
+    conn = [int(x) for x in model.conn_siteid]
+    pairs, angles = np.zeros((len(ids), 2), dtype=np.int32), np.full(len(ids), np.nan, dtype=np.float32)
+    for r, i in enumerate(ids):
+        row = model.meta["site_recipe"][int(i)]
+        pairs[r] = [conn.index(sites.index(row[1])), conn.index(sites.index(row[0]))]
+        if len(row) == 3:
+            angles[r] = float(row[2])
+    return ids, pairs, angles
 
 
 def default_config():
@@ -203,6 +222,13 @@ class FSim:
         coef = np.ascontiguousarray(coef, dtype=np.float32)
         subtasks = np.ascontiguousarray(subtasks, dtype=np.float32)
         self._chk(lib().fsim_set_dense_reward(self._h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
+    def set_preassembled(self, preassembled, num_connects=None):
+        """config.preassembled / set_subtask (furniture.py:163, 204-207): weld ids (furniture without a recipe) or recipe step
+        indices (with one) that every following reset starts from; num_connects as in config.num_connects."""
+        ids, pairs, angles = preassembled_rows(self.cm, preassembled)
+        self._chk(lib().fsim_set_preassembled(self._h, len(ids), ids.ctypes.data, pairs.ctypes.data if pairs is not None else None,
+                                              angles.ctypes.data if angles is not None else None, -1 if num_connects is None else int(num_connects)))
 
     def _chk(self, rc):
         if rc:

@@ -175,6 +175,18 @@ enum {
 enum { FSIM_DENSE_NCOEF = 33, FSIM_DENSE_SUBW = 16, FSIM_DENSE_OBSW = 40, FSIM_DENSE_STATEW = 27 };
 int fsim_set_dense_reward(fsim_t *, const float *coef, int ncoef, const float *subtasks, int nsub);
 
+/* ---- pre-assembled starts: FurnitureEnv.set_subtask / config.preassembled / config.num_connects ------------------------
+ * (furniture.py:163, 204-207, 1476-1503, 1542-1566).  Applies to every reset that follows, for all envs of the handle.
+ *   ids[n_pre]           the reference's `preassembled` list: weld equality ids for a furniture WITHOUT a recipe file (the welds are
+ *                        switched on and the part groups merged before the parts are placed), recipe step indices for one WITH a
+ *                        recipe (models/assets/recipes/<name>.yaml), in which case the caller also passes, per listed step,
+ *   conn_pairs[n_pre][2] the connector indices (rows of the model's connector table) of the recipe's site2 and site1 -- the
+ *                        arguments of the reset's _connect(site2_id, site1_id) -- and
+ *   angles[n_pre]        the recipe's angle in degrees, NaN for none (_project_connector_quat);
+ *   num_connects         config.num_connects: success when num_connected == num_connects + n_pre; < 0 = None (all parts).
+ * n_pre = 0 restores the default.  Not combined with fsim_set_init_state (either call then returns FSIM_EINVAL).  Host pointers. */
+int fsim_set_preassembled(fsim_t *, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects);
+
 /* Parity hook: run the device implementation of the reward state machine alone, on recorded sensor values (the layout of
  * oracle/dense_reward.py O_*: obs0 [nsub][40] at reset, obs [T][nsub][40], ac [T][dof], connected [T]); out_reward [T],
  * out_flags [T][4] = done, success, phase, subtask after each step.  Host pointers; synchronous; needs no handle. */

@@ -52,6 +52,8 @@ class OracleConfig:
         self.solver_iterations = 100
         self.solver_tolerance = 1e-8
         self.dense = None  # an oracle.dense_reward.DenseConfig -> FurnitureSawyerDenseRewardEnv behaviour
+        self.preassembled = []   # config.preassembled (furniture.py:163): weld ids / recipe steps every reset starts from
+        self.num_connects = None  # config.num_connects
         self.control_type = "impedance"  # or one of NEW_CONTROLLERS (furniture.py:41-47): needs the __torque compiled model
         for k, v in kw.items():
             setattr(self, k, v)
@@ -211,6 +213,26 @@ class FurnitureEnvOracle:
         """F.py:315-316: {qpos, qvel} (get_env_state's format) or None"""
         self._init_qpos = init_qpos
 
+    def set_subtask(self, subtask, num_connects=None):
+        """F.py:204-207"""
+        self.cfg.preassembled = list(range(subtask))
+        self.cfg.num_connects = num_connects
+
+    def _project_connector_quat(self, k1, k2, angle=None):
+        """F.py:1201-1222: connector k2's xquat when aligned with connector k1 (at `angle` degrees about k1's up axis)"""
+        m = self.m
+        R1 = self.sim.data.site_xmat[m.conn_siteid[k1]].reshape(3, 3)
+        R2 = self.sim.data.site_xmat[m.conn_siteid[k2]].reshape(3, 3)
+        up1, f1, f2 = R1[:, 2].copy(), R1[:, 1].copy(), R2[:, 1].copy()
+        if angle is None:
+            cs = T.cos_siml(f1, f2)
+            rp = T.rotate_vector_cos_siml(f1, up1, cs, 1)
+            rn = T.rotate_vector_cos_siml(f1, up1, cs, -1)
+            fr = rp if T.cos_siml(rp, f2) > T.cos_siml(rn, f2) else rn
+        else:
+            fr = T.rotate_vector(f1, up1, angle)
+        return T.convert_quat(T.lookat_to_quat(up1, fr), "wxyz")
+
     def reset(self):
         m, sim = self.m, self.sim
         self.reset_draws = {"noise": []}
@@ -234,11 +256,17 @@ class FurnitureEnvOracle:
         self._site1_id = self._site2_id = -1
         if self.agent == "Cursor":
             self._cursor_selected = [None, None]
-        self._success_num_conn = self.nparts - 1
+        pre = list(getattr(self.cfg, "preassembled", None) or [])
+        nc = getattr(self.cfg, "num_connects", None)
+        self._success_num_conn = self.nparts - 1 if nc is None else nc + len(pre)  # F.py:1476-1481
         self._touched = [False] * self.nparts
         self._picked = [False] * self.nparts
         sim.model.eq_active[:] = 0
         sim.model.eq_data[:] = m.eq_data0
+        if pre and not self._has_recipe:  # F.py:1493-1501: the listed welds are on from the start, their groups merged
+            for e in pre:
+                sim.model.eq_active[e] = 1
+                self._merge_groups(int(m.eq_part1[e]), int(m.eq_part2[e]))
         init = getattr(self, "_init_qpos", None)
         if init is not None:
             # F.py:1505-1519, 1568-1569, 1617-1618 (set_init_qpos): the given state replaces placement, settling and the robot
@@ -260,6 +288,7 @@ class FurnitureEnvOracle:
                 self._set_part_qpos(i, pos[i], quat[i])
             self._settle()
             if self._has_recipe:
+                self._preassemble(pre, auto_align=True)
                 self._settle()
             if self.agent != "Cursor":
                 self._gravity_comp()
@@ -298,8 +327,21 @@ class FurnitureEnvOracle:
         self._success = False
         self._fail = False
         if self._dense is not None:
+            self._dense.success_num_conn, self._dense.n_pre = self._success_num_conn, len(pre)
             self._dense.reset(self._dense_obs)  # _reset_reward_variables (furniture_sawyer_dense.py:218-220)
         return self._get_obs()
+
+    def _preassemble(self, pre, auto_align):
+        """F.py:1542-1557: recipe steps `pre` are connected during the reset -- _connect(site2, site1) with the recipe's angle"""
+        m = self.m
+        sites, conn = list(m.meta["site_names"]), [int(x) for x in m.conn_siteid]
+        for i in pre:
+            row = m.meta["site_recipe"][i]
+            k1, k2 = conn.index(sites.index(row[0])), conn.index(sites.index(row[1]))
+            self._target_connector_xquat = self._project_connector_quat(k2, k1, row[2] if len(row) == 3 else None)
+            self._connect(k2, k1, auto_align=auto_align)
+            self._connected = False
+            self._connected_body1 = None
 
     def _settle(self):
         for _ in range(10):

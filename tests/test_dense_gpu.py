@@ -194,3 +194,42 @@ def test_dense_env_classes_and_auto_reset():
         if t % 5 == 4:  # fresh episode: _prev_grasp_dist = -1, lift distances reset (:214-216)
             assert bool((ds[:, 19] == -1).all()) and bool((ds[:, 20] - 0.1).abs().max() < 1e-6)
     venv.close()
+
+
+def test_dense_env_with_a_preassembled_recipe_step_matches_oracle():
+    """FurnitureSawyerDenseRewardEnv with config.preassembled = [0]: the reset connects recipe step 0 and _reset_reward_variables
+    starts at subtask 1 with leg 0's grasp sites marked used (furniture_sawyer_dense.py:128-139)."""
+    import torch
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.sim import FSim, INFO_DIM, INFO_NUM_CONNECTED, default_config
+    from oracle.dense_reward import DenseConfig
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+
+    m = load_compiled("Sawyer", "table_lack_0825")
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset, cfg.dense_reward = 150, 0, 1
+    sim = FSim(m, 1, config=cfg)
+    sim.set_dense_reward(*pack_dense(m, {}))
+    sim.set_preassembled([0])
+    env = FurnitureEnvOracle(m, OracleConfig(seed=99, solver_tolerance=1e-10, max_episode_steps=150, dense=DenseConfig(), preassembled=[0]))
+    env.reset()
+    sim.set_reset_tables(env.reset_draws["part_qpos"].reshape(1, -1), np.stack(env.reset_draws["noise"]).reshape(1, -1))
+    dev = sim.device
+    obs = torch.zeros((1, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    v = sim.get_state("dense")["dense"][0].cpu().numpy()
+    assert (int(v[0]), int(v[1])) == (env._dense.subtask_step, env._dense.phase_i) == (1, 0)
+    act, rew = torch.zeros((1, 9), device=dev), torch.zeros(1, device=dev)
+    done, info = torch.zeros(1, dtype=torch.uint8, device=dev), torch.zeros((1, INFO_DIM), dtype=torch.int32, device=dev)
+    rng = np.random.RandomState(4)
+    for t in range(3):
+        a = rng.uniform(-1, 1, 9)
+        act.copy_(torch.as_tensor(a[None].astype(np.float32)))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        _, r, d, _ = env.step(a)
+        assert abs(float(rew[0]) - r) < 1e-4 * abs(r) + 0.05, (t, float(rew[0]), r)
+        assert bool(done[0]) == bool(d) and int(info[0, INFO_NUM_CONNECTED]) == env._num_connected == 1
+    sim.close()

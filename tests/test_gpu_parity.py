@@ -615,3 +615,59 @@ def test_reset_with_another_furniture_id_swaps_the_model_and_keeps_the_rng_strea
     ob, rew, done, info = env.step(np.zeros(9, dtype=np.float32))
     assert np.isfinite(ob["robot_ob"]).all() and "touch_reward" in info and info["ctrl_penalty"] == 0.0
     env.close()
+
+
+def test_preassembled_starts_match_the_oracle_env(sawyer_lack):
+    """config.preassembled / set_subtask / num_connects (furniture.py:163, 204-207, 1476-1503, 1542-1566).  With a recipe the reset
+    connects the listed recipe steps (_project_connector_quat + _connect(site2, site1)) between its two settling phases; without one
+    it switches the listed welds on before the parts are placed.  Device vs oracle env: observation, weld activity, groups,
+    counters, the first step's reward (which pays the pre-assembled connects: _prev_num_connected starts at 0)."""
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+
+    def err(d, o, nparts):
+        """observation error with each part's quaternion compared up to its sign: the recipe's 90 / 270 degree targets put
+        lookat_to_quat exactly on its m00 == m11 branch tie (x = -y), which fp32 and fp64 rounding break differently -- q or -q,
+        the same rotation (the reference's own sign there is decided by fp64 rounding noise)"""
+        x = np.concatenate([d["object_ob"], d["robot_ob"]]).copy()
+        for i in range(nparts):
+            if np.dot(x[7 * i + 3:7 * i + 7], o[7 * i + 3:7 * i + 7]) < 0:
+                x[7 * i + 3:7 * i + 7] *= -1
+        return np.abs(x - o).max()
+
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50, seed=31)
+    env = FurnitureSawyerEnv(make_config(preassembled=[0, 1], **kw))
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=31, solver_tolerance=1e-10, preassembled=[0, 1]))
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert err(d, o, 5) < 5e-4
+    st = env._b.sim.get_state("eq_active", "env_block")
+    assert st["eq_active"][0].cpu().numpy().astype(int).tolist() == np.asarray(orc.sim.model.eq_active).astype(int).tolist()
+    rng = np.random.RandomState(5)
+    for t in range(3):
+        a = rng.uniform(-1, 1, 9)
+        ob, r, done, info = env.step(a)
+        ob_o, r_o, done_o, _ = orc.step(a)
+        assert err(ob, orc.flat_obs(ob_o), 5) < 1e-3, t
+        assert abs(r - r_o) < 1e-3 and done == done_o, (t, r, r_o)
+        assert info["num_connected"] == orc._num_connected == 2
+        if t == 0:
+            assert r > 190  # 2 x success_reward
+    # set_subtask(3, num_connects=1): three legs on, success after one more connect
+    env.set_subtask(3, num_connects=1)
+    orc.set_subtask(3, num_connects=1)
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert err(d, o, 5) < 5e-4
+    assert env.num_subtask() == 1
+    env.close()
+    # a furniture without a recipe file: the list holds weld ids
+    m2 = load_compiled("Sawyer", "swivel_chair_0700")
+    kw["furniture_name"] = "swivel_chair_0700"
+    env = FurnitureSawyerEnv(make_config(preassembled=[0], **kw))
+    orc = FurnitureEnvOracle(m2, OracleConfig(max_episode_steps=50, seed=31, solver_tolerance=1e-10, preassembled=[0]))
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert err(d, o, m2.nparts) < 5e-3  # (the active weld yanks the two parts together across the floor during the reset: measured 1.0e-3)
+    st = env._b.sim.get_state("eq_active")
+    assert st["eq_active"][0].cpu().numpy().astype(int).tolist() == np.asarray(orc.sim.model.eq_active).astype(int).tolist() == [1, 0]
+    env.close()
