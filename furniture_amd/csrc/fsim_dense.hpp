@@ -14,7 +14,7 @@ enum {
   DC_PHASE_BONUS = 0, DC_EEF_FWD, DC_EEF_UP, DC_EEF_ROT_THR, DC_GRIPPER_PEN, DC_MOVE_OTHER, DC_DROP_PEN, DC_EARLY_TERM, DC_INIT_EEF,
   DC_MOVE_EEF, DC_LOWER_EEF, DC_GRASP, DC_LIFT_Z, DC_LIFT_XY, DC_LIFT_Z_THR, DC_LIFT_XY_THR, DC_ALIGN_POS, DC_ALIGN_ROT,
   DC_ALIGN_POS_THR, DC_ALIGN_ROT_THR, DC_MOVE_POS, DC_MOVE_ROT, DC_MOVE_POS_THR, DC_MOVE_ROT_THR, DC_FINE_EXP, DC_FINE_POS,
-  DC_FINE_ROT, DC_ALIGNED_BONUS, DC_CTRL_PEN, DC_RESET_ROBOT, DC_Z_FINEDIST, DC_GRIPTIP_SITE, DC_GRIP_SITE, DC_WORDS
+  DC_FINE_ROT, DC_ALIGNED_BONUS, DC_CTRL_PEN, DC_RESET_ROBOT, DC_Z_FINEDIST, DC_GRIPTIP_SITE, DC_GRIP_SITE, DC_PHASE_OB, DC_WORDS
 };
 // per-subtask row
 enum { DS_LEG_PART = 0, DS_TABLE_PART, DS_LEG_SITE, DS_TABLE_SITE, DS_GL_SITE, DS_GR_SITE, DS_ANGLE, DS_HAS_ANGLES, DS_WAYPOINT_Z,
@@ -128,9 +128,10 @@ template <class P> DEV DenseOut dense_compute(float *S, const float *C_, const f
     if (ph >= 1 && ph <= 4) s = s && fd > C[DC_EEF_ROT_THR];
     return s;
   };
-  // early picking / early fine alignment (phase_ob False)
-  if (safe_grasp && stable_succ(phase) && phase < 3) phase = 4;
-  if (touched && (phase == 4 || phase == 5)) {
+  // early picking / early fine alignment: only with phase_ob False (furniture_sawyer_dense.py:306-345)
+  const bool skips = C[DC_PHASE_OB] == 0.0f;
+  if (skips && safe_grasp && stable_succ(phase) && phase < 3) phase = 4;
+  if (skips && touched && (phase == 4 || phase == 5)) {
     if ((move_pos_dist < C[DC_MOVE_POS_THR] || move_above_dist < C[DC_MOVE_POS_THR]) && up_ang > C[DC_MOVE_ROT_THR] &&
         fwd_ang > C[DC_MOVE_ROT_THR]) {
       phase = 7;

@@ -14,7 +14,7 @@ DENSE_COEF_DEFAULTS = [
     ("move_rot_dist_coef", 50.0), ("move_pos_threshold", 0.06), ("move_rot_threshold", 0.85),
     ("move_fine_pos_exp_coef", -25.0), ("move_fine_pos_dist_coef", 500.0), ("move_fine_rot_dist_coef", 200.0),
     ("aligned_bonus_coef", 10.0), ("ctrl_penalty_coef", 1e-3), ("reset_robot_after_attach", 0.0), ("z_finedist", 0.05),
-    ("griptip_site", 0.0), ("grip_site", 0.0),
+    ("griptip_site", 0.0), ("grip_site", 0.0), ("phase_ob", 0.0),
 ]
 DENSE_NCOEF = len(DENSE_COEF_DEFAULTS)
 # per-subtask row (floats): see FSIM_DS_* in include/fsim.h

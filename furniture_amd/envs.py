@@ -186,8 +186,6 @@ class FurnitureBatchEnv:
                 raise ValueError("the dense-reward env exists for the Sawyer agent only")
             if not getattr(cfg, "diff_rew", True):
                 raise NotImplementedError("diff_rew=False: the reference itself fails in grasp_leg (furniture_sawyer_dense.py:668)")
-            if getattr(cfg, "phase_ob", False):
-                raise NotImplementedError("phase_ob is not part of the accelerated dense-reward path")
         if cfg.unity or cfg.record_vid:
             # the reference's defaults (config/furniture.py:21-23, 146-148) would launch the Unity binary / a video writer;
             # neither changes what reset()/step() return, so the accelerated env accepts the flags and switches them off
@@ -239,6 +237,7 @@ class FurnitureBatchEnv:
         if dense:
             coef = {k: float(getattr(cfg, k)) for k, _ in DENSE_COEF_DEFAULTS
                     if k not in ("z_finedist", "griptip_site", "grip_site") and getattr(cfg, k, None) is not None}
+            coef["phase_ob"] = 1.0 if getattr(cfg, "phase_ob", False) else 0.0  # also switches the early-pick shortcuts off (furniture_sawyer_dense.py:306)
             self.sim.set_dense_reward(*pack_dense(self.model, coef))
         self._num_connects = getattr(cfg, "num_connects", None)
         if getattr(cfg, "preassembled", None) or self._num_connects is not None:  # config.preassembled / num_connects (furniture.py:163, 1476-1503)
@@ -273,6 +272,8 @@ class FurnitureBatchEnv:
             sp.append(("subtask_ob", spaces.Box(0.0, float(self.n_obj), shape=(2,))))
         if getattr(cfg, "robot_ob", True):
             sp.append(("robot_ob", spaces.Box(-np.inf, np.inf, shape=(self.sim.obs_dim - 7 * self.n_obj,))))
+        if self.dense and getattr(cfg, "phase_ob", False):  # furniture_sawyer_dense.py:98-108
+            sp.append(("phase_ob", spaces.Box(0.0, 1.0, shape=(8,))))
         return spaces.Dict(sp)
 
     @property
@@ -302,6 +303,11 @@ class FurnitureBatchEnv:
             out["subtask_ob"] = (subtask + 1).to(flat.dtype)
         if getattr(cfg, "robot_ob", True):
             out["robot_ob"] = flat[:, k:]
+        if self.dense and getattr(cfg, "phase_ob", False):
+            # one-hot of _phase_i of the state the observation describes (furniture_sawyer_dense.py:111-126): read from the
+            # env's reward variables on the device -- the info word is the phase the step STARTED in
+            ph = self.sim.get_state("dense")["dense"][:, 1].long().clamp(0, 7)
+            out["phase_ob"] = torch.nn.functional.one_hot(ph, 8).to(flat.dtype)
         return out
 
     def _refill(self, mask=None, skip=None):

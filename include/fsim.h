@@ -168,11 +168,11 @@ enum {
 };
 
 /* ---- dense-reward env (FurnitureSawyerDenseRewardEnv) -------------------------------------- */
-/* coef: FSIM_DENSE_NCOEF floats = the config/furniture_sawyer_dense.py coefficients + z_finedist + the griptip/grip site ids, in
+/* coef: FSIM_DENSE_NCOEF floats = the config/furniture_sawyer_dense.py coefficients + z_finedist + the griptip/grip site ids + phase_ob, in
  * the order of furniture_amd/dense.py DENSE_COEF_DEFAULTS; subtasks: [nsub][FSIM_DENSE_SUBW] floats, one row per recipe step
  * (furniture_sawyer_dense.py:149-216: leg/table part, leg/table connector site, grasp-target sites, angle (NaN = None), ...).
  * Host pointers, copied before return. */
-enum { FSIM_DENSE_NCOEF = 33, FSIM_DENSE_SUBW = 16, FSIM_DENSE_OBSW = 40, FSIM_DENSE_STATEW = 27 };
+enum { FSIM_DENSE_NCOEF = 34, FSIM_DENSE_SUBW = 16, FSIM_DENSE_OBSW = 40, FSIM_DENSE_STATEW = 27 };
 int fsim_set_dense_reward(fsim_t *, const float *coef, int ncoef, const float *subtasks, int nsub);
 
 /* ---- pre-assembled starts: FurnitureEnv.set_subtask / config.preassembled / config.num_connects ------------------------

@@ -195,6 +195,15 @@ def test_dense_env_classes_and_auto_reset():
             assert bool((ds[:, 19] == -1).all()) and bool((ds[:, 20] - 0.1).abs().max() < 1e-6)
     venv.close()
 
+    # phase_ob (furniture_sawyer_dense.py:98-126): a one-hot of _phase_i joins the observation
+    env = make("IKEASawyerDense-v0", record_vid=False, phase_ob=True)
+    assert env.observation_space.spaces["phase_ob"].shape == (8,)
+    ob = env.reset()
+    assert ob["phase_ob"].tolist() == np.eye(8)[1].tolist()  # subtask 0 starts in phase 1
+    ob, r, d, info = env.step(np.zeros(9, dtype=np.float32))
+    assert ob["phase_ob"].sum() == 1 and int(np.argmax(ob["phase_ob"])) == int(env.get_env_state()["dense"][1])
+    env.close()
+
 
 def test_dense_env_with_a_preassembled_recipe_step_matches_oracle():
     """FurnitureSawyerDenseRewardEnv with config.preassembled = [0]: the reset connects recipe step 0 and _reset_reward_variables
