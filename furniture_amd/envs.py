@@ -303,7 +303,7 @@ class FurnitureBatchEnv:
             out["subtask_ob"] = (subtask + 1).to(flat.dtype)
         if getattr(cfg, "robot_ob", True):
             out["robot_ob"] = flat[:, k:]
-        if self.dense and getattr(cfg, "phase_ob", False):
+        if getattr(self, "dense", False) and getattr(cfg, "phase_ob", False):
             # one-hot of _phase_i of the state the observation describes (furniture_sawyer_dense.py:111-126): read from the
             # env's reward variables on the device -- the info word is the phase the step STARTED in
             ph = self.sim.get_state("dense")["dense"][:, 1].long().clamp(0, 7)

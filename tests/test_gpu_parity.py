@@ -671,3 +671,21 @@ def test_preassembled_starts_match_the_oracle_env(sawyer_lack):
     st = env._b.sim.get_state("eq_active")
     assert st["eq_active"][0].cpu().numpy().astype(int).tolist() == np.asarray(orc.sim.model.eq_active).astype(int).tolist() == [1, 0]
     env.close()
+
+
+def test_furniture_gym_wrapper_takes_the_reference_kwargs():
+    """furniture/env/furniture_gym.py:16-46: FurnitureGym(id=, name=, **overrides) -> parser defaults, overrides, make_env"""
+    import sys
+    from furniture_amd.config import FurnitureGym
+    argv, sys.argv = sys.argv, ["prog"]
+    try:
+        env = FurnitureGym(id="IKEASawyer-v0", name="FurnitureSawyerEnv", unity=False, record_vid=False, max_episode_steps=4, control_type="impedance")
+    finally:
+        sys.argv = argv
+    assert env._max_episode_steps == 4 and env.num_subtask() == 2  # swivel_chair_0700: the id's furniture
+    ob = env.reset()
+    assert ob["object_ob"].shape == (21,)
+    for t in range(4):
+        ob, r, d, info = env.step(np.zeros(9))
+    assert d and np.isfinite(ob["robot_ob"]).all()
+    env.close()

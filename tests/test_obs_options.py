@@ -92,3 +92,18 @@ def test_bf16_observation_slab_is_the_rounded_f32_one():
         assert torch.equal(ra, rb) and torch.equal(da, db)
     a.close()
     b.close()
+
+
+def test_argparse_intake_has_the_reference_option_names():
+    """furniture/config/__init__.py:7-35: create_parser(env) -> namespace with the reference's option names and defaults"""
+    import sys
+    from furniture_amd.config import create_parser
+    argv, sys.argv = sys.argv, ["prog"]
+    try:
+        cfg, _ = create_parser("IKEASawyer-v0").parse_known_args(["--max_episode_steps", "50", "--preassembled", "0,1", "--unity", "False"])
+        assert cfg.max_episode_steps == 50 and cfg.preassembled == [0, 1] and cfg.unity is False and cfg.control_type == "ik"
+        assert cfg.alignment_pos_dist == 0.1 and cfg.seed == 123 and cfg.num_connects is None
+        d, _ = create_parser("IKEASawyerDense-v0").parse_known_args([])
+        assert d.max_episode_steps == 150 and d.control_type == "impedance" and d.phase_bonus == 5000.0 and d.phase_ob is False
+    finally:
+        sys.argv = argv
