@@ -128,27 +128,35 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
 // Key (written by env_step): -1 = will reset; bit 30 = a robot hand is near a part (likely to couple); low bits = shader
 // cycles >> 10 of the step just taken.  One workgroup, bucket sort: [reset | near, by cost | the rest, by cost]; order
 // inside a bucket is arbitrary -- it only affects timing, never results (envs are independent).
-__global__ __launch_bounds__(1024) void k_schedule(const int *cost, int *order, int n) {
-  __shared__ int hist[257], mx;
-  int tid = threadIdx.x;
-  if (tid < 257) hist[tid] = 0;
-  if (tid == 0) mx = 0;
-  __syncthreads();
+// ONE wavefront with a few registers: the kernel runs between two step kernels of its stream while the other slab's step kernel
+// holds every SIMD's register file (2 x 256 VGPRs) -- a 1024-thread workgroup had to wait ~0.2 ms for a whole CU to drain
+// before it could start (rocprofv3: 217 us average for 10 us of work), a single small wave takes the first slot that frees.
+__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n) {
+  __shared__ int hist[257];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < 257; b += 64) hist[b] = 0;
   int lm = 0;
-  for (int i = tid; i < n; i += 1024) { int cv = cost[i]; if (cv >= 0) lm = max(lm, cv & 0x3fffffff); }
-  atomicMax(&mx, lm);
+  for (int i = tid; i < n; i += 64) { int cv = cost[i]; if (cv >= 0) lm = max(lm, cv & 0x3fffffff); }
+  for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
   __syncthreads();
-  long long M = (long long)mx + 1;
+  const long long M = (long long)lm + 1;
   auto bucket = [&](int cv) {
     if (cv < 0) return 0;
     int base = (cv >> 30) & 1 ? 1 : 129;
     return base + 127 - (int)((long long)(cv & 0x3fffffff) * 128 / M);
   };
-  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[bucket(cost[i])], 1);
+  for (int i = tid; i < n; i += 64) atomicAdd(&hist[bucket(cost[i])], 1);
   __syncthreads();
-  if (tid == 0) { int acc = 0; for (int b = 0; b < 257; b++) { int h = hist[b]; hist[b] = acc; acc += h; } }
+  { // exclusive prefix sum over the 257 buckets: five consecutive buckets per lane, wave scan of the lane totals
+    int h[5], tot = 0;
+    for (int k = 0; k < 5; k++) { const int b = 5 * tid + k; h[k] = b < 257 ? hist[b] : 0; tot += h[k]; }
+    int inc = tot;
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if (tid >= o) inc += up; }
+    int acc = inc - tot;
+    for (int k = 0; k < 5; k++) { const int b = 5 * tid + k; if (b < 257) hist[b] = acc; acc += h[k]; }
+  }
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
+  for (int i = tid; i < n; i += 64) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
 }
 
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays
@@ -680,7 +688,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
-  if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(1024), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
+  if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
   if (s->timing) timing_begin(s);
   hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
                      action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
