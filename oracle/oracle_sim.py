@@ -27,7 +27,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        L = ctypes.CDLL(os.environ.get("OSIM_LIB") or build())  # (OSIM_LIB: the sanitizer build, tests/test_oracle_sanitizers.py)
         L.osim_create.restype = ctypes.c_void_p
         L.osim_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.osim_destroy.argtypes = [ctypes.c_void_p]
