@@ -309,7 +309,8 @@ static int build_model(fsim *s) {
   s->nbody = m.nbody; s->ngeom = m.ngeom;
   m.timestep = opt[0]; m.gravity[0] = opt[1]; m.gravity[1] = opt[2]; m.gravity[2] = opt[3]; m.impratio = opt[4];
   m.meaninertia_scale = 1.0f / fmaxf(trace[0], 1e-15f);
-  if (m.nv > 64) FAIL(FSIM_ENOMEM, "nv=%d > 64: the lane-per-row Newton factorisation supports at most 64 dofs", m.nv);
+  if (m.nv > 128) FAIL(FSIM_ENOMEM, "nv=%d > 128: the Newton factorisation maps the dofs on two passes of 64 solver lanes", m.nv);
+  if (m.nparts > 10) FAIL(FSIM_ENOMEM, "%d furniture parts: with more than 10 parts the contacts at rest (4 per part on the floor plus part-part contacts) exceed the 64 contact slots one wavefront scans", m.nparts);
   if (m.nr > 31) FAIL(FSIM_ENOMEM, "more than 31 moving bodies");
   if (m.ncp > 65535) FAIL(FSIM_ENOMEM, "too many candidate pairs");
   if (m.ncg > 255) FAIL(FSIM_ENOMEM, "more than 255 colliding geoms (broadphase records hold 8-bit geom indices)");
@@ -404,6 +405,8 @@ static LayoutIn layout_in(const fsim *s, int ncon_max) {
   in.env_words = E_FIXED_WORDS + m.nparts + env_extra_words(m, s->cfg);
   in.eik_rel = s->cfg.dense_reward ? ED_WORDS : 0;
   in.ncon_max = ncon_max;
+  // furniture with many long parts (bookcase planks lying side by side): more part-part pairs survive the broadphase
+  in.maxsurv = m.nparts > 8 ? 128 : FSIM_MAXSURV;
   return in;
 }
 
@@ -431,7 +434,8 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (cfg) s->cfg = *cfg; else fsim_default_config(&s->cfg);
   int rc = build_model(s);
   if (rc) { delete s; return rc; }
-  int ncon_max = 48;
+  // contact slots: 48 by default; furniture with nine or more parts (>= 36 part-floor contacts at rest) gets the 64 a wave can scan
+  int ncon_max = (s->m.nparts > 8 || s->m.ncg > 48) ? 64 : 48; // (or many collision primitives per part: chairs, table_torsby)
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
   if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
@@ -443,7 +447,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (s->m.nu != 9 || ag.size() != 9 || ag[0] != 1.0f) { delete s; FAIL(FSIM_EINVAL, "arm controllers need the motor-actuated model (compiled with a torque-level control_type, robot_torque.xml)"); }
   }
   if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
-  if (s->m.ntree > 16 || s->m.nv > 64) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 64 dofs (one lane per dof)", nt_, nv_); }
+  if (s->m.ntree > 16 || s->m.nv > 128) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 128 dofs", nt_, nv_); }
   const LayoutIn lin = layout_in(s, ncon_max);
   s->ly = make_layout(lin);
   s->ks = pick_kernels(s->m, lin);

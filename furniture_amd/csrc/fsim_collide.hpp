@@ -593,10 +593,10 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
     }
     unsigned long long mask = __ballot(pass);
     int idx = nsurv + __popcll(mask & ((1ull << c.lane) - 1ull));
-    if (pass && idx < FSIM_MAXSURV) surv[idx] = p;
+    if (pass && idx < c.ly.maxsurv) surv[idx] = p;
     nsurv += __popcll(mask);
   }
-  if (nsurv > FSIM_MAXSURV) { nsurv = FSIM_MAXSURV; if (c.lane == 0) scal[SC_OVERFLOW] |= 1; }
+  if (nsurv > c.ly.maxsurv) { nsurv = c.ly.maxsurv; if (c.lane == 0) scal[SC_OVERFLOW] |= 1; }
   SYNC();
   if (c.lane == 0) { scal[SC_NSURV] = nsurv; scal[SC_NSLOT] = 0; }
   SYNC();

@@ -16,7 +16,7 @@
 #define FSIM_XW 54       // words per body-pair block: the 6 x 6 cross block X, overwritten by Y = X * cdof (6 x chain length <= 9)
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
-#define FSIM_MAXSURV 48  // broadphase survivors per substep (22 is the most seen on Sawyer + table_lack)
+#define FSIM_MAXSURV 48  // broadphase survivors per substep of models with <= 8 parts (22 is the most seen on Sawyer + table_lack); LayoutIn::maxsurv
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
@@ -88,7 +88,7 @@ struct Layout {
   int hmap;   // per-substep island map of the Newton system (FSIM_MAPW(nv) words, format at fs_build_map in fsim_solver.hpp)
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int pitem;  // [FSIM_PCAP] body-pair projection items of this substep (fs_pair_cache)
-  int lds_words, ncon_max;
+  int lds_words, ncon_max, maxsurv;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
   int k_dof_parent, k_r_submask, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_chain, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
   int k_begin, k_end;
@@ -132,6 +132,7 @@ struct LayoutIn {
   int env_words; // env-logic block of the record: E_FIXED_WORDS + nparts + agent / reward / controller extras
   int eik_rel;   // offset of the IK blocks behind the group table (the dense block, if any, comes first)
   int ncon_max;
+  int maxsurv;   // broadphase survivor list (FSIM_MAXSURV; more for furniture with many long parts lying next to each other)
 };
 
 // One function for host and device: fsim_create calls it at run time, fsim_spec.hpp at compile time.
@@ -170,7 +171,7 @@ constexpr Layout make_layout(const LayoutIn &in) {
     // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
     ly.W = ly.gpos; ly.G = ly.gpos + 6 * in.nr;
   }
-  TAKE(surv, FSIM_MAXSURV); TAKE(pitem, FSIM_PCAP);
+  TAKE(surv, in.maxsurv); TAKE(pitem, FSIM_PCAP);
   TAKE(con, FSIM_CONW * in.ncon_max); TAKE(weld, FSIM_WELDW * in.neq); TAKE(lim, FSIM_LIMW * 2 * in.nlim);
   TAKE(scal, SC_WORDS); TAKE(hmap, FSIM_MAPW(in.nv));
   // LDS model cache
@@ -186,6 +187,7 @@ constexpr Layout make_layout(const LayoutIn &in) {
 #undef TAKE
   ly.lds_words = o;
   ly.ncon_max = in.ncon_max;
+  ly.maxsurv = in.maxsurv;
   return ly;
 }
 

@@ -92,9 +92,10 @@ template <class S> DEV SpecCtx<S> fs_rebuild(const SpecCtx<S> &cv, float *lds) {
 //   [0, nv)        per dof:  row base in the packed triangles (12 bits) | local index l in its island (6) << 12 |
 //                            island size nI (7) << 18 | solver lane (6) << 25
 //   [nv, nv + 64)  per lane: byte 0 = dof this lane owns in the ROW phase (0xff none), byte 1 = dof it owns in the BIG phase,
-//                            byte 2 = number of occupied positions in the lane's 16-lane row
-//   [nv + 64, +16) tail:     [0] row-phase steps (largest row fill), [1] number of big islands, [2 + 2b], [3 + 2b] = first
-//                            lane and size of big island b (b < 6), [14] largest big island
+//                            byte 2 = dof it owns in the SECOND row pass (models with more than 64 dofs: the four 16-lane rows are
+//                            filled twice)
+//   [nv + 64, +16) tail:     [0] row-phase steps (largest row fill) of pass 0 | pass 1 << 8, [1] number of big islands,
+//                            [2 + 2b], [3 + 2b] = first lane and size of big island b (b < 6), [14] largest big island
 // Islands of <= 16 dofs are packed into the four 16-lane DPP rows of the wave (several islands may share a row: they are
 // factored as one block-diagonal matrix); the factorisation then needs no LDS traffic at all -- the pivot row travels by
 // `row_newbcast` DPP moves.  Larger islands (a robot holding two parts, Baxter's 19-dof tree) get a contiguous lane range
@@ -119,34 +120,41 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
     // islands in the order of their lowest tree: H base, then a lane range.  Small islands go to the least-filled row that
     // still has room (keeps the row phase short: 9 | 6+6 | 6+6 | 6 for a free Sawyer + table_lack), the others (and any small
     // island that no row can take) become "big".
-    int fill[4] = {0, 0, 0, 0}, hb = 0, sb = 0, nbig = 0, maxbig = 0;
+    // (a model with more than 64 dofs fills the four rows a second time: second row pass of fs_chol_solve)
+    const int nrow = nv > 64 ? 8 : 4;
+    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hb = 0, sb = 0, nbig = 0, maxbig = 0;
     for (int u = 0; u < ntree; u++) {
       if (__ffs(isl[u]) - 1 != u) continue;
       const int n = (tmp[u] >> 8) & 255;
       tmp[16 + u] = hb;
       hb += n * (n + 1) / 2;
       int row = -1;
-      if (n <= 16) for (int r = 0; r < 4; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
+      if (n <= 16) {
+        for (int r = 0; r < 4; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
+        if (row < 0) for (int r = 4; r < nrow; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
+      }
       int lane0;
-      if (row >= 0) { lane0 = 16 * row + fill[row]; fill[row] += n; }
+      if (row >= 0) { lane0 = 16 * (row & 3) + fill[row]; fill[row] += n; }
       else { lane0 = sb; if (nbig < MAP_BIGCAP) { tail[MAP_BIG0 + 2 * nbig] = sb; tail[MAP_BIG0 + 2 * nbig + 1] = n; } nbig++; sb += n; maxbig = max(maxbig, n); }
-      tmp[u] |= (lane0 << 16) | ((row < 0 ? 1 : 0) << 24);
+      tmp[u] |= (lane0 << 16) | ((row < 0 ? 1 : 0) << 24) | ((row >= 4 ? 1 : 0) << 25);
+      // an island of more than 64 dofs (or big islands that overflow the 64 big-phase lanes) cannot be mapped: the solve is
+      // flagged bad, which the env treats like an unstable simulation -- a robot holding ten mutually coupled parts
+      if (n > 64 || sb > 64) scal_[SC_BAD] |= 3;
     }
-    tail[MAP_RSTEPS] = max(max(fill[0], fill[1]), max(fill[2], fill[3]));
+    tail[MAP_RSTEPS] = max(max(fill[0], fill[1]), max(fill[2], fill[3])) | (max(max(fill[4], fill[5]), max(fill[6], fill[7])) << 8);
     tail[MAP_NBIG] = nbig;
     tail[MAP_MAXBIG] = nbig > MAP_BIGCAP ? 99 : maxbig; // (more big islands than the table holds: LDS fallback handles them all)
-    tail[15] = fill[0] | (fill[1] << 8) | (fill[2] << 16) | (fill[3] << 24);
     scal_[hwords_slot] = hb;
   }
   SYNC();
-  hm[nv + c.lane] = 0xffff | (((tail[15] >> (8 * (c.lane >> 4))) & 255) << 16);
+  hm[nv + c.lane] = 0xffffff;
   SYNC();
   for (int i = c.lane; i < nv; i += 64) {
     const int t = KI(r_tree, KI(dof_rbody, i)), rep = __ffs(isl[t]) - 1;
     const int nI = (tmp[rep] >> 8) & 255, l = (tmp[t] & 255) + i - KI(tree_dofadr, t), lane = ((tmp[rep] >> 16) & 63) + l;
     hm[i] = (tmp[16 + rep] + l * (l + 1) / 2) | (l << 12) | (nI << 18) | (lane << 25);
-    const bool big = (tmp[rep] >> 24) & 1;
-    reinterpret_cast<unsigned char *>(hm + nv)[4 * lane + (big ? 1 : 0)] = (unsigned char)i;
+    const bool big = (tmp[rep] >> 24) & 1, second = (tmp[rep] >> 25) & 1;
+    if (lane < 64) reinterpret_cast<unsigned char *>(hm + nv)[4 * lane + (big ? 1 : (second ? 2 : 0))] = (unsigned char)i;
   }
   SYNC();
 }

@@ -1080,7 +1080,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
-  const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
+  const int rs2 = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
 #ifdef FSIM_PROFILE
   if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += nbig > 0; }
 #endif
@@ -1091,11 +1091,17 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
 #else
 #define FS_CHPROF(slot) do { } while (0)
 #endif
-  if (rsteps > 0) {
-    const int dofr = lw & 255;
-    const int dof = dofr == 255 ? -1 : dofr;
-    if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
-    else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+  // (second row pass: only models with more than 64 dofs have one -- a compile-time fact for the specialised kernels)
+  const int npass = c.D.nv > 64 ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; pass++) {
+    const int rsteps = (rs2 >> (8 * pass)) & 255;
+    if (rsteps > 0) {
+      const int dofr = (lw >> (16 * pass)) & 255;
+      const int dof = dofr == 255 ? -1 : dofr;
+      if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+      else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+    }
   }
   FS_CHPROF(48);
   if (nbig > 0) {
