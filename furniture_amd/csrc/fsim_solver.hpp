@@ -878,7 +878,9 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
       e[q] = H[hI + (l >= lq ? triL + lq : triQ + l)];
       lq++; triQ += lq;
     }
-    if (NLOC == 12)
+    if (NLOC == 6)
+      asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));
+    else if (NLOC == 12)
       asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
     else
 #pragma unroll
@@ -1099,7 +1101,9 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
     if (rsteps > 0) {
       const int dofr = (lw >> (16 * pass)) & 255;
       const int dof = dofr == 255 ? -1 : dofr;
-      if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+      // (<= 6: what is left for the rows when the robot and the part it holds form a big island -- single parts, one per row)
+      if (rsteps <= 6) bad |= fs_chol_phase<6>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+      else if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
       else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
     }
   }
