@@ -923,9 +923,9 @@ extern "C" int fsim_step(fsim_t *s, const float *action, void *obs, float *rewar
 }
 extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
   if (!s || n_pre < 0 || n_pre > 16 || (n_pre > 0 && !ids)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: bad arguments");
-  const bool recipe = s->ecfg.has_recipe != 0;
+  const bool recipe = s->ecfg.has_recipe != 0 && conn_pairs != nullptr; // (no connector pairs: the list holds weld ids -- config.assembled)
   if (n_pre > 0 && s->d_init) FAIL(FSIM_EINVAL, "fsim_set_preassembled: not combined with fsim_set_init_state");
-  if (n_pre > 0 && recipe && (!conn_pairs || !angles)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: this furniture has a recipe: pass the connector pair and angle of every listed recipe step");
+  if (n_pre > 0 && recipe && !angles) FAIL(FSIM_EINVAL, "fsim_set_preassembled: recipe steps need their angles next to the connector pairs");
   std::vector<int> tab(3 * (size_t)n_pre, 0);
   for (int i = 0; i < n_pre; i++) {
     if (recipe) {

@@ -87,6 +87,7 @@ class ResetTableSampler:
         assert len(idx) == n_envs
         self.rngs = [np.random.RandomState(seed + i) for i in idx]
         self.hist = [[] for _ in idx]  # RNG states before each of the last draws (rng_handover rolls unconsumed draws back)
+        self._fixed = [None] * n_envs  # config.fix_init (furniture.py:1518-1525): the first placement of an env is kept for its later resets
         self.narm = len(model.arm_qposadr)
 
     def _placement(self, rng):
@@ -125,7 +126,13 @@ class ResetTableSampler:
             if mask is not None and not mask[i]:
                 continue
             self.hist[i] = self.hist[i][-2:] + [rng.get_state()]
-            parts[i] = self._placement(rng).reshape(-1)
+            if getattr(self.cfg, "fix_init", False) and self._fixed[i] is not None:
+                placement = self._fixed[i]  # (no placement draw: _place_objects is not called again)
+            else:
+                placement = self._placement(rng).reshape(-1)
+                self._fixed[i] = placement
+            # config.assembled (furniture.py:1526-1530): the parts stay where sim.reset() put them (the XML's assembled poses); the draw is still taken
+            parts[i] = np.asarray(self.m.part_initqpos, dtype=np.float64).reshape(-1) if getattr(self.cfg, "assembled", False) else placement
             if self.narm:
                 a = self.cfg.agent_xyz_rand
                 # one (101, narm) draw consumes the Mersenne-Twister stream exactly like 101 successive size-narm draws
@@ -207,7 +214,7 @@ class FurnitureBatchEnv:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them
         for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect)"),
-                          ("no_collision", "furniture.py:1919-1924"), ("fix_init", "furniture.py:1516-1521"), ("assembled", "furniture.py:1503, 1526"),
+                          ("no_collision", "furniture.py:1919-1924"),
                           ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325")):
             if getattr(cfg, flag, None):
                 raise NotImplementedError("config.%s (%s) is not part of the accelerated path" % (flag, ref))
@@ -240,7 +247,11 @@ class FurnitureBatchEnv:
             coef["phase_ob"] = 1.0 if getattr(cfg, "phase_ob", False) else 0.0  # also switches the early-pick shortcuts off (furniture_sawyer_dense.py:306)
             self.sim.set_dense_reward(*pack_dense(self.model, coef))
         self._num_connects = getattr(cfg, "num_connects", None)
-        if getattr(cfg, "preassembled", None) or self._num_connects is not None:  # config.preassembled / num_connects (furniture.py:163, 1476-1503)
+        if getattr(cfg, "assembled", False):  # furniture.py:1502-1503, 1526-1530: every weld on from the start, one group
+            if getattr(cfg, "preassembled", None):
+                raise ValueError("config.assembled and config.preassembled exclude each other (furniture.py:1493-1503)")
+            self.sim.set_preassembled(list(range(self.model.neq)), self._num_connects, welds=True)
+        elif getattr(cfg, "preassembled", None) or self._num_connects is not None:  # config.preassembled / num_connects (furniture.py:163, 1476-1503)
             self.sim.set_preassembled(list(getattr(cfg, "preassembled", None) or []), self._num_connects)
         self.num_envs = num_envs
         torch = self.sim.torch

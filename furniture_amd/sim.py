@@ -223,10 +223,13 @@ class FSim:
         subtasks = np.ascontiguousarray(subtasks, dtype=np.float32)
         self._chk(lib().fsim_set_dense_reward(self._h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
 
-    def set_preassembled(self, preassembled, num_connects=None):
+    def set_preassembled(self, preassembled, num_connects=None, welds=False):
         """config.preassembled / set_subtask (furniture.py:163, 204-207): weld ids (furniture without a recipe) or recipe step
-        indices (with one) that every following reset starts from; num_connects as in config.num_connects."""
+        indices (with one) that every following reset starts from; num_connects as in config.num_connects.  welds=True: the list
+        holds weld ids whatever the furniture (config.assembled: all of them)."""
         ids, pairs, angles = preassembled_rows(self.cm, preassembled)
+        if welds:
+            pairs, angles = None, None
         self._chk(lib().fsim_set_preassembled(self._h, len(ids), ids.ctypes.data, pairs.ctypes.data if pairs is not None else None,
                                               angles.ctypes.data if angles is not None else None, -1 if num_connects is None else int(num_connects)))
 

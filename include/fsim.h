@@ -184,6 +184,8 @@ int fsim_set_dense_reward(fsim_t *, const float *coef, int ncoef, const float *s
  *                        arguments of the reset's _connect(site2_id, site1_id) -- and
  *   angles[n_pre]        the recipe's angle in degrees, NaN for none (_project_connector_quat);
  *   num_connects         config.num_connects: success when num_connected == num_connects + n_pre; < 0 = None (all parts).
+ * conn_pairs = NULL: ids are weld ids whatever the furniture (config.assembled, furniture.py:1502-1503: all welds on, the host leaves
+ * the parts at the XML's assembled poses).
  * n_pre = 0 restores the default.  Not combined with fsim_set_init_state (either call then returns FSIM_EINVAL).  Host pointers. */
 int fsim_set_preassembled(fsim_t *, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects);
 

@@ -54,6 +54,8 @@ class OracleConfig:
         self.dense = None  # an oracle.dense_reward.DenseConfig -> FurnitureSawyerDenseRewardEnv behaviour
         self.preassembled = []   # config.preassembled (furniture.py:163): weld ids / recipe steps every reset starts from
         self.num_connects = None  # config.num_connects
+        self.assembled = False    # config.assembled (furniture.py:1502-1503, 1526-1530)
+        self.fix_init = False     # config.fix_init (furniture.py:1518-1525)
         self.control_type = "impedance"  # or one of NEW_CONTROLLERS (furniture.py:41-47): needs the __torque compiled model
         for k, v in kw.items():
             setattr(self, k, v)
@@ -263,6 +265,8 @@ class FurnitureEnvOracle:
         self._picked = [False] * self.nparts
         sim.model.eq_active[:] = 0
         sim.model.eq_data[:] = m.eq_data0
+        if getattr(self.cfg, "assembled", False) and not pre:  # F.py:1502-1503
+            sim.model.eq_active[:] = 1
         if pre and not self._has_recipe:  # F.py:1493-1501: the listed welds are on from the start, their groups merged
             for e in pre:
                 sim.model.eq_active[e] = 1
@@ -282,10 +286,16 @@ class FurnitureEnvOracle:
                 sim.forward()
         else:
             # placement (init_pos is sampled on first reset and re-sampled afterwards: fix_init=False)
-            pos, quat = sample_placement(self._rng, m, self.cfg)
-            self.reset_draws["part_qpos"] = np.array([np.concatenate([pos[i], quat[i]]) for i in range(self.nparts)])
-            for i in range(self.nparts):
-                self._set_part_qpos(i, pos[i], quat[i])
+            if self.init_pos is None or not getattr(self.cfg, "fix_init", False):  # F.py:1518-1525
+                self.init_pos, self.init_quat = sample_placement(self._rng, m, self.cfg)
+            pos, quat = self.init_pos, self.init_quat
+            if getattr(self.cfg, "assembled", False):  # F.py:1526-1530: one group, the parts stay at the XML's assembled poses
+                self._group = [0] * self.nparts
+                self.reset_draws["part_qpos"] = np.asarray(m.part_initqpos, dtype=np.float64).copy()
+            else:
+                self.reset_draws["part_qpos"] = np.array([np.concatenate([pos[i], quat[i]]) for i in range(self.nparts)])
+                for i in range(self.nparts):
+                    self._set_part_qpos(i, pos[i], quat[i])
             self._settle()
             if self._has_recipe:
                 self._preassemble(pre, auto_align=True)

@@ -689,3 +689,41 @@ def test_furniture_gym_wrapper_takes_the_reference_kwargs():
         ob, r, d, info = env.step(np.zeros(9))
     assert d and np.isfinite(ob["robot_ob"]).all()
     env.close()
+
+
+def test_assembled_and_fix_init_match_the_oracle_env(sawyer_lack):
+    """config.assembled (every weld on from the start, one group, the parts start from the XML layout and are pulled together) and
+    config.fix_init (the first placement is kept; later resets take no placement draw), furniture.py:1502-1503, 1518-1530"""
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=50, seed=21)
+    cat = lambda d: np.concatenate([d["object_ob"], d["robot_ob"]])
+    env = FurnitureSawyerEnv(make_config(fix_init=True, **kw))
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=21, solver_tolerance=1e-10, fix_init=True))
+    first = None
+    for rep in range(3):
+        o = orc.flat_obs(orc.reset())
+        d = cat(env.reset())
+        assert np.abs(d - o).max() < 2e-4, rep
+        if first is None:
+            first = d[:35].copy()
+        else:
+            assert np.abs(d[:35] - first).max() < 1e-4  # the same placement every time (the robot's joint noise differs)
+    env.close()
+    env = FurnitureSawyerEnv(make_config(assembled=True, **kw))
+    orc = FurnitureEnvOracle(sawyer_lack, OracleConfig(max_episode_steps=50, seed=21, solver_tolerance=1e-10, assembled=True))
+    o = orc.flat_obs(orc.reset())
+    d = cat(env.reset())
+    st = env._b.sim.get_state("eq_active")
+    assert st["eq_active"][0].cpu().numpy().astype(int).tolist() == [1] * sawyer_lack.neq
+    # five parts yanked together over ~1 m by four welds inside the reset -- a violent transient in which the two integrators part
+    # company; what both must reach is the assembled configuration: every weld's relative pose as the model prescribes it
+    from furniture_amd import transform_utils as T
+    for dev_or_orc in (d, o):
+        parts = dev_or_orc[:35].reshape(5, 7)
+        assert np.isfinite(dev_or_orc).all()
+        for e in range(sawyer_lack.neq):
+            rel = T.rel_pose(parts[int(sawyer_lack.eq_part1[e])], parts[int(sawyer_lack.eq_part2[e])])
+            assert np.abs(rel[:3] - sawyer_lack.eq_data0[e][:3]).max() < 2e-2, (e, rel[:3], sawyer_lack.eq_data0[e][:3])
+    ob, r, done, info = env.step(np.zeros(9))
+    assert info["num_connected"] == 0 and not done and np.isfinite(cat(ob)).all()
+    env.close()

@@ -61,3 +61,41 @@ def test_oracle_reset_with_welds_preassembled_without_a_recipe():
     from furniture_amd import transform_utils as T
     rel = T.rel_pose(env._part_qpos(p1), env._part_qpos(p2))
     assert np.abs(rel[:3] - m.eq_data0[0][:3]).max() < 5e-3
+
+
+def test_oracle_assembled_and_fix_init():
+    """config.assembled (furniture.py:1502-1503, 1526-1530): every weld on, one group, the parts stay at the XML's assembled poses;
+    config.fix_init (furniture.py:1518-1525): the first placement is kept, later resets take no placement draw"""
+    m = load_compiled("Sawyer", "table_lack_0825")
+    env = FurnitureEnvOracle(m, OracleConfig(seed=4, assembled=True))
+    ob = env.reset()
+    assert np.asarray(env.sim.model.eq_active).astype(int).tolist() == [1] * m.neq
+    assert len({env._find_group(i) for i in range(env.nparts)}) == 1 and (env._subtask_part1, env._subtask_part2) == (-1, -1)
+    # (the XML lays the parts out side by side: the active welds pull them into the assembled relative poses during the reset)
+    from furniture_amd import transform_utils as T
+    for e in range(m.neq):
+        rel = T.rel_pose(env._part_qpos(int(m.eq_part1[e])), env._part_qpos(int(m.eq_part2[e])))
+        assert np.abs(rel[:3] - m.eq_data0[e][:3]).max() < 2e-2, (e, rel[:3], m.eq_data0[e][:3])
+    assert np.isfinite(env.flat_obs(ob)).all()
+    a = FurnitureEnvOracle(m, OracleConfig(seed=4, fix_init=True))
+    b = FurnitureEnvOracle(m, OracleConfig(seed=4))
+    a.reset(); b.reset()
+    pa0, pb0 = a.reset_draws["part_qpos"].copy(), b.reset_draws["part_qpos"].copy()
+    assert np.array_equal(pa0, pb0)
+    a.reset(); b.reset()
+    assert np.array_equal(a.reset_draws["part_qpos"], pa0) and not np.array_equal(b.reset_draws["part_qpos"], pb0)
+    # ... and the robot noise of the second reset comes earlier in the stream (no placement draws in between)
+    assert not np.array_equal(np.stack(a.reset_draws["noise"]), np.stack(b.reset_draws["noise"]))
+
+
+def test_host_sampler_follows_fix_init_and_assembled():
+    from furniture_amd.envs import ResetTableSampler, make_config
+    m = load_compiled("Sawyer", "table_lack_0825")
+    for kw in (dict(fix_init=True), dict(assembled=True), dict()):
+        s = ResetTableSampler(m, make_config(**kw), 4, 0, 1)
+        o = FurnitureEnvOracle(m, OracleConfig(seed=4, **kw))
+        for rep in range(3):
+            p, nz = s.draw()
+            o.reset()
+            assert np.abs(p[0] - o.reset_draws["part_qpos"].reshape(-1)).max() < 1e-6, (kw, rep)
+            assert np.abs(nz[0] - np.stack(o.reset_draws["noise"]).reshape(-1)).max() < 1e-7, (kw, rep)
