@@ -1084,7 +1084,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int lw = c.I(mp)[nv + c.lane];
   const int rs2 = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]), nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
 #ifdef FSIM_PROFILE
-  if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += nbig > 0; }
+  if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += (nbig > 0) + ((nbig > 0 && tail[MAP_MAXBIG] > 31) << 10); } // (bits 10..15: solves with an island beyond the MFMA tile)
 #endif
   int bad = 0;
 #ifdef FSIM_CHOLPROF

@@ -24,10 +24,10 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 80):
     tot = (p[:, 1] + p[:, 3] + p[:, 4] + p[:, 16:22].sum(axis=1)) * 16
     e = int(np.argmax(tot))
     nsub, nit, maxit = p[e, 5], p[e, 6], p[e, 10]
-    nbig, szsum = p[e, 36] & 0xffff, p[e, 35]
+    nbig, szsum, nover = p[e, 36] & 0x3ff, p[e, 35], (p[e, 36] >> 10) & 0x3f
     unc = (p[e, 36] >> 16) & 0xff
-    rows.append((dt * 1e3, tot[e] / 1e6, nit / max(1, nsub), maxit, nbig, szsum / max(1, nbig), unc, np.sort(tot)[-5] / 1e6))
+    rows.append((dt * 1e3, tot[e] / 1e6, nit / max(1, nsub), maxit, nbig, szsum / max(1, nbig), unc, np.sort(tot)[-5] / 1e6, nover))
     if t >= 8:
-        print("step %2d: %.1f ms | worst env %4d: %.1f Mcyc, it/substep %.2f (max %d), solves with a big island %d (mean size %.1f), uncached-pair solves %d | 5th worst %.1f Mcyc" % ((t, rows[-1][0], e) + rows[-1][1:]))
+        print("step %2d: %.1f ms | worst env %4d: %.1f Mcyc, it/substep %.2f (max %d), solves with a big island %d (mean size %.1f), uncached-pair solves %d | 5th worst %.1f Mcyc | solves with an island > 31 dofs (at least, 6-bit counter) %d" % ((t, rows[-1][0], e) + rows[-1][1:]))
 R = np.array(rows[8:])
 print("mean step %.2f ms; worst env mean %.1f Mcyc; steps with worst > 16 Mcyc: %d of %d; mean big-island size of the worst env %.1f" % (R[:, 0].mean(), R[:, 1].mean(), (R[:, 1] > 16).sum(), len(R), R[:, 5].mean()))

@@ -40,7 +40,7 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         print("    line search: evaluations per Newton iteration: all envs %.2f, slow (top 64) %.2f" % (
             pall[:, 13].sum() / max(1, pall[:, 14].sum()), pall[np.argsort(-tot)[:64], 13].sum() / max(1, pall[np.argsort(-tot)[:64], 14].sum())))
         for e in np.argsort(-tot)[:3]:
-            print("    SLOW env %d: Newton solves with a big island %d, mean size %.1f; solves with cached body pairs %d, with uncached (multi-pass) pairs %d" % (e, pall[e, 36] & 0xffff, pall[e, 35] / max(1, pall[e, 36] & 0xffff), pall[e, 36] >> 24, (pall[e, 36] >> 16) & 0xff))
+            print("    SLOW env %d: Newton solves with a big island %d, mean size %.1f; solves with cached body pairs %d, with uncached (multi-pass) pairs %d" % (e, pall[e, 36] & 0x3ff, pall[e, 35] / max(1, pall[e, 36] & 0x3ff), pall[e, 36] >> 24, (pall[e, 36] >> 16) & 0xff))
             print("    SLOW env %d: Mcyc %.1f it/sub %.2f coupled %.2f | per-substep kcyc: " % (e, tot[e] / 1e6, nit[e] / max(1, nsub[e]), ncoup[e] / max(1, nsub[e])) + " ".join("%s %.1f" % (n, v / 50e3) for n, v in zip(fn, fine[e])) + " | collide %.1f constraints %.1f" % (cyc[e, 1] / 50e3, cyc[e, 3] / 50e3))
     if t == 5:
         for e in list(np.argsort(-tot)[:4]) + [int(np.argsort(tot)[N // 2])]:
