@@ -409,6 +409,14 @@ class FurnitureBatchEnv:
                 self._tables_fresh[need > 0] = False
                 self._refill(need > 0, skip=need > 1)
         info = self._info
+        # a model whose contacts do not fit the 48 / 64 slots of a wavefront loses contacts silently otherwise: say so once
+        self._steps_done = getattr(self, "_steps_done", 0) + 1
+        if not getattr(self, "_overflow_warned", False) and self._steps_done % 64 == 1 and bool((info[:, 12] != 0).any()):
+            import warnings
+            warnings.warn("furniture_amd: %s overflowed the contact slots / broadphase list of the step kernel (info['contact_overflow']); "
+                          "contacts are being dropped -- this furniture has more simultaneous contacts than the accelerated path holds"
+                          % self.furniture_name, stacklevel=2)
+            self._overflow_warned = True
         infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
                      site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
                      connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
