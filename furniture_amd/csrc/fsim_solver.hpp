@@ -1110,7 +1110,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   FS_CHPROF(48);
   if (nbig > 0) {
     const int maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
-    if (maxbig > 32) bad |= fs_chol_lds(c, mp);
+    if (maxbig > 31) bad |= fs_chol_lds(c, mp);
     else {
       const int dofb = (lw >> 8) & 255;
 #pragma unroll 1
@@ -1123,8 +1123,8 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
         if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, bc);
         else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc);
 #else
-        if (n <= 31) bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
-        else { LaneBcast bc; bc.first = first; bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc); }
+        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
+        (void)dof;
 #endif
       }
     }
