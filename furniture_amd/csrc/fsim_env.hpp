@@ -206,15 +206,17 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
 template <bool CTRL, class Ctx> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
   FS_REBUILD_CTX(cv);
   const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
-  if (mode & 1) {
-    fs_forward_body(c);
-    if (mode & 2) fs_touch_flags(c);
-    return;
-  }
+  // (ONE inlined copy of the forward pass: the forward-only mode leaves the loop after its first pass -- with a call site of its
+  //  own the 18 k-instruction body sat in this function twice)
+  const bool fwd_only = mode & 1;
 #pragma unroll 1
-  for (int s = CTRL ? -1 : 0; s < n; s++) {
-    if (CTRL && s >= 0) fs_controller(c, s == 0);
+  for (int s = CTRL ? -1 : 0; fwd_only || s < n; s++) {
+    if (CTRL && s >= 0 && !fwd_only) fs_controller(c, s == 0);
     fs_forward_body(c);
+    if (fwd_only) {
+      if (mode & 2) fs_touch_flags(c);
+      return;
+    }
     if (CTRL && s < 0) continue;
     if ((mode & 2) && s == n - 1) fs_touch_flags(c);
 #ifdef FSIM_TIMELINE
