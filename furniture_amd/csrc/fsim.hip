@@ -37,19 +37,23 @@ __device__ __forceinline__ void store_record(float *rec, const float *L, int n, 
   for (int i = lane; i < n; i += 64) rec[i] = L[i];
 }
 
-template <class Ctx> __global__ __launch_bounds__(64, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
+template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_physics(const DModel *mp, const Layout *lp, KParams kp, float *state, float *aux) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
-  int env = blockIdx.x, lane = threadIdx.x;
+  const int env = blockIdx.x;
   if (env >= kp.n_envs) return;
-  const Ctx c(L, m, *(CLayout *)lp, lane, kp.newton_maxit, kp.newton_tol);
+  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+  const int lane = c.lane;
+  if constexpr (Ctx::NW > 1) if (c.wave > 0) { mw_helper_loop(c); return; } // helper waves (multi-wave kernel)
   float *rec = state + (size_t)env * c.ly.stride;
   load_record(L, rec, c.ly.stride, lane);
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
+  if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
   SYNC();
   fs_load_cache(c);
   if (kp.mode == 1) fs_substeps(c, 1, 1);
   else fs_substeps(c, kp.n_substeps, 0);
+  if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   // aux: [qacc nv][xpos 3nr][xquat 4nr][ncon, niter, overflow, bad][contact geoms 2*ncon_max]
   if (aux) {
     float *a = aux + (size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max);
@@ -73,21 +77,27 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_physics(const DM
   store_record(rec, L, c.ly.stride, lane);
 }
 
-template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
+// One-wave kernel (Ctx::NW == 1): workgroup b steps env order[b] (all envs; those the scheduler gave to the multi-wave kernel of
+// the same launch -- mwsel[env] != 0 -- are skipped).  Multi-wave kernel (Ctx::NW == 4): workgroup b steps env mworder[b], b < *mwn.
+template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
                                                  float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
                                                  const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost,
-                                                 const float *init_state, const uint8_t *init_mask, int *nreset) {
+                                                 const float *init_state, const uint8_t *init_mask, int *nreset, const uint8_t *mwsel, const int *mwn) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
-  int lane = threadIdx.x;
   if ((int)blockIdx.x >= kp.n_envs) return;
+  if (Ctx::NW > 1 && mwn && (int)blockIdx.x >= *mwn) return;
   // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
-  int env = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const Ctx c(L, m, *(CLayout *)lp, lane, kp.newton_maxit, kp.newton_tol);
+  const int env = order ? order[blockIdx.x] : (int)blockIdx.x;
+  if (Ctx::NW == 1 && mwsel && mwsel[env]) return;
+  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+  const int lane = c.lane;
+  if constexpr (Ctx::NW > 1) if (c.wave > 0) { mw_helper_loop(c); return; } // helper waves (multi-wave kernel)
   float *rec = state + (size_t)env * c.ly.stride;
   load_record(L, rec, c.ly.stride, lane);
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
+  if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
   SYNC();
   fs_load_cache(c);
   EnvIO io;
@@ -105,6 +115,7 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
   io.t0 = t_entry;
   if (do_step) env_step(c, cfg, io);
   else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
+  if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   SYNC();
 #ifdef FSIM_PROFILE
 #ifdef FSIM_TIMELINE
@@ -131,9 +142,33 @@ template <class Ctx> __global__ __launch_bounds__(64, 2) void k_env_step(const D
 // ONE wavefront with a few registers: the kernel runs between two step kernels of its stream while the other slab's step kernel
 // holds every SIMD's register file (2 x 256 VGPRs) -- a 1024-thread workgroup had to wait ~0.2 ms for a whole CU to drain
 // before it could start (rocprofv3: 217 us average for 10 us of work), a single small wave takes the first slot that frees.
-__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n) {
+// Multi-wave selection (mwsel != null): env i goes to the multi-wave kernel of this launch iff its last step took at least mw_k
+// Newton iterations (E_NITER of its record: a function of the env's state, never of timing, so results do not depend on the
+// schedule), the first mw_cap such envs in index order; the one-wave kernel skips them.
+__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int mw_cap,
+                                                uint8_t *mwsel, int *mworder, int *mwn) {
   __shared__ int hist[257];
   const int tid = threadIdx.x;
+  if (mwsel) {
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + tid; v[u] = i < n ? state[(size_t)i * stride + niter_off] : -0x7fffffff; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + 64 * u + tid;
+        const bool sel = i < n && v[u] >= mw_k;
+        const unsigned long long mask = __ballot(sel);
+        const int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
+        const bool take = sel && idx < mw_cap;
+        if (i < n) mwsel[i] = take ? 1 : 0;
+        if (take) mworder[idx] = i;
+        base += __popcll(mask);
+      }
+    }
+    if (tid == 0) *mwn = min(base, mw_cap);
+  }
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
   int lm = 0;
   for (int i = tid; i < n; i += 64) { int cv = cost[i]; if (cv >= 0) lm = max(lm, cv & 0x3fffffff); }
@@ -213,14 +248,26 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, EnvCfg, float *, const float *, float *, float *, uint8_t *, int *, const float *,
-                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *, int *);
-struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; };
+                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *, int *, const uint8_t *, const int *);
+#define FSIM_MW_NW 4 // waves per env of the multi-wave kernels
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; };
 
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
   hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
+  // multi-wave kernels (fsim_solver.hpp): mode 0 off, 1 = the scheduler picks the envs (default), 2 = every env, every launch
+  // (FSIM_MW=0 / all; development and tests).  In mode 1 a step is two kernels: the multi-wave one on `stream` right behind the
+  // scheduler (its workgroups -- the long jobs -- are dispatched first), the one-wave one on `stream2`; `stream` then waits for it.
+  int mw_mode = 1, mw_k = 150, mw_cap = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_sched = nullptr, ev_bulk = nullptr;
+  Layout ly_mw{};
+  Layout *d_ly_mw = nullptr;
+  int lds_bytes_mw = 0;
+  uint8_t *d_mwsel = nullptr;
+  int *d_mworder = nullptr, *d_mwn = nullptr;
   DModel m{};
   Layout ly{};
   fsim_config_t cfg{};
@@ -414,11 +461,11 @@ static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, size
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
 static KernelSet pick_kernels(const Dims &d, const LayoutIn &in) {
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
-  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>};
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -457,6 +504,24 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  { // multi-wave kernels
+    s->ly_mw = make_layout(lin, FSIM_MW_NW);
+    s->lds_bytes_mw = s->ly_mw.lds_words * 4;
+    if (const char *e = getenv("FSIM_MW")) s->mw_mode = !strcmp(e, "all") ? 2 : (atoi(e) ? 1 : 0);
+    if (const char *e = getenv("FSIM_MW_K")) s->mw_k = atoi(e);
+    s->mw_cap = std::max(1, n_envs / 8);
+    if (const char *e = getenv("FSIM_MW_CAP")) s->mw_cap = std::max(1, std::min(n_envs, atoi(e)));
+    if (getenv("FSIM_NO_LPT") && s->mw_mode == 1) s->mw_mode = 0; // (the selection is part of the scheduler kernel)
+    if (s->lds_bytes_mw > 160 * 1024) s->mw_mode = 0;
+    if (s->mw_mode) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
+      HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&s->ev_sched, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_bulk, hipEventDisableTiming));
+      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 4));
+      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 4));
+    }
+  }
   HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
   size_t sbytes = (size_t)n_envs * s->ly.stride * 4;
   HIPCHK(hipMalloc(&s->d_state, sbytes));
@@ -500,13 +565,20 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step));
     fprintf(stderr, "[fsim] kernel=%s lds_bytes=%d stride_words=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu ncon_max=%d\n", s->ks.name, s->lds_bytes, s->ly.stride, nb,
             fa.numRegs, (size_t)fa.localSizeBytes, s->ly.ncon_max);
+    if (s->mw_mode) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step_mw), 64 * FSIM_MW_NW, s->lds_bytes_mw);
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step_mw));
+      fprintf(stderr, "[fsim] multi-wave kernel (%d waves per env, mode %d, k %d, cap %d): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW, s->mw_mode,
+              s->mw_k, s->mw_cap, s->lds_bytes_mw, nb, fa.numRegs, (size_t)fa.localSizeBytes);
+    }
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
   if (s->ecfg.obs_dim > 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4) { int od = s->ecfg.obs_dim; delete s; FAIL(FSIM_ENOMEM, "obs_dim %d exceeds the LDS staging area of the observation (%d words)", od, 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4); }
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
-  HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout)));
+  HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout))); HIPCHK(hipMalloc(&s->d_ly_mw, sizeof(Layout)));
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
   *out = s;
   return FSIM_OK;
 }
@@ -516,6 +588,10 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
+  if (s->stream2) { hipStreamSynchronize(s->stream2); hipStreamDestroy(s->stream2); }
+  if (s->ev_sched) hipEventDestroy(s->ev_sched);
+  if (s->ev_bulk) hipEventDestroy(s->ev_bulk);
+  hipFree(s->d_ly_mw); hipFree(s->d_mwsel); hipFree(s->d_mworder); hipFree(s->d_mwn);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -556,14 +632,16 @@ static void timing_collect(fsim *s) {
 extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
   if (!s || nsub < 0) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
+  if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, nsub, 0), s->d_state, s->d_aux);
+  else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
   return FSIM_OK;
 }
 extern "C" int fsim_physics_forward(fsim_t *s) {
   if (!s) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
+  if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, 0, 1), s->d_state, s->d_aux);
+  else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
   return FSIM_OK;
 }
@@ -692,11 +770,32 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
-  if (sched) hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), 0, s->stream, s->d_cost, s->d_order, s->n_envs);
+  const bool mw_auto = sched && s->mw_mode == 1, mw_all = s->mw_mode == 2;
+  if (sched)
+    hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), 0, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
+                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? s->d_mwsel : nullptr, s->d_mworder, s->d_mwn);
   if (s->timing) timing_begin(s);
-  hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, s->cfg.n_substeps, 0), s->ecfg, s->d_state,
-                     action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, reinterpret_cast<int *>(s->d_aux),
-                     sched ? s->d_order : nullptr, do_step ? s->d_cost : nullptr, s->d_init, s->d_init_mask, do_step ? s->d_nreset : nullptr);
+  const KParams kp = kparams(s, s->cfg.n_substeps, 0);
+  int *prof = reinterpret_cast<int *>(s->d_aux), *costp = do_step ? s->d_cost : nullptr, *nres = do_step ? s->d_nreset : nullptr;
+  if (mw_all)
+    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, s->ecfg, s->d_state,
+                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, sched ? s->d_order : nullptr, costp,
+                       s->d_init, s->d_init_mask, nres, nullptr, nullptr);
+  else if (mw_auto) {
+    hipEventRecord(s->ev_sched, s->stream);
+    hipStreamWaitEvent(s->stream2, s->ev_sched, 0);
+    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->mw_cap), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, s->ecfg, s->d_state,
+                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, s->d_mworder, costp,
+                       s->d_init, s->d_init_mask, nres, nullptr, s->d_mwn);
+    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream2, s->d_m, s->d_ly, kp, s->ecfg, s->d_state,
+                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, s->d_order, costp,
+                       s->d_init, s->d_init_mask, nres, s->d_mwsel, nullptr);
+    hipEventRecord(s->ev_bulk, s->stream2);
+    hipStreamWaitEvent(s->stream, s->ev_bulk, 0);
+  } else
+    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, s->ecfg, s->d_state,
+                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof,
+                       sched ? s->d_order : nullptr, costp, s->d_init, s->d_init_mask, nres, nullptr, nullptr);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

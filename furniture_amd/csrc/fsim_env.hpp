@@ -129,6 +129,18 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
   FS_PROF(16);
   fs_com_inertia(c);
   FS_PROF(17);
+  if constexpr (Ctx::NW > 1) {
+    // multi-wave: helper wave 1 runs the collision pipeline (it reads the body poses only) beside the dynamics passes here
+    mw_post(c, MW_COLLIDE);
+    fs_crb_factor(c);
+    FS_PROF(18);
+    fs_velocity_bias(c);
+    FS_PROF(20);
+    fs_smooth(c);
+    FS_PROF(21);
+    mw_post(c, MW_IDLE);
+    FS_PROF(1);
+  } else {
   fs_crb_factor(c);
   FS_PROF(18);
   fs_collide(c);
@@ -137,6 +149,7 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
   FS_PROF(20);
   fs_smooth(c);
   FS_PROF(21);
+  }
   int coupled = fs_make_constraints(c);
   FS_PROF(3);
 #ifdef FSIM_PRIO
@@ -947,6 +960,42 @@ template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg
   SYNC();
 }
 
+// Smallest clearance between a robot collision geom and a furniture part's collision geom, from the body poses of the last
+// forward pass: a LOWER bound on the true distance (exact point-to-solid distance from one geom's centre to the other geom's box /
+// cylinder, minus the first geom's bounding radius; the larger of the two directions).  A function of the state only -- it decides
+// which envs the next launch steps with the multi-wave kernel (an env about to enter robot-part contact is the expensive kind),
+// so results never depend on timing.  lanes = candidate pairs (robot x part pairs only).
+template <class Ctx> DEV float env_robot_clearance(const Ctx &c) {
+  CModel &m = c.m;
+  const float *L = c.L;
+  float best = 1e9f;
+  for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
+    const int p = min(p0 + c.lane, c.D.ncp - 1);
+    const int w = GP(m.pair_bp)[2 * p], g1 = w & 255, g2 = (w >> 8) & 255;
+    const bool rp = (m.cg_isrobot[g1] && m.cg_ispartcol[g2]) || (m.cg_isrobot[g2] && m.cg_ispartcol[g1]);
+    if (!rp || p0 + c.lane >= c.D.ncp) continue;
+    const int b1 = m.cg_body[g1], b2 = m.cg_body[g2];
+    const M3 B1 = ldm3(L + c.ly.xmat + 9 * b1), B2 = ldm3(L + c.ly.xmat + 9 * b2);
+    const V3 c1 = ldv3(L + c.ly.xpos + 3 * b1) + mulv(B1, ldv3(GP(m.cg_pos) + 3 * g1)), c2 = ldv3(L + c.ly.xpos + 3 * b2) + mulv(B2, ldv3(GP(m.cg_pos) + 3 * g2));
+    const M3 R1 = mulm(B1, ldm3(GP(m.cg_mat) + 9 * g1)), R2 = mulm(B2, ldm3(GP(m.cg_mat) + 9 * g2));
+    const V3 d = c2 - c1;
+    float lb = norm(d) - GP(m.cg_rbound)[g1] - GP(m.cg_rbound)[g2];
+#pragma unroll
+    for (int side = 0; side < 2; side++) { // side 0: centre of geom 1 against the solid of geom 2
+      const int gs = side ? g1 : g2, go = side ? g2 : g1, ty = m.cg_type[gs];
+      const M3 &R = side ? R1 : R2;
+      const V3 dw = side ? d : -d; // centre(other) - centre(solid)
+      const V3 cl = multv(R, dw), sz = ldv3(GP(m.cg_size) + 3 * gs);
+      const V3 e = v3(fmaxf(fabsf(cl.x) - sz.x, 0.0f), fmaxf(fabsf(cl.y) - sz.y, 0.0f), fmaxf(fabsf(cl.z) - sz.z, 0.0f));
+      const float er = fmaxf(sqrtf(cl.x * cl.x + cl.y * cl.y) - sz.x, 0.0f), ez = fmaxf(fabsf(cl.z) - sz.y, 0.0f);
+      if (ty == GT_BOX) lb = fmaxf(lb, norm(e) - GP(m.cg_rbound)[go]);
+      else if (ty == GT_CYLINDER) lb = fmaxf(lb, sqrtf(er * er + ez * ez) - GP(m.cg_rbound)[go]);
+    }
+    best = fminf(best, lb);
+  }
+  return -wave_max(-best);
+}
+
 // ---------------------------------------------------------------------------------------------------- step
 template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   CModel &m = c.m;
@@ -1177,8 +1226,13 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   }
   SYNC();
   terminal = scal[14];
+  const int nit_step = scal[SC_NITSUM];
   if (terminal && cfg.auto_reset) env_reset(c, &cfg, &io); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
   else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
+  { // what the scheduler of the next launch reads (k_schedule): this step's Newton iterations (0 after a reset), the robot-part clearance now
+    const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;
+    if (c.lane == 0) { E[E_NITER] = (terminal && cfg.auto_reset) ? 0 : nit_step; L[c.ly.env + E_CLEARANCE] = clr; }
+  }
   env_write_obs(c, cfg, io);
 #ifdef FSIM_TIMELINE
   if (c.lane == 0) scal[52] = (int)(clock64() >> 4) - scal[52];

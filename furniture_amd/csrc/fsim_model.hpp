@@ -16,6 +16,8 @@
 #define FSIM_XW 54       // words per body-pair block: the 6 x 6 cross block X, overwritten by Y = X * cdof (6 x chain length <= 9)
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
+#define FSIM_JSTW 5      // words per staged slot (multi-wave kernel): jar[3], limit jar, pair-block id; odd stride
+#define FSIM_MWCW 16     // command words of the multi-wave protocol (MWC_*)
 #define FSIM_MAXSURV 48  // broadphase survivors per substep of models with <= 8 parts (22 is the most seen on Sawyer + table_lack); LayoutIn::maxsurv
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
@@ -88,6 +90,11 @@ struct Layout {
   int hmap;   // per-substep island map of the Newton system (FSIM_MAPW(nv) words, format at fs_build_map in fsim_solver.hpp)
   int hA, hP; // Hessian body blocks / pair blocks: alias gpos+gmat (geom poses are dead once the contacts exist)
   int pitem;  // [FSIM_PCAP] body-pair projection items of this substep (fs_pair_cache)
+  // multi-wave layout only (make_layout(in, nw > 1); zero otherwise): see fsim_solver.hpp "multi-wave Newton iteration"
+  int hAhi, hAc; // second set of contact blocks (the higher body of each contact) and the composite blocks; hA = the lower bodies' set
+  int jst;       // [64][FSIM_JSTW] this iteration's J a - aref per contact slot / joint-limit record, staged for the helper waves
+  int mwc;       // [FSIM_MWCW] command words of the workgroup's main wave / helper waves protocol
+  int anc2;      // [nr] pointer-doubling scratch of fs_velocity_bias (the survivor list is live: fs_collide runs beside it)
   int lds_words, ncon_max, maxsurv;
   // LDS cache of the small model tables that sit inside serial / dependent loops (loaded once per launch)
   int k_dof_parent, k_r_submask, k_dof_rbody, k_dof_tree, k_r_parent, k_r_jtype, k_r_qposadr, k_r_dofadr, k_r_chain, k_r_tree, k_r_chainadr, k_r_chainlen, k_r_ancmask, k_chain_dofs, k_tree_dofadr, k_tree_dofnum, k_tree_bodyadr, k_tree_bodynum, k_M_ij, k_r_pos, k_r_quat, k_r_jpos, k_r_jaxis, k_r_ipos, k_r_mass, k_r_inertia, k_dof_damping, k_dof_armature, k_tmap;
@@ -102,6 +109,7 @@ struct Layout {
 #define FSIM_SC_BASE 16
 #endif
 enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8,
+       SC_NITSUM = 15, // Newton iterations of all solves since the launch began (env_step stores it in E_NITER)
        SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 64,
        SC_HWORDS = FSIM_SC_BASE + 80, SC_TWORDS = FSIM_SC_BASE + 81, SC_WORDS = FSIM_SC_BASE + 84 };
 
@@ -110,7 +118,7 @@ enum {
   E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL, E_TERMINAL,
   E_CONNECTED_THIS_STEP, E_SITE1, E_SITE2, E_SUBTASK1, E_SUBTASK2, E_TOUCHED, E_PICKED, E_CONNSITES0, E_CONNSITES1,
   E_CONNSITES2, E_CONNSITES3, E_TOUCH_L, E_TOUCH_R, E_TOUCH_FLOOR, E_CONNBODY1, E_CB1_POS, E_CB1_QUAT = E_CB1_POS + 3,
-  E_TARGET_QUAT = E_CB1_QUAT + 4, E_EPISODE_REWARD = E_TARGET_QUAT + 4, E_NCON, E_NITER, E_RESET_CURSOR, E_EPISODE_COUNT,
+  E_TARGET_QUAT = E_CB1_QUAT + 4, E_EPISODE_REWARD = E_TARGET_QUAT + 4, E_CLEARANCE /* float: env_robot_clearance at the end of the last step */, E_NITER /* Newton iterations of the last step */, E_RESET_CURSOR, E_EPISODE_COUNT,
   E_GROUP, // nparts ints follow
   E_FIXED_WORDS = E_GROUP
 };
@@ -136,7 +144,7 @@ struct LayoutIn {
 };
 
 // One function for host and device: fsim_create calls it at run time, fsim_spec.hpp at compile time.
-constexpr Layout make_layout(const LayoutIn &in) {
+constexpr Layout make_layout(const LayoutIn &in, int nw = 1) {
   Layout ly{};
   int o = 0;
 #define TAKE(field, n) do { ly.field = o; o += (n); } while (0)
@@ -164,12 +172,18 @@ constexpr Layout make_layout(const LayoutIn &in) {
   TAKE(smooth, in.nv); ly.asmooth = ly.smooth; TAKE(x, in.nv); TAKE(Mx, in.nv); TAKE(grad, in.nv); TAKE(p, in.nv); TAKE(Mp, in.nv);
   TAKE(gpos, 3 * in.ncg); TAKE(gmat, 9 * in.ncg);
   {
-    int need = 21 * in.nr + FSIM_XW * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
-    ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * in.nr;
+    // (multi-wave: three sets of body blocks -- lower body, higher body, composite -- because different waves fill them)
+    const int nsets = nw > 1 ? 3 : 1;
+    int need = 21 * in.nr * nsets + FSIM_XW * FSIM_NPAIR + 3 * FSIM_NPAIR + 4;
+    ly.hA = ly.gpos; ly.hP = ly.gpos + 21 * in.nr * nsets;
+    if (nw > 1) { ly.hAhi = ly.gpos + 21 * in.nr; ly.hAc = ly.gpos + 42 * in.nr; }
     if (need < 12 * in.nr) need = 12 * in.nr;
     if (need > 12 * in.ncg) o += need - 12 * in.ncg;
     // per-body spatial vectors W (J*v) and wrenches G (J'f) are dead while the Hessian blocks are live and vice versa
     ly.W = ly.gpos; ly.G = ly.gpos + 6 * in.nr;
+  }
+  if (nw > 1) { // the gradient's wrenches are accumulated while the helper waves fill the Hessian blocks: no aliasing
+    TAKE(G, 6 * in.nr); TAKE(jst, FSIM_JSTW * 64); TAKE(mwc, FSIM_MWCW); TAKE(anc2, in.nr);
   }
   TAKE(surv, in.maxsurv); TAKE(pitem, FSIM_PCAP);
   TAKE(con, FSIM_CONW * in.ncon_max); TAKE(weld, FSIM_WELDW * in.neq); TAKE(lim, FSIM_LIMW * 2 * in.nlim);

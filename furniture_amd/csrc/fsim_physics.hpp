@@ -9,44 +9,58 @@
 #include "fsim_math.hpp"
 #include "fsim_model.hpp"
 
-// Ordering point between lanes of the env's wavefront (a workgroup is exactly one wave).  A compiler-only barrier
-// (-DFSIM_SW_SYNC: a wave's LDS instructions execute in issue order, so no s_barrier / s_waitcnt is strictly needed) passes
-// every test but measures the same (10.15 vs 10.25 ms per step), so the real barrier stays the default.
-#ifdef FSIM_SW_SYNC
-#define SYNC() __asm__ volatile("" ::: "memory")
-#else
-#define SYNC() __syncthreads()
-#endif
+// Ordering point between the lanes working on one env.
+//   one-wave kernels (NW == 1): workgroup = wave = env, SYNC() is __syncthreads() (a compiler-only barrier -- a wave's LDS
+//     instructions execute in issue order -- passes every test but measures the same, so the real barrier stays);
+//   multi-wave kernels (NW > 1): a workgroup of NW waves steps ONE env.  Wave 0 ("main") runs the same code as the one-wave
+//     kernel and hands whole passes to the helper waves at fork points (fsim_solver.hpp, "multi-wave"); inside a pass a single
+//     wave works, so SYNC() is a compiler barrier only (the hardware keeps one wave's LDS operations in order) and the waves meet
+//     at explicit workgroup barriers, c.xbar().
+#define SYNC() (c.sync())
 
 // The per-wave context.  Two flavours with the same member names, so the physics / solver / env code is written once as
 // templates over the context type:
 //   GenCtx  -- layout offsets and model dimensions are run-time values (scalar loads from constant memory): any model;
 //   SpecCtx -- they are compile-time constants of the specialisation S (fsim_spec.hpp): offsets become instruction
 //              immediates, `for (i = lane; i < n; i += 64)` loops become a single test, no SGPRs are spent on the layout.
-struct GenCtx {
+// Both take the number of waves per env as a template parameter (NW; lane = lane inside the wave, wave = which wave).
+template <int NW_> struct FsSync {
+  DEV static void sync() { if (NW_ == 1) __syncthreads(); else __asm__ volatile("" ::: "memory"); }
+  DEV static void xbar() { __syncthreads(); }
+};
+template <int NW_> struct GenCtxT {
+  static constexpr int NW = NW_;
   float *L;          // LDS base (state image followed by work arrays)
   CModel &m;         // model tables (pointers)
   CLayout &ly;       // LDS / record layout
   CModel &D;         // dimensions + scalar options (the Dims base of the same struct)
-  int lane;
+  int lane, wave;
   int newton_maxit;
   float newton_tol;
-  __device__ GenCtx(float *L_, CModel &m_, CLayout &ly_, int lane_, int it, float tol)
-      : L(L_), m(m_), ly(ly_), D(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
+  __device__ GenCtxT(float *L_, CModel &m_, CLayout &ly_, int tid, int it, float tol)
+      : L(L_), m(m_), ly(ly_), D(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
+  DEV void sync() const { FsSync<NW_>::sync(); }
+  DEV void xbar() const { FsSync<NW_>::xbar(); }
 };
-template <class S> struct SpecCtx {
+typedef GenCtxT<1> GenCtx;
+template <class S, int NW_> struct FsSpecLayout { static constexpr Layout ly = make_layout(S::in, NW_); };
+template <class S, int NW_ = 1> struct SpecCtx {
+  static constexpr int NW = NW_;
   float *L;
   CModel &m;
-  static constexpr Layout ly = S::ly;
+  static constexpr Layout ly = FsSpecLayout<S, NW_>::ly;
   static constexpr Dims D = S::D;
-  int lane;
+  int lane, wave;
   int newton_maxit;
   float newton_tol;
-  __device__ SpecCtx(float *L_, CModel &m_, CLayout &, int lane_, int it, float tol)
-      : L(L_), m(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
-  __device__ SpecCtx(float *L_, CModel &m_, int lane_, int it, float tol) : L(L_), m(m_), lane(lane_), newton_maxit(it), newton_tol(tol) {}
+  __device__ SpecCtx(float *L_, CModel &m_, CLayout &, int tid, int it, float tol)
+      : L(L_), m(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
+  __device__ SpecCtx(float *L_, CModel &m_, int tid, int it, float tol)
+      : L(L_), m(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
+  DEV void sync() const { FsSync<NW_>::sync(); }
+  DEV void xbar() const { FsSync<NW_>::xbar(); }
 };
 
 // Re-derive wave-uniform values after a real function call so the callee's model-table loads stay scalar.
@@ -55,14 +69,14 @@ template <class T> DEV T *fs_uniform_ptr(T *p) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (T *)(((unsigned long long)hi << 32) | lo);
 }
-DEV GenCtx fs_rebuild(const GenCtx &cv, float *lds) {
-  return GenCtx(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
-                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+template <int NW_> DEV GenCtxT<NW_> fs_rebuild(const GenCtxT<NW_> &cv, float *lds) {
+  return GenCtxT<NW_>(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                      __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
 }
-template <class S> DEV SpecCtx<S> fs_rebuild(const SpecCtx<S> &cv, float *lds) {
+template <class S, int NW_> DEV SpecCtx<S, NW_> fs_rebuild(const SpecCtx<S, NW_> &cv, float *lds) {
   CModel &mu = *fs_uniform_ptr(&cv.m);
-  return SpecCtx<S>(lds, mu, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
-                    __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+  return SpecCtx<S, NW_>(lds, mu, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                         __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
 }
 #define FS_REBUILD_CTX(cv)            \
   extern __shared__ float fs_lds_[];  \
@@ -390,7 +404,7 @@ template <class Ctx> DEV void fs_velocity_bias(const Ctx &c) {
   // and ceil(log2(depth)) pointer-doubling rounds replace the per-dof pointer chase up the chain plus the per-body walk down it.
   CModel &m = c.m;
   float *L = c.L;
-  int *ancs = c.I(c.ly.surv);             // (broadphase survivor list: dead here)
+  int *ancs = c.I(Ctx::NW > 1 ? c.ly.anc2 : c.ly.surv); // (broadphase survivor list: dead here -- unless a helper wave runs fs_collide beside this pass)
   float *SU = L + c.ly.cacc, *SC = L + c.ly.cfrc; // round scratch: cacc is free (anchors / axes were consumed by fs_com_inertia)
   const int b = c.lane;
   const bool on = b < c.D.nr && b > 0;

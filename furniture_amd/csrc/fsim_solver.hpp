@@ -1134,6 +1134,312 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   return !wave_or(bad);
 }
 
+// ------------------------------------------------------------------------------------------ multi-wave Newton iteration
+// The step of a launch lasts as long as its slowest env, and that env is a robot holding a part: 5-8 Newton iterations per
+// substep on a coupled island, one instruction stream.  The multi-wave kernels (Ctx::NW = 4 waves per env, k_env_step_mw)
+// shorten that stream: wave 0 ("main") runs the env exactly like the one-wave kernel and, at fork points, hands whole passes to
+// the three helper waves, which otherwise sleep at a workgroup barrier:
+//   * fs_collide on helper 1 beside composite inertia / M / RNE bias / actuation on main (fs_forward_body);
+//   * per Newton iteration (mw_iterate): the gradient on main beside the Hessian on the helpers -- contact blocks of the lower
+//     bodies / the higher bodies / the body-pair cross blocks on one helper each, composite sums with one lane per
+//     (body, component), the projection on M's pattern over all 256 lanes --, the DPP-row factorisation on helper 1 beside the
+//     MFMA island on main, M p on helper 1 beside J p on main.
+// Protocol: main posts a command word and everybody meets at a workgroup barrier (mw_post); the helpers run the command and go
+// back to the barrier.  Command slots alternate (a slow helper may still be reading the previous one).  Every accumulator is
+// filled by exactly ONE wave in lane order and sums across accumulators are taken in a fixed order, so the result is a function
+// of the state alone, as in the one-wave kernel (run-to-run bit-identical) -- though not bit-identical TO the one-wave kernel.
+enum { MW_IDLE = 0, MW_EXIT = 1, MW_COLLIDE = 2, MW_ITER = 3, MW_CHOL = 4, MW_MULM = 5 };
+enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9 };
+
+template <class Ctx> DEV void mw_post(const Ctx &c, int cmd) { // main wave only
+  int *w = c.I(c.ly.mwc);
+  const int k = w[MWC_SEQ];
+  if (c.lane == 0) { w[k & 1] = cmd; w[MWC_SEQ] = k + 1; }
+  c.xbar();
+}
+
+// cone state, world-frame stiffness K = F' Hcone F and world force of this lane's contact slot (what fs_gradient computes on its way)
+DEV SlotK fs_slot_k(const SolSlot &S, V3 *Fw) {
+  SlotK sk;
+  sk.on = false;
+  sk.zone = 0;
+  for (int q = 0; q < 6; q++) sk.K[q] = 0;
+  *Fw = v3(0, 0, 0);
+  if (S.act) {
+    float f[3] = {0, 0, 0}, cc, Hc[9];
+    bool on;
+    if (S.dim1) {
+      on = S.jar[0] < 0;
+      if (on) f[0] = -S.dn * S.jar[0];
+      for (int q = 0; q < 9; q++) Hc[q] = 0;
+      Hc[0] = S.dn;
+      sk.zone = on ? 1 : 0;
+    } else { sk.zone = fs_cone(S.jar, S.dn, S.dt, S.mu, f, &cc, Hc); on = sk.zone != 0; }
+    if (on) {
+      const V3 fx = S.fx, fy = S.fy, fz = S.fz;
+      V3 w0 = fx * Hc[0] + fy * Hc[1] + fz * Hc[2], w1 = fx * Hc[3] + fy * Hc[4] + fz * Hc[5], w2 = fx * Hc[6] + fy * Hc[7] + fz * Hc[8];
+      sk.on = true;
+      sk.K[0] = fx.x * w0.x + fy.x * w1.x + fz.x * w2.x; sk.K[1] = fx.x * w0.y + fy.x * w1.y + fz.x * w2.y; sk.K[2] = fx.x * w0.z + fy.x * w1.z + fz.x * w2.z;
+      sk.K[3] = fx.y * w0.y + fy.y * w1.y + fz.y * w2.y; sk.K[4] = fx.y * w0.z + fy.y * w1.z + fz.y * w2.z; sk.K[5] = fx.z * w0.z + fy.z * w1.z + fz.z * w2.z;
+      *Fw = fx * f[0] + fy * f[1] + fz * f[2];
+    }
+  }
+  if (S.lact && S.ljar < 0) sk.zone |= 4;
+  return sk;
+}
+
+// zero this wave's share of the Hessian work arrays (H, the two block sets, the cached pair blocks)
+template <class Ctx> DEV void mw_zero(const Ctx &c, int npc) {
+  float *L = c.L;
+  const int nH = c.I(c.ly.scal)[SC_HWORDS], t = 64 * c.wave + c.lane;
+  for (int i = t; i < nH; i += 64 * Ctx::NW) L[c.ly.H + i] = 0;
+  for (int i = t; i < 42 * c.D.nr; i += 64 * Ctx::NW) L[c.ly.hA + i] = 0; // (hA and hAhi are contiguous)
+  if (npc > 0) for (int i = t; i < FSIM_XW * npc; i += 64 * Ctx::NW) L[c.ly.hP + i] = 0;
+}
+
+// contact blocks: role 1 = the lower body of every contact -> hA, role 2 = the higher body -> hAhi, role 3 = the cached pair blocks
+template <class Ctx> DEV void mw_blocks(const Ctx &c, const SolSlot &S, const SlotK &sk, int role) {
+  float *L = c.L;
+  if (!sk.on) return;
+  const bool first_lo = (S.bt1 & 255) <= (S.bt2 & 255);
+  const int blo = (first_lo ? S.bt1 : S.bt2) & 255, bhi = (first_lo ? S.bt2 : S.bt1) & 255;
+  const V3 rlo = first_lo ? S.r1 : S.r2, rhi = first_lo ? S.r2 : S.r1;
+  const float *K = sk.K;
+  const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
+  if (role <= 2) {
+    const int b = role == 1 ? blo : bhi;
+    if (b == 0) return;
+    const V3 rr = role == 1 ? rlo : rhi;
+    V3 c0 = cross(rr, K0), c1 = cross(rr, K1), c2 = cross(rr, K2);
+    V3 G0 = v3(c0.x, c1.x, c2.x), G1 = v3(c0.y, c1.y, c2.y), G2 = v3(c0.z, c1.z, c2.z);
+    V3 a0 = cross(rr, G0), a1 = cross(rr, G1), a2 = cross(rr, G2);
+    float *Ab = L + (role == 1 ? c.ly.hA : c.ly.hAhi) + 21 * b;
+    atomicAdd(Ab + 0, a0.x); atomicAdd(Ab + 1, a0.y); atomicAdd(Ab + 2, a0.z); atomicAdd(Ab + 3, a1.y); atomicAdd(Ab + 4, a1.z); atomicAdd(Ab + 5, a2.z);
+    atomicAdd(Ab + 6, G0.x); atomicAdd(Ab + 7, G0.y); atomicAdd(Ab + 8, G0.z); atomicAdd(Ab + 9, G1.x); atomicAdd(Ab + 10, G1.y); atomicAdd(Ab + 11, G1.z);
+    atomicAdd(Ab + 12, G2.x); atomicAdd(Ab + 13, G2.y); atomicAdd(Ab + 14, G2.z);
+    atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]);
+  } else if (S.pid >= 0) {
+    // X = [[Glo * Rhi, Glo], [K * Rhi, K]],  v' * Rhi = (rhi x v)'  row-wise  (fs_hessian, FS_ADD_X)
+    V3 c0 = cross(rlo, K0), c1 = cross(rlo, K1), c2 = cross(rlo, K2);
+    V3 Glo0 = v3(c0.x, c1.x, c2.x), Glo1 = v3(c0.y, c1.y, c2.y), Glo2 = v3(c0.z, c1.z, c2.z);
+    float *Xp = L + c.ly.hP + FSIM_XW * S.pid;
+    V3 x0 = cross(rhi, Glo0), x1 = cross(rhi, Glo1), x2 = cross(rhi, Glo2), y0 = cross(rhi, K0), y1 = cross(rhi, K1), y2 = cross(rhi, K2);
+    atomicAdd(Xp + 0, x0.x); atomicAdd(Xp + 1, x0.y); atomicAdd(Xp + 2, x0.z); atomicAdd(Xp + 3, Glo0.x); atomicAdd(Xp + 4, Glo0.y); atomicAdd(Xp + 5, Glo0.z);
+    atomicAdd(Xp + 6, x1.x); atomicAdd(Xp + 7, x1.y); atomicAdd(Xp + 8, x1.z); atomicAdd(Xp + 9, Glo1.x); atomicAdd(Xp + 10, Glo1.y); atomicAdd(Xp + 11, Glo1.z);
+    atomicAdd(Xp + 12, x2.x); atomicAdd(Xp + 13, x2.y); atomicAdd(Xp + 14, x2.z); atomicAdd(Xp + 15, Glo2.x); atomicAdd(Xp + 16, Glo2.y); atomicAdd(Xp + 17, Glo2.z);
+    atomicAdd(Xp + 18, y0.x); atomicAdd(Xp + 19, y0.y); atomicAdd(Xp + 20, y0.z); atomicAdd(Xp + 21, K0.x); atomicAdd(Xp + 22, K0.y); atomicAdd(Xp + 23, K0.z);
+    atomicAdd(Xp + 24, y1.x); atomicAdd(Xp + 25, y1.y); atomicAdd(Xp + 26, y1.z); atomicAdd(Xp + 27, K1.x); atomicAdd(Xp + 28, K1.y); atomicAdd(Xp + 29, K1.z);
+    atomicAdd(Xp + 30, y2.x); atomicAdd(Xp + 31, y2.y); atomicAdd(Xp + 32, y2.z); atomicAdd(Xp + 33, K2.x); atomicAdd(Xp + 34, K2.y); atomicAdd(Xp + 35, K2.z);
+  }
+}
+
+// which cached pairs have a contact in an active cone zone (a pair with none is skipped: its dofs may lie in different islands)
+DEV int mw_pairon(const SolSlot &S, const SlotK &sk) {
+  int pairon = 0;
+#pragma unroll
+  for (int q = 0; q < FSIM_NPAIR; q++) pairon |= (__ballot(sk.on && S.pid == q) != 0) << q;
+  return pairon;
+}
+
+// composite blocks: hAc[b] = sum over the subtree of b of (hA + hAhi), one lane per (body, component), helper waves 1..3
+template <class Ctx> DEV void mw_composite(const Ctx &c) {
+  float *L = c.L;
+  const float *Alo = L + c.ly.hA, *Ahi = L + c.ly.hAhi;
+  for (int i = 64 * (c.wave - 1) + c.lane; i < 21 * c.D.nr; i += 64 * (Ctx::NW - 1)) {
+    const int b = (int)(((float)i + 0.5f) * (1.0f / 21.0f)), k = i - 21 * b;
+    float acc = 0;
+    for (int mm = KI(r_submask, b); mm;) {
+      FS_BITS3(mm, b0, b1, b2, h1, h2);
+      const float x0 = Alo[21 * b0 + k] + Ahi[21 * b0 + k], x1 = Alo[21 * b1 + k] + Ahi[21 * b1 + k], x2 = Alo[21 * b2 + k] + Ahi[21 * b2 + k];
+      acc += x0 + (h1 ? x1 : 0.0f) + (h2 ? x2 : 0.0f);
+    }
+    L[c.ly.hAc + i] = acc;
+  }
+}
+
+// cached pairs, stage 1 (one wave): Y_q = X_q * cdof(chain(hi_q)), one lane per column, written over X_q
+template <class Ctx> DEV void mw_pair_y(const Ctx &c, int nye, int pairon) {
+  float *L = c.L;
+  if (!pairon) return;
+  float *X = L + c.ly.hP;
+  const int w = c.I(c.ly.pitem)[FSIM_PCAP - FSIM_YCAP + min(c.lane, nye - 1)];
+  const int q = w & 255, d2 = (w >> 8) & 255, e2 = w >> 16;
+  const float *Xq = X + FSIM_XW * q;
+  const float *s2 = L + c.ly.cdof + 6 * d2;
+  float y[6];
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++) {
+    float t = 0;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) t += Xq[6 * rr + cc] * s2[cc];
+    y[rr] = t;
+  }
+  SYNC(); // every column has read X before the first one overwrites it
+  if (c.lane < nye) {
+    float *Yq = X + FSIM_XW * q + 6 * e2;
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++) Yq[rr] = y[rr];
+  }
+}
+
+// tree blocks on M's pattern, all waves: H[i][j] = M[i][j] + cdof_i' hAc[body(i)] cdof_j
+template <class Ctx> DEV void mw_project(const Ctx &c) {
+  float *L = c.L;
+  const int hm = c.ly.hmap;
+  for (int e = 64 * c.wave + c.lane; e < c.D.nM; e += 64 * Ctx::NW) {
+    int i = KM_I(e), j = KM_J(e);
+    const float *Ab = L + c.ly.hAc + 21 * KI(dof_rbody, i);
+    S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
+    V3 ta = v3(Ab[0] * sj.a.x + Ab[1] * sj.a.y + Ab[2] * sj.a.z + Ab[6] * sj.l.x + Ab[7] * sj.l.y + Ab[8] * sj.l.z,
+               Ab[1] * sj.a.x + Ab[3] * sj.a.y + Ab[4] * sj.a.z + Ab[9] * sj.l.x + Ab[10] * sj.l.y + Ab[11] * sj.l.z,
+               Ab[2] * sj.a.x + Ab[4] * sj.a.y + Ab[5] * sj.a.z + Ab[12] * sj.l.x + Ab[13] * sj.l.y + Ab[14] * sj.l.z);
+    V3 tl = v3(Ab[6] * sj.a.x + Ab[9] * sj.a.y + Ab[12] * sj.a.z + Ab[15] * sj.l.x + Ab[16] * sj.l.y + Ab[17] * sj.l.z,
+               Ab[7] * sj.a.x + Ab[10] * sj.a.y + Ab[13] * sj.a.z + Ab[16] * sj.l.x + Ab[18] * sj.l.y + Ab[19] * sj.l.z,
+               Ab[8] * sj.a.x + Ab[11] * sj.a.y + Ab[14] * sj.a.z + Ab[17] * sj.l.x + Ab[19] * sj.l.y + Ab[20] * sj.l.z);
+    L[c.ly.H + fs_hidx(c, hm, i, j)] = L[c.ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
+  }
+}
+
+// cached pairs, stage 2 + joint limits (one wave, after the projection's stores)
+template <class Ctx> DEV void mw_pairs_limits(const Ctx &c, const SolSlot &S, int ptot, int pairon) {
+  float *L = c.L;
+  const int hm = c.ly.hmap;
+  if (pairon) {
+    const float *X = L + c.ly.hP;
+    const int *pitem = c.I(c.ly.pitem);
+    for (int it = c.lane; it < ptot; it += 64) {
+      const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = (w >> 16) & 255, e2 = w >> 24;
+      const float *Yq = X + FSIM_XW * q + 6 * e2;
+      const float *s1 = L + c.ly.cdof + 6 * d1;
+      float v = 0;
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) v += s1[rr] * Yq[rr];
+      if (d1 == d2) v *= 2.0f;
+      const int hx = fs_hidx(c, hm, max(d1, d2), min(d1, d2));
+      if ((pairon >> q) & 1) atomicAdd(L + c.ly.H + hx, -v);
+    }
+  }
+  if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
+}
+
+// the helper waves' side of one Newton iteration (command MW_ITER); barriers pair up with mw_iterate_main's
+template <class Ctx> DEV void mw_iter_helper(const Ctx &c) {
+  const int *w = c.I(c.ly.mwc);
+  const int npc = __builtin_amdgcn_readfirstlane(w[MWC_NPC]), ptot = __builtin_amdgcn_readfirstlane(w[MWC_PTOT]), nye = __builtin_amdgcn_readfirstlane(w[MWC_NYE]);
+  mw_zero(c, npc);
+  SolSlot S = fs_load_slots(c);
+  {
+    const float *j = c.L + c.ly.jst + FSIM_JSTW * c.lane;
+    S.jar[0] = j[0]; S.jar[1] = j[1]; S.jar[2] = j[2]; S.ljar = j[3];
+    S.pid = reinterpret_cast<const int *>(j)[4];
+  }
+  V3 Fw;
+  const SlotK sk = fs_slot_k(S, &Fw);
+  const int pairon = npc > 0 ? mw_pairon(S, sk) : 0;
+  c.xbar(); // [2] arrays zeroed
+  mw_blocks(c, S, sk, c.wave);
+  c.xbar(); // [3] blocks complete
+  if (c.wave == Ctx::NW - 1 && npc > 0) mw_pair_y(c, nye, pairon);
+  mw_composite(c);
+  c.xbar(); // [4] composite blocks, Y; main has decided whether the iteration goes on
+  if (!__builtin_amdgcn_readfirstlane(w[MWC_CONT])) return;
+  mw_project(c);
+  c.xbar(); // [5] tree blocks stored
+  if (c.wave == 1) mw_pairs_limits(c, S, ptot, pairon);
+}
+
+// main's side: gradient (the code of fs_gradient, split at its barriers) beside the helpers' Hessian.  Returns the gradient
+// norm; *go = false: converged, the helpers have left the iteration and H is not complete.
+template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go) {
+  float *L = c.L;
+  int *w = c.I(c.ly.mwc);
+  { // stage this iteration's J a - aref for the helpers
+    float *j = L + c.ly.jst + FSIM_JSTW * c.lane;
+    j[0] = S.jar[0]; j[1] = S.jar[1]; j[2] = S.jar[2]; j[3] = S.ljar;
+  }
+  mw_post(c, MW_ITER); // [1]
+  mw_zero(c, S.npc);
+  for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
+  V3 Fw;
+  sk = fs_slot_k(S, &Fw);
+  c.xbar(); // [2]
+  if (sk.on) {
+    fs_add_wrench_r(c, S.bt2, S.r2, Fw, 1.0f);
+    fs_add_wrench_r(c, S.bt1, S.r1, Fw, -1.0f);
+  }
+  if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar);
+  c.xbar(); // [3]
+  for (int d = c.lane; d < c.D.nv; d += 64) {
+    const int bd = KI(dof_rbody, d);
+    const S6 s_ = lds6(L + c.ly.cdof + 6 * d);
+    float acc = 0;
+    for (int mm = KI(r_submask, bd) & S.tb; mm;) {
+      const int b0 = __ffs(mm) - 1;
+      mm &= mm - 1;
+      const bool two = mm != 0;
+      const int b1 = two ? __ffs(mm) - 1 : b0;
+      mm &= mm - 1;
+      const S6 g0 = lds6(L + c.ly.G + 6 * b0), g1 = lds6(L + c.ly.G + 6 * b1);
+      acc += dot6(s_, g0) + (two ? dot6(s_, g1) : 0.0f);
+    }
+    L[c.ly.grad + d] -= acc;
+  }
+  SYNC();
+  const float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
+  *go = !(scale * gn < c.newton_tol);
+  if (c.lane == 0) w[MWC_CONT] = *go ? 1 : 0;
+  c.xbar(); // [4]
+  if (!*go) return gn;
+  mw_project(c);
+  c.xbar(); // [5]
+  return gn;
+}
+
+// the factorisation of fs_chol_solve in two halves: the DPP rows (helper 1) and the big islands (main)
+template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp) {
+  const int nv = c.D.nv;
+  const int *tail = c.I(mp) + nv + 64;
+  const int lw = c.I(mp)[nv + c.lane];
+  const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]) & 255;
+  int bad = 0;
+  const int dofr = lw & 255;
+  const int dof = dofr == 255 ? -1 : dofr;
+  if (rsteps <= 6) bad |= fs_chol_phase<6>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+  else if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+  else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
+  if (__ballot(bad != 0) && c.lane == 0) c.I(c.ly.mwc)[MWC_BAD] = 1;
+}
+template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp) {
+  const int nv = c.D.nv;
+  const int *tail = c.I(mp) + nv + 64;
+  const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
+  int bad = 0;
+  if (maxbig > 31) bad |= fs_chol_lds(c, mp);
+  else {
+#pragma unroll 1
+    for (int q = 0; q < nbig; q++) {
+      const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
+      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
+    }
+  }
+  return wave_or(bad);
+}
+
+// helper waves: sleep at the barrier, run what main posts (fs_collide is instantiated here only: main never runs it)
+template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
+  const int *w = c.I(c.ly.mwc);
+  for (int k = 0;; k++) {
+    c.xbar();
+    const int cmd = __builtin_amdgcn_readfirstlane(w[k & 1]);
+    if (cmd == MW_EXIT) break;
+    if (cmd == MW_COLLIDE) { if (c.wave == 1) fs_collide(c); }
+    else if (cmd == MW_ITER) mw_iter_helper(c);
+    else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap); }
+    else if (cmd == MW_MULM) { if (c.wave == 1) fs_mulM(c, __builtin_amdgcn_readfirstlane(w[MWC_A0]), __builtin_amdgcn_readfirstlane(w[MWC_A1])); }
+  }
+}
+
 template <class Ctx> DEV float fs_dotv(const Ctx &c, int a, int b) {
   float s = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) s += c.L[a + d] * c.L[b + d];
@@ -1168,19 +1474,61 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   fs_jdot(c, S, c.ly.x, true);
   float scale = c.D.meaninertia_scale;
   int it = 0;
+  // multi-wave kernels: the helper waves take part in the iteration unless the solve is one of the rare kinds they do not
+  // know (welds, body pairs beyond the cache, a second row pass) -- then main iterates alone, as in the one-wave kernel
+  bool mw = false;
+  if constexpr (Ctx::NW > 1) {
+    mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64;
+    if (mw) {
+      c.I(c.ly.jst)[FSIM_JSTW * c.lane + 4] = S.pid;
+      if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; }
+    }
+  }
   for (; it < c.newton_maxit; it++) {
-    const SlotK sk = fs_gradient(c, S);
-    float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
-    FS_SPROF(23);
-    if (scale * gn < c.newton_tol) break;
-    fs_hessian(c, sk, S);
-    FS_SPROF(24);
-    bool ok = fs_chol_solve(c, c.ly.hmap);
-    FS_SPROF(25);
-    if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
-    fs_mulM(c, c.ly.Mp, c.ly.p);
-    fs_body_spatial(c, c.ly.p);
-    fs_jdot(c, S, c.ly.p, false);
+    SlotK sk;
+    bool ok;
+    bool iterated = false;
+    if constexpr (Ctx::NW > 1) if (mw) {
+      iterated = true;
+      bool go;
+      mw_iterate_main(c, S, sk, scale, &go);
+      FS_SPROF(24);
+      if (!go) break;
+      int *w = c.I(c.ly.mwc);
+      const int *tail = c.I(c.ly.hmap) + c.D.nv + 64;
+      const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]) & 255, nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
+      if (nbig > 0 && rsteps > 0) { // the DPP rows on helper 1 beside the big island(s) here
+        if (c.lane == 0) w[MWC_BAD] = 0;
+        mw_post(c, MW_CHOL);
+        const int bad = mw_chol_big(c, c.ly.hmap);
+        mw_post(c, MW_IDLE);
+        ok = !(bad | __builtin_amdgcn_readfirstlane(w[MWC_BAD]));
+      } else {
+        mw_post(c, MW_IDLE); // (helper 1 is still adding the body-pair entries)
+        ok = fs_chol_solve(c, c.ly.hmap);
+      }
+      FS_SPROF(25);
+      if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
+      if (c.lane == 0) { w[MWC_A0] = c.ly.Mp; w[MWC_A1] = c.ly.p; }
+      mw_post(c, MW_MULM); // M p on helper 1 beside J p here
+      fs_body_spatial(c, c.ly.p);
+      fs_jdot(c, S, c.ly.p, false);
+      mw_post(c, MW_IDLE);
+    }
+    if (!iterated) {
+      sk = fs_gradient(c, S);
+      float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
+      FS_SPROF(23);
+      if (scale * gn < c.newton_tol) break;
+      fs_hessian(c, sk, S);
+      FS_SPROF(24);
+      ok = fs_chol_solve(c, c.ly.hmap);
+      FS_SPROF(25);
+      if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
+      fs_mulM(c, c.ly.Mp, c.ly.p);
+      fs_body_spatial(c, c.ly.p);
+      fs_jdot(c, S, c.ly.p, false);
+    }
     // phi'(0) along the Newton direction (= -g' H^-1 g < 0), p'Mp and p'(Mx - smooth) in one pass over the dofs
     float dphi0 = 0, pMp = 0, pg0 = 0;
     for (int d = c.lane; d < c.D.nv; d += 64) {
@@ -1239,7 +1587,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     // full J'f pass, a quarter of an uncoupled env's solve) could only confirm that -- the iteration ends here.
     if (!nonquad && nls == 0 && alpha == 1.0f) { it++; break; }
   }
-  if (c.lane == 0) scal[SC_NITER] = it;
+  if (c.lane == 0) { scal[SC_NITER] = it; scal[SC_NITSUM] += it; }
   SYNC();
 }
 
