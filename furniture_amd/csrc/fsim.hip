@@ -77,44 +77,48 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_physic
   store_record(rec, L, c.ly.stride, lane);
 }
 
-// One-wave kernel (Ctx::NW == 1): workgroup b steps env order[b] (all envs; those the scheduler gave to the multi-wave kernel of
-// the same launch -- mwsel[env] != 0 -- are skipped).  Multi-wave kernel (Ctx::NW == 4): workgroup b steps env mworder[b], b < *mwn.
-template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, EnvCfg cfg, float *state, const float *action,
-                                                 float *obs, float *reward, uint8_t *done, int *info, const float *tab_parts,
-                                                 const float *tab_noise, int n_noise, const uint8_t *reset_mask, int do_step, int *prof, const int *order, int *cost,
-                                                 const float *init_state, const uint8_t *init_mask, int *nreset, const uint8_t *mwsel, const int *mwn) {
-  extern __shared__ float L[];
-  CModel &m = *(CModel *)mp;
-  long long t_entry = clock64();
-  if ((int)blockIdx.x >= kp.n_envs) return;
-  if (Ctx::NW > 1 && mwn && (int)blockIdx.x >= *mwn) return;
-  // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
-  const int env = order ? order[blockIdx.x] : (int)blockIdx.x;
-  if (Ctx::NW == 1 && mwsel && mwsel[env]) return;
-  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+// What every flavour of the step kernel does for ONE env once it knows which env and which waves (fsim_env.hpp does the work).
+struct StepArgs {
+  EnvCfg cfg;
+  float *state;
+  const float *action;
+  float *obs, *reward;
+  uint8_t *done;
+  int *info;
+  const float *tab_parts, *tab_noise;
+  int n_noise;
+  const uint8_t *reset_mask;
+  int do_step;
+  int *prof, *cost;
+  const float *init_state;
+  const uint8_t *init_mask;
+  int *nreset;
+};
+template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, long long t_entry) {
+  float *L = c.L;
   const int lane = c.lane;
-  if constexpr (Ctx::NW > 1) if (c.wave > 0) { mw_helper_loop(c); return; } // helper waves (multi-wave kernel)
-  float *rec = state + (size_t)env * c.ly.stride;
+  const EnvCfg &cfg = a.cfg;
+  float *rec = a.state + (size_t)env * c.ly.stride;
   load_record(L, rec, c.ly.stride, lane);
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
   SYNC();
   fs_load_cache(c);
   EnvIO io;
-  io.action = action ? action + (size_t)env * cfg.dof_action : nullptr;
-  io.obs = obs ? reinterpret_cast<float *>(reinterpret_cast<char *>(obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4)) : nullptr;
-  io.reward = reward ? reward + env : nullptr;
-  io.done = done ? done + env : nullptr;
-  io.info = info ? info + (size_t)env * FSIM_INFO_DIM : nullptr;
-  io.tab_parts = tab_parts ? tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
-  io.tab_noise = tab_noise ? tab_noise + (size_t)env * n_noise * c.D.narmj : nullptr;
-  io.n_noise = n_noise;
-  io.nreset = nreset;
-  io.init_state = (init_state && init_mask && init_mask[env]) ? init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
-  io.cost = cost ? cost + env : nullptr;
+  io.action = a.action ? a.action + (size_t)env * cfg.dof_action : nullptr;
+  io.obs = a.obs ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4)) : nullptr;
+  io.reward = a.reward ? a.reward + env : nullptr;
+  io.done = a.done ? a.done + env : nullptr;
+  io.info = a.info ? a.info + (size_t)env * FSIM_INFO_DIM : nullptr;
+  io.tab_parts = a.tab_parts ? a.tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
+  io.tab_noise = a.tab_noise ? a.tab_noise + (size_t)env * a.n_noise * c.D.narmj : nullptr;
+  io.n_noise = a.n_noise;
+  io.nreset = a.nreset;
+  io.init_state = (a.init_state && a.init_mask && a.init_mask[env]) ? a.init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
+  io.cost = a.cost ? a.cost + env : nullptr;
   io.t0 = t_entry;
-  if (do_step) env_step(c, cfg, io);
-  else if (!reset_mask || reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
+  if (a.do_step) env_step(c, cfg, io);
+  else if (!a.reset_mask || a.reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
   if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   SYNC();
 #ifdef FSIM_PROFILE
@@ -128,9 +132,47 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_st
   }
   SYNC();
 #endif
-  if (prof && lane < 48) prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + lane] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
+  if (a.prof && lane < 48) a.prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + lane] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
 #endif
   store_record(rec, L, c.ly.stride, lane);
+}
+
+// One env per workgroup: the one-wave kernel (Ctx::NW == 1; workgroup b steps env order[b]) and the multi-wave kernel on its own
+// (Ctx::NW == 4, FSIM_MW=all: every env gets four waves -- development and tests).
+template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, StepArgs a, const int *order) {
+  extern __shared__ float L[];
+  CModel &m = *(CModel *)mp;
+  long long t_entry = clock64();
+  if ((int)blockIdx.x >= kp.n_envs) return;
+  // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
+  const int env = order ? order[blockIdx.x] : (int)blockIdx.x;
+  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+  if constexpr (Ctx::NW > 1) if (c.wave > 0) { mw_helper_loop(c); return; } // helper waves
+  env_run(c, a, env, t_entry);
+}
+
+// The step kernel proper: ONE launch of 4-wave workgroups.  Workgroups [0, mw_cap) are multi-wave envs (workgroup b steps env
+// mworder[b] with four waves if b < *mwn, else it leaves at once); every workgroup behind them is a BUNDLE of four one-wave envs
+// (wave w of bundle j steps env order[4 j + w] on its own LDS image; the four waves never synchronise).  Workgroups are
+// dispatched in index order, so the multi-wave envs -- the long jobs -- are placed first; with the two kinds in separate launches
+// the one-wave workgroups took every slot that freed up and the 4-wave ones starved until the others had all been dispatched.
+template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_env_step_x(const DModel *mp, const Layout *lp, const Layout *lp_mw, KParams kp, StepArgs a,
+                                                                                           const int *order, const int *nbulk, const int *mworder, const int *mwn, int mw_cap) {
+  extern __shared__ float L[];
+  CModel &m = *(CModel *)mp;
+  long long t_entry = clock64();
+  const int b = blockIdx.x;
+  if (b < mw_cap) {
+    if (b >= *mwn) return;
+    const CtxM c(L, m, *(CLayout *)lp_mw, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+    if (c.wave > 0) { mw_helper_loop(c); return; }
+    env_run(c, a, mworder[b], t_entry);
+  } else {
+    const int slot = 4 * (b - mw_cap) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (slot >= *nbulk) return;
+    const CtxB c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+    env_run(c, a, order[slot], t_entry);
+  }
 }
 
 // Longest-job-first launch order.  An env-step's cost varies 5x with its contact state (robot gripping a part =>
@@ -146,9 +188,10 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_st
 // Newton iterations (E_NITER of its record: a function of the env's state, never of timing, so results do not depend on the
 // schedule), the first mw_cap such envs in index order; the one-wave kernel skips them.
 __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int mw_cap,
-                                                uint8_t *mwsel, int *mworder, int *mwn) {
+                                                uint8_t *mwsel, int *mworder, int *mwn, int *nbulk) {
   __shared__ int hist[257];
   const int tid = threadIdx.x;
+  int nsel = 0;
   if (mwsel) {
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
@@ -162,12 +205,13 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
         const unsigned long long mask = __ballot(sel);
         const int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
         const bool take = sel && idx < mw_cap;
-        if (i < n) mwsel[i] = take ? 1 : 0;
+        if (i < n) mwsel[i] = take ? 1 : 0; // (lane tid handles the envs i = tid mod 64 in every loop of this kernel: it re-reads its own stores)
         if (take) mworder[idx] = i;
         base += __popcll(mask);
       }
     }
-    if (tid == 0) *mwn = min(base, mw_cap);
+    nsel = min(base, mw_cap);
+    if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; }
   }
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
   int lm = 0;
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
     int base = (cv >> 30) & 1 ? 1 : 129;
     return base + 127 - (int)((long long)(cv & 0x3fffffff) * 128 / M);
   };
-  for (int i = tid; i < n; i += 64) atomicAdd(&hist[bucket(cost[i])], 1);
+  for (int i = tid; i < n; i += 64) if (!mwsel || !mwsel[i]) atomicAdd(&hist[bucket(cost[i])], 1);
   __syncthreads();
   { // exclusive prefix sum over the 257 buckets: five consecutive buckets per lane, wave scan of the lane totals
     int h[5], tot = 0;
@@ -191,7 +235,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
     for (int k = 0; k < 5; k++) { const int b = 5 * tid + k; if (b < 257) hist[b] = acc; acc += h[k]; }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 64) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
+  for (int i = tid; i < n; i += 64) if (!mwsel || !mwsel[i]) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
 }
 
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays
@@ -247,27 +291,25 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
-typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, EnvCfg, float *, const float *, float *, float *, uint8_t *, int *, const float *,
-                          const float *, int, const uint8_t *, int, int *, const int *, int *, const float *, const uint8_t *, int *, const uint8_t *, const int *);
-#define FSIM_MW_NW 4 // waves per env of the multi-wave kernels
-struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; };
+typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *);
+typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, const int *, const int *, int);
+#define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
   hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
-  // multi-wave kernels (fsim_solver.hpp): mode 0 off, 1 = the scheduler picks the envs (default), 2 = every env, every launch
-  // (FSIM_MW=0 / all; development and tests).  In mode 1 a step is two kernels: the multi-wave one on `stream` right behind the
-  // scheduler (its workgroups -- the long jobs -- are dispatched first), the one-wave one on `stream2`; `stream` then waits for it.
-  int mw_mode = 1, mw_k = 150, mw_cap = 0;
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_sched = nullptr, ev_bulk = nullptr;
+  // multi-wave kernels (fsim_solver.hpp): mode 0 off (one-wave kernel only), 1 = a step is ONE launch of k_env_step_x -- the envs
+  // the scheduler picks get four waves, the others ride in bundles of four (default) --, 2 = every env gets four waves in every
+  // launch (FSIM_MW=0 / all; development and tests)
+  int mw_mode = 1, mw_k = 200, mw_cap = 0;
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
-  int lds_bytes_mw = 0;
+  int lds_bytes_mw = 0, lds_bytes_x = 0;
   uint8_t *d_mwsel = nullptr;
-  int *d_mworder = nullptr, *d_mwn = nullptr;
+  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others
   DModel m{};
   Layout ly{};
   fsim_config_t cfg{};
@@ -461,11 +503,11 @@ static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, size
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
 static KernelSet pick_kernels(const Dims &d, const LayoutIn &in) {
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
-  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>};
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -507,19 +549,21 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   { // multi-wave kernels
     s->ly_mw = make_layout(lin, FSIM_MW_NW);
     s->lds_bytes_mw = s->ly_mw.lds_words * 4;
+    s->lds_bytes_x = std::max(s->lds_bytes_mw, FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words));
     if (const char *e = getenv("FSIM_MW")) s->mw_mode = !strcmp(e, "all") ? 2 : (atoi(e) ? 1 : 0);
     if (const char *e = getenv("FSIM_MW_K")) s->mw_k = atoi(e);
-    s->mw_cap = std::max(1, n_envs / 8);
+    s->mw_cap = std::max(1, n_envs / 16);
     if (const char *e = getenv("FSIM_MW_CAP")) s->mw_cap = std::max(1, std::min(n_envs, atoi(e)));
     if (getenv("FSIM_NO_LPT") && s->mw_mode == 1) s->mw_mode = 0; // (the selection is part of the scheduler kernel)
     if (s->lds_bytes_mw > 160 * 1024) s->mw_mode = 0;
+    // bundles of four keep today's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
+    if (s->mw_mode == 1 && 2 * s->lds_bytes_x > 160 * 1024) s->mw_mode = 0;
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
-      HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&s->ev_sched, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_bulk, hipEventDisableTiming));
-      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 4));
-      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 4));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_x), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
+      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 8));
+      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 8));
     }
   }
   HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
@@ -570,6 +614,10 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
       hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step_mw));
       fprintf(stderr, "[fsim] multi-wave kernel (%d waves per env, mode %d, k %d, cap %d): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW, s->mw_mode,
               s->mw_k, s->mw_cap, s->lds_bytes_mw, nb, fa.numRegs, (size_t)fa.localSizeBytes);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step_x), 64 * FSIM_MW_NW, s->lds_bytes_x);
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step_x));
+      fprintf(stderr, "[fsim] step kernel (multi-wave workgroups + bundles of %d one-wave envs): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW,
+              s->lds_bytes_x, nb, fa.numRegs, (size_t)fa.localSizeBytes);
     }
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
@@ -588,9 +636,6 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  if (s->stream2) { hipStreamSynchronize(s->stream2); hipStreamDestroy(s->stream2); }
-  if (s->ev_sched) hipEventDestroy(s->ev_sched);
-  if (s->ev_bulk) hipEventDestroy(s->ev_bulk);
   hipFree(s->d_ly_mw); hipFree(s->d_mwsel); hipFree(s->d_mworder); hipFree(s->d_mwn);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -773,29 +818,21 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   const bool mw_auto = sched && s->mw_mode == 1, mw_all = s->mw_mode == 2;
   if (sched)
     hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), 0, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
-                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? s->d_mwsel : nullptr, s->d_mworder, s->d_mwn);
+                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? s->d_mwsel : nullptr, s->d_mworder, s->d_mwn, s->d_mwn + 1);
   if (s->timing) timing_begin(s);
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
-  int *prof = reinterpret_cast<int *>(s->d_aux), *costp = do_step ? s->d_cost : nullptr, *nres = do_step ? s->d_nreset : nullptr;
+  StepArgs a;
+  a.cfg = s->ecfg; a.state = s->d_state; a.action = action; a.obs = obs; a.reward = reward; a.done = done; a.info = info;
+  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.n_noise = s->n_noise; a.reset_mask = mask; a.do_step = do_step;
+  a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
+  a.nreset = do_step ? s->d_nreset : nullptr;
   if (mw_all)
-    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, s->ecfg, s->d_state,
-                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, sched ? s->d_order : nullptr, costp,
-                       s->d_init, s->d_init_mask, nres, nullptr, nullptr);
-  else if (mw_auto) {
-    hipEventRecord(s->ev_sched, s->stream);
-    hipStreamWaitEvent(s->stream2, s->ev_sched, 0);
-    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->mw_cap), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, s->ecfg, s->d_state,
-                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, s->d_mworder, costp,
-                       s->d_init, s->d_init_mask, nres, nullptr, s->d_mwn);
-    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream2, s->d_m, s->d_ly, kp, s->ecfg, s->d_state,
-                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof, s->d_order, costp,
-                       s->d_init, s->d_init_mask, nres, s->d_mwsel, nullptr);
-    hipEventRecord(s->ev_bulk, s->stream2);
-    hipStreamWaitEvent(s->stream, s->ev_bulk, 0);
-  } else
-    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, s->ecfg, s->d_state,
-                       action, obs, reward, done, info, s->d_tab_parts, s->d_tab_noise, s->n_noise, mask, do_step, prof,
-                       sched ? s->d_order : nullptr, costp, s->d_init, s->d_init_mask, nres, nullptr, nullptr);
+    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr);
+  else if (mw_auto)
+    hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->mw_cap + (s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream, s->d_m, s->d_ly,
+                       s->d_ly_mw, kp, a, s->d_order, s->d_mwn + 1, s->d_mworder, s->d_mwn, s->mw_cap);
+  else
+    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));

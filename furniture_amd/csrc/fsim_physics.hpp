@@ -24,12 +24,17 @@
 //   SpecCtx -- they are compile-time constants of the specialisation S (fsim_spec.hpp): offsets become instruction
 //              immediates, `for (i = lane; i < n; i += 64)` loops become a single test, no SGPRs are spent on the layout.
 // Both take the number of waves per env as a template parameter (NW; lane = lane inside the wave, wave = which wave).
-template <int NW_> struct FsSync {
-  DEV static void sync() { if (NW_ == 1) __syncthreads(); else __asm__ volatile("" ::: "memory"); }
+// BUNDLE: four one-wave envs share a workgroup (k_env_step_x: one launch holds the multi-wave workgroups and, behind them in
+// dispatch order, bundles of one-wave envs, so both kinds are 4-wave workgroups and the long jobs are placed first).  A bundled
+// wave is on its own: SYNC() must not be a workgroup barrier, and its LDS image starts at wave * FSIM_BUNDLE_STRIDE(lds_words).
+#define FSIM_BUNDLE_STRIDE(words) (((words) + 3) / 4 * 4)
+template <int NW_, bool BUNDLE_> struct FsSync {
+  DEV static void sync() { if (NW_ == 1 && !BUNDLE_) __syncthreads(); else __asm__ volatile("" ::: "memory"); }
   DEV static void xbar() { __syncthreads(); }
 };
-template <int NW_> struct GenCtxT {
+template <int NW_, bool BUNDLE_ = false> struct GenCtxT {
   static constexpr int NW = NW_;
+  static constexpr bool BUNDLE = BUNDLE_;
   float *L;          // LDS base (state image followed by work arrays)
   CModel &m;         // model tables (pointers)
   CLayout &ly;       // LDS / record layout
@@ -37,16 +42,21 @@ template <int NW_> struct GenCtxT {
   int lane, wave;
   int newton_maxit;
   float newton_tol;
-  __device__ GenCtxT(float *L_, CModel &m_, CLayout &ly_, int tid, int it, float tol)
-      : L(L_), m(m_), ly(ly_), D(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
+  // lds_: the workgroup's dynamic LDS; tid: threadIdx.x
+  __device__ GenCtxT(float *lds_, CModel &m_, CLayout &ly_, int tid, int it, float tol)
+      : L(lds_), m(m_), ly(ly_), D(m_), lane(tid & 63), wave((NW_ > 1 || BUNDLE_) ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {
+    if (BUNDLE_) L = lds_ + wave * FSIM_BUNDLE_STRIDE(ly_.lds_words);
+  }
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
-  DEV void sync() const { FsSync<NW_>::sync(); }
-  DEV void xbar() const { FsSync<NW_>::xbar(); }
+  DEV float *wg_lds() const { return BUNDLE_ ? L - wave * FSIM_BUNDLE_STRIDE(ly.lds_words) : L; } // the workgroup's LDS base (what fs_rebuild takes)
+  DEV void sync() const { FsSync<NW_, BUNDLE_>::sync(); }
+  DEV void xbar() const { FsSync<NW_, BUNDLE_>::xbar(); }
 };
 typedef GenCtxT<1> GenCtx;
 template <class S, int NW_> struct FsSpecLayout { static constexpr Layout ly = make_layout(S::in, NW_); };
-template <class S, int NW_ = 1> struct SpecCtx {
+template <class S, int NW_ = 1, bool BUNDLE_ = false> struct SpecCtx {
   static constexpr int NW = NW_;
+  static constexpr bool BUNDLE = BUNDLE_;
   float *L;
   CModel &m;
   static constexpr Layout ly = FsSpecLayout<S, NW_>::ly;
@@ -54,13 +64,18 @@ template <class S, int NW_ = 1> struct SpecCtx {
   int lane, wave;
   int newton_maxit;
   float newton_tol;
-  __device__ SpecCtx(float *L_, CModel &m_, CLayout &, int tid, int it, float tol)
-      : L(L_), m(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
-  __device__ SpecCtx(float *L_, CModel &m_, int tid, int it, float tol)
-      : L(L_), m(m_), lane(tid & 63), wave(NW_ > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {}
+  __device__ SpecCtx(float *lds_, CModel &m_, CLayout &, int tid, int it, float tol)
+      : L(lds_), m(m_), lane(tid & 63), wave((NW_ > 1 || BUNDLE_) ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {
+    if (BUNDLE_) L = lds_ + wave * FSIM_BUNDLE_STRIDE(ly.lds_words);
+  }
+  __device__ SpecCtx(float *lds_, CModel &m_, int tid, int it, float tol)
+      : L(lds_), m(m_), lane(tid & 63), wave((NW_ > 1 || BUNDLE_) ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0), newton_maxit(it), newton_tol(tol) {
+    if (BUNDLE_) L = lds_ + wave * FSIM_BUNDLE_STRIDE(ly.lds_words);
+  }
   DEV int *I(int off) const { return reinterpret_cast<int *>(L + off); }
-  DEV void sync() const { FsSync<NW_>::sync(); }
-  DEV void xbar() const { FsSync<NW_>::xbar(); }
+  DEV float *wg_lds() const { return BUNDLE_ ? L - wave * FSIM_BUNDLE_STRIDE(ly.lds_words) : L; } // the workgroup's LDS base (what fs_rebuild takes)
+  DEV void sync() const { FsSync<NW_, BUNDLE_>::sync(); }
+  DEV void xbar() const { FsSync<NW_, BUNDLE_>::xbar(); }
 };
 
 // Re-derive wave-uniform values after a real function call so the callee's model-table loads stay scalar.
@@ -69,14 +84,15 @@ template <class T> DEV T *fs_uniform_ptr(T *p) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (T *)(((unsigned long long)hi << 32) | lo);
 }
-template <int NW_> DEV GenCtxT<NW_> fs_rebuild(const GenCtxT<NW_> &cv, float *lds) {
-  return GenCtxT<NW_>(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
-                      __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+// (lds: the workgroup's dynamic LDS base -- a bundled wave's image offset is applied by the constructor)
+template <int NW_, bool B_> DEV GenCtxT<NW_, B_> fs_rebuild(const GenCtxT<NW_, B_> &cv, float *lds) {
+  return GenCtxT<NW_, B_>(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                          __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
 }
-template <class S, int NW_> DEV SpecCtx<S, NW_> fs_rebuild(const SpecCtx<S, NW_> &cv, float *lds) {
+template <class S, int NW_, bool B_> DEV SpecCtx<S, NW_, B_> fs_rebuild(const SpecCtx<S, NW_, B_> &cv, float *lds) {
   CModel &mu = *fs_uniform_ptr(&cv.m);
-  return SpecCtx<S, NW_>(lds, mu, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
-                         __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
+  return SpecCtx<S, NW_, B_>(lds, mu, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+                             __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
 }
 #define FS_REBUILD_CTX(cv)            \
   extern __shared__ float fs_lds_[];  \

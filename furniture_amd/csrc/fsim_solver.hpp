@@ -1123,7 +1123,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
         if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, bc);
         else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc);
 #else
-        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
+        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
         (void)dof;
 #endif
       }
@@ -1420,7 +1420,7 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp) {
 #pragma unroll 1
     for (int q = 0; q < nbig; q++) {
       const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
-      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.L, mp, first, n);
+      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
     }
   }
   return wave_or(bad);
