@@ -304,7 +304,7 @@ struct fsim {
   // multi-wave kernels (fsim_solver.hpp): mode 0 off (one-wave kernel only), 1 = a step is ONE launch of k_env_step_x -- the envs
   // the scheduler picks get four waves, the others ride in bundles of four (default) --, 2 = every env gets four waves in every
   // launch (FSIM_MW=0 / all; development and tests)
-  int mw_mode = 1, mw_k = 200, mw_cap = 0;
+  int mw_mode = 1, mw_k = 150, mw_cap = 0;
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
@@ -552,7 +552,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->lds_bytes_x = std::max(s->lds_bytes_mw, FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words));
     if (const char *e = getenv("FSIM_MW")) s->mw_mode = !strcmp(e, "all") ? 2 : (atoi(e) ? 1 : 0);
     if (const char *e = getenv("FSIM_MW_K")) s->mw_k = atoi(e);
-    s->mw_cap = std::max(1, n_envs / 16);
+    s->mw_cap = std::max(1, n_envs / 8);
     if (const char *e = getenv("FSIM_MW_CAP")) s->mw_cap = std::max(1, std::min(n_envs, atoi(e)));
     if (getenv("FSIM_NO_LPT") && s->mw_mode == 1) s->mw_mode = 0; // (the selection is part of the scheduler kernel)
     if (s->lds_bytes_mw > 160 * 1024) s->mw_mode = 0;

@@ -972,7 +972,7 @@ template <class Ctx> DEV float env_robot_clearance(const Ctx &c) {
   for (int p0 = 0; p0 < c.D.ncp; p0 += 64) {
     const int p = min(p0 + c.lane, c.D.ncp - 1);
     const int w = GP(m.pair_bp)[2 * p], g1 = w & 255, g2 = (w >> 8) & 255;
-    const bool rp = (m.cg_isrobot[g1] && m.cg_ispartcol[g2]) || (m.cg_isrobot[g2] && m.cg_ispartcol[g1]);
+    const bool rp = (m.cg_fingerrole[g1] && m.cg_ispartcol[g2]) || (m.cg_fingerrole[g2] && m.cg_ispartcol[g1]); // finger geoms x part geoms
     if (!rp || p0 + c.lane >= c.D.ncp) continue;
     const int b1 = m.cg_body[g1], b2 = m.cg_body[g2];
     const M3 B1 = ldm3(L + c.ly.xmat + 9 * b1), B2 = ldm3(L + c.ly.xmat + 9 * b2);
@@ -1231,7 +1231,10 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
   { // what the scheduler of the next launch reads (k_schedule): this step's Newton iterations (0 after a reset), the robot-part clearance now
     const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;
-    if (c.lane == 0) { E[E_NITER] = (terminal && cfg.auto_reset) ? 0 : nit_step; L[c.ly.env + E_CLEARANCE] = clr; }
+    if (c.lane == 0) {
+      E[E_NITER] = (terminal && cfg.auto_reset) ? 0 : nit_step; L[c.ly.env + E_CLEARANCE] = clr;
+      E[E_TOUCH_L] = scal[SC_TOUCHL]; E[E_TOUCH_R] = scal[SC_TOUCHR]; E[E_TOUCH_FLOOR] = c.D.nr > 1 ? scal[SC_ISL + KI(r_tree, 1)] : 0; // (development: candidate features of the scheduler's rule)
+    }
   }
   env_write_obs(c, cfg, io);
 #ifdef FSIM_TIMELINE

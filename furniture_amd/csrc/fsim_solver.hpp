@@ -1149,7 +1149,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
 // filled by exactly ONE wave in lane order and sums across accumulators are taken in a fixed order, so the result is a function
 // of the state alone, as in the one-wave kernel (run-to-run bit-identical) -- though not bit-identical TO the one-wave kernel.
 enum { MW_IDLE = 0, MW_EXIT = 1, MW_COLLIDE = 2, MW_ITER = 3, MW_CHOL = 4, MW_MULM = 5 };
-enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9 };
+enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9, MWC_SOLVE = 10 };
 
 template <class Ctx> DEV void mw_post(const Ctx &c, int cmd) { // main wave only
   int *w = c.I(c.ly.mwc);
@@ -1188,13 +1188,18 @@ DEV SlotK fs_slot_k(const SolSlot &S, V3 *Fw) {
   return sk;
 }
 
-// zero this wave's share of the Hessian work arrays (H, the two block sets, the cached pair blocks)
+// zero the Hessian work array THIS helper wave fills next (no barrier between the zeroing and the wave's own atomics): helper 1
+// the lower bodies' blocks, helper 2 the higher bodies', helper 3 the cached pair blocks and H itself (complete at barrier [3])
 template <class Ctx> DEV void mw_zero(const Ctx &c, int npc) {
   float *L = c.L;
-  const int nH = c.I(c.ly.scal)[SC_HWORDS], t = 64 * c.wave + c.lane;
-  for (int i = t; i < nH; i += 64 * Ctx::NW) L[c.ly.H + i] = 0;
-  for (int i = t; i < 42 * c.D.nr; i += 64 * Ctx::NW) L[c.ly.hA + i] = 0; // (hA and hAhi are contiguous)
-  if (npc > 0) for (int i = t; i < FSIM_XW * npc; i += 64 * Ctx::NW) L[c.ly.hP + i] = 0;
+  if (c.wave == 1) for (int i = c.lane; i < 21 * c.D.nr; i += 64) L[c.ly.hA + i] = 0;
+  else if (c.wave == 2) for (int i = c.lane; i < 21 * c.D.nr; i += 64) L[c.ly.hAhi + i] = 0;
+  else {
+    if (npc > 0) for (int i = c.lane; i < FSIM_XW * npc; i += 64) L[c.ly.hP + i] = 0;
+    const int nH = c.I(c.ly.scal)[SC_HWORDS];
+    for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
+  }
+  SYNC();
 }
 
 // contact blocks: role 1 = the lower body of every contact -> hA, role 2 = the higher body -> hAhi, role 3 = the cached pair blocks
@@ -1282,11 +1287,11 @@ template <class Ctx> DEV void mw_pair_y(const Ctx &c, int nye, int pairon) {
   }
 }
 
-// tree blocks on M's pattern, all waves: H[i][j] = M[i][j] + cdof_i' hAc[body(i)] cdof_j
+// tree blocks on M's pattern, waves 0 .. NW - 2: H[i][j] = M[i][j] + cdof_i' hAc[body(i)] cdof_j
 template <class Ctx> DEV void mw_project(const Ctx &c) {
   float *L = c.L;
   const int hm = c.ly.hmap;
-  for (int e = 64 * c.wave + c.lane; e < c.D.nM; e += 64 * Ctx::NW) {
+  for (int e = 64 * c.wave + c.lane; e < c.D.nM; e += 64 * (Ctx::NW - 1)) { // (waves 0 .. NW - 2; the last one adds the pair entries meanwhile)
     int i = KM_I(e), j = KM_J(e);
     const float *Ab = L + c.ly.hAc + 21 * KI(dof_rbody, i);
     S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
@@ -1300,52 +1305,60 @@ template <class Ctx> DEV void mw_project(const Ctx &c) {
   }
 }
 
-// cached pairs, stage 2 + joint limits (one wave, after the projection's stores)
-template <class Ctx> DEV void mw_pairs_limits(const Ctx &c, const SolSlot &S, int ptot, int pairon) {
+// cached pairs, stage 2.  An entry (d1, d2) whose dofs belong to DIFFERENT kinematic trees (a finger against a part: the usual
+// kind) lies outside M's pattern, i.e. outside what mw_project stores, so one wave adds those beside the projection
+// (cross = true); entries inside a tree (robot self-contact) and the joint limits wait for the projection's stores
+// (cross = false, helper 1).  One wave per kind: entries of different pairs may share a word of H.
+template <class Ctx> DEV void mw_pair_items(const Ctx &c, int ptot, int pairon, bool cross) {
   float *L = c.L;
   const int hm = c.ly.hmap;
-  if (pairon) {
-    const float *X = L + c.ly.hP;
-    const int *pitem = c.I(c.ly.pitem);
-    for (int it = c.lane; it < ptot; it += 64) {
-      const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = (w >> 16) & 255, e2 = w >> 24;
-      const float *Yq = X + FSIM_XW * q + 6 * e2;
-      const float *s1 = L + c.ly.cdof + 6 * d1;
-      float v = 0;
+  if (!pairon) return;
+  const float *X = L + c.ly.hP;
+  const int *pitem = c.I(c.ly.pitem);
+  for (int it = c.lane; it < ptot; it += 64) {
+    const int w = pitem[it], q = w & 255, d1 = (w >> 8) & 255, d2 = (w >> 16) & 255, e2 = w >> 24;
+    const bool same = KI(r_tree, KI(dof_rbody, d1)) == KI(r_tree, KI(dof_rbody, d2));
+    const float *Yq = X + FSIM_XW * q + 6 * e2;
+    const float *s1 = L + c.ly.cdof + 6 * d1;
+    float v = 0;
 #pragma unroll
-      for (int rr = 0; rr < 6; rr++) v += s1[rr] * Yq[rr];
-      if (d1 == d2) v *= 2.0f;
-      const int hx = fs_hidx(c, hm, max(d1, d2), min(d1, d2));
-      if ((pairon >> q) & 1) atomicAdd(L + c.ly.H + hx, -v);
-    }
+    for (int rr = 0; rr < 6; rr++) v += s1[rr] * Yq[rr];
+    if (d1 == d2) v *= 2.0f;
+    const int hx = fs_hidx(c, hm, max(d1, d2), min(d1, d2));
+    if (((pairon >> q) & 1) && same != cross) atomicAdd(L + c.ly.H + hx, -v);
   }
-  if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
 }
 
 // the helper waves' side of one Newton iteration (command MW_ITER); barriers pair up with mw_iterate_main's
-template <class Ctx> DEV void mw_iter_helper(const Ctx &c) {
+// (S: the helper's copy of the slot records, loaded once per solve -- sid tells which solve it belongs to)
+template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid) {
   const int *w = c.I(c.ly.mwc);
   const int npc = __builtin_amdgcn_readfirstlane(w[MWC_NPC]), ptot = __builtin_amdgcn_readfirstlane(w[MWC_PTOT]), nye = __builtin_amdgcn_readfirstlane(w[MWC_NYE]);
+  const int solve = __builtin_amdgcn_readfirstlane(w[MWC_SOLVE]);
   mw_zero(c, npc);
-  SolSlot S = fs_load_slots(c);
-  {
-    const float *j = c.L + c.ly.jst + FSIM_JSTW * c.lane;
-    S.jar[0] = j[0]; S.jar[1] = j[1]; S.jar[2] = j[2]; S.ljar = j[3];
+  const float *j = c.L + c.ly.jst + FSIM_JSTW * c.lane;
+  if (solve != sid) {
+    S = fs_load_slots(c);
     S.pid = reinterpret_cast<const int *>(j)[4];
+    sid = solve;
   }
+  S.jar[0] = j[0]; S.jar[1] = j[1]; S.jar[2] = j[2]; S.ljar = j[3];
   V3 Fw;
   const SlotK sk = fs_slot_k(S, &Fw);
   const int pairon = npc > 0 ? mw_pairon(S, sk) : 0;
-  c.xbar(); // [2] arrays zeroed
   mw_blocks(c, S, sk, c.wave);
-  c.xbar(); // [3] blocks complete
+  c.xbar(); // [3] blocks complete, H zeroed
   if (c.wave == Ctx::NW - 1 && npc > 0) mw_pair_y(c, nye, pairon);
   mw_composite(c);
   c.xbar(); // [4] composite blocks, Y; main has decided whether the iteration goes on
   if (!__builtin_amdgcn_readfirstlane(w[MWC_CONT])) return;
-  mw_project(c);
+  if (c.wave == Ctx::NW - 1) { if (npc > 0) mw_pair_items(c, ptot, pairon, true); } // (the projection's 3 x 64 lanes cover M's entries of every in-scope model in one or two passes)
+  else mw_project(c);
   c.xbar(); // [5] tree blocks stored
-  if (c.wave == 1) mw_pairs_limits(c, S, ptot, pairon);
+  if (c.wave == 1) {
+    if (npc > 0) mw_pair_items(c, ptot, pairon, false);
+    if (S.lact && S.ljar < 0) atomicAdd(c.L + c.ly.H + fs_hidx(c, c.ly.hmap, S.ldof, S.ldof), S.ld);
+  }
 }
 
 // main's side: gradient (the code of fs_gradient, split at its barriers) beside the helpers' Hessian.  Returns the gradient
@@ -1353,23 +1366,31 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c) {
 template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go) {
   float *L = c.L;
   int *w = c.I(c.ly.mwc);
+#if defined(FSIM_PROFILE) && !defined(FSIM_NPPROF) && !defined(FSIM_CHOLPROF) && !defined(FSIM_TIMELINE)
+  long long tm_ = clock64();
+#define FS_MWPROF(slot) do { long long t1m_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[slot] += (int)((t1m_ - tm_) >> 4); tm_ = t1m_; } while (0)
+#else
+#define FS_MWPROF(slot) do { } while (0)
+#endif
   { // stage this iteration's J a - aref for the helpers
     float *j = L + c.ly.jst + FSIM_JSTW * c.lane;
     j[0] = S.jar[0]; j[1] = S.jar[1]; j[2] = S.jar[2]; j[3] = S.ljar;
   }
   mw_post(c, MW_ITER); // [1]
-  mw_zero(c, S.npc);
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
   V3 Fw;
   sk = fs_slot_k(S, &Fw);
-  c.xbar(); // [2]
+  SYNC();
+  FS_MWPROF(48);
   if (sk.on) {
     fs_add_wrench_r(c, S.bt2, S.r2, Fw, 1.0f);
     fs_add_wrench_r(c, S.bt1, S.r1, Fw, -1.0f);
   }
   if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar);
+  FS_MWPROF(50);
   c.xbar(); // [3]
+  FS_MWPROF(53);
   for (int d = c.lane; d < c.D.nv; d += 64) {
     const int bd = KI(dof_rbody, d);
     const S6 s_ = lds6(L + c.ly.cdof + 6 * d);
@@ -1389,10 +1410,14 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
   const float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
   *go = !(scale * gn < c.newton_tol);
   if (c.lane == 0) w[MWC_CONT] = *go ? 1 : 0;
+  FS_MWPROF(54);
   c.xbar(); // [4]
+  FS_MWPROF(55);
   if (!*go) return gn;
   mw_project(c);
+  FS_MWPROF(56);
   c.xbar(); // [5]
+  FS_MWPROF(57);
   return gn;
 }
 
@@ -1429,12 +1454,14 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp) {
 // helper waves: sleep at the barrier, run what main posts (fs_collide is instantiated here only: main never runs it)
 template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
   const int *w = c.I(c.ly.mwc);
+  SolSlot S = {};
+  int sid = -1;
   for (int k = 0;; k++) {
     c.xbar();
     const int cmd = __builtin_amdgcn_readfirstlane(w[k & 1]);
     if (cmd == MW_EXIT) break;
-    if (cmd == MW_COLLIDE) { if (c.wave == 1) fs_collide(c); }
-    else if (cmd == MW_ITER) mw_iter_helper(c);
+    if (cmd == MW_COLLIDE) { sid = -1; if (c.wave == 1) fs_collide(c); } // (a new substep: the slot records will change)
+    else if (cmd == MW_ITER) mw_iter_helper(c, S, sid);
     else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap); }
     else if (cmd == MW_MULM) { if (c.wave == 1) fs_mulM(c, __builtin_amdgcn_readfirstlane(w[MWC_A0]), __builtin_amdgcn_readfirstlane(w[MWC_A1])); }
   }
@@ -1464,14 +1491,19 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   // active slot the first Newton step (H = M, alpha = 1) is exactly M^-1 qfrc_smooth, so M is never factored on its own.
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.x + d] = L[c.ly.qaccws + d];
   SYNC();
+  if constexpr (Ctx::NW > 1) { // M x on helper 1 beside the slot records and J x here
+    if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_A0] = c.ly.Mx; w[MWC_A1] = c.ly.x; }
+    mw_post(c, MW_MULM);
+  }
   SolSlot S = fs_load_slots(c);
   fs_pair_cache(c, S);
 #ifdef FSIM_PROFILE
   if (c.lane == 0) scal[52] += ((S.npc < 0) << 16) + ((S.npc > 0) << 24); // solves whose body pairs did not fit the cache / did
 #endif
-  fs_mulM(c, c.ly.Mx, c.ly.x);
+  if constexpr (Ctx::NW == 1) fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
   fs_jdot(c, S, c.ly.x, true);
+  if constexpr (Ctx::NW > 1) mw_post(c, MW_IDLE);
   float scale = c.D.meaninertia_scale;
   int it = 0;
   // multi-wave kernels: the helper waves take part in the iteration unless the solve is one of the rare kinds they do not
@@ -1481,7 +1513,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64;
     if (mw) {
       c.I(c.ly.jst)[FSIM_JSTW * c.lane + 4] = S.pid;
-      if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; }
+      if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; }
     }
   }
   for (; it < c.newton_maxit; it++) {

@@ -21,7 +21,7 @@ obs = torch.zeros((N, sim.obs_dim), device=dev); rew = torch.zeros(N, device=dev
 info = torch.zeros((N, INFO_DIM), dtype=torch.int32, device=dev)
 act = torch.empty((N, 9), device=dev); g = torch.Generator(device=dev); g.manual_seed(123)
 sim.reset(None, obs); sim.sync()
-clear = np.zeros((T, N), np.float32); nit = np.zeros((T, N), np.int64)
+clear = np.zeros((T, N), np.float32); nit = np.zeros((T, N), np.int64); touch = np.zeros((T, N), np.int64); both = np.zeros((T, N), np.int64); isl = np.zeros((T, N), np.int64)
 for t in range(T):
     act.uniform_(-1, 1, generator=g); torch.cuda.synchronize()
     sim.step(act, obs, rew, done, info); sim.sync()
@@ -30,19 +30,21 @@ for t in range(T):
         pq, nz = sampler.draw()
         sim.set_reset_tables(pq, nz, mask=mask)
     eb = sim.get_state("env_block")["env_block"].cpu().numpy()
-    eb = np.ascontiguousarray(eb).view(np.int32); clear[t] = eb[:, E_CLEAR].copy().view(np.float32); nit[t] = eb[:, E_NITER]
+    eb = np.ascontiguousarray(eb).view(np.int32); clear[t] = eb[:, E_CLEAR].copy().view(np.float32); nit[t] = eb[:, E_NITER]; touch[t] = (eb[:, 18] | eb[:, 19]) != 0; both[t] = (eb[:, 18] & eb[:, 19]) != 0; isl[t] = np.array([bin(int(x) & 0xffff).count('1') for x in eb[:, 20]]) > 1
 print("steps %d envs %d | Newton iterations per step: median %.0f p90 %.0f p99 %.0f max %d" % (T, N, np.median(nit), np.percentile(nit, 90), np.percentile(nit, 99), nit.max()))
 for t in (0, 5, 20, 60, 100, 140, 149, 150, 160):
     if t < T: print("  step %3d: clearance p10 %.3f p50 %.3f | <2cm %.3f <5cm %.3f <10cm %.3f | niter>=100: %.3f >=150: %.3f >=200: %.3f" % (
         t, np.percentile(clear[t], 10), np.median(clear[t]), (clear[t] < .02).mean(), (clear[t] < .05).mean(), (clear[t] < .10).mean(), (nit[t] >= 100).mean(), (nit[t] >= 150).mean(), (nit[t] >= 200).mean()))
-nxt = nit[1:]; cl = clear[:-1]; prev = nit[:-1]
-ok = nxt > 0  # (the step after a reset records 0 for the terminal step itself)
-print("rule: select if clearance < r or niter_prev >= k  ->  mean / max selected fraction; max and p99.9 of next-step iterations among the NON-selected; recall of next >= 150")
-for r in (0.0, 0.005, 0.01, 0.02, 0.03, 0.05):
-    for k in (70, 100, 10**9):
-        sel = (cl < r) | (prev >= k)
-        frac = sel.mean(axis=1)
-        rest = np.where(sel, 0, nxt)
-        big = nxt >= 150
-        print("  r %.2f k %-10d selected mean %.3f max %.3f | non-selected next iters: max %4d p99.9 %4.0f mean-of-step-max %5.1f | recall(next>=150) %.3f" % (
-            r, k, frac.mean(), frac.max(), rest.max(), np.percentile(rest, 99.9), rest.max(axis=1).mean(), (sel & big).sum() / max(1, big.sum())))
+nxt = nit[1:]; cl = clear[:-1]; prev = nit[:-1]; tc = touch[:-1] > 0; bt = both[:-1] > 0; cp = isl[:-1] > 0
+print("touch-any frac %.3f, touch-both frac %.3f, robot-coupled frac %.3f, clearance<1cm %.3f <2cm %.3f <3cm %.3f" % (tc.mean(), bt.mean(), cp.mean(), (cl < .01).mean(), (cl < .02).mean(), (cl < .03).mean()))
+def score(name, sel):
+    frac = sel.mean(axis=1); rest = np.where(sel, 0, nxt); big = nxt >= 150
+    print("  %-44s selected mean %.3f max %.3f | non-selected next iters: max %4d p99.9 %4.0f mean-of-step-max %5.1f | recall(next>=150) %.3f" % (
+        name, frac.mean(), frac.max(), rest.max(), np.percentile(rest, 99.9), rest.max(axis=1).mean(), (sel & big).sum() / max(1, big.sum())))
+for k in (100, 150, 200):
+    score("prev>=%d" % k, prev >= k)
+    score("prev>=%d or touch" % k, (prev >= k) | tc)
+    score("prev>=%d or coupled" % k, (prev >= k) | cp)
+    score("prev>=%d or touch or coupled" % k, (prev >= k) | tc | cp)
+    for r in (0.005, 0.01, 0.02, 0.03):
+        score("prev>=%d or touch or coupled or clear<%.3f" % (k, r), (prev >= k) | tc | cp | (cl < r))

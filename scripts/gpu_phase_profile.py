@@ -30,6 +30,16 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         t, dt * 1e3, tot.mean() / 1e6, np.percentile(tot, 50) / 1e6, np.percentile(tot, 99) / 1e6, tot.max() / 1e6,
         " ".join("%s %.0f%%" % (n, 100 * cyc[:, i].sum() / tot.sum()) for i, n in enumerate(names)),
         nsub.mean(), nit.sum() / max(1, nsub.sum()), maxit.max(), ncoup.sum() / max(1, nsub.sum()), nsurv.sum() / max(1, nsub.sum()), nslot.sum() / max(1, nsub.sum())))
+    # which envs the scheduler gave four waves in THIS step (its rule, recomputed: last step's Newton iterations >= K, first cap envs)
+    K = int(os.environ.get("FSIM_MW_K", "200")); cap = int(os.environ.get("FSIM_MW_CAP", str(max(1, N // 16))))
+    if t > 0 and os.environ.get("FSIM_MW", "1") not in ("0", "all"):
+        selm = prev_nit >= K
+        idx = np.nonzero(selm)[0][:cap]; selm = np.zeros(N, bool); selm[idx] = True
+        print("    multi-wave envs %d (%.1f%%): max %.2f mean %.2f Mcyc | one-wave envs: max %.2f Mcyc, %d above 5 Mcyc, %d above 7 Mcyc" % (
+            selm.sum(), 100 * selm.mean(), tot[selm].max() / 1e6 if selm.any() else 0, tot[selm].mean() / 1e6 if selm.any() else 0,
+            tot[~selm].max() / 1e6, (tot[~selm] > 5e6).sum(), (tot[~selm] > 7e6).sum()))
+    eb = sim.get_state("env_block")["env_block"].cpu().numpy()
+    prev_nit = np.ascontiguousarray(eb).view(np.int32)[:, 35].copy()
     fine = pall[:, 16:29] * 16
     cfine = pall[:, 29:32] * 16
     fn = ["kinematics", "com_inertia", "crb+M", "factor", "vel_bias", "smooth", "solve:setup", "grad", "hessian", "chol", "Mp+jp", "linesearch", "update+cost"]
@@ -46,6 +56,11 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         for e in list(np.argsort(-tot)[:4]) + [int(np.argsort(tot)[N // 2])]:
             print("    env %d Hessian split kcyc/substep: zero+contact blocks %.1f composite %.1f tree projection %.1f body pairs %.1f limits+welds %.1f" % (
                 e, pall[e, 32] * 16 / 50e3, pall[e, 33] * 16 / 50e3, pall[e, 34] * 16 / 50e3, pall[e, 37] * 16 / 50e3, pall[e, 38] * 16 / 50e3))
+    if t == 5 and os.environ.get("FSIM_MW") == "all":
+        for e in list(np.argsort(-tot)[:3]) + [int(np.argsort(tot)[N // 2])]:
+            q = pall[e, 32:42] * 16 / max(1, nit[e]) / 1e3
+            print("    env %d multi-wave iteration, main wave kcyc per Newton iteration: stage+post+zero+K %.2f wait[2] %.2f wrench atomics %.2f wait[3] %.2f J'f+norm %.2f wait[4] %.2f project %.2f wait[5] %.2f" % (
+                e, q[0], q[1], q[2], q[5], q[6], q[7], q[8], q[9]))
     if t in (3, 8):
         order = np.argsort(-tot)[:5]
         for e in order:
