@@ -6,7 +6,11 @@ One "step" = one FurnitureEnv.step() on every env = 50 physics substeps + connec
 
     python bench.py                      # SURVEY 8(d) protocol: 100 warm-up + 1000 timed steps (>= 6 full-batch resets inside)
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 ...         # launched plainly: re-executes itself as 8 ranks (torch.distributed.run, RCCL); refuses (rc 2)
+                                         # if fewer than 8 GPUs are visible -- it never falls back to one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config 4 --gpus 8  # BASELINE configs: 2 (default), 3 Sawyer + swivel_chair 8192 envs, 4 Baxter + desk_mikael,
+                                         # 5 mixed-furniture batch (table_lack / chair_agne / shelf_ivar per lane)
 
 Rank 0 prints ONE JSON line.  `value` is the whole-job aggregate; inputs are resident in HBM when the timed region
 starts (actions are generated on the device).  `roofline` prices the fused step kernel against HBM peak with the
@@ -65,8 +69,109 @@ def cpu_baseline(seconds=10.0):
                       "%.1f env-steps/s per core" % (cores, seconds, steps / wall / cores)}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, selftest=False):
+    """`python bench.py --gpus N` launched plainly (no RANK in the environment): run N ranks of this script under
+    torch.distributed.run, one per GPU (the reference's fan-out is one worker process per env, furniture/env/base.py:55-80; here it
+    is one process per GPU).  Returns the launcher's exit code; rank 0's JSON line goes to this process's stdout."""
+    import subprocess
+    if not selftest:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py: %d GPUs requested, %d visible -- refusing to run on fewer (no silent fallback)\n" % (n, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest():
+    """CPU stand-in for the N-rank launch path (tests/test_bench_launcher.py): the ranks meet over gloo, reduce their ranks, and
+    rank 0 prints one JSON line.  No GPU, no physics -- it checks the spawning, the rendezvous and the one-line contract."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "rank_sum": float(t)}))
+    dist.destroy_process_group()
+
+
+def mixed_bench(args):
+    """BASELINE config 5: every lane of the batch runs one of several furniture models (round robin over the global lane index),
+    one FSim handle + HIP stream per model, padded observation slab, RCCL gather of the padded slab (furniture_amd/mixed.py)."""
+    import torch
+    import torch.distributed as dist
+    from furniture_amd.envs import make_config
+    from furniture_amd.mixed import FurnitureMixedBatchEnv
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (args.gpus, world))
+        sys.exit(2)
+    names = args.furniture.split(",")
+    n = args.envs_per_gpu // len(names) * len(names)
+    env = FurnitureMixedBatchEnv(args.agent, names, n, device=local, first_env_index=rank * n,
+                                 config=make_config(unity=False, record_vid=False, control_type="impedance", max_episode_steps=MAX_EPISODE_STEPS, seed=SEED))
+    env.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(SEED + rank)
+    acts = torch.empty((args.warmup + args.steps, n, env.dof), device=env.device).uniform_(-1, 1, generator=g)
+    for t in range(args.warmup):
+        env.step(acts[t]); env.gather()
+    torch.cuda.synchronize(env.device)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        env.step(acts[t]); env.gather()
+    torch.cuda.synchronize(env.device)
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], device=env.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec (whole node), EXPLORATION config 5: mixed batch %s, %d envs/GPU" % ("/".join(names), n),
+                          "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "BASELINE config 5: Furniture%sEnv, lane i -> %s[i %% %d], padded observation slab %d wide" % (args.agent, names, len(names), env.obs_dim),
+                                                          "envs_per_gpu": n, "global_envs": world * n, "obs_finite": bool(torch.isfinite(env.obs).all())}}))
+    env.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+CONFIGS = {  # BASELINE.json `configs` (1 is the CPU reference case: tests/test_oracle_env.py)
+    2: dict(agent="Sawyer", furniture="table_lack_0825", envs=4096),
+    3: dict(agent="Sawyer", furniture="swivel_chair_0700", envs=8192),
+    4: dict(agent="Baxter", furniture="desk_mikael_1064", envs=4096),
+    5: dict(agent="Sawyer", furniture="table_lack_0825,chair_agne_0007,shelf_ivar_0678", envs=4095),  # one model per lane, round robin
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline benchmark)")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
@@ -81,6 +186,15 @@ def main():
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:  # plain launch: become N ranks
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], selftest=args.launcher_selftest))
+    if args.launcher_selftest:
+        return launcher_selftest()
+    if args.config != 2:
+        preset = CONFIGS[args.config]
+        args.agent, args.furniture, args.envs_per_gpu = preset["agent"], preset["furniture"], preset["envs"]
+    if args.config == 5:
+        return mixed_bench(args)
 
     import torch
     import torch.distributed as dist
@@ -97,7 +211,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (args.gpus, world))
+        sys.exit(2)
     n = args.envs_per_gpu
     lo, hi = shard_range(rank, world, n)
 
@@ -246,7 +362,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
             traffic = pmc["bytes_per_env_step"] * ng
-            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, %s), %d B per env-step x %d envs per launch"
+            traffic_note = ("builder-lease PMC, not this run: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, %s), %d B per env-step x %d envs per launch"
                             % (pmc.get("source", "profiles/"), pmc["bytes_per_env_step"], ng))
         except Exception:
             pass
@@ -261,9 +377,12 @@ def main():
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
                        "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: the contract offers "hbm" | "mfma"; the path is neither (see `binding`) -- HBM is the one of the two it is priced
+            # against, as BASELINE.json asks.  `traffic` / `binding` come from the builder's own rocprofv3 PMC passes of this workload
+            # (profiles/pmc_latest.json), not from this run.
+            "roofline": {"bound": "hbm", "bound_actual": "per-wave instruction issue + LDS latency (see binding)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_env_step", "kernel_avg_ms": kms, "kernel_launches": klaunches,
+                         "kernel": "k_env_step_x" if os.environ.get("FSIM_MW", "1") not in ("0", "all") else "k_env_step", "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
@@ -278,7 +397,7 @@ def main():
                                      "algorithmic_flops_per_env_step": [1.5e6, 5.5e6],
                                      "fp32_vector_peak_tflops": 157.3,
                                      "achieved_tflops_algorithmic": [1.5e6 * value / 1e12, 5.5e6 * value / 1e12],
-                                     "source": pmc.get("source")}},
+                                     "source": "builder-lease PMC passes, not this run: %s" % pmc.get("source")}},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -322,6 +322,7 @@ struct fsim {
   int *d_nreset = nullptr, *h_nreset = nullptr; // envs that consumed their reset table in the last step launch (device counter, pinned host copy)
   float *d_init = nullptr;       // set_init_qpos: [n][nq + nv] state the masked envs' resets start from
   uint8_t *d_init_mask = nullptr;
+  std::vector<uint8_t> h_init_mask; // host mirror of d_init_mask: "is any init state set" is asked by fsim_set_preassembled
   float *d_dense = nullptr; // dense-reward tables: DC_WORDS coefficients, then nsub rows of DS_WORDS
   int *d_pre = nullptr;     // pre-assembled starts: [n_pre][3] (EnvCfg::pre_tab)
   bool lpt = true;
@@ -790,23 +791,26 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   const int n = s->n_envs, nq = s->m.nq, nv = s->m.nv, w = nq + nv;
-  if (!s->d_init) {
-    HIPCHK(hipMalloc(&s->d_init, (size_t)n * w * 4)); HIPCHK(hipMalloc(&s->d_init_mask, n));
-    HIPCHK(hipMemset(s->d_init_mask, 0, n));
-  }
-  if (!qpos) { // set_init_qpos(None)
-    if (!mask) HIPCHK(hipMemset(s->d_init_mask, 0, n));
-    else for (int e = 0; e < n; e++) if (mask[e]) HIPCHK(hipMemset(s->d_init_mask + e, 0, 1));
+  if (!qpos) { // set_init_qpos(None): clears; allocates nothing
+    if (!s->d_init) return FSIM_OK;
+    for (int e = 0; e < n; e++) if (!mask || mask[e]) s->h_init_mask[e] = 0;
+    HIPCHK(hipMemcpy(s->d_init_mask, s->h_init_mask.data(), n, hipMemcpyHostToDevice));
     return FSIM_OK;
   }
   if (!qvel) FAIL(FSIM_EINVAL, "fsim_set_init_state: qvel missing");
+  if (!s->d_init) {
+    HIPCHK(hipMalloc(&s->d_init, (size_t)n * w * 4)); HIPCHK(hipMalloc(&s->d_init_mask, n));
+    HIPCHK(hipMemset(s->d_init_mask, 0, n));
+    s->h_init_mask.assign(n, 0);
+  }
   std::vector<float> row(w);
   for (int e = 0; e < n; e++) {
     if (mask && !mask[e]) continue;
     memcpy(row.data(), qpos + (size_t)e * nq, (size_t)nq * 4); memcpy(row.data() + nq, qvel + (size_t)e * nv, (size_t)nv * 4);
     HIPCHK(hipMemcpy(s->d_init + (size_t)e * w, row.data(), (size_t)w * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(s->d_init_mask + e, 1, 1));
+    s->h_init_mask[e] = 1;
   }
+  HIPCHK(hipMemcpy(s->d_init_mask, s->h_init_mask.data(), n, hipMemcpyHostToDevice));
   return FSIM_OK;
 }
 
@@ -1060,7 +1064,8 @@ extern "C" int fsim_step(fsim_t *s, const float *action, void *obs, float *rewar
 extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
   if (!s || n_pre < 0 || n_pre > 16 || (n_pre > 0 && !ids)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: bad arguments");
   const bool recipe = s->ecfg.has_recipe != 0 && conn_pairs != nullptr; // (no connector pairs: the list holds weld ids -- config.assembled)
-  if (n_pre > 0 && s->d_init) FAIL(FSIM_EINVAL, "fsim_set_preassembled: not combined with fsim_set_init_state");
+  if (n_pre > 0 && std::any_of(s->h_init_mask.begin(), s->h_init_mask.end(), [](uint8_t v) { return v != 0; }))
+    FAIL(FSIM_EINVAL, "fsim_set_preassembled: not combined with fsim_set_init_state (an env still has an init state set; clear it with qpos = NULL)");
   if (n_pre > 0 && recipe && !angles) FAIL(FSIM_EINVAL, "fsim_set_preassembled: recipe steps need their angles next to the connector pairs");
   std::vector<int> tab(3 * (size_t)n_pre, 0);
   for (int i = 0; i < n_pre; i++) {

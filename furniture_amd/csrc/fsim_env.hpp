@@ -1119,6 +1119,10 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // would leave nothing behind but ONE consumed pass of the env's reset-time RNG stream, so it is not executed -- the info
     // block tells the host to drop one draw instead (FSIM_INFO_NEEDS_TABLE = 2).  (The dense reward is computed on the reset
     // state by the reference, so the dense env keeps the in-step reset and its stream runs one draw behind after a failure.)
+    // Known one-episode deviation: the table already on the device is draw k+1, and it is what the reset below consumes, while
+    // the reference's post-failure episode starts from draw k+2 (its in-step reset took k+1).  The host drops k+2 and uploads
+    // k+3, so from the following episode on both streams agree again; only the placement of the episode right after an
+    // unstable step differs (same distribution).  Keeping two tables per env on the device would remove it.
     const bool skip_reset = cfg.auto_reset && !cfg.dense;
     if (!skip_reset) env_reset(c, &cfg, &io);
     if (c.lane == 0) { E[E_FAIL] = skip_reset ? 2 : 1; scal[SC_BAD] = 0; if (skip_reset) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; } }

@@ -34,6 +34,22 @@ def gather_observations(obs, reward, done, tag=0, stream=None, group=None):
             return gather_observations(obs, reward, done, tag=tag, group=group)
     w = dist.get_world_size(group)
     n, d = obs.shape
+    if obs.dtype == torch.bfloat16 and reward.dtype == torch.float32 and obs.is_contiguous():
+        # bf16 observation slab (BASELINE config 2's narrow slab): still ONE collective and persistent buffers -- the row is packed
+        # byte-wise as [obs bf16 x d | reward fp32 | done u8], half the bytes of the fp32 slab
+        key = (obs.device, n, d, w, tag, "bf16")
+        row = 2 * d + 5
+        if key not in _BUF:
+            _BUF[key] = (torch.empty((n, row), dtype=torch.uint8, device=obs.device), torch.empty((w * n, row), dtype=torch.uint8, device=obs.device),
+                         torch.empty((w * n, 2 * d), dtype=torch.uint8, device=obs.device), torch.empty((w * n, 4), dtype=torch.uint8, device=obs.device))
+        send, recv, o8, r8 = _BUF[key]
+        send[:, :2 * d] = obs.view(torch.uint8)
+        send[:, 2 * d:2 * d + 4] = reward.contiguous().view(torch.uint8).view(n, 4)
+        send[:, 2 * d + 4] = done.to(torch.uint8)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        o8.copy_(recv[:, :2 * d])
+        r8.copy_(recv[:, 2 * d:2 * d + 4])
+        return o8.view(torch.bfloat16), r8.view(torch.float32).view(w * n), recv[:, 2 * d + 4].to(done.dtype)
     if obs.dtype != torch.float32 or reward.dtype != torch.float32:
         out = []
         for t in (obs, reward, done):  # generic path: one collective per field

@@ -371,8 +371,9 @@ class FurnitureBatchEnv:
         self.sim.reset(None, self._obs)
         self.sim.sync()  # the reset kernel reads the tables: the next ones may only be uploaded once it has finished
         self._tables_fresh[:] = False
-        if self._auto_reset:
-            self._refill()  # tables for the first auto-reset
+        # the next draw of every env's stream goes to the device now: the in-kernel resets read it (the auto-reset of a terminal
+        # step; without auto_reset, the reset an unstable simulation triggers inside step(), furniture.py:2889-2897)
+        self._refill()
         return self._split(self._obs)
 
     def rng_handover(self):
@@ -408,6 +409,11 @@ class FurnitureBatchEnv:
                 need = self._info[:, INFO_NEEDS_TABLE].cpu().numpy()
                 self._tables_fresh[need > 0] = False
                 self._refill(need > 0, skip=need > 1)
+        if not self._auto_reset and bool((self._info[:, INFO_FAIL] != 0).any()):
+            # an unstable simulation reset the env inside step() and consumed the table on the device: upload the env's next draw
+            failed = (self._info[:, INFO_FAIL] != 0).cpu().numpy()
+            self._tables_fresh[failed] = False
+            self._refill(failed)
         info = self._info
         # a model whose contacts do not fit the 48 / 64 slots of a wavefront loses contacts silently otherwise: say so once
         self._steps_done = getattr(self, "_steps_done", 0) + 1

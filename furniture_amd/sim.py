@@ -227,9 +227,10 @@ class FSim:
         """config.preassembled / set_subtask (furniture.py:163, 204-207): weld ids (furniture without a recipe) or recipe step
         indices (with one) that every following reset starts from; num_connects as in config.num_connects.  welds=True: the list
         holds weld ids whatever the furniture (config.assembled: all of them)."""
-        ids, pairs, angles = preassembled_rows(self.cm, preassembled)
-        if welds:
-            pairs, angles = None, None
+        if welds:  # weld ids as they are: no recipe lookup (a furniture may have more welds than recipe steps)
+            ids, pairs, angles = np.ascontiguousarray(list(preassembled), dtype=np.int32), None, None
+        else:
+            ids, pairs, angles = preassembled_rows(self.cm, preassembled)
         self._chk(lib().fsim_set_preassembled(self._h, len(ids), ids.ctypes.data, pairs.ctypes.data if pairs is not None else None,
                                               angles.ctypes.data if angles is not None else None, -1 if num_connects is None else int(num_connects)))
 
@@ -320,6 +321,9 @@ class FSim:
         self._chk(lib().fsim_reset(self._h, None if mask is None else mask.data_ptr(), None if obs is None else obs.data_ptr()))
 
     def step(self, action, obs, reward, done, info):
+        """Enqueue one FurnitureEnv.step() of every env on the handle's stream (asynchronous).  sync() before the next step():
+        the counter tables_needed() reads lives in host memory and is cleared when a step is enqueued, so a second step enqueued
+        without a sync in between loses the first one's reset notifications."""
         self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
 
     def tables_needed(self):

@@ -86,3 +86,18 @@ def test_a_model_with_more_than_64_dofs_matches_the_oracle_env():
         assert np.abs(np.concatenate([ob["object_ob"], ob["robot_ob"]]) - orc.flat_obs(ob_o)).max() < 1e-3, t
         assert abs(r - r_o) < 1e-4 and done == done_o
     env.close()
+
+
+def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_steps():
+    """config.assembled switches every weld on (furniture.py:1502-1503): the weld ids go to the device as they are -- furniture whose
+    recipe has fewer steps than the model has welds (bench_bjursta_0210: 8 welds, 4 steps) used to die in the constructor."""
+    from furniture_amd.envs import make_vec_env
+    from furniture_amd.mjcf.model import load_compiled
+    for name in ("bench_bjursta_0210", "chair_ingolf_0650", "table_bjorkudden_0207", "table_lack_0825"):
+        m = load_compiled("Sawyer", name)
+        env = make_vec_env("Sawyer", 2, furniture_name=name, max_episode_steps=5, seed=3, record_vid=False, unity=False, control_type="impedance", assembled=True)
+        ob = env.reset()
+        assert ob["object_ob"].shape == (2, 7 * m.nparts)
+        act = env.sim.get_state("eq_active")["eq_active"]
+        assert int(act.sum()) == 2 * m.neq, name
+        env.close()

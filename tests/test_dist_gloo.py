@@ -37,6 +37,10 @@ def _worker(rank, world, port, q):
     assert g_done.tolist() == [i % 2 for i in range(world * per)]
     whole, _ = ResetTableSampler(m, cfg, 123, 0, world * per).draw()
     assert np.array_equal(g_obs.numpy(), whole[:, :8])  # 1-process and 2-process batches are identical per env
+    # bf16 observation slab: one byte-packed collective; the bf16 values, the fp32 rewards and the done flags arrive unchanged
+    b_obs, b_rew, b_done = gather_observations(obs.bfloat16(), rew + 0.125, done, tag=1)
+    assert b_obs.dtype == torch.bfloat16 and torch.equal(b_obs, torch.as_tensor(whole[:, :8]).float().bfloat16())
+    assert b_rew.tolist() == [i + 0.125 for i in range(world * per)] and b_done.tolist() == g_done.tolist()
     # the timing reduction bench.py uses: max over ranks
     t = torch.tensor([1.0 + rank])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

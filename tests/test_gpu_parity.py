@@ -591,6 +591,13 @@ def test_set_init_qpos_resets_from_the_given_state(sawyer_lack):
     o2 = orc.flat_obs(orc.reset())  # the second draw of the stream (the init-state resets took none)
     d2 = env.reset()
     assert np.abs(np.concatenate([d2["object_ob"], d2["robot_ob"]]) - o2).max() < 2e-4
+    # the reference's policy sequencing alternates set_init_qpos and set_subtask on one env: once the init state is cleared,
+    # pre-assembled starts must be accepted again (they used to be refused for the life of the handle)
+    env.set_subtask(1)
+    orc.set_subtask(1)
+    o3 = orc.flat_obs(orc.reset())
+    d3 = env.reset()
+    assert np.abs(np.concatenate([d3["object_ob"], d3["robot_ob"]])[:35:7] - o3[:35:7]).max() < 5e-3
     env.close()
 
 
