@@ -94,16 +94,20 @@ struct StepArgs {
   const uint8_t *init_mask;
   int *nreset;
 };
-template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, long long t_entry) {
+// load_cache: the wave's LDS copy of the model tables is not there yet (a bundled wave steps several envs one after the other
+// and loads it once)
+template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, long long t_entry, bool load_cache = true) {
   float *L = c.L;
   const int lane = c.lane;
   const EnvCfg &cfg = a.cfg;
   float *rec = a.state + (size_t)env * c.ly.stride;
   load_record(L, rec, c.ly.stride, lane);
+  const int twords = reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS]; // (set by fs_load_cache: survives the per-env clearing)
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
   SYNC();
-  fs_load_cache(c);
+  if (load_cache) fs_load_cache(c);
+  else { if (lane == 0) reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS] = twords; SYNC(); }
   EnvIO io;
   io.action = a.action ? a.action + (size_t)env * cfg.dof_action : nullptr;
   io.obs = a.obs ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4)) : nullptr;
@@ -153,11 +157,11 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_st
 
 // The step kernel proper: ONE launch of 4-wave workgroups.  Workgroups [0, mw_cap) are multi-wave envs (workgroup b steps env
 // mworder[b] with four waves if b < *mwn, else it leaves at once); every workgroup behind them is a BUNDLE of four one-wave envs
-// (wave w of bundle j steps env order[4 j + w] on its own LDS image; the four waves never synchronise).  Workgroups are
+// (each wave has its own LDS image; the four waves never synchronise).  Workgroups are
 // dispatched in index order, so the multi-wave envs -- the long jobs -- are placed first; with the two kinds in separate launches
 // the one-wave workgroups took every slot that freed up and the 4-wave ones starved until the others had all been dispatched.
 template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_env_step_x(const DModel *mp, const Layout *lp, const Layout *lp_mw, KParams kp, StepArgs a,
-                                                                                           const int *order, const int *nbulk, const int *mworder, const int *mwn, int mw_cap) {
+                                                                                           const int *order, const int *nbulk, const int *mworder, const int *mwn, int mw_cap, int *qhead) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
@@ -168,10 +172,17 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
     if (c.wave > 0) { mw_helper_loop(c); return; }
     env_run(c, a, mworder[b], t_entry);
   } else {
-    const int slot = 4 * (b - mw_cap) + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (slot >= *nbulk) return;
+    // bundled waves are persistent: each takes the next env of the longest-job-first list from a device-wide queue until it is
+    // empty (a workgroup's LDS is only released when its last wave ends, so fixed bundles would idle behind their slowest env)
     const CtxB c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
-    env_run(c, a, order[slot], t_entry);
+    const int nb = *nbulk;
+    for (bool first = true;; first = false) {
+      int slot = 0;
+      if (c.lane == 0) slot = atomicAdd(qhead, 1);
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      if (slot >= nb) break;
+      env_run(c, a, order[slot], first ? t_entry : clock64(), first);
+    }
   }
 }
 
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
       }
     }
     nsel = min(base, mw_cap);
-    if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; }
+    if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; nbulk[1] = 0; } // (nbulk[1]: head of the bundled waves' work queue)
   }
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
   int lm = 0;
@@ -292,7 +303,7 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *);
-typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, const int *, const int *, int);
+typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, const int *, const int *, int, int *);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
 struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 
@@ -309,7 +320,8 @@ struct fsim {
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
   uint8_t *d_mwsel = nullptr;
-  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others
+  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others, d_mwn[2] = work-queue head
+  int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   DModel m{};
   Layout ly{};
   fsim_config_t cfg{};
@@ -559,12 +571,16 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (s->lds_bytes_mw > 160 * 1024) s->mw_mode = 0;
     // bundles of four keep today's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
     if (s->mw_mode == 1 && 2 * s->lds_bytes_x > 160 * 1024) s->mw_mode = 0;
+    // a launch with many rounds of envs per wave slot is bound by throughput, not by its slowest env: four waves per env cost
+    // slots there (Sawyer + swivel_chair at 8192 envs: 1.03 M env-steps/s on the one-wave kernel, 0.95 M with the default rule)
+    if (s->mw_mode == 1 && n_envs > 4096 && !getenv("FSIM_MW")) s->mw_mode = 0;
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_x), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
-      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 8));
-      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 8));
+      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 16));
+      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 16));
+      { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, device)); s->x_resident = 2 * pr.multiProcessorCount; }
     }
   }
   HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
@@ -833,8 +849,8 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (mw_all)
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr);
   else if (mw_auto)
-    hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->mw_cap + (s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream, s->d_m, s->d_ly,
-                       s->d_ly_mw, kp, a, s->d_order, s->d_mwn + 1, s->d_mworder, s->d_mwn, s->mw_cap);
+    hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->mw_cap + std::min((s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW, s->x_resident)), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
+                       s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mwn + 1, s->d_mworder, s->d_mwn, s->mw_cap, s->d_mwn + 2);
   else
     hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr);
   hipError_t e = hipGetLastError();
