@@ -195,38 +195,42 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
 // ONE wavefront with a few registers: the kernel runs between two step kernels of its stream while the other slab's step kernel
 // holds every SIMD's register file (2 x 256 VGPRs) -- a 1024-thread workgroup had to wait ~0.2 ms for a whole CU to drain
 // before it could start (rocprofv3: 217 us average for 10 us of work), a single small wave takes the first slot that frees.
-// Multi-wave selection (mwsel != null): env i goes to the multi-wave kernel of this launch iff its last step took at least mw_k
+// Multi-wave selection (use_mw): env i goes to the multi-wave workgroups of this launch iff its last step took at least mw_k
 // Newton iterations (E_NITER of its record: a function of the env's state, never of timing, so results do not depend on the
-// schedule), the first mw_cap such envs in index order; the one-wave kernel skips them.
-__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int mw_cap,
-                                                uint8_t *mwsel, int *mworder, int *mwn, int *nbulk) {
+// schedule), the first mw_cap such envs in index order -> mworder / *mwn; `order` / *nbulk then list the others.
+// The kernel is one latency chain (it sits between two step kernels of its stream): the keys are fetched once, eight loads in
+// flight per lane, and kept in LDS for the sorting passes (208 us -> ~20 us for 2048 envs).
+#define FSIM_SCHED_SELECTED ((int)0x80000000)
+__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int mw_cap, int use_mw,
+                                                int *mworder, int *mwn, int *nbulk) {
+  extern __shared__ int keys[]; // [n]
   __shared__ int hist[257];
   const int tid = threadIdx.x;
-  int nsel = 0;
-  if (mwsel) {
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-      int v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int i = i0 + 64 * u + tid; v[u] = i < n ? state[(size_t)i * stride + niter_off] : -0x7fffffff; }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + 64 * u + tid;
-        const bool sel = i < n && v[u] >= mw_k;
-        const unsigned long long mask = __ballot(sel);
-        const int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
-        const bool take = sel && idx < mw_cap;
-        if (i < n) mwsel[i] = take ? 1 : 0; // (lane tid handles the envs i = tid mod 64 in every loop of this kernel: it re-reads its own stores)
-        if (take) mworder[idx] = i;
-        base += __popcll(mask);
-      }
-    }
-    nsel = min(base, mw_cap);
-    if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; nbulk[1] = 0; } // (nbulk[1]: head of the bundled waves' work queue)
-  }
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
-  int lm = 0;
-  for (int i = tid; i < n; i += 64) { int cv = cost[i]; if (cv >= 0) lm = max(lm, cv & 0x3fffffff); }
+  int base = 0, lm = 0;
+  for (int i0 = 0; i0 < n; i0 += 512) {
+    int cv[8], v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 64 * u + tid;
+      cv[u] = i < n ? cost[i] : -1;
+      v[u] = (use_mw && i < n) ? state[(size_t)i * stride + niter_off] : -0x7fffffff;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 64 * u + tid;
+      const bool sel = i < n && v[u] >= mw_k;
+      const unsigned long long mask = __ballot(sel);
+      const int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
+      const bool take = sel && idx < mw_cap;
+      if (take) mworder[idx] = i;
+      base += __popcll(mask);
+      if (i < n) keys[i] = take ? FSIM_SCHED_SELECTED : cv[u];
+      if (i < n && !take && cv[u] >= 0) lm = max(lm, cv[u] & 0x3fffffff);
+    }
+  }
+  const int nsel = min(base, mw_cap);
+  if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; nbulk[1] = 0; } // (nbulk[1]: head of the bundled waves' work queue)
   for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
   __syncthreads();
   const long long M = (long long)lm + 1;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
     int base = (cv >> 30) & 1 ? 1 : 129;
     return base + 127 - (int)((long long)(cv & 0x3fffffff) * 128 / M);
   };
-  for (int i = tid; i < n; i += 64) if (!mwsel || !mwsel[i]) atomicAdd(&hist[bucket(cost[i])], 1);
+  for (int i = tid; i < n; i += 64) { const int cv = keys[i]; if (cv != FSIM_SCHED_SELECTED) atomicAdd(&hist[bucket(cv)], 1); }
   __syncthreads();
   { // exclusive prefix sum over the 257 buckets: five consecutive buckets per lane, wave scan of the lane totals
     int h[5], tot = 0;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
     for (int k = 0; k < 5; k++) { const int b = 5 * tid + k; if (b < 257) hist[b] = acc; acc += h[k]; }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 64) if (!mwsel || !mwsel[i]) order[atomicAdd(&hist[bucket(cost[i])], 1)] = i;
+  for (int i = tid; i < n; i += 64) { const int cv = keys[i]; if (cv != FSIM_SCHED_SELECTED) order[atomicAdd(&hist[bucket(cv)], 1)] = i; }
 }
 
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays
@@ -319,7 +323,6 @@ struct fsim {
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
-  uint8_t *d_mwsel = nullptr;
   int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others, d_mwn[2] = work-queue head
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   DModel m{};
@@ -573,13 +576,17 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (s->mw_mode == 1 && 2 * s->lds_bytes_x > 160 * 1024) s->mw_mode = 0;
     // a launch with many rounds of envs per wave slot is bound by throughput, not by its slowest env: four waves per env cost
     // slots there (Sawyer + swivel_chair at 8192 envs: 1.03 M env-steps/s on the one-wave kernel, 0.95 M with the default rule)
-    if (s->mw_mode == 1 && n_envs > 4096 && !getenv("FSIM_MW")) s->mw_mode = 0;
+    // -- rule: more envs than the chip has wave slots (8 per CU) -> one-wave kernel
+    if (s->mw_mode == 1 && !getenv("FSIM_MW")) {
+      hipDeviceProp_t pr;
+      HIPCHK(hipGetDeviceProperties(&pr, device));
+      if (n_envs > 8 * pr.multiProcessorCount) s->mw_mode = 0;
+    }
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_x), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
-      HIPCHK(hipMalloc(&s->d_mwsel, n_envs)); HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 16));
-      HIPCHK(hipMemset(s->d_mwsel, 0, n_envs)); HIPCHK(hipMemset(s->d_mwn, 0, 16));
+
       { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, device)); s->x_resident = 2 * pr.multiProcessorCount; }
     }
   }
@@ -597,6 +604,11 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   *s->h_nreset = 0;
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_nreset), s->h_nreset, 0));
   s->lpt = !getenv("FSIM_NO_LPT");
+  HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 16));
+  HIPCHK(hipMemset(s->d_mwn, 0, 16));
+  if ((size_t)n_envs * 4 > 150 * 1024) s->lpt = false; // (the scheduler keeps one key per env in LDS)
+  else if ((size_t)n_envs * 4 > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_schedule), hipFuncAttributeMaxDynamicSharedMemorySize, n_envs * 4));
+  if (!s->lpt && s->mw_mode == 1) s->mw_mode = 0;
   // initial record: qpos0, default masks, weld data, env block zero
   {
     std::vector<float> rec(s->ly.stride, 0.0f), q0, ed;
@@ -653,7 +665,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_ly_mw); hipFree(s->d_mwsel); hipFree(s->d_mworder); hipFree(s->d_mwn);
+  hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -837,8 +849,8 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
   const bool mw_auto = sched && s->mw_mode == 1, mw_all = s->mw_mode == 2;
   if (sched)
-    hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), 0, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
-                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? s->d_mwsel : nullptr, s->d_mworder, s->d_mwn, s->d_mwn + 1);
+    hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), (size_t)s->n_envs * 4, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
+                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? 1 : 0, s->d_mworder, s->d_mwn, s->d_mwn + 1);
   if (s->timing) timing_begin(s);
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
   StepArgs a;

@@ -74,30 +74,117 @@ def furniture_names():
         return [x.strip() for x in f if x.strip()]
 
 
+_HOSTLIB = None
+
+
+def _host_lib():
+    """libfsim_host.so (csrc/fsim_host.c, plain C): the reset-time RNG stream for many envs per call.  None if it is not built --
+    the sampler then runs its per-env Python loop (same stream, 100x slower)."""
+    global _HOSTLIB
+    if _HOSTLIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfsim_host.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.fsim_host_reset_draw.restype = ctypes.c_int
+            lib.fsim_host_seed.restype = None
+            lib.fsim_host_seed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            lib.fsim_host_reset_draw.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+            _HOSTLIB = lib
+        except OSError:
+            _HOSTLIB = False
+    return _HOSTLIB or None
+
+
 class ResetTableSampler:
     """Per-env replay of the reference's reset-time RNG stream (``self._rng = RandomState(seed)``, furniture.py:72):
     UniformRandomSampler.sample() draws (tasks/placement_sampler.py:138-190) followed by the 101 joint-noise draws of
     _initialize_robot_pos() (furniture.py:1761-1779 called at :1580 and 100x at :1606-1611).  Env i of the global batch
-    is seeded seed + i (furniture/env/base.py:77), independent of how the batch is split over GPUs."""
+    is seeded seed + i (furniture/env/base.py:77), independent of how the batch is split over GPUs.
+
+    Two implementations of the same stream: ``draw()`` hands the whole batch to libfsim_host.so (MT19937 states kept as a
+    [n, 625] array, ~1 ms for 4096 envs); the per-env Python loop over ``RandomState`` objects (``_draw_python``) is what the golden
+    test pins against the reference's own sampler and what runs when the C helper is not built.  Touching ``.rngs`` / ``.hist``
+    (the furniture switch of reset(furniture_id) hands the generators on) moves the sampler to the Python objects for good."""
 
     def __init__(self, model, cfg, seed, first_env_index, n_envs, env_indices=None):
         """env_indices: explicit global env index per row (mixed-furniture batches own non-contiguous lanes)."""
         self.m, self.cfg = model, cfg
         idx = [first_env_index + i for i in range(n_envs)] if env_indices is None else [int(i) for i in env_indices]
         assert len(idx) == n_envs
-        self.rngs = [np.random.RandomState(seed + i) for i in idx]
-        self.hist = [[] for _ in idx]  # RNG states before each of the last draws (rng_handover rolls unconsumed draws back)
+        self._native = _host_lib() is not None and all(0 <= seed + i < 2 ** 32 for i in idx)
+        # (native: the generators exist as state rows; the Python objects are only made when somebody asks for them)
+        self._rngs = [None] * n_envs if self._native else [np.random.RandomState(seed + i) for i in idx]
+        self._seeds = [seed + i for i in idx]
+        self._hist = [[] for _ in idx]  # RNG states before each of the last draws (rng_handover rolls unconsumed draws back)
         self._fixed = [None] * n_envs  # config.fix_init (furniture.py:1518-1525): the first placement of an env is kept for its later resets
         self.narm = len(model.arm_qposadr)
+        if self._native:
+            self._mt = np.empty((n_envs, 625), dtype=np.uint32)
+            sd = np.ascontiguousarray(self._seeds, dtype=np.uint32)
+            _host_lib().fsim_host_seed(self._mt.ctypes.data, n_envs, sd.ctypes.data)
+            self._mt_hist = np.zeros((3, n_envs, 625), dtype=np.uint32)  # states before the last three draws of every env
+            self._mt_nhist = np.zeros(n_envs, dtype=np.int64)
+            self._placed = np.zeros(n_envs, dtype=bool)
+            self._xy = np.zeros((n_envs, model.nparts, 2))
+
+    # -- the generators as Python objects (leaves the native path) ---------------------------------------------------------
+    def _to_python(self):
+        if not self._native:
+            return
+        self._native = False
+        for i in range(len(self._rngs)):
+            r = self._rngs[i] = np.random.RandomState(0)
+            r.set_state(("MT19937", self._mt[i, :624].copy(), int(self._mt[i, 624]), 0, 0.0))
+            c = int(self._mt_nhist[i])  # draws so far; the ring holds the states before the last min(c, 3) of them, oldest first below
+            self._hist[i] = [("MT19937", self._mt_hist[d % 3, i, :624].copy(), int(self._mt_hist[d % 3, i, 624]), 0, 0.0) for d in range(max(0, c - 3), c)]
+            if self._placed[i]:
+                self._fixed[i] = self._full_placement(self._xy[i]).reshape(-1)
+
+    @property
+    def rngs(self):
+        self._to_python()
+        return self._rngs
+
+    @rngs.setter
+    def rngs(self, v):
+        self._to_python()
+        self._rngs = list(v)
+
+    @property
+    def hist(self):
+        self._to_python()
+        return self._hist
+
+    @hist.setter
+    def hist(self, v):
+        self._to_python()
+        self._hist = v
+
+    def _quats(self):
+        if getattr(self, "_quat_cache", None) is None:
+            # reference quirk: uniform(high=rot_hi, low=rot_hi) is the constant rot_hi (one draw is still consumed), so the
+            # per-part orientation does not depend on the stream
+            rot_hi = max(-self.cfg.furn_rot_rand, self.cfg.furn_rot_rand)
+            self._quat_cache = [list(T.euler_to_quat([rot_hi, 0, 0], self.m.part_initqpos[i][3:7])) for i in range(self.m.nparts)]
+        return self._quat_cache
+
+    def _full_placement(self, xy):
+        """[nparts, 7] part poses from the sampled x / y (z = the XML height + 1 cm, the constant orientation)"""
+        m = self.m
+        out = np.zeros((m.nparts, 7))
+        out[:, :2] = xy
+        out[:, 2] = np.asarray(m.part_initqpos)[:, 2] + 0.01
+        out[:, 3:7] = np.asarray(self._quats())
+        return out
 
     def _placement(self, rng):
         m, r = self.m, self.cfg.furn_xyz_rand
         lo, hi = min(-r, r), max(-r, r)
         rot_hi = max(-self.cfg.furn_rot_rand, self.cfg.furn_rot_rand)
-        if getattr(self, "_quat_cache", None) is None:
-            # reference quirk: uniform(high=rot_hi, low=rot_hi) is the constant rot_hi (one draw is still consumed), so the
-            # per-part orientation does not depend on the stream
-            self._quat_cache = [list(T.euler_to_quat([rot_hi, 0, 0], m.part_initqpos[i][3:7])) for i in range(m.nparts)]
+        quats = self._quats()
         out = np.zeros((m.nparts, 7))
         placed = []
         uni = rng.uniform
@@ -110,7 +197,7 @@ class ResetTableSampler:
                 if all(math.hypot(x - px, y - py) > pr + rad for px, py, pr in placed):
                     uni(high=rot_hi, low=rot_hi)
                     out[i, 0], out[i, 1], out[i, 2] = x, y, base[2] + 0.01
-                    out[i, 3:7] = self._quat_cache[i]
+                    out[i, 3:7] = quats[i]
                     placed.append((x, y, rad))
                     break
             else:
@@ -119,13 +206,49 @@ class ResetTableSampler:
 
     def draw(self, mask=None):
         """(part_qpos [n, nparts*7], robot_noise [n, 101*narm]) for the envs selected by mask (others zero)."""
-        n = len(self.rngs)
+        return self._draw_native(mask) if self._native else self._draw_python(mask)
+
+    def _draw_native(self, mask):
+        m, cfg = self.m, self.cfg
+        n = len(self._rngs)
+        sel = np.ones(n, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        # the states before this draw (rng_handover rolls draws back that no reset consumed)
+        idx = np.nonzero(sel)[0]
+        self._mt_hist[self._mt_nhist[idx] % 3, idx] = self._mt[idx]  # ring of three per env: slot (draw count) mod 3
+        self._mt_nhist[idx] += 1
+        place = sel & ~(self._placed if getattr(cfg, "fix_init", False) else np.zeros(n, dtype=bool))
+        r = cfg.furn_xyz_rand
+        lo, hi = min(-r, r), max(-r, r)
+        rot_hi = max(-cfg.furn_rot_rand, cfg.furn_rot_rand)
+        base = np.ascontiguousarray(np.asarray(m.part_initqpos, dtype=np.float64)[:, :2])
+        rad = np.ascontiguousarray(np.asarray(m.part_hradius, dtype=np.float64).reshape(-1))
+        n_noise = N_NOISE * self.narm
+        noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
+        dm, pm = np.ascontiguousarray(sel.astype(np.uint8)), np.ascontiguousarray(place.astype(np.uint8))
+        rc = _host_lib().fsim_host_reset_draw(self._mt.ctypes.data, n, dm.ctypes.data, pm.ctypes.data, m.nparts, base.ctypes.data, rad.ctypes.data, lo, hi, rot_hi,
+                                              n_noise, float(cfg.agent_xyz_rand), self._xy.ctypes.data, noise.ctypes.data)
+        if rc:
+            raise RuntimeError("Cannot place all objects on the desk")
+        self._placed |= place
+        parts = np.zeros((n, m.nparts * 7), dtype=np.float32)
+        if getattr(cfg, "assembled", False):  # furniture.py:1526-1530: the parts stay at the XML's assembled poses; the draw is still taken
+            parts[sel] = np.asarray(m.part_initqpos, dtype=np.float64).reshape(-1)
+        else:
+            full = np.zeros((n, m.nparts, 7))
+            full[:, :, :2] = self._xy
+            full[:, :, 2] = np.asarray(m.part_initqpos)[:, 2] + 0.01
+            full[:, :, 3:7] = np.asarray(self._quats())
+            parts[sel] = full.reshape(n, -1)[sel]
+        return parts, noise
+
+    def _draw_python(self, mask=None):
+        n = len(self._rngs)
         parts = np.zeros((n, self.m.nparts * 7), dtype=np.float32)
         noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
-        for i, rng in enumerate(self.rngs):
+        for i, rng in enumerate(self._rngs):
             if mask is not None and not mask[i]:
                 continue
-            self.hist[i] = self.hist[i][-2:] + [rng.get_state()]
+            self._hist[i] = self._hist[i][-2:] + [rng.get_state()]
             if getattr(self.cfg, "fix_init", False) and self._fixed[i] is not None:
                 placement = self._fixed[i]  # (no placement draw: _place_objects is not called again)
             else:

@@ -67,7 +67,16 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_host(verbose)
     return _LIBPATH
+
+
+def build_host(verbose=False):
+    """libfsim_host.so: plain-C host helper of the env layer (the reference's reset-time RNG stream for a whole batch per call)."""
+    cmd = ["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", os.path.join(_CSRC, "libfsim_host.so"), os.path.join(_CSRC, "fsim_host.c"), "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
 
 
 def lib():
