@@ -32,7 +32,21 @@ def _check(frames_parts, frames_cursor, connected_at):
     assert abs(rec_p[61, 1, 2] - 0.0720) < 2e-4 and abs(frames_parts[-1, 1, 2] - 0.0720) < 5e-4
 
 
-def test_oracle_replays_mujoco_recorded_cursor_demo():
+def _check_ext(frames_parts, frames_cursor):
+    """frames 62-91: one cursor carries the welded column + seat about, the base stays where it is"""
+    rec_p, rec_c = D["parts_ext"], np.concatenate([D["cursor0_ext"], D["cursor1_ext"]], axis=1)
+    n = len(rec_p)
+    assert np.abs(frames_cursor - rec_c[1:n]).max() < 1e-6
+    dp = frames_parts[61:, :, :3] - rec_p[62:n, :, :3]
+    assert np.abs(dp[:, 0]).max() < 5e-4                                          # the base
+    assert np.abs(dp[:, 1]).max() < 2.5e-3                                        # the column, carried (x, y, z)
+    assert np.abs(dp[:, 2, :2]).max() < 2.5e-3 and np.abs(dp[:, 2, 2]).max() < 1.2e-2  # the seat on it (height: asset revision offset)
+    assert np.abs(rec_p[91, 1, :3] - rec_p[62, 1, :3]).max() > 0.1                # (the recording: it is carried more than 10 cm)
+    dq = np.minimum(np.abs(frames_parts[61:, :, 3:] - rec_p[62:n, :, 3:]), np.abs(frames_parts[61:, :, 3:] + rec_p[62:n, :, 3:]))
+    assert dq.max() < 6e-3
+
+
+def _replay_oracle(actions):
     from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
     m = load_compiled("Cursor", "swivel_chair_0700")
     assert list(m.meta["part_names"]) == [str(x) for x in D["part_names"]]
@@ -46,13 +60,23 @@ def test_oracle_replays_mujoco_recorded_cursor_demo():
     env.sim.forward()
     env._cursor_selected = [None, None]
     P, C, connected_at = [], [], None
-    for t, a in enumerate(D["actions"]):
+    for t, a in enumerate(actions):
         ob, r, done, info = env.step(a)
         P.append([env._part_qpos(i) for i in range(m.nparts)])
         C.append(np.concatenate([env._cursor_pos(0), env._cursor_pos(1)]))
         if info["connected_this_step"] and connected_at is None:
             connected_at = t
-    _check(np.array(P), np.array(C), connected_at)
+    return np.array(P), np.array(C), connected_at
+
+
+def test_oracle_replays_mujoco_recorded_cursor_demo():
+    _check(*_replay_oracle(D["actions"]))
+
+
+def test_oracle_carries_the_connected_parts_as_recorded():
+    P, C, connected_at = _replay_oracle(D["actions_ext"])
+    assert connected_at == 60
+    _check_ext(P, C)
 
 
 @pytest.mark.gpu
@@ -87,7 +111,7 @@ def test_device_replays_mujoco_recorded_cursor_demo():
     done = torch.zeros(n, dtype=torch.uint8, device=dev)
     info = torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
     P, C, connected_at = [], [], None
-    for t, a in enumerate(D["actions"]):
+    for t, a in enumerate(D["actions_ext"]):
         act.copy_(torch.as_tensor(np.tile(a.astype(np.float32), (n, 1))))
         torch.cuda.synchronize()
         sim.step(act, obs, rew, done, info)
@@ -97,6 +121,7 @@ def test_device_replays_mujoco_recorded_cursor_demo():
         C.append(ob[7 * m.nparts:7 * m.nparts + 6])
         if int(info[0, 6]) and connected_at is None:
             connected_at = t
-    _check(np.array(P), np.array(C), connected_at)
+    _check(np.array(P)[:61], np.array(C)[:61], connected_at)
+    _check_ext(np.array(P), np.array(C))  # frames 62-91: the welded column + seat carried about
     assert torch.equal(obs[0], obs[1])
     sim.close()
