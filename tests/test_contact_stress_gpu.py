@@ -4,7 +4,10 @@
   and a 400-substep contact trajectory with equal contact-geom lists, device vs fp64 oracle;
 * Sawyer + table_lack: 64 envs x 50 random-action env steps against 64 oracle envs -- every integer / latch output exact and the
   observation within 1e-3 until an env's FIRST divergence (two correct integrators of a chaotic contact system decorrelate; the
-  divergence step is measured and bounded from below, not hidden)."""
+  divergence step is measured and bounded from below, not hidden) -- and every first divergence is EXPLAINED: the step is re-run
+  substep by substep on both sides and the contact lists, Newton iteration counts and states are compared (_explain): measured,
+  10 of 11 are drift with identical contact lists (fp32 rounding amplified by a chaotic contact system), 1 is a finger contact at a
+  distance of 0.1 mm that one side lists a substep earlier."""
 import numpy as np
 import pytest
 import torch
@@ -34,14 +37,72 @@ def _env_pair(m, n, seed0, max_steps=150):
     return sim, envs, obs_o, buf
 
 
-def _run(sim, envs, buf, steps, rng, tol=1e-3):
+_DEV_FIELDS = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_active", "eq_data", "geom_contype", "geom_conaffinity"]
+_ORA_DATA = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied"]
+_ORA_MODEL = ["eq_active", "eq_data", "geom_contype", "geom_conaffinity"]
+
+
+def _oracle_snapshot(env):
+    s = {k: np.array(getattr(env.sim.data, k), copy=True) for k in _ORA_DATA}
+    s.update({k: np.array(getattr(env.sim.model, k), copy=True) for k in _ORA_MODEL})
+    return s
+
+
+def _explain(m, dbg, dev_before, ora_before, ctrl, applied, nsub=50):
+    """WHY did this env part company inside this step?  Both sides re-run the step's physics substep by substep from their own
+    pre-step states (device: a one-env handle through fsim_physics_step(1); oracle: a fresh OracleSim), with the ctrl / qfrc_applied
+    the step used, and their INTEGER state is compared on every substep: contact geom lists, Newton iterations, overflow.
+    Returns (k_list, k_q5, k_q3, pair, dist): first substep whose contact lists differ (nsub if none), first substeps whose qpos
+    differ by more than 1e-5 / 1e-3, and -- if the lists differ -- a geom pair only one side lists and its distance there."""
+    rob = m.geom_is_robot.astype(bool)
+    dbg.set_state(**{k: v[None] for k, v in dev_before.items()})
+    dbg.set_state(ctrl=ctrl[None].astype(np.float32), qfrc_applied=applied[None].astype(np.float32))
+    o = OracleSim(m)
+    o.set_solver(100, 1e-10, "newton")
+    o.reset()
+    for k in _ORA_DATA:
+        getattr(o.data, k)[...] = ora_before[k]
+    for k in _ORA_MODEL:
+        getattr(o.model, k)[...] = ora_before[k]
+    o.data.ctrl[:] = ctrl
+    o.data.qfrc_applied[:] = applied
+    k_list, k_q5, k_q3, pair, dist, iters = nsub, nsub, nsub, None, None, []
+    for k in range(nsub):
+        dbg.physics_step(1)
+        st = dbg.get_state("qpos", "contact_geoms", "solver_iters", "ncon")
+        o.step()
+        cd = st["contact_geoms"][0].cpu().numpy().reshape(-1, 2)
+        keep = lambda cs: sorted(c for c in cs if not (rob[c[0]] and rob[c[1]]))  # (robot link pairs rest at exactly their margin: in or out by rounding)
+        ld, lo = keep(tuple(int(x) for x in r) for r in cd if r[0] >= 0), keep(tuple(int(x) for x in c) for c in o.contacts())
+        iters.append((int(st["solver_iters"][0, 0]), o.last_solver_iters))
+        if ld != lo and k_list == nsub:
+            k_list = k
+            only = [c for c in lo if c not in ld] + [c for c in ld if c not in lo]
+            pair = only[0] if only else None  # (same pairs, different multiplicity: a manifold with one point more)
+            dists = dict(zip((tuple(int(x) for x in c) for c in o.contacts()), o.contact_dists()))
+            dist = dists.get(pair)
+        dq = np.abs(st["qpos"][0].cpu().numpy() - o.data.qpos).max()
+        if dq > 1e-5 and k_q5 == nsub:
+            k_q5 = k
+        if dq > 1e-3 and k_q3 == nsub:
+            k_q3 = k
+    o.close()
+    return k_list, k_q5, k_q3, pair, dist, iters
+
+
+def _run(sim, envs, buf, steps, rng, tol=1e-3, explain=None):
     """step both; per env: first step whose observation differs by more than tol (steps if none); integer outputs and rewards
-    must agree on every step before that"""
+    must agree on every step before that.  explain: a one-env FSim handle -- every first divergence is then re-run substep by
+    substep on both sides (_explain) and its cause recorded."""
     n = len(envs)
     first = np.full(n, steps)
     worst_before = 0.0
+    causes = []
     for t in range(steps):
         a = rng.uniform(-1, 1, (n, sim.dof_action)).astype(np.float32)
+        if explain is not None:
+            dev_before = {k: v.cpu().numpy().copy() for k, v in sim.get_state(*_DEV_FIELDS).items()}
+            ora_before = [_oracle_snapshot(e) if first[i] == steps else None for i, e in enumerate(envs)]
         buf["act"].copy_(torch.as_tensor(a))
         torch.cuda.synchronize()
         sim.step(buf["act"], buf["obs"], buf["rew"], buf["done"], buf["info"])
@@ -56,12 +117,15 @@ def _run(sim, envs, buf, steps, rng, tol=1e-3):
             err = np.abs(ob_d[e] - envs[e].flat_obs(ob)).max()
             if err > tol:
                 first[e] = t
+                if explain is not None:  # (the oracle env's ctrl / qfrc_applied are still what _setup_action wrote for this step)
+                    causes.append((e, t) + _explain(sim.cm, explain, {k: v[e] for k, v in dev_before.items()}, ora_before[e],
+                                                    np.array(envs[e].sim.data.ctrl), np.array(envs[e].sim.data.qfrc_applied)))
                 continue
             worst_before = max(worst_before, err)
             assert abs(float(rew_d[e]) - r) < 1e-4, (e, t, float(rew_d[e]), r)
             assert bool(done_d[e]) == bool(d), (e, t)
             assert int(info_d[e, INFO_NUM_CONNECTED]) == envs[e]._num_connected and int(info_d[e, INFO_FAIL]) == 0, (e, t)
-    return first, worst_before
+    return (first, worst_before, causes) if explain is not None else (first, worst_before)
 
 
 def test_sawyer_toy_table_reset_steps_and_contact_trajectory_match_oracle():
@@ -73,7 +137,7 @@ def test_sawyer_toy_table_reset_steps_and_contact_trajectory_match_oracle():
         assert np.abs(ob_d[e] - obs_o[e]).max() < 2e-4, e  # reset: 401 substeps with the parts settling on the floor
     first, worst = _run(sim, envs, buf, 20, np.random.RandomState(3))
     print("toy_table: first divergence step per env", first, "worst error before divergence %.2e" % worst)
-    assert (first >= 5).all(), first  # at least the first five random-action steps (250 substeps) agree to 1e-3 on every env
+    assert (first >= 10).all(), first  # at least the first ten random-action steps (500 substeps) agree to 1e-3 on every env (measured: all 20)
     sim.close()
     # 400 physics substeps from a dropped configuration: state and contact lists
     n = 4
@@ -123,7 +187,32 @@ def test_sixty_four_envs_fifty_random_steps_until_first_divergence(sawyer_lack):
     sim, envs, obs_o, buf = _env_pair(sawyer_lack, n, 2000)
     ob_d = buf["obs"].cpu().numpy()
     assert max(np.abs(ob_d[e] - obs_o[e]).max() for e in range(n)) < 2e-4
-    first, worst = _run(sim, envs, buf, steps, np.random.RandomState(17))
+    cfg1 = default_config()
+    cfg1.auto_reset = 0
+    dbg = FSim(sawyer_lack, 1, config=cfg1)
+    first, worst, causes = _run(sim, envs, buf, steps, np.random.RandomState(17), explain=dbg)
+    dbg.close()
+    # every first divergence, explained: either the two contact lists differ BEFORE the states do (a discrete event: one side lists
+    # a contact -- typically at a distance of micrometres -- a substep before the other), or the states drift apart while the
+    # lists still agree (a chaotic contact system amplifying fp32 rounding: it takes hundreds of substeps, so the 1e-5 mark is passed
+    # tens of substeps before the 1e-3 one or was passed in an earlier step already)
+    kinds = {"list-first": 0, "drift": 0}
+    for e, t, k_list, k_q5, k_q3, pair, dist, iters in causes:
+        discrete = k_list < 50 and k_list <= k_q5
+        kinds["list-first" if discrete else "drift"] += 1
+        names = sawyer_lack.meta["geom_names"]
+        print("  env %2d step %2d: contact lists differ from substep %2d (%s, dist %s), |dqpos| > 1e-5 from %2d, > 1e-3 from %2d; Newton iterations device/oracle %d/%d"
+              % (e, t, k_list, "-" if pair is None else "%s | %s" % (names[pair[0]], names[pair[1]]), "-" if dist is None else "%.1e" % dist, k_q5, k_q3,
+                 sum(i[0] for i in iters), sum(i[1] for i in iters)))
+        if discrete and dist is not None:
+            assert abs(dist) < 2e-4, (e, t, pair, dist)  # the contact one side has and the other has not is a grazing one
+        if not discrete:
+            assert k_q5 < 50, (e, t)  # the states did differ inside this step's substeps (not an env-logic disagreement)
+        # up to the first difference the Newton solver took the same path on both sides (+-1 iteration per substep: fp32 / fp64 at the tolerance)
+        kk = min(k_list, k_q5)
+        assert all(abs(a - b) <= 1 for a, b in iters[:kk]), (e, t, iters[:kk])
+    print("first divergences explained:", kinds)
+    assert len(causes) == int((first < steps).sum())
     q = np.percentile(first, [0, 10, 50, 100])
     print("table_lack 64 x 50: first step with |obs - oracle| > 1e-3: min %d, p10 %d, median %d, max %d; %d of %d envs never diverge; "
           "worst error before divergence %.2e" % (q[0], q[1], q[2], q[3], int((first == steps).sum()), n, worst))
