@@ -415,7 +415,6 @@ static int build_model(fsim *s) {
   m.timestep = opt[0]; m.gravity[0] = opt[1]; m.gravity[1] = opt[2]; m.gravity[2] = opt[3]; m.impratio = opt[4];
   m.meaninertia_scale = 1.0f / fmaxf(trace[0], 1e-15f);
   if (m.nv > 128) FAIL(FSIM_ENOMEM, "nv=%d > 128: the Newton factorisation maps the dofs on two passes of 64 solver lanes", m.nv);
-  if (m.nparts > 10) FAIL(FSIM_ENOMEM, "%d furniture parts: with more than 10 parts the contacts at rest (4 per part on the floor plus part-part contacts) exceed the 64 contact slots one wavefront scans", m.nparts);
   if (m.nr > 31) FAIL(FSIM_ENOMEM, "more than 31 moving bodies");
   if (m.ncp > 65535) FAIL(FSIM_ENOMEM, "too many candidate pairs");
   if (m.ncg > 255) FAIL(FSIM_ENOMEM, "more than 255 colliding geoms (broadphase records hold 8-bit geom indices)");
@@ -511,7 +510,7 @@ static LayoutIn layout_in(const fsim *s, int ncon_max) {
   in.eik_rel = s->cfg.dense_reward ? ED_WORDS : 0;
   in.ncon_max = ncon_max;
   // furniture with many long parts (bookcase planks lying side by side): more part-part pairs survive the broadphase
-  in.maxsurv = m.nparts > 8 ? 128 : FSIM_MAXSURV;
+  in.maxsurv = ncon_max > 64 ? 192 : (m.nparts > 8 ? 128 : FSIM_MAXSURV);
   return in;
 }
 
@@ -523,6 +522,8 @@ static KernelSet pick_kernels(const Dims &d, const LayoutIn &in) {
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
+  // (more than 64 contact slots: two slot sets per lane in the Newton solve -- one-wave kernels only)
+  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr};
   return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
 }
 
@@ -539,10 +540,12 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (cfg) s->cfg = *cfg; else fsim_default_config(&s->cfg);
   int rc = build_model(s);
   if (rc) { delete s; return rc; }
-  // contact slots: 48 by default; furniture with nine or more parts (>= 36 part-floor contacts at rest) gets the 64 a wave can scan
-  int ncon_max = (s->m.nparts > 8 || s->m.ncg > 48) ? 64 : 48; // (or many collision primitives per part: chairs, table_torsby)
+  // contact slots: 48 by default (Sawyer + table_lack holds 21 at rest); 64 for furniture with eight or nine parts or many collision
+  // primitives (>= 34 colliding geoms: chairs, table_torsby); 128 -- two slots per lane in the Newton solve, Ctx::NS == 2 -- for ten
+  // parts and more (4 part-floor contacts per part at rest plus the part-part ones)
+  int ncon_max = s->m.nparts >= 10 ? 128 : ((s->m.nparts >= 8 || s->m.ncg >= 34) ? 64 : 48);
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
-  if (ncon_max < 8 || ncon_max > 64) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 64] (one wave scans the contact slots)"); }
+  if (ncon_max < 8 || ncon_max > 128) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 128] (the Newton solve keeps one or two contact slots per lane)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
   if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, on a model compiled with the IK chain table"); }
   if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built; the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl", cfg ? cfg->control_type : 0); }
@@ -571,7 +574,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->mw_cap = std::max(1, n_envs / 8);
     if (const char *e = getenv("FSIM_MW_CAP")) s->mw_cap = std::max(1, std::min(n_envs, atoi(e)));
     if (getenv("FSIM_NO_LPT") && s->mw_mode == 1) s->mw_mode = 0; // (the selection is part of the scheduler kernel)
-    if (s->lds_bytes_mw > 160 * 1024) s->mw_mode = 0;
+    if (s->lds_bytes_mw > 160 * 1024 || !s->ks.env_step_x) s->mw_mode = 0;
     // bundles of four keep today's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
     if (s->mw_mode == 1 && 2 * s->lds_bytes_x > 160 * 1024) s->mw_mode = 0;
     // a launch with many rounds of envs per wave slot is bound by throughput, not by its slowest env: four waves per env cost

@@ -32,9 +32,10 @@ template <int NW_, bool BUNDLE_> struct FsSync {
   DEV static void sync() { if (NW_ == 1 && !BUNDLE_) __syncthreads(); else __asm__ volatile("" ::: "memory"); }
   DEV static void xbar() { __syncthreads(); }
 };
-template <int NW_, bool BUNDLE_ = false> struct GenCtxT {
+template <int NW_, bool BUNDLE_ = false, int NS_ = 1> struct GenCtxT {
   static constexpr int NW = NW_;
   static constexpr bool BUNDLE = BUNDLE_;
+  static constexpr int NS = NS_; // contact-slot sets of 64 the Newton solve carries per lane (2: models with more than 64 contact slots)
   float *L;          // LDS base (state image followed by work arrays)
   CModel &m;         // model tables (pointers)
   CLayout &ly;       // LDS / record layout
@@ -61,6 +62,7 @@ template <class S, int NW_ = 1, bool BUNDLE_ = false> struct SpecCtx {
   CModel &m;
   static constexpr Layout ly = FsSpecLayout<S, NW_>::ly;
   static constexpr Dims D = S::D;
+  static constexpr int NS = FsSpecLayout<S, NW_>::ly.ncon_max > 64 ? 2 : 1;
   int lane, wave;
   int newton_maxit;
   float newton_tol;
@@ -85,8 +87,8 @@ template <class T> DEV T *fs_uniform_ptr(T *p) {
   return (T *)(((unsigned long long)hi << 32) | lo);
 }
 // (lds: the workgroup's dynamic LDS base -- a bundled wave's image offset is applied by the constructor)
-template <int NW_, bool B_> DEV GenCtxT<NW_, B_> fs_rebuild(const GenCtxT<NW_, B_> &cv, float *lds) {
-  return GenCtxT<NW_, B_>(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
+template <int NW_, bool B_, int NS_> DEV GenCtxT<NW_, B_, NS_> fs_rebuild(const GenCtxT<NW_, B_, NS_> &cv, float *lds) {
+  return GenCtxT<NW_, B_, NS_>(lds, *fs_uniform_ptr(&cv.m), *fs_uniform_ptr(&cv.ly), (int)threadIdx.x, __builtin_amdgcn_readfirstlane(cv.newton_maxit),
                           __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cv.newton_tol))));
 }
 template <class S, int NW_, bool B_> DEV SpecCtx<S, NW_, B_> fs_rebuild(const SpecCtx<S, NW_, B_> &cv, float *lds) {

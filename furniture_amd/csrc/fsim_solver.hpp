@@ -212,14 +212,16 @@ struct SolSlot {
   bool anyweld;            // (wave-uniform) some weld is active
   int pid, npc, ptot, nye; // body-pair cache (fs_pair_cache): this slot's pair block (-1 none), pairs (wave-uniform; -1 = not cached), items, column items
 };
-template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
+// base: first contact slot of the set (0; 64 for the second set of a model with more than 64 contact slots -- Ctx::NS == 2: the
+// solve then carries two SolSlot per lane; joint limits and welds belong to the first set)
+template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c, const int base = 0) {
   float *L = c.L;
   SolSlot S;
   const int nslot = c.I(c.ly.scal)[SC_NSLOT];
-  const int sc = min(c.lane, c.ly.ncon_max - 1), sl = min(c.lane, max(2 * c.D.nlim - 1, 0));
+  const int sc = min(base + c.lane, c.ly.ncon_max - 1), sl = min(c.lane, max(2 * c.D.nlim - 1, 0));
   const float *r = L + c.ly.con + FSIM_CONW * sc;
   const int *ri = reinterpret_cast<const int *>(r);
-  S.act = c.lane < nslot && ri[C_ACTIVE] == 1;
+  S.act = base + c.lane < nslot && ri[C_ACTIVE] == 1;
   S.dim1 = ri[C_DIM] == 1;
   S.bt1 = S.act ? ri[C_B1] : 0; S.bt2 = S.act ? ri[C_B2] : 0;
   {
@@ -231,7 +233,7 @@ template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c) {
   fs_frame(r, S.fx, S.fy, S.fz);
   const float *q = L + c.ly.lim + FSIM_LIMW * sl;
   const int *qi = reinterpret_cast<const int *>(q);
-  S.lact = c.lane < 2 * c.D.nlim && qi[LM_ACTIVE] != 0;
+  S.lact = base == 0 && c.lane < 2 * c.D.nlim && qi[LM_ACTIVE] != 0;
   S.ldof = qi[LM_DOF]; S.ld = q[LM_D]; S.laref = q[LM_AREF]; S.lsign = q[LM_SIGN]; S.ljar = 0; S.ljp = 0;
   if (!S.lact) S.ldof = 0;
   int aw = 0, tb = S.act ? ((1 << (S.bt1 & 255)) | (1 << (S.bt2 & 255))) : 0;
@@ -308,7 +310,7 @@ template <class Ctx> DEV void fs_pair_cache(const Ctx &c, SolSlot &S) {
 }
 
 // S.jar (to_jar: minus aref) or S.jp = J * vec, using W from fs_body_spatial(vec)
-template <class Ctx> DEV void fs_jdot(const Ctx &c, SolSlot &S, int off_vec, bool to_jar) {
+template <class Ctx> DEV void fs_jdot(const Ctx &c, SolSlot &S, int off_vec, bool to_jar, const bool welds = true) {
   float *L = c.L;
   {
     // (unconditional loads: inactive lanes read body 0 / valid addresses and drop the result)
@@ -320,7 +322,7 @@ template <class Ctx> DEV void fs_jdot(const Ctx &c, SolSlot &S, int off_vec, boo
     const float lv = S.lsign * L[off_vec + S.ldof];
     if (to_jar) S.ljar = lv - S.laref; else S.ljp = lv;
   }
-  if (S.anyweld) {
+  if (welds && S.anyweld) {
     for (int e = c.lane; e < c.D.neq; e += 64) {
       float *r = L + c.ly.weld + FSIM_WELDW * e;
       int *ri = reinterpret_cast<int *>(r);
@@ -394,10 +396,9 @@ DEV int fs_cone_dir(const float *jar, const float *jp, float Dn, float Dt, float
 // zone: per-lane record of which piece of the piecewise cost this lane's contact slot (bits 0-1: 0 top / 1 bottom / 2 middle)
 // and joint-limit record (bit 2: active) were in when the gradient was taken; *nonquad: some lane's slot / limit is now in another
 // piece than at `zone`, or on the cone surface (the only non-quadratic piece)
-template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float alpha, float *d1, float *d2, int zone, bool *nonquad) {
-  float *L = c.L;
-  float a1 = 0, a2 = 0;
-  int zc = 0, zl = 0; // this lane's contact zone / limit activity at alpha
+// this lane's contact slot: adds the first / second directional derivative of its cost at alpha, returns its zone there
+DEV int fs_line_slot(const SolSlot &S, float alpha, float &a1, float &a2) {
+  int zc = 0;
   if (S.act) {
     if (S.dim1) {
       float j = S.jar[0] + alpha * S.jp[0];
@@ -408,6 +409,20 @@ template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float
       zc = fs_cone_dir(jar, S.jp, S.dn, S.dt, S.mu, &e1, &e2);
       a1 += e1; a2 += e2;
     }
+  }
+  return zc;
+}
+// (T / zoneT: the second slot set of a model with more than 64 contact slots, Ctx::NS == 2)
+template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float alpha, float *d1, float *d2, int zone, bool *nonquad, const SolSlot *T = nullptr,
+                                          int zoneT = 0) {
+  float *L = c.L;
+  float a1 = 0, a2 = 0;
+  int zl = 0; // this lane's limit activity at alpha
+  const int zc = fs_line_slot(S, alpha, a1, a2); // this lane's contact zone at alpha
+  bool moved = zc == 2 || zc != (zone & 3);
+  if constexpr (Ctx::NS > 1) {
+    const int zt = fs_line_slot(*T, alpha, a1, a2);
+    moved = moved || zt == 2 || zt != (zoneT & 3);
   }
   if (S.lact) {
     float j = S.ljar + alpha * S.ljp;
@@ -422,7 +437,7 @@ template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float
         a1 += D * j * r[WD_JP + q]; a2 += D * r[WD_JP + q] * r[WD_JP + q];
       }
     }
-  *nonquad = __ballot(zc == 2 || zc != (zone & 3) || zl != ((zone >> 2) & 1)) != 0;
+  *nonquad = __ballot(moved || zl != ((zone >> 2) & 1)) != 0;
   *d1 = wave_sum(a1); *d2 = wave_sum(a2);
 }
 
@@ -449,15 +464,12 @@ template <class Ctx> DEV void fs_add_wrench_r(const Ctx &c, int bt, V3 r, V3 F, 
 // cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
 struct SlotK { bool on; int zone; float K[6]; }; // zone: see fs_line_eval
 
-template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S) {
-  float *L = c.L;
+// this lane's contact slot: cone force -> wrenches on its two bodies; returns the cone state and world stiffness
+template <class Ctx> DEV SlotK fs_grad_slot(const Ctx &c, const SolSlot &S) {
   SlotK sk;
   sk.on = false;
   sk.zone = 0;
   for (int q = 0; q < 6; q++) sk.K[q] = 0;
-  for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
-  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
-  SYNC();
   if (S.act) {
     float f[3] = {0, 0, 0}, cc, Hc[9];
     bool on;
@@ -479,6 +491,18 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S) {
       fs_add_wrench_r(c, S.bt1, S.r1, F, -1.0f);
     }
   }
+  return sk;
+}
+
+// (T / skT: the second slot set, Ctx::NS == 2)
+template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const SolSlot *T = nullptr, SlotK *skT = nullptr) {
+  float *L = c.L;
+  for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
+  for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
+  SYNC();
+  SlotK sk = fs_grad_slot(c, S);
+  int tb = S.tb;
+  if constexpr (Ctx::NS > 1) { *skT = fs_grad_slot(c, *T); tb |= T->tb; }
   if (S.lact && S.ljar < 0) {
     sk.zone |= 4;
     atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar); // -sign*f, f = -D*jar
@@ -491,10 +515,10 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S) {
       float f[6];
       for (int q = 0; q < 6; q++) f[q] = -r[WD_D + q] * r[WD_JAR + q];
       V3 F = v3(f[0], f[1], f[2]);
-      V3 T = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
-                r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
-      fs_add_wrench(c, fs_bt(c, ri[WD_B1]), ldv3(r + WD_P0), F, T, 1.0f);
-      fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T, -1.0f);
+      V3 T_ = v3(r[WD_C] * f[3] + r[WD_C + 3] * f[4] + r[WD_C + 6] * f[5], r[WD_C + 1] * f[3] + r[WD_C + 4] * f[4] + r[WD_C + 7] * f[5],
+                 r[WD_C + 2] * f[3] + r[WD_C + 5] * f[4] + r[WD_C + 8] * f[5]);
+      fs_add_wrench(c, fs_bt(c, ri[WD_B1]), ldv3(r + WD_P0), F, T_, 1.0f);
+      fs_add_wrench(c, fs_bt(c, ri[WD_B2]), ldv3(r + WD_X2), F, T_, -1.0f);
     }
   SYNC();
   for (int d = c.lane; d < c.D.nv; d += 64) {
@@ -503,7 +527,7 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S) {
     float acc = 0;
     // only the bodies that carry a constraint hold a wrench (a free arm's dofs skip the walk); two bodies per trip, the second
     // predicated, so that a trip's loads are independent
-    for (int mm = KI(r_submask, bd) & S.tb; mm;) {
+    for (int mm = KI(r_submask, bd) & tb; mm;) {
       const int b0 = __ffs(mm) - 1;
       mm &= mm - 1;
       const bool two = mm != 0;
@@ -542,7 +566,9 @@ template <class Ctx> DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   a contact between two moving bodies (lo, hi) additionally adds -cdof_d1' X cdof_d2, X = P_lo' K P_hi, on
 //   chain(lo) x chain(hi).  The cost is independent of the number of contacts per body (20 part-floor contacts
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
-template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const SolSlot &S) {
+// ADD (second slot set of a model with more than 64 contact slots): the blocks of S are assembled the same way and ADDED to the H
+// the first set left -- the projection is linear in the blocks --, without M, joint limits and welds (they came with the first set).
+template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const SolSlot &S) {
   CModel &m = c.m;
   float *L = c.L;
   const int nH = c.I(c.ly.scal)[SC_HWORDS]; // packed island triangles
@@ -556,7 +582,7 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
 #else
 #define FS_HPROF(slot) do { } while (0)
 #endif
-  for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
+  if (!ADD) for (int i = c.lane; i < nH; i += 64) L[c.ly.H + i] = 0;
   for (int i = c.lane; i < 21 * c.D.nr; i += 64) A[i] = 0;
   if (S.npc > 0) for (int i = c.lane; i < FSIM_XW * S.npc; i += 64) X[i] = 0; // cached pairs: the blocks are filled with the body blocks below
   SYNC();
@@ -664,7 +690,8 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
     V3 tl = v3(Ab[6] * sj.a.x + Ab[9] * sj.a.y + Ab[12] * sj.a.z + Ab[15] * sj.l.x + Ab[16] * sj.l.y + Ab[17] * sj.l.z,
                Ab[7] * sj.a.x + Ab[10] * sj.a.y + Ab[13] * sj.a.z + Ab[16] * sj.l.x + Ab[18] * sj.l.y + Ab[19] * sj.l.z,
                Ab[8] * sj.a.x + Ab[11] * sj.a.y + Ab[14] * sj.a.z + Ab[17] * sj.l.x + Ab[19] * sj.l.y + Ab[20] * sj.l.z);
-    L[c.ly.H + fs_hidx(c, hm, i, j)] = L[c.ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
+    if (ADD) L[c.ly.H + fs_hidx(c, hm, i, j)] += dot(si.a, ta) + dot(si.l, tl);
+    else L[c.ly.H + fs_hidx(c, hm, i, j)] = L[c.ly.M + KM_P(e)] + dot(si.a, ta) + dot(si.l, tl);
   }
   SYNC();
   FS_HPROF(50);
@@ -736,8 +763,8 @@ template <class Ctx> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const So
 #undef FS_PAIR_ITEM
 #undef FS_ADD_X
   FS_HPROF(53);
-  if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
-  if (S.anyweld)
+  if (!ADD && S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
+  if (!ADD && S.anyweld)
   for (int e = c.lane; e < c.D.neq; e += 64) {
     float *r = L + c.ly.weld + FSIM_WELDW * e;
     int *ri = reinterpret_cast<int *>(r);
@@ -1496,6 +1523,16 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     mw_post(c, MW_MULM);
   }
   SolSlot S = fs_load_slots(c);
+  SolSlot T = {};  // (second slot set: models with more than 64 contact slots, Ctx::NS == 2; dead code otherwise)
+  if constexpr (Ctx::NS > 1) {
+    // two sets: the body-pair cache is not used (its election runs over one set of lanes); every set takes fs_hessian's multi-pass path
+    T = fs_load_slots(c, 64);
+    {
+      const int b1 = S.bt1 & 255, b2 = S.bt2 & 255, u1 = T.bt1 & 255, u2 = T.bt2 & 255;
+      S.npc = __ballot(S.act && min(b1, b2) != 0 && b1 != b2) ? -1 : 0;
+      T.npc = __ballot(T.act && min(u1, u2) != 0 && u1 != u2) ? -1 : 0;
+    }
+  } else
   fs_pair_cache(c, S);
 #ifdef FSIM_PROFILE
   if (c.lane == 0) scal[52] += ((S.npc < 0) << 16) + ((S.npc > 0) << 24); // solves whose body pairs did not fit the cache / did
@@ -1503,6 +1540,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   if constexpr (Ctx::NW == 1) fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
   fs_jdot(c, S, c.ly.x, true);
+  if constexpr (Ctx::NS > 1) fs_jdot(c, T, c.ly.x, true, false);
   if constexpr (Ctx::NW > 1) mw_post(c, MW_IDLE);
   float scale = c.D.meaninertia_scale;
   int it = 0;
@@ -1510,14 +1548,14 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   // know (welds, body pairs beyond the cache, a second row pass) -- then main iterates alone, as in the one-wave kernel
   bool mw = false;
   if constexpr (Ctx::NW > 1) {
-    mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64;
+    mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64 && Ctx::NS == 1;
     if (mw) {
       c.I(c.ly.jst)[FSIM_JSTW * c.lane + 4] = S.pid;
       if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; }
     }
   }
   for (; it < c.newton_maxit; it++) {
-    SlotK sk;
+    SlotK sk, skT = {};
     bool ok;
     bool iterated = false;
     if constexpr (Ctx::NW > 1) if (mw) {
@@ -1548,11 +1586,12 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       mw_post(c, MW_IDLE);
     }
     if (!iterated) {
-      sk = fs_gradient(c, S);
+      sk = fs_gradient(c, S, &T, &skT);
       float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
       FS_SPROF(23);
       if (scale * gn < c.newton_tol) break;
       fs_hessian(c, sk, S);
+      if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T);
       FS_SPROF(24);
       ok = fs_chol_solve(c, c.ly.hmap);
       FS_SPROF(25);
@@ -1560,6 +1599,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       fs_mulM(c, c.ly.Mp, c.ly.p);
       fs_body_spatial(c, c.ly.p);
       fs_jdot(c, S, c.ly.p, false);
+      if constexpr (Ctx::NS > 1) fs_jdot(c, T, c.ly.p, false, false);
     }
     // phi'(0) along the Newton direction (= -g' H^-1 g < 0), p'Mp and p'(Mx - smooth) in one pass over the dofs
     float dphi0 = 0, pMp = 0, pg0 = 0;
@@ -1576,7 +1616,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     for (int ls = 0; ls < 20; ls++) {
       float d1, d2;
       bool nq;
-      fs_line_eval(c, S, alpha, &d1, &d2, sk.zone, &nq);
+      fs_line_eval(c, S, alpha, &d1, &d2, sk.zone, &nq, &T, skT.zone);
       if (ls == 0) nonquad = nq;
 #ifdef FSIM_PROFILE
       if (c.lane == 0) { scal[16 + 13] += 1; }
@@ -1600,6 +1640,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     FS_SPROF(27);
     for (int d = c.lane; d < c.D.nv; d += 64) { L[c.ly.x + d] += alpha * L[c.ly.p + d]; L[c.ly.Mx + d] += alpha * L[c.ly.Mp + d]; }
     for (int a = 0; a < 3; a++) S.jar[a] += alpha * S.jp[a];
+    if constexpr (Ctx::NS > 1) for (int a = 0; a < 3; a++) T.jar[a] += alpha * T.jp[a];
     S.ljar += alpha * S.ljp;
     if (S.anyweld)
       for (int e = c.lane; e < c.D.neq; e += 64) {

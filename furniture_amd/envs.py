@@ -242,6 +242,7 @@ class ResetTableSampler:
         return parts, noise
 
     def _draw_python(self, mask=None):
+        self._to_python()
         n = len(self._rngs)
         parts = np.zeros((n, self.m.nparts * 7), dtype=np.float32)
         noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
@@ -261,6 +262,10 @@ class ResetTableSampler:
                 # one (101, narm) draw consumes the Mersenne-Twister stream exactly like 101 successive size-narm draws
                 noise[i] = rng.uniform(low=-a, high=a, size=(N_NOISE, self.narm)).reshape(-1)
         return parts, noise
+
+
+class ContactOverflowError(RuntimeError):
+    """a step dropped contacts (see FurnitureBatchEnv.step_wait)"""
 
 
 class ResetTableQueue:
@@ -284,8 +289,8 @@ class ResetTableQueue:
     def take(self, mask=None):
         """Tables for the envs in mask (all if None); schedules their replacements."""
         if self._fut is not None:
-            self._fut.result()
-            self._fut = None
+            fut, self._fut = self._fut, None
+            fut.result()  # (raises what the worker's draw raised, once)
         n = self._parts.shape[0]
         m = np.ones(n, dtype=bool) if mask is None else np.asarray(mask, dtype=bool).copy()
         parts, noise = self._parts.copy(), self._noise.copy()
@@ -444,14 +449,26 @@ class FurnitureBatchEnv:
             out["phase_ob"] = torch.nn.functional.one_hot(ph, 8).to(flat.dtype)
         return out
 
-    def _refill(self, mask=None, skip=None):
+    def _refill(self, mask=None, skip=None, lookahead=False):
         """Upload the next reset table of the envs in mask (all if None).  skip: envs whose stream first loses one draw (the
-        reference draws twice when an unstable simulation resets inside step() and the vec-env worker resets again)."""
-        if getattr(self, "_table_queue", None) is None:
-            self._table_queue = ResetTableQueue(self._sampler)
-        if skip is not None and skip.any():
-            self._table_queue.take(skip)  # drawn and dropped
-        parts, noise = self._table_queue.take(mask)
+        reference draws twice when an unstable simulation resets inside step() and the vec-env worker resets again).
+        lookahead: the tables are for a reset that has not been asked for yet -- if the placement sampler gives up on one of them
+        ("Cannot place all objects": the reference's RandomizationError, common for furniture with many large parts), the error is
+        kept for the reset() that would have drawn it, as in the reference."""
+        if getattr(self, "_place_error", None) is not None and not lookahead:
+            e, self._place_error = self._place_error, None
+            raise e
+        try:
+            if getattr(self, "_table_queue", None) is None:
+                self._table_queue = ResetTableQueue(self._sampler)
+            if skip is not None and skip.any():
+                self._table_queue.take(skip)  # drawn and dropped
+            parts, noise = self._table_queue.take(mask)
+        except RuntimeError as e:
+            if lookahead and "Cannot place" in str(e):
+                self._place_error = e
+                return
+            raise
         self.sim.set_reset_tables(parts, noise, mask=mask)
         if mask is None:
             self._tables_fresh[:] = True
@@ -496,7 +513,7 @@ class FurnitureBatchEnv:
         self._tables_fresh[:] = False
         # the next draw of every env's stream goes to the device now: the in-kernel resets read it (the auto-reset of a terminal
         # step; without auto_reset, the reset an unstable simulation triggers inside step(), furniture.py:2889-2897)
-        self._refill()
+        self._refill(lookahead=True)
         return self._split(self._obs)
 
     def rng_handover(self):
@@ -531,21 +548,27 @@ class FurnitureBatchEnv:
             if self.sim.tables_needed():
                 need = self._info[:, INFO_NEEDS_TABLE].cpu().numpy()
                 self._tables_fresh[need > 0] = False
-                self._refill(need > 0, skip=need > 1)
+                self._refill(need > 0, skip=need > 1, lookahead=True)
         if not self._auto_reset and bool((self._info[:, INFO_FAIL] != 0).any()):
             # an unstable simulation reset the env inside step() and consumed the table on the device: upload the env's next draw
             failed = (self._info[:, INFO_FAIL] != 0).cpu().numpy()
             self._tables_fresh[failed] = False
-            self._refill(failed)
+            self._refill(failed, lookahead=True)
         info = self._info
-        # a model whose contacts do not fit the 48 / 64 slots of a wavefront loses contacts silently otherwise: say so once
+        # a step in which contacts did not fit the slots (48 / 64 / 128 by model size) or the broadphase list integrated WRONG physics
+        # for those envs: an error, not a warning (FSIM_ALLOW_OVERFLOW=1 downgrades it; the flags stay in info["contact_overflow"])
         self._steps_done = getattr(self, "_steps_done", 0) + 1
-        if not getattr(self, "_overflow_warned", False) and self._steps_done % 64 == 1 and bool((info[:, 12] != 0).any()):
-            import warnings
-            warnings.warn("furniture_amd: %s overflowed the contact slots / broadphase list of the step kernel (info['contact_overflow']); "
-                          "contacts are being dropped -- this furniture has more simultaneous contacts than the accelerated path holds"
-                          % self.furniture_name, stacklevel=2)
-            self._overflow_warned = True
+        if self._steps_done % 16 == 1 and bool((info[:, 12] != 0).any()):
+            import os
+            msg = ("furniture_amd: %s overflowed the contact slots / broadphase list of the step kernel in %d env(s) (info['contact_overflow']): "
+                   "contacts were dropped -- this furniture has more simultaneous contacts than the accelerated path holds (%d slots)"
+                   % (self.furniture_name, int((info[:, 12] != 0).sum()), self.sim.max_contacts))
+            if os.environ.get("FSIM_ALLOW_OVERFLOW") != "1":
+                raise ContactOverflowError(msg)
+            if not getattr(self, "_overflow_warned", False):
+                import warnings
+                warnings.warn(msg, stacklevel=2)
+                self._overflow_warned = True
         infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
                      site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
                      connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])

@@ -1,7 +1,7 @@
-"""Every furniture shipped compiled for the Sawyer agent (61 of the reference's 64: three carry mesh geoms with a density and
-need mesh volumes) runs reset + random steps on the device, including those with more than 64 dofs (69: ten parts -- the island
-solver fills its four 16-lane rows twice); furniture with eleven or more parts is refused at fsim_create (its contacts at rest
-exceed the 64 slots a wavefront scans).  The parity tests cover the BASELINE configs' models; this one is
+"""Every furniture shipped compiled for the Sawyer agent (61 of the reference's 64: three collide MESH geoms, for which there is no
+narrow-phase routine) runs reset + random steps on the device, including those with more than 64 dofs (up to 93: fourteen parts --
+the island solver fills its four 16-lane rows twice) and those with ten parts and more, whose contacts at rest need more than 64
+slots (128: two contact slots per lane in the Newton solve); nothing is refused at fsim_create, and a step that drops contacts raises.  The parity tests cover the BASELINE configs' models; this one is
 breadth: the generic kernels, the model compiler's tables and the host-side samplers on models nobody looked at individually;
 plus one device-vs-oracle reset on the largest model."""
 import glob
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def test_every_compiled_sawyer_furniture_resets_and_steps():
     import torch
-    from furniture_amd.envs import make_vec_env
+    from furniture_amd.envs import ContactOverflowError, make_vec_env
     from furniture_amd.mjcf.model import _COMPILED_DIR, load_compiled
     from furniture_amd.sim import FsimError
 
@@ -27,8 +27,7 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
         try:
             env = make_vec_env("Sawyer", 4, furniture_name=name, max_episode_steps=3, seed=11, record_vid=False, unity=False, control_type="impedance")
         except FsimError as e:
-            assert m.nparts > 10 and "contact slots" in str(e), (name, m.nparts, str(e))
-            refused.append(name)
+            refused.append((name, str(e)))
             continue
         try:
             ob = env.reset()
@@ -45,7 +44,11 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
         trouble = 0
         for t in range(4):  # crosses an in-kernel auto-reset (max_episode_steps = 3)
             a = torch.empty((4, 9), device=env.sim.device).uniform_(-1, 1, generator=g)
-            ob, rew, done, info = env.step(a)
+            try:
+                ob, rew, done, info = env.step(a)
+            except ContactOverflowError:
+                trouble = 2
+                break
             assert bool(torch.isfinite(ob["object_ob"]).all()) and bool(torch.isfinite(ob["robot_ob"]).all()) and bool(torch.isfinite(rew).all()), (name, t)
             trouble |= int(info["fail"].max()) | (int(info["contact_overflow"].max()) << 1)
             if not trouble:
@@ -62,7 +65,10 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
     print("ran %d furniture models (%d of them with more than 64 dofs), refused %d: %s; placement sampler gives up (as the reference's does) on %s" % (
         len(ran), sum(load_compiled("Sawyer", x).nv > 64 for x in ran), len(refused), refused, unplaceable))
     print("overflowed or failed (name, parts, fail | overflow << 1):", troubled)
-    assert len(ran) >= 47 and len(refused) <= 7 and len(unplaceable) <= 4 and len(troubled) <= 5
+    # two models do not fit even 128 slots: bookcase_billy_0191 (11 planks) and table_liden_0921 (12 parts) pass through 230-250
+    # simultaneous contacts while the reset settles them (counted with the oracle); their steps raise ContactOverflowError
+    assert refused == [] and sorted(x[0] for x in troubled) == ["bookcase_billy_0191", "table_liden_0921"], (refused, troubled)
+    assert len(ran) >= 55 and len(unplaceable) <= 4
 
 
 def test_a_model_with_more_than_64_dofs_matches_the_oracle_env():
@@ -101,3 +107,22 @@ def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_s
         act = env.sim.get_state("eq_active")["eq_active"]
         assert int(act.sum()) == 2 * m.neq, name
         env.close()
+
+
+def test_the_fourteen_part_bookcase_is_accepted_and_says_when_it_drops_contacts():
+    """Sawyer + bookcase_grevback_0484 (SURVEY section 8's size table: 14 parts, 93 dofs).  fsim_create takes it now (128 contact slots,
+    two per lane in the Newton solve), but the reference's own placement puts its fourteen planks INSIDE each other (the XML gives every
+    part a placement radius of 5 mm, the jitter is 2 cm): 256 contacts and one 84-dof island at the first substep of the reset, measured
+    with the oracle, which MuJoCo resolves by throwing the planks apart.  That is beyond the 128 slots / 64-dof islands of the device
+    path, and the env says so instead of integrating wrong physics."""
+    from furniture_amd.envs import ContactOverflowError, FurnitureSawyerEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    m = load_compiled("Sawyer", "bookcase_grevback_0484")
+    assert m.nparts == 14 and m.nv == 93 and float(np.max(m.part_hradius)) < 0.01
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="bookcase_grevback_0484", max_episode_steps=50, seed=3)
+    env = FurnitureSawyerEnv(make_config(**kw))
+    assert env._b.sim.max_contacts == 128 and env._b.sim.kernel_variant == "generic2"
+    env.reset()
+    with pytest.raises(ContactOverflowError):
+        env.step(np.zeros(9))
+    env.close()
