@@ -264,6 +264,18 @@ class ResetTableSampler:
         return parts, noise
 
 
+def robot_without_collision(m):
+    """config.no_collision (furniture.py:1961-1965): the robot's geoms collide with nothing -- their contype / conaffinity are 0 in
+    the model, so the reset's "robot collision off / on" (furniture.py:1441-1461) restores zeros and the finger-touch scan never fires."""
+    from .mjcf.model import CompiledModel
+    arr = dict(m.arrays)
+    for full, flag in (("geom_contype", "geom_is_robot"), ("geom_conaffinity", "geom_is_robot"), ("cg_contype0", "cg_isrobot"), ("cg_conaffinity0", "cg_isrobot")):
+        a = np.array(arr[full]).copy()
+        a[np.asarray(arr[flag]).astype(bool)] = 0
+        arr[full] = a
+    return CompiledModel(arr, m.meta)
+
+
 class ContactOverflowError(RuntimeError):
     """a step dropped contacts (see FurnitureBatchEnv.step_wait)"""
 
@@ -330,10 +342,11 @@ class FurnitureBatchEnv:
             cfg.unity, cfg.record_vid = False, False
         if cfg.visual_ob:
             raise ValueError("visual_ob must be False: camera observations need the renderer, which is outside the accelerated hot path")
-        if agent != "Cursor" and cfg.control_type != "impedance" and cfg.control_type not in CONTROLLER_CODES:
-            raise NotImplementedError("control_type %r: the accelerated path implements 'impedance' and the torque-level arm "
-                                      "controllers / ik %s (the reference's 'torque' path writes an 8-vector into "
-                                      "a 9-actuator ctrl)" % (cfg.control_type, sorted(CONTROLLER_CODES)))
+        # "torque" (furniture.py:1268): _do_simulation(action[:-1]) = the impedance flow -- _setup_action turns [7 arm, 1 grip] into the 9
+        # actuator controls and rescales them to the ctrlrange -- on the motor-actuated robot (robot_torque.xml): same kernel, other model
+        if agent != "Cursor" and cfg.control_type not in ("impedance", "torque") and cfg.control_type not in CONTROLLER_CODES:
+            raise NotImplementedError("control_type %r: the accelerated path implements 'impedance', 'torque' and the torque-level arm "
+                                      "controllers / ik %s" % (cfg.control_type, sorted(CONTROLLER_CODES)))
         if agent != "Cursor" and cfg.control_type in CONTROLLER_CODES and dense and cfg.control_type not in ("ik", "ik_quaternion"):
             raise NotImplementedError("the dense-reward env runs with control_type 'impedance' (config/furniture_sawyer_dense.py:7) or ik / ik_quaternion")
         if agent == "Baxter" and cfg.control_type in CONTROLLER_CODES and cfg.control_type not in ("ik", "ik_quaternion"):
@@ -341,8 +354,9 @@ class FurnitureBatchEnv:
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them
-        for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect)"),
-                          ("no_collision", "furniture.py:1919-1924"),
+        # (reset_robot_after_attach: _connect draws the arm's re-pose noise from the env's ONE RandomState, i.e. between the draws of two
+        #  resets; the reset tables here are drawn one reset ahead, so a connect would have to rewind and redraw them)
+        for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect, between two resets' draws)"),
                           ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325")):
             if getattr(cfg, flag, None):
                 raise NotImplementedError("config.%s (%s) is not part of the accelerated path" % (flag, ref))
@@ -350,6 +364,8 @@ class FurnitureBatchEnv:
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg
         self.model = load_compiled(agent, fname, cfg.control_type if agent != "Cursor" else "impedance")
+        if getattr(cfg, "no_collision", False):  # furniture.py:1961-1965: every robot geom gets contype = conaffinity = 0 in the XML
+            self.model = robot_without_collision(self.model)
         c = default_config()
         c.control_type = CONTROLLER_CODES.get(cfg.control_type, 0) if agent != "Cursor" else 0
         c.n_substeps = int((1.0 / cfg.control_freq) / float(self.model.opt[0]))
