@@ -16,7 +16,7 @@
 #define FSIM_XW 54       // words per body-pair block: the 6 x 6 cross block X, overwritten by Y = X * cdof (6 x chain length <= 9)
 #define FSIM_WELDW 44    // words per weld record
 #define FSIM_LIMW 7      // words per joint-limit record (odd stride, see FSIM_CONW)
-#define FSIM_JSTW 5      // words per staged slot (multi-wave kernel): jar[3], limit jar, pair-block id; odd stride
+#define FSIM_JSTW 9      // words per staged slot (multi-wave kernel): world stiffness K[6], cone-active flag, pair-block id, limit flag; odd stride
 #define FSIM_MWCW 16     // command words of the multi-wave protocol (MWC_*)
 #define FSIM_MAXSURV 48  // broadphase survivors per substep of models with <= 8 parts (22 is the most seen on Sawyer + table_lack); LayoutIn::maxsurv
 
@@ -92,7 +92,7 @@ struct Layout {
   int pitem;  // [FSIM_PCAP] body-pair projection items of this substep (fs_pair_cache)
   // multi-wave layout only (make_layout(in, nw > 1); zero otherwise): see fsim_solver.hpp "multi-wave Newton iteration"
   int hAhi, hAc; // second set of contact blocks (the higher body of each contact) and the composite blocks; hA = the lower bodies' set
-  int jst;       // [64][FSIM_JSTW] this iteration's J a - aref per contact slot / joint-limit record, staged for the helper waves
+  int jst;       // [64][FSIM_JSTW] this iteration's cone state of every contact slot (world stiffness, active flag), staged by the main wave for the helpers
   int mwc;       // [FSIM_MWCW] command words of the workgroup's main wave / helper waves protocol
   int anc2;      // [nr] pointer-doubling scratch of fs_velocity_bias (the survivor list is live: fs_collide runs beside it)
   int lds_words, ncon_max, maxsurv;

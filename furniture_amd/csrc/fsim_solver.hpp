@@ -1357,7 +1357,9 @@ template <class Ctx> DEV void mw_pair_items(const Ctx &c, int ptot, int pairon, 
 }
 
 // the helper waves' side of one Newton iteration (command MW_ITER); barriers pair up with mw_iterate_main's
-// (S: the helper's copy of the slot records, loaded once per solve -- sid tells which solve it belongs to)
+// (S: the helper's copy of the slot records, loaded once per solve -- sid tells which solve it belongs to.  The cone state of the
+//  iteration -- which slots are in an active zone, their world stiffness K -- is computed ONCE, by main, and staged in LDS: three
+//  helpers re-deriving it from J a - aref cost more than the block atomics they then issue)
 template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid) {
   const int *w = c.I(c.ly.mwc);
   const int npc = __builtin_amdgcn_readfirstlane(w[MWC_NPC]), ptot = __builtin_amdgcn_readfirstlane(w[MWC_PTOT]), nye = __builtin_amdgcn_readfirstlane(w[MWC_NYE]);
@@ -1366,12 +1368,16 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid)
   const float *j = c.L + c.ly.jst + FSIM_JSTW * c.lane;
   if (solve != sid) {
     S = fs_load_slots(c);
-    S.pid = reinterpret_cast<const int *>(j)[4];
+    S.pid = reinterpret_cast<const int *>(j)[7];
     sid = solve;
   }
-  S.jar[0] = j[0]; S.jar[1] = j[1]; S.jar[2] = j[2]; S.ljar = j[3];
-  V3 Fw;
-  const SlotK sk = fs_slot_k(S, &Fw);
+  SlotK sk;
+#pragma unroll
+  for (int q = 0; q < 6; q++) sk.K[q] = j[q];
+  const int fl = reinterpret_cast<const int *>(j)[6];
+  sk.on = (fl & 1) != 0;
+  sk.zone = 0;
+  const bool limit_on = (fl & 2) != 0;
   const int pairon = npc > 0 ? mw_pairon(S, sk) : 0;
   mw_blocks(c, S, sk, c.wave);
   c.xbar(); // [3] blocks complete, H zeroed
@@ -1384,7 +1390,7 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid)
   c.xbar(); // [5] tree blocks stored
   if (c.wave == 1) {
     if (npc > 0) mw_pair_items(c, ptot, pairon, false);
-    if (S.lact && S.ljar < 0) atomicAdd(c.L + c.ly.H + fs_hidx(c, c.ly.hmap, S.ldof, S.ldof), S.ld);
+    if (limit_on) atomicAdd(c.L + c.ly.H + fs_hidx(c, c.ly.hmap, S.ldof, S.ldof), S.ld);
   }
 }
 
@@ -1399,15 +1405,17 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
 #else
 #define FS_MWPROF(slot) do { } while (0)
 #endif
-  { // stage this iteration's J a - aref for the helpers
+  V3 Fw;
+  sk = fs_slot_k(S, &Fw);
+  { // stage this iteration's cone state for the helpers
     float *j = L + c.ly.jst + FSIM_JSTW * c.lane;
-    j[0] = S.jar[0]; j[1] = S.jar[1]; j[2] = S.jar[2]; j[3] = S.ljar;
+#pragma unroll
+    for (int q = 0; q < 6; q++) j[q] = sk.K[q];
+    reinterpret_cast<int *>(j)[6] = (sk.on ? 1 : 0) | ((S.lact && S.ljar < 0) ? 2 : 0);
   }
   mw_post(c, MW_ITER); // [1]
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
-  V3 Fw;
-  sk = fs_slot_k(S, &Fw);
   SYNC();
   FS_MWPROF(48);
   if (sk.on) {
@@ -1550,7 +1558,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   if constexpr (Ctx::NW > 1) {
     mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64 && Ctx::NS == 1;
     if (mw) {
-      c.I(c.ly.jst)[FSIM_JSTW * c.lane + 4] = S.pid;
+      c.I(c.ly.jst)[FSIM_JSTW * c.lane + 7] = S.pid;
       if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; }
     }
   }

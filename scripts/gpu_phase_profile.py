@@ -8,7 +8,7 @@ from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, default_config, INFO_DIM
 from furniture_amd.envs import ResetTableSampler, make_config
 m = load_compiled("Sawyer", "table_lack_0825")
-N = int(os.environ.get("FSIM_PROF_N", "4096"))
+N = int(os.environ.get("FSIM_PROF_N", "2048"))  # (one slab of the benchmark: handles of up to 2048 envs use the multi-wave scheduling)
 cfg = default_config(); cfg.max_episode_steps = 150; cfg.solver_tolerance = float(os.environ.get('FSIM_TOL', '1e-6'))
 sim = FSim(m, N, config=cfg)
 sampler = ResetTableSampler(m, make_config(), 123, 0, N)
@@ -31,8 +31,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         " ".join("%s %.0f%%" % (n, 100 * cyc[:, i].sum() / tot.sum()) for i, n in enumerate(names)),
         nsub.mean(), nit.sum() / max(1, nsub.sum()), maxit.max(), ncoup.sum() / max(1, nsub.sum()), nsurv.sum() / max(1, nsub.sum()), nslot.sum() / max(1, nsub.sum())))
     # which envs the scheduler gave four waves in THIS step (its rule, recomputed: last step's Newton iterations >= K, first cap envs)
-    K = int(os.environ.get("FSIM_MW_K", "200")); cap = int(os.environ.get("FSIM_MW_CAP", str(max(1, N // 16))))
-    if t > 0 and os.environ.get("FSIM_MW", "1") not in ("0", "all"):
+    K = int(os.environ.get("FSIM_MW_K", "150")); cap = int(os.environ.get("FSIM_MW_CAP", str(max(1, N // 8))))
+    if t > 0 and os.environ.get("FSIM_MW", "1") not in ("0", "all") and N <= 2048:
         selm = prev_nit >= K
         idx = np.nonzero(selm)[0][:cap]; selm = np.zeros(N, bool); selm[idx] = True
         print("    multi-wave envs %d (%.1f%%): max %.2f mean %.2f Mcyc | one-wave envs: max %.2f Mcyc, %d above 5 Mcyc, %d above 7 Mcyc" % (

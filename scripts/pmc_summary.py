@@ -2,10 +2,12 @@
 figures bench.py reports beside the HBM roofline (what actually binds the fused step kernel)."""
 import glob
 import json
+import os
 import sqlite3
 import sys
 
-N_SIMD, N_XCD, ENVS = 1024, 8, 4096
+N_SIMD, N_XCD = 1024, 8
+ENVS = int(os.environ.get("FSIM_PMC_ENVS", "2048"))  # envs per step launch of the profiled command (bench.py's default: 2 slabs of 2048)
 
 
 def counters(db):
@@ -25,10 +27,11 @@ def main(root, txt, js):
     allc = {}
     for db in sorted(glob.glob(root + "/pmc*/**/*.db", recursive=True)):
         allc.update(counters(db))
-    lines = ["# rocprofv3 --kernel-trace --pmc passes (separate runs, see commands.txt), k_env_step, bench.py --steps 6 --warmup 1 --groups 1",
-             "# (4096 envs, Sawyer+table_lack_0825); values per launch, summed over XCDs: first = reset launch, then warm-up + step launches", ""]
+    lines = ["# rocprofv3 --kernel-trace --pmc passes (separate runs, see commands.txt), k_env_step / k_env_step_x, bench.py --steps 6 --warmup 1",
+             "# (2 slabs of %d envs, Sawyer+table_lack_0825; PMC collection serialises the kernels); values per launch, summed over XCDs:" % ENVS,
+             "# the slabs' reset launches first, then their warm-up + step launches in turn", ""]
     for k in sorted(allc):
-        lines.append("%-28s " % k + " ".join("%.4g" % v for v in allc[k]))
+        lines.append("%-28s " % k + " ".join("%.4g" % v for v in allc[k][-10:]))
     d = {}
     last = lambda k: allc[k][-1] if k in allc and allc[k] else None
     if last("SQ_INSTS_VALU"):

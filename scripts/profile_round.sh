@@ -12,7 +12,7 @@ DB=$(find $O/kt -name "*.db" | head -1)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt1 -o kt1 -- $BENCH --groups 1 > $O/kt1.log 2>&1
 DB=$(find $O/kt1 -name "*.db" | head -1)
 [ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_single_stream.txt "bench.py --steps 30 --warmup 5 --groups 1 (one 4096-env launch per step)" | tail -4
-PB="python $R/bench.py --steps 6 --warmup 1 --groups 1 --no-cpu-baseline"
+PB="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline"
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
