@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
     ap.add_argument("--control-type", default="impedance", help="(exploration only) a torque-level arm controller, e.g. position_orientation")
     ap.add_argument("--obs-bf16", action="store_true", help="store the observation slab as bfloat16 (BASELINE config 2's narrow slab; state stays fp32)")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "2")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "4")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
     if "RANK" not in os.environ and args.gpus > 1:  # plain launch: become N ranks
@@ -273,12 +273,19 @@ def main():
         sl.sim.sync()  # the handle's stream: step kernel + the gather chained behind it
         sl.inflight = False
         if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
-            need = sl.info[:, INFO_NEEDS_TABLE].cpu().numpy()
+            t_h = time.perf_counter()
+            # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave
+            #  slot -- behind the other slabs' reset-step kernels that was 55 ms of an idle host)
+            need = sl.info.cpu().numpy()[:, INFO_NEEDS_TABLE]
             mask = need > 0
             if (need > 1).any():  # an unstable env: the reference draws twice (reset inside step() + the worker's reset)
                 sl.tables.take(need > 1)
+            t_a = time.perf_counter()
             p, nz = sl.tables.take(mask)
+            t_b = time.perf_counter()
             sl.sim.set_reset_tables(p, nz, mask=mask)
+            if os.environ.get("FSIM_BENCH_TRACE") and mask.sum() > 100:
+                sys.stderr.write("  tables for slab %d (%d envs): info %.1f ms, take %.1f ms, upload %.1f ms\n" % (sl.index, int(mask.sum()), (t_a - t_h) * 1e3, (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3))
 
     # U(-1,1) actions of every step, generated on the device BEFORE the timed region (the contract: inputs resident in HBM when
     # the clock starts) -- one slab-step's actions are a [ng, dof] slice; no torch kernel is launched inside the loop, where it
@@ -312,10 +319,16 @@ def main():
     # default (2 slabs, round robin), and the 1000-step protocol is unchanged (631 k) -- not adopted.
     ASYNC = os.environ.get("FSIM_BENCH_ASYNC", "0") == "1" and not distributed
 
+    TRACE = os.environ.get("FSIM_BENCH_TRACE")  # development: wall time of every block of 50 batched steps, on stderr
+
     def run_steps(k):
         if not ASYNC:
-            for _ in range(k):
+            tb = time.perf_counter()
+            for i in range(k):
                 one_step()
+                if TRACE and i % 50 == 49:
+                    sys.stderr.write("steps %4d..%4d: %.3f ms/step\n" % (i - 49, i, (time.perf_counter() - tb) / 50 * 1e3))
+                    tb = time.perf_counter()
             return
         left = {sl.index: k for sl in slabs}
         while any(left.values()) or any(sl.inflight for sl in slabs):

@@ -562,7 +562,7 @@ class FurnitureBatchEnv:
         self.sim.sync()
         if self.refill_tables_every_step:
             if self.sim.tables_needed():
-                need = self._info[:, INFO_NEEDS_TABLE].cpu().numpy()
+                need = self._info.cpu().numpy()[:, INFO_NEEDS_TABLE]  # (whole block = a DMA copy; a column slice would launch a gather kernel)
                 self._tables_fresh[need > 0] = False
                 self._refill(need > 0, skip=need > 1, lookahead=True)
         if not self._auto_reset and bool((self._info[:, INFO_FAIL] != 0).any()):
