@@ -7,7 +7,7 @@ import sqlite3
 import sys
 
 N_SIMD, N_XCD = 1024, 8
-ENVS = int(os.environ.get("FSIM_PMC_ENVS", "2048"))  # envs per step launch of the profiled command (bench.py's default: 2 slabs of 2048)
+ENVS = int(os.environ.get("FSIM_PMC_ENVS", "1024"))
 
 
 def counters(db):
@@ -28,7 +28,7 @@ def main(root, txt, js):
     for db in sorted(glob.glob(root + "/pmc*/**/*.db", recursive=True)):
         allc.update(counters(db))
     lines = ["# rocprofv3 --kernel-trace --pmc passes (separate runs, see commands.txt), k_env_step / k_env_step_x, bench.py --steps 6 --warmup 1",
-             "# (2 slabs of %d envs, Sawyer+table_lack_0825; PMC collection serialises the kernels); values per launch, summed over XCDs:" % ENVS,
+             "# (slabs of %d envs, Sawyer+table_lack_0825; PMC collection serialises the kernels); values per launch, summed over XCDs:" % ENVS,
              "# the slabs' reset launches first, then their warm-up + step launches in turn", ""]
     for k in sorted(allc):
         lines.append("%-28s " % k + " ".join("%.4g" % v for v in allc[k][-10:]))

@@ -8,7 +8,7 @@ BENCH="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline"
 echo "rocprofv3 --kernel-trace --stats -- $BENCH" > $O/commands.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH > $O/kt.log 2>&1
 DB=$(find $O/kt -name "*.db" | head -1)
-[ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_two_slabs.txt "bench.py --steps 30 --warmup 5 (default: 2 slabs of 2048 envs on separate streams), Sawyer+table_lack_0825 4096 envs" | tail -6
+[ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_two_slabs.txt "bench.py --steps 30 --warmup 5 (default: 4 slabs of 1024 envs on separate streams), Sawyer+table_lack_0825 4096 envs" | tail -6
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt1 -o kt1 -- $BENCH --groups 1 > $O/kt1.log 2>&1
 DB=$(find $O/kt1 -name "*.db" | head -1)
 [ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_single_stream.txt "bench.py --steps 30 --warmup 5 --groups 1 (one 4096-env launch per step)" | tail -4
