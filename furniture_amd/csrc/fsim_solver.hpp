@@ -497,8 +497,10 @@ template <class Ctx> DEV SlotK fs_grad_slot(const Ctx &c, const SolSlot &S) {
 // (T / skT: the second slot set, Ctx::NS == 2)
 template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const SolSlot *T = nullptr, SlotK *skT = nullptr) {
   float *L = c.L;
+  float *tsum = L + c.ly.scal + SC_TMP; // [ntree] squared gradient norm per kinematic tree (fs_active_islands)
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
+  if (c.lane < 16) tsum[c.lane] = 0;
   SYNC();
   SlotK sk = fs_grad_slot(c, S);
   int tb = S.tb;
@@ -536,11 +538,48 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const
       const S6 g0 = lds6(L + c.ly.G + 6 * b0), g1 = lds6(L + c.ly.G + 6 * b1);
       acc += dot6(s_, g0) + (two ? dot6(s_, g1) : 0.0f);
     }
-    L[c.ly.grad + d] -= acc;
+    const float g = L[c.ly.grad + d] - acc;
+    L[c.ly.grad + d] = g;
+    atomicAdd(tsum + KI(r_tree, bd), g * g);
   }
   SYNC();
   return sk;
 }
+
+// Which islands still move.  The Newton system is block diagonal over islands (sets of kinematic trees joined by an active
+// constraint), so island I's step is -H_I^-1 g_I whatever the others do, and an island whose own residual is below a quarter of the
+// tolerance (scale |g_I| < tol / 4: with <= 16 islands all of them below that puts the whole gradient below tol, the stopping rule)
+// takes no step worth taking: parts at rest on the floor, whose contact forces the warm start already balances, while the robot
+// island iterates.  Such islands are left out of the iteration -- no contact blocks, no projection, no factorisation, p = 0 --
+// which is what a gripping env spends a third of an iteration on and a median env a tenth of a substep.  An island that is below
+// the threshold stays there (its x does not move), so the set only shrinks during a solve.  Returns the squared gradient norm;
+// *am = bit mask of the trees in islands that still move; dact[d] (int, in the M p vector, dead until the solve) = dof d moves.
+template <class Ctx> DEV float fs_active_islands(const Ctx &c, float scale, bool all, int *am) {
+  float *L = c.L;
+  const float *tsum = L + c.ly.scal + SC_TMP;
+  const int *isl = c.I(c.ly.scal) + SC_ISL;
+  const int t = min(c.lane, c.D.ntree - 1);
+  const float tv = c.lane < c.D.ntree ? tsum[t] : 0.0f;
+  float isum = 0;
+  for (int mm = isl[t]; mm;) {
+    FS_BITS3(mm, u0, u1, u2, h1, h2);
+    const float x0 = tsum[u0], x1 = tsum[u1], x2 = tsum[u2];
+    isum += x0 + (h1 ? x1 : 0.0f) + (h2 ? x2 : 0.0f);
+  }
+  const float thr = 0.25f * c.newton_tol;
+  const bool moves = c.lane < c.D.ntree && (all || scale * scale * isum >= thr * thr || !(isum == isum));
+  *am = (int)(unsigned)__ballot(moves);
+  int *dact = c.I(c.ly.Mp);
+  for (int d = c.lane; d < c.D.nv; d += 64) {
+    const int on = (*am >> KI(r_tree, KI(dof_rbody, d))) & 1;
+    dact[d] = on;
+    if (!on) L[c.ly.p + d] = 0.0f;
+  }
+  const float g2 = wave_sum(tv);
+  SYNC();
+  return g2;
+}
+
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
@@ -568,7 +607,8 @@ template <class Ctx> DEV V3 fs_col(const Ctx &c, int d, V3 pos) {
 //   collapse into 5 blocks) and every projection runs with one lane per output entry.
 // ADD (second slot set of a model with more than 64 contact slots): the blocks of S are assembled the same way and ADDED to the H
 // the first set left -- the projection is linear in the blocks --, without M, joint limits and welds (they came with the first set).
-template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const SolSlot &S) {
+// am: trees of the islands that still move (fs_active_islands); contacts, entries and limits of the others are left out
+template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const SlotK &sk, const SolSlot &S, const int am = -1) {
   CModel &m = c.m;
   float *L = c.L;
   const int nH = c.I(c.ly.scal)[SC_HWORDS]; // packed island triangles
@@ -587,7 +627,8 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
   if (S.npc > 0) for (int i = c.lane; i < FSIM_XW * S.npc; i += 64) X[i] = 0; // cached pairs: the blocks are filled with the body blocks below
   SYNC();
   // ---- contacts: lane = slot (ncon_max <= 64)
-  const bool on = sk.on; // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration
+  // cone state and world stiffness of this lane's slot, from the gradient pass of this iteration; the slot's island still moves?
+  const bool on = sk.on && (((S.bt1 & 255) != 0 && ((am >> (S.bt1 >> 8)) & 1)) || ((S.bt2 & 255) != 0 && ((am >> (S.bt2 >> 8)) & 1)));
   int blo = 0, bhi = 0, tlo = 0, thi = 0;
   float K[6];
   for (int q = 0; q < 6; q++) K[q] = sk.K[q];
@@ -679,8 +720,10 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
   }
   FS_HPROF(49);
   // ---- tree blocks on M's pattern: lane = M entry
+  const int *dact = c.I(c.ly.Mp); // (fs_active_islands)
   for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = KM_I(e), j = KM_J(e);
+    if (am != -1 && !dact[i]) continue;
     const float *Ab = A + 21 * KI(dof_rbody, i);
     S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
     // t = A * sj
@@ -763,7 +806,7 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
 #undef FS_PAIR_ITEM
 #undef FS_ADD_X
   FS_HPROF(53);
-  if (!ADD && S.lact && S.ljar < 0) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
+  if (!ADD && S.lact && S.ljar < 0 && (am == -1 || dact[S.ldof])) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
   if (!ADD && S.anyweld)
   for (int e = c.lane; e < c.D.neq; e += 64) {
     float *r = L + c.ly.weld + FSIM_WELDW * e;
@@ -1105,7 +1148,9 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
 }
 
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
-template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
+// dact (optional): per dof, does its island take a step (fs_active_islands)?  Lanes of the others act as empty lanes (unit diagonal)
+// and the row phase only runs as many pivots as the last active lane needs; a big island that does not move is skipped.
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int *dact = nullptr) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
@@ -1124,10 +1169,17 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
   const int npass = c.D.nv > 64 ? 2 : 1;
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
-    const int rsteps = (rs2 >> (8 * pass)) & 255;
+    int rsteps = (rs2 >> (8 * pass)) & 255;
     if (rsteps > 0) {
       const int dofr = (lw >> (16 * pass)) & 255;
-      const int dof = dofr == 255 ? -1 : dofr;
+      int dof = dofr == 255 ? -1 : dofr;
+      if (dact) {
+        if (dof >= 0 && !dact[dof]) dof = -1;
+        // the islands of a row sit at consecutive positions and are factored independently: pivots beyond the last moving lane are
+        // not needed (and an island is all moving or all still, so no island is cut)
+        rsteps = min(rsteps, (int)wave_max(dof >= 0 ? (float)((c.lane & 15) + 1) : 0.0f));
+        if (rsteps == 0) continue;
+      }
       // (<= 6: what is left for the rows when the robot and the part it holds form a big island -- single parts, one per row)
       if (rsteps <= 6) bad |= fs_chol_phase<6>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
       else if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
@@ -1143,6 +1195,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp) {
 #pragma unroll 1
       for (int q = 0; q < nbig; q++) {
         const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
+        if (dact && !dact[__builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255)]) continue; // this island does not move
         const bool mine = c.lane >= first && c.lane < first + n && dofb != 255;
         const int dof = mine ? dofb : -1;
 #ifdef FSIM_CHOL_READLANE
@@ -1595,13 +1648,17 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     }
     if (!iterated) {
       sk = fs_gradient(c, S, &T, &skT);
-      float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
+      int am;
+      // (welds and the LDS-resident factorisation of islands beyond the MFMA tile keep every island in the iteration)
+      const int *tailh = c.I(c.ly.hmap) + c.D.nv + 64;
+      const bool every = S.anyweld || (__builtin_amdgcn_readfirstlane(tailh[MAP_NBIG]) > 0 && __builtin_amdgcn_readfirstlane(tailh[MAP_MAXBIG]) > 31);
+      const float gn = sqrtf(fs_active_islands(c, scale, every, &am));
       FS_SPROF(23);
       if (scale * gn < c.newton_tol) break;
-      fs_hessian(c, sk, S);
-      if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T);
+      fs_hessian(c, sk, S, am);
+      if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
       FS_SPROF(24);
-      ok = fs_chol_solve(c, c.ly.hmap);
+      ok = fs_chol_solve(c, c.ly.hmap, c.I(c.ly.Mp));
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
       fs_mulM(c, c.ly.Mp, c.ly.p);

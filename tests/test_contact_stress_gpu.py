@@ -5,9 +5,10 @@
 * Sawyer + table_lack: 64 envs x 50 random-action env steps against 64 oracle envs -- every integer / latch output exact and the
   observation within 1e-3 until an env's FIRST divergence (two correct integrators of a chaotic contact system decorrelate; the
   divergence step is measured and bounded from below, not hidden) -- and every first divergence is EXPLAINED: the step is re-run
-  substep by substep on both sides and the contact lists, Newton iteration counts and states are compared (_explain): measured,
-  10 of 11 are drift with identical contact lists (fp32 rounding amplified by a chaotic contact system), 1 is a finger contact at a
-  distance of 0.1 mm that one side lists a substep earlier."""
+  substep by substep on both sides (each with its own stale gravity compensation; the re-run must land where the fused step landed)
+  and the contact lists, Newton iteration counts and states are compared (_explain): measured, 11 of 13 are drift with identical contact
+  lists (fp32 rounding amplified by a chaotic contact system: most show up first in the joint VELOCITIES of the flailing arm, 1e-3 on
+  2 rad/s), 2 are a finger contact that one side lists a substep earlier."""
 import numpy as np
 import pytest
 import torch
@@ -52,11 +53,18 @@ def _explain(m, dbg, dev_before, ora_before, ctrl, applied, nsub=50):
     """WHY did this env part company inside this step?  Both sides re-run the step's physics substep by substep from their own
     pre-step states (device: a one-env handle through fsim_physics_step(1); oracle: a fresh OracleSim), with the ctrl / qfrc_applied
     the step used, and their INTEGER state is compared on every substep: contact geom lists, Newton iterations, overflow.
-    Returns (k_list, k_q5, k_q3, pair, dist): first substep whose contact lists differ (nsub if none), first substeps whose qpos
-    differ by more than 1e-5 / 1e-3, and -- if the lists differ -- a geom pair only one side lists and its distance there."""
+    Returns (k_list, k_q5, k_q3, pair, dist, iters): first substep whose contact lists differ (nsub if none), first substeps whose qpos
+    differ by more than 1e-5 (or qvel by more than 1e-4: an impact a substep apart shows in the velocities first) / qpos by more than 1e-3, and -- if the
+    lists differ -- a geom pair only one side lists and its distance there."""
     rob = m.geom_is_robot.astype(bool)
     dbg.set_state(**{k: v[None] for k, v in dev_before.items()})
-    dbg.set_state(ctrl=ctrl[None].astype(np.float32), qfrc_applied=applied[None].astype(np.float32))
+    # each side with ITS OWN gravity compensation (_setup_action copies the qfrc_bias of the last forward pass -- one integration old --
+    # into qfrc_applied, furniture.py:3346-3353): on a fast arm that stale bias differs by what the two states differ, and the weak
+    # velocity servos turn it into a velocity difference
+    rd = np.concatenate([m.arm_dofadr, m.grip_dofadr])
+    applied_dev = dev_before["qfrc_applied"].copy()
+    applied_dev[rd] = dev_before["qfrc_bias"][rd]
+    dbg.set_state(ctrl=ctrl[None].astype(np.float32), qfrc_applied=applied_dev[None].astype(np.float32))
     o = OracleSim(m)
     o.set_solver(100, 1e-10, "newton")
     o.reset()
@@ -69,7 +77,7 @@ def _explain(m, dbg, dev_before, ora_before, ctrl, applied, nsub=50):
     k_list, k_q5, k_q3, pair, dist, iters = nsub, nsub, nsub, None, None, []
     for k in range(nsub):
         dbg.physics_step(1)
-        st = dbg.get_state("qpos", "contact_geoms", "solver_iters", "ncon")
+        st = dbg.get_state("qpos", "qvel", "contact_geoms", "solver_iters", "ncon")
         o.step()
         cd = st["contact_geoms"][0].cpu().numpy().reshape(-1, 2)
         keep = lambda cs: sorted(c for c in cs if not (rob[c[0]] and rob[c[1]]))  # (robot link pairs rest at exactly their margin: in or out by rounding)
@@ -82,10 +90,12 @@ def _explain(m, dbg, dev_before, ora_before, ctrl, applied, nsub=50):
             dists = dict(zip((tuple(int(x) for x in c) for c in o.contacts()), o.contact_dists()))
             dist = dists.get(pair)
         dq = np.abs(st["qpos"][0].cpu().numpy() - o.data.qpos).max()
-        if dq > 1e-5 and k_q5 == nsub:
+        dv = np.abs(st["qvel"][0].cpu().numpy() - o.data.qvel).max()
+        if (dq > 1e-5 or dv > 1e-4) and k_q5 == nsub:
             k_q5 = k
         if dq > 1e-3 and k_q3 == nsub:
             k_q3 = k
+    _explain.last = (st["qpos"][0].cpu().numpy().copy(), st["qvel"][0].cpu().numpy().copy(), np.array(o.data.qpos), np.array(o.data.qvel))
     o.close()
     return k_list, k_q5, k_q3, pair, dist, iters
 
@@ -118,8 +128,14 @@ def _run(sim, envs, buf, steps, rng, tol=1e-3, explain=None):
             if err > tol:
                 first[e] = t
                 if explain is not None:  # (the oracle env's ctrl / qfrc_applied are still what _setup_action wrote for this step)
+                    real_d = {k: v[e].cpu().numpy().copy() for k, v in sim.get_state("qpos", "qvel").items()}
+                    real_o = (np.array(envs[e].sim.data.qpos), np.array(envs[e].sim.data.qvel))
                     causes.append((e, t) + _explain(sim.cm, explain, {k: v[e] for k, v in dev_before.items()}, ora_before[e],
                                                     np.array(envs[e].sim.data.ctrl), np.array(envs[e].sim.data.qfrc_applied)))
+                    # the re-run IS the step: the device's 50 single-substep launches land where its fused step landed, the oracle's too
+                    rq, rv, oq, ov = _explain.last
+                    assert np.abs(rq - real_d["qpos"]).max() < 1e-5 and np.abs(rv - real_d["qvel"]).max() < 1e-4, (e, t)
+                    assert np.abs(oq - real_o[0]).max() < 1e-12 and np.abs(ov - real_o[1]).max() < 1e-12, (e, t)
                 continue
             worst_before = max(worst_before, err)
             assert abs(float(rew_d[e]) - r) < 1e-4, (e, t, float(rew_d[e]), r)
