@@ -190,7 +190,7 @@ constexpr Layout make_layout(const LayoutIn &in, int nw = 1) {
   TAKE(scal, SC_WORDS); TAKE(hmap, FSIM_MAPW(in.nv));
   // LDS model cache
   ly.k_begin = o;
-  TAKE(k_dof_parent, in.nv); TAKE(k_r_submask, in.nr); TAKE(k_dof_rbody, in.nv); ly.k_dof_tree = 0; // (dof -> tree goes through dof_rbody, r_tree)
+  TAKE(k_dof_tree, in.nv); ly.k_dof_parent = 0; TAKE(k_r_submask, in.nr); TAKE(k_dof_rbody, in.nv); // (dof -> kinematic tree: the island bookkeeping of the Newton solve; the dof-parent table it replaced was never read)
   TAKE(k_r_parent, in.nr); TAKE(k_r_jtype, in.nr); TAKE(k_r_qposadr, in.nr); TAKE(k_r_dofadr, in.nr); TAKE(k_r_chain, in.nr);
   TAKE(k_r_tree, in.nr); TAKE(k_r_chainadr, in.nr); TAKE(k_r_chainlen, in.nr); ly.k_r_ancmask = 0; TAKE(k_chain_dofs, in.nchain);
   TAKE(k_tree_dofadr, in.ntree); TAKE(k_tree_dofnum, in.ntree); TAKE(k_tree_bodyadr, in.ntree); TAKE(k_tree_bodynum, in.ntree);

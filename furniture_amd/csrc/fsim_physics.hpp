@@ -198,7 +198,7 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
   for (int b = 0; b < nb; b++) nchain = max(nchain, GP(m.r_chainadr)[b] + GP(m.r_chainlen)[b]);
 #define CPI(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.I(c.ly.k_##field)[i_] = m.field[i_]
 #define CPF(field, n) for (int i_ = c.lane; i_ < (n); i_ += 64) c.L[c.ly.k_##field + i_] = m.field[i_]
-  CPI(dof_parent, nv); CPI(dof_rbody, nv);
+  CPI(dof_tree, nv); CPI(dof_rbody, nv);
   CPI(r_parent, nb); CPI(r_jtype, nb); CPI(r_qposadr, nb); CPI(r_dofadr, nb); CPI(r_tree, nb);
   CPI(r_chainadr, nb); CPI(r_chainlen, nb); CPI(chain_dofs, nchain);
   CPI(tree_dofadr, c.D.ntree); CPI(tree_dofnum, c.D.ntree); CPI(tree_bodyadr, c.D.ntree); CPI(tree_bodynum, c.D.ntree);

@@ -540,7 +540,7 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const
     }
     const float g = L[c.ly.grad + d] - acc;
     L[c.ly.grad + d] = g;
-    atomicAdd(tsum + KI(r_tree, bd), g * g);
+    atomicAdd(tsum + KI(dof_tree, d), g * g);
   }
   SYNC();
   return sk;
@@ -553,7 +553,7 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const
 // island iterates.  Such islands are left out of the iteration -- no contact blocks, no projection, no factorisation, p = 0 --
 // which is what a gripping env spends a third of an iteration on and a median env a tenth of a substep.  An island that is below
 // the threshold stays there (its x does not move), so the set only shrinks during a solve.  Returns the squared gradient norm;
-// *am = bit mask of the trees in islands that still move; dact[d] (int, in the M p vector, dead until the solve) = dof d moves.
+// *am = bit mask of the trees in islands that still move (dof d moves iff bit KI(dof_tree, d)).
 template <class Ctx> DEV float fs_active_islands(const Ctx &c, float scale, bool all, int *am) {
   float *L = c.L;
   const float *tsum = L + c.ly.scal + SC_TMP;
@@ -569,17 +569,9 @@ template <class Ctx> DEV float fs_active_islands(const Ctx &c, float scale, bool
   const float thr = 0.25f * c.newton_tol;
   const bool moves = c.lane < c.D.ntree && (all || scale * scale * isum >= thr * thr || !(isum == isum));
   *am = (int)(unsigned)__ballot(moves);
-  int *dact = c.I(c.ly.Mp);
-  for (int d = c.lane; d < c.D.nv; d += 64) {
-    const int on = (*am >> KI(r_tree, KI(dof_rbody, d))) & 1;
-    dact[d] = on;
-    if (!on) L[c.ly.p + d] = 0.0f;
-  }
-  const float g2 = wave_sum(tv);
-  SYNC();
-  return g2;
+  return wave_sum(tv);
 }
-
+#define FS_DOF_MOVES(am_, d_) ((((am_) >> KI(dof_tree, (d_))) & 1) != 0)
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
@@ -720,10 +712,9 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
   }
   FS_HPROF(49);
   // ---- tree blocks on M's pattern: lane = M entry
-  const int *dact = c.I(c.ly.Mp); // (fs_active_islands)
   for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = KM_I(e), j = KM_J(e);
-    if (am != -1 && !dact[i]) continue;
+    if (am != -1 && !FS_DOF_MOVES(am, i)) continue;
     const float *Ab = A + 21 * KI(dof_rbody, i);
     S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
     // t = A * sj
@@ -806,7 +797,7 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
 #undef FS_PAIR_ITEM
 #undef FS_ADD_X
   FS_HPROF(53);
-  if (!ADD && S.lact && S.ljar < 0 && (am == -1 || dact[S.ldof])) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
+  if (!ADD && S.lact && S.ljar < 0 && (am == -1 || FS_DOF_MOVES(am, S.ldof))) atomicAdd(L + c.ly.H + fs_hidx(c, hm, S.ldof, S.ldof), S.ld);
   if (!ADD && S.anyweld)
   for (int e = c.lane; e < c.D.neq; e += 64) {
     float *r = L + c.ly.weld + FSIM_WELDW * e;
@@ -1148,9 +1139,9 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
 }
 
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
-// dact (optional): per dof, does its island take a step (fs_active_islands)?  Lanes of the others act as empty lanes (unit diagonal)
-// and the row phase only runs as many pivots as the last active lane needs; a big island that does not move is skipped.
-template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int *dact = nullptr) {
+// am (-1: every island): trees of the islands that take a step (fs_active_islands).  Lanes of the others act as empty lanes (unit
+// diagonal) and set p = 0, the row phase only runs as many pivots as the last moving lane needs, a big island that does not move is skipped.
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
@@ -1173,8 +1164,8 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int *dac
     if (rsteps > 0) {
       const int dofr = (lw >> (16 * pass)) & 255;
       int dof = dofr == 255 ? -1 : dofr;
-      if (dact) {
-        if (dof >= 0 && !dact[dof]) dof = -1;
+      if (am != -1) {
+        if (dof >= 0 && !FS_DOF_MOVES(am, dof)) { c.L[c.ly.p + dof] = 0.0f; dof = -1; }
         // the islands of a row sit at consecutive positions and are factored independently: pivots beyond the last moving lane are
         // not needed (and an island is all moving or all still, so no island is cut)
         rsteps = min(rsteps, (int)wave_max(dof >= 0 ? (float)((c.lane & 15) + 1) : 0.0f));
@@ -1195,7 +1186,10 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int *dac
 #pragma unroll 1
       for (int q = 0; q < nbig; q++) {
         const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
-        if (dact && !dact[__builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255)]) continue; // this island does not move
+        if (am != -1 && !FS_DOF_MOVES(am, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))) { // this island does not move
+          if (c.lane >= first && c.lane < first + n && dofb != 255) c.L[c.ly.p + dofb] = 0.0f;
+          continue;
+        }
         const bool mine = c.lane >= first && c.lane < first + n && dofb != 255;
         const int dof = mine ? dofb : -1;
 #ifdef FSIM_CHOL_READLANE
@@ -1229,7 +1223,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int *dac
 // filled by exactly ONE wave in lane order and sums across accumulators are taken in a fixed order, so the result is a function
 // of the state alone, as in the one-wave kernel (run-to-run bit-identical) -- though not bit-identical TO the one-wave kernel.
 enum { MW_IDLE = 0, MW_EXIT = 1, MW_COLLIDE = 2, MW_ITER = 3, MW_CHOL = 4, MW_MULM = 5 };
-enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9, MWC_SOLVE = 10 };
+enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9, MWC_SOLVE = 10, MWC_AM = 11 /* trees of the islands that still move (fs_active_islands) */ };
 
 template <class Ctx> DEV void mw_post(const Ctx &c, int cmd) { // main wave only
   int *w = c.I(c.ly.mwc);
@@ -1285,7 +1279,7 @@ template <class Ctx> DEV void mw_zero(const Ctx &c, int npc) {
 // contact blocks: role 1 = the lower body of every contact -> hA, role 2 = the higher body -> hAhi, role 3 = the cached pair blocks
 template <class Ctx> DEV void mw_blocks(const Ctx &c, const SolSlot &S, const SlotK &sk, int role) {
   float *L = c.L;
-  if (!sk.on) return;
+  if (!sk.on) return; // (sk.on: in an active cone zone AND in an island that still moves -- mw_iter_helper)
   const bool first_lo = (S.bt1 & 255) <= (S.bt2 & 255);
   const int blo = (first_lo ? S.bt1 : S.bt2) & 255, bhi = (first_lo ? S.bt2 : S.bt1) & 255;
   const V3 rlo = first_lo ? S.r1 : S.r2, rhi = first_lo ? S.r2 : S.r1;
@@ -1368,11 +1362,12 @@ template <class Ctx> DEV void mw_pair_y(const Ctx &c, int nye, int pairon) {
 }
 
 // tree blocks on M's pattern, waves 0 .. NW - 2: H[i][j] = M[i][j] + cdof_i' hAc[body(i)] cdof_j
-template <class Ctx> DEV void mw_project(const Ctx &c) {
+template <class Ctx> DEV void mw_project(const Ctx &c, const int am) {
   float *L = c.L;
   const int hm = c.ly.hmap;
   for (int e = 64 * c.wave + c.lane; e < c.D.nM; e += 64 * (Ctx::NW - 1)) { // (waves 0 .. NW - 2; the last one adds the pair entries meanwhile)
     int i = KM_I(e), j = KM_J(e);
+    if (!FS_DOF_MOVES(am, i)) continue; // (an island that takes no step: fs_active_islands)
     const float *Ab = L + c.ly.hAc + 21 * KI(dof_rbody, i);
     S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
     V3 ta = v3(Ab[0] * sj.a.x + Ab[1] * sj.a.y + Ab[2] * sj.a.z + Ab[6] * sj.l.x + Ab[7] * sj.l.y + Ab[8] * sj.l.z,
@@ -1428,7 +1423,10 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid)
 #pragma unroll
   for (int q = 0; q < 6; q++) sk.K[q] = j[q];
   const int fl = reinterpret_cast<const int *>(j)[6];
-  sk.on = (fl & 1) != 0;
+  // the islands that were still moving after the LAST iteration's gradient (this iteration's is being computed by main right now; the
+  // set only shrinks, so last iteration's is a superset): the contacts of the others get no blocks
+  const int am0 = __builtin_amdgcn_readfirstlane(w[MWC_AM]);
+  sk.on = (fl & 1) != 0 && (((S.bt1 & 255) != 0 && ((am0 >> (S.bt1 >> 8)) & 1)) || ((S.bt2 & 255) != 0 && ((am0 >> (S.bt2 >> 8)) & 1)));
   sk.zone = 0;
   const bool limit_on = (fl & 2) != 0;
   const int pairon = npc > 0 ? mw_pairon(S, sk) : 0;
@@ -1438,20 +1436,22 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid)
   mw_composite(c);
   c.xbar(); // [4] composite blocks, Y; main has decided whether the iteration goes on
   if (!__builtin_amdgcn_readfirstlane(w[MWC_CONT])) return;
+  const int am = __builtin_amdgcn_readfirstlane(w[MWC_AM]); // (this iteration's: main has stored it before barrier [4])
   if (c.wave == Ctx::NW - 1) { if (npc > 0) mw_pair_items(c, ptot, pairon, true); } // (the projection's 3 x 64 lanes cover M's entries of every in-scope model in one or two passes)
-  else mw_project(c);
+  else mw_project(c, am);
   c.xbar(); // [5] tree blocks stored
   if (c.wave == 1) {
     if (npc > 0) mw_pair_items(c, ptot, pairon, false);
-    if (limit_on) atomicAdd(c.L + c.ly.H + fs_hidx(c, c.ly.hmap, S.ldof, S.ldof), S.ld);
+    if (limit_on && FS_DOF_MOVES(am, S.ldof)) atomicAdd(c.L + c.ly.H + fs_hidx(c, c.ly.hmap, S.ldof, S.ldof), S.ld);
   }
 }
 
 // main's side: gradient (the code of fs_gradient, split at its barriers) beside the helpers' Hessian.  Returns the gradient
 // norm; *go = false: converged, the helpers have left the iteration and H is not complete.
-template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go) {
+template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go, int *am) {
   float *L = c.L;
   int *w = c.I(c.ly.mwc);
+  float *tsum = L + c.ly.scal + SC_TMP; // (fs_active_islands)
 #if defined(FSIM_PROFILE) && !defined(FSIM_NPPROF) && !defined(FSIM_CHOLPROF) && !defined(FSIM_TIMELINE)
   long long tm_ = clock64();
 #define FS_MWPROF(slot) do { long long t1m_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[slot] += (int)((t1m_ - tm_) >> 4); tm_ = t1m_; } while (0)
@@ -1467,6 +1467,7 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
     reinterpret_cast<int *>(j)[6] = (sk.on ? 1 : 0) | ((S.lact && S.ljar < 0) ? 2 : 0);
   }
   mw_post(c, MW_ITER); // [1]
+  if (c.lane < 16) tsum[c.lane] = 0;
   for (int i = c.lane; i < 6 * c.D.nr; i += 64) L[c.ly.G + i] = 0;
   for (int d = c.lane; d < c.D.nv; d += 64) L[c.ly.grad + d] = L[c.ly.Mx + d] - L[c.ly.smooth + d];
   SYNC();
@@ -1492,17 +1493,21 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
       const S6 g0 = lds6(L + c.ly.G + 6 * b0), g1 = lds6(L + c.ly.G + 6 * b1);
       acc += dot6(s_, g0) + (two ? dot6(s_, g1) : 0.0f);
     }
-    L[c.ly.grad + d] -= acc;
+    const float g = L[c.ly.grad + d] - acc;
+    L[c.ly.grad + d] = g;
+    atomicAdd(tsum + KI(dof_tree, d), g * g);
   }
   SYNC();
-  const float gn = sqrtf(fs_dotv(c, c.ly.grad, c.ly.grad));
+  const int *tailh = c.I(c.ly.hmap) + c.D.nv + 64; // (the LDS-resident factorisation of islands beyond the MFMA tile takes them all)
+  const bool every = __builtin_amdgcn_readfirstlane(tailh[MAP_NBIG]) > 0 && __builtin_amdgcn_readfirstlane(tailh[MAP_MAXBIG]) > 31;
+  const float gn = sqrtf(fs_active_islands(c, scale, every, am));
   *go = !(scale * gn < c.newton_tol);
-  if (c.lane == 0) w[MWC_CONT] = *go ? 1 : 0;
+  if (c.lane == 0) { w[MWC_CONT] = *go ? 1 : 0; w[MWC_AM] = *am; }
   FS_MWPROF(54);
   c.xbar(); // [4]
   FS_MWPROF(55);
   if (!*go) return gn;
-  mw_project(c);
+  mw_project(c, *am);
   FS_MWPROF(56);
   c.xbar(); // [5]
   FS_MWPROF(57);
@@ -1510,20 +1515,23 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
 }
 
 // the factorisation of fs_chol_solve in two halves: the DPP rows (helper 1) and the big islands (main)
-template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp) {
+template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp, const int am) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
-  const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]) & 255;
+  int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]) & 255;
   int bad = 0;
   const int dofr = lw & 255;
-  const int dof = dofr == 255 ? -1 : dofr;
+  int dof = dofr == 255 ? -1 : dofr;
+  if (dof >= 0 && !FS_DOF_MOVES(am, dof)) { c.L[c.ly.p + dof] = 0.0f; dof = -1; } // (as in fs_chol_solve)
+  rsteps = min(rsteps, (int)wave_max(dof >= 0 ? (float)((c.lane & 15) + 1) : 0.0f));
+  if (rsteps == 0) return;
   if (rsteps <= 6) bad |= fs_chol_phase<6>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   else if (rsteps <= 12) bad |= fs_chol_phase<12>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   if (__ballot(bad != 0) && c.lane == 0) c.I(c.ly.mwc)[MWC_BAD] = 1;
 }
-template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp) {
+template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
@@ -1533,6 +1541,11 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp) {
 #pragma unroll 1
     for (int q = 0; q < nbig; q++) {
       const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]), n = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q + 1]);
+      const int lwb = c.I(mp)[nv + c.lane];
+      if (!FS_DOF_MOVES(am, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))) { // this island does not move
+        if (c.lane >= first && c.lane < first + n && ((lwb >> 8) & 255) != 255) c.L[c.ly.p + ((lwb >> 8) & 255)] = 0.0f;
+        continue;
+      }
       bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
     }
   }
@@ -1550,7 +1563,7 @@ template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
     if (cmd == MW_EXIT) break;
     if (cmd == MW_COLLIDE) { sid = -1; if (c.wave == 1) fs_collide(c); } // (a new substep: the slot records will change)
     else if (cmd == MW_ITER) mw_iter_helper(c, S, sid);
-    else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap); }
+    else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap, __builtin_amdgcn_readfirstlane(w[MWC_AM])); }
     else if (cmd == MW_MULM) { if (c.wave == 1) fs_mulM(c, __builtin_amdgcn_readfirstlane(w[MWC_A0]), __builtin_amdgcn_readfirstlane(w[MWC_A1])); }
   }
 }
@@ -1612,7 +1625,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     mw = !S.anyweld && S.npc >= 0 && c.D.nv <= 64 && Ctx::NS == 1;
     if (mw) {
       c.I(c.ly.jst)[FSIM_JSTW * c.lane + 7] = S.pid;
-      if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; }
+      if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; w[MWC_AM] = -1; }
     }
   }
   for (; it < c.newton_maxit; it++) {
@@ -1622,7 +1635,8 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     if constexpr (Ctx::NW > 1) if (mw) {
       iterated = true;
       bool go;
-      mw_iterate_main(c, S, sk, scale, &go);
+      int am;
+      mw_iterate_main(c, S, sk, scale, &go, &am);
       FS_SPROF(24);
       if (!go) break;
       int *w = c.I(c.ly.mwc);
@@ -1631,12 +1645,12 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       if (nbig > 0 && rsteps > 0) { // the DPP rows on helper 1 beside the big island(s) here
         if (c.lane == 0) w[MWC_BAD] = 0;
         mw_post(c, MW_CHOL);
-        const int bad = mw_chol_big(c, c.ly.hmap);
+        const int bad = mw_chol_big(c, c.ly.hmap, am);
         mw_post(c, MW_IDLE);
         ok = !(bad | __builtin_amdgcn_readfirstlane(w[MWC_BAD]));
       } else {
         mw_post(c, MW_IDLE); // (helper 1 is still adding the body-pair entries)
-        ok = fs_chol_solve(c, c.ly.hmap);
+        ok = fs_chol_solve(c, c.ly.hmap, am);
       }
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
@@ -1658,7 +1672,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       fs_hessian(c, sk, S, am);
       if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
       FS_SPROF(24);
-      ok = fs_chol_solve(c, c.ly.hmap, c.I(c.ly.Mp));
+      ok = fs_chol_solve(c, c.ly.hmap, am);
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
       fs_mulM(c, c.ly.Mp, c.ly.p);

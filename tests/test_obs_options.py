@@ -61,7 +61,7 @@ def test_obs_options_match_oracle_env():
     env.close()
 
 
-@pytest.mark.parametrize("flag", ["reset_robot_after_attach", "no_collision", "load_demo", "record_demo"])
+@pytest.mark.parametrize("flag", ["reset_robot_after_attach", "load_demo", "record_demo"])
 def test_unsupported_reference_options_fail_loudly(flag):
     """Options of furniture/config/furniture.py that change the reset / connect flow and are not built raise before any device work
     (no silent ignore); checked on CPU: the guard sits ahead of the FSim construction."""
