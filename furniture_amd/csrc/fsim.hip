@@ -101,6 +101,9 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   const int lane = c.lane;
   const EnvCfg &cfg = a.cfg;
   float *rec = a.state + (size_t)env * c.ly.stride;
+#if defined(FSIM_PROFILE) && defined(FSIM_TIMELINE)
+  const long long tw0_ = wall_clock64(); // (100 MHz, one counter for the whole device: clock64() has an offset per XCD)
+#endif
   load_record(L, rec, c.ly.stride, lane);
   const int twords = reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS]; // (set by fs_load_cache: survives the per-env clearing)
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
@@ -130,13 +133,14 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   // development: when and where this workgroup ran (scripts/dev/timeline.py: how many are resident at a time)
   if (lane == 0) {
     int *ps_ = reinterpret_cast<int *>(L + c.ly.scal);
-    ps_[53] = (int)((t_entry >> 6) & 0x7fffffff); ps_[54] = (int)((clock64() >> 6) & 0x7fffffff);
+    ps_[53] = (int)(tw0_ & 0x7fffffff); ps_[54] = (int)(wall_clock64() & 0x7fffffff);
     ps_[50] = (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID, 32 bits
     int xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ps_[49] = xcc;
   }
   SYNC();
 #endif
-  if (a.prof && lane < 48) a.prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + lane] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
+  // (the debug row: words [0, nv) are read back as `qacc`, the ones behind that as `contact_geoms` -- the fields whose read-back is a plain copy)
+  if (a.prof && lane < 48) a.prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + (lane < c.D.nv ? lane : 7 * c.D.nr + 4 + lane)] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
 #endif
   store_record(rec, L, c.ly.stride, lane);
 }

@@ -666,8 +666,10 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
     if (S.pid >= 0) FS_ADD_X(X + FSIM_XW * S.pid); // cached pair block of this slot (zeroed above)
   }
   FS_HPROF(48);
-  // the subtree sums are only needed when a non-root body (a robot link beyond the base) carries a contact block
-  const bool deep = on && ((blo > 0 && KI(r_parent, blo) > 0) || (bhi > 0 && KI(r_parent, bhi) > 0));
+  // the subtree sums are only needed when a non-root body (a robot link beyond the base) carries a contact block: dm = those bodies
+  int dm = 0;
+  if (on) dm = ((blo > 0 && KI(r_parent, blo) > 0) ? 1 << blo : 0) | ((bhi > 0 && KI(r_parent, bhi) > 0) ? 1 << bhi : 0);
+  dm = wave_or(dm);
   SYNC();
   // cached pairs, stage 1: Y_q = X_q * cdof(chain(hi_q)), one lane per column, written over X_q
   int pairon = 0;
@@ -697,25 +699,24 @@ template <class Ctx, bool ADD = false> DEV void fs_hessian(const Ctx &c, const S
       }
     }
   }
-  // ---- composite blocks: children are numbered after their parents
-  if (__ballot(deep)) {
-    // lane = component: a lane only ever touches its own component of every block, so the child -> parent chain needs
-    // no barrier (a wave's LDS operations complete in order).  (Measured alternatives, both slower on gripping envs, 21 kcycles/substep here:
-    // lane-per-(body, component) bitmask sums with register staging 25, register-carried chain with prefetch 28 --
-    // this code is bound by instruction count, not by the LDS round trips.)
-    if (c.lane < 21)
-      for (int b = c.D.nr - 1; b >= 1; b--) {
-        int p = KI(r_parent, b);
-        if (p > 0) A[21 * p + c.lane] += A[21 * b + c.lane];
-      }
-    SYNC();
-  }
+  // ---- composite blocks A^c_b = sum of A over the subtree of b.  Only the contact-carrying non-root bodies (dm: a finger or two)
+  // have anything to pass up, so the projection below adds THEIR blocks to the block of body(i) on the fly -- instead of a chain walk
+  // over every body (one dependent LDS round trip per link of the arm: 4 kcycles per Newton iteration of a gripping env, 1.6 k now).
   FS_HPROF(49);
   // ---- tree blocks on M's pattern: lane = M entry
   for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = KM_I(e), j = KM_J(e);
     if (am != -1 && !FS_DOF_MOVES(am, i)) continue;
-    const float *Ab = A + 21 * KI(dof_rbody, i);
+    const int bi = KI(dof_rbody, i);
+    float Ab[21];
+#pragma unroll
+    for (int q = 0; q < 21; q++) Ab[q] = A[21 * bi + q];
+    if (dm)
+      for (int mm = KI(r_submask, bi) & dm & ~(1 << bi); mm; mm &= mm - 1) {
+        const float *Ad = A + 21 * (__ffs(mm) - 1);
+#pragma unroll
+        for (int q = 0; q < 21; q++) Ab[q] += Ad[q];
+      }
     S6 si = lds6(L + c.ly.cdof + 6 * i), sj = lds6(L + c.ly.cdof + 6 * j);
     // t = A * sj
     V3 ta = v3(Ab[0] * sj.a.x + Ab[1] * sj.a.y + Ab[2] * sj.a.z + Ab[6] * sj.l.x + Ab[7] * sj.l.y + Ab[8] * sj.l.z,
@@ -1286,6 +1287,13 @@ template <class Ctx> DEV void mw_blocks(const Ctx &c, const SolSlot &S, const Sl
   const float *K = sk.K;
   const V3 K0 = v3(K[0], K[1], K[2]), K1 = v3(K[1], K[3], K[4]), K2 = v3(K[2], K[4], K[5]);
   if (role <= 2) {
+    // (the linear-linear part K of the HIGHER body's block is added by helper 1, into its own array -- the composite pass sums the two
+    //  arrays anyway: most contacts have the table (body 0, no block) as their lower body, so helper 1 has lanes to spare while helper 2
+    //  carries every contact; an LDS atomic costs ~4 cycles per active lane, scripts/dev/micro/atom.hip)
+    if (role == 1 && bhi != 0) {
+      float *Ah = L + c.ly.hA + 21 * bhi;
+      atomicAdd(Ah + 15, K[0]); atomicAdd(Ah + 16, K[1]); atomicAdd(Ah + 17, K[2]); atomicAdd(Ah + 18, K[3]); atomicAdd(Ah + 19, K[4]); atomicAdd(Ah + 20, K[5]);
+    }
     const int b = role == 1 ? blo : bhi;
     if (b == 0) return;
     const V3 rr = role == 1 ? rlo : rhi;
@@ -1296,7 +1304,7 @@ template <class Ctx> DEV void mw_blocks(const Ctx &c, const SolSlot &S, const Sl
     atomicAdd(Ab + 0, a0.x); atomicAdd(Ab + 1, a0.y); atomicAdd(Ab + 2, a0.z); atomicAdd(Ab + 3, a1.y); atomicAdd(Ab + 4, a1.z); atomicAdd(Ab + 5, a2.z);
     atomicAdd(Ab + 6, G0.x); atomicAdd(Ab + 7, G0.y); atomicAdd(Ab + 8, G0.z); atomicAdd(Ab + 9, G1.x); atomicAdd(Ab + 10, G1.y); atomicAdd(Ab + 11, G1.z);
     atomicAdd(Ab + 12, G2.x); atomicAdd(Ab + 13, G2.y); atomicAdd(Ab + 14, G2.z);
-    atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]);
+    if (role == 1) { atomicAdd(Ab + 15, K[0]); atomicAdd(Ab + 16, K[1]); atomicAdd(Ab + 17, K[2]); atomicAdd(Ab + 18, K[3]); atomicAdd(Ab + 19, K[4]); atomicAdd(Ab + 20, K[5]); }
   } else if (S.pid >= 0) {
     // X = [[Glo * Rhi, Glo], [K * Rhi, K]],  v' * Rhi = (rhi x v)'  row-wise  (fs_hessian, FS_ADD_X)
     V3 c0 = cross(rlo, K0), c1 = cross(rlo, K1), c2 = cross(rlo, K2);
@@ -1408,16 +1416,25 @@ template <class Ctx> DEV void mw_pair_items(const Ctx &c, int ptot, int pairon, 
 // (S: the helper's copy of the slot records, loaded once per solve -- sid tells which solve it belongs to.  The cone state of the
 //  iteration -- which slots are in an active zone, their world stiffness K -- is computed ONCE, by main, and staged in LDS: three
 //  helpers re-deriving it from J a - aref cost more than the block atomics they then issue)
-template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid) {
+template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid, int &am_last) {
   const int *w = c.I(c.ly.mwc);
   const int npc = __builtin_amdgcn_readfirstlane(w[MWC_NPC]), ptot = __builtin_amdgcn_readfirstlane(w[MWC_PTOT]), nye = __builtin_amdgcn_readfirstlane(w[MWC_NYE]);
   const int solve = __builtin_amdgcn_readfirstlane(w[MWC_SOLVE]);
+#if defined(FSIM_PROFILE) && !defined(FSIM_NPPROF) && !defined(FSIM_CHOLPROF) && !defined(FSIM_TIMELINE)
+  // development: where helper 1 / helper 3 spend the time between barriers [1] and [3] (slots 58..60 / 61..63: zero | state + blocks | wait)
+  long long thl_ = clock64();
+#define FS_HLPROF(k_) do { long long t1h_ = clock64(); if (c.lane == 0 && (c.wave & 1)) c.I(c.ly.scal)[58 + 3 * (c.wave >> 1) + (k_)] += (int)((t1h_ - thl_) >> 4); thl_ = t1h_; } while (0)
+#else
+#define FS_HLPROF(k_) do { } while (0)
+#endif
   mw_zero(c, npc);
+  FS_HLPROF(0);
   const float *j = c.L + c.ly.jst + FSIM_JSTW * c.lane;
   if (solve != sid) {
     S = fs_load_slots(c);
     S.pid = reinterpret_cast<const int *>(j)[7];
     sid = solve;
+    am_last = -1; // (first iteration of a solve: every island)
   }
   SlotK sk;
 #pragma unroll
@@ -1425,18 +1442,24 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid)
   const int fl = reinterpret_cast<const int *>(j)[6];
   // the islands that were still moving after the LAST iteration's gradient (this iteration's is being computed by main right now; the
   // set only shrinks, so last iteration's is a superset): the contacts of the others get no blocks
-  const int am0 = __builtin_amdgcn_readfirstlane(w[MWC_AM]);
+  const int am0 = am_last;
   sk.on = (fl & 1) != 0 && (((S.bt1 & 255) != 0 && ((am0 >> (S.bt1 >> 8)) & 1)) || ((S.bt2 & 255) != 0 && ((am0 >> (S.bt2 >> 8)) & 1)));
   sk.zone = 0;
   const bool limit_on = (fl & 2) != 0;
   const int pairon = npc > 0 ? mw_pairon(S, sk) : 0;
   mw_blocks(c, S, sk, c.wave);
-  c.xbar(); // [3] blocks complete, H zeroed
-  if (c.wave == Ctx::NW - 1 && npc > 0) mw_pair_y(c, nye, pairon);
-  mw_composite(c);
-  c.xbar(); // [4] composite blocks, Y; main has decided whether the iteration goes on
-  if (!__builtin_amdgcn_readfirstlane(w[MWC_CONT])) return;
-  const int am = __builtin_amdgcn_readfirstlane(w[MWC_AM]); // (this iteration's: main has stored it before barrier [4])
+  FS_HLPROF(1);
+  c.xbar(); // [3] blocks complete, H zeroed; main has decided whether the iteration goes on
+  FS_HLPROF(2);
+  const bool cont = __builtin_amdgcn_readfirstlane(w[MWC_CONT]) != 0;
+  const int am = __builtin_amdgcn_readfirstlane(w[MWC_AM]); // (this iteration's: main has stored it before barrier [3])
+  am_last = am;
+  if (cont) {
+    if (c.wave == Ctx::NW - 1 && npc > 0) mw_pair_y(c, nye, pairon);
+    mw_composite(c);
+  }
+  c.xbar(); // [4] composite blocks, Y
+  if (!cont) return;
   if (c.wave == Ctx::NW - 1) { if (npc > 0) mw_pair_items(c, ptot, pairon, true); } // (the projection's 3 x 64 lanes cover M's entries of every in-scope model in one or two passes)
   else mw_project(c, am);
   c.xbar(); // [5] tree blocks stored
@@ -1478,8 +1501,9 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
   }
   if (S.lact && S.ljar < 0) atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar);
   FS_MWPROF(50);
-  c.xbar(); // [3]
-  FS_MWPROF(53);
+  SYNC();
+  // J'f, the island norms and the decision whether the iteration goes on: main's own data only (the wrenches above are this wave's
+  // atomics), so all of it runs BEFORE barrier [3], while the helpers are still filling the Hessian blocks
   for (int d = c.lane; d < c.D.nv; d += 64) {
     const int bd = KI(dof_rbody, d);
     const S6 s_ = lds6(L + c.ly.cdof + 6 * d);
@@ -1502,8 +1526,11 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
   const bool every = __builtin_amdgcn_readfirstlane(tailh[MAP_NBIG]) > 0 && __builtin_amdgcn_readfirstlane(tailh[MAP_MAXBIG]) > 31;
   const float gn = sqrtf(fs_active_islands(c, scale, every, am));
   *go = !(scale * gn < c.newton_tol);
+  // (the helpers gate THIS iteration's blocks with the set they kept from the last one -- a register of theirs, not this word)
   if (c.lane == 0) { w[MWC_CONT] = *go ? 1 : 0; w[MWC_AM] = *am; }
   FS_MWPROF(54);
+  c.xbar(); // [3]
+  FS_MWPROF(53);
   c.xbar(); // [4]
   FS_MWPROF(55);
   if (!*go) return gn;
@@ -1556,13 +1583,13 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am) {
 template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
   const int *w = c.I(c.ly.mwc);
   SolSlot S = {};
-  int sid = -1;
+  int sid = -1, am_last = -1;
   for (int k = 0;; k++) {
     c.xbar();
     const int cmd = __builtin_amdgcn_readfirstlane(w[k & 1]);
     if (cmd == MW_EXIT) break;
     if (cmd == MW_COLLIDE) { sid = -1; if (c.wave == 1) fs_collide(c); } // (a new substep: the slot records will change)
-    else if (cmd == MW_ITER) mw_iter_helper(c, S, sid);
+    else if (cmd == MW_ITER) mw_iter_helper(c, S, sid, am_last);
     else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap, __builtin_amdgcn_readfirstlane(w[MWC_AM])); }
     else if (cmd == MW_MULM) { if (c.wave == 1) fs_mulM(c, __builtin_amdgcn_readfirstlane(w[MWC_A0]), __builtin_amdgcn_readfirstlane(w[MWC_A1])); }
   }

@@ -19,8 +19,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     act.uniform_(-1, 1, generator=g); torch.cuda.synchronize()
     t0 = time.time(); sim.step(act, obs, rew, done, info); sim.sync(); dt = time.time() - t0
     p = sim.get_state("qacc")["qacc"].view(torch.int32).cpu().numpy().astype(np.int64)
-    st, en, hw, xcc = p[:, 37] * 64, p[:, 38] * 64, p[:, 34], p[:, 33]
-    en = np.where(en < st, en + (1 << 37), en)
+    st, en, hw, xcc = p[:, 37], p[:, 38], p[:, 34], p[:, 33]  # (10 ns ticks of the device-wide 100 MHz counter)
+    en = np.where(en < st, en + (1 << 31), en)
     t_0 = st.min(); st -= t_0; en -= t_0
     span = en.max()
     ev = np.concatenate([np.stack([st, np.ones(N)], 1), np.stack([en, -np.ones(N)], 1)])

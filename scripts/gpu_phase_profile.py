@@ -21,7 +21,8 @@ names = ["kin+crb+factor", "collide", "vel+smooth", "constraints", "solve"]
 for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     act.uniform_(-1, 1, generator=g); torch.cuda.synchronize()
     t0 = time.time(); sim.step(act, obs, rew, done, info); sim.sync(); dt = time.time() - t0
-    pall = sim.get_state("qacc")["qacc"].view(torch.int32)[:, :48].cpu().numpy().astype(np.int64)
+    st_ = sim.get_state("qacc", "contact_geoms")  # (the profile words lie over the debug row: qacc, and behind it contact_geoms)
+    pall = torch.cat([st_["qacc"].view(torch.int32), st_["contact_geoms"].reshape(N, -1).view(torch.int32)], 1)[:, :48].cpu().numpy().astype(np.int64)
     p = pall[:, :16]
     cyc = p[:, :5] * 16
     tot = cyc.sum(axis=1)
@@ -61,6 +62,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
             q = pall[e, 32:42] * 16 / max(1, nit[e]) / 1e3
             print("    env %d multi-wave iteration, main wave kcyc per Newton iteration: stage+post+zero+K %.2f wait[2] %.2f wrench atomics %.2f wait[3] %.2f J'f+norm %.2f wait[4] %.2f project %.2f wait[5] %.2f" % (
                 e, q[0], q[1], q[2], q[5], q[6], q[7], q[8], q[9]))
+            h = pall[e, 42:48] * 16 / max(1, nit[e]) / 1e3
+            print("    env %d helpers between barriers [1] and [3], kcyc per Newton iteration: helper 1 zero %.2f state+blocks %.2f wait %.2f | helper 3 zero %.2f state+blocks %.2f wait %.2f" % (e, h[0], h[1], h[2], h[3], h[4], h[5]))
     if t in (3, 8):
         order = np.argsort(-tot)[:5]
         for e in order:

@@ -71,7 +71,7 @@ def check_segment(name, traj, slip=6e-3, fp32=False):
         # fell 8 cm and came to rest within the frame (fp32: the column slides out of the opening fingers ~40 substeps later and is still
         # 1.5 cm up when the frame ends; it lies where the recording has it one frame later)
         assert dp[4, COL] < (2.5e-2 if fp32 else 4e-3) and dq[4, COL] < (0.15 if fp32 else 0.04)  # (fp32: caught in mid-fall, tumbling)
-        assert dp[5:, COL].max() < 4e-3 and dq[5:, COL].max() < (0.06 if fp32 else 0.045)  # ... and stays there (a lying column is free to roll: 2.6 deg)
+        assert dp[5:, COL].max() < (6e-3 if fp32 else 4e-3) and dq[5:, COL].max() < (0.06 if fp32 else 0.045)  # ... and stays there (a lying column is free to roll: 2.6 deg; fp32: where it comes to rest after the tumble moves by 1 mm with the summation order of the solver)
         z = np.array([p[COL, 2] for p in traj[5:]])
         assert np.abs(z - 0.0149).max() < 1e-4                                 # MuJoCo's resting height of the lying column
         assert dp[:, BASE].max() < 5e-4 and dp[:, SEAT].max() < 1e-3           # nothing else moves (the arm brushes the seat: 0.5 mm)
