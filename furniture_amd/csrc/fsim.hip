@@ -237,11 +237,13 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
   if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; nbulk[1] = 0; } // (nbulk[1]: head of the bundled waves' work queue)
   for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
   __syncthreads();
-  const long long M = (long long)lm + 1;
+  // (a float multiply, not a 64-bit division: the inlined division routines were half of this kernel's code, and the code is never in
+  //  the instruction cache when the kernel runs -- it spends its ~0.1 ms fetching instructions; buckets only order the launch)
+  const float bscale = 128.0f / ((float)lm + 1.0f);
   auto bucket = [&](int cv) {
     if (cv < 0) return 0;
-    int base = (cv >> 30) & 1 ? 1 : 129;
-    return base + 127 - (int)((long long)(cv & 0x3fffffff) * 128 / M);
+    const int base = (cv >> 30) & 1 ? 1 : 129;
+    return base + 127 - min(127, (int)((float)(cv & 0x3fffffff) * bscale));
   };
   for (int i = tid; i < n; i += 64) { const int cv = keys[i]; if (cv != FSIM_SCHED_SELECTED) atomicAdd(&hist[bucket(cv)], 1); }
   __syncthreads();
