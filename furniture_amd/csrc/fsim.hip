@@ -93,6 +93,7 @@ struct StepArgs {
   const float *init_state;
   const uint8_t *init_mask;
   int *nreset;
+  const EnvCfg *cfg_dev; // `cfg` again, in device memory (for the out-of-line env_reset: EnvResetIO)
 };
 // load_cache: the wave's LDS copy of the model tables is not there yet (a bundled wave steps several envs one after the other
 // and loads it once)
@@ -124,8 +125,9 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   io.init_state = (a.init_state && a.init_mask && a.init_mask[env]) ? a.init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
   io.cost = a.cost ? a.cost + env : nullptr;
   io.t0 = t_entry;
+  io.cfg_dev = a.cfg_dev;
   if (a.do_step) env_step(c, cfg, io);
-  else if (!a.reset_mask || a.reset_mask[env]) { env_reset(c, &cfg, &io); env_write_obs(c, cfg, io); }
+  else if (!a.reset_mask || a.reset_mask[env]) { env_reset(c, a.cfg_dev, env_reset_io(io)); env_write_obs(c, cfg, io); }
   if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   SYNC();
 #ifdef FSIM_PROFILE
@@ -335,6 +337,8 @@ struct fsim {
   Layout ly{};
   fsim_config_t cfg{};
   EnvCfg ecfg{};
+  EnvCfg ecfg_sent{};          // what d_ecfg holds
+  EnvCfg *d_ecfg = nullptr;    // device copy of ecfg (StepArgs::cfg_dev), refreshed by launch_env when ecfg has changed
   void *d_model = nullptr;
   DModel *d_m = nullptr;
   Layout *d_ly = nullptr;
@@ -674,7 +678,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn);
+  hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -867,6 +871,13 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.n_noise = s->n_noise; a.reset_mask = mask; a.do_step = do_step;
   a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = do_step ? s->d_nreset : nullptr;
+  if (!s->d_ecfg) { HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); }
+  if (memcmp(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg)) != 0) { // (rare: max_episode_steps, dense tables, pre-assembled starts)
+    HIPCHK(hipMemcpyAsync(s->d_ecfg, &s->ecfg, sizeof(EnvCfg), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream)); // (pageable source: the copy must have left the host struct before it can change again)
+    memcpy(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg));
+  }
+  a.cfg_dev = s->d_ecfg;
   if (mw_all)
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr);
   else if (mw_auto)

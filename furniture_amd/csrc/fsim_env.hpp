@@ -47,7 +47,16 @@ struct EnvIO {
   int *nreset;    // device counter: envs that consumed their reset table in this launch (host reads it instead of scanning info)
   int *cost;      // scheduler key written by env_step (shader cycles >> 10 of the step just taken, -1 = will time out next step)
   long long t0;   // shader clock at kernel entry
+  const EnvCfg *cfg_dev; // the handle's copy of the EnvCfg in device memory: what the out-of-line env_reset is given (see EnvResetIO)
 };
+// What env_reset reads of an env's EnvIO, passed BY VALUE (registers).  env_reset is a real function: handing it the addresses of the
+// kernel's EnvCfg (a kernel argument) and EnvIO made the compiler keep both in scratch -- a private copy per LANE, ~100 dwords
+// written by every lane of every launch.
+struct EnvResetIO {
+  const float *tab_parts, *tab_noise, *init_state;
+  int n_noise;
+};
+DEV EnvResetIO env_reset_io(const EnvIO &io) { return EnvResetIO{io.tab_parts, io.tab_noise, io.init_state, io.n_noise}; }
 
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
@@ -216,7 +225,7 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
 //   CTRL (separate instantiation, so the default path's code and register allocation are untouched): the torque-level arm
 //   controller runs before every substep (_do_controller_step, furniture.py:3065-3093); pass -1 is the sim.forward() that
 //   precedes the loop, whose results the first _pre_action reads.
-template <bool CTRL, class Ctx> __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
+template <bool CTRL, class Ctx> static __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
   FS_REBUILD_CTX(cv);
   const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
   // (ONE inlined copy of the forward pass: the forward-only mode leaves the loop after its first pass -- with a call site of its
@@ -828,7 +837,7 @@ template <class Ctx> DEV void env_gravity_comp(const Ctx &c) {
   for (int k = c.lane; k < c.D.ngripj; k += 64) c.L[c.ly.qfrcapp + GP(m.grip_dofadr)[k]] = c.L[c.ly.qfrcbias + GP(m.grip_dofadr)[k]];
   SYNC();
 }
-template <class Ctx> DEV void env_init_robot(const Ctx &c, const EnvIO &io, int draw, float move_speed) {
+template <class Ctx> DEV void env_init_robot(const Ctx &c, const EnvResetIO &io, int draw, float move_speed) {
   CModel &m = c.m;
   if (c.D.agent == 2 && c.lane < 2) { // furniture.py:1763-1768: cursors at x = -+0.2, half a move step above the floor
     float *p = c.L + c.ly.env + E_GROUP + c.D.nparts + EC_POS + 3 * c.lane;
@@ -860,10 +869,11 @@ template <class Ctx> DEV void env_settle_parts(const Ctx &c) {
   }
 }
 
-template <class Ctx> __device__ __noinline__ void env_reset(Ctx cv, const EnvCfg *cfgp, const EnvIO *iop) {
-  FS_REBUILD_CTX(cv);
-  const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp));
-  const EnvIO io = *iop;
+template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, const EnvCfg *cfgp, const EnvResetIO io) {
+  extern __shared__ float fs_lds_[];
+  typedef FsIn<Ctx0> Ctx; // (see FsIn: the physics routine called from here is not the one the step calls)
+  const Ctx c(fs_rebuild(cv, fs_lds_));
+  const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp)); // (device memory: EnvIO::cfg_dev)
   CModel &m = c.m;
   float *L = c.L;
   int *E = c.I(c.ly.env);
@@ -1124,7 +1134,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // k+3, so from the following episode on both streams agree again; only the placement of the episode right after an
     // unstable step differs (same distribution).  Keeping two tables per env on the device would remove it.
     const bool skip_reset = cfg.auto_reset && !cfg.dense;
-    if (!skip_reset) env_reset(c, &cfg, &io);
+    if (!skip_reset) env_reset(c, io.cfg_dev, env_reset_io(io));
     if (c.lane == 0) { E[E_FAIL] = skip_reset ? 2 : 1; scal[SC_BAD] = 0; if (skip_reset) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; } }
     SYNC();
     if (!skip_reset) fs_substeps(c, 1, 3);
@@ -1231,7 +1241,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   SYNC();
   terminal = scal[14];
   const int nit_step = scal[SC_NITSUM];
-  if (terminal && cfg.auto_reset) env_reset(c, &cfg, &io); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
+  if (terminal && cfg.auto_reset) env_reset(c, io.cfg_dev, env_reset_io(io)); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
   else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
   { // what the scheduler of the next launch reads (k_schedule): this step's Newton iterations (0 after a reset), the robot-part clearance now
     const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;

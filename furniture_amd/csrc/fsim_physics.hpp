@@ -99,6 +99,15 @@ template <class S, int NW_, bool B_> DEV SpecCtx<S, NW_, B_> fs_rebuild(const Sp
 #define FS_REBUILD_CTX(cv)            \
   extern __shared__ float fs_lds_[];  \
   const Ctx c = fs_rebuild(cv, fs_lds_)
+// The same context under another TYPE, for the code under env_reset: the out-of-line physics routine that code calls is then an
+// instantiation of its own, and the one the step calls is called from KERNELS only.  A function whose callers are all kernels
+// keeps no callee-saved registers (nothing above it has live registers); called from env_reset as well, fs_substeps_t saved 113
+// VGPRs per lane to scratch on every call -- 29 KB per wave, three calls per env-step: the 72 KB of HBM writes per env-step the
+// counters showed (profiles/r03_e_pmc_counters.txt).
+template <class B> struct FsIn : B {
+  DEV explicit FsIn(const B &b) : B(b) {}
+};
+template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { return FsIn<B>(fs_rebuild(static_cast<const B &>(cv), lds)); }
 
 
 // Walk the set bits of a mask three per trip: i0 is valid, i1 / i2 fall back to i0 with their flag cleared.  A loop with a
