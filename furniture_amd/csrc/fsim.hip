@@ -86,6 +86,7 @@ struct StepArgs {
   uint8_t *done;
   int *info;
   const float *tab_parts, *tab_noise;
+  const float *tab_attach; // [n][narmj]: joint noise of each env's next attach (config.reset_robot_after_attach), or null
   int n_noise;
   const uint8_t *reset_mask;
   int do_step;
@@ -121,6 +122,7 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   io.tab_parts = a.tab_parts ? a.tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
   io.tab_noise = a.tab_noise ? a.tab_noise + (size_t)env * a.n_noise * c.D.narmj : nullptr;
   io.n_noise = a.n_noise;
+  io.tab_attach = a.tab_attach ? a.tab_attach + (size_t)env * c.D.narmj : nullptr;
   io.nreset = a.nreset;
   io.init_state = (a.init_state && a.init_mask && a.init_mask[env]) ? a.init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
   io.cost = a.cost ? a.cost + env : nullptr;
@@ -342,7 +344,7 @@ struct fsim {
   void *d_model = nullptr;
   DModel *d_m = nullptr;
   Layout *d_ly = nullptr;
-  float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr;
+  float *d_state = nullptr, *d_aux = nullptr, *d_tab_parts = nullptr, *d_tab_noise = nullptr, *d_tab_attach = nullptr;
   int *d_cost = nullptr, *d_order = nullptr; // longest-job-first scheduling (k_schedule)
   int *d_nreset = nullptr, *h_nreset = nullptr; // envs that consumed their reset table in the last step launch (device counter, pinned host copy)
   float *d_init = nullptr;       // set_init_qpos: [n][nq + nv] state the masked envs' resets start from
@@ -679,7 +681,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
-  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
+  hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -826,6 +828,28 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
   return FSIM_OK;
 }
 
+extern "C" int fsim_set_attach_noise(fsim_t *s, const uint8_t *mask, const float *noise) {
+  if (!s || !noise) FAIL(FSIM_EINVAL, "bad args");
+  if (!s->ecfg.reset_robot_after_attach) FAIL(FSIM_EINVAL, "fsim_set_attach_noise: the handle was not created with reset_robot_after_attach = 1");
+  HIPCHK(hipSetDevice(s->device));
+  const size_t w = (size_t)s->m.narmj;
+  if (w == 0) return FSIM_OK; // (the Cursor agent: _initialize_robot_pos draws nothing)
+  if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+  if (!s->d_tab_attach) { // (cleared on the SAME stream the rows are then copied on: a null-stream memset is not ordered against it)
+    HIPCHK(hipMalloc(&s->d_tab_attach, (size_t)s->n_envs * w * 4 + 16));
+    HIPCHK(hipMemsetAsync(s->d_tab_attach, 0, (size_t)s->n_envs * w * 4, s->xfer));
+  }
+  for (int e = 0; e < s->n_envs;) { // one copy per run of consecutive masked envs
+    if (mask && !mask[e]) { e++; continue; }
+    int e1 = e;
+    while (e1 < s->n_envs && (!mask || mask[e1])) e1++;
+    HIPCHK(hipMemcpyAsync(s->d_tab_attach + e * w, noise + e * w, (size_t)(e1 - e) * w * 4, hipMemcpyHostToDevice, s->xfer));
+    e = e1;
+  }
+  HIPCHK(hipStreamSynchronize(s->xfer));
+  return FSIM_OK;
+}
+
 extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (s->ecfg.n_pre > 0 && qpos) FAIL(FSIM_EINVAL, "fsim_set_init_state: not combined with pre-assembled starts (fsim_set_preassembled)");
@@ -868,7 +892,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
   StepArgs a;
   a.cfg = s->ecfg; a.state = s->d_state; a.action = action; a.obs = obs; a.reward = reward; a.done = done; a.info = info;
-  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.n_noise = s->n_noise; a.reset_mask = mask; a.do_step = do_step;
+  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = mask; a.do_step = do_step;
   a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = do_step ? s->d_nreset : nullptr;
   if (!s->d_ecfg) { HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); }

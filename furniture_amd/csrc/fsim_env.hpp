@@ -35,6 +35,7 @@ struct EnvCfg {
                             //          1: rows = {connector of the recipe's site2, connector of its site1, angle bits or NaN} (_connect per row)
   const int *pre_tab;       // [n_pre][3], device memory
   int success_num_conn;     // _success_num_conn (furniture.py:1476-1481)
+  int reset_robot_after_attach; // config.reset_robot_after_attach (furniture.py:919-925): _connect ends with _initialize_robot_pos()
 };
 struct EnvIO {
   const float *action;
@@ -47,6 +48,7 @@ struct EnvIO {
   int *nreset;    // device counter: envs that consumed their reset table in this launch (host reads it instead of scanning info)
   int *cost;      // scheduler key written by env_step (shader cycles >> 10 of the step just taken, -1 = will time out next step)
   long long t0;   // shader clock at kernel entry
+  const float *tab_attach; // [narmj] joint noise of this env's NEXT attach (fsim_set_attach_noise), or null
   const EnvCfg *cfg_dev; // the handle's copy of the EnvCfg in device memory: what the out-of-line env_reset is given (see EnvResetIO)
 };
 // What env_reset reads of an env's EnvIO, passed BY VALUE (registers).  env_reset is a real function: handing it the addresses of the
@@ -65,6 +67,7 @@ static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
+  e.reset_robot_after_attach = c.reset_robot_after_attach ? 1 : 0;
   e.agent = m.agent;
   e.dof_action = m.agent == 0 ? 9 : (m.agent == 1 ? 17 : 15);
   e.obs_dim = 7 * m.nparts + (m.agent == 2 ? 8 : 29 * m.narm);
@@ -1067,6 +1070,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // FurnitureCursorEnv._step: _step_discrete(a) then _do_simulation(None) (furniture_cursor.py:59-70, furniture.py:2857-2897)
     connect = 0; // the arm agents' finger scan below does not apply
     env_cursor_discrete(c, cfg, io.action);
+    if (cfg.reset_robot_after_attach && E[E_CONNECTED_THIS_STEP]) env_init_robot(c, EnvResetIO{nullptr, nullptr, nullptr, 0}, 0, cfg.move_speed); // (furniture.py:919-925: the cursors go back to their start positions)
     if (c.lane == 0) { // parts in a selected group float (gravity compensated), the others are only stopped
       int *grp = E + E_GROUP;
       const int *eci = c.I(env_ecur(c));
@@ -1141,6 +1145,15 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   } else if (connect > 0) {
     // finger-touch scan -> first part (in part order) pinched by both fingers of an arm -> _try_connect
     env_finger_scan(c.D.narm, scal, [&](int part) { return env_try_connect(c, cfg, part, -1); });
+    SYNC();
+    // config.reset_robot_after_attach (furniture.py:919-925): the last thing _connect does is _initialize_robot_pos() -- the arm's
+    // joints jump to the initial pose plus ONE fresh draw of joint noise, the gripper opens, velocities stay; the IK controller is
+    // re-synchronised.  The draw comes from the env's one RandomState, between the draws of two resets: the host keeps it waiting in
+    // the attach table (fsim_set_attach_noise) and learns from FSIM_INFO_CONNECTED_THIS_STEP that it was taken.
+    if (cfg.reset_robot_after_attach && E[E_CONNECTED_THIS_STEP]) {
+      env_init_robot(c, EnvResetIO{nullptr, io.tab_attach, nullptr, 1}, 0, cfg.move_speed);
+      if (cfg.ik) env_ik_sync(c, true);
+    }
   }
   // post-connect re-pose of body1's (merged) group (furniture.py:426-436)
   if (E[E_CONNBODY1] > 0) {

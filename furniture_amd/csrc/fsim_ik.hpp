@@ -103,7 +103,8 @@ DEV void ik_mat2quat_xyzw(const M3 &R, float *q) {
 }
 
 // end of _reset (furniture.py:1643-1650): _initial_<arm>_hand_quat = _<arm>_hand_quat; controller.sync_state()
-template <class Ctx> DEV void env_ik_sync(const Ctx &c) {
+// target_only: controller.sync_state() alone (what _connect calls after config.reset_robot_after_attach re-posed the arm, furniture.py:921-924)
+template <class Ctx> DEV void env_ik_sync(const Ctx &c, const bool target_only = false) {
   CModel &m = c.m;
   const auto tail = GP(m.ik_tab) + IKT_ARM * c.D.narm;
   const M3 RbT = ck_transpose(q2m(qnormalized(ldq(tail + IKT_BQUAT))));
@@ -120,8 +121,10 @@ template <class Ctx> DEV void env_ik_sync(const Ctx &c) {
     ik_fk(GP(m.ik_tab) + IKT_ARM * arm, q, f);
     if (c.lane == 0) {
       stv3(K + EI_TARGET, f.p); // ik_robot_target_pos := the IK chain's own end-effector position (sync_state)
-      for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = iq[i];
-      stv3(K + EI_HPOS, hp);
+      if (!target_only) {
+        for (int i = 0; i < 4; i++) K[EI_IQUAT + i] = iq[i];
+        stv3(K + EI_HPOS, hp);
+      }
     }
   }
   SYNC();

@@ -354,12 +354,20 @@ class FurnitureBatchEnv:
         if cfg.furn_size_rand != 0:
             raise NotImplementedError("furn_size_rand != 0 (XML rescale) is out of scope")
         # reference options that change the reset / connect flow and are not built: fail loudly instead of ignoring them
-        # (reset_robot_after_attach: _connect draws the arm's re-pose noise from the env's ONE RandomState, i.e. between the draws of two
-        #  resets; the reset tables here are drawn one reset ahead, so a connect would have to rewind and redraw them)
-        for flag, ref in (("reset_robot_after_attach", "furniture.py:919-925 (draws from the env RNG inside _connect, between two resets' draws)"),
-                          ("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325")):
+        for flag, ref in (("load_demo", "furniture.py:121-124"), ("load_init_states", "furniture.py:126-129"), ("record_demo", "furniture.py:324-325")):
             if getattr(cfg, flag, None):
                 raise NotImplementedError("config.%s (%s) is not part of the accelerated path" % (flag, ref))
+        # config.reset_robot_after_attach (furniture.py:919-925): _connect re-poses the arm with ONE draw of the env's RandomState, taken
+        # between the draws of two resets.  Built as a mode of its own (see _attach_*): the env's stream is kept on the host, the kernel is
+        # handed the next attach draw and the next reset table ahead of time, resets of finished episodes are issued by the host (device
+        # auto_reset off) once it knows whether the last step attached.  Combinations whose resets call _connect themselves are refused.
+        self._attach_mode = bool(getattr(cfg, "reset_robot_after_attach", False)) and agent != "Cursor"
+        if getattr(cfg, "reset_robot_after_attach", False):
+            for flag in ("preassembled", "assembled", "fix_init", "num_connects"):
+                if getattr(cfg, flag, None):
+                    raise NotImplementedError("config.reset_robot_after_attach with config.%s (pre-assembled resets call _connect -- and draw -- inside the reset, furniture.py:1542-1566) is not built" % flag)
+            if dense:
+                raise NotImplementedError("config.reset_robot_after_attach with the dense-reward env is not built")
         names = furniture_names()
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg
@@ -371,7 +379,8 @@ class FurnitureBatchEnv:
         c.n_substeps = int((1.0 / cfg.control_freq) / float(self.model.opt[0]))
         c.max_episode_steps = int(cfg.max_episode_steps)
         c.discrete_grip, c.rescale_actions, c.auto_align = int(cfg.discrete_grip), int(cfg.rescale_actions), int(cfg.auto_align)
-        c.auto_reset = 1 if auto_reset else 0
+        c.auto_reset = 1 if (auto_reset and not self._attach_mode) else 0  # (attach mode: the host resets finished episodes, see _attach_after_step)
+        c.reset_robot_after_attach = 1 if getattr(cfg, "reset_robot_after_attach", False) else 0
         for k in ("alignment_pos_dist", "alignment_rot_dist_up", "alignment_rot_dist_forward", "alignment_project_dist",
                   "ctrl_penalty_coef", "unstable_penalty_coef", "success_reward", "touch_reward", "pick_reward",
                   "furn_xyz_rand", "furn_rot_rand", "agent_xyz_rand"):
@@ -512,7 +521,61 @@ class FurnitureBatchEnv:
             as_np = lambda v: v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
             self.sim.set_init_state(as_np(init_qpos["qpos"]), as_np(init_qpos["qvel"]))
 
+    # -- config.reset_robot_after_attach: the env's RNG stream with attach draws in it -----------------------------------------
+    # sampler.rngs[i] is env i's RandomState at the position every CONSUMED draw has left it (committed).  Ahead of every step the
+    # device holds two speculative draws taken from copies of it: the next reset table (read by a reset INSIDE step(): an unstable
+    # simulation) and the next attach noise (read by _connect).  After the step the info block says which of the two the kernel
+    # used (they exclude each other: the finger scan only runs after a stable simulation, furniture.py:1262-1330), the stream advances
+    # past that one, finished episodes are reset from the stream as it then stands, and the speculative draws are renewed.
+    def _attach_peek(self, mask):
+        rngs, narm, a = self._sampler.rngs, self._sampler.narm, self.config.agent_xyz_rand
+        idx = np.nonzero(mask)[0]
+        keep = [rngs[i].get_state() for i in idx]
+        parts, noise = self._sampler._draw_python(mask)
+        for k, i in enumerate(idx):
+            self._attach_after_reset[i] = rngs[i].get_state()
+            rngs[i].set_state(keep[k])
+        att = np.zeros((self.num_envs, max(narm, 1)), dtype=np.float32)
+        for k, i in enumerate(idx):
+            att[i, :narm] = rngs[i].uniform(low=-a, high=a, size=narm)  # _init_random(init_qpos.shape, "agent"), furniture.py:336-349
+            self._attach_after_attach[i] = rngs[i].get_state()
+            rngs[i].set_state(keep[k])
+        self.sim.set_reset_tables(parts, noise, mask=mask)
+        self.sim.set_attach_noise(att, mask=mask)
+
+    def _attach_reset(self, mask):
+        """reset the envs in mask (numpy bool) from their committed streams; the observation rows of those envs are rewritten"""
+        parts, noise = self._sampler._draw_python(mask)  # advances the committed generators
+        self.sim.set_reset_tables(parts, noise, mask=mask)
+        torch = self.sim.torch
+        self.sim.reset(torch.as_tensor(mask.astype(np.uint8), device=self.sim.device), self._obs)
+        self.sim.sync()
+        self._attach_peek(mask)
+
+    def _attach_after_step(self):
+        info = self._info.cpu().numpy()
+        attached, failed = info[:, INFO_CONNECTED_THIS_STEP] != 0, info[:, INFO_FAIL] != 0
+        rngs = self._sampler.rngs
+        for i in np.nonzero(attached & ~failed)[0]:
+            rngs[i].set_state(self._attach_after_attach[i])
+        for i in np.nonzero(failed)[0]:  # the reset inside step() took the table (furniture.py:2889-2897)
+            rngs[i].set_state(self._attach_after_reset[i])
+        done = self._done.cpu().numpy() != 0
+        if self._auto_reset and done.any():
+            self._attach_reset(done)  # SubprocVecEnv worker semantics: the observation of a finished env is that of its reset
+        renew = (attached | failed) & ~(done if self._auto_reset else np.zeros_like(done))
+        if renew.any():
+            self._attach_peek(renew)
+
     def reset(self):
+        if self._attach_mode:
+            if getattr(self, "_init_qpos", None) is not None:
+                raise NotImplementedError("config.reset_robot_after_attach with set_init_qpos is not built")
+            self._sampler.rngs  # (the Python generators: the attach draws are taken from copies of them)
+            if not hasattr(self, "_attach_after_reset"):
+                self._attach_after_reset, self._attach_after_attach = [None] * self.num_envs, [None] * self.num_envs
+            self._attach_reset(np.ones(self.num_envs, dtype=bool))
+            return self._split(self._obs)
         if getattr(self, "_init_qpos", None) is not None:
             if not self._tables_fresh.all():  # (the kernel insists on tables being present; these are not consumed)
                 self._refill(None if not self._tables_fresh.any() else ~self._tables_fresh)
@@ -560,12 +623,14 @@ class FurnitureBatchEnv:
 
     def step_wait(self):
         self.sim.sync()
-        if self.refill_tables_every_step:
+        if self._attach_mode:
+            self._attach_after_step()
+        elif self.refill_tables_every_step:
             if self.sim.tables_needed():
                 need = self._info.cpu().numpy()[:, INFO_NEEDS_TABLE]  # (whole block = a DMA copy; a column slice would launch a gather kernel)
                 self._tables_fresh[need > 0] = False
                 self._refill(need > 0, skip=need > 1, lookahead=True)
-        if not self._auto_reset and bool((self._info[:, INFO_FAIL] != 0).any()):
+        if not self._auto_reset and not self._attach_mode and bool((self._info[:, INFO_FAIL] != 0).any()):
             # an unstable simulation reset the env inside step() and consumed the table on the device: upload the env's next draw
             failed = (self._info[:, INFO_FAIL] != 0).cpu().numpy()
             self._tables_fresh[failed] = False

@@ -112,6 +112,7 @@ def lib():
         L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_set_attach_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_set_init_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled",
+    "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
 ]
 
 
@@ -315,6 +316,13 @@ class FSim:
         mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self._chk(lib().fsim_set_reset_tables(self._h, None if mk is None else mk.ctypes.data, pq.ctypes.data,
                                               None if rn is None else rn.ctypes.data, n_noise))
+
+    def set_attach_noise(self, noise, mask=None):
+        """config.reset_robot_after_attach: the joint noise [n, narm joints] each env's NEXT attach re-poses the arm with
+        (include/fsim.h: fsim_set_attach_noise)"""
+        nz = np.ascontiguousarray(noise, dtype=np.float32).reshape(self.n_envs, -1)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._chk(lib().fsim_set_attach_noise(self._h, None if mk is None else mk.ctypes.data, nz.ctypes.data))
 
     def set_init_state(self, qpos=None, qvel=None, mask=None):
         """set_init_qpos for the masked envs (None = all); qpos None clears it (include/fsim.h: fsim_set_init_state)"""

@@ -126,6 +126,13 @@ int fsim_env_block_words(const fsim_t *);
  * replaced while other envs are being stepped (asynchronous stepping). */
 int fsim_set_reset_tables(fsim_t *, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise);
 
+/* config.reset_robot_after_attach (config/furniture.py:298-303; furniture.py:919-925: `_connect` ends with `_initialize_robot_pos()`):
+ * the joint noise [n, narmjoints] the NEXT attach of each env adds to the arm's initial pose -- one `_init_random(.., "agent")` draw of
+ * the env's RandomState, taken BETWEEN the draws of two resets, which is why the host keeps it waiting here and advances the env's
+ * stream when FSIM_INFO_CONNECTED_THIS_STEP reports that the kernel used it (furniture_amd/envs.py).  Host pointers, copied on the
+ * handle's transfer stream, complete on return; mask as above.  Only for handles created with reset_robot_after_attach = 1. */
+int fsim_set_attach_noise(fsim_t *, const uint8_t *mask, const float *noise);
+
 /* FurnitureEnv.reset() on the masked envs (device uint8 mask or NULL = all); writes obs if non-NULL. */
 /* FurnitureEnv.set_init_qpos (furniture.py:315-316; applied inside _reset, :1505-1519, 1568, 1617): the resets of the masked envs
  * (host uint8 [n], NULL = all) start from the given state -- qpos [n][nq], qvel [n][nv], host float32 (the format of

@@ -112,6 +112,7 @@ class FurnitureEnvOracle:
         self.init_pos = None
         self.init_quat = None
         self.reset_draws = None  # filled by reset(): what a device reset table must contain
+        self.attach_draws = []   # config.reset_robot_after_attach: the joint-noise draw of every _connect so far (what the device's attach table held)
         self._fail = False
         self._dense = None
         self._ctrl = None
@@ -201,10 +202,10 @@ class FurnitureEnvOracle:
         self.sim.step()
 
     # ---- reset (F.py:1406-1663) ------------------------------------------------------------
-    def _initialize_robot_pos(self):
+    def _initialize_robot_pos(self, record=None):
         if self.agent != "Cursor":
             noise = self._rng.uniform(low=-self.cfg.agent_xyz_rand, high=self.cfg.agent_xyz_rand, size=self.m.arm_initqpos.shape)
-            self.reset_draws["noise"].append(noise.copy())
+            (self.reset_draws["noise"] if record is None else record).append(noise.copy())
             self.sim.data.qpos[self.m.arm_qposadr] = self.m.arm_initqpos + noise
             self.sim.data.qpos[self.m.grip_qposadr] = self.m.grip_initqpos
         else:
@@ -541,6 +542,11 @@ class FurnitureEnvOracle:
         q = self._part_qpos(pA)
         self._connected_body1_pos, self._connected_body1_quat = q[:3], q[3:]
         self._get_next_subtask()
+        if getattr(self.cfg, "reset_robot_after_attach", False):  # F.py:919-925: reset robot arm (one more draw of the env's ONE RandomState)
+            self._initialize_robot_pos(record=self.attach_draws)
+            if self._ik:  # controller.sync_state(): the IK target position := the chain's forward kinematics at the new joints
+                self._ik_tp = [self._IK.fk(m, self.sim.data.qpos[m.arm_qposadr[7 * a:7 * a + 7]], a)[0] for a in range(len(self.arms))]
+                self._ik_target_pos = self._ik_tp[0]
 
     def _try_connect(self, part1=None, part2=None):
         m = self.m

@@ -77,3 +77,82 @@ def test_no_collision_lets_the_arm_pass_through_the_parts():
     assert moved_ref > 5e-3  # (the colliding robot of the twin env does plough into them on the same actions)
     env.close()
     ref.close()
+
+
+def test_reset_robot_after_attach_reposes_the_arm_and_keeps_the_rng_stream():
+    """config.reset_robot_after_attach (furniture.py:919-925): _connect ends with _initialize_robot_pos() -- the arm jumps to its
+    initial pose plus ONE draw of joint noise taken from the env's RandomState between the draws of two resets.  Device vs the oracle env:
+    the scripted pinch + connect of test_gpu_parity.py with the option on (arm joints after the step, observation, integer outcomes), then
+    the next resets of BOTH envs (the one that attached and the one that did not) land on the oracle's placements -- i.e. the host
+    advanced each stream by exactly what the kernel consumed --, and a finished episode is reset by the host with the reset observation
+    in the returned slab (SubprocVecEnv worker semantics, the device's auto_reset being off in this mode)."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions, pinch_attach_state
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n, T = 2, 12
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                           max_episode_steps=T, seed=31, reset_robot_after_attach=True))
+    assert env.sim.cfg.auto_reset == 0 and env.sim.cfg.reset_robot_after_attach == 1
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=31 + i, solver_tolerance=1e-10, reset_robot_after_attach=True)) for i in range(n)]
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+    od = flat(env.reset())
+    oo = [o.flat_obs(o.reset()) for o in orcs]
+    for i in range(n):
+        assert np.abs(od[i] - oo[i]).max() < 5e-5
+    for t in range(3):
+        a = np.stack([counter_actions(31, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0  # no connect yet
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, _ = orcs[i].step(a[i])
+            assert np.abs(flat(ob)[i] - orcs[i].flat_obs(o)).max() < 1e-3 and not d  # (random actions: joint velocities of 2 rad/s to 3e-4)
+    # env 0: the gripper pinches a leg whose connector faces the table's; both envs get the connect action
+    o0 = orcs[0]
+    q, xfrc, masks = pinch_attach_state(m, o0.sim.data.qpos.copy(), o0.sim.data.xpos.copy(), o0.sim.data.xquat.copy())
+    o0.sim.data.qpos[:], o0.sim.data.qvel[:], o0.sim.data.qacc_warmstart[:] = q, 0, 0
+    for i in range(m.nparts):
+        o0.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+    sim = env.sim
+    st = sim.get_state("qpos", "qvel", "qacc_warmstart", "xfrc_applied", "geom_contype", "geom_conaffinity")
+    for g, (ct, ca) in masks.items():
+        o0.sim.model.geom_contype[g], o0.sim.model.geom_conaffinity[g] = ct, ca
+        st["geom_contype"][0, g], st["geom_conaffinity"][0, g] = ct, ca
+    st["qpos"][0] = torch.as_tensor(q, dtype=st["qpos"].dtype)
+    st["qvel"][0], st["qacc_warmstart"][0] = 0, 0
+    st["xfrc_applied"][0] = torch.as_tensor(xfrc.reshape(-1), dtype=st["xfrc_applied"].dtype)
+    sim.set_state(**st)
+    a = np.zeros((n, 9), dtype=np.float32)
+    a[:, 7] = a[:, 8] = 1.0
+    ob, rew, done, info = env.step(a)
+    res = [orcs[i].step(a[i]) for i in range(n)]
+    assert res[0][3]["connected_this_step"] == 1 and int(info["connected"][0]) == 1 and int(info["connected"][1]) == res[1][3]["connected_this_step"] == 0
+    assert len(o0.attach_draws) == 1 and np.abs(o0.attach_draws[0]).max() <= 1e-3 + 1e-12
+    # the arm was re-posed with the oracle's draw (then took the post-connect forward + step like the oracle's)
+    qd = sim.get_state("qpos")["qpos"].cpu().numpy()
+    for i in range(n):
+        assert np.abs(qd[i][m.arm_qposadr] - orcs[i].sim.data.qpos[m.arm_qposadr]).max() < 2e-4, i
+        assert np.abs(flat(ob)[i] - orcs[i].flat_obs(res[i][0])).max() < 5e-4, i
+    assert np.abs(orcs[0].sim.data.qpos[m.arm_qposadr] - m.arm_initqpos).max() < 0.05  # (it IS near the initial pose again)
+    # run both to the end of the episode: the host resets them, the returned observation is the oracle's reset observation
+    for t in range(4, T):
+        a = np.stack([counter_actions(31, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, _ = orcs[i].step(a[i])
+            assert bool(done[i]) == d
+            if d:
+                o = orcs[i].reset()
+                assert np.abs(flat(ob)[i][:7 * m.nparts] - orcs[i].flat_obs(o)[:7 * m.nparts]).max() < 5e-5, (t, i)  # the placement: the stream is where the oracle's is
+                assert np.abs(flat(ob)[i] - orcs[i].flat_obs(o)).max() < 2e-4, (t, i)
+        if bool(done.all()):
+            break
+    assert bool(done.all())
+    # and one more explicit reset of the whole batch
+    od = flat(env.reset())
+    for i in range(n):
+        assert np.abs(od[i] - orcs[i].flat_obs(orcs[i].reset())).max() < 5e-5
+    env.close()

@@ -61,13 +61,22 @@ def test_obs_options_match_oracle_env():
     env.close()
 
 
-@pytest.mark.parametrize("flag", ["reset_robot_after_attach", "load_demo", "record_demo"])
+@pytest.mark.parametrize("flag", ["load_demo", "record_demo"])
 def test_unsupported_reference_options_fail_loudly(flag):
     """Options of furniture/config/furniture.py that change the reset / connect flow and are not built raise before any device work
     (no silent ignore); checked on CPU: the guard sits ahead of the FSim construction."""
     with pytest.raises(NotImplementedError, match=flag):
         FurnitureBatchEnv("Sawyer", 1, config=make_config(unity=False, record_vid=False, control_type="impedance",
                                                           furniture_name="table_lack_0825", **{flag: True}))
+
+
+@pytest.mark.parametrize("other", [dict(preassembled=[0]), dict(assembled=True), dict(fix_init=True)])
+def test_reset_robot_after_attach_refuses_the_resets_that_connect_themselves(other):
+    """config.reset_robot_after_attach is built (tests/test_b1_residuals_gpu.py) -- except together with the options whose resets call
+    _connect, and therefore draw from the env's stream, inside the reset (furniture.py:1542-1566): refused before any device work."""
+    with pytest.raises(NotImplementedError, match="reset_robot_after_attach"):
+        FurnitureBatchEnv("Sawyer", 1, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                          reset_robot_after_attach=True, **other))
 
 
 @pytest.mark.gpu
