@@ -278,18 +278,21 @@ def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack):
     sim.close()
 
 
-def test_cursor_agent_matches_oracle():
+@pytest.mark.parametrize("after_attach", [False, True])
+def test_cursor_agent_matches_oracle(after_attach):
     """FurnitureCursorEnv on the device: reset, random 15-dof steps (cursor moves, selection by contact), then
     a scripted attach -- both cursors hold an aligned leg / table pair and ask to connect: ten approach steps
-    (slerp / lerp of the held group) and the connect itself, all against the oracle env."""
+    (slerp / lerp of the held group) and the connect itself, all against the oracle env.  after_attach: with
+    config.reset_robot_after_attach the connect sends both cursors back to their start positions (furniture.py:919-925, 1763-1768)."""
     m = load_compiled("Cursor", "table_lack_0825")
     n = 2
     cfg = default_config()
     cfg.max_episode_steps = 150
     cfg.auto_reset = 0
+    cfg.reset_robot_after_attach = 1 if after_attach else 0
     sim = FSim(m, n, config=cfg)
     assert sim.dof_action == 15 and sim.obs_dim == 7 * m.nparts + 8
-    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10)) for i in range(n)]
+    envs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=123 + i, solver_tolerance=1e-10, reset_robot_after_attach=after_attach)) for i in range(n)]
     obs_o = [e.reset() for e in envs]
     parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
     sim.set_reset_tables(parts, None)
@@ -349,6 +352,9 @@ def test_cursor_agent_matches_oracle():
     assert np.array_equal(st["eq_active"][0].cpu().numpy(), envs[0].sim.model.eq_active)
     assert np.abs(st["eq_data"][0].cpu().numpy().reshape(-1, 7) - envs[0].sim.model.eq_data).max() < 2e-3
     assert st["cursor"][0, 7].item() == 0  # _connect drops cursor 1's selection (furniture.py:914-915)
+    if after_attach:  # (at the connect step; the two steps after it moved them by nothing: the action's move entries are zero)
+        assert np.abs(st["cursor"][0, :6].cpu().numpy() - np.array([-0.2, 0.0, 0.05, 0.2, 0.0, 0.05])).max() < 1e-6
+        assert np.abs(np.asarray(envs[0].sim.model.body_pos)[m.cursor_bodyid].reshape(-1) - np.array([-0.2, 0.0, 0.05, 0.2, 0.0, 0.05])).max() < 1e-12
     sim.close()
 
 
