@@ -528,9 +528,9 @@ static LayoutIn layout_in(const fsim *s, int ncon_max) {
 
 static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, sizeof(Dims)) == 0; }
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
-static KernelSet pick_kernels(const Dims &d, const LayoutIn &in) {
+static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg) { // plain_cfg: no controller / IK / dense reward (SpecCtx::PLAIN)
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
@@ -570,7 +570,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (s->m.ntree > 16 || s->m.nv > 128) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 128 dofs", nt_, nv_); }
   const LayoutIn lin = layout_in(s, ncon_max);
   s->ly = make_layout(lin);
-  s->ks = pick_kernels(s->m, lin);
+  s->ks = pick_kernels(s->m, lin, !s->cfg.dense_reward && !env_controller_kind(s->cfg) && s->cfg.control_type != 7 && s->cfg.control_type != 8);
   s->lds_bytes = s->ly.lds_words * 4;
   if (const char *e = getenv("FSIM_LDS_PAD")) s->lds_bytes += atoi(e); // development: lower the occupancy on purpose
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }

@@ -774,6 +774,7 @@ template <class Ctx> DEV void env_cursor_discrete(const Ctx &c, const EnvCfg &cf
 
 // ---------------------------------------------------------------------------------------------------- observation / reward
 template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_controller = Ctx::PLAIN ? 0 : cfg.controller; // (SpecCtx::PLAIN)
   if (!io.obs) return;
   CModel &m = c.m;
   const float *L = c.L;
@@ -801,7 +802,7 @@ template <class Ctx> DEV void env_write_obs(const Ctx &c, const EnvCfg &cfg, con
   for (int arm = 0; arm < c.D.narm; arm++) {
     const int njm = c.D.narmj / c.D.narm;
     // joint_pos / joint_vel are part of robot_ob for impedance / torque only (furniture_sawyer.py:112-124)
-    const int nj = (cfg.controller || cfg.ik) ? 0 : njm;
+    const int nj = (cfg_controller || cfg_ik) ? 0 : njm;
     float *o = ob + base + (2 * nj + 15) * arm;
     for (int k = c.lane; k < nj; k += 64) {
       o[k] = L[c.ly.qpos + GP(m.arm_qposadr)[arm * njm + k]];
@@ -877,6 +878,7 @@ template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, con
   typedef FsIn<Ctx0> Ctx; // (see FsIn: the physics routine called from here is not the one the step calls)
   const Ctx c(fs_rebuild(cv, fs_lds_));
   const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp)); // (device memory: EnvIO::cfg_dev)
+  const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
   CModel &m = c.m;
   float *L = c.L;
   int *E = c.I(c.ly.env);
@@ -962,10 +964,10 @@ template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, con
   fs_forward(c);
   if (c.D.narm > 0) env_gravity_comp(c);
   for (int k = 0; k < 100; k++) fs_step(c);
-  if (cfg.ik) env_ik_sync(c); // furniture.py:1643-1650
+  if (cfg_ik) env_ik_sync(c); // furniture.py:1643-1650
   if (c.lane == 0) {
     env_next_subtask(c);
-    if (cfg.dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
+    if (cfg_dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
       DenseSimP<Ctx> dp{c, cfg};
       dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, cfg.n_pre);
     }
@@ -1011,6 +1013,7 @@ template <class Ctx> DEV float env_robot_clearance(const Ctx &c) {
 
 // ---------------------------------------------------------------------------------------------------- step
 template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_controller = Ctx::PLAIN ? 0 : cfg.controller, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
   CModel &m = c.m;
   float *L = c.L;
   int *E = c.I(c.ly.env);
@@ -1019,10 +1022,10 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   // _before_step + action plumbing
   if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
   float connect = io.action[dof - 1];
-  if (cfg.ik) {
+  if (cfg_ik) {
     // _do_ik_step (furniture.py:2911-2958, 2999-3018): per arm d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed
     // in env_ik); the grips follow the arm commands, the last entry is connect.  Block layout per arm: EI_ACT + [dpos 3, rot 3|4, grip]
-    const int nrot = cfg.ik == 1 ? 3 : 4, stride = 3 + nrot;
+    const int nrot = cfg_ik == 1 ? 3 : 4, stride = 3 + nrot;
     for (int t = c.lane; t < c.D.narm * (stride + 1); t += 64) {
       const int arm = t / (stride + 1), k = t % (stride + 1);
       float *K = L + c.ly.eik + EI_WORDS * arm;
@@ -1035,7 +1038,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       else { v = io.action[c.D.narm * stride + arm]; if (cfg.discrete_grip && cfg.agent == 0) v = v < 0 ? -1.0f : 1.0f; } // furniture_sawyer.py:72-74
       K[EI_ACT + k] = v;
     }
-  } else if (cfg.controller) {
+  } else if (cfg_controller) {
     // FurnitureSawyerEnv._step discretises the grip (furniture_sawyer.py:72-74); _do_controller_step scales the first three
     // entries by move_speed and permutes them [-a1, a0, a2] whatever the controller kind (furniture.py:3069-3071)
     float *K = L + c.ly.env + E_GROUP + c.D.nparts;
@@ -1049,7 +1052,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       else if (c.lane == 7) { v = io.action[cd]; if (cfg.discrete_grip) v = v < 0 ? -1.0f : 1.0f; }
       K[EK_ACT + c.lane] = v;
     }
-    if (c.lane == 0) reinterpret_cast<int *>(K)[EK_KIND] = cfg.controller;
+    if (c.lane == 0) reinterpret_cast<int *>(K)[EK_KIND] = cfg_controller;
   } else
   // _setup_action (impedance): clip, gripper 1 -> 2, rescale to ctrlrange, stale gravity compensation
   for (int u = c.lane; u < c.D.nu; u += 64) {
@@ -1084,12 +1087,12 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     SYNC();
     fs_substeps(c, cfg.n_substeps, 0);
     env_stop_selected(c, 1.0f);
-  } else if (cfg.ik) {
+  } else if (cfg_ik) {
     SYNC();
-    env_ik(c, cfg.rotate_speed, cfg.ik);
+    env_ik(c, cfg.rotate_speed, cfg_ik);
     const float *K0 = L + c.ly.eik;
     const float pgain = GP(m.ik_tab)[IKT_ARM * c.D.narm + IKT_GAIN];
-    const int ng = 3 + (cfg.ik == 1 ? 3 : 4); // offset of the grip entry inside EI_ACT
+    const int ng = 3 + (cfg_ik == 1 ? 3 : 4); // offset of the grip entry inside EI_ACT
     for (int rep = 0; rep < 3; rep++) { // action_repeat = 3 (furniture.py:172): closed loop on the commanded joint positions
       // get_control's P controller (sawyer_ik_controller.py:75-84, baxter_ik_controller.py:86-95), then _setup_action on [velocities, grips]
       for (int u = c.lane; u < c.D.nu; u += 64) {
@@ -1110,7 +1113,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       fs_substeps(c, cfg.n_substeps, rep == 2 ? 2 : 0);
       if (scal[SC_BAD] & 2) break;
     }
-  } else if (cfg.controller) {
+  } else if (cfg_controller) {
     // _do_controller_step: sim.forward(), then n_substeps x (_pre_action, sim.step()); no _setup_action, so qfrc_applied keeps
     // the gravity compensation the reset left (furniture.py:1624-1632) on top of the qfrc_bias inside ctrl
     fs_substeps_t<true>(c, cfg.n_substeps, 2);
@@ -1137,7 +1140,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // the reference's post-failure episode starts from draw k+2 (its in-step reset took k+1).  The host drops k+2 and uploads
     // k+3, so from the following episode on both streams agree again; only the placement of the episode right after an
     // unstable step differs (same distribution).  Keeping two tables per env on the device would remove it.
-    const bool skip_reset = cfg.auto_reset && !cfg.dense;
+    const bool skip_reset = cfg.auto_reset && !cfg_dense;
     if (!skip_reset) env_reset(c, io.cfg_dev, env_reset_io(io));
     if (c.lane == 0) { E[E_FAIL] = skip_reset ? 2 : 1; scal[SC_BAD] = 0; if (skip_reset) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; } }
     SYNC();
@@ -1152,7 +1155,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // the attach table (fsim_set_attach_noise) and learns from FSIM_INFO_CONNECTED_THIS_STEP that it was taken.
     if (cfg.reset_robot_after_attach && E[E_CONNECTED_THIS_STEP]) {
       env_init_robot(c, EnvResetIO{nullptr, io.tab_attach, nullptr, 1}, 0, cfg.move_speed);
-      if (cfg.ik) env_ik_sync(c, true);
+      if (cfg_ik) env_ik_sync(c, true);
     }
   }
   // post-connect re-pose of body1's (merged) group (furniture.py:426-436)
@@ -1207,7 +1210,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     if (E[E_NUM_CONNECTED] == cfg.success_num_conn && c.D.nparts > 1) { E[E_SUCCESS] = 1; success = 1; }
     terminal = success;
     int dense_phase = 0;
-    if (cfg.dense) {
+    if (cfg_dense) {
       // FurnitureSawyerEnv._step (furniture_sawyer.py:76-79): the dense _compute_reward replaces the reward and owns _success;
       // done = (all parts connected) or its own done
       DenseSimP<Ctx> dp{c, cfg};
@@ -1225,7 +1228,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       terminal = 1;
       if (fail) { E[E_FAIL] = 0; penalty = -cfg.unstable_penalty_coef; }
     }
-    float rew = cfg.dense ? dense_rew + penalty : succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
+    float rew = cfg_dense ? dense_rew + penalty : succ_rew + touch_rew + pick_rew + ctrl_pen + penalty;
     L[c.ly.env + E_EPISODE_REWARD] += rew;
     if (io.reward) *io.reward = rew;
     if (io.done) *io.done = (uint8_t)terminal;
@@ -1255,7 +1258,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   terminal = scal[14];
   const int nit_step = scal[SC_NITSUM];
   if (terminal && cfg.auto_reset) env_reset(c, io.cfg_dev, env_reset_io(io)); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
-  else if (cfg.ik) env_ik_remember(c, cfg.ik);              // (a reset stores its own poses: env_ik_sync)
+  else if (cfg_ik) env_ik_remember(c, cfg_ik);              // (a reset stores its own poses: env_ik_sync)
   { // what the scheduler of the next launch reads (k_schedule): this step's Newton iterations (0 after a reset), the robot-part clearance now
     const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;
     if (c.lane == 0) {

@@ -33,6 +33,7 @@ template <int NW_, bool BUNDLE_> struct FsSync {
   DEV static void xbar() { __syncthreads(); }
 };
 template <int NW_, bool BUNDLE_ = false, int NS_ = 1> struct GenCtxT {
+  static constexpr bool PLAIN = false; // (the generic kernels serve every configuration: controllers, IK, dense reward)
   static constexpr int NW = NW_;
   static constexpr bool BUNDLE = BUNDLE_;
   static constexpr int NS = NS_; // contact-slot sets of 64 the Newton solve carries per lane (2: models with more than 64 contact slots)
@@ -56,6 +57,10 @@ template <int NW_, bool BUNDLE_ = false, int NS_ = 1> struct GenCtxT {
 typedef GenCtxT<1> GenCtx;
 template <class S, int NW_> struct FsSpecLayout { static constexpr Layout ly = make_layout(S::in, NW_); };
 template <class S, int NW_ = 1, bool BUNDLE_ = false> struct SpecCtx {
+  // the env record of a specialised kernel has no controller / IK / dense-reward block (its LayoutIn says so, and pick_kernels only
+  // takes the kernel for a configuration with the same LayoutIn): EnvCfg::controller / ik / dense are compile-time zeros here, and
+  // the code behind them -- env_ik, the controller instantiation of fs_substeps_t, the dense reward -- is not in these kernels
+  static constexpr bool PLAIN = S::plain;
   static constexpr int NW = NW_;
   static constexpr bool BUNDLE = BUNDLE_;
   float *L;
