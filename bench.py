@@ -193,6 +193,11 @@ def main():
     if args.config != 2:
         preset = CONFIGS[args.config]
         args.agent, args.furniture, args.envs_per_gpu = preset["agent"], preset["furniture"], preset["envs"]
+    if args.envs_per_gpu > 4096 and "FSIM_MW" not in os.environ:
+        # four waves for the envs that set the step time pay while the chip has idle wave slots behind them (4096 envs on 2048 slots);
+        # with more envs per GPU the step is throughput-bound and the helpers' slots are missed: Sawyer + swivel_chair at 8192 envs,
+        # four slabs of 2048: 953 k env-steps/s with the multi-wave rule, 1.06 M on the one-wave kernel (a handle cannot see the others')
+        os.environ["FSIM_MW"] = "0"
     if args.config == 5:
         return mixed_bench(args)
 
