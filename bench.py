@@ -193,11 +193,6 @@ def main():
     if args.config != 2:
         preset = CONFIGS[args.config]
         args.agent, args.furniture, args.envs_per_gpu = preset["agent"], preset["furniture"], preset["envs"]
-    if args.envs_per_gpu > 4096 and "FSIM_MW" not in os.environ:
-        # four waves for the envs that set the step time pay while the chip has idle wave slots behind them (4096 envs on 2048 slots);
-        # with more envs per GPU the step is throughput-bound and the helpers' slots are missed: Sawyer + swivel_chair at 8192 envs,
-        # four slabs of 2048: 953 k env-steps/s with the multi-wave rule, 1.06 M on the one-wave kernel (a handle cannot see the others')
-        os.environ["FSIM_MW"] = "0"
     if args.config == 5:
         return mixed_bench(args)
 
@@ -400,7 +395,7 @@ def main():
             # (profiles/pmc_latest.json), not from this run.
             "roofline": {"bound": "hbm", "bound_actual": "per-wave instruction issue + LDS latency (see binding)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_env_step_x" if os.environ.get("FSIM_MW", "1") not in ("0", "all") else "k_env_step", "kernel_avg_ms": kms, "kernel_launches": klaunches,
+                         "kernel": "k_env_step_x" if (os.environ.get("FSIM_MW", "1") not in ("0", "all") and n <= 4096 and ng <= 2048) else "k_env_step",  # (the library's rule: fsim.hip mw_total_limit) "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <atomic>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -321,6 +322,8 @@ typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KPara
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
 struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 
+static std::atomic<int> g_envs_on_device[64]; // envs of the live handles of this process, per device (the multi-wave rule looks at the whole load)
+
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
@@ -330,6 +333,8 @@ struct fsim {
   // the scheduler picks get four waves, the others ride in bundles of four (default) --, 2 = every env gets four waves in every
   // launch (FSIM_MW=0 / all; development and tests)
   int mw_mode = 1, mw_k = 150, mw_cap = 0;
+  bool registered = false;
+  int mw_total_limit = 0; // 0: no limit; else the multi-wave rule is only applied while the process's handles on this device hold at most this many envs
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
@@ -596,6 +601,10 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
       hipDeviceProp_t pr;
       HIPCHK(hipGetDeviceProperties(&pr, device));
       if (n_envs > 8 * pr.multiProcessorCount) s->mw_mode = 0;
+      // ... and the same across handles: slabs stepped on separate streams share the chip, so the rule is also off while the live
+      // handles of this process on this device hold more than TWO rounds of envs together (g_envs_on_device, checked per launch:
+      // four slabs of 2048 swivel-chair envs ran 953 k env-steps/s with the rule and 1.06 M without)
+      s->mw_total_limit = 2 * 8 * pr.multiProcessorCount;
     }
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
@@ -671,12 +680,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
+  g_envs_on_device[s->device & 63] += s->n_envs; s->registered = true;
   *out = s;
   return FSIM_OK;
 }
 
 extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
+  if (s->registered) g_envs_on_device[s->device & 63] -= s->n_envs;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
@@ -884,7 +895,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
-  const bool mw_auto = sched && s->mw_mode == 1, mw_all = s->mw_mode == 2;
+  const bool mw_auto = sched && s->mw_mode == 1 && (!s->mw_total_limit || g_envs_on_device[s->device & 63].load() <= s->mw_total_limit), mw_all = s->mw_mode == 2;
   if (sched)
     hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), (size_t)s->n_envs * 4, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
                        s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? 1 : 0, s->d_mworder, s->d_mwn, s->d_mwn + 1);
