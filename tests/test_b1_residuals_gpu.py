@@ -156,3 +156,70 @@ def test_reset_robot_after_attach_reposes_the_arm_and_keeps_the_rng_stream():
     for i in range(n):
         assert np.abs(od[i] - orcs[i].flat_obs(orcs[i].reset())).max() < 5e-5
     env.close()
+
+
+def test_reset_robot_after_attach_resynchronises_the_ik_target():
+    """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
+    target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it
+    attached.  Scripted pinch + connect with both sides' IK state synchronised to the pinch pose; compared: the target after the connect step,
+    the arm after it and after one more (motionless) IK step."""
+    import torch
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.sim import FSim, INFO_DIM, default_config
+    from oracle import ik as IK
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import pinch_attach_state
+    m = load_compiled("Sawyer", "table_lack_0825")
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset, cfg.control_type, cfg.reset_robot_after_attach = 150, 0, 7, 1
+    sim = FSim(m, 1, config=cfg)
+    o = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=150, seed=5, solver_tolerance=1e-10, control_type="ik", reset_robot_after_attach=True))
+    o.reset()
+    sim.set_reset_tables(o.reset_draws["part_qpos"].reshape(1, -1), np.stack(o.reset_draws["noise"]).reshape(1, -1))
+    dev = sim.device
+    obs = torch.zeros((1, sim.obs_dim), device=dev)
+    sim.reset(None, obs)
+    sim.sync()
+    # the pinch pose on both sides, IK state (target position, reference orientation, hand position) synchronised to it
+    q, xfrc, masks = pinch_attach_state(m, o.sim.data.qpos.copy(), o.sim.data.xpos.copy(), o.sim.data.xquat.copy())
+    o.sim.data.qpos[:], o.sim.data.qvel[:], o.sim.data.qacc_warmstart[:] = q, 0, 0
+    for i in range(m.nparts):
+        o.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+    st = sim.get_state("qpos", "qvel", "qacc_warmstart", "xfrc_applied", "geom_contype", "geom_conaffinity", "env_block")
+    for g, (ct, ca) in masks.items():
+        o.sim.model.geom_contype[g], o.sim.model.geom_conaffinity[g] = ct, ca
+        st["geom_contype"][0, g], st["geom_conaffinity"][0, g] = ct, ca
+    o.sim.forward()
+    o._initial_hand_quat = [o._hand_quat(0)]
+    o._ik_tp = [IK.fk(m, o.sim.data.qpos[m.arm_qposadr[:7]], 0)[0]]
+    o._initial_right_hand_quat, o._ik_target_pos = o._initial_hand_quat[0], o._ik_tp[0]
+    blk = st["env_block"][:, -26:].cpu().numpy().view(np.float32).copy()  # fsim_ik.hpp EI_*: target 0..2, reference quaternion 3..6, hand position 22..24
+    blk[0, 0:3], blk[0, 3:7], blk[0, 22:25] = o._ik_tp[0], o._initial_hand_quat[0], o.sim.data.xpos[int(m.hand_bodyid[0])]
+    st["env_block"][:, -26:] = torch.as_tensor(blk.view(np.int32), device=st["env_block"].device)
+    st["qpos"][0] = torch.as_tensor(q, dtype=st["qpos"].dtype)
+    st["qvel"][0], st["qacc_warmstart"][0] = 0, 0
+    st["xfrc_applied"][0] = torch.as_tensor(xfrc.reshape(-1), dtype=st["xfrc_applied"].dtype)
+    sim.set_state(**st)
+    # the attach draw the oracle is about to take
+    r = np.random.RandomState()
+    r.set_state(o._rng.get_state())
+    sim.set_attach_noise(r.uniform(low=-o.cfg.agent_xyz_rand, high=o.cfg.agent_xyz_rand, size=7)[None])
+    act = torch.zeros((1, 8), device=dev)
+    rew, done = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.uint8, device=dev)
+    info = torch.zeros((1, INFO_DIM), dtype=torch.int32, device=dev)
+    for t, a in enumerate([np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32), np.array([0, 0, 0, 0, 0, 0, 1, -1], dtype=np.float32)]):
+        act.copy_(torch.as_tensor(a[None]))
+        torch.cuda.synchronize()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        ob, rr, d, inf = o.step(a.astype(np.float64))
+        if t == 0:
+            assert inf["connected_this_step"] == 1 and int(info[0, 6]) == 1 and len(o.attach_draws) == 1
+        tgt = sim.get_state("env_block")["env_block"][:, -26:].cpu().numpy().view(np.float32)[0, :3]
+        qd = sim.get_state("qpos")["qpos"][0].cpu().numpy()
+        assert np.abs(tgt - o._ik_target_pos).max() < 1e-4, t
+        assert np.abs(qd[m.arm_qposadr] - o.sim.data.qpos[m.arm_qposadr]).max() < 2e-3, t
+        if t == 0:  # re-posed: near the initial pose.  (The next IK step turns the hand back to the orientation it had when the IK state was
+            #         synchronised -- sync_state() moves the target POSITION only, on both sides -- so the joints move again, by 0.6 rad.)
+            assert np.abs(o.sim.data.qpos[m.arm_qposadr] - m.arm_initqpos).max() < 0.05
+    sim.close()
