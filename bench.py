@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
     ap.add_argument("--control-type", default="impedance", help="(exploration only) a torque-level arm controller, e.g. position_orientation")
     ap.add_argument("--obs-bf16", action="store_true", help="store the observation slab as bfloat16 (BASELINE config 2's narrow slab; state stays fp32)")
+    ap.add_argument("--no-lookahead", action="store_true", help="(exploration only) resets run inside the terminal step's launch instead of ahead of time (fsim_config_t::lookahead_reset = 0)")
+    ap.add_argument("--multi-wave", default="auto", choices=["auto", "off", "rule", "all"], help="(exploration only) fsim_config_t::multi_wave of every slab")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "4")),
                     help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
     args = ap.parse_args()
@@ -201,7 +203,7 @@ def main():
     from furniture_amd.dist import gather_observations, shard_range
     from furniture_amd.envs import ResetTableQueue, ResetTableSampler, make_config
     from furniture_amd.mjcf.model import load_compiled
-    from furniture_amd.sim import FSim, INFO_DIM, INFO_NEEDS_TABLE, default_config
+    from furniture_amd.sim import FSim, INFO_DIM, INFO_NEEDS_TABLE, MULTI_WAVE, default_config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -224,6 +226,12 @@ def main():
     cfg.max_episode_steps = MAX_EPISODE_STEPS
     cfg.auto_reset = 1
     cfg.obs_bf16 = 1 if args.obs_bf16 else 0
+    cfg.lookahead_reset = 0 if args.no_lookahead else 1
+    # which step kernel: the library's "auto" looks at one handle's env count; the slabs of this rank share the chip, so the rule is
+    # applied while they hold at most two rounds of envs together (8 env slots per CU: 4096 on MI355X) and the one-wave kernel
+    # otherwise (config 3: four slabs of 2048 swivel-chair envs ran 953 k env-steps/s with the rule and 1.06 M without)
+    slots = 8 * torch.cuda.get_device_properties(local).multi_processor_count
+    cfg.multi_wave = MULTI_WAVE[args.multi_wave] if args.multi_wave != "auto" else (MULTI_WAVE["off"] if n > 2 * slots else MULTI_WAVE["auto"])
     if args.control_type != "impedance":
         from furniture_amd.envs import CONTROLLER_CODES
         cfg.control_type = CONTROLLER_CODES[args.control_type]
@@ -342,6 +350,7 @@ def main():
 
     run_steps(args.warmup)
     drain()
+    la0 = [sl.sim.lookahead_stats() for sl in slabs]
     for sl in slabs:
         sl.sim.kernel_time_ms()  # reset the accumulators
     if distributed:
@@ -355,6 +364,9 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     kt = [sl.sim.kernel_time_ms() for sl in slabs]
+    la1 = [sl.sim.lookahead_stats() for sl in slabs]
+    la = {k: sum(b[k] - a[k] for a, b in zip(la0, la1)) for k in ("launched", "swapped", "inline")}
+    reset_substeps = 401 if m.meta.get("has_recipe") else 301  # sim.step() calls of one _reset (tests/golden/reset_trace.npz)
     klaunches = sum(k[1] for k in kt)
     kms = sum(k[0] * k[1] for k in kt) / max(1, klaunches)
     if distributed:
@@ -379,6 +391,24 @@ def main():
                             % (pmc.get("source", "profiles/"), pmc["bytes_per_env_step"], ng))
         except Exception:
             pass
+        # chip-wide utilisation of THIS run: instructions per env-step (PMC, a property of the workload) x the measured env-step rate
+        # over the issue slots of the chip (SIMDs x clock; one wave-instruction per SIMD per cycle at best)
+        props = torch.cuda.get_device_properties(local)
+        simds, clk = props.multi_processor_count * 4, props.clock_rate * 1e3
+        per_gpu_rate = value / world
+        util = lambda k: (pmc[k] * per_gpu_rate / (simds * clk)) if pmc.get(k) else None
+        binding = {"bound": "per-wave instruction issue + LDS wait (not HBM, not MFMA); the step ends with its slowest env",
+                   "issue_util_this_run": util("insts_per_env_step"), "valu_util_this_run": util("valu_insts_per_env_step"),
+                   "util_def": "wave-instructions (all / VALU) issued per SIMD per cycle, chip-wide, over the timed region: PMC instructions per env-step x measured env-steps/s / (SIMDs x clock)",
+                   "simds": simds, "clock_hz": clk,
+                   "occupancy_this_run_waves_per_simd": (pmc["wave_cycles_per_env_step"] * per_gpu_rate / (simds * clk)) if pmc.get("wave_cycles_per_env_step") else None,
+                   "waves_per_simd_limit": 2,
+                   "wait_frac": pmc.get("wait_frac"), "issue_frac": pmc.get("issue_frac"),
+                   "insts_per_env_step": pmc.get("insts_per_env_step"), "valu_insts_per_env_step": pmc.get("valu_insts_per_env_step"),
+                   "wave_cycles_per_env_step": pmc.get("wave_cycles_per_env_step"),
+                   "algorithmic_flops_per_env_step": [1.5e6, 5.5e6], "fp32_vector_peak_tflops": 157.3,
+                   "achieved_tflops_algorithmic": [1.5e6 * per_gpu_rate / 1e12, 5.5e6 * per_gpu_rate / 1e12],
+                   "pmc_source": "builder-lease PMC passes (per-env-step counts), not this run: %s" % pmc.get("source")}
         line = {
             "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n, args.dense, args.control_type) == (AGENT, FURNITURE, ENVS_PER_GPU, False, "impedance")
             else "env-steps/sec (whole node), EXPLORATION %s+%s%s %d envs/GPU" % (args.agent, args.furniture, (" dense-reward" if args.dense else "") + ("" if args.control_type == "impedance" else " control_type=" + args.control_type), n), "value": value, "unit": "env-steps/s",
@@ -388,29 +418,28 @@ def main():
                                    "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
+                       "rccl_world": dist.get_world_size() if distributed else 1,  # ranks RCCL's communicator saw (1 without torch.distributed.run)
+                       # every episode end costs its reset (the reference's _reset: 401 sim.step() calls here).  They are executed INSIDE the
+                       # timed region, ahead of the step that needs them (look-ahead: shadow launches on a low-priority stream) or inside it
+                       "resets_in_timed_region": la["swapped"] + la["inline"], "resets_taken_from_lookahead": la["swapped"], "resets_inside_step_launch": la["inline"],
+                       "lookahead_resets_launched_in_timed_region": la["launched"],
+                       "reset_substeps_in_timed_region": (la["launched"] + la["inline"]) * reset_substeps,
                        "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
-            # `bound`: the contract offers "hbm" | "mfma"; the path is neither (see `binding`) -- HBM is the one of the two it is priced
-            # against, as BASELINE.json asks.  `traffic` / `binding` come from the builder's own rocprofv3 PMC passes of this workload
-            # (profiles/pmc_latest.json), not from this run.
-            "roofline": {"bound": "hbm", "bound_actual": "per-wave instruction issue + LDS latency (see binding)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: what the contract's two choices are priced against is HBM (BASELINE.json asks for the HBM fraction) and `frac` is
+            # computed against it; what actually binds is neither -- `bound_actual` / `binding` say what, with numbers.  `traffic` and the
+            # per-env-step instruction counts come from the builder's own rocprofv3 PMC passes of this workload (profiles/pmc_latest.json),
+            # the utilisation figures below are recomputed FOR THIS RUN from them and this run's measured rate.
+            "roofline": {"bound": "hbm", "bound_actual": "per-wave instruction issue + LDS latency, at a batch-synchronous step that ends with its slowest env (see binding)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_env_step_x" if (os.environ.get("FSIM_MW", "1") not in ("0", "all") and n <= 4096 and ng <= 2048) else "k_env_step",  # (the library's rule: fsim.hip mw_total_limit) "kernel_avg_ms": kms, "kernel_launches": klaunches,
+                         "kernel": slabs[0].sim.step_kernel, "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
                          # wave issues at most one instruction per ~5 cycles (scripts/dev/micro: 5.0 cycles per dependent-distance-4
                          # v_fma at 1-2 waves per SIMD), so an env-step costs ~5 cycles x instructions + LDS waits
-                         "binding": {"bound": "per-wave instruction issue + LDS wait (not HBM, not MFMA)",
-                                     "valu_util": pmc.get("valu_issue_util"), "valu_util_def": "VALU wave-instructions per SIMD per cycle over the launch (peak ~1)",
-                                     "waves_per_simd": pmc.get("waves_per_simd"), "waves_per_simd_limit": 2,
-                                     "wait_frac": pmc.get("wait_frac"), "issue_frac": pmc.get("issue_frac"),
-                                     "insts_per_env_step": pmc.get("insts_per_env_step"), "valu_insts_per_env_step": pmc.get("valu_insts_per_env_step"),
-                                     "wave_cycles_per_env_step": pmc.get("wave_cycles_per_env_step"),
-                                     "algorithmic_flops_per_env_step": [1.5e6, 5.5e6],
-                                     "fp32_vector_peak_tflops": 157.3,
-                                     "achieved_tflops_algorithmic": [1.5e6 * value / 1e12, 5.5e6 * value / 1e12],
-                                     "source": "builder-lease PMC passes, not this run: %s" % pmc.get("source")}},
+                         "binding": binding},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -16,7 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
-#include <atomic>
+#include <deque>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -96,10 +96,18 @@ struct StepArgs {
   const uint8_t *init_mask;
   int *nreset;
   const EnvCfg *cfg_dev; // `cfg` again, in device memory (for the out-of-line env_reset: EnvResetIO)
+  // look-ahead reset: shadow records [n][stride], shadow observation rows [n][obs_dim] (f32 | bf16), tags [n]; null = off
+  float *sh_state;
+  void *sh_obs;
+  int *sh_tag;
+  int ready_seq;
+  int *stats; // host-mapped counters (fsim::h_nreset + 1): [0] resets taken from a shadow record, [1] resets executed in a step / reset launch
 };
+enum { JOB_AUTO = 0 /* a.do_step decides */, JOB_RESET = 1 /* the deferred reset of a multi-wave workgroup's env */ };
 // load_cache: the wave's LDS copy of the model tables is not there yet (a bundled wave steps several envs one after the other
 // and loads it once)
-template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, long long t_entry, bool load_cache = true) {
+// returns 1 if the env's reset was deferred (DEFER, see env_step): the caller runs it as a JOB_RESET
+template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const StepArgs &a, int env, long long t_entry, bool load_cache = true, int job = JOB_AUTO) {
   float *L = c.L;
   const int lane = c.lane;
   const EnvCfg &cfg = a.cfg;
@@ -129,8 +137,15 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   io.cost = a.cost ? a.cost + env : nullptr;
   io.t0 = t_entry;
   io.cfg_dev = a.cfg_dev;
-  if (a.do_step) env_step(c, cfg, io);
-  else if (!a.reset_mask || a.reset_mask[env]) { env_reset(c, a.cfg_dev, env_reset_io(io)); env_write_obs(c, cfg, io); }
+  io.sh_state = a.sh_state ? a.sh_state + (size_t)env * c.ly.stride : nullptr;
+  io.sh_obs = a.sh_obs ? static_cast<const char *>(a.sh_obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4) : nullptr;
+  io.sh_tag = a.sh_tag ? a.sh_tag + env : nullptr;
+  io.ready_seq = a.ready_seq;
+  io.stats = a.stats;
+  int deferred = 0;
+  if (job == JOB_RESET) env_reset_or_swap(c, cfg, io);
+  else if (a.do_step) deferred = env_step<Ctx, DEFER>(c, cfg, io);
+  else if (!a.reset_mask || a.reset_mask[env]) env_reset_or_swap(c, cfg, io);
   if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   SYNC();
 #ifdef FSIM_PROFILE
@@ -148,6 +163,46 @@ template <class Ctx> DEV void env_run(const Ctx &c, const StepArgs &a, int env, 
   if (a.prof && lane < 48) a.prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + (lane < c.D.nv ? lane : 7 * c.D.nr + 4 + lane)] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
 #endif
   store_record(rec, L, c.ly.stride, lane);
+  return deferred;
+}
+
+// Look-ahead reset of ONE env (k_env_shadow): the reset its next episode will start from, computed from the reset table the host has
+// already uploaded, into the env's shadow record + observation row.  env_reset + env_post: exactly what a reset inside a launch runs.
+template <class Ctx> DEV void env_shadow_run(const Ctx &c, const StepArgs &a, int env, int seq) {
+  float *L = c.L;
+  const int lane = c.lane;
+  const EnvCfg &cfg = a.cfg;
+  // (a reset overwrites every word of the record but the episode counter and the sticky overflow report, which the swap takes from the
+  //  live record; the live record itself is being stepped on another stream and is not read here)
+  for (int i = lane; i < c.ly.stride; i += 64) L[i] = 0.0f;
+  for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
+  SYNC();
+  fs_load_cache(c);
+  EnvIO io{};
+  io.obs = reinterpret_cast<float *>(static_cast<char *>(a.sh_obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4));
+  io.tab_parts = a.tab_parts ? a.tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
+  io.tab_noise = a.tab_noise ? a.tab_noise + (size_t)env * a.n_noise * c.D.narmj : nullptr;
+  io.n_noise = a.n_noise;
+  io.init_state = (a.init_state && a.init_mask && a.init_mask[env]) ? a.init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
+  io.cfg_dev = a.cfg_dev;
+  env_reset(c, a.cfg_dev, env_reset_io(io));
+  env_post(c, cfg, io, 0);
+  SYNC();
+  store_record(a.sh_state + (size_t)env * c.ly.stride, L, c.ly.stride, lane);
+  __threadfence();
+  if (lane == 0) a.sh_tag[env] = seq;
+}
+struct ShadowList { int n; int env[63]; };
+// one env per wave; Ctx::BUNDLE: four independent waves (own LDS images) per workgroup, as in the bundles of k_env_step_x -- a
+// workgroup of the step kernel needs half a CU's LDS, so a lone 20 KB shadow workgroup would cost the CU one of its two slots for the
+// ~40 ms a reset takes; four resets per workgroup take that slot for four envs
+template <class Ctx> __global__ __launch_bounds__(64 * (Ctx::BUNDLE ? 4 : 1), 2) void k_env_shadow(const DModel *mp, const Layout *lp, KParams kp, StepArgs a, ShadowList list, int seq) {
+  extern __shared__ float L[];
+  CModel &m = *(CModel *)mp;
+  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+  const int idx = (int)blockIdx.x * (Ctx::BUNDLE ? 4 : 1) + c.wave;
+  if (idx >= list.n) return;
+  env_shadow_run(c, a, list.env[idx], seq);
 }
 
 // One env per workgroup: the one-wave kernel (Ctx::NW == 1; workgroup b steps env order[b]) and the multi-wave kernel on its own
@@ -164,33 +219,57 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_st
   env_run(c, a, env, t_entry);
 }
 
-// The step kernel proper: ONE launch of 4-wave workgroups.  Workgroups [0, mw_cap) are multi-wave envs (workgroup b steps env
-// mworder[b] with four waves if b < *mwn, else it leaves at once); every workgroup behind them is a BUNDLE of four one-wave envs
-// (each wave has its own LDS image; the four waves never synchronise).  Workgroups are
-// dispatched in index order, so the multi-wave envs -- the long jobs -- are placed first; with the two kinds in separate launches
-// the one-wave workgroups took every slot that freed up and the 4-wave ones starved until the others had all been dispatched.
+// The step kernel proper: ONE launch of persistent 4-wave workgroups.  Every workgroup first serves the MULTI-WAVE queue -- the envs
+// the scheduler selected (mworder[0 .. *mwn)): four waves step one env, wave 0 as main, the others as its helpers -- and, once that
+// queue is empty, turns into a BUNDLE: four independent one-wave workers (each wave its own LDS image, never synchronising again) that
+// take envs of the longest-job-first list from a device-wide queue until it is empty (a workgroup's LDS is only released when its
+// last wave ends, so fixed bundles would idle behind their slowest env).  Workgroups are dispatched in index order and the first
+// thing any of them does is take a multi-wave env, so the long jobs start first; with the two kinds in separate launches the one-wave
+// workgroups took every slot that freed up and the 4-wave ones starved.  There is no cap on the number of multi-wave envs: the
+// selection is a function of each env's own state, whatever the rest of the batch does (a cap would make an env's arithmetic depend
+// on its neighbours), and a launch with more of them than workgroups just serves them in turn.
+// q: [0] multi-wave envs of the launch, [1] the others, [2] head of the bundle queue, [3] head of the multi-wave queue (k_schedule)
 template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_env_step_x(const DModel *mp, const Layout *lp, const Layout *lp_mw, KParams kp, StepArgs a,
-                                                                                           const int *order, const int *nbulk, const int *mworder, const int *mwn, int mw_cap, int *qhead) {
+                                                                                           const int *order, const int *mworder, int *q) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
-  const int b = blockIdx.x;
-  if (b < mw_cap) {
-    if (b >= *mwn) return;
-    const CtxM c(L, m, *(CLayout *)lp_mw, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
-    if (c.wave > 0) { mw_helper_loop(c); return; }
-    env_run(c, a, mworder[b], t_entry);
-  } else {
-    // bundled waves are persistent: each takes the next env of the longest-job-first list from a device-wide queue until it is
-    // empty (a workgroup's LDS is only released when its last wave ends, so fixed bundles would idle behind their slowest env)
+  const int nmw = q[0];
+  // Envs of this workgroup's multi-wave phase whose step ended the episode with no shadow record ready: their reset is ONE-wave work
+  // (env_step DEFER) and runs in the bundle phase below, on wave 0, before it takes anything from the queue -- the same instantiation
+  // a bundled env's reset runs, so a reset's bits do not depend on who stepped the env.  Up to four 16-bit env indices in a register
+  // pair (wave 0's); a workgroup whose list is full leaves the multi-wave phase (the other workgroups serve the queue).
+  unsigned long long defs = 0;
+  int ndef = 0;
+  if (nmw > 0) {
+    int *s_slot = reinterpret_cast<int *>(L); // (between two envs nothing in the workgroup's LDS is live)
+    for (;;) {
+      if (threadIdx.x == 0) *s_slot = ndef == 4 ? 0x7fffffff : atomicAdd(q + 3, 1);
+      __syncthreads();
+      const int slot = __builtin_amdgcn_readfirstlane(*s_slot);
+      __syncthreads(); // (everybody has read the slot before wave 0 goes on and overwrites it)
+      if (slot >= nmw) break;
+      const CtxM c(L, m, *(CLayout *)lp_mw, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+      if (c.wave > 0) { mw_helper_loop(c); continue; }
+      const int env = mworder[slot];
+      if (env_run<CtxM, true>(c, a, env, t_entry)) { defs = (defs << 16) | (unsigned)env; ndef++; }
+      t_entry = clock64();
+    }
+  }
+  {
     const CtxB c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
-    const int nb = *nbulk;
+    const int nb = q[1];
     for (bool first = true;; first = false) {
-      int slot = 0;
-      if (c.lane == 0) slot = atomicAdd(qhead, 1);
-      slot = __builtin_amdgcn_readfirstlane(slot);
-      if (slot >= nb) break;
-      env_run(c, a, order[slot], first ? t_entry : clock64(), first);
+      int env, job = JOB_AUTO;
+      if (ndef > 0) { env = (int)(defs & 0xffffu); defs >>= 16; ndef--; job = JOB_RESET; } // (wave 0 only: ndef is 0 on the others)
+      else {
+        int slot = 0;
+        if (c.lane == 0) slot = atomicAdd(q + 2, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= nb) break;
+        env = order[slot];
+      }
+      env_run(c, a, env, first ? t_entry : clock64(), first, job);
     }
   }
 }
@@ -204,14 +283,15 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
 // ONE wavefront with a few registers: the kernel runs between two step kernels of its stream while the other slab's step kernel
 // holds every SIMD's register file (2 x 256 VGPRs) -- a 1024-thread workgroup had to wait ~0.2 ms for a whole CU to drain
 // before it could start (rocprofv3: 217 us average for 10 us of work), a single small wave takes the first slot that frees.
-// Multi-wave selection (use_mw): env i goes to the multi-wave workgroups of this launch iff its last step took at least mw_k
-// Newton iterations (E_NITER of its record: a function of the env's state, never of timing, so results do not depend on the
-// schedule), the first mw_cap such envs in index order -> mworder / *mwn; `order` / *nbulk then list the others.
+// Multi-wave selection (use_mw): env i goes to the multi-wave queue of this launch iff its last step took at least mw_k
+// Newton iterations (E_NITER of its record) and it is not about to hit the time limit (key -1: its step ends in a reset, which is
+// one-wave work) -- a function of the env's OWN state, never of timing or of the other envs of the batch, so an env's results do not
+// depend on the schedule, the batch it is stepped in or the slab layout -> mworder / q[0]; `order` / q[1] then list the others.
 // The kernel is one latency chain (it sits between two step kernels of its stream): the keys are fetched once, eight loads in
 // flight per lane, and kept in LDS for the sorting passes (208 us -> ~20 us for 2048 envs).
 #define FSIM_SCHED_SELECTED ((int)0x80000000)
-__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int mw_cap, int use_mw,
-                                                int *mworder, int *mwn, int *nbulk) {
+__global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int use_mw,
+                                                int *mworder, int *q) {
   extern __shared__ int keys[]; // [n]
   __shared__ int hist[257];
   const int tid = threadIdx.x;
@@ -228,18 +308,17 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int i = i0 + 64 * u + tid;
-      const bool sel = i < n && v[u] >= mw_k;
-      const unsigned long long mask = __ballot(sel);
+      const bool take = i < n && v[u] >= mw_k && cv[u] != -1;
+      const unsigned long long mask = __ballot(take);
       const int idx = base + __popcll(mask & ((1ull << tid) - 1ull));
-      const bool take = sel && idx < mw_cap;
       if (take) mworder[idx] = i;
       base += __popcll(mask);
       if (i < n) keys[i] = take ? FSIM_SCHED_SELECTED : cv[u];
       if (i < n && !take && cv[u] >= 0) lm = max(lm, cv[u] & 0x3fffffff);
     }
   }
-  const int nsel = min(base, mw_cap);
-  if (tid == 0) { *mwn = nsel; *nbulk = n - nsel; nbulk[1] = 0; } // (nbulk[1]: head of the bundled waves' work queue)
+  const int nsel = base;
+  if (tid == 0) { q[0] = nsel; q[1] = n - nsel; q[2] = 0; q[3] = 0; } // (q[2], q[3]: heads of the bundle / multi-wave work queues)
   for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
   __syncthreads();
   // (a float multiply, not a 64-bit division: the inlined division routines were half of this kernel's code, and the code is never in
@@ -318,27 +397,30 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *);
-typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, const int *, const int *, int, int *);
+typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *);
+typedef void (*EnvShadowFn)(const DModel *, const Layout *, KParams, StepArgs, ShadowList, int);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
-struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
-
-static std::atomic<int> g_envs_on_device[64]; // envs of the live handles of this process, per device (the multi-wave rule looks at the whole load)
+// env_shadow_1 / env_shadow_b: the look-ahead reset kernel on the context type whose env_reset the handle's step kernel runs -- the
+// one-wave kernel's, or the bundled waves' of k_env_step_x (same instantiation = same bits)
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; EnvShadowFn env_shadow_1, env_shadow_b; };
+enum { MW_OFF = 0, MW_RULE = 1, MW_ALL = 2 }; // fsim::mw_mode
+struct ShadowBatch { int seq; hipEvent_t ev; };
 
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
   hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
-  // multi-wave kernels (fsim_solver.hpp): mode 0 off (one-wave kernel only), 1 = a step is ONE launch of k_env_step_x -- the envs
-  // the scheduler picks get four waves, the others ride in bundles of four (default) --, 2 = every env gets four waves in every
-  // launch (FSIM_MW=0 / all; development and tests)
-  int mw_mode = 1, mw_k = 150, mw_cap = 0;
-  bool registered = false;
-  int mw_total_limit = 0; // 0: no limit; else the multi-wave rule is only applied while the process's handles on this device hold at most this many envs
+  // multi-wave kernels (fsim_solver.hpp): MW_OFF one-wave kernel only, MW_RULE = a step is ONE launch of k_env_step_x -- the envs
+  // the scheduler's rule picks get four waves, the others ride in bundles of four --, MW_ALL = every env gets four waves in every
+  // launch (development and tests).  Decided ONCE, at fsim_create, from fsim_config_t::multi_wave (auto: from n_envs and the device's CU
+  // count alone) and reported by fsim_step_kernel(): an env's arithmetic depends on the mode, so nothing else may change it.
+  int mw_mode = MW_RULE, mw_k = 150;
+  char step_kernel[96] = "";
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
-  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others, d_mwn[2] = work-queue head
+  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others, d_mwn[2] / [3] = heads of the bundle / multi-wave queues
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   DModel m{};
   Layout ly{};
@@ -367,7 +449,25 @@ struct fsim {
   int acc_n = 0;
   bool timing_pending = false, timing = false; // HIP-event timing of the step kernel: off until fsim_kernel_time_ms is first called
   int nbody = 0, ngeom = 0;
+  // ---- look-ahead reset (env_shadow_run): the reset of every env's NEXT episode is computed ahead of time on a low-priority stream
+  // from the reset table the host has already uploaded, into shadow records the terminal step copies in
+  bool la_on = false;
+  hipStream_t la_stream = nullptr;
+  float *d_sh_state = nullptr;
+  void *d_sh_obs = nullptr;
+  int *d_sh_tag = nullptr;             // [n] sequence number of the shadow launch that wrote the env's shadow (0: none / consumed)
+  std::vector<uint8_t> la_pending;     // env needs a shadow (its table is fresh, no shadow launch covers it yet)
+  std::vector<int> la_since;           // la_step at which it became pending (launches are deferred: see la_launch)
+  std::vector<int> la_env_seq;         // sequence number of the last shadow launch that contained the env
+  int la_npending = 0, la_seq = 0, la_ready = 0, la_step = 0, la_cursor = 0;
+  int la_defer = 0, la_rate = 0;
+  std::deque<ShadowBatch> la_inflight;
+  std::vector<hipEvent_t> la_evpool;
+  long long la_launched = 0;           // shadow resets launched so far
 };
+
+static void la_policy(fsim *s);
+static int la_invalidate(fsim *s, const uint8_t *mask);
 
 struct Arena {
   std::vector<char> host;
@@ -409,6 +509,7 @@ extern "C" void fsim_default_config(fsim_config_t *c) {
   c->control_type = 0; c->n_substeps = 50; c->max_episode_steps = 2000; c->discrete_grip = 1; c->rescale_actions = 1;
   c->auto_align = 1; c->num_connect_steps = 0; c->auto_reset = 1; c->solver_iterations = 100; c->reset_robot_after_attach = 0;
   c->solver_tolerance = 1e-6f;
+  c->multi_wave = 0; c->lookahead_reset = 1;
   c->alignment_pos_dist = 0.1f; c->alignment_rot_dist_up = 0.9f; c->alignment_rot_dist_forward = 0.9f; c->alignment_project_dist = 0.3f;
   c->ctrl_penalty_coef = 1e-3f; c->unstable_penalty_coef = 100.f; c->success_reward = 100.f; c->touch_reward = 10.f; c->pick_reward = 100.f;
   c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3.f; c->agent_xyz_rand = 0.001f;
@@ -535,13 +636,13 @@ static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, size
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
 static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg) { // plain_cfg: no controller / IK / dense reward (SpecCtx::PLAIN)
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>, k_env_shadow<SpecCtx<S>>, k_env_shadow<SpecCtx<S, 1, true>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
   // (more than 64 contact slots: two slot sets per lane in the Newton solve -- one-wave kernels only)
-  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr};
-  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
+  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr, k_env_shadow<GenCtxT<1, false, 2>>, nullptr};
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>, k_env_shadow<GenCtx>, k_env_shadow<GenCtxT<1, true>>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -565,7 +666,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (ncon_max < 8 || ncon_max > 128) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 128] (the Newton solve keeps one or two contact slots per lane)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
   if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, on a model compiled with the IK chain table"); }
-  if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built; the reference's 'torque' path writes an 8-vector into a 9-actuator ctrl", cfg ? cfg->control_type : 0); }
+  if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance; also the reference's 'torque', which is the impedance flow on the motor-actuated model), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built", cfg ? cfg->control_type : 0); }
   if (env_controller_kind(s->cfg)) {
     if (s->m.agent != 0 || s->cfg.dense_reward) { delete s; FAIL(FSIM_EINVAL, "arm controllers (control_type 2..6) are built for the Sawyer agent, sparse reward"); }
     std::vector<float> ag; blob_f(s->blob, "actuator_gain", ag);
@@ -586,32 +687,32 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->ly_mw = make_layout(lin, FSIM_MW_NW);
     s->lds_bytes_mw = s->ly_mw.lds_words * 4;
     s->lds_bytes_x = std::max(s->lds_bytes_mw, FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words));
-    if (const char *e = getenv("FSIM_MW")) s->mw_mode = !strcmp(e, "all") ? 2 : (atoi(e) ? 1 : 0);
+    // fsim_config_t::multi_wave: 0 auto, 1 off, 2 rule, 3 all.  (FSIM_MW=0 / 1 / all in the environment overrides it: development)
+    int want = s->cfg.multi_wave;
+    if (const char *e = getenv("FSIM_MW")) want = !strcmp(e, "all") ? 3 : (atoi(e) ? 2 : 1);
+    if (want < 0 || want > 3) { delete s; FAIL(FSIM_EINVAL, "fsim_config_t::multi_wave must be 0 (auto), 1 (off), 2 (rule) or 3 (all)"); }
     if (const char *e = getenv("FSIM_MW_K")) s->mw_k = atoi(e);
-    s->mw_cap = std::max(1, n_envs / 8);
-    if (const char *e = getenv("FSIM_MW_CAP")) s->mw_cap = std::max(1, std::min(n_envs, atoi(e)));
-    if (getenv("FSIM_NO_LPT") && s->mw_mode == 1) s->mw_mode = 0; // (the selection is part of the scheduler kernel)
-    if (s->lds_bytes_mw > 160 * 1024 || !s->ks.env_step_x) s->mw_mode = 0;
-    // bundles of four keep today's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
-    if (s->mw_mode == 1 && 2 * s->lds_bytes_x > 160 * 1024) s->mw_mode = 0;
-    // a launch with many rounds of envs per wave slot is bound by throughput, not by its slowest env: four waves per env cost
-    // slots there (Sawyer + swivel_chair at 8192 envs: 1.03 M env-steps/s on the one-wave kernel, 0.95 M with the default rule)
-    // -- rule: more envs than the chip has wave slots (8 per CU) -> one-wave kernel
-    if (s->mw_mode == 1 && !getenv("FSIM_MW")) {
-      hipDeviceProp_t pr;
-      HIPCHK(hipGetDeviceProperties(&pr, device));
-      if (n_envs > 8 * pr.multiProcessorCount) s->mw_mode = 0;
-      // ... and the same across handles: slabs stepped on separate streams share the chip, so the rule is also off while the live
-      // handles of this process on this device hold more than TWO rounds of envs together (g_envs_on_device, checked per launch:
-      // four slabs of 2048 swivel-chair envs ran 953 k env-steps/s with the rule and 1.06 M without)
-      s->mw_total_limit = 2 * 8 * pr.multiProcessorCount;
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, device));
+    const bool can_all = s->ks.env_step_mw && s->lds_bytes_mw <= 160 * 1024;
+    // bundles of four keep the one-wave kernel's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
+    const bool can_rule = can_all && s->ks.env_step_x && 2 * s->lds_bytes_x <= 160 * 1024 && !getenv("FSIM_NO_LPT") && n_envs <= 32768; // (the scheduler keeps one key per env in LDS; deferred resets travel as 16-bit env indices)
+    if (want == 3) { if (!can_all) { delete s; FAIL(FSIM_EINVAL, "multi_wave = all: this model has no multi-wave kernel (more than 64 contact slots, or its LDS image does not fit)"); } s->mw_mode = MW_ALL; }
+    else if (want == 2) { if (!can_rule) { delete s; FAIL(FSIM_EINVAL, "multi_wave = rule: this model / batch cannot run k_env_step_x (LDS image, contact slots or batch size)"); } s->mw_mode = MW_RULE; }
+    else if (want == 1) s->mw_mode = MW_OFF;
+    else {
+      // auto: a launch with more envs than the chip has wave slots (8 per CU) is bound by throughput, not by its slowest env, and four
+      // waves per env only cost slots there (Sawyer + swivel_chair at 8192 envs: 1.03 M env-steps/s on the one-wave kernel, 0.95 M with
+      // the rule).  A function of n_envs and the device alone -- callers that split a big batch into slabs say multi_wave = off themselves
+      // (bench.py --config 3); nothing about OTHER handles or the process is looked at.
+      s->mw_mode = (can_rule && n_envs <= 8 * pr.multiProcessorCount) ? MW_RULE : MW_OFF;
     }
+    s->x_resident = 2 * pr.multiProcessorCount;
+    snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_x), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
-
-      { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, device)); s->x_resident = 2 * pr.multiProcessorCount; }
+      if (s->mw_mode == MW_RULE) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step_x), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
     }
   }
   HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1));
@@ -624,15 +725,19 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemsetAsync(s->d_cost, 0, (size_t)n_envs * 4, s->stream));
   // counter in pinned host memory the kernel increments in place (system-scope atomic, only when an episode ends): no copy or
   // memset kernel queues behind the step kernel's waves
+  // (words 1, 2: look-ahead statistics -- resets taken from a shadow record / executed inside a step or reset launch; never cleared)
   HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s->h_nreset), 64, hipHostMallocMapped));
-  *s->h_nreset = 0;
+  memset(s->h_nreset, 0, 64);
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_nreset), s->h_nreset, 0));
   s->lpt = !getenv("FSIM_NO_LPT");
   HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 16));
   HIPCHK(hipMemset(s->d_mwn, 0, 16));
   if ((size_t)n_envs * 4 > 150 * 1024) s->lpt = false; // (the scheduler keeps one key per env in LDS)
   else if ((size_t)n_envs * 4 > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_schedule), hipFuncAttributeMaxDynamicSharedMemorySize, n_envs * 4));
-  if (!s->lpt && s->mw_mode == 1) s->mw_mode = 0;
+  // look-ahead reset: off for what carries state across a reset or draws inside it (arm controllers keep their ramps, the IK controller
+  // its target, reset_robot_after_attach resets from the host) and for MW_ALL (every reset then runs on four waves: other bits)
+  s->la_on = s->cfg.lookahead_reset != 0 && !getenv("FSIM_NO_LOOKAHEAD") && s->mw_mode != MW_ALL && !env_controller_kind(s->cfg) && s->cfg.control_type == 0 &&
+             !s->cfg.reset_robot_after_attach && (s->mw_mode == MW_RULE ? s->ks.env_shadow_b != nullptr : s->ks.env_shadow_1 != nullptr);
   // initial record: qpos0, default masks, weld data, env block zero
   {
     std::vector<float> rec(s->ly.stride, 0.0f), q0, ed;
@@ -665,8 +770,8 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (s->mw_mode) {
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step_mw), 64 * FSIM_MW_NW, s->lds_bytes_mw);
       hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step_mw));
-      fprintf(stderr, "[fsim] multi-wave kernel (%d waves per env, mode %d, k %d, cap %d): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW, s->mw_mode,
-              s->mw_k, s->mw_cap, s->lds_bytes_mw, nb, fa.numRegs, (size_t)fa.localSizeBytes);
+      fprintf(stderr, "[fsim] multi-wave kernel (%d waves per env, mode %d, k %d): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW, s->mw_mode,
+              s->mw_k, s->lds_bytes_mw, nb, fa.numRegs, (size_t)fa.localSizeBytes);
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step_x), 64 * FSIM_MW_NW, s->lds_bytes_x);
       hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(s->ks.env_step_x));
       fprintf(stderr, "[fsim] step kernel (multi-wave workgroups + bundles of %d one-wave envs): lds_bytes=%d occupancy(blocks/CU)=%d regs=%d localmem(scratch)=%zu\n", FSIM_MW_NW,
@@ -674,22 +779,38 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     }
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
+  if (s->la_on) {
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = the numerically largest value = the LOWEST priority)
+    HIPCHK(hipStreamCreateWithPriority(&s->la_stream, hipStreamNonBlocking, lo));
+    HIPCHK(hipMalloc(&s->d_sh_state, sbytes));
+    HIPCHK(hipMalloc(&s->d_sh_obs, (size_t)n_envs * s->ecfg.obs_dim * 4 + 16));
+    HIPCHK(hipMalloc(&s->d_sh_tag, (size_t)n_envs * 4));
+    HIPCHK(hipMemset(s->d_sh_tag, 0, (size_t)n_envs * 4));
+    s->la_pending.assign(n_envs, 0); s->la_since.assign(n_envs, 0); s->la_env_seq.assign(n_envs, 0);
+    la_policy(s);
+    const bool bundle = s->mw_mode == MW_RULE;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(bundle ? s->ks.env_shadow_b : s->ks.env_shadow_1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               bundle ? FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words) : s->lds_bytes));
+  }
   if (s->ecfg.obs_dim > 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4) { int od = s->ecfg.obs_dim; delete s; FAIL(FSIM_ENOMEM, "obs_dim %d exceeds the LDS staging area of the observation (%d words)", od, 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4); }
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
   HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout))); HIPCHK(hipMalloc(&s->d_ly_mw, sizeof(Layout)));
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
-  g_envs_on_device[s->device & 63] += s->n_envs; s->registered = true;
   *out = s;
   return FSIM_OK;
 }
 
 extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
-  if (s->registered) g_envs_on_device[s->device & 63] -= s->n_envs;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->la_stream) { hipStreamSynchronize(s->la_stream); hipStreamDestroy(s->la_stream); }
+  for (auto &b : s->la_inflight) hipEventDestroy(b.ev);
+  for (auto &e : s->la_evpool) hipEventDestroy(e);
+  hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_tag);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
@@ -710,6 +831,7 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
 extern "C" int fsim_tables_needed(const fsim_t *s) { return s && s->h_nreset ? *s->h_nreset : 0; }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
 extern "C" const char *fsim_kernel_variant(const fsim_t *s) { return s && s->ks.name ? s->ks.name : ""; }
+extern "C" const char *fsim_step_kernel(const fsim_t *s) { return s ? s->step_kernel : ""; }
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
@@ -815,11 +937,12 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
   size_t pw = (size_t)7 * m.nparts, nw = (size_t)n_noise * m.narmj;
   if (!s->d_tab_parts) HIPCHK(hipMalloc(&s->d_tab_parts, (size_t)s->n_envs * pw * 4 + 16));
   if (robot_noise && (!s->d_tab_noise || s->n_noise != n_noise)) {
-    if (s->d_tab_noise) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->d_tab_noise); s->d_tab_noise = nullptr; }
+    if (s->d_tab_noise) { HIPCHK(hipStreamSynchronize(s->stream)); if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); hipFree(s->d_tab_noise); s->d_tab_noise = nullptr; }
     HIPCHK(hipMalloc(&s->d_tab_noise, (size_t)s->n_envs * nw * 4 + 16));
     s->n_noise = n_noise;
   }
   if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+  if (int rc = la_invalidate(s, mask)) return rc; // (before the rows change: waits for a shadow launch that still reads them)
   // rows of envs that are not in flight: safe to write while other envs' step kernels run (asynchronous stepping)
   if (!mask) {
     HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->xfer));
@@ -866,6 +989,11 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   if (s->ecfg.n_pre > 0 && qpos) FAIL(FSIM_EINVAL, "fsim_set_init_state: not combined with pre-assembled starts (fsim_set_preassembled)");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->la_on && (s->d_init || qpos)) { // the resets of the masked envs start elsewhere from now on: their shadow records are void
+    if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); // (shadow launches read d_init / d_init_mask)
+    if (int rc = la_invalidate(s, mask)) return rc;
+    HIPCHK(hipStreamSynchronize(s->xfer));
+  }
   const int n = s->n_envs, nq = s->m.nq, nv = s->m.nv, w = nq + nv;
   if (!qpos) { // set_init_qpos(None): clears; allocates nothing
     if (!s->d_init) return FSIM_OK;
@@ -890,15 +1018,116 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   return FSIM_OK;
 }
 
+// ---- look-ahead reset, host side.  Shadow launches go to la_stream (lowest priority: their workgroups only take slots no step kernel
+// wants) in batches of <= 60 envs passed by value; every batch has a sequence number, written as the tag of the envs it finishes.  A
+// step kernel trusts a tag only if it is <= la_ready = the last batch whose completion event had fired when that kernel was enqueued:
+// the shadow kernel then ENDED before the step kernel STARTED, and kernel boundaries make its stores visible on every XCD.
+static void la_policy(fsim *s) {
+  const int T = std::max(1, s->cfg.max_episode_steps);
+  s->la_defer = T / 5;
+  s->la_rate = std::max(FSIM_MW_NW, ((int)std::ceil(s->n_envs / std::max(1.0, 0.45 * T)) + FSIM_MW_NW - 1) / FSIM_MW_NW * FSIM_MW_NW);
+  if (const char *e = getenv("FSIM_LA_DEFER")) s->la_defer = std::max(0, atoi(e));  // (development)
+  if (const char *e = getenv("FSIM_LA_RATE")) s->la_rate = std::max(1, atoi(e));
+}
+static void la_poll(fsim *s) {
+  while (!s->la_inflight.empty() && hipEventQuery(s->la_inflight.front().ev) == hipSuccess) {
+    s->la_ready = s->la_inflight.front().seq;
+    s->la_evpool.push_back(s->la_inflight.front().ev);
+    s->la_inflight.pop_front();
+  }
+}
+// The envs in mask (host, null = all) get a new reset table, or the handle's reset configuration changes: their shadows are void and
+// they need new ones.  The caller synchronises s->xfer (the tags are cleared on it) before any launch can read them.
+static int la_invalidate(fsim *s, const uint8_t *mask) {
+  if (!s->la_on) return FSIM_OK;
+  la_poll(s);
+  for (int e = 0; e < s->n_envs; e++)
+    if ((!mask || mask[e]) && s->la_env_seq[e] > s->la_ready) {
+      // a shadow launch that may still be reading the old table (an env whose episode ended before its shadow was done): wait for it
+      HIPCHK(hipStreamSynchronize(s->la_stream));
+      la_poll(s);
+      break;
+    }
+  if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+  for (int e = 0; e < s->n_envs;) {
+    if (mask && !mask[e]) { e++; continue; }
+    int e1 = e;
+    while (e1 < s->n_envs && (!mask || mask[e1])) e1++;
+    HIPCHK(hipMemsetAsync(s->d_sh_tag + e, 0, (size_t)(e1 - e) * 4, s->xfer));
+    for (int k = e; k < e1; k++) {
+      if (!s->la_pending[k]) { s->la_pending[k] = 1; s->la_npending++; }
+      s->la_since[k] = s->la_step; s->la_env_seq[k] = 0;
+    }
+    e = e1;
+  }
+  return FSIM_OK;
+}
+static int la_flush(fsim *s, const StepArgs &a_step, const KParams &kp, ShadowList &list) {
+  if (list.n == 0) return FSIM_OK;
+  const int seq = ++s->la_seq;
+  for (int k = 0; k < list.n; k++) s->la_env_seq[list.env[k]] = seq;
+  StepArgs a = a_step;
+  a.state = nullptr; a.action = nullptr; a.obs = nullptr; a.reward = nullptr; a.done = nullptr; a.info = nullptr; a.reset_mask = nullptr; a.do_step = 0;
+  a.prof = nullptr; a.cost = nullptr; a.nreset = nullptr; a.stats = nullptr; a.tab_attach = nullptr;
+  a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_tag = s->d_sh_tag; a.ready_seq = 0;
+  const bool bundle = s->mw_mode == MW_RULE;
+  if (bundle)
+    hipLaunchKernelGGL(s->ks.env_shadow_b, dim3((list.n + FSIM_MW_NW - 1) / FSIM_MW_NW), dim3(64 * FSIM_MW_NW), FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words), s->la_stream,
+                       s->d_m, s->d_ly, kp, a, list, seq);
+  else
+    hipLaunchKernelGGL(s->ks.env_shadow_1, dim3(list.n), dim3(64), s->lds_bytes, s->la_stream, s->d_m, s->d_ly, kp, a, list, seq);
+  HIPCHK(hipGetLastError());
+  hipEvent_t ev;
+  if (!s->la_evpool.empty()) { ev = s->la_evpool.back(); s->la_evpool.pop_back(); }
+  else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ev, s->la_stream));
+  s->la_inflight.push_back(ShadowBatch{seq, ev});
+  s->la_launched += list.n;
+  list.n = 0;
+  return FSIM_OK;
+}
+// Called once per step launch: start the shadows of up to la_rate pending envs whose table has been on the device for la_defer steps.
+// Deferred and rationed on purpose: the resets of a batch that ended its episodes together are spread over the following episode
+// (~8 % more resident waves, in slots the step kernels leave idle) instead of landing on it as one block, and the first steps of an
+// episode -- the ones with the most robot-part contacts, i.e. the slowest -- are left alone.
+static int la_launch(fsim *s, const StepArgs &a_step, const KParams &kp) {
+  if (!s->la_on || s->la_npending == 0 || !s->d_tab_parts) return FSIM_OK;
+  int quota = s->la_rate, scanned = 0, e = s->la_cursor;
+  ShadowList list;
+  list.n = 0;
+  while (quota > 0 && scanned < s->n_envs && s->la_npending > 0) {
+    if (s->la_pending[e] && s->la_step - s->la_since[e] >= s->la_defer) {
+      list.env[list.n++] = e; s->la_pending[e] = 0; s->la_npending--; quota--;
+      if (list.n == 60) { if (int rc = la_flush(s, a_step, kp, list)) return rc; }
+    }
+    e = e + 1 == s->n_envs ? 0 : e + 1; scanned++;
+  }
+  s->la_cursor = e;
+  return la_flush(s, a_step, kp, list);
+}
+extern "C" int fsim_lookahead_sync(fsim_t *s) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  if (!s->la_on) return FSIM_OK;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->la_stream));
+  la_poll(s);
+  return FSIM_OK;
+}
+extern "C" int fsim_lookahead_stats(fsim_t *s, int64_t *out) {
+  if (!s || !out) FAIL(FSIM_EINVAL, "null");
+  out[0] = s->la_on ? 1 : 0; out[1] = s->la_launched; out[2] = s->h_nreset[1]; out[3] = s->h_nreset[2]; out[4] = s->la_npending; out[5] = (int64_t)s->la_inflight.size();
+  return FSIM_OK;
+}
+
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
-  const bool mw_auto = sched && s->mw_mode == 1 && (!s->mw_total_limit || g_envs_on_device[s->device & 63].load() <= s->mw_total_limit), mw_all = s->mw_mode == 2;
+  const bool mw_rule = sched && s->mw_mode == MW_RULE, mw_all = s->mw_mode == MW_ALL;
   if (sched)
     hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), (size_t)s->n_envs * 4, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
-                       s->ly.env + E_NITER, s->mw_k, s->mw_cap, mw_auto ? 1 : 0, s->d_mworder, s->d_mwn, s->d_mwn + 1);
+                       s->ly.env + E_NITER, s->mw_k, mw_rule ? 1 : 0, s->d_mworder, s->d_mwn);
   if (s->timing) timing_begin(s);
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
   StepArgs a;
@@ -906,8 +1135,12 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = mask; a.do_step = do_step;
   a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = do_step ? s->d_nreset : nullptr;
+  a.stats = s->d_nreset + 1;
+  a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_tag = nullptr; a.ready_seq = 0;
+  if (s->la_on) { la_poll(s); a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_tag = s->d_sh_tag; a.ready_seq = s->la_ready; }
   if (!s->d_ecfg) { HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); }
   if (memcmp(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg)) != 0) { // (rare: max_episode_steps, dense tables, pre-assembled starts)
+    if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); // (shadow launches read it too)
     HIPCHK(hipMemcpyAsync(s->d_ecfg, &s->ecfg, sizeof(EnvCfg), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream)); // (pageable source: the copy must have left the host struct before it can change again)
     memcpy(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg));
@@ -915,14 +1148,15 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.cfg_dev = s->d_ecfg;
   if (mw_all)
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr);
-  else if (mw_auto)
-    hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->mw_cap + std::min((s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW, s->x_resident)), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
-                       s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mwn + 1, s->d_mworder, s->d_mwn, s->mw_cap, s->d_mwn + 2);
+  else if (mw_rule) // persistent workgroups: as many as the one-wave envs need in bundles of four plus an eighth of the batch for multi-wave envs, at most what is resident at once
+    hipLaunchKernelGGL(s->ks.env_step_x, dim3(std::min((s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, s->n_envs / 8), s->x_resident)), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
+                       s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mworder, s->d_mwn);
   else
     hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
+  if (do_step && s->la_on) { s->la_step++; if (int rc = la_launch(s, a, kp)) return rc; }
   return FSIM_OK;
 }
 // ---- dense-reward env
@@ -947,6 +1181,7 @@ extern "C" int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, co
   if (int rc = dense_check(coef, ncoef, sub, nsub, s->m.nsite, s->m.nparts, s->m.nconn)) return rc;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->la_on) { HIPCHK(hipStreamSynchronize(s->la_stream)); if (int rc = la_invalidate(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
   if (s->d_dense) { hipFree(s->d_dense); s->d_dense = nullptr; }
   HIPCHK(hipMalloc(&s->d_dense, (size_t)(DC_WORDS + DS_WORDS * nsub) * 4));
   HIPCHK(hipMemcpy(s->d_dense, coef, DC_WORDS * 4, hipMemcpyHostToDevice));
@@ -1163,6 +1398,7 @@ extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, c
   }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->la_on) { HIPCHK(hipStreamSynchronize(s->la_stream)); if (int rc = la_invalidate(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
   if (s->d_pre) { hipFree(s->d_pre); s->d_pre = nullptr; }
   if (n_pre > 0) {
     HIPCHK(hipMalloc(&s->d_pre, tab.size() * 4));
@@ -1176,6 +1412,7 @@ extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, c
 extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   if (!s || n <= 0) FAIL(FSIM_EINVAL, "fsim_set_max_episode_steps: bad arguments");
   s->cfg.max_episode_steps = n; s->ecfg.max_episode_steps = n; // EnvCfg is passed by value with every launch
+  if (s->la_on) la_policy(s);
   return FSIM_OK;
 }
 extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {

@@ -50,6 +50,12 @@ struct EnvIO {
   long long t0;   // shader clock at kernel entry
   const float *tab_attach; // [narmj] joint noise of this env's NEXT attach (fsim_set_attach_noise), or null
   const EnvCfg *cfg_dev; // the handle's copy of the EnvCfg in device memory: what the out-of-line env_reset is given (see EnvResetIO)
+  // look-ahead reset (fsim.hip "look-ahead reset"): this env's shadow record / observation row / tag, or null
+  const float *sh_state;
+  const void *sh_obs;
+  int *sh_tag;
+  int ready_seq;  // tags in (0, ready_seq] belong to shadow launches that had completed when this launch was enqueued
+  int *stats;     // host-mapped counters: [0] resets taken from a shadow record, [1] resets executed inside a step / reset launch
 };
 // What env_reset reads of an env's EnvIO, passed BY VALUE (registers).  env_reset is a real function: handing it the addresses of the
 // kernel's EnvCfg (a kernel argument) and EnvIO made the compiler keep both in scratch -- a private copy per LANE, ~100 dwords
@@ -895,14 +901,14 @@ template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, con
     c.I(c.ly.contype)[g] = ct; c.I(c.ly.conaff)[g] = ca;
   }
   for (int e = c.lane; e < c.D.neq; e += 64) { c.I(c.ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[c.ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
-  int episodes = E[E_EPISODE_COUNT];
+  int episodes = E[E_EPISODE_COUNT], sticky = E[E_OVERFLOW];
   SYNC();
   for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
   for (int p = c.lane; p < c.D.nparts; p += 64) E[E_GROUP + p] = p;
   if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
   SYNC();
   if (c.lane == 0) {
-    E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1;
+    E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; E[E_OVERFLOW] = sticky;
     if (cfg.n_pre > 0 && cfg.pre_mode == 0) // no recipe: the listed welds are switched on, their groups merged (furniture.py:1493-1501)
       for (int i = 0; i < cfg.n_pre; i++) {
         const int e = GP(cfg.pre_tab)[3 * i];
@@ -965,6 +971,12 @@ template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, con
   if (c.D.narm > 0) env_gravity_comp(c);
   for (int k = 0; k < 100; k++) fs_step(c);
   if (cfg_ik) env_ik_sync(c); // furniture.py:1643-1650
+  // the finger / floor touch masks describe the contact list of a forward pass run with mode bit 1; none of the reset's passes is one,
+  // so what is there belongs to the state BEFORE the reset (the terminal step's last pass) -- the reset state has the fingers open and
+  // away from the parts.  Cleared, so that what follows (the dense reward's _reset_reward_variables, the scheduler features) does not
+  // depend on where the previous episode ended -- which also makes the reset a function of the reset table alone (look-ahead reset).
+  if (c.lane == 0) { int *scal = c.I(c.ly.scal); scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; E[E_OVERFLOW] |= scal[SC_OVERFLOW]; }
+  SYNC();
   if (c.lane == 0) {
     env_next_subtask(c);
     if (cfg_dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
@@ -1011,8 +1023,77 @@ template <class Ctx> DEV float env_robot_clearance(const Ctx &c) {
   return -wave_max(-best);
 }
 
+// ---------------------------------------------------------------------------------------------------- after a reset / a step
+// What a launch leaves behind for the NEXT one, and the observation: the Newton iterations the scheduler's multi-wave rule reads
+// (0 after a reset), the robot-part clearance, the sticky overflow report.  One function for the step, the in-kernel reset, the reset
+// launch and the look-ahead (shadow) reset, so that all of them leave the same words.
+template <class Ctx> DEV void env_post(const Ctx &c, const EnvCfg &cfg, const EnvIO &io, int niter) {
+  int *E = c.I(c.ly.env);
+  const int *scal = c.I(c.ly.scal);
+  const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;
+  if (c.lane == 0) {
+    E[E_NITER] = niter; c.L[c.ly.env + E_CLEARANCE] = clr;
+    E[E_TOUCH_L] = scal[SC_TOUCHL]; E[E_TOUCH_R] = scal[SC_TOUCHR]; E[E_TOUCH_FLOOR] = c.D.nr > 1 ? scal[SC_ISL + KI(r_tree, 1)] : 0; // (development: candidate features of the scheduler's rule)
+    if (io.info) io.info[FSIM_INFO_OVERFLOW] = (scal[SC_OVERFLOW] & 0xff) | (E[E_OVERFLOW] << 8);
+  }
+  env_write_obs(c, cfg, io);
+}
+
+// ---- look-ahead reset.  The state a reset leaves is a function of the env's reset table (and the handle's configuration) alone, and
+// the host uploads that table one episode ahead.  A low-priority kernel (k_env_shadow, fsim.hip) runs env_reset + env_post for it into a
+// SHADOW record + observation row while the episode is still being stepped; the terminal step then copies the shadow in instead of
+// running 301 / 401 substeps on the critical path of its launch.  Same code, same context type, same inputs: the record is bit-identical
+// to what the in-kernel reset would leave (tests/test_lookahead_gpu.py).  A shadow counts only if its tag lies in (0, ready_seq]: the
+// launch that wrote it had COMPLETED when this launch was enqueued (kernel boundaries order the two; no intra-kernel coherence needed).
+DEV bool env_shadow_ready(const EnvIO &io) {
+  if (!io.sh_tag) return false;
+  const int t = __builtin_amdgcn_readfirstlane(*io.sh_tag);
+  return t > 0 && t <= io.ready_seq;
+}
+template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  float *L = c.L;
+  int *E = c.I(c.ly.env);
+  const int *scal = c.I(c.ly.scal);
+  const int episodes = E[E_EPISODE_COUNT], sticky = E[E_OVERFLOW];
+  SYNC();
+  for (int i = c.lane; i < c.ly.stride; i += 64) L[i] = io.sh_state[i];
+  SYNC();
+  if (c.lane == 0) {
+    // (the two words of the record that belong to the env, not to the reset: how many episodes it has seen, whether it ever dropped contacts)
+    E[E_EPISODE_COUNT] = episodes + 1; E[E_OVERFLOW] |= sticky;
+    *io.sh_tag = 0; // consumed
+    if (io.stats) __hip_atomic_fetch_add(io.stats, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (io.info) {
+      io.info[FSIM_INFO_SUBTASK1] = E[E_SUBTASK1]; io.info[FSIM_INFO_SUBTASK2] = E[E_SUBTASK2];
+      io.info[FSIM_INFO_OVERFLOW] = (scal[SC_OVERFLOW] & 0xff) | (E[E_OVERFLOW] << 8);
+    }
+  }
+  if (io.obs) {
+    if (cfg.obs_bf16) {
+      const unsigned short *src = static_cast<const unsigned short *>(io.sh_obs);
+      unsigned short *dst = reinterpret_cast<unsigned short *>(io.obs);
+      for (int i = c.lane; i < cfg.obs_dim; i += 64) dst[i] = src[i];
+    } else {
+      const float *src = static_cast<const float *>(io.sh_obs);
+      for (int i = c.lane; i < cfg.obs_dim; i += 64) io.obs[i] = src[i];
+    }
+  }
+  SYNC();
+}
+// The reset of ONE env inside a launch: the shadow record if one is ready, else the reset itself.  (reset launches, deferred resets
+// of the multi-wave workgroups and -- through env_step -- the auto-reset of a terminal step)
+template <class Ctx> DEV void env_reset_or_swap(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+  if (env_shadow_ready(io)) { env_swap_in(c, cfg, io); return; }
+  env_reset(c, io.cfg_dev, env_reset_io(io));
+  if (c.lane == 0 && io.stats) __hip_atomic_fetch_add(io.stats + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  env_post(c, cfg, io, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------- step
-template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
+// DEFER (the multi-wave workgroups of k_env_step_x): a terminal env without a ready shadow record is NOT reset here -- env_step returns 1
+// and the workgroup's wave 0 runs the reset as a one-wave job right afterwards (fsim.hip), so that a reset's bits never depend on
+// whether the env happened to be stepped by four waves (a reset is one-wave arithmetic wherever it runs).  Returns 0 otherwise.
+template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_controller = Ctx::PLAIN ? 0 : cfg.controller, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
   CModel &m = c.m;
   float *L = c.L;
@@ -1020,7 +1101,7 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   int *scal = c.I(c.ly.scal);
   int dof = cfg.dof_action;
   // _before_step + action plumbing
-  if (c.lane == 0) E[E_CONNECTED_THIS_STEP] = 0;
+  if (c.lane == 0) { E[E_CONNECTED_THIS_STEP] = 0; if (Ctx::NW > 1) E[E_MW_STEPS] += 1; }
   float connect = io.action[dof - 1];
   if (cfg_ik) {
     // _do_ik_step (furniture.py:2911-2958, 2999-3018): per arm d_pos = move_speed * [-a1, a0, a2]; rotation entries stay raw (x rotate_speed
@@ -1141,7 +1222,13 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
     // k+3, so from the following episode on both streams agree again; only the placement of the episode right after an
     // unstable step differs (same distribution).  Keeping two tables per env on the device would remove it.
     const bool skip_reset = cfg.auto_reset && !cfg_dense;
-    if (!skip_reset) env_reset(c, io.cfg_dev, env_reset_io(io));
+    if (!skip_reset) {
+      if (env_shadow_ready(io)) env_swap_in(c, cfg, io); // (the record only matters here: the forward pass below rebuilds the poses)
+      else {
+        env_reset(c, io.cfg_dev, env_reset_io(io));
+        if (c.lane == 0 && io.stats) __hip_atomic_fetch_add(io.stats + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (c.lane == 0) { E[E_FAIL] = skip_reset ? 2 : 1; scal[SC_BAD] = 0; if (skip_reset) { scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; } }
     SYNC();
     if (!skip_reset) fs_substeps(c, 1, 3);
@@ -1240,7 +1327,6 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
       if (terminal && cfg.auto_reset && io.nreset) __hip_atomic_fetch_add(io.nreset, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       io.info[FSIM_INFO_SUCCESS_REWARD_F] = __float_as_int(succ_rew); io.info[FSIM_INFO_TOUCH_REWARD_F] = __float_as_int(touch_rew);
       io.info[FSIM_INFO_PICK_REWARD_F] = __float_as_int(pick_rew); io.info[FSIM_INFO_CTRL_PENALTY_F] = __float_as_int(ctrl_pen);
-      io.info[FSIM_INFO_OVERFLOW] = scal[SC_OVERFLOW];
       io.info[FSIM_INFO_DENSE_PHASE] = dense_phase;
       io.info[FSIM_INFO_EPISODE_REWARD_F] = __float_as_int(L[c.ly.env + E_EPISODE_REWARD]);
     }
@@ -1257,17 +1343,17 @@ template <class Ctx> DEV void env_step(const Ctx &c, const EnvCfg &cfg, const En
   SYNC();
   terminal = scal[14];
   const int nit_step = scal[SC_NITSUM];
-  if (terminal && cfg.auto_reset) env_reset(c, io.cfg_dev, env_reset_io(io)); // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
-  else if (cfg_ik) env_ik_remember(c, cfg_ik);              // (a reset stores its own poses: env_ik_sync)
-  { // what the scheduler of the next launch reads (k_schedule): this step's Newton iterations (0 after a reset), the robot-part clearance now
-    const float clr = c.D.narm > 0 ? env_robot_clearance(c) : 1e9f;
-    if (c.lane == 0) {
-      E[E_NITER] = (terminal && cfg.auto_reset) ? 0 : nit_step; L[c.ly.env + E_CLEARANCE] = clr;
-      E[E_TOUCH_L] = scal[SC_TOUCHL]; E[E_TOUCH_R] = scal[SC_TOUCHR]; E[E_TOUCH_FLOOR] = c.D.nr > 1 ? scal[SC_ISL + KI(r_tree, 1)] : 0; // (development: candidate features of the scheduler's rule)
-    }
+  if (c.lane == 0) E[E_OVERFLOW] |= scal[SC_OVERFLOW]; // sticky: a step that dropped contacts is never lost between two host reads
+  SYNC();
+  if (terminal && cfg.auto_reset) { // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
+    if (DEFER && !env_shadow_ready(io)) return 1;
+    env_reset_or_swap(c, cfg, io);
+  } else {
+    if (cfg_ik) env_ik_remember(c, cfg_ik); // (a reset stores its own poses: env_ik_sync)
+    env_post(c, cfg, io, nit_step);
   }
-  env_write_obs(c, cfg, io);
 #ifdef FSIM_TIMELINE
   if (c.lane == 0) scal[52] = (int)(clock64() >> 4) - scal[52];
 #endif
+  return 0;
 }

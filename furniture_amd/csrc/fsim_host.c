@@ -11,6 +11,7 @@
 // The state layout is RandomState.get_state()'s: 624 key words + the position.  Pinned against the reference's own sampler
 // through tests/golden/placement_sampler.npz (tests/test_sampler_golden.py runs both paths).
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 
 #define MT_N 624
@@ -50,18 +51,26 @@ static double mt_uniform(uint32_t *st, double low, double high) { return low + (
 // states [n][625]; draw_mask / place_mask [n] (null = all): envs that draw at all / that take the placement draws (config.fix_init
 // envs keep their first placement: later resets take only the joint-noise draws).  base_xy [nparts][2], radius [nparts];
 // out_xy [n][nparts][2] (written for placing envs), noise [n][n_noise] float32, uniform(-a, a).  Returns 0, or 1 + the index of
-// an env whose parts could not be placed in 10000 tries per part (the reference raises RandomizationError there).
+// an env whose parts could not be placed in 10000 tries per part (the reference raises RandomizationError there): that env stops
+// at the failing part, as the reference's sampler does (no further part, no joint noise), and status[e] (null = not wanted) says
+// which envs failed; the caller rolls the generators back (furniture_amd/envs.py: a failed draw consumes nothing).
+// nthreads: OpenMP threads of this call (<= 0: the runtime's default) -- N ranks of one node hit their batch-wide reset on the same
+// step, each must stay on its share of the host cores.
+// (compiled with -ffp-contract=off: `low + (high - low) * u` must round twice, as NumPy's does, also where the target has an FMA)
 int fsim_host_reset_draw(uint32_t *states, int n, const uint8_t *draw_mask, const uint8_t *place_mask, int nparts, const double *base_xy,
-                         const double *radius, double lo, double hi, double rot_hi, int n_noise, double a, double *out_xy, float *noise) {
+                         const double *radius, double lo, double hi, double rot_hi, int n_noise, double a, double *out_xy, float *noise,
+                         uint8_t *status, int nthreads) {
   int e, failed = 0;
-#pragma omp parallel for schedule(static) reduction(max : failed)
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) reduction(max : failed) num_threads(nthreads)
   for (e = 0; e < n; e++) {
-    int i, j, t;
+    int i, j, t, env_failed = 0;
     uint32_t *st = states + (long)e * FSIM_MT_WORDS;
+    if (status) status[e] = 0;
     if (draw_mask && !draw_mask[e]) continue;
     if (!place_mask || place_mask[e]) {
       double *xy = out_xy + (long)e * nparts * 2;
-      for (i = 0; i < nparts; i++) {
+      for (i = 0; i < nparts && !env_failed; i++) {
         int ok = 0;
         for (t = 0; t < 10000 && !ok; t++) {
           const double x = base_xy[2 * i] + mt_uniform(st, lo, hi), y = base_xy[2 * i + 1] + mt_uniform(st, lo, hi);
@@ -70,9 +79,10 @@ int fsim_host_reset_draw(uint32_t *states, int n, const uint8_t *draw_mask, cons
             if (!(hypot(x - xy[2 * j], y - xy[2 * j + 1]) > radius[j] + radius[i])) { ok = 0; break; }
           if (ok) { (void)mt_uniform(st, rot_hi, rot_hi); xy[2 * i] = x; xy[2 * i + 1] = y; }
         }
-        if (!ok && failed < 1 + e) failed = 1 + e;
+        if (!ok) { env_failed = 1; if (failed < 1 + e) failed = 1 + e; }
       }
     }
+    if (env_failed) { if (status) status[e] = 1; continue; }
     if (n_noise > 0) {
       float *z = noise + (long)e * n_noise;
       for (i = 0; i < n_noise; i++) z[i] = (float)mt_uniform(st, -a, a);

@@ -115,10 +115,12 @@ enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4,
 
 // env-logic block (word offsets relative to Layout::env)
 enum {
-  E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL, E_TERMINAL,
+  E_NUM_CONNECTED = 0, E_PREV_NUM_CONNECTED, E_CONNECT_STEP, E_EPISODE_LENGTH, E_SUCCESS, E_FAIL,
+  E_OVERFLOW /* sticky SC_OVERFLOW bits: some launch of this env (a step, a reset, a look-ahead reset swapped in) dropped contacts; survives resets */,
   E_CONNECTED_THIS_STEP, E_SITE1, E_SITE2, E_SUBTASK1, E_SUBTASK2, E_TOUCHED, E_PICKED, E_CONNSITES0, E_CONNSITES1,
   E_CONNSITES2, E_CONNSITES3, E_TOUCH_L, E_TOUCH_R, E_TOUCH_FLOOR, E_CONNBODY1, E_CB1_POS, E_CB1_QUAT = E_CB1_POS + 3,
-  E_TARGET_QUAT = E_CB1_QUAT + 4, E_EPISODE_REWARD = E_TARGET_QUAT + 4, E_CLEARANCE /* float: env_robot_clearance at the end of the last step */, E_NITER /* Newton iterations of the last step */, E_RESET_CURSOR, E_EPISODE_COUNT,
+  E_TARGET_QUAT = E_CB1_QUAT + 4, E_EPISODE_REWARD = E_TARGET_QUAT + 4, E_CLEARANCE /* float: env_robot_clearance at the end of the last step */, E_NITER /* Newton iterations of the last step */,
+  E_MW_STEPS /* steps of this episode that four waves took (multi-wave workgroups): lets a test see which kernel path an env ran */, E_EPISODE_COUNT,
   E_GROUP, // nparts ints follow
   E_FIXED_WORDS = E_GROUP
 };

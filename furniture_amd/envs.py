@@ -21,7 +21,7 @@ from . import spaces
 from . import transform_utils as T
 from .mjcf.model import load_compiled
 from .dense import DENSE_COEF_DEFAULTS, pack_dense
-from .sim import (FSim, INFO_CONNECTED_THIS_STEP, INFO_DENSE_PHASE, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
+from .sim import (FSim, INFO_OVERFLOW, INFO_CONNECTED_THIS_STEP, INFO_DENSE_PHASE, INFO_DIM, INFO_EPISODE_LENGTH, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2,
                   INFO_NEEDS_TABLE, INFO_NUM_CONNECTED, INFO_SUBTASK1, INFO_SUCCESS, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F,
                   INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F, N_NOISE, default_config)
 
@@ -91,11 +91,22 @@ def _host_lib():
             lib.fsim_host_seed.restype = None
             lib.fsim_host_seed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
             lib.fsim_host_reset_draw.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_int]
             _HOSTLIB = lib
         except OSError:
             _HOSTLIB = False
     return _HOSTLIB or None
+
+
+def host_threads():
+    """OpenMP threads one call of libfsim_host.so may use: this rank's share of the host cores.  The ranks of one node reach their
+    batch-wide reset on the same step; uncapped, each of 8 ranks would start one thread per core for the same 14 ms."""
+    import os
+    if os.environ.get("FSIM_HOST_THREADS"):
+        return max(1, int(os.environ["FSIM_HOST_THREADS"]))
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    return max(1, (os.cpu_count() or 1) // max(1, ranks))
 
 
 class ResetTableSampler:
@@ -225,10 +236,17 @@ class ResetTableSampler:
         n_noise = N_NOISE * self.narm
         noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
         dm, pm = np.ascontiguousarray(sel.astype(np.uint8)), np.ascontiguousarray(place.astype(np.uint8))
+        status = np.zeros(n, dtype=np.uint8)
         rc = _host_lib().fsim_host_reset_draw(self._mt.ctypes.data, n, dm.ctypes.data, pm.ctypes.data, m.nparts, base.ctypes.data, rad.ctypes.data, lo, hi, rot_hi,
-                                              n_noise, float(cfg.agent_xyz_rand), self._xy.ctypes.data, noise.ctypes.data)
+                                              n_noise, float(cfg.agent_xyz_rand), self._xy.ctypes.data, noise.ctypes.data, status.ctypes.data, host_threads())
         if rc:
-            raise RuntimeError("Cannot place all objects on the desk")
+            # A failed draw consumes NOTHING: the tables of this call are not handed out (ResetTableQueue / _refill see the exception),
+            # so every generator that took part goes back to where it was -- the env that could not be placed and the others alike.
+            # (The reference has one env per process: its RandomizationError ends that env's reset and nobody else's stream moves.)
+            self._mt[idx] = self._mt_hist[(self._mt_nhist[idx] - 1) % 3, idx]
+            self._mt_nhist[idx] -= 1
+            self.last_failed = np.nonzero(status)[0]
+            raise RuntimeError("Cannot place all objects on the desk (env rows %s)" % self.last_failed[:8].tolist())
         self._placed |= place
         parts = np.zeros((n, m.nparts * 7), dtype=np.float32)
         if getattr(cfg, "assembled", False):  # furniture.py:1526-1530: the parts stay at the XML's assembled poses; the draw is still taken
@@ -392,6 +410,11 @@ class FurnitureBatchEnv:
             c.solver_tolerance = float(cfg.solver_tolerance)
         c.dense_reward = 1 if dense else 0
         c.obs_bf16 = 1 if obs_bf16 else 0
+        # accelerated-path options (not in the reference): which step kernel the handle runs ("auto" | "off" | "rule" | "all",
+        # include/fsim.h fsim_config_t::multi_wave) and whether resets are computed ahead of time (lookahead_reset)
+        from .sim import MULTI_WAVE
+        c.multi_wave = MULTI_WAVE[getattr(cfg, "multi_wave", None) or "auto"]
+        c.lookahead_reset = 1 if getattr(cfg, "lookahead_reset", True) else 0
         self.dense = bool(dense)
         self.sim = FSim(self.model, num_envs, device=device, config=c)
         if dense:
@@ -581,6 +604,7 @@ class FurnitureBatchEnv:
                 self._refill(None if not self._tables_fresh.any() else ~self._tables_fresh)
             self.sim.reset(None, self._obs)
             self.sim.sync()
+            self._check_overflow_after_reset()
             return self._split(self._obs)
         # one table = one pass of the reference's reset-time RNG stream: a table that is on the device but was never
         # consumed (uploaded for an auto-reset that did not happen yet) IS the next draw of that env and is used as is
@@ -590,6 +614,7 @@ class FurnitureBatchEnv:
         self.sim.reset(None, self._obs)
         self.sim.sync()  # the reset kernel reads the tables: the next ones may only be uploaded once it has finished
         self._tables_fresh[:] = False
+        self._check_overflow_after_reset()
         # the next draw of every env's stream goes to the device now: the in-kernel resets read it (the auto-reset of a terminal
         # step; without auto_reset, the reset an unstable simulation triggers inside step(), furniture.py:2889-2897)
         self._refill(lookahead=True)
@@ -636,23 +661,16 @@ class FurnitureBatchEnv:
             self._tables_fresh[failed] = False
             self._refill(failed, lookahead=True)
         info = self._info
-        # a step in which contacts did not fit the slots (48 / 64 / 128 by model size) or the broadphase list integrated WRONG physics
-        # for those envs: an error, not a warning (FSIM_ALLOW_OVERFLOW=1 downgrades it; the flags stay in info["contact_overflow"])
+        # a launch in which contacts did not fit the slots (48 / 64 / 128 by model size) or the broadphase list integrated WRONG physics
+        # for that env: an error, not a warning (FSIM_ALLOW_OVERFLOW=1 downgrades it; the flags stay in info["contact_overflow"]).  The
+        # device keeps the flags STICKY in the env's record (bits 8-9 of the info word: any step, any reset -- the one inside reset(),
+        # the auto-reset of a terminal step, a look-ahead reset that was copied in), so reading the block every 16th step misses nothing.
         self._steps_done = getattr(self, "_steps_done", 0) + 1
-        if self._steps_done % 16 == 1 and bool((info[:, 12] != 0).any()):
-            import os
-            msg = ("furniture_amd: %s overflowed the contact slots / broadphase list of the step kernel in %d env(s) (info['contact_overflow']): "
-                   "contacts were dropped -- this furniture has more simultaneous contacts than the accelerated path holds (%d slots)"
-                   % (self.furniture_name, int((info[:, 12] != 0).sum()), self.sim.max_contacts))
-            if os.environ.get("FSIM_ALLOW_OVERFLOW") != "1":
-                raise ContactOverflowError(msg)
-            if not getattr(self, "_overflow_warned", False):
-                import warnings
-                warnings.warn(msg, stacklevel=2)
-                self._overflow_warned = True
+        if self._steps_done % 16 == 1:
+            self._check_overflow((info[:, INFO_OVERFLOW] >> 8) != 0)
         infos = dict(num_connected=info[:, INFO_NUM_CONNECTED], episode_success=info[:, INFO_SUCCESS], fail=info[:, INFO_FAIL],
                      site1=info[:, INFO_LAST_SITE1], site2=info[:, INFO_LAST_SITE2], episode_length=info[:, INFO_EPISODE_LENGTH],
-                     connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, 12])
+                     connected=info[:, INFO_CONNECTED_THIS_STEP], contact_overflow=info[:, INFO_OVERFLOW] & 0xff)
         if self.dense:
             infos["phase_i"] = info[:, INFO_DENSE_PHASE]  # phase + 8 * subtask (furniture_sawyer_dense.py:347)
         else:  # the reward terms _compute_reward reports (furniture.py:535-540); float bits in the int32 info block
@@ -663,6 +681,25 @@ class FurnitureBatchEnv:
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+    def _check_overflow(self, flags):
+        """flags: bool tensor [n], env dropped contacts at some point (sticky on the device)"""
+        if not bool(flags.any()):
+            return
+        import os
+        msg = ("furniture_amd: %s overflowed the contact slots / broadphase list of the step kernel in %d env(s) (info['contact_overflow']): "
+               "contacts were dropped -- this furniture has more simultaneous contacts than the accelerated path holds (%d slots)"
+               % (self.furniture_name, int(flags.sum()), self.sim.max_contacts))
+        if os.environ.get("FSIM_ALLOW_OVERFLOW") != "1":
+            raise ContactOverflowError(msg)
+        if not getattr(self, "_overflow_warned", False):
+            import warnings
+            warnings.warn(msg, stacklevel=3)
+            self._overflow_warned = True
+
+    def _check_overflow_after_reset(self):
+        # reset launches write no info block: the sticky word of the env record (fsim_model.hpp E_OVERFLOW = word 6 of env_block)
+        self._check_overflow(self.sim.get_state("env_block")["env_block"][:, 6] != 0)
 
     def set_max_episode_steps(self, max_episode_steps):
         """furniture.py:312-313 (forwarded by FurnitureGym, furniture_gym.py:46-48)."""

@@ -21,7 +21,8 @@ INFO_SUBTASK1, INFO_SUBTASK2 = 15, 16
 INFO_DENSE_PHASE = 13
 INFO_EPISODE_REWARD_F = 14
 DENSE_STATEW = 27  # FSIM_DENSE_STATEW; ED_* of csrc/fsim_dense.hpp (subtask, phase, flags, fine-aligned, 4 x vec3, 11 prev values)
-INFO_OVERFLOW = 12
+INFO_OVERFLOW = 12  # bits 0-1: this launch, bits 8-9: sticky (include/fsim.h)
+E_OVERFLOW, E_NITER, E_MW_STEPS, E_EPISODE_COUNT = 6, 35, 36, 37  # words of env_block (csrc/fsim_model.hpp E_*)
 INFO_NUM_CONNECTED, INFO_SUCCESS, INFO_FAIL, INFO_LAST_SITE1, INFO_LAST_SITE2, INFO_EPISODE_LENGTH = range(6)
 INFO_CONNECTED_THIS_STEP, INFO_NEEDS_TABLE, INFO_SUCCESS_REWARD_F, INFO_TOUCH_REWARD_F, INFO_PICK_REWARD_F, INFO_CTRL_PENALTY_F = range(6, 12)
 N_NOISE = 101  # _initialize_robot_pos draws per reset (furniture.py:1580, 1606-1611)
@@ -41,7 +42,11 @@ class FsimConfig(ctypes.Structure):
         ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
         ("move_speed", ctypes.c_float), ("rotate_speed", ctypes.c_float), ("cursor_boundary", ctypes.c_float),
         ("dense_reward", ctypes.c_int32), ("obs_bf16", ctypes.c_int32),
+        ("multi_wave", ctypes.c_int32), ("lookahead_reset", ctypes.c_int32),
     ]
+
+
+MULTI_WAVE = {"auto": 0, "off": 1, "rule": 2, "all": 3}  # fsim_config_t::multi_wave
 
 
 class StatePtrs(ctypes.Structure):
@@ -58,6 +63,15 @@ def build(force=False, verbose=False):
     """Compile libfsim.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fsim.h"))
+    # the host helper is a library of its own with its own staleness: a checkout that has libfsim.so but no (or an old) libfsim_host.so
+    # must not silently run the 100x slower Python sampler
+    host_so, host_c = os.path.join(_CSRC, "libfsim_host.so"), os.path.join(_CSRC, "fsim_host.c")
+    if force or not os.path.exists(host_so) or os.path.getmtime(host_c) > os.path.getmtime(host_so):
+        try:
+            build_host(verbose)
+        except (OSError, subprocess.CalledProcessError) as e:  # optional: no gcc / no OpenMP -> the Python sampler (same stream, slower)
+            import warnings
+            warnings.warn("furniture_amd: libfsim_host.so could not be built (%s); reset tables will be drawn by the per-env Python loop" % e)
     if not force and os.path.exists(_LIBPATH) and all(os.path.getmtime(s) <= os.path.getmtime(_LIBPATH) for s in srcs):
         return _LIBPATH
     # (max-ilp: one wavefront per env has no other wave to hide latency behind, so the machine scheduler is asked to interleave
@@ -70,13 +84,13 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    build_host(verbose)
     return _LIBPATH
 
 
 def build_host(verbose=False):
     """libfsim_host.so: plain-C host helper of the env layer (the reference's reset-time RNG stream for a whole batch per call)."""
-    cmd = ["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", os.path.join(_CSRC, "libfsim_host.so"), os.path.join(_CSRC, "fsim_host.c"), "-lm"]
+    # (-ffp-contract=off: low + (high - low) * u rounds twice, as NumPy's uniform does -- gcc's default may fuse it where the target has an FMA)
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-o", os.path.join(_CSRC, "libfsim_host.so"), os.path.join(_CSRC, "fsim_host.c"), "-lm"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -113,6 +127,10 @@ def lib():
         L.fsim_replay_try_connect.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
         L.fsim_replay_touch_scan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.fsim_kernel_variant.restype = ctypes.c_char_p
+        L.fsim_step_kernel.argtypes = [ctypes.c_void_p]
+        L.fsim_step_kernel.restype = ctypes.c_char_p
+        L.fsim_lookahead_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_lookahead_sync.argtypes = [ctypes.c_void_p]
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_set_attach_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -133,6 +151,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
+    "fsim_step_kernel", "fsim_lookahead_stats", "fsim_lookahead_sync",
     "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
 ]
 
@@ -220,6 +239,7 @@ class FSim:
         self.nq, self.nv, self.nu, self.dof_action, self.obs_dim, self.info_dim, self.stride = [x.value for x in d]
         self.max_contacts = lib().fsim_max_contacts(self._h)
         self.kernel_variant = lib().fsim_kernel_variant(self._h).decode()
+        self.step_kernel = lib().fsim_step_kernel(self._h).decode()  # the launch structure fsim_config_t::multi_wave resolved to
         st = ctypes.c_void_p()
         self._chk(lib().fsim_stream(self._h, ctypes.byref(st)))
         # the handle's HIP stream as a torch stream: work enqueued under `with torch.cuda.stream(sim.torch_stream)` (an RCCL
@@ -349,6 +369,15 @@ class FSim:
     def tables_needed(self):
         """envs that consumed their reset table in the last step (valid after sync())"""
         return int(lib().fsim_tables_needed(self._h))
+
+    def lookahead_stats(self):
+        """fsim_lookahead_stats: dict(enabled, launched, swapped, inline, pending, inflight) -- valid after sync()"""
+        out = (ctypes.c_int64 * 6)()
+        self._chk(lib().fsim_lookahead_stats(self._h, out))
+        return dict(zip(("enabled", "launched", "swapped", "inline", "pending", "inflight"), [int(x) for x in out]))
+
+    def lookahead_sync(self):
+        self._chk(lib().fsim_lookahead_sync(self._h))
 
     def set_max_episode_steps(self, n):
         self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))

@@ -34,7 +34,9 @@ enum {
 
 /* env configuration that the reference keeps in its argparse Namespace (furniture/config/furniture.py) */
 typedef struct fsim_config {
-  int32_t control_type;       /* 0 impedance (velocity actuators), 1 torque (rejected), and the torque-level arm controllers of
+  int32_t control_type;       /* 0 impedance -- `_do_simulation` on whatever actuators the compiled model has: the velocity-actuated robot for the
+                                 reference's "impedance", the motor-actuated one (robot_torque.xml) for its "torque" (furniture.py:1268); 1 is not
+                                 used --, and the torque-level arm controllers of
                                  furniture/env/controllers/arm_controller.py run per physics substep (furniture.py:41-47, 3065-3093;
                                  Sawyer, motor-actuated model): 2 position_orientation, 3 position, 4 joint_impedance,
                                  5 joint_velocity, 6 joint_torque.  Action = [arm command (6|3|7|7|7), grip, connect].
@@ -63,6 +65,20 @@ typedef struct fsim_config {
   int32_t obs_bf16;           /* 1: the observation slab handed to fsim_step / fsim_reset is bfloat16 [n, obs_dim] (round to nearest even) --
                                  half the bytes of the per-step all-gather to the learner (BASELINE config 2).  State, reward and the whole
                                  computation stay float32; only the store of the finished observation is narrowed. */
+  int32_t multi_wave;         /* which step kernel the handle runs -- decided once, here, because an env's arithmetic (summation order) depends on it:
+                                 0 auto: 2 if the model has the kernel and n_envs <= 8 x the device's CU count (a launch with more envs than wave
+                                   slots is throughput-bound and four waves per env only cost slots), else 1.  A function of n_envs and the device;
+                                 1 off:  one wave per env in every launch (k_env_step);
+                                 2 rule: ONE launch of persistent 4-wave workgroups (k_env_step_x): an env whose previous step took >= 150 Newton
+                                   iterations -- its OWN state, nothing else -- is stepped by four cooperating waves, the others by one wave each;
+                                 3 all:  four waves for every env (development / tests).
+                                 Within one mode env i's results depend on env i's state and actions alone: not on the batch it is in, the slab
+                                 layout, other handles or timing.  Across modes they agree like two fp32 implementations.  fsim_step_kernel() reports it. */
+  int32_t lookahead_reset;    /* 1 (default): the reset of every env's NEXT episode is computed ahead of time, on a low-priority stream, from the
+                                 reset table the host has already uploaded (fsim_set_reset_tables), into a shadow record; the step / reset that ends
+                                 the episode copies it in instead of running the 301 / 401 reset substeps inside its launch.  Same code on the same
+                                 inputs: bit-identical to the in-launch reset, which remains the fallback whenever no shadow is ready.  Not used
+                                 with the arm controllers, ik / ik_quaternion, reset_robot_after_attach and multi_wave = all.  0: off. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -115,6 +131,8 @@ int fsim_max_contacts(const fsim_t *);
 /* Which step kernel the handle runs: "generic" (run-time layout, any model) or the name of a kernel specialised at build
  * time for this (agent, furniture, config) -- same arithmetic, layout offsets as instruction immediates (csrc/fsim_spec.hpp). */
 const char *fsim_kernel_variant(const fsim_t *);
+/* Which launch structure fsim_step uses (fsim_config_t::multi_wave as resolved at fsim_create): "k_env_step_x (...)" / "k_env_step (...)". */
+const char *fsim_step_kernel(const fsim_t *);
 int fsim_env_block_words(const fsim_t *);
 
 /* ---- the env hot path ------------------------------------------------------------------- */
@@ -152,6 +170,14 @@ int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bf
  * host skip the scan of the info block on the (many) steps in which no episode ended. */
 int fsim_tables_needed(const fsim_t *);
 
+/* Look-ahead reset bookkeeping (fsim_config_t::lookahead_reset): out[6] = { enabled, shadow resets launched so far, resets taken from a
+ * shadow record, resets executed inside a step / reset launch, envs waiting for a shadow launch, shadow launches in flight }.  The two
+ * device-side counters are valid once the launches that bumped them have completed (fsim_sync).  Every reset still costs its 301 / 401
+ * substeps; the counters say on which stream they ran. */
+int fsim_lookahead_stats(fsim_t *, int64_t *out);
+/* Wait for the shadow launches in flight (tests, and callers that want the next reset to be a copy for sure).  Never needed for correctness. */
+int fsim_lookahead_sync(fsim_t *);
+
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);
 
@@ -163,7 +189,10 @@ enum {
                               * step() (furniture.py:2889-2897) and the vec-env worker resets again; only the second reset is run */
   FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
   FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
-  FSIM_INFO_OVERFLOW = 12, /* bit 0: broadphase survivor list truncated, bit 1: contact slots exhausted (contacts dropped) in this step */
+  FSIM_INFO_OVERFLOW = 12, /* bits 0-1: this launch -- bit 0 broadphase survivor list truncated, bit 1 contact slots exhausted (contacts dropped);
+                              bits 8-9: the same two flags, STICKY: raised by any launch of this env so far (a step, a reset, the look-ahead
+                              reset that was copied in) and kept in its record across resets, so a host that reads the block every k-th step
+                              misses nothing */
   FSIM_INFO_DENSE_PHASE = 13, /* dense-reward env: info["phase_i"] = phase + 8 * subtask (furniture_sawyer_dense.py:347); then
                                  FSIM_INFO_SUCCESS_REWARD_F carries info["phase_bonus"] and the other *_F columns are 0 */
   FSIM_INFO_EPISODE_REWARD_F = 14, /* float bits: the episode's reward so far incl. this step (step_log["episode_reward"] at done,

@@ -10,6 +10,6 @@ for f in "" "-DFSIM_PROFILE"; do
     mv furniture_amd/csrc/$out.tmp furniture_amd/csrc/$out
   fi
 done
-gcc -O2 -fopenmp -shared -fPIC -o furniture_amd/csrc/libfsim_host.so furniture_amd/csrc/fsim_host.c -lm || rc=1
+gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC -o furniture_amd/csrc/libfsim_host.so furniture_amd/csrc/fsim_host.c -lm || rc=1
 ls -la furniture_amd/csrc/*.so | awk '{print $5, $6, $7, $8, $9}'
 exit $rc

@@ -22,3 +22,14 @@ def sawyer_lack():
 def have_reference():
     from furniture_amd.mjcf.assemble import default_assets_root
     return default_assets_root() is not None
+
+
+@pytest.fixture
+def fsim_mw(request, monkeypatch):
+    """Which step kernel the handles created inside the test run: parametrize indirectly with "0" (one wave per env), "1" (the
+    scheduler's rule: k_env_step_x, multi-wave workgroups + bundles) or "all" (four waves for every env).  FSIM_MW is read by
+    fsim_create and overrides fsim_config_t::multi_wave (include/fsim.h)."""
+    mode = getattr(request, "param", None)
+    if mode is not None:
+        monkeypatch.setenv("FSIM_MW", mode)
+    return mode

@@ -93,3 +93,34 @@ def cursor_attach_state(m, qpos, leg=0, table_conn=4, leg_conn=0, gap=0.03):
     q[ta:ta + 3] = table_site_w - Rt @ m.site_pos[m.conn_siteid[table_conn]]
     q[ta + 3:ta + 7] = table_q
     return q, tpart
+
+
+def spread_layout(m, x0=0.9, gap=0.03):
+    """Part poses [nparts, 7] that lay every part flat on the floor without touching another part or the robot: for furniture whose XML
+    stacks all parts at the origin (bookcase_grevback_0484: fourteen planks, no *_initpos entries), where the reference's sampler -- 5 mm
+    placement radii, 2 cm jitter -- starts the episode with the planks inside each other.  Each part is turned so that the thinnest
+    extent of its first collision box points up and put on a grid row by row, rows along y, starting x0 metres in front of the robot."""
+    cg_body, cg_pos = np.asarray(m.cg_body), np.asarray(m.cg_pos).reshape(-1, 3)
+    cg_mat, cg_size, cg_rb = np.asarray(m.cg_mat).reshape(-1, 3, 3), np.asarray(m.cg_size).reshape(-1, 3), np.asarray(m.cg_rbound)
+    out = np.zeros((m.nparts, 7))
+    x, y, row_h = x0, -1.2, 0.0
+    for p in range(m.nparts):
+        gs = [g for g in range(len(cg_body)) if cg_body[g] == m.part_rbody[p]]
+        g0 = gs[0]
+        thin = int(np.argmin(cg_size[g0]))
+        # rotation taking the geom's thinnest local axis to world z (and the other two to x, y)
+        axes = [a for a in range(3) if a != thin] + [thin]
+        Rg = cg_mat[g0][:, axes]            # columns: geom axes (in the body frame) that shall become world x, y, z
+        if np.linalg.det(Rg) < 0:
+            Rg[:, 0] = -Rg[:, 0]
+        Rb = Rg.T                           # body -> world
+        q = quat_from_axes(Rb[:, 0], Rb[:, 1], Rb[:, 2])
+        rad = max(np.linalg.norm(cg_pos[g]) + cg_rb[g] for g in gs)
+        if y + 2 * rad > 1.2 and y > -1.2:
+            x, y, row_h = x + row_h + gap, -1.2, 0.0
+        centre = Rb @ cg_pos[g0]
+        out[p, :3] = [x + rad - centre[0], y + rad - centre[1], cg_size[g0][thin] + 0.002 - centre[2]]
+        out[p, 3:] = q
+        y += 2 * rad + gap
+        row_h = max(row_h, 2 * rad)
+    return out

@@ -1,5 +1,4 @@
-"""Every furniture shipped compiled for the Sawyer agent (61 of the reference's 64: three collide MESH geoms, for which there is no
-narrow-phase routine) runs reset + random steps on the device, including those with more than 64 dofs (up to 93: fourteen parts --
+"""Every furniture shipped compiled for the Sawyer agent runs reset + random steps on the device, including those with more than 64 dofs (up to 93: fourteen parts --
 the island solver fills its four 16-lane rows twice) and those with ten parts and more, whose contacts at rest need more than 64
 slots (128: two contact slots per lane in the Newton solve); nothing is refused at fsim_create, and a step that drops contacts raises.  The parity tests cover the BASELINE configs' models; this one is
 breadth: the generic kernels, the model compiler's tables and the host-side samplers on models nobody looked at individually;
@@ -31,9 +30,14 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
             continue
         try:
             ob = env.reset()
+        except ContactOverflowError:  # (the reset itself dropped contacts: reported by reset() since round 4 -- the flag is sticky on the device)
+            troubled.append((name, m.nparts, 2))
+            env.close()
+            continue
         except RuntimeError as e:
             # the reference's UniformRandomSampler raises RandomizationError for the same furniture and seeds (checked by running
-            # it: cabinet_akurum_0021, table_hemnes_0539 never place with the default jitter) -- not a device matter
+            # it: cabinet_akurum_0021, table_hemnes_0539 never place with the default jitter; bookcase_grevback_0484's fourteen
+            # planks all start at the origin with 5 mm placement radii and do not place for these seeds either) -- not a device matter
             assert "Cannot place all objects" in str(e), (name, str(e))
             unplaceable.append(name)
             env.close()
@@ -71,7 +75,8 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
     # two models do not fit even 128 slots: bookcase_billy_0191 (11 planks) and table_liden_0921 (12 parts) pass through 230-250
     # simultaneous contacts while the reset settles them (counted with the oracle); their steps raise ContactOverflowError
     assert refused == [] and sorted(x[0] for x in troubled) == ["bookcase_billy_0191", "table_liden_0921"], (refused, troubled)
-    assert len(ran) >= 55 and len(unplaceable) <= 4
+    assert sorted(unplaceable) == ["bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"], unplaceable
+    assert len(ran) == len(names) - 5
 
 
 def test_a_model_with_more_than_64_dofs_matches_the_oracle_env():
@@ -112,12 +117,12 @@ def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_s
         env.close()
 
 
-def test_the_fourteen_part_bookcase_is_accepted_and_says_when_it_drops_contacts():
-    """Sawyer + bookcase_grevback_0484 (SURVEY section 8's size table: 14 parts, 93 dofs).  fsim_create takes it now (128 contact slots,
-    two per lane in the Newton solve), but the reference's own placement puts its fourteen planks INSIDE each other (the XML gives every
-    part a placement radius of 5 mm, the jitter is 2 cm): 256 contacts and one 84-dof island at the first substep of the reset, measured
-    with the oracle, which MuJoCo resolves by throwing the planks apart.  That is beyond the 128 slots / 64-dof islands of the device
-    path, and the env says so instead of integrating wrong physics."""
+def test_the_fourteen_part_bookcase_says_when_it_drops_contacts():
+    """Sawyer + bookcase_grevback_0484 (SURVEY section 8's size table: 14 parts, 93 dofs) as the reference places it: the XML stacks the
+    fourteen planks at the origin with placement radii of 5 mm and the jitter is 2 cm, so -- for the seeds the sampler places at all --
+    the episode starts with the planks INSIDE each other: 256 contacts and one 84-dof island at the first substep of the reset (measured
+    with the oracle), which MuJoCo resolves by throwing the planks apart.  That is beyond the 128 slots / 64-dof islands of the device
+    path, and reset() says so (the overflow flag is sticky in the env record) instead of integrating wrong physics."""
     from furniture_amd.envs import ContactOverflowError, FurnitureSawyerEnv, make_config
     from furniture_amd.mjcf.model import load_compiled
     m = load_compiled("Sawyer", "bookcase_grevback_0484")
@@ -125,7 +130,41 @@ def test_the_fourteen_part_bookcase_is_accepted_and_says_when_it_drops_contacts(
     kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="bookcase_grevback_0484", max_episode_steps=50, seed=3)
     env = FurnitureSawyerEnv(make_config(**kw))
     assert env._b.sim.max_contacts == 128 and env._b.sim.kernel_variant == "generic2"
-    env.reset()
     with pytest.raises(ContactOverflowError):
-        env.step(np.zeros(9))
+        env.reset()
+    env.close()
+
+
+def test_the_fourteen_part_bookcase_matches_the_oracle_env_from_a_laid_out_start():
+    """The largest model of SURVEY section 8's size table stepped on the device: bookcase_grevback_0484 (93 dofs: the island solver's four
+    16-lane rows filled twice; 128 contact slots: two per lane, kernels `generic2`) from a start in which the fourteen planks lie flat
+    next to each other (set_init_qpos, furniture.py:315-316, 1505-1519 -- tests/scenarios.py spread_layout), reset and random-action
+    steps against the fp64 oracle env: 56 plank-floor contacts throughout."""
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import spread_layout
+    m = load_compiled("Sawyer", "bookcase_grevback_0484")
+    lay = spread_layout(m)
+    q = np.array(m.qpos0, dtype=float)
+    q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+    for p in range(m.nparts):
+        q[m.part_qposadr[p]:m.part_qposadr[p] + 7] = lay[p]
+    init = {"qpos": q, "qvel": np.zeros(m.nv)}
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="bookcase_grevback_0484", max_episode_steps=50, seed=3)
+    env = FurnitureSawyerEnv(make_config(**kw))
+    orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=3, solver_tolerance=1e-10))
+    env.set_init_qpos(init), orc.set_init_qpos(init)
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert len(orc.sim.contacts()) == 56
+    assert np.abs(np.concatenate([d["object_ob"], d["robot_ob"]]) - o).max() < 5e-4
+    rng = np.random.RandomState(2)
+    for t in range(4):
+        a = rng.uniform(-1, 1, 9)
+        ob, r, done, info = env.step(a)
+        ob_o, r_o, done_o, _ = orc.step(a)
+        assert np.abs(np.concatenate([ob["object_ob"], ob["robot_ob"]]) - orc.flat_obs(ob_o)).max() < 1e-3, t
+        assert abs(r - r_o) < 1e-4 and done == done_o
+        assert int(info["contact_overflow"]) == 0
     env.close()

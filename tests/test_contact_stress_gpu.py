@@ -201,9 +201,11 @@ def test_sawyer_toy_table_reset_steps_and_contact_trajectory_match_oracle():
     sim.close()
 
 
-def test_sixty_four_envs_fifty_random_steps_until_first_divergence(sawyer_lack):
+@pytest.mark.parametrize("fsim_mw", ["0", "1"], indirect=True)  # the one-wave kernel, and the kernel the benchmark times (rule: k_env_step_x)
+def test_sixty_four_envs_fifty_random_steps_until_first_divergence(sawyer_lack, fsim_mw):
     n, steps = 64, 50
     sim, envs, obs_o, buf = _env_pair(sawyer_lack, n, 2000)
+    assert sim.step_kernel.startswith("k_env_step_x" if fsim_mw == "1" else "k_env_step (one wave")
     ob_d = buf["obs"].cpu().numpy()
     assert max(np.abs(ob_d[e] - obs_o[e]).max() for e in range(n)) < 2e-4
     cfg1 = default_config()
@@ -242,4 +244,9 @@ def test_sixty_four_envs_fifty_random_steps_until_first_divergence(sawyer_lack):
     # company does so after several steps (an arm flailing into the parts amplifies 1e-7 to 1e-3 within a few hundred substeps)
     # measured on MI355X: min 2, p10 12, median 50 (= never), 70 % of the envs never diverge
     assert q[0] >= 1 and q[1] >= 8 and q[2] >= 20, q
+    # which envs the rule handed to four-wave workgroups at least once (E_MW_STEPS of the env record; no reset inside the run)
+    from furniture_amd.sim import E_MW_STEPS
+    mw_steps = sim.get_state("env_block")["env_block"][:, E_MW_STEPS].cpu().numpy()
+    print("env-steps taken by four waves: %d of %d (%d envs)" % (int(mw_steps.sum()), n * steps, int((mw_steps > 0).sum())))
+    assert (mw_steps.sum() > 0) == (fsim_mw == "1"), mw_steps  # the multi-wave half of the benchmark's kernel IS under this comparison
     sim.close()

@@ -116,7 +116,9 @@ def test_thousand_substeps_within_1e4_of_oracle(sawyer_lack):
     sim.close()
 
 
-def test_env_reset_steps_and_attach_match_oracle(sawyer_lack):
+@pytest.mark.parametrize("fsim_mw", ["0", "1", "all"], indirect=True)
+def test_env_reset_steps_and_attach_match_oracle(sawyer_lack, fsim_mw):
+    """(every kernel path: one wave per env, the rule's k_env_step_x, four waves for every env)"""
     m = sawyer_lack
     n = 4
     cfg = default_config()
@@ -229,7 +231,8 @@ def test_env_reset_and_steps_match_oracle_other_models(key):
     sim.close()
 
 
-def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack):
+@pytest.mark.parametrize("fsim_mw", ["0", "all"], indirect=True)  # (fsim_physics_step: the one-wave and the four-wave physics kernel)
+def test_welded_assembly_in_the_gripper_matches_oracle(sawyer_lack, fsim_mw):
     """All four welds active + the gripper pinching a leg: one 39-dof island (robot + 5 welded parts), i.e. the
     large-island Cholesky path and the weld/contact cross blocks of the Hessian, against the fp64 oracle."""
     from furniture_amd import transform_utils as T
@@ -749,7 +752,8 @@ def test_assembled_and_fix_init_match_the_oracle_env(sawyer_lack):
     env.close()
 
 
-def test_specialised_and_generic_kernels_agree(sawyer_lack):
+@pytest.mark.parametrize("fsim_mw", ["0", "1", "all"], indirect=True)
+def test_specialised_and_generic_kernels_agree(sawyer_lack, fsim_mw):
     """The benchmark model runs on kernels whose layout offsets and sizes are compile-time constants (fsim_spec.hpp); FSIM_GENERIC=1
     forces the run-time-layout kernels every other model uses.  Same templates, same algorithm; not bit-identical (the compiler
     contracts a * b + c into an FMA where the expression shape allows it, and that shape differs once offsets and sizes are
