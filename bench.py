@@ -365,7 +365,7 @@ def main():
     dt = time.perf_counter() - t0
     kt = [sl.sim.kernel_time_ms() for sl in slabs]
     la1 = [sl.sim.lookahead_stats() for sl in slabs]
-    la = {k: sum(b[k] - a[k] for a, b in zip(la0, la1)) for k in ("launched", "swapped", "inline")}
+    la = {k: sum(b[k] - a[k] for a, b in zip(la0, la1)) for k in ("units", "swapped", "inline")}
     reset_substeps = 401 if m.meta.get("has_recipe") else 301  # sim.step() calls of one _reset (tests/golden/reset_trace.npz)
     klaunches = sum(k[1] for k in kt)
     kms = sum(k[0] * k[1] for k in kt) / max(1, klaunches)
@@ -394,7 +394,7 @@ def main():
         # chip-wide utilisation of THIS run: instructions per env-step (PMC, a property of the workload) x the measured env-step rate
         # over the issue slots of the chip (SIMDs x clock; one wave-instruction per SIMD per cycle at best)
         props = torch.cuda.get_device_properties(local)
-        simds, clk = props.multi_processor_count * 4, props.clock_rate * 1e3
+        simds, clk = props.multi_processor_count * 4, float(getattr(props, "clock_rate", 2.4e6)) * 1e3  # (kHz; MI355X_MICROARCH.md: 2.4 GHz peak engine clock)
         per_gpu_rate = value / world
         util = lambda k: (pmc[k] * per_gpu_rate / (simds * clk)) if pmc.get(k) else None
         binding = {"bound": "per-wave instruction issue + LDS wait (not HBM, not MFMA); the step ends with its slowest env",
@@ -420,10 +420,10 @@ def main():
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
                        "rccl_world": dist.get_world_size() if distributed else 1,  # ranks RCCL's communicator saw (1 without torch.distributed.run)
                        # every episode end costs its reset (the reference's _reset: 401 sim.step() calls here).  They are executed INSIDE the
-                       # timed region, ahead of the step that needs them (look-ahead: shadow launches on a low-priority stream) or inside it
+                       # timed region: ahead of the step that needs them (look-ahead jobs) or inside that step's launch
                        "resets_in_timed_region": la["swapped"] + la["inline"], "resets_taken_from_lookahead": la["swapped"], "resets_inside_step_launch": la["inline"],
-                       "lookahead_resets_launched_in_timed_region": la["launched"],
-                       "reset_substeps_in_timed_region": (la["launched"] + la["inline"]) * reset_substeps,
+                       "lookahead_reset_units_in_timed_region": la["units"],  # reset substeps run by look-ahead jobs (waves of the step launches that had no env left)
+                       "reset_substeps_in_timed_region": la["units"] + la["inline"] * reset_substeps,
                        "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
             # `bound`: what the contract's two choices are priced against is HBM (BASELINE.json asks for the HBM fraction) and `frac` is

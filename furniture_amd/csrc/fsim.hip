@@ -16,7 +16,6 @@
 #include <cstring>
 #include <map>
 #include <string>
-#include <deque>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -96,12 +95,14 @@ struct StepArgs {
   const uint8_t *init_mask;
   int *nreset;
   const EnvCfg *cfg_dev; // `cfg` again, in device memory (for the out-of-line env_reset: EnvResetIO)
-  // look-ahead reset: shadow records [n][stride], shadow observation rows [n][obs_dim] (f32 | bf16), tags [n]; null = off
+  // look-ahead reset: shadow records [n][stride], shadow observation rows [n][obs_dim] (f32 | bf16), progress / serial words [n]; null = off
   float *sh_state;
   void *sh_obs;
-  int *sh_tag;
-  int ready_seq;
-  int *stats; // host-mapped counters (fsim::h_nreset + 1): [0] resets taken from a shadow record, [1] resets executed in a step / reset launch
+  int *sh_prog, *sh_serial;
+  const int *tab_serial; // [n] serial number of the reset table on the device (bumped by the host with every upload)
+  const int *sh_jobs;    // look-ahead jobs of this launch (env indices, listed by k_schedule; q[4] of them), or null
+  int la_chunk;          // reset units per look-ahead job
+  int *stats; // host-mapped counters (fsim::h_nreset + 1): [0] resets taken from a shadow record, [1] resets executed in a step / reset launch, [2] reset units run by look-ahead jobs
 };
 enum { JOB_AUTO = 0 /* a.do_step decides */, JOB_RESET = 1 /* the deferred reset of a multi-wave workgroup's env */ };
 // load_cache: the wave's LDS copy of the model tables is not there yet (a bundled wave steps several envs one after the other
@@ -139,8 +140,9 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   io.cfg_dev = a.cfg_dev;
   io.sh_state = a.sh_state ? a.sh_state + (size_t)env * c.ly.stride : nullptr;
   io.sh_obs = a.sh_obs ? static_cast<const char *>(a.sh_obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4) : nullptr;
-  io.sh_tag = a.sh_tag ? a.sh_tag + env : nullptr;
-  io.ready_seq = a.ready_seq;
+  io.sh_prog = a.sh_prog ? a.sh_prog + env : nullptr;
+  io.sh_serial = a.sh_prog ? a.sh_serial[env] : 0;
+  io.tab_serial = a.sh_prog ? a.tab_serial[env] : 0;
   io.stats = a.stats;
   int deferred = 0;
   if (job == JOB_RESET) env_reset_or_swap(c, cfg, io);
@@ -166,18 +168,28 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   return deferred;
 }
 
-// Look-ahead reset of ONE env (k_env_shadow): the reset its next episode will start from, computed from the reset table the host has
-// already uploaded, into the env's shadow record + observation row.  env_reset + env_post: exactly what a reset inside a launch runs.
-template <class Ctx> DEV void env_shadow_run(const Ctx &c, const StepArgs &a, int env, int seq) {
+// One look-ahead JOB: the next a.la_chunk units of the reset env's next episode will start from (env_reset_units), on the shadow
+// record -- which carries the intermediate state from job to job -- from the reset table the host has already uploaded.  The last job
+// adds what a reset inside a launch adds (env_post: scheduler words, observation -> the shadow observation row).  Run by the waves of a
+// step launch that have no env left to step (k_env_step_x) / by extra workgroups (k_env_step); k_schedule lists the jobs.
+// A shadow that belongs to another table (serial) is started over.
+template <class Ctx> DEV void env_shadow_job(const Ctx &c, const StepArgs &a, int env, bool load_cache) {
   float *L = c.L;
   const int lane = c.lane;
   const EnvCfg &cfg = a.cfg;
+  const int serial = a.tab_serial[env];
+  int prog = a.sh_prog[env];
+  if (a.sh_serial[env] != serial) prog = 0;
+  float *rec = a.sh_state + (size_t)env * c.ly.stride;
   // (a reset overwrites every word of the record but the episode counter and the sticky overflow report, which the swap takes from the
-  //  live record; the live record itself is being stepped on another stream and is not read here)
-  for (int i = lane; i < c.ly.stride; i += 64) L[i] = 0.0f;
+  //  live record: the first job starts from zeros)
+  if (prog > 0) load_record(L, rec, c.ly.stride, lane);
+  else for (int i = lane; i < c.ly.stride; i += 64) L[i] = 0.0f;
+  const int twords = reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS];
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   SYNC();
-  fs_load_cache(c);
+  if (load_cache) fs_load_cache(c);
+  else { if (lane == 0) reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS] = twords; SYNC(); }
   EnvIO io{};
   io.obs = reinterpret_cast<float *>(static_cast<char *>(a.sh_obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4));
   io.tab_parts = a.tab_parts ? a.tab_parts + (size_t)env * 7 * c.D.nparts : nullptr;
@@ -185,36 +197,30 @@ template <class Ctx> DEV void env_shadow_run(const Ctx &c, const StepArgs &a, in
   io.n_noise = a.n_noise;
   io.init_state = (a.init_state && a.init_mask && a.init_mask[env]) ? a.init_state + (size_t)env * (c.D.nq + c.D.nv) : nullptr;
   io.cfg_dev = a.cfg_dev;
-  env_reset(c, a.cfg_dev, env_reset_io(io));
-  env_post(c, cfg, io, 0);
+  const int total = env_reset_total(cfg, io.init_state != nullptr), p1 = min(prog + a.la_chunk, total);
+  env_reset_units(c, a.cfg_dev, env_reset_io(io), prog, p1);
+  if (p1 == total) env_post(c, cfg, io, 0);
   SYNC();
-  store_record(a.sh_state + (size_t)env * c.ly.stride, L, c.ly.stride, lane);
-  __threadfence();
-  if (lane == 0) a.sh_tag[env] = seq;
-}
-struct ShadowList { int n; int env[63]; };
-// one env per wave; Ctx::BUNDLE: four independent waves (own LDS images) per workgroup, as in the bundles of k_env_step_x -- a
-// workgroup of the step kernel needs half a CU's LDS, so a lone 20 KB shadow workgroup would cost the CU one of its two slots for the
-// ~40 ms a reset takes; four resets per workgroup take that slot for four envs
-template <class Ctx> __global__ __launch_bounds__(64 * (Ctx::BUNDLE ? 4 : 1), 2) void k_env_shadow(const DModel *mp, const Layout *lp, KParams kp, StepArgs a, ShadowList list, int seq) {
-  extern __shared__ float L[];
-  CModel &m = *(CModel *)mp;
-  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
-  const int idx = (int)blockIdx.x * (Ctx::BUNDLE ? 4 : 1) + c.wave;
-  if (idx >= list.n) return;
-  env_shadow_run(c, a, list.env[idx], seq);
+  store_record(rec, L, c.ly.stride, lane);
+  if (lane == 0) {
+    a.sh_prog[env] = p1; a.sh_serial[env] = serial;
+    if (a.stats) __hip_atomic_fetch_add(a.stats + 2, p1 - prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // One env per workgroup: the one-wave kernel (Ctx::NW == 1; workgroup b steps env order[b]) and the multi-wave kernel on its own
 // (Ctx::NW == 4, FSIM_MW=all: every env gets four waves -- development and tests).
-template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, StepArgs a, const int *order) {
+template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_env_step(const DModel *mp, const Layout *lp, KParams kp, StepArgs a, const int *order, const int *q) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
-  if ((int)blockIdx.x >= kp.n_envs) return;
+  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+  if ((int)blockIdx.x >= kp.n_envs) { // workgroups behind the envs: this launch's look-ahead jobs (one-wave kernel only), q[4] of them
+    if constexpr (Ctx::NW == 1) { const int j = (int)blockIdx.x - kp.n_envs; if (a.sh_jobs && j < q[4]) env_shadow_job(c, a, a.sh_jobs[j], true); }
+    return;
+  }
   // workgroups are dispatched in blockIdx order: `order` lists the envs longest-predicted-job first (k_schedule)
   const int env = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const Ctx c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
   if constexpr (Ctx::NW > 1) if (c.wave > 0) { mw_helper_loop(c); return; } // helper waves
   env_run(c, a, env, t_entry);
 }
@@ -259,7 +265,8 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
   {
     const CtxB c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
     const int nb = q[1];
-    for (bool first = true;; first = false) {
+    bool first = true;
+    for (;; first = false) {
       int env, job = JOB_AUTO;
       if (ndef > 0) { env = (int)(defs & 0xffffu); defs >>= 16; ndef--; job = JOB_RESET; } // (wave 0 only: ndef is 0 on the others)
       else {
@@ -270,6 +277,18 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
         env = order[slot];
       }
       env_run(c, a, env, first ? t_entry : clock64(), first, job);
+    }
+    // nothing left to step: this wave would retire while the launch waits for its slowest env -- it runs look-ahead jobs instead
+    // (the next reset of envs whose table is on the device already: env_shadow_job), q[4] of them listed by k_schedule
+    if (a.sh_jobs) {
+      const int nj = q[4];
+      for (;; first = false) {
+        int j = 0;
+        if (c.lane == 0) j = atomicAdd(q + 5, 1);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= nj) break;
+        env_shadow_job(c, a, a.sh_jobs[j], first);
+      }
     }
   }
 }
@@ -290,20 +309,30 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
 // The kernel is one latency chain (it sits between two step kernels of its stream): the keys are fetched once, eight loads in
 // flight per lane, and kept in LDS for the sorting passes (208 us -> ~20 us for 2048 envs).
 #define FSIM_SCHED_SELECTED ((int)0x80000000)
+// Look-ahead jobs (la.sh_prog != null): env i gets one this launch iff a reset table is on the device (serial > 0), its shadow record
+// does not yet hold that table's complete reset, and its episode is la.defer steps old -- the first la.maxjobs such envs in index
+// order (an env keeps its job from launch to launch until its shadow is complete) -> la.jobs / q[4].  Device state only.
+struct LaSched { const int *sh_prog, *sh_serial, *tab_serial; const uint8_t *init_mask; int *jobs; int maxjobs, defer, total, total_init, eplen_off; };
 __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k, int use_mw,
-                                                int *mworder, int *q) {
+                                                int *mworder, int *q, LaSched la) {
   extern __shared__ int keys[]; // [n]
   __shared__ int hist[257];
   const int tid = threadIdx.x;
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
-  int base = 0, lm = 0;
+  int base = 0, lm = 0, jbase = 0;
   for (int i0 = 0; i0 < n; i0 += 512) {
     int cv[8], v[8];
+    bool jb[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int i = i0 + 64 * u + tid;
       cv[u] = i < n ? cost[i] : -1;
       v[u] = (use_mw && i < n) ? state[(size_t)i * stride + niter_off] : -0x7fffffff;
+      jb[u] = false;
+      if (la.sh_prog && i < n) {
+        const int ts = la.tab_serial[i], done = (la.init_mask && la.init_mask[i]) ? la.total_init : la.total;
+        jb[u] = ts > 0 && (la.sh_serial[i] != ts || la.sh_prog[i] < done) && state[(size_t)i * stride + la.eplen_off] >= la.defer;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -315,10 +344,16 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
       base += __popcll(mask);
       if (i < n) keys[i] = take ? FSIM_SCHED_SELECTED : cv[u];
       if (i < n && !take && cv[u] >= 0) lm = max(lm, cv[u] & 0x3fffffff);
+      if (la.sh_prog) {
+        const unsigned long long jm = __ballot(jb[u]);
+        const int jx = jbase + __popcll(jm & ((1ull << tid) - 1ull));
+        if (jb[u] && jx < la.maxjobs) la.jobs[jx] = i;
+        jbase += __popcll(jm);
+      }
     }
   }
   const int nsel = base;
-  if (tid == 0) { q[0] = nsel; q[1] = n - nsel; q[2] = 0; q[3] = 0; } // (q[2], q[3]: heads of the bundle / multi-wave work queues)
+  if (tid == 0) { q[0] = nsel; q[1] = n - nsel; q[2] = 0; q[3] = 0; q[4] = min(jbase, la.maxjobs); q[5] = 0; } // (q[2], q[3], q[5]: heads of the bundle / multi-wave / look-ahead work queues)
   for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
   __syncthreads();
   // (a float multiply, not a 64-bit division: the inlined division routines were half of this kernel's code, and the code is never in
@@ -396,15 +431,12 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
-typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *);
+typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *, const int *);
 typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *);
-typedef void (*EnvShadowFn)(const DModel *, const Layout *, KParams, StepArgs, ShadowList, int);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
-// env_shadow_1 / env_shadow_b: the look-ahead reset kernel on the context type whose env_reset the handle's step kernel runs -- the
-// one-wave kernel's, or the bundled waves' of k_env_step_x (same instantiation = same bits)
-struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; EnvShadowFn env_shadow_1, env_shadow_b; };
+#define FSIM_LA_MAXJOBS 512 // look-ahead jobs per launch, at most
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 enum { MW_OFF = 0, MW_RULE = 1, MW_ALL = 2 }; // fsim::mw_mode
-struct ShadowBatch { int seq; hipEvent_t ev; };
 
 struct fsim {
   int device = 0, n_envs = 0;
@@ -420,7 +452,7 @@ struct fsim {
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
-  int *d_mworder = nullptr, *d_mwn = nullptr; // d_mwn[0] = multi-wave envs of the launch, d_mwn[1] = the others, d_mwn[2] / [3] = heads of the bundle / multi-wave queues
+  int *d_mworder = nullptr, *d_mwn = nullptr; // q: [0] multi-wave envs of the launch, [1] the others, [2] / [3] heads of the bundle / multi-wave queues, [4] look-ahead jobs, [5] head of their queue
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   DModel m{};
   Layout ly{};
@@ -449,25 +481,19 @@ struct fsim {
   int acc_n = 0;
   bool timing_pending = false, timing = false; // HIP-event timing of the step kernel: off until fsim_kernel_time_ms is first called
   int nbody = 0, ngeom = 0;
-  // ---- look-ahead reset (env_shadow_run): the reset of every env's NEXT episode is computed ahead of time on a low-priority stream
-  // from the reset table the host has already uploaded, into shadow records the terminal step copies in
+  // ---- look-ahead reset (env_shadow_job): waves of the step launches that have run out of envs compute every env's NEXT reset, a
+  // chunk per launch, from the reset table the host has already uploaded, into shadow records the terminal step copies in.  All of
+  // it on the handle's stream, decided on the device (k_schedule lists the jobs); the host only numbers the tables.
   bool la_on = false;
-  hipStream_t la_stream = nullptr;
   float *d_sh_state = nullptr;
   void *d_sh_obs = nullptr;
-  int *d_sh_tag = nullptr;             // [n] sequence number of the shadow launch that wrote the env's shadow (0: none / consumed)
-  std::vector<uint8_t> la_pending;     // env needs a shadow (its table is fresh, no shadow launch covers it yet)
-  std::vector<int> la_since;           // la_step at which it became pending (launches are deferred: see la_launch)
-  std::vector<int> la_env_seq;         // sequence number of the last shadow launch that contained the env
-  int la_npending = 0, la_seq = 0, la_ready = 0, la_step = 0, la_cursor = 0;
-  int la_defer = 0, la_rate = 0;
-  std::deque<ShadowBatch> la_inflight;
-  std::vector<hipEvent_t> la_evpool;
-  long long la_launched = 0;           // shadow resets launched so far
+  int *d_sh_prog = nullptr, *d_sh_serial = nullptr, *d_tab_serial = nullptr, *d_sh_jobs = nullptr;
+  std::vector<int> h_tab_serial;       // serial number of each env's reset table (bumped with every upload / change of what a reset starts from)
+  int la_jobs = 0, la_defer = 0, la_chunk = 0; // jobs per launch, steps into the episode before an env's shadow is started, reset units per job
 };
 
 static void la_policy(fsim *s);
-static int la_invalidate(fsim *s, const uint8_t *mask);
+static int la_new_tables(fsim *s, const uint8_t *mask);
 
 struct Arena {
   std::vector<char> host;
@@ -636,13 +662,13 @@ static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, size
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
 static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg) { // plain_cfg: no controller / IK / dense reward (SpecCtx::PLAIN)
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>, k_env_shadow<SpecCtx<S>>, k_env_shadow<SpecCtx<S, 1, true>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
   // (more than 64 contact slots: two slot sets per lane in the Newton solve -- one-wave kernels only)
-  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr, k_env_shadow<GenCtxT<1, false, 2>>, nullptr};
-  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>, k_env_shadow<GenCtx>, k_env_shadow<GenCtxT<1, true>>};
+  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr};
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -730,14 +756,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   memset(s->h_nreset, 0, 64);
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_nreset), s->h_nreset, 0));
   s->lpt = !getenv("FSIM_NO_LPT");
-  HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 16));
-  HIPCHK(hipMemset(s->d_mwn, 0, 16));
+  HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 32));
+  HIPCHK(hipMemset(s->d_mwn, 0, 32));
   if ((size_t)n_envs * 4 > 150 * 1024) s->lpt = false; // (the scheduler keeps one key per env in LDS)
   else if ((size_t)n_envs * 4 > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_schedule), hipFuncAttributeMaxDynamicSharedMemorySize, n_envs * 4));
   // look-ahead reset: off for what carries state across a reset or draws inside it (arm controllers keep their ramps, the IK controller
   // its target, reset_robot_after_attach resets from the host) and for MW_ALL (every reset then runs on four waves: other bits)
   s->la_on = s->cfg.lookahead_reset != 0 && !getenv("FSIM_NO_LOOKAHEAD") && s->mw_mode != MW_ALL && !env_controller_kind(s->cfg) && s->cfg.control_type == 0 &&
-             !s->cfg.reset_robot_after_attach && (s->mw_mode == MW_RULE ? s->ks.env_shadow_b != nullptr : s->ks.env_shadow_1 != nullptr);
+             !s->cfg.reset_robot_after_attach && s->lpt; // (s->lpt: the look-ahead jobs are listed by the scheduler kernel)
   // initial record: qpos0, default masks, weld data, env block zero
   {
     std::vector<float> rec(s->ly.stride, 0.0f), q0, ed;
@@ -780,18 +806,13 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   }
   env_fill_cfg(s->ecfg, s->cfg, s->m);
   if (s->la_on) {
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); // (lo = the numerically largest value = the LOWEST priority)
-    HIPCHK(hipStreamCreateWithPriority(&s->la_stream, hipStreamNonBlocking, lo));
     HIPCHK(hipMalloc(&s->d_sh_state, sbytes));
     HIPCHK(hipMalloc(&s->d_sh_obs, (size_t)n_envs * s->ecfg.obs_dim * 4 + 16));
-    HIPCHK(hipMalloc(&s->d_sh_tag, (size_t)n_envs * 4));
-    HIPCHK(hipMemset(s->d_sh_tag, 0, (size_t)n_envs * 4));
-    s->la_pending.assign(n_envs, 0); s->la_since.assign(n_envs, 0); s->la_env_seq.assign(n_envs, 0);
+    HIPCHK(hipMalloc(&s->d_sh_prog, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_sh_serial, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_tab_serial, (size_t)n_envs * 4));
+    HIPCHK(hipMemset(s->d_sh_prog, 0, (size_t)n_envs * 4)); HIPCHK(hipMemset(s->d_sh_serial, 0, (size_t)n_envs * 4)); HIPCHK(hipMemset(s->d_tab_serial, 0, (size_t)n_envs * 4));
+    HIPCHK(hipMalloc(&s->d_sh_jobs, (size_t)FSIM_LA_MAXJOBS * 4));
+    s->h_tab_serial.assign(n_envs, 0);
     la_policy(s);
-    const bool bundle = s->mw_mode == MW_RULE;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(bundle ? s->ks.env_shadow_b : s->ks.env_shadow_1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               bundle ? FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words) : s->lds_bytes));
   }
   if (s->ecfg.obs_dim > 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4) { int od = s->ecfg.obs_dim; delete s; FAIL(FSIM_ENOMEM, "obs_dim %d exceeds the LDS staging area of the observation (%d words)", od, 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4); }
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
@@ -807,10 +828,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  if (s->la_stream) { hipStreamSynchronize(s->la_stream); hipStreamDestroy(s->la_stream); }
-  for (auto &b : s->la_inflight) hipEventDestroy(b.ev);
-  for (auto &e : s->la_evpool) hipEventDestroy(e);
-  hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_tag);
+  hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_prog); hipFree(s->d_sh_serial); hipFree(s->d_tab_serial); hipFree(s->d_sh_jobs);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
@@ -937,12 +955,12 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
   size_t pw = (size_t)7 * m.nparts, nw = (size_t)n_noise * m.narmj;
   if (!s->d_tab_parts) HIPCHK(hipMalloc(&s->d_tab_parts, (size_t)s->n_envs * pw * 4 + 16));
   if (robot_noise && (!s->d_tab_noise || s->n_noise != n_noise)) {
-    if (s->d_tab_noise) { HIPCHK(hipStreamSynchronize(s->stream)); if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); hipFree(s->d_tab_noise); s->d_tab_noise = nullptr; }
+    if (s->d_tab_noise) { HIPCHK(hipStreamSynchronize(s->stream)); hipFree(s->d_tab_noise); s->d_tab_noise = nullptr; }
     HIPCHK(hipMalloc(&s->d_tab_noise, (size_t)s->n_envs * nw * 4 + 16));
     s->n_noise = n_noise;
   }
   if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
-  if (int rc = la_invalidate(s, mask)) return rc; // (before the rows change: waits for a shadow launch that still reads them)
+  if (int rc = la_new_tables(s, mask)) return rc; // (new serial numbers: shadows computed from the old rows no longer count)
   // rows of envs that are not in flight: safe to write while other envs' step kernels run (asynchronous stepping)
   if (!mask) {
     HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->xfer));
@@ -990,8 +1008,7 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   if (s->la_on && (s->d_init || qpos)) { // the resets of the masked envs start elsewhere from now on: their shadow records are void
-    if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); // (shadow launches read d_init / d_init_mask)
-    if (int rc = la_invalidate(s, mask)) return rc;
+    if (int rc = la_new_tables(s, mask)) return rc;
     HIPCHK(hipStreamSynchronize(s->xfer));
   }
   const int n = s->n_envs, nq = s->m.nq, nv = s->m.nv, w = nq + nv;
@@ -1018,104 +1035,39 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   return FSIM_OK;
 }
 
-// ---- look-ahead reset, host side.  Shadow launches go to la_stream (lowest priority: their workgroups only take slots no step kernel
-// wants) in batches of <= 60 envs passed by value; every batch has a sequence number, written as the tag of the envs it finishes.  A
-// step kernel trusts a tag only if it is <= la_ready = the last batch whose completion event had fired when that kernel was enqueued:
-// the shadow kernel then ENDED before the step kernel STARTED, and kernel boundaries make its stores visible on every XCD.
+// ---- look-ahead reset, host side: the policy numbers and the table serials -- everything else happens on the device.
 static void la_policy(fsim *s) {
   const int T = std::max(1, s->cfg.max_episode_steps);
+  // reset units per job: about what a cheap env-step costs (50 substeps), so that a job fits the idle tail of a launch
+  s->la_chunk = 51;
+  // an env's shadow is started la_defer steps into its episode: the first steps of an episode are the ones with the most robot-part
+  // contacts, i.e. the slowest, and the jobs of a batch that ended together are spread over the rest of the episode
   s->la_defer = T / 5;
-  s->la_rate = std::max(FSIM_MW_NW, ((int)std::ceil(s->n_envs / std::max(1.0, 0.45 * T)) + FSIM_MW_NW - 1) / FSIM_MW_NW * FSIM_MW_NW);
-  if (const char *e = getenv("FSIM_LA_DEFER")) s->la_defer = std::max(0, atoi(e));  // (development)
-  if (const char *e = getenv("FSIM_LA_RATE")) s->la_rate = std::max(1, atoi(e));
+  if (const char *e = getenv("FSIM_LA_CHUNK")) s->la_chunk = std::max(1, atoi(e));  // (development / tests)
+  if (const char *e = getenv("FSIM_LA_DEFER")) s->la_defer = std::max(0, atoi(e));
+  // jobs per launch: every env's reset (at most 401 units) done within ~half of what is left of the episode
+  const int per_env = (401 + s->la_chunk - 1) / s->la_chunk;
+  s->la_jobs = (int)std::ceil((double)s->n_envs * per_env / std::max(1.0, 0.5 * (T - s->la_defer)));
+  if (const char *e = getenv("FSIM_LA_JOBS")) s->la_jobs = atoi(e);
+  s->la_jobs = std::max(1, std::min(s->la_jobs, FSIM_LA_MAXJOBS));
 }
-static void la_poll(fsim *s) {
-  while (!s->la_inflight.empty() && hipEventQuery(s->la_inflight.front().ev) == hipSuccess) {
-    s->la_ready = s->la_inflight.front().seq;
-    s->la_evpool.push_back(s->la_inflight.front().ev);
-    s->la_inflight.pop_front();
-  }
-}
-// The envs in mask (host, null = all) get a new reset table, or the handle's reset configuration changes: their shadows are void and
-// they need new ones.  The caller synchronises s->xfer (the tags are cleared on it) before any launch can read them.
-static int la_invalidate(fsim *s, const uint8_t *mask) {
+// The envs in mask (host, null = all) get a new reset table, or what their reset starts from changes: a new serial number (a shadow
+// computed from the old one no longer counts and is started over).  Copied on s->xfer; the caller synchronises it.
+static int la_new_tables(fsim *s, const uint8_t *mask) {
   if (!s->la_on) return FSIM_OK;
-  la_poll(s);
-  for (int e = 0; e < s->n_envs; e++)
-    if ((!mask || mask[e]) && s->la_env_seq[e] > s->la_ready) {
-      // a shadow launch that may still be reading the old table (an env whose episode ended before its shadow was done): wait for it
-      HIPCHK(hipStreamSynchronize(s->la_stream));
-      la_poll(s);
-      break;
-    }
   if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
   for (int e = 0; e < s->n_envs;) {
     if (mask && !mask[e]) { e++; continue; }
     int e1 = e;
-    while (e1 < s->n_envs && (!mask || mask[e1])) e1++;
-    HIPCHK(hipMemsetAsync(s->d_sh_tag + e, 0, (size_t)(e1 - e) * 4, s->xfer));
-    for (int k = e; k < e1; k++) {
-      if (!s->la_pending[k]) { s->la_pending[k] = 1; s->la_npending++; }
-      s->la_since[k] = s->la_step; s->la_env_seq[k] = 0;
-    }
+    while (e1 < s->n_envs && (!mask || mask[e1])) { s->h_tab_serial[e1] = (s->h_tab_serial[e1] & 0x3fffffff) + 1; e1++; }
+    HIPCHK(hipMemcpyAsync(s->d_tab_serial + e, s->h_tab_serial.data() + e, (size_t)(e1 - e) * 4, hipMemcpyHostToDevice, s->xfer));
     e = e1;
   }
   return FSIM_OK;
 }
-static int la_flush(fsim *s, const StepArgs &a_step, const KParams &kp, ShadowList &list) {
-  if (list.n == 0) return FSIM_OK;
-  const int seq = ++s->la_seq;
-  for (int k = 0; k < list.n; k++) s->la_env_seq[list.env[k]] = seq;
-  StepArgs a = a_step;
-  a.state = nullptr; a.action = nullptr; a.obs = nullptr; a.reward = nullptr; a.done = nullptr; a.info = nullptr; a.reset_mask = nullptr; a.do_step = 0;
-  a.prof = nullptr; a.cost = nullptr; a.nreset = nullptr; a.stats = nullptr; a.tab_attach = nullptr;
-  a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_tag = s->d_sh_tag; a.ready_seq = 0;
-  const bool bundle = s->mw_mode == MW_RULE;
-  if (bundle)
-    hipLaunchKernelGGL(s->ks.env_shadow_b, dim3((list.n + FSIM_MW_NW - 1) / FSIM_MW_NW), dim3(64 * FSIM_MW_NW), FSIM_MW_NW * 4 * FSIM_BUNDLE_STRIDE(s->ly.lds_words), s->la_stream,
-                       s->d_m, s->d_ly, kp, a, list, seq);
-  else
-    hipLaunchKernelGGL(s->ks.env_shadow_1, dim3(list.n), dim3(64), s->lds_bytes, s->la_stream, s->d_m, s->d_ly, kp, a, list, seq);
-  HIPCHK(hipGetLastError());
-  hipEvent_t ev;
-  if (!s->la_evpool.empty()) { ev = s->la_evpool.back(); s->la_evpool.pop_back(); }
-  else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ev, s->la_stream));
-  s->la_inflight.push_back(ShadowBatch{seq, ev});
-  s->la_launched += list.n;
-  list.n = 0;
-  return FSIM_OK;
-}
-// Called once per step launch: start the shadows of up to la_rate pending envs whose table has been on the device for la_defer steps.
-// Deferred and rationed on purpose: the resets of a batch that ended its episodes together are spread over the following episode
-// (~8 % more resident waves, in slots the step kernels leave idle) instead of landing on it as one block, and the first steps of an
-// episode -- the ones with the most robot-part contacts, i.e. the slowest -- are left alone.
-static int la_launch(fsim *s, const StepArgs &a_step, const KParams &kp) {
-  if (!s->la_on || s->la_npending == 0 || !s->d_tab_parts) return FSIM_OK;
-  int quota = s->la_rate, scanned = 0, e = s->la_cursor;
-  ShadowList list;
-  list.n = 0;
-  while (quota > 0 && scanned < s->n_envs && s->la_npending > 0) {
-    if (s->la_pending[e] && s->la_step - s->la_since[e] >= s->la_defer) {
-      list.env[list.n++] = e; s->la_pending[e] = 0; s->la_npending--; quota--;
-      if (list.n == 60) { if (int rc = la_flush(s, a_step, kp, list)) return rc; }
-    }
-    e = e + 1 == s->n_envs ? 0 : e + 1; scanned++;
-  }
-  s->la_cursor = e;
-  return la_flush(s, a_step, kp, list);
-}
-extern "C" int fsim_lookahead_sync(fsim_t *s) {
-  if (!s) FAIL(FSIM_EINVAL, "null");
-  if (!s->la_on) return FSIM_OK;
-  HIPCHK(hipSetDevice(s->device));
-  HIPCHK(hipStreamSynchronize(s->la_stream));
-  la_poll(s);
-  return FSIM_OK;
-}
 extern "C" int fsim_lookahead_stats(fsim_t *s, int64_t *out) {
   if (!s || !out) FAIL(FSIM_EINVAL, "null");
-  out[0] = s->la_on ? 1 : 0; out[1] = s->la_launched; out[2] = s->h_nreset[1]; out[3] = s->h_nreset[2]; out[4] = s->la_npending; out[5] = (int64_t)s->la_inflight.size();
+  out[0] = s->la_on ? 1 : 0; out[1] = s->h_nreset[3]; out[2] = s->h_nreset[1]; out[3] = s->h_nreset[2]; out[4] = s->la_jobs; out[5] = s->la_chunk;
   return FSIM_OK;
 }
 
@@ -1125,9 +1077,16 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
   const bool mw_rule = sched && s->mw_mode == MW_RULE, mw_all = s->mw_mode == MW_ALL;
-  if (sched)
+  if (sched) {
+    LaSched la{};
+    if (s->la_on && s->d_tab_parts) {
+      la.sh_prog = s->d_sh_prog; la.sh_serial = s->d_sh_serial; la.tab_serial = s->d_tab_serial; la.init_mask = s->d_init_mask; la.jobs = s->d_sh_jobs;
+      la.maxjobs = s->la_jobs; la.defer = std::min(s->la_defer, std::max(0, s->cfg.max_episode_steps - 1)); la.eplen_off = s->ly.env + E_EPISODE_LENGTH;
+      la.total = 100 + (s->ecfg.has_recipe ? 100 : 0) + 201; la.total_init = 100; // (env_reset_total)
+    }
     hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), (size_t)s->n_envs * 4, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
-                       s->ly.env + E_NITER, s->mw_k, mw_rule ? 1 : 0, s->d_mworder, s->d_mwn);
+                       s->ly.env + E_NITER, s->mw_k, mw_rule ? 1 : 0, s->d_mworder, s->d_mwn, la);
+  }
   if (s->timing) timing_begin(s);
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
   StepArgs a;
@@ -1136,27 +1095,27 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = do_step ? s->d_nreset : nullptr;
   a.stats = s->d_nreset + 1;
-  a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_tag = nullptr; a.ready_seq = 0;
-  if (s->la_on) { la_poll(s); a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_tag = s->d_sh_tag; a.ready_seq = s->la_ready; }
+  a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
+  if (s->la_on) { a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_prog = s->d_sh_prog; a.sh_serial = s->d_sh_serial; a.tab_serial = s->d_tab_serial; }
+  const bool jobs = sched && s->la_on && s->d_tab_parts && !mw_all; // (k_schedule has listed them)
+  if (jobs) a.sh_jobs = s->d_sh_jobs;
   if (!s->d_ecfg) { HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); }
   if (memcmp(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg)) != 0) { // (rare: max_episode_steps, dense tables, pre-assembled starts)
-    if (s->la_stream) HIPCHK(hipStreamSynchronize(s->la_stream)); // (shadow launches read it too)
     HIPCHK(hipMemcpyAsync(s->d_ecfg, &s->ecfg, sizeof(EnvCfg), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream)); // (pageable source: the copy must have left the host struct before it can change again)
     memcpy(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg));
   }
   a.cfg_dev = s->d_ecfg;
   if (mw_all)
-    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr);
+    hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   else if (mw_rule) // persistent workgroups: as many as the one-wave envs need in bundles of four plus an eighth of the batch for multi-wave envs, at most what is resident at once
     hipLaunchKernelGGL(s->ks.env_step_x, dim3(std::min((s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, s->n_envs / 8), s->x_resident)), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
                        s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mworder, s->d_mwn);
   else
-    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr);
+    hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs + (jobs ? s->la_jobs : 0)), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
-  if (do_step && s->la_on) { s->la_step++; if (int rc = la_launch(s, a, kp)) return rc; }
   return FSIM_OK;
 }
 // ---- dense-reward env
@@ -1181,7 +1140,7 @@ extern "C" int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, co
   if (int rc = dense_check(coef, ncoef, sub, nsub, s->m.nsite, s->m.nparts, s->m.nconn)) return rc;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (s->la_on) { HIPCHK(hipStreamSynchronize(s->la_stream)); if (int rc = la_invalidate(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
+  if (s->la_on) { if (int rc = la_new_tables(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
   if (s->d_dense) { hipFree(s->d_dense); s->d_dense = nullptr; }
   HIPCHK(hipMalloc(&s->d_dense, (size_t)(DC_WORDS + DS_WORDS * nsub) * 4));
   HIPCHK(hipMemcpy(s->d_dense, coef, DC_WORDS * 4, hipMemcpyHostToDevice));
@@ -1398,7 +1357,7 @@ extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, c
   }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (s->la_on) { HIPCHK(hipStreamSynchronize(s->la_stream)); if (int rc = la_invalidate(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
+  if (s->la_on) { if (int rc = la_new_tables(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
   if (s->d_pre) { hipFree(s->d_pre); s->d_pre = nullptr; }
   if (n_pre > 0) {
     HIPCHK(hipMalloc(&s->d_pre, tab.size() * 4));

@@ -50,12 +50,13 @@ struct EnvIO {
   long long t0;   // shader clock at kernel entry
   const float *tab_attach; // [narmj] joint noise of this env's NEXT attach (fsim_set_attach_noise), or null
   const EnvCfg *cfg_dev; // the handle's copy of the EnvCfg in device memory: what the out-of-line env_reset is given (see EnvResetIO)
-  // look-ahead reset (fsim.hip "look-ahead reset"): this env's shadow record / observation row / tag, or null
+  // look-ahead reset (fsim.hip "look-ahead reset"): this env's shadow record / observation row / progress words, or null
   const float *sh_state;
   const void *sh_obs;
-  int *sh_tag;
-  int ready_seq;  // tags in (0, ready_seq] belong to shadow launches that had completed when this launch was enqueued
-  int *stats;     // host-mapped counters: [0] resets taken from a shadow record, [1] resets executed inside a step / reset launch
+  int *sh_prog;   // reset units of the shadow record done so far (env_reset_units); total + 1 = taken by a reset
+  int sh_serial;  // serial number of the reset table the shadow record was (is being) computed from
+  int tab_serial; // serial number of the table on the device (the host bumps it with every upload)
+  int *stats;     // host-mapped counters: [0] resets taken from a shadow record, [1] resets executed inside a step / reset launch, [2] reset units run by look-ahead jobs
 };
 // What env_reset reads of an env's EnvIO, passed BY VALUE (registers).  env_reset is a real function: handing it the addresses of the
 // kernel's EnvCfg (a kernel argument) and EnvIO made the compiler keep both in scratch -- a private copy per LANE, ~100 dwords
@@ -860,12 +861,101 @@ template <class Ctx> DEV void env_init_robot(const Ctx &c, const EnvResetIO &io,
   for (int k = c.lane; k < c.D.ngripj; k += 64) c.L[c.ly.qpos + GP(m.grip_qposadr)[k]] = GP(m.grip_initqpos)[k];
   SYNC();
 }
-template <class Ctx> DEV void env_settle_parts(const Ctx &c) {
+// The reset as a sequence of UNITS, one physics substep each (the reference's _reset calls sim.step() 401 times with a recipe, 301
+// without, 100 from set_init_qpos: tests/golden/reset_trace.npz), so that it can be run whole -- env_reset -- or in pieces whose
+// intermediate state travels in the env record (the look-ahead reset computes an env's NEXT reset a few dozen units per launch in
+// waves the step kernel would otherwise retire, fsim.hip env_shadow_job).  Unit u of the normal path, NS = 100 (+ 100 with a recipe):
+//   u = 0           before it: sim.reset(), masks, env block, part placement
+//   u < NS          settling: every tenth unit starts by stopping the parts; step; _slow_objects.  u = 100 (recipe) starts with the
+//                   pre-assembled connects
+//   u = NS          gravity compensation, robot at its initial pose (draw 0), step, robot collision on, gravity compensation
+//   u <= NS + 100   robot at its initial pose (draw u - NS), step
+//   u >  NS + 100   the common tail: (first unit: controls cleared, forward pass, gravity compensation) step
+// set_init_qpos path: 100 tail units.  After the last unit: IK sync, subtask, dense-reward variables.
+// The SAME loop serves both uses, so running it in pieces executes the same instructions on the same values (every derived quantity
+// is rebuilt by the forward pass of each step; what persists is the record): bit-identical, tests/test_lookahead_gpu.py.
+DEV int env_reset_total(const EnvCfg &cfg, bool init) { return init ? 100 : (100 + (cfg.has_recipe ? 100 : 0) + 201); }
+template <class Ctx0> static __device__ __noinline__ void env_reset_units(Ctx0 cv, const EnvCfg *cfgp, const EnvResetIO io, int p0_, int p1_) {
+  extern __shared__ float fs_lds_[];
+  typedef FsIn<Ctx0> Ctx; // (see FsIn: the physics routine called from here is not the one the step calls)
+  const Ctx c(fs_rebuild(cv, fs_lds_));
+  const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp)); // (device memory: EnvIO::cfg_dev)
+  const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
   CModel &m = c.m;
-  for (int o = 0; o < 10; o++) {
-    if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
-    SYNC();
-    for (int i = 0; i < 10; i++) {
+  float *L = c.L;
+  int *E = c.I(c.ly.env);
+  const bool init = io.init_state != nullptr;
+  const int NS = init ? 0 : 100 + (cfg.has_recipe ? 100 : 0), total = env_reset_total(cfg, init);
+  const int p0 = __builtin_amdgcn_readfirstlane(p0_), p1 = min(__builtin_amdgcn_readfirstlane(p1_), total);
+#pragma unroll 1
+  for (int u = p0; u < p1; u++) {
+    if (u == 0) {
+      // sim.reset()
+      for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = GP(m.qpos0)[i];
+      for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qvel + i] = 0; L[c.ly.qaccws + i] = 0; L[c.ly.qfrcbias + i] = 0; L[c.ly.qfrcapp + i] = 0; }
+      for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
+      for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
+      // robot collision off, part colliders on (furniture.py:1441-1461)
+      for (int g = c.lane; g < c.D.ncg; g += 64) {
+        int ct = m.cg_contype0[g], ca = m.cg_conaffinity0[g];
+        if (m.cg_isrobot[g]) { ct = 0; ca = 0; }
+        if (m.cg_ispartcol[g]) { ct = 1; ca = 1; }
+        c.I(c.ly.contype)[g] = ct; c.I(c.ly.conaff)[g] = ca;
+      }
+      for (int e = c.lane; e < c.D.neq; e += 64) { c.I(c.ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[c.ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
+      int episodes = E[E_EPISODE_COUNT], sticky = E[E_OVERFLOW];
+      SYNC();
+      for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
+      for (int p = c.lane; p < c.D.nparts; p += 64) E[E_GROUP + p] = p;
+      if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
+      SYNC();
+      if (c.lane == 0) {
+        E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; E[E_OVERFLOW] = sticky;
+        if (cfg.n_pre > 0 && cfg.pre_mode == 0) // no recipe: the listed welds are switched on, their groups merged (furniture.py:1493-1501)
+          for (int i = 0; i < cfg.n_pre; i++) {
+            const int e = GP(cfg.pre_tab)[3 * i];
+            c.I(c.ly.eqactive)[e] = 1;
+            int *grp = E + E_GROUP;
+            const int r1 = env_find(grp, GP(m.eq_part1)[e]), r2 = env_find(grp, GP(m.eq_part2)[e]);
+            grp[r1] = r2;
+          }
+      }
+      SYNC();
+      if (init) {
+        // set_init_qpos (furniture.py:1505-1519, 1568-1569, 1617-1618): set_env_state(given state) replaces placement, settling and the
+        // robot initialisation (no RNG draw is consumed); robot collision on; the reference's forward passes in between do not change
+        // qpos / qvel, the common tail below starts with one
+        if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
+        SYNC();
+        for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = io.init_state[i];
+        for (int i = c.lane; i < c.D.nv; i += 64) L[c.ly.qvel + i] = io.init_state[c.D.nq + i];
+        for (int g = c.lane; g < c.D.ncg; g += 64)
+          if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
+        SYNC();
+      } else {
+        // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
+        for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
+          int p = i / 7, k = i % 7;
+          if (io.tab_parts) L[c.ly.qpos + GP(m.part_qposadr)[p] + k] = io.tab_parts[i];
+        }
+        SYNC();
+      }
+    }
+    if (u < NS) { // ---- settling (env_settle: 10 x [stop the parts, 10 x (step, _slow_objects)]), twice with a recipe
+      if (u == 100 && cfg.pre_mode == 1) // pre-assembled recipe steps (furniture.py:1542-1557): _connect(site2, site1) with the recipe's angle, latches cleared
+        for (int i = 0; i < cfg.n_pre; i++) {
+          const int k1 = GP(cfg.pre_tab)[3 * i], k2 = GP(cfg.pre_tab)[3 * i + 1];
+          const float ang = __int_as_float(GP(cfg.pre_tab)[3 * i + 2]);
+          if (c.lane == 0) env_project_connector_quat(c, k1, k2, ang == ang, ang);
+          SYNC();
+          env_connect(c, cfg, k1, k2, true);
+          if (c.lane == 0) { E[E_CONNECTED_THIS_STEP] = 0; E[E_CONNBODY1] = 0; }
+          SYNC();
+        }
+      if (u % 10 == 0) {
+        if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
+        SYNC();
+      }
       fs_step(c);
       // _slow_objects: gravity compensation + clip |qvel| <= 0.2
       for (int p = c.lane; p < c.D.nparts; p += 64) {
@@ -875,117 +965,49 @@ template <class Ctx> DEV void env_settle_parts(const Ctx &c) {
         for (int k = 0; k < 6; k++) { c.L[c.ly.qvel + d + k] = fminf(fmaxf(c.L[c.ly.qvel + d + k], -0.2f), 0.2f); c.L[c.ly.qfrcapp + d + k] = 0; }
       }
       SYNC();
+    } else if (!init && u <= NS + 100) { // ---- the robot: initial pose + joint noise, 1 + 100 times
+      if (u == NS && c.D.narm > 0) env_gravity_comp(c);
+      env_init_robot(c, io, u - NS, cfg.move_speed);
+      fs_step(c);
+      if (u == NS) {
+        for (int g = c.lane; g < c.D.ncg; g += 64)
+          if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
+        SYNC();
+        if (c.D.narm > 0) env_gravity_comp(c);
+      }
+    } else { // ---- the common tail
+      if (u == (init ? 0 : NS + 101)) {
+        for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
+        for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qfrcapp + i] = 0; L[c.ly.qaccws + i] = 0; }
+        for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
+        SYNC();
+        fs_forward(c);
+        if (c.D.narm > 0) env_gravity_comp(c);
+      }
+      fs_step(c);
     }
   }
-}
-
-template <class Ctx0> static __device__ __noinline__ void env_reset(Ctx0 cv, const EnvCfg *cfgp, const EnvResetIO io) {
-  extern __shared__ float fs_lds_[];
-  typedef FsIn<Ctx0> Ctx; // (see FsIn: the physics routine called from here is not the one the step calls)
-  const Ctx c(fs_rebuild(cv, fs_lds_));
-  const EnvCfg &cfg = *static_cast<const EnvCfg *>(fs_uniform_ptr(cfgp)); // (device memory: EnvIO::cfg_dev)
-  const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
-  CModel &m = c.m;
-  float *L = c.L;
-  int *E = c.I(c.ly.env);
-  // sim.reset()
-  for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = GP(m.qpos0)[i];
-  for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qvel + i] = 0; L[c.ly.qaccws + i] = 0; L[c.ly.qfrcbias + i] = 0; L[c.ly.qfrcapp + i] = 0; }
-  for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
-  for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
-  // robot collision off, part colliders on (furniture.py:1441-1461)
-  for (int g = c.lane; g < c.D.ncg; g += 64) {
-    int ct = m.cg_contype0[g], ca = m.cg_conaffinity0[g];
-    if (m.cg_isrobot[g]) { ct = 0; ca = 0; }
-    if (m.cg_ispartcol[g]) { ct = 1; ca = 1; }
-    c.I(c.ly.contype)[g] = ct; c.I(c.ly.conaff)[g] = ca;
-  }
-  for (int e = c.lane; e < c.D.neq; e += 64) { c.I(c.ly.eqactive)[e] = 0; for (int k = 0; k < 7; k++) L[c.ly.eqdata + 7 * e + k] = GP(m.eq_data0)[7 * e + k]; }
-  int episodes = E[E_EPISODE_COUNT], sticky = E[E_OVERFLOW];
-  SYNC();
-  for (int i = c.lane; i < E_FIXED_WORDS; i += 64) E[i] = 0;
-  for (int p = c.lane; p < c.D.nparts; p += 64) E[E_GROUP + p] = p;
-  if (c.D.agent == 2) for (int i = c.lane; i < EC_WORDS; i += 64) E[E_GROUP + c.D.nparts + i] = 0;
-  SYNC();
-  if (c.lane == 0) {
-    E[E_EPISODE_COUNT] = episodes + 1; E[E_SITE1] = -1; E[E_SITE2] = -1; E[E_OVERFLOW] = sticky;
-    if (cfg.n_pre > 0 && cfg.pre_mode == 0) // no recipe: the listed welds are switched on, their groups merged (furniture.py:1493-1501)
-      for (int i = 0; i < cfg.n_pre; i++) {
-        const int e = GP(cfg.pre_tab)[3 * i];
-        c.I(c.ly.eqactive)[e] = 1;
-        int *grp = E + E_GROUP;
-        const int r1 = env_find(grp, GP(m.eq_part1)[e]), r2 = env_find(grp, GP(m.eq_part2)[e]);
-        grp[r1] = r2;
+  if (p1 == total && p0 < total) {
+    if (cfg_ik) env_ik_sync(c); // furniture.py:1643-1650
+    // the finger / floor touch masks describe the contact list of a forward pass run with mode bit 1; none of the reset's passes is one,
+    // so what is there belongs to the state BEFORE the reset (the terminal step's last pass) -- the reset state has the fingers open and
+    // away from the parts.  Cleared, so that what follows (the dense reward's _reset_reward_variables, the scheduler features) does not
+    // depend on where the previous episode ended -- which also makes the reset a function of the reset table alone (look-ahead reset).
+    if (c.lane == 0) { int *scal = c.I(c.ly.scal); scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; }
+    SYNC();
+    if (c.lane == 0) {
+      env_next_subtask(c);
+      if (cfg_dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
+        DenseSimP<Ctx> dp{c, cfg};
+        dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, cfg.n_pre);
       }
-  }
-  SYNC();
-  if (io.init_state) {
-    // set_init_qpos (furniture.py:1505-1519, 1568-1569, 1617-1618): set_env_state(given state) replaces placement, settling and the
-    // robot initialisation (no RNG draw is consumed); robot collision on; the reference's forward passes in between do not change
-    // qpos / qvel, the common tail below starts with one
-    if (c.lane == 0) for (int p = 0; p < c.D.nparts; p++) env_stop_part(c, p, 0.0f);
-    SYNC();
-    for (int i = c.lane; i < c.D.nq; i += 64) L[c.ly.qpos + i] = io.init_state[i];
-    for (int i = c.lane; i < c.D.nv; i += 64) L[c.ly.qvel + i] = io.init_state[c.D.nq + i];
-    for (int g = c.lane; g < c.D.ncg; g += 64)
-      if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
-    SYNC();
-  } else {
-  // place parts (host ran the reference's sampler; tasks/placement_sampler.py:138-190)
-  for (int i = c.lane; i < 7 * c.D.nparts; i += 64) {
-    int p = i / 7, k = i % 7;
-    if (io.tab_parts) L[c.ly.qpos + GP(m.part_qposadr)[p] + k] = io.tab_parts[i];
-  }
-  SYNC();
-  env_settle_parts(c);
-  if (cfg.has_recipe) {
-    // pre-assembled recipe steps (furniture.py:1542-1557): _connect(site2, site1) with the recipe's angle, latches cleared
-    if (cfg.pre_mode == 1)
-      for (int i = 0; i < cfg.n_pre; i++) {
-        const int k1 = GP(cfg.pre_tab)[3 * i], k2 = GP(cfg.pre_tab)[3 * i + 1];
-        const float ang = __int_as_float(GP(cfg.pre_tab)[3 * i + 2]);
-        if (c.lane == 0) env_project_connector_quat(c, k1, k2, ang == ang, ang);
-        SYNC();
-        env_connect(c, cfg, k1, k2, true);
-        if (c.lane == 0) { E[E_CONNECTED_THIS_STEP] = 0; E[E_CONNBODY1] = 0; }
-        SYNC();
-      }
-    env_settle_parts(c);
-  }
-  {
-    if (c.D.narm > 0) env_gravity_comp(c);
-    env_init_robot(c, io, 0, cfg.move_speed);
-    fs_step(c);
-    for (int g = c.lane; g < c.D.ncg; g += 64)
-      if (m.cg_isrobot[g]) { c.I(c.ly.contype)[g] = m.cg_contype0[g]; c.I(c.ly.conaff)[g] = m.cg_conaffinity0[g]; }
-    SYNC();
-    if (c.D.narm > 0) env_gravity_comp(c);
-    for (int k = 0; k < 100; k++) { env_init_robot(c, io, 1 + k, cfg.move_speed); fs_step(c); }
-  }
-  }
-  for (int i = c.lane; i < c.D.nu; i += 64) L[c.ly.ctrl + i] = 0;
-  for (int i = c.lane; i < c.D.nv; i += 64) { L[c.ly.qfrcapp + i] = 0; L[c.ly.qaccws + i] = 0; }
-  for (int i = c.lane; i < 6 * c.D.nparts; i += 64) L[c.ly.xfrc + i] = 0;
-  SYNC();
-  fs_forward(c);
-  if (c.D.narm > 0) env_gravity_comp(c);
-  for (int k = 0; k < 100; k++) fs_step(c);
-  if (cfg_ik) env_ik_sync(c); // furniture.py:1643-1650
-  // the finger / floor touch masks describe the contact list of a forward pass run with mode bit 1; none of the reset's passes is one,
-  // so what is there belongs to the state BEFORE the reset (the terminal step's last pass) -- the reset state has the fingers open and
-  // away from the parts.  Cleared, so that what follows (the dense reward's _reset_reward_variables, the scheduler features) does not
-  // depend on where the previous episode ended -- which also makes the reset a function of the reset table alone (look-ahead reset).
-  if (c.lane == 0) { int *scal = c.I(c.ly.scal); scal[SC_TOUCHL] = 0; scal[SC_TOUCHR] = 0; scal[SC_TOUCHF] = 0; E[E_OVERFLOW] |= scal[SC_OVERFLOW]; }
-  SYNC();
-  if (c.lane == 0) {
-    env_next_subtask(c);
-    if (cfg_dense) { // FurnitureSawyerDenseRewardEnv._reset: _reset_reward_variables (furniture_sawyer_dense.py:218-220)
-      DenseSimP<Ctx> dp{c, cfg};
-      dense_reset(env_edense(c), cfg.dense_coef, cfg.dense_sub, dp, cfg.n_pre);
     }
   }
+  // (sticky overflow report: this call's substeps -- the LDS scalars do not outlive a launch, the record does)
+  if (c.lane == 0) E[E_OVERFLOW] |= c.I(c.ly.scal)[SC_OVERFLOW];
   SYNC();
 }
+template <class Ctx> DEV void env_reset(const Ctx &c, const EnvCfg *cfgp, const EnvResetIO &io) { env_reset_units(c, cfgp, io, 0, 1 << 20); }
 
 // Smallest clearance between a robot collision geom and a furniture part's collision geom, from the body poses of the last
 // forward pass: a LOWER bound on the true distance (exact point-to-solid distance from one geom's centre to the other geom's box /
@@ -1040,15 +1062,16 @@ template <class Ctx> DEV void env_post(const Ctx &c, const EnvCfg &cfg, const En
 }
 
 // ---- look-ahead reset.  The state a reset leaves is a function of the env's reset table (and the handle's configuration) alone, and
-// the host uploads that table one episode ahead.  A low-priority kernel (k_env_shadow, fsim.hip) runs env_reset + env_post for it into a
-// SHADOW record + observation row while the episode is still being stepped; the terminal step then copies the shadow in instead of
-// running 301 / 401 substeps on the critical path of its launch.  Same code, same context type, same inputs: the record is bit-identical
-// to what the in-kernel reset would leave (tests/test_lookahead_gpu.py).  A shadow counts only if its tag lies in (0, ready_seq]: the
-// launch that wrote it had COMPLETED when this launch was enqueued (kernel boundaries order the two; no intra-kernel coherence needed).
-DEV bool env_shadow_ready(const EnvIO &io) {
-  if (!io.sh_tag) return false;
-  const int t = __builtin_amdgcn_readfirstlane(*io.sh_tag);
-  return t > 0 && t <= io.ready_seq;
+// the host uploads that table one episode ahead.  While the episode is still being stepped, waves of the step kernel that have run
+// out of envs run the NEXT reset a few dozen units per launch (env_shadow_job, fsim.hip) into a SHADOW record + observation row; the
+// terminal step then copies the shadow in instead of running 301 / 401 substeps on the critical path of its launch.  Same loop
+// (env_reset_units), same context type, same inputs: the record is bit-identical to what the in-kernel reset leaves
+// (tests/test_lookahead_gpu.py).  A shadow counts when it is complete and was computed from the table that is on the device now
+// (serial numbers); everything happens on the handle's one stream, in launch order.
+DEV bool env_shadow_ready(const EnvCfg &cfg, const EnvIO &io) {
+  if (!io.sh_prog) return false;
+  const int p = __builtin_amdgcn_readfirstlane(*io.sh_prog);
+  return io.sh_serial == io.tab_serial && io.tab_serial > 0 && p == env_reset_total(cfg, io.init_state != nullptr);
 }
 template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   float *L = c.L;
@@ -1061,7 +1084,7 @@ template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const
   if (c.lane == 0) {
     // (the two words of the record that belong to the env, not to the reset: how many episodes it has seen, whether it ever dropped contacts)
     E[E_EPISODE_COUNT] = episodes + 1; E[E_OVERFLOW] |= sticky;
-    *io.sh_tag = 0; // consumed
+    *io.sh_prog = env_reset_total(cfg, io.init_state != nullptr) + 1; // taken (a new table -- another serial -- starts the next one)
     if (io.stats) __hip_atomic_fetch_add(io.stats, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (io.info) {
       io.info[FSIM_INFO_SUBTASK1] = E[E_SUBTASK1]; io.info[FSIM_INFO_SUBTASK2] = E[E_SUBTASK2];
@@ -1083,7 +1106,7 @@ template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const
 // The reset of ONE env inside a launch: the shadow record if one is ready, else the reset itself.  (reset launches, deferred resets
 // of the multi-wave workgroups and -- through env_step -- the auto-reset of a terminal step)
 template <class Ctx> DEV void env_reset_or_swap(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
-  if (env_shadow_ready(io)) { env_swap_in(c, cfg, io); return; }
+  if (env_shadow_ready(cfg, io)) { env_swap_in(c, cfg, io); return; }
   env_reset(c, io.cfg_dev, env_reset_io(io));
   if (c.lane == 0 && io.stats) __hip_atomic_fetch_add(io.stats + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   env_post(c, cfg, io, 0);
@@ -1223,7 +1246,7 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
     // unstable step differs (same distribution).  Keeping two tables per env on the device would remove it.
     const bool skip_reset = cfg.auto_reset && !cfg_dense;
     if (!skip_reset) {
-      if (env_shadow_ready(io)) env_swap_in(c, cfg, io); // (the record only matters here: the forward pass below rebuilds the poses)
+      if (env_shadow_ready(cfg, io)) env_swap_in(c, cfg, io); // (the record only matters here: the forward pass below rebuilds the poses)
       else {
         env_reset(c, io.cfg_dev, env_reset_io(io));
         if (c.lane == 0 && io.stats) __hip_atomic_fetch_add(io.stats + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1346,11 +1369,14 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
   if (c.lane == 0) E[E_OVERFLOW] |= scal[SC_OVERFLOW]; // sticky: a step that dropped contacts is never lost between two host reads
   SYNC();
   if (terminal && cfg.auto_reset) { // SubprocVecEnv worker semantics (subproc_vec_env.py:15-48)
-    if (DEFER && !env_shadow_ready(io)) return 1;
+    if (DEFER && !env_shadow_ready(cfg, io)) return 1;
     env_reset_or_swap(c, cfg, io);
   } else {
     if (cfg_ik) env_ik_remember(c, cfg_ik); // (a reset stores its own poses: env_ik_sync)
-    env_post(c, cfg, io, nit_step);
+    // what the multi-wave rule reads: Newton iterations per 50 substeps (an IK step runs 3 x n_substeps of them: unscaled, every IK env
+    // would pass the threshold of 150 = three iterations per substep without touching anything)
+    const int nsub = max(1, cfg.n_substeps * (cfg_ik ? 3 : 1));
+    env_post(c, cfg, io, nsub == 50 ? nit_step : (int)((float)nit_step * 50.0f / (float)nsub));
   }
 #ifdef FSIM_TIMELINE
   if (c.lane == 0) scal[52] = (int)(clock64() >> 4) - scal[52];

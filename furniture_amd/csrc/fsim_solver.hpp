@@ -1035,14 +1035,28 @@ template <> struct FsMfmaStep<32> {
 // (the LDS base travels as a 32-bit LDS address: naming the dynamic-LDS symbol inside a non-kernel function costs a table lookup
 //  -- s_getpc + s_load + wait, ~400 cycles -- at every use the compiler does not merge)
 typedef __attribute__((address_space(3))) float fs_lds_f;
-template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_) {
+// nst_ < 0: the tile is read from the packed Hessian in LDS (what fs_hessian assembled; the integrator's M + h D).
+// nst_ >= 0 (round 4): the tile is ASSEMBLED HERE, on the matrix cores.  The island's Hessian is M + sum_c Jc' Kc Jc over its nst_
+// active contacts (+ D e e' per active joint limit).  Column k of Jc is the velocity the contact point picks up per unit velocity of
+// dof k, v_k = [k in chain(b2)] (lin_k + ang_k x r2) - [k in chain(b1)] (lin_k + ang_k x r1) -- lane k has cdof_k in registers and
+// the chain test is one bit of its body's subtree mask --, the world stiffness Kc = G G' was factored by the contact's lane
+// (fs_stage_big), so the contact adds the three rank-1 terms u_a u_a', u = G' v: exactly what v_mfma_f32_32x32x2_f32 accumulates,
+// two at a time (K = 2: the lanes of the lower half carry one contact, those of the upper half the next one).  1.5 MFMAs per
+// contact straight into the accumulator tile the factorisation then works on, instead of 21 + 21 + 36 LDS float atomics per contact
+// (which cost ~4 cycles per active lane in the CU's one LDS unit), a projection pass over M's pattern, a pass over the body-pair
+// entries and the read-back of the packed triangle.  stage_: word offset of the staged records (FS_STW words each, pairs zero-padded),
+// preceded by 32 words of right-hand side and 32 words of joint-limit diagonal (tile order).
+#define FS_STW 16
+#define FS_ST_HEAD 64
+template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int nst_, int stage_) {
   float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
   const Ctx c = fs_rebuild(cv, lds_);
   const int mp = __builtin_amdgcn_readfirstlane(mp_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_);
+  const int nst = __builtin_amdgcn_readfirstlane(nst_), stage = __builtin_amdgcn_readfirstlane(stage_);
   float *L = c.L;
   const float *H = L + c.ly.H;
   const int nv = c.D.nv;
-  float *rhs = L + c.ly.hA; // 32 words of scratch: the Hessian body blocks (>= 21 nr + 160 words) are dead once H is assembled
+  float *rhs = L + (nst >= 0 ? stage : c.ly.hA); // 32 words of scratch: the Hessian body blocks (>= 21 nr + 160 words) are dead once H is assembled
   const int k = c.lane & 31, h = c.lane >> 5;
   // every load below is unconditional on a clamped index and the selection follows: behind `if` the 32 reads of the tile
   // became 32 exec-masked blocks with a wait each
@@ -1054,6 +1068,7 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
   SYNC();
   fs_f16v D;
   float eH[16], eR[16];
+  if (nst < 0) {
   // element (i, k) of the packed lower triangle: tri(max) + min.  The index is NOT clamped for rows / columns outside the
   // island: hI + 527 words is inside the LDS image whatever follows H, and the selection below drops what was read
   const int triK = k * (k + 1) / 2;
@@ -1064,6 +1079,25 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
     eH[v] = H[hI + (i >= k ? triI + k : triK + i)];
     eR[v] = rhs[i]; // column 31 (lanes 31 and 63): the right-hand side.  (row 31 is never read: zero)
   }
+  } else {
+    // M's block of the island, from the tree-packed triangles of M: entry (i, k) exists iff the two dofs belong to one kinematic tree.
+    // This lane's column word: packed row base of dof k in M (12 bits) | its index inside its tree (6) << 12 | its tree (4) << 18; the
+    // row's word comes from lane i (rows and columns are the same dofs), i = i0 + 4 h with i0 a compile-time constant
+    const int Tk = c.I(c.ly.k_tmap)[dofk];
+    const int Pk = (Tk & 0x3ffff) | (KI(dof_tree, dofk) << 18);
+    const int lk = (Pk >> 12) & 63, rbk = Pk & 0xfff;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int i0 = 8 * (v >> 2) + (v & 3);
+      const int P0 = __builtin_amdgcn_readlane(Pk, i0), P1 = __builtin_amdgcn_readlane(Pk, i0 + 4);
+      const int Pi = h ? P1 : P0, li = (Pi >> 12) & 63;
+      const bool same = ((Pi ^ Pk) >> 18) == 0;
+      const int idx = li >= lk ? (Pi & 0xfff) + lk : rbk + li;
+      const float mv = L[c.ly.M + idx]; // (unconditional: the index is inside M whatever the pair of dofs)
+      eH[v] = same ? mv : 0.0f;
+      eR[v] = rhs[i0 + 4 * h];
+    }
+  }
   // (pins the 32 loads where they are: the compiler otherwise sinks each of them into the branch of the selection below)
   asm volatile("" : "+v"(eH[0]), "+v"(eH[1]), "+v"(eH[2]), "+v"(eH[3]), "+v"(eH[4]), "+v"(eH[5]), "+v"(eH[6]), "+v"(eH[7]),
                     "+v"(eH[8]), "+v"(eH[9]), "+v"(eH[10]), "+v"(eH[11]), "+v"(eH[12]), "+v"(eH[13]), "+v"(eH[14]), "+v"(eH[15]));
@@ -1072,7 +1106,37 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
 #pragma unroll
   for (int v = 0; v < 16; v++) {
     const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-    D[v] = max(i, k) < n ? eH[v] : ((k == 31 && i < n) ? eR[v] : 0.0f);
+    D[v] = max(i, k) < n ? eH[v] : 0.0f; // (the right-hand side column is put in after the assembly: its lanes carry u = 0 until then)
+  }
+  if (nst >= 0) {
+    const bool valid = k < n;
+    const S6 sk_ = lds6(L + c.ly.cdof + 6 * dofk);
+    const int sub = valid ? KI(r_submask, KI(dof_rbody, dofk)) : 0; // bodies whose chain holds dof k
+    // joint limits: one more rank-1 term per limited dof, all of them in ONE instruction (the terms touch disjoint diagonal entries)
+    {
+      const float dl = L[stage + 32 + k];
+      const float ul = (valid && h == 0) ? __builtin_sqrtf(dl) : 0.0f;
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(ul, ul, D, 0, 0, 0);
+    }
+    const float *rec = L + stage + FS_ST_HEAD + FS_STW * h;
+    for (int q = 0; q < nst; q += 2) {
+      const float *r = rec + FS_STW * q;
+      const V3 r1 = ldv3(r), r2 = ldv3(r + 3);
+      const float g00 = r[6], g10 = r[7], g11 = r[8], g20 = r[9], g21 = r[10], g22 = r[11];
+      const int bb = __float_as_int(r[12]);
+      const bool in1 = (sub >> (bb & 255)) & 1, in2 = (sub >> ((bb >> 8) & 255)) & 1;
+      const V3 v1 = sk_.l + cross(sk_.a, r1), v2 = sk_.l + cross(sk_.a, r2);
+      const V3 vv = (in2 ? v2 : v3(0, 0, 0)) - (in1 ? v1 : v3(0, 0, 0));
+      const float u0 = g00 * vv.x + g10 * vv.y + g20 * vv.z, u1 = g11 * vv.y + g21 * vv.z, u2 = g22 * vv.z;
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, u0, D, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, u1, D, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u2, u2, D, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+    D[v] = (k == 31 && i < n) ? eR[v] : D[v];
   }
   float myrinv = 0.0f, acc = 0.0f, res = 0.0f, dmin = 1.0f;
 #ifdef FSIM_CHOLPROF
@@ -1088,6 +1152,68 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
 #endif
   if (c.lane < n) L[c.ly.p + dofk] = res;
   return !(dmin > 1e-30f);
+}
+
+// Stage the active contacts and joint limits of ONE big island for the assembly above.  Lane = contact slot: the world stiffness
+// K (SlotK, from this iteration's gradient pass) is factored K = G G' here -- K is positive semi-definite (the cone cost is convex)
+// and may be singular (a frictionless contact, the cone's surface): a pivot below 1e-12 of the largest diagonal entry drops its
+// column.  trees: kinematic trees of the island.  Returns the number of staged contacts (wave-uniform), -1 if they do not fit
+// (the caller then assembles this island's Hessian the LDS way).
+template <class Ctx> DEV int fs_stage_big(const Ctx &c, const SolSlot &S, const SlotK &sk, const int trees, const int stage, const int cap) {
+  float *L = c.L;
+  const int b1 = S.bt1 & 255, b2 = S.bt2 & 255;
+  const bool mine = sk.on && ((b1 != 0 && ((trees >> (S.bt1 >> 8)) & 1)) || (b2 != 0 && ((trees >> (S.bt2 >> 8)) & 1)));
+  const unsigned long long mask = __ballot(mine);
+  const int nst = __popcll(mask);
+  if (nst > cap) return -1;
+  if (c.lane < 32) L[stage + 32 + c.lane] = 0.0f;
+  SYNC();
+  if (mine) {
+    const float *K = sk.K; // xx xy xz yy yz zz
+    const float big = fmaxf(fmaxf(K[0], K[3]), K[5]), eps = 1e-6f * big; // (a rank-deficient K leaves rounding noise of ~1e-7 K in the later pivots: not a direction)
+    float g00 = 0, g10 = 0, g20 = 0, g11 = 0, g21 = 0, g22 = 0;
+    if (K[0] > eps) { g00 = __builtin_sqrtf(K[0]); const float r = 1.0f / g00; g10 = K[1] * r; g20 = K[2] * r; }
+    const float d1 = K[3] - g10 * g10;
+    if (d1 > eps) { g11 = __builtin_sqrtf(d1); g21 = (K[4] - g20 * g10) / g11; }
+    const float d2 = K[5] - g20 * g20 - g21 * g21;
+    if (d2 > eps) g22 = __builtin_sqrtf(d2);
+    float *r = L + stage + FS_ST_HEAD + FS_STW * __popcll(mask & ((1ull << c.lane) - 1ull));
+    stv3(r, S.r1); stv3(r + 3, S.r2);
+    r[6] = g00; r[7] = g10; r[8] = g11; r[9] = g20; r[10] = g21; r[11] = g22;
+    r[12] = __int_as_float(b1 | (b2 << 8));
+  }
+  if ((nst & 1) && c.lane < FS_STW) L[stage + FS_ST_HEAD + FS_STW * nst + c.lane] = 0.0f; // (the odd contact's partner: G = 0, bodies 0)
+  if (S.lact && S.ljar < 0 && ((trees >> KI(dof_tree, S.ldof)) & 1)) atomicAdd(L + stage + 32 + ((c.I(c.ly.hmap)[S.ldof] >> 12) & 63), S.ld);
+  SYNC();
+  return nst;
+}
+
+// Which big islands of this solve have their Hessian assembled on the matrix cores (fs_chol_mfma, nst >= 0): those whose constraint-
+// active contacts fit the staging area -- decided ONCE per solve on the slots that are active constraints at all (the cone zones, hence
+// the contacts that actually contribute, change from iteration to iteration; the bound does not), so that the set of trees the LDS
+// path leaves out is fixed for the solve.  Welds couple rows the tile assembly does not know: the solve then takes the LDS path.
+// Returns the kinematic trees of those islands (bit mask).
+template <class Ctx> DEV int fs_asm_trees(const Ctx &c, const SolSlot &S) {
+#ifdef FSIM_NO_MFMA_HESSIAN
+  return 0;
+#endif
+  if (Ctx::NS != 1 || S.anyweld) return 0;
+  const int nv = c.D.nv;
+  const int *hm = c.I(c.ly.hmap), *tail = hm + nv + 64, *isl = c.I(c.ly.scal) + SC_ISL;
+  const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
+  if (nbig == 0 || maxbig > 31) return 0;
+  const int cap = (21 * c.D.nr + FSIM_XW * FSIM_NPAIR + 3 * FSIM_NPAIR + 4 - FS_ST_HEAD) / FS_STW - 1; // (- 1: the zero partner of an odd contact)
+  const int t1 = S.bt1 >> 8, t2 = S.bt2 >> 8;
+  const bool m1 = S.act && (S.bt1 & 255) != 0, m2 = S.act && (S.bt2 & 255) != 0;
+  int out = 0;
+  for (int q = 0; q < nbig; q++) {
+    const int first = __builtin_amdgcn_readfirstlane(tail[MAP_BIG0 + 2 * q]);
+    const int d0 = __builtin_amdgcn_readfirstlane((hm[nv + first] >> 8) & 255);
+    const int trees = __builtin_amdgcn_readfirstlane(isl[KI(dof_tree, d0)]);
+    const int cnt = __popcll(__ballot((m1 && ((trees >> t1) & 1)) || (m2 && ((trees >> t2) & 1))));
+    if (cnt <= cap) out |= trees;
+  }
+  return out;
 }
 
 // islands larger than 32 dofs (e.g. the fully welded table plus the robot): the factor stays in LDS, left-looking, lane = row
@@ -1142,7 +1268,9 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
 // am (-1: every island): trees of the islands that take a step (fs_active_islands).  Lanes of the others act as empty lanes (unit
 // diagonal) and set p = 0, the row phase only runs as many pivots as the last moving lane needs, a big island that does not move is skipped.
-template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1) {
+// asm_ok / S / sk: trees of the big islands whose Hessian is assembled on the matrix cores (fs_asm_trees), with this lane's slot records
+// and this iteration's cone state (Newton solve only; 0 / null: every tile is read from the packed Hessian in LDS)
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1, const int asm_ok = 0, const SolSlot *S = nullptr, const SlotK *sk = nullptr) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
@@ -1191,16 +1319,15 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am =
           if (c.lane >= first && c.lane < first + n && dofb != 255) c.L[c.ly.p + dofb] = 0.0f;
           continue;
         }
-        const bool mine = c.lane >= first && c.lane < first + n && dofb != 255;
-        const int dof = mine ? dofb : -1;
-#ifdef FSIM_CHOL_READLANE
-        LaneBcast bc; bc.first = first;
-        if (n <= 24) bad |= fs_chol_phase<24>(c, mp, dof, c.lane - first, n, bc);
-        else bad |= fs_chol_phase<32>(c, mp, dof, c.lane - first, n, bc);
-#else
-        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
-        (void)dof;
-#endif
+        if (asm_ok) {
+          const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
+          if (trees & asm_ok) {
+            const int nst = fs_stage_big(c, *S, *sk, trees, c.ly.hA, 1 << 30);
+            bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, nst, c.ly.hA);
+            continue;
+          }
+        }
+        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, -1, 0);
       }
     }
   }
@@ -1224,7 +1351,7 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am =
 // filled by exactly ONE wave in lane order and sums across accumulators are taken in a fixed order, so the result is a function
 // of the state alone, as in the one-wave kernel (run-to-run bit-identical) -- though not bit-identical TO the one-wave kernel.
 enum { MW_IDLE = 0, MW_EXIT = 1, MW_COLLIDE = 2, MW_ITER = 3, MW_CHOL = 4, MW_MULM = 5 };
-enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9, MWC_SOLVE = 10, MWC_AM = 11 /* trees of the islands that still move (fs_active_islands) */ };
+enum { MWC_CMD0 = 0, MWC_CMD1 = 1, MWC_SEQ = 2, MWC_BAD = 3, MWC_CONT = 4, MWC_NPC = 5, MWC_PTOT = 6, MWC_NYE = 7, MWC_A0 = 8, MWC_A1 = 9, MWC_SOLVE = 10, MWC_AM = 11 /* trees of the islands that still move (fs_active_islands) and are assembled in LDS */, MWC_ASM = 12 /* fs_asm_trees of the solve */ };
 
 template <class Ctx> DEV void mw_post(const Ctx &c, int cmd) { // main wave only
   int *w = c.I(c.ly.mwc);
@@ -1434,7 +1561,7 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid,
     S = fs_load_slots(c);
     S.pid = reinterpret_cast<const int *>(j)[7];
     sid = solve;
-    am_last = -1; // (first iteration of a solve: every island)
+    am_last = ~__builtin_amdgcn_readfirstlane(w[MWC_ASM]); // (first iteration of a solve: every island the LDS path assembles)
   }
   SlotK sk;
 #pragma unroll
@@ -1471,7 +1598,7 @@ template <class Ctx> DEV void mw_iter_helper(const Ctx &c, SolSlot &S, int &sid,
 
 // main's side: gradient (the code of fs_gradient, split at its barriers) beside the helpers' Hessian.  Returns the gradient
 // norm; *go = false: converged, the helpers have left the iteration and H is not complete.
-template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go, int *am) {
+template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, SlotK &sk, float scale, bool *go, int *am, const int asm_ok) {
   float *L = c.L;
   int *w = c.I(c.ly.mwc);
   float *tsum = L + c.ly.scal + SC_TMP; // (fs_active_islands)
@@ -1527,14 +1654,15 @@ template <class Ctx> DEV float mw_iterate_main(const Ctx &c, const SolSlot &S, S
   const float gn = sqrtf(fs_active_islands(c, scale, every, am));
   *go = !(scale * gn < c.newton_tol);
   // (the helpers gate THIS iteration's blocks with the set they kept from the last one -- a register of theirs, not this word)
-  if (c.lane == 0) { w[MWC_CONT] = *go ? 1 : 0; w[MWC_AM] = *am; }
+  // (the islands assembled on the matrix cores -- asm_ok -- are none of the helpers' business: no blocks, no projection)
+  if (c.lane == 0) { w[MWC_CONT] = *go ? 1 : 0; w[MWC_AM] = *am & ~asm_ok; }
   FS_MWPROF(54);
   c.xbar(); // [3]
   FS_MWPROF(53);
   c.xbar(); // [4]
   FS_MWPROF(55);
   if (!*go) return gn;
-  mw_project(c, *am);
+  mw_project(c, *am & ~asm_ok);
   FS_MWPROF(56);
   c.xbar(); // [5]
   FS_MWPROF(57);
@@ -1558,7 +1686,7 @@ template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp, const int am) {
   else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   if (__ballot(bad != 0) && c.lane == 0) c.I(c.ly.mwc)[MWC_BAD] = 1;
 }
-template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am) {
+template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, const int asm_ok, const SolSlot &S, const SlotK &sk) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
@@ -1573,7 +1701,15 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am) {
         if (c.lane >= first && c.lane < first + n && ((lwb >> 8) & 255) != 255) c.L[c.ly.p + ((lwb >> 8) & 255)] = 0.0f;
         continue;
       }
-      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
+      if (asm_ok) {
+        const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
+        if (trees & asm_ok) {
+          const int nst = fs_stage_big(c, S, sk, trees, c.ly.hA, 1 << 30);
+          bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, nst, c.ly.hA);
+          continue;
+        }
+      }
+      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, -1, 0);
     }
   }
   return wave_or(bad);
@@ -1655,6 +1791,9 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       if (c.lane == 0) { int *w = c.I(c.ly.mwc); w[MWC_NPC] = S.npc; w[MWC_PTOT] = S.ptot; w[MWC_NYE] = S.nye; w[MWC_SOLVE] += 1; w[MWC_AM] = -1; }
     }
   }
+  // big islands whose Hessian is assembled on the matrix cores, straight into the tile the factorisation works on (fs_chol_mfma)
+  const int asm_ok = fs_asm_trees(c, S);
+  if constexpr (Ctx::NW > 1) { if (mw && c.lane == 0) c.I(c.ly.mwc)[MWC_ASM] = asm_ok; }
   for (; it < c.newton_maxit; it++) {
     SlotK sk, skT = {};
     bool ok;
@@ -1663,7 +1802,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       iterated = true;
       bool go;
       int am;
-      mw_iterate_main(c, S, sk, scale, &go, &am);
+      mw_iterate_main(c, S, sk, scale, &go, &am, asm_ok);
       FS_SPROF(24);
       if (!go) break;
       int *w = c.I(c.ly.mwc);
@@ -1672,12 +1811,12 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       if (nbig > 0 && rsteps > 0) { // the DPP rows on helper 1 beside the big island(s) here
         if (c.lane == 0) w[MWC_BAD] = 0;
         mw_post(c, MW_CHOL);
-        const int bad = mw_chol_big(c, c.ly.hmap, am);
+        const int bad = mw_chol_big(c, c.ly.hmap, am, asm_ok, S, sk);
         mw_post(c, MW_IDLE);
         ok = !(bad | __builtin_amdgcn_readfirstlane(w[MWC_BAD]));
       } else {
         mw_post(c, MW_IDLE); // (helper 1 is still adding the body-pair entries)
-        ok = fs_chol_solve(c, c.ly.hmap, am);
+        ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S, &sk);
       }
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
@@ -1696,10 +1835,11 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       const float gn = sqrtf(fs_active_islands(c, scale, every, &am));
       FS_SPROF(23);
       if (scale * gn < c.newton_tol) break;
-      fs_hessian(c, sk, S, am);
+      // (the LDS assembly serves the islands the matrix cores do not take: none at all when a robot island is all that still moves)
+      if (!asm_ok || (am & ~asm_ok)) fs_hessian(c, sk, S, am & ~asm_ok);
       if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
       FS_SPROF(24);
-      ok = fs_chol_solve(c, c.ly.hmap, am);
+      ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S, &sk);
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
       fs_mulM(c, c.ly.Mp, c.ly.p);

@@ -130,7 +130,6 @@ def lib():
         L.fsim_step_kernel.argtypes = [ctypes.c_void_p]
         L.fsim_step_kernel.restype = ctypes.c_char_p
         L.fsim_lookahead_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        L.fsim_lookahead_sync.argtypes = [ctypes.c_void_p]
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_set_attach_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -151,7 +150,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_step_kernel", "fsim_lookahead_stats", "fsim_lookahead_sync",
+    "fsim_step_kernel", "fsim_lookahead_stats",
     "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
 ]
 
@@ -371,13 +370,10 @@ class FSim:
         return int(lib().fsim_tables_needed(self._h))
 
     def lookahead_stats(self):
-        """fsim_lookahead_stats: dict(enabled, launched, swapped, inline, pending, inflight) -- valid after sync()"""
+        """fsim_lookahead_stats: dict(enabled, units (reset substeps run by look-ahead jobs), swapped, inline, jobs_per_launch, units_per_job) -- valid after sync()"""
         out = (ctypes.c_int64 * 6)()
         self._chk(lib().fsim_lookahead_stats(self._h, out))
-        return dict(zip(("enabled", "launched", "swapped", "inline", "pending", "inflight"), [int(x) for x in out]))
-
-    def lookahead_sync(self):
-        self._chk(lib().fsim_lookahead_sync(self._h))
+        return dict(zip(("enabled", "units", "swapped", "inline", "jobs_per_launch", "units_per_job"), [int(x) for x in out]))
 
     def set_max_episode_steps(self, n):
         self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))

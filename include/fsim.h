@@ -74,11 +74,12 @@ typedef struct fsim_config {
                                  3 all:  four waves for every env (development / tests).
                                  Within one mode env i's results depend on env i's state and actions alone: not on the batch it is in, the slab
                                  layout, other handles or timing.  Across modes they agree like two fp32 implementations.  fsim_step_kernel() reports it. */
-  int32_t lookahead_reset;    /* 1 (default): the reset of every env's NEXT episode is computed ahead of time, on a low-priority stream, from the
-                                 reset table the host has already uploaded (fsim_set_reset_tables), into a shadow record; the step / reset that ends
-                                 the episode copies it in instead of running the 301 / 401 reset substeps inside its launch.  Same code on the same
-                                 inputs: bit-identical to the in-launch reset, which remains the fallback whenever no shadow is ready.  Not used
-                                 with the arm controllers, ik / ik_quaternion, reset_robot_after_attach and multi_wave = all.  0: off. */
+  int32_t lookahead_reset;    /* 1 (default): the reset of every env's NEXT episode is computed ahead of time from the reset table the host has already
+                                 uploaded (fsim_set_reset_tables), a few dozen substeps per step launch, by the waves of that launch that have no env
+                                 left to step, into a shadow record; the step / reset that ends the episode copies it in instead of running the
+                                 301 / 401 reset substeps inside its launch.  Same loop on the same inputs: bit-identical to the in-launch reset,
+                                 which remains the fallback whenever the shadow is not complete.  Not used with the arm controllers, ik /
+                                 ik_quaternion, reset_robot_after_attach and multi_wave = all.  0: off. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -170,13 +171,11 @@ int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bf
  * host skip the scan of the info block on the (many) steps in which no episode ended. */
 int fsim_tables_needed(const fsim_t *);
 
-/* Look-ahead reset bookkeeping (fsim_config_t::lookahead_reset): out[6] = { enabled, shadow resets launched so far, resets taken from a
- * shadow record, resets executed inside a step / reset launch, envs waiting for a shadow launch, shadow launches in flight }.  The two
- * device-side counters are valid once the launches that bumped them have completed (fsim_sync).  Every reset still costs its 301 / 401
- * substeps; the counters say on which stream they ran. */
+/* Look-ahead reset bookkeeping (fsim_config_t::lookahead_reset): out[6] = { enabled, reset units (= physics substeps of a reset) run by
+ * look-ahead jobs so far, resets taken from a shadow record, resets executed inside a step / reset launch, look-ahead jobs per launch,
+ * reset units per job }.  The device-side counters are valid once the launches that bumped them have completed (fsim_sync).  Every
+ * reset still costs its 301 / 401 substeps; the counters say where they ran. */
 int fsim_lookahead_stats(fsim_t *, int64_t *out);
-/* Wait for the shadow launches in flight (tests, and callers that want the next reset to be a copy for sure).  Never needed for correctness. */
-int fsim_lookahead_sync(fsim_t *);
 
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);

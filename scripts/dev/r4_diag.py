@@ -1,0 +1,61 @@
+"""development (round 4): GPU diagnostics run by scripts/gpu_r4c.sh -- (a) which multi-wave situations abort, (b) grevback laid-out start: where device and oracle part company"""
+import os, sys, subprocess
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def ik_case(n, control, steps=3):
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type=control, furniture_name="table_lack_0825", max_episode_steps=50, seed=9), auto_reset=False)
+    env.reset()
+    rng = np.random.RandomState(2)
+    for t in range(steps):
+        env.step(rng.uniform(-1, 1, (n, env.dof)).astype(np.float32))
+        eb = env.sim.get_state("env_block")["env_block"].cpu().numpy()
+        print("  step", t, "kernel", env.sim.step_kernel, "E_NITER", eb[:, 35].tolist(), "mw_steps", eb[:, 36].tolist(), flush=True)
+    env.close()
+    print("  ok", flush=True)
+
+
+def grev():
+    from furniture_amd.envs import FurnitureSawyerEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import spread_layout
+    for name in ("bookcase_grevback_0484", "bed_dalselv_0270"):
+        m = load_compiled("Sawyer", name)
+        lay = spread_layout(m)
+        q = np.array(m.qpos0, dtype=float)
+        q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+        for p in range(m.nparts):
+            q[m.part_qposadr[p]:m.part_qposadr[p] + 7] = lay[p]
+        init = {"qpos": q, "qvel": np.zeros(m.nv)}
+        kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name=name, max_episode_steps=50, seed=3)
+        env = FurnitureSawyerEnv(make_config(**kw))
+        orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=3, solver_tolerance=1e-10))
+        env.set_init_qpos(init), orc.set_init_qpos(init)
+        orc.reset(); env.reset()
+        rng = np.random.RandomState(2)
+        rd = np.concatenate([m.arm_dofadr, m.grip_dofadr])
+        for t in range(3):
+            st = {k: v[0].cpu().numpy() for k, v in env._b.sim.get_state("qpos", "qvel", "qfrc_bias", "qfrc_applied", "ctrl").items()}
+            print(name, "before step", t, "|dq robot| %.2e |dv robot| %.2e |dbias| %.2e |dapplied| %.2e |dq all| %.2e |dv all| %.2e" % (
+                np.abs(st["qpos"][m.arm_qposadr] - orc.sim.data.qpos[m.arm_qposadr]).max(), np.abs(st["qvel"][rd] - orc.sim.data.qvel[rd]).max(),
+                np.abs(st["qfrc_bias"][rd] - orc.sim.data.qfrc_bias[rd]).max(), np.abs(st["qfrc_applied"][rd] - orc.sim.data.qfrc_applied[rd]).max(),
+                np.abs(st["qpos"] - orc.sim.data.qpos).max(), np.abs(st["qvel"] - orc.sim.data.qvel).max()), flush=True)
+            a = rng.uniform(-1, 1, 9)
+            ob, r, d, info = env.step(a)
+            ob_o, r_o, d_o, _ = orc.step(a)
+            e = np.abs(np.concatenate([ob["object_ob"], ob["robot_ob"]]) - orc.flat_obs(ob_o))
+            print("   obs err max %.2e at %d of %d; robot_ob err %s" % (e.max(), int(e.argmax()), len(e), np.array2string(e[-29:], precision=1)), "ncon oracle", len(orc.sim.contacts()), "overflow", info["contact_overflow"], flush=True)
+        env.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    if what == "ik":
+        ik_case(int(sys.argv[2]), sys.argv[3])
+    elif what == "grev":
+        grev()

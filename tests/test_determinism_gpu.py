@@ -85,7 +85,10 @@ def _run(m, mode, snap, idx, acts, other=None):
 
 
 @pytest.mark.parametrize("mode", ["off", "rule", "all"])
-def test_fsim_step_bits_depend_on_the_env_alone(sawyer_lack, mode):
+def test_fsim_step_bits_depend_on_the_env_alone(sawyer_lack, mode, monkeypatch):
+    # (the rule's threshold, 150 Newton iterations per step, lowered so that a leg held still between the fingers -- about two
+    #  iterations per substep -- already goes to the four-wave workgroups: development knob FSIM_MW_K, read by fsim_create)
+    monkeypatch.setenv("FSIM_MW_K", "60")
     m = sawyer_lack
     n, steps = 48, 6
     snap = _start_states(m, n, mode)

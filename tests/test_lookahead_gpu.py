@@ -1,6 +1,6 @@
-"""Look-ahead reset (include/fsim.h fsim_config_t::lookahead_reset, csrc/fsim.hip "look-ahead reset"): the reset of every env's next
-episode is computed ahead of time from the reset table the host has already uploaded, into a shadow record that the terminal step
-copies in.  The claim under test: the swapped-in record, observation and info words are BIT-IDENTICAL to what the reset inside the
+"""Look-ahead reset (include/fsim.h fsim_config_t::lookahead_reset, csrc/fsim.hip env_shadow_job): the reset of every env's next
+episode is computed ahead of time from the reset table the host has already uploaded -- a chunk of reset substeps per step launch, by
+waves of that launch that have no env left to step -- into a shadow record that the terminal step copies in.  The claim under test: the swapped-in record, observation and info words are BIT-IDENTICAL to what the reset inside the
 launch leaves (reference flow: furniture/env/furniture.py:1406-1663 run by the vec-env worker on `done`, util/subproc_vec_env.py:15-20),
 whether a shadow was ready or not -- i.e. the option changes when the 301 / 401 reset substeps run, never what they compute."""
 import numpy as np
@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 SNAP = ["qpos", "qvel", "qacc_warmstart", "qfrc_bias", "ctrl", "qfrc_applied", "xfrc_applied", "eq_active", "eq_data", "geom_contype", "geom_conaffinity", "group", "env_block"]
 
 
-def _make(agent, lookahead, mw, monkeypatch, n=24, steps=3, dense=False, **kw):
-    # (development knobs of the launch policy: start the shadows at once and all together, so that the short episodes of this test find them ready)
+def _make(agent, lookahead, mw, monkeypatch, n=24, steps=3, dense=False, chunk=1000, jobs=64, **kw):
+    # (development knobs of the job policy: start the shadows at once, `jobs` envs per launch, `chunk` reset substeps per job -- 1000: the
+    #  whole reset in one job, so that the short episodes of this test find the shadows complete)
     monkeypatch.setenv("FSIM_LA_DEFER", "0")
-    monkeypatch.setenv("FSIM_LA_RATE", "64")
+    monkeypatch.setenv("FSIM_LA_JOBS", str(jobs))
+    monkeypatch.setenv("FSIM_LA_CHUNK", str(chunk))
     env_id = "IKEASawyerDense-v0" if dense else {"Sawyer": "IKEASawyer-v0", "Cursor": "IKEACursor-v0", "Baxter": "IKEABaxter-v0"}[agent]
     from furniture_amd.envs import FurnitureBatchEnv, make_config, DENSE_OVERRIDES
     over = dict(DENSE_OVERRIDES) if dense else {}
@@ -35,8 +37,6 @@ def _run(env, nsteps, sync_shadows, seed=4):
     for t in range(nsteps):
         a = torch.empty((env.num_envs, env.dof), device=env.sim.device).uniform_(-1, 1, generator=g)
         ob, rew, done, info = env.step(a)
-        if sync_shadows:
-            env.sim.lookahead_sync()
         out.append({k: v.clone() for k, v in ob.items()})
         trace.append((rew.clone(), done.clone(), env._info.clone()))
     snap = {k: v.clone() for k, v in env.sim.get_state(*SNAP).items()}
@@ -65,11 +65,18 @@ def test_swapped_in_reset_is_bit_identical_to_the_reset_inside_the_step(monkeypa
     la = _run(_make("Sawyer", True, mw, monkeypatch, n, T), nsteps, True)
     st = la[3]
     assert st["enabled"] == 1 and st["swapped"] == 3 * n, st  # every auto-reset took its shadow record
-    assert st["launched"] >= 3 * n
+    assert st["units"] >= 3 * n * 401
     _same(ref, la)
-    # shadows that are NOT waited for: some resets swap, some run inside the step -- same bits either way
-    mixed = _run(_make("Sawyer", True, mw, monkeypatch, n, T), nsteps, False)
-    assert mixed[3]["swapped"] + mixed[3]["inline"] == ref[3]["inline"]
+    # the reset in PIECES (the shipped policy: 51 substeps per job, eight jobs per reset) on longer episodes ...
+    T, nsteps = 12, 26
+    ref = _run(_make("Sawyer", False, mw, monkeypatch, n, T), nsteps, False)
+    la = _run(_make("Sawyer", True, mw, monkeypatch, n, T, chunk=51), nsteps, True)
+    assert la[3]["swapped"] == 2 * n and la[3]["units_per_job"] == 51, la[3]
+    _same(ref, la)
+    # ... and with too few jobs per launch for every shadow to be complete in time: some resets swap, the others run inside the step
+    # (their half-done shadows are dropped) -- same bits either way
+    mixed = _run(_make("Sawyer", True, mw, monkeypatch, n, T, chunk=51, jobs=10), nsteps, False)
+    assert 0 < mixed[3]["swapped"] < 2 * n and mixed[3]["swapped"] + mixed[3]["inline"] == ref[3]["inline"], mixed[3]
     _same(ref, mixed)
 
 
@@ -87,7 +94,8 @@ def test_reset_call_takes_the_shadow_record_and_new_tables_void_it(monkeypatch):
     ran), and changing what a reset starts from (set_init_qpos) voids the shadows."""
     from furniture_amd.envs import FurnitureBatchEnv, make_config
     monkeypatch.setenv("FSIM_LA_DEFER", "0")
-    monkeypatch.setenv("FSIM_LA_RATE", "64")
+    monkeypatch.setenv("FSIM_LA_JOBS", "64")
+    monkeypatch.setenv("FSIM_LA_CHUNK", "1000")
     mk = lambda la: FurnitureBatchEnv("Sawyer", 6, auto_reset=False, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
                                                                                        max_episode_steps=50, seed=3, lookahead_reset=la, multi_wave="off"))
     a, b = mk(True), mk(False)
@@ -99,7 +107,6 @@ def test_reset_call_takes_the_shadow_record_and_new_tables_void_it(monkeypatch):
     for t in range(3):
         act = torch.empty((6, a.dof), device=a.sim.device).uniform_(-1, 1, generator=g)
         a.step(act), b.step(act)
-    a.sim.lookahead_sync()
     before = a.sim.lookahead_stats()
     oa, ob = a.reset(), b.reset()
     st = a.sim.lookahead_stats()
@@ -113,7 +120,6 @@ def test_reset_call_takes_the_shadow_record_and_new_tables_void_it(monkeypatch):
     init = {k: v[0].cpu().numpy() for k, v in a.sim.get_state("qpos", "qvel").items()}
     for e in (a, b):
         e.step(act)
-        e.sim.lookahead_sync()
         e.set_init_qpos(init)
     oa, ob = a.reset(), b.reset()
     for k in oa:
