@@ -111,7 +111,9 @@ struct Layout {
 enum { SC_NSURV = 0, SC_NSLOT = 1, SC_OVERFLOW = 2, SC_NITER = 3, SC_TOUCHL = 4, SC_TOUCHR = 5, SC_TOUCHF = 6, SC_NCON = 7, SC_BAD = 8,
        SC_NITSUM = 15, // Newton iterations of all solves since the launch began (env_step stores it in E_NITER)
        SC_ADJ = FSIM_SC_BASE, SC_ISL = FSIM_SC_BASE + 16, SC_TMP = FSIM_SC_BASE + 32, SC_PADJ = FSIM_SC_BASE + 64,
-       SC_HWORDS = FSIM_SC_BASE + 80, SC_TWORDS = FSIM_SC_BASE + 81, SC_WORDS = FSIM_SC_BASE + 84 };
+       SC_HWORDS = FSIM_SC_BASE + 80, SC_TWORDS = FSIM_SC_BASE + 81,
+       SC_ASM = FSIM_SC_BASE + 82, // trees of the big islands assembled on the matrix cores in this solve (fs_asm_trees; kept here, not in a register)
+       SC_WORDS = FSIM_SC_BASE + 84 };
 
 // env-logic block (word offsets relative to Layout::env)
 enum {

@@ -147,6 +147,9 @@ template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { retur
 // `row_newbcast` DPP moves.  Larger islands (a robot holding two parts, Baxter's 19-dof tree) get a contiguous lane range
 // and are factored one after the other with v_readlane broadcasts.  (fs_chol_solve, fsim_solver.hpp)
 enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP = 6 };
+#ifndef FSIM_BIG_MIN
+#define FSIM_BIG_MIN 12
+#endif
 template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl, int hwords_slot) {
   const int nv = c.D.nv, ntree = c.D.ntree;
   int *scal_ = c.I(c.ly.scal);
@@ -175,7 +178,10 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
       tmp[16 + u] = hb;
       hb += n * (n + 1) / 2;
       int row = -1;
-      if (n <= 16) {
+      // (round 4: an island of 12..16 dofs around the robot -- tree 0: the arm and the part it touches -- is a BIG island too: its
+      //  Hessian is then assembled on the matrix cores, straight into the tile that is factored (fs_newton_mfma), instead of through
+      //  the body blocks in LDS and the row phase; FSIM_BIG_MIN = 17 restores the old split)
+      if (n <= 16 && !(u == 0 && n >= FSIM_BIG_MIN)) {
         for (int r = 0; r < 4; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
         if (row < 0) for (int r = 4; r < nrow; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
       }

@@ -1048,11 +1048,7 @@ typedef __attribute__((address_space(3))) float fs_lds_f;
 // preceded by 32 words of right-hand side and 32 words of joint-limit diagonal (tile order).
 #define FS_STW 16
 #define FS_ST_HEAD 64
-template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int nst_, int stage_) {
-  float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
-  const Ctx c = fs_rebuild(cv, lds_);
-  const int mp = __builtin_amdgcn_readfirstlane(mp_), first = __builtin_amdgcn_readfirstlane(first_), n = __builtin_amdgcn_readfirstlane(n_);
-  const int nst = __builtin_amdgcn_readfirstlane(nst_), stage = __builtin_amdgcn_readfirstlane(stage_);
+template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, const int first, const int n, const int nst, const int stage) {
   float *L = c.L;
   const float *H = L + c.ly.H;
   const int nv = c.D.nv;
@@ -1112,11 +1108,12 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
     const bool valid = k < n;
     const S6 sk_ = lds6(L + c.ly.cdof + 6 * dofk);
     const int sub = valid ? KI(r_submask, KI(dof_rbody, dofk)) : 0; // bodies whose chain holds dof k
-    // joint limits: one more rank-1 term per limited dof, all of them in ONE instruction (the terms touch disjoint diagonal entries)
+    // joint limits: D e_k e_k' per limited dof -- a DIAGONAL term (as many rank-1 terms as there are active limits, so no single MFMA):
+    // entry (k, k) sits in lane k + 32 ((k >> 2) & 1), register 4 (k >> 3) + (k & 3)
     {
-      const float dl = L[stage + 32 + k];
-      const float ul = (valid && h == 0) ? __builtin_sqrtf(dl) : 0.0f;
-      D = __builtin_amdgcn_mfma_f32_32x32x2f32(ul, ul, D, 0, 0, 0);
+      const float dl = valid ? L[stage + 32 + k] : 0.0f;
+#pragma unroll
+      for (int v = 0; v < 16; v++) D[v] += (8 * (v >> 2) + 4 * h + (v & 3)) == k ? dl : 0.0f;
     }
     const float *rec = L + stage + FS_ST_HEAD + FS_STW * h;
     for (int q = 0; q < nst; q += 2) {
@@ -1154,23 +1151,54 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
   return !(dmin > 1e-30f);
 }
 
-// Stage the active contacts and joint limits of ONE big island for the assembly above.  Lane = contact slot: the world stiffness
-// K (SlotK, from this iteration's gradient pass) is factored K = G G' here -- K is positive semi-definite (the cone cost is convex)
-// and may be singular (a frictionless contact, the cone's surface): a pivot below 1e-12 of the largest diagonal entry drops its
-// column.  trees: kinematic trees of the island.  Returns the number of staged contacts (wave-uniform), -1 if they do not fit
-// (the caller then assembles this island's Hessian the LDS way).
-template <class Ctx> DEV int fs_stage_big(const Ctx &c, const SolSlot &S, const SlotK &sk, const int trees, const int stage, const int cap) {
+// cone state, world-frame stiffness K = F' Hcone F and world force of this lane's contact slot (what fs_gradient computes on its way)
+DEV SlotK fs_slot_k(const SolSlot &S, V3 *Fw) {
+  SlotK sk;
+  sk.on = false;
+  sk.zone = 0;
+  for (int q = 0; q < 6; q++) sk.K[q] = 0;
+  *Fw = v3(0, 0, 0);
+  if (S.act) {
+    float f[3] = {0, 0, 0}, cc, Hc[9];
+    bool on;
+    if (S.dim1) {
+      on = S.jar[0] < 0;
+      if (on) f[0] = -S.dn * S.jar[0];
+      for (int q = 0; q < 9; q++) Hc[q] = 0;
+      Hc[0] = S.dn;
+      sk.zone = on ? 1 : 0;
+    } else { sk.zone = fs_cone(S.jar, S.dn, S.dt, S.mu, f, &cc, Hc); on = sk.zone != 0; }
+    if (on) {
+      const V3 fx = S.fx, fy = S.fy, fz = S.fz;
+      V3 w0 = fx * Hc[0] + fy * Hc[1] + fz * Hc[2], w1 = fx * Hc[3] + fy * Hc[4] + fz * Hc[5], w2 = fx * Hc[6] + fy * Hc[7] + fz * Hc[8];
+      sk.on = true;
+      sk.K[0] = fx.x * w0.x + fy.x * w1.x + fz.x * w2.x; sk.K[1] = fx.x * w0.y + fy.x * w1.y + fz.x * w2.y; sk.K[2] = fx.x * w0.z + fy.x * w1.z + fz.x * w2.z;
+      sk.K[3] = fx.y * w0.y + fy.y * w1.y + fz.y * w2.y; sk.K[4] = fx.y * w0.z + fy.y * w1.z + fz.y * w2.z; sk.K[5] = fx.z * w0.z + fy.z * w1.z + fz.z * w2.z;
+      *Fw = fx * f[0] + fy * f[1] + fz * f[2];
+    }
+  }
+  if (S.lact && S.ljar < 0) sk.zone |= 4;
+  return sk;
+}
+
+// Stage the active contacts and joint limits of ONE big island (kinematic trees `trees`) for the assembly.  Lane = contact slot: the
+// cone state is recomputed from the slot record (J a - aref has not changed since the gradient pass), the world stiffness K = F' Hcone F
+// is factored K = G G' -- K is positive semi-definite (the cone cost is convex) and may be singular (a frictionless contact, the cone's
+// surface): a pivot below 1e-6 of the largest diagonal entry drops its column (a rank-deficient K leaves rounding noise of ~1e-7 K in
+// the later pivots: not a direction).  Returns the number of staged contacts (wave-uniform).
+template <class Ctx> DEV int fs_stage_big(const Ctx &c, const SolSlot &S, const int trees, const int stage) {
   float *L = c.L;
   const int b1 = S.bt1 & 255, b2 = S.bt2 & 255;
+  V3 Fw_;
+  const SlotK sk = fs_slot_k(S, &Fw_);
   const bool mine = sk.on && ((b1 != 0 && ((trees >> (S.bt1 >> 8)) & 1)) || (b2 != 0 && ((trees >> (S.bt2 >> 8)) & 1)));
   const unsigned long long mask = __ballot(mine);
   const int nst = __popcll(mask);
-  if (nst > cap) return -1;
   if (c.lane < 32) L[stage + 32 + c.lane] = 0.0f;
   SYNC();
   if (mine) {
     const float *K = sk.K; // xx xy xz yy yz zz
-    const float big = fmaxf(fmaxf(K[0], K[3]), K[5]), eps = 1e-6f * big; // (a rank-deficient K leaves rounding noise of ~1e-7 K in the later pivots: not a direction)
+    const float big = fmaxf(fmaxf(K[0], K[3]), K[5]), eps = 1e-6f * big;
     float g00 = 0, g10 = 0, g20 = 0, g11 = 0, g21 = 0, g22 = 0;
     if (K[0] > eps) { g00 = __builtin_sqrtf(K[0]); const float r = 1.0f / g00; g10 = K[1] * r; g20 = K[2] * r; }
     const float d1 = K[3] - g10 * g10;
@@ -1187,7 +1215,39 @@ template <class Ctx> DEV int fs_stage_big(const Ctx &c, const SolSlot &S, const 
   SYNC();
   return nst;
 }
+// The two out-of-line entry points: the tile read from the packed Hessian in LDS (fs_hessian's / the integrator's), and the tile
+// assembled here from the staged contacts of the island.  (real functions: the 16-register accumulator tile must not weigh on the
+// register allocation of the substep loop, and only the env with a big island ever calls them.  The LDS base travels as a 32-bit LDS
+// address: naming the dynamic-LDS symbol inside a non-kernel function costs a table lookup -- s_getpc + s_load + wait, ~400 cycles --
+// at every use the compiler does not merge)
+template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_) {
+  float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
+  const Ctx c = fs_rebuild(cv, lds_);
+  return fs_mfma_tile_solve(c, __builtin_amdgcn_readfirstlane(mp_), __builtin_amdgcn_readfirstlane(first_), __builtin_amdgcn_readfirstlane(n_), -1, 0);
+}
+// (the staging runs inside this routine and reads this lane's constraint records from LDS again, where fs_load_slots found them; the
+//  four numbers that live in registers alone -- the slot's J a - aref and the limit's -- are parked in record words nobody reads any more
+//  during the solve (C_AREF: in SolSlot::aref since the solve began; LM_JAR) by fs_park_jar.  With the staging code in the substep loop,
+//  or its inputs as VGPR arguments, that loop's register allocation went from 14 spill instructions to 34-70, ten to twenty reloads
+//  per substep, and the benchmark lost 7 %)
+template <class Ctx> __device__ __noinline__ int fs_newton_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int trees_) {
+  float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
+  const Ctx c = fs_rebuild(cv, lds_);
+  const int stage = c.ly.hA;
+  SolSlot S = fs_load_slots(c);
+  for (int a = 0; a < 3; a++) S.jar[a] = S.aref[a]; // (parked there by fs_park_jar)
+  S.ljar = c.L[c.ly.lim + FSIM_LIMW * min(c.lane, max(2 * c.D.nlim - 1, 0)) + LM_JAR];
+  const int nst = fs_stage_big(c, S, __builtin_amdgcn_readfirstlane(trees_), stage);
+  return fs_mfma_tile_solve(c, __builtin_amdgcn_readfirstlane(mp_), __builtin_amdgcn_readfirstlane(first_), __builtin_amdgcn_readfirstlane(n_), nst, stage);
+}
 
+template <class Ctx> DEV void fs_park_jar(const Ctx &c, const SolSlot &S) {
+  const int sc = min(c.lane, c.ly.ncon_max - 1), sl = min(c.lane, max(2 * c.D.nlim - 1, 0));
+  float *r = c.L + c.ly.con + FSIM_CONW * sc;
+  if (c.lane < c.ly.ncon_max) { r[C_AREF] = S.jar[0]; r[C_AREF + 1] = S.jar[1]; r[C_AREF + 2] = S.jar[2]; }
+  if (c.lane < 2 * c.D.nlim) c.L[c.ly.lim + FSIM_LIMW * sl + LM_JAR] = S.ljar;
+  SYNC();
+}
 // Which big islands of this solve have their Hessian assembled on the matrix cores (fs_chol_mfma, nst >= 0): those whose constraint-
 // active contacts fit the staging area -- decided ONCE per solve on the slots that are active constraints at all (the cone zones, hence
 // the contacts that actually contribute, change from iteration to iteration; the bound does not), so that the set of trees the LDS
@@ -1268,9 +1328,9 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
 // am (-1: every island): trees of the islands that take a step (fs_active_islands).  Lanes of the others act as empty lanes (unit
 // diagonal) and set p = 0, the row phase only runs as many pivots as the last moving lane needs, a big island that does not move is skipped.
-// asm_ok / S / sk: trees of the big islands whose Hessian is assembled on the matrix cores (fs_asm_trees), with this lane's slot records
-// and this iteration's cone state (Newton solve only; 0 / null: every tile is read from the packed Hessian in LDS)
-template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1, const int asm_ok = 0, const SolSlot *S = nullptr, const SlotK *sk = nullptr) {
+// asm_ok / S: trees of the big islands whose Hessian is assembled on the matrix cores (fs_asm_trees), with this lane's slot records
+// (Newton solve only; 0 / null: every tile is read from the packed Hessian in LDS)
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1, const int asm_ok = 0, const SolSlot *S = nullptr) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
@@ -1322,12 +1382,12 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am =
         if (asm_ok) {
           const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
           if (trees & asm_ok) {
-            const int nst = fs_stage_big(c, *S, *sk, trees, c.ly.hA, 1 << 30);
-            bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, nst, c.ly.hA);
+            fs_park_jar(c, *S);
+            bad |= fs_newton_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, trees);
             continue;
           }
         }
-        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, -1, 0);
+        bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
       }
     }
   }
@@ -1358,36 +1418,6 @@ template <class Ctx> DEV void mw_post(const Ctx &c, int cmd) { // main wave only
   const int k = w[MWC_SEQ];
   if (c.lane == 0) { w[k & 1] = cmd; w[MWC_SEQ] = k + 1; }
   c.xbar();
-}
-
-// cone state, world-frame stiffness K = F' Hcone F and world force of this lane's contact slot (what fs_gradient computes on its way)
-DEV SlotK fs_slot_k(const SolSlot &S, V3 *Fw) {
-  SlotK sk;
-  sk.on = false;
-  sk.zone = 0;
-  for (int q = 0; q < 6; q++) sk.K[q] = 0;
-  *Fw = v3(0, 0, 0);
-  if (S.act) {
-    float f[3] = {0, 0, 0}, cc, Hc[9];
-    bool on;
-    if (S.dim1) {
-      on = S.jar[0] < 0;
-      if (on) f[0] = -S.dn * S.jar[0];
-      for (int q = 0; q < 9; q++) Hc[q] = 0;
-      Hc[0] = S.dn;
-      sk.zone = on ? 1 : 0;
-    } else { sk.zone = fs_cone(S.jar, S.dn, S.dt, S.mu, f, &cc, Hc); on = sk.zone != 0; }
-    if (on) {
-      const V3 fx = S.fx, fy = S.fy, fz = S.fz;
-      V3 w0 = fx * Hc[0] + fy * Hc[1] + fz * Hc[2], w1 = fx * Hc[3] + fy * Hc[4] + fz * Hc[5], w2 = fx * Hc[6] + fy * Hc[7] + fz * Hc[8];
-      sk.on = true;
-      sk.K[0] = fx.x * w0.x + fy.x * w1.x + fz.x * w2.x; sk.K[1] = fx.x * w0.y + fy.x * w1.y + fz.x * w2.y; sk.K[2] = fx.x * w0.z + fy.x * w1.z + fz.x * w2.z;
-      sk.K[3] = fx.y * w0.y + fy.y * w1.y + fz.y * w2.y; sk.K[4] = fx.y * w0.z + fy.y * w1.z + fz.y * w2.z; sk.K[5] = fx.z * w0.z + fy.z * w1.z + fz.z * w2.z;
-      *Fw = fx * f[0] + fy * f[1] + fz * f[2];
-    }
-  }
-  if (S.lact && S.ljar < 0) sk.zone |= 4;
-  return sk;
 }
 
 // zero the Hessian work array THIS helper wave fills next (no barrier between the zeroing and the wave's own atomics): helper 1
@@ -1686,7 +1716,7 @@ template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp, const int am) {
   else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   if (__ballot(bad != 0) && c.lane == 0) c.I(c.ly.mwc)[MWC_BAD] = 1;
 }
-template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, const int asm_ok, const SolSlot &S, const SlotK &sk) {
+template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, const int asm_ok, const SolSlot &S) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
@@ -1704,12 +1734,12 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, con
       if (asm_ok) {
         const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
         if (trees & asm_ok) {
-          const int nst = fs_stage_big(c, S, sk, trees, c.ly.hA, 1 << 30);
-          bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, nst, c.ly.hA);
+          fs_park_jar(c, S);
+          bad |= fs_newton_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, trees);
           continue;
         }
       }
-      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, -1, 0);
+      bad |= fs_chol_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n);
     }
   }
   return wave_or(bad);
@@ -1729,6 +1759,14 @@ template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
     else if (cmd == MW_CHOL) { if (c.wave == 1) mw_chol_rows(c, c.ly.hmap, __builtin_amdgcn_readfirstlane(w[MWC_AM])); }
     else if (cmd == MW_MULM) { if (c.wave == 1) fs_mulM(c, __builtin_amdgcn_readfirstlane(w[MWC_A0]), __builtin_amdgcn_readfirstlane(w[MWC_A1])); }
   }
+}
+
+// The helper waves' loop as a REAL function: inlined into k_env_step_x it shared one register allocation with the kernel's two env
+// loops and the look-ahead job (63 k instructions, 3 092 scratch instructions in the kernel body, against 1 008 in round 3), and what the
+// helpers run -- the collision pipeline, the Hessian blocks, the row factorisation -- is per-substep code.
+template <class Ctx> static __device__ __noinline__ void mw_helper_fn(Ctx cv) {
+  FS_REBUILD_CTX(cv);
+  mw_helper_loop(c);
 }
 
 template <class Ctx> DEV float fs_dotv(const Ctx &c, int a, int b) {
@@ -1792,8 +1830,13 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     }
   }
   // big islands whose Hessian is assembled on the matrix cores, straight into the tile the factorisation works on (fs_chol_mfma)
-  const int asm_ok = fs_asm_trees(c, S);
-  if constexpr (Ctx::NW > 1) { if (mw && c.lane == 0) c.I(c.ly.mwc)[MWC_ASM] = asm_ok; }
+  // (kept in an LDS scalar and read back where it is used: one more value alive across the whole Newton loop cost the substep loop
+  //  ten spill reloads per substep)
+  {
+    const int asm_set = fs_asm_trees(c, S);
+    if (c.lane == 0) { scal[SC_ASM] = asm_set; if constexpr (Ctx::NW > 1) { if (mw) c.I(c.ly.mwc)[MWC_ASM] = asm_set; } }
+    SYNC();
+  }
   for (; it < c.newton_maxit; it++) {
     SlotK sk, skT = {};
     bool ok;
@@ -1802,6 +1845,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       iterated = true;
       bool go;
       int am;
+      const int asm_ok = __builtin_amdgcn_readfirstlane(scal[SC_ASM]);
       mw_iterate_main(c, S, sk, scale, &go, &am, asm_ok);
       FS_SPROF(24);
       if (!go) break;
@@ -1811,12 +1855,12 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       if (nbig > 0 && rsteps > 0) { // the DPP rows on helper 1 beside the big island(s) here
         if (c.lane == 0) w[MWC_BAD] = 0;
         mw_post(c, MW_CHOL);
-        const int bad = mw_chol_big(c, c.ly.hmap, am, asm_ok, S, sk);
+        const int bad = mw_chol_big(c, c.ly.hmap, am, asm_ok, S);
         mw_post(c, MW_IDLE);
         ok = !(bad | __builtin_amdgcn_readfirstlane(w[MWC_BAD]));
       } else {
         mw_post(c, MW_IDLE); // (helper 1 is still adding the body-pair entries)
-        ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S, &sk);
+        ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S);
       }
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
@@ -1836,10 +1880,11 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       FS_SPROF(23);
       if (scale * gn < c.newton_tol) break;
       // (the LDS assembly serves the islands the matrix cores do not take: none at all when a robot island is all that still moves)
+      const int asm_ok = __builtin_amdgcn_readfirstlane(scal[SC_ASM]);
       if (!asm_ok || (am & ~asm_ok)) fs_hessian(c, sk, S, am & ~asm_ok);
       if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
       FS_SPROF(24);
-      ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S, &sk);
+      ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S);
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
       fs_mulM(c, c.ly.Mp, c.ly.p);

@@ -73,7 +73,7 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
         len(ran), sum(load_compiled("Sawyer", x).nv > 64 for x in ran), len(refused), refused, unplaceable))
     print("overflowed or failed (name, parts, fail | overflow << 1):", troubled)
     # two models do not fit even 128 slots: bookcase_billy_0191 (11 planks) and table_liden_0921 (12 parts) pass through 230-250
-    # simultaneous contacts while the reset settles them (counted with the oracle); their steps raise ContactOverflowError
+    # simultaneous contacts while the reset settles them (counted with the oracle); their resets raise ContactOverflowError
     assert refused == [] and sorted(x[0] for x in troubled) == ["bookcase_billy_0191", "table_liden_0921"], (refused, troubled)
     assert sorted(unplaceable) == ["bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"], unplaceable
     assert len(ran) == len(names) - 5
@@ -102,10 +102,14 @@ def test_a_model_with_more_than_64_dofs_matches_the_oracle_env():
     env.close()
 
 
-def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_steps():
+def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_steps(monkeypatch):
     """config.assembled switches every weld on (furniture.py:1502-1503): the weld ids go to the device as they are -- furniture whose
-    recipe has fewer steps than the model has welds (bench_bjursta_0210: 8 welds, 4 steps) used to die in the constructor."""
+    recipe has fewer steps than the model has welds (bench_bjursta_0210: 8 welds, 4 steps) used to die in the constructor.
+    (The welds pull the parts -- started at the XML's poses -- together in a violent transient that runs through more simultaneous
+    contacts than the slots hold on some models: reported by reset() since the overflow flag is sticky; downgraded to a warning here,
+    the test is about construction and weld activity.)"""
     from furniture_amd.envs import make_vec_env
+    monkeypatch.setenv("FSIM_ALLOW_OVERFLOW", "1")
     from furniture_amd.mjcf.model import load_compiled
     for name in ("bench_bjursta_0210", "chair_ingolf_0650", "table_bjorkudden_0207", "table_lack_0825"):
         m = load_compiled("Sawyer", name)
