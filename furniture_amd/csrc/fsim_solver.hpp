@@ -1077,19 +1077,19 @@ template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, cons
   }
   } else {
     // M's block of the island, from the tree-packed triangles of M: entry (i, k) exists iff the two dofs belong to one kinematic tree.
-    // This lane's column word: packed row base of dof k in M (12 bits) | its index inside its tree (6) << 12 | its tree (4) << 18; the
-    // row's word comes from lane i (rows and columns are the same dofs), i = i0 + 4 h with i0 a compile-time constant
+    // The tile's columns are the island's dofs tree by tree, so the tree of column k occupies the tile indices [k - lk, k - lk + nk)
+    // (lk: index of dof k inside its tree, nk: the tree's size -- both in the dof's word of the tree map), and row i = i0 + 4 h with
+    // i0 a compile-time constant: no cross-lane traffic, a handful of integer instructions per entry
     const int Tk = c.I(c.ly.k_tmap)[dofk];
-    const int Pk = (Tk & 0x3ffff) | (KI(dof_tree, dofk) << 18);
-    const int lk = (Pk >> 12) & 63, rbk = Pk & 0xfff;
+    const int rbk = Tk & 0xfff, lk = (Tk >> 12) & 63, nk = (Tk >> 18) & 127, lock = k - lk, hbk = rbk - lk * (lk + 1) / 2;
 #pragma unroll
     for (int v = 0; v < 16; v++) {
       const int i0 = 8 * (v >> 2) + (v & 3);
-      const int P0 = __builtin_amdgcn_readlane(Pk, i0), P1 = __builtin_amdgcn_readlane(Pk, i0 + 4);
-      const int Pi = h ? P1 : P0, li = (Pi >> 12) & 63;
-      const bool same = ((Pi ^ Pk) >> 18) == 0;
-      const int idx = li >= lk ? (Pi & 0xfff) + lk : rbk + li;
-      const float mv = L[c.ly.M + idx]; // (unconditional: the index is inside M whatever the pair of dofs)
+      const int li = i0 + 4 * h - lock;
+      const bool same = (unsigned)li < (unsigned)nk;
+      const int lic = same ? li : 0; // (clamped: the index stays inside M whatever the row)
+      const int idx = lic >= lk ? hbk + lic * (lic + 1) / 2 + lk : rbk + lic;
+      const float mv = L[c.ly.M + idx];
       eH[v] = same ? mv : 0.0f;
       eR[v] = rhs[i0 + 4 * h];
     }
@@ -1115,20 +1115,36 @@ template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, cons
 #pragma unroll
       for (int v = 0; v < 16; v++) D[v] += (8 * (v >> 2) + 4 * h + (v & 3)) == k ? dl : 0.0f;
     }
+    // two accumulator tiles (this routine has the registers): the three rank-1 terms of a pair of contacts alternate between them, so
+    // an MFMA never waits for the one before it; the NEXT pair's record is fetched before this pair's arithmetic (one LDS round trip
+    // per pair would otherwise sit in front of every iteration: a lone wave has nothing else to hide it behind)
+    fs_f16v D2;
+#pragma unroll
+    for (int v = 0; v < 16; v++) D2[v] = 0.0f;
     const float *rec = L + stage + FS_ST_HEAD + FS_STW * h;
+    float w[13];
+#pragma unroll
+    for (int t = 0; t < 13; t++) w[t] = rec[t];
+#pragma unroll 1
     for (int q = 0; q < nst; q += 2) {
-      const float *r = rec + FS_STW * q;
-      const V3 r1 = ldv3(r), r2 = ldv3(r + 3);
-      const float g00 = r[6], g10 = r[7], g11 = r[8], g20 = r[9], g21 = r[10], g22 = r[11];
-      const int bb = __float_as_int(r[12]);
+      float wn[13];
+      const float *rn = rec + FS_STW * min(q + 2, nst - 1); // (the last trip re-reads a record it does not use)
+#pragma unroll
+      for (int t = 0; t < 13; t++) wn[t] = rn[t];
+      const V3 r1 = v3(w[0], w[1], w[2]), r2 = v3(w[3], w[4], w[5]);
+      const int bb = __float_as_int(w[12]);
       const bool in1 = (sub >> (bb & 255)) & 1, in2 = (sub >> ((bb >> 8) & 255)) & 1;
       const V3 v1 = sk_.l + cross(sk_.a, r1), v2 = sk_.l + cross(sk_.a, r2);
       const V3 vv = (in2 ? v2 : v3(0, 0, 0)) - (in1 ? v1 : v3(0, 0, 0));
-      const float u0 = g00 * vv.x + g10 * vv.y + g20 * vv.z, u1 = g11 * vv.y + g21 * vv.z, u2 = g22 * vv.z;
+      const float u0 = w[6] * vv.x + w[7] * vv.y + w[9] * vv.z, u1 = w[8] * vv.y + w[10] * vv.z, u2 = w[11] * vv.z; // u = G' v
       D = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, u0, D, 0, 0, 0);
-      D = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, u1, D, 0, 0, 0);
+      D2 = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, u1, D2, 0, 0, 0);
       D = __builtin_amdgcn_mfma_f32_32x32x2f32(u2, u2, D, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 13; t++) w[t] = wn[t];
     }
+#pragma unroll
+    for (int v = 0; v < 16; v++) D[v] += D2[v];
   }
 #pragma unroll
   for (int v = 0; v < 16; v++) {
@@ -1181,37 +1197,62 @@ DEV SlotK fs_slot_k(const SolSlot &S, V3 *Fw) {
   return sk;
 }
 
-// Stage the active contacts and joint limits of ONE big island (kinematic trees `trees`) for the assembly.  Lane = contact slot: the
-// cone state is recomputed from the slot record (J a - aref has not changed since the gradient pass), the world stiffness K = F' Hcone F
-// is factored K = G G' -- K is positive semi-definite (the cone cost is convex) and may be singular (a frictionless contact, the cone's
+// What the gradient pass leaves for the assembly (fs_stage_k, called by the Newton loop once the iteration is known to go on): this
+// lane's world stiffness K = F' Hcone F -- zero unless the slot is an active constraint in an active cone zone -- in the six record
+// words behind C_G2 (C_AREF .. C_DT and the pad: all of them in SolSlot registers since the solve began, rewritten by the next
+// substep's constraint assembly), and the limit's J a - aref in LM_JAR.  Six plain LDS stores per iteration; the cone state is NOT
+// recomputed by the assembly, and nothing travels as an argument (with the staging code in the substep loop, or its inputs as VGPR
+// arguments, that loop's register allocation went from 14 spill instructions to 34-70, ten to twenty reloads per substep: -7 %).
+#define C_KW C_AREF
+template <class Ctx> DEV void fs_stage_k(const Ctx &c, const SolSlot &S, const SlotK &sk) {
+  // (the lane index goes through an opaque copy: the record addresses are functions of the lane alone, and the compiler otherwise hoists
+  //  the two 64-bit pointers to the top of the substep routine and keeps them alive -- spilled -- across the whole loop)
+  int ln = c.lane;
+  asm volatile("" : "+v"(ln));
+  float *r = c.L + c.ly.con + FSIM_CONW * min(ln, c.ly.ncon_max - 1) + C_KW;
+  if (ln < c.ly.ncon_max) { r[0] = sk.K[0]; r[1] = sk.K[1]; r[2] = sk.K[2]; r[3] = sk.K[3]; r[4] = sk.K[4]; r[5] = sk.K[5]; }
+  if (ln < 2 * c.D.nlim) c.L[c.ly.lim + FSIM_LIMW * ln + LM_JAR] = S.ljar;
+  SYNC();
+}
+// Stage the active contacts and joint limits of ONE big island (kinematic trees `trees`) for the assembly.  Lane = contact slot: K is
+// factored K = G G' -- positive semi-definite (the cone cost is convex), possibly singular (a frictionless contact, the cone's
 // surface): a pivot below 1e-6 of the largest diagonal entry drops its column (a rank-deficient K leaves rounding noise of ~1e-7 K in
 // the later pivots: not a direction).  Returns the number of staged contacts (wave-uniform).
-template <class Ctx> DEV int fs_stage_big(const Ctx &c, const SolSlot &S, const int trees, const int stage) {
+template <class Ctx> DEV int fs_stage_big(const Ctx &c, const int trees, const int stage) {
+  static_assert(C_KW + 6 <= FSIM_CONW && C_KW > C_G2, "the stiffness words lie behind the geom ids");
   float *L = c.L;
-  const int b1 = S.bt1 & 255, b2 = S.bt2 & 255;
-  V3 Fw_;
-  const SlotK sk = fs_slot_k(S, &Fw_);
-  const bool mine = sk.on && ((b1 != 0 && ((trees >> (S.bt1 >> 8)) & 1)) || (b2 != 0 && ((trees >> (S.bt2 >> 8)) & 1)));
+  const int nslot = c.I(c.ly.scal)[SC_NSLOT];
+  const float *r = L + c.ly.con + FSIM_CONW * min(c.lane, c.ly.ncon_max - 1);
+  const int *ri = reinterpret_cast<const int *>(r);
+  const float K[6] = {r[C_KW], r[C_KW + 1], r[C_KW + 2], r[C_KW + 3], r[C_KW + 4], r[C_KW + 5]};
+  const int bt1 = ri[C_B1], bt2 = ri[C_B2], b1 = bt1 & 255, b2 = bt2 & 255;
+  const V3 pos = ldv3(r + C_POS);
+  const V3 r1 = pos - ldv3(L + c.ly.com + 3 * (bt1 >> 8)), r2 = pos - ldv3(L + c.ly.com + 3 * (bt2 >> 8));
+  const bool on = c.lane < nslot && ri[C_ACTIVE] == 1 && K[0] + K[3] + K[5] > 0.0f;
+  const bool mine = on && ((b1 != 0 && ((trees >> (bt1 >> 8)) & 1)) || (b2 != 0 && ((trees >> (bt2 >> 8)) & 1)));
   const unsigned long long mask = __ballot(mine);
   const int nst = __popcll(mask);
   if (c.lane < 32) L[stage + 32 + c.lane] = 0.0f;
   SYNC();
   if (mine) {
-    const float *K = sk.K; // xx xy xz yy yz zz
     const float big = fmaxf(fmaxf(K[0], K[3]), K[5]), eps = 1e-6f * big;
     float g00 = 0, g10 = 0, g20 = 0, g11 = 0, g21 = 0, g22 = 0;
-    if (K[0] > eps) { g00 = __builtin_sqrtf(K[0]); const float r = 1.0f / g00; g10 = K[1] * r; g20 = K[2] * r; }
+    if (K[0] > eps) { g00 = __builtin_sqrtf(K[0]); const float q = 1.0f / g00; g10 = K[1] * q; g20 = K[2] * q; }
     const float d1 = K[3] - g10 * g10;
     if (d1 > eps) { g11 = __builtin_sqrtf(d1); g21 = (K[4] - g20 * g10) / g11; }
     const float d2 = K[5] - g20 * g20 - g21 * g21;
     if (d2 > eps) g22 = __builtin_sqrtf(d2);
-    float *r = L + stage + FS_ST_HEAD + FS_STW * __popcll(mask & ((1ull << c.lane) - 1ull));
-    stv3(r, S.r1); stv3(r + 3, S.r2);
-    r[6] = g00; r[7] = g10; r[8] = g11; r[9] = g20; r[10] = g21; r[11] = g22;
-    r[12] = __int_as_float(b1 | (b2 << 8));
+    float *w = L + stage + FS_ST_HEAD + FS_STW * __popcll(mask & ((1ull << c.lane) - 1ull));
+    stv3(w, r1); stv3(w + 3, r2);
+    w[6] = g00; w[7] = g10; w[8] = g11; w[9] = g20; w[10] = g21; w[11] = g22;
+    w[12] = __int_as_float(b1 | (b2 << 8));
   }
   if ((nst & 1) && c.lane < FS_STW) L[stage + FS_ST_HEAD + FS_STW * nst + c.lane] = 0.0f; // (the odd contact's partner: G = 0, bodies 0)
-  if (S.lact && S.ljar < 0 && ((trees >> KI(dof_tree, S.ldof)) & 1)) atomicAdd(L + stage + 32 + ((c.I(c.ly.hmap)[S.ldof] >> 12) & 63), S.ld);
+  if (c.lane < 2 * c.D.nlim) {
+    const float *q = L + c.ly.lim + FSIM_LIMW * c.lane;
+    const int *qi = reinterpret_cast<const int *>(q);
+    if (qi[LM_ACTIVE] != 0 && q[LM_JAR] < 0 && ((trees >> KI(dof_tree, qi[LM_DOF])) & 1)) atomicAdd(L + stage + 32 + ((c.I(c.ly.hmap)[qi[LM_DOF]] >> 12) & 63), q[LM_D]);
+  }
   SYNC();
   return nst;
 }
@@ -1225,29 +1266,14 @@ template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned l
   const Ctx c = fs_rebuild(cv, lds_);
   return fs_mfma_tile_solve(c, __builtin_amdgcn_readfirstlane(mp_), __builtin_amdgcn_readfirstlane(first_), __builtin_amdgcn_readfirstlane(n_), -1, 0);
 }
-// (the staging runs inside this routine and reads this lane's constraint records from LDS again, where fs_load_slots found them; the
-//  four numbers that live in registers alone -- the slot's J a - aref and the limit's -- are parked in record words nobody reads any more
-//  during the solve (C_AREF: in SolSlot::aref since the solve began; LM_JAR) by fs_park_jar.  With the staging code in the substep loop,
-//  or its inputs as VGPR arguments, that loop's register allocation went from 14 spill instructions to 34-70, ten to twenty reloads
-//  per substep, and the benchmark lost 7 %)
 template <class Ctx> __device__ __noinline__ int fs_newton_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int trees_) {
   float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
   const Ctx c = fs_rebuild(cv, lds_);
   const int stage = c.ly.hA;
-  SolSlot S = fs_load_slots(c);
-  for (int a = 0; a < 3; a++) S.jar[a] = S.aref[a]; // (parked there by fs_park_jar)
-  S.ljar = c.L[c.ly.lim + FSIM_LIMW * min(c.lane, max(2 * c.D.nlim - 1, 0)) + LM_JAR];
-  const int nst = fs_stage_big(c, S, __builtin_amdgcn_readfirstlane(trees_), stage);
+  const int nst = fs_stage_big(c, __builtin_amdgcn_readfirstlane(trees_), stage);
   return fs_mfma_tile_solve(c, __builtin_amdgcn_readfirstlane(mp_), __builtin_amdgcn_readfirstlane(first_), __builtin_amdgcn_readfirstlane(n_), nst, stage);
 }
 
-template <class Ctx> DEV void fs_park_jar(const Ctx &c, const SolSlot &S) {
-  const int sc = min(c.lane, c.ly.ncon_max - 1), sl = min(c.lane, max(2 * c.D.nlim - 1, 0));
-  float *r = c.L + c.ly.con + FSIM_CONW * sc;
-  if (c.lane < c.ly.ncon_max) { r[C_AREF] = S.jar[0]; r[C_AREF + 1] = S.jar[1]; r[C_AREF + 2] = S.jar[2]; }
-  if (c.lane < 2 * c.D.nlim) c.L[c.ly.lim + FSIM_LIMW * sl + LM_JAR] = S.ljar;
-  SYNC();
-}
 // Which big islands of this solve have their Hessian assembled on the matrix cores (fs_chol_mfma, nst >= 0): those whose constraint-
 // active contacts fit the staging area -- decided ONCE per solve on the slots that are active constraints at all (the cone zones, hence
 // the contacts that actually contribute, change from iteration to iteration; the bound does not), so that the set of trees the LDS
@@ -1328,9 +1354,9 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
 // am (-1: every island): trees of the islands that take a step (fs_active_islands).  Lanes of the others act as empty lanes (unit
 // diagonal) and set p = 0, the row phase only runs as many pivots as the last moving lane needs, a big island that does not move is skipped.
-// asm_ok / S: trees of the big islands whose Hessian is assembled on the matrix cores (fs_asm_trees), with this lane's slot records
-// (Newton solve only; 0 / null: every tile is read from the packed Hessian in LDS)
-template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1, const int asm_ok = 0, const SolSlot *S = nullptr) {
+// asm_ok: trees of the big islands whose Hessian is assembled on the matrix cores (fs_asm_trees; their contacts' stiffness staged by
+// fs_stage_k) (Newton solve only; 0 / null: every tile is read from the packed Hessian in LDS)
+template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am = -1, const int asm_ok = 0) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int lw = c.I(mp)[nv + c.lane];
@@ -1382,7 +1408,6 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am =
         if (asm_ok) {
           const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
           if (trees & asm_ok) {
-            fs_park_jar(c, *S);
             bad |= fs_newton_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, trees);
             continue;
           }
@@ -1716,7 +1741,7 @@ template <class Ctx> DEV void mw_chol_rows(const Ctx &c, int mp, const int am) {
   else bad |= fs_chol_phase<16>(c, mp, dof, c.lane & 15, rsteps, RowBcast());
   if (__ballot(bad != 0) && c.lane == 0) c.I(c.ly.mwc)[MWC_BAD] = 1;
 }
-template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, const int asm_ok, const SolSlot &S) {
+template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, const int asm_ok) {
   const int nv = c.D.nv;
   const int *tail = c.I(mp) + nv + 64;
   const int nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]), maxbig = __builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]);
@@ -1734,7 +1759,6 @@ template <class Ctx> DEV int mw_chol_big(const Ctx &c, int mp, const int am, con
       if (asm_ok) {
         const int trees = __builtin_amdgcn_readfirstlane(c.I(c.ly.scal)[SC_ISL + KI(dof_tree, __builtin_amdgcn_readfirstlane((c.I(mp)[nv + first] >> 8) & 255))]);
         if (trees & asm_ok) {
-          fs_park_jar(c, S);
           bad |= fs_newton_mfma(c, (unsigned)(size_t)(fs_lds_f *)c.wg_lds(), mp, first, n, trees);
           continue;
         }
@@ -1849,18 +1873,19 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       mw_iterate_main(c, S, sk, scale, &go, &am, asm_ok);
       FS_SPROF(24);
       if (!go) break;
+      if (asm_ok) fs_stage_k(c, S, sk);
       int *w = c.I(c.ly.mwc);
       const int *tail = c.I(c.ly.hmap) + c.D.nv + 64;
       const int rsteps = __builtin_amdgcn_readfirstlane(tail[MAP_RSTEPS]) & 255, nbig = __builtin_amdgcn_readfirstlane(tail[MAP_NBIG]);
       if (nbig > 0 && rsteps > 0) { // the DPP rows on helper 1 beside the big island(s) here
         if (c.lane == 0) w[MWC_BAD] = 0;
         mw_post(c, MW_CHOL);
-        const int bad = mw_chol_big(c, c.ly.hmap, am, asm_ok, S);
+        const int bad = mw_chol_big(c, c.ly.hmap, am, asm_ok);
         mw_post(c, MW_IDLE);
         ok = !(bad | __builtin_amdgcn_readfirstlane(w[MWC_BAD]));
       } else {
         mw_post(c, MW_IDLE); // (helper 1 is still adding the body-pair entries)
-        ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S);
+        ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok);
       }
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
@@ -1881,10 +1906,11 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       if (scale * gn < c.newton_tol) break;
       // (the LDS assembly serves the islands the matrix cores do not take: none at all when a robot island is all that still moves)
       const int asm_ok = __builtin_amdgcn_readfirstlane(scal[SC_ASM]);
+      if (asm_ok) fs_stage_k(c, S, sk);
       if (!asm_ok || (am & ~asm_ok)) fs_hessian(c, sk, S, am & ~asm_ok);
       if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
       FS_SPROF(24);
-      ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok, &S);
+      ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok);
       FS_SPROF(25);
       if (!ok) { if (c.lane == 0) scal[SC_BAD] |= 1; break; }
       fs_mulM(c, c.ly.Mp, c.ly.p);

@@ -86,17 +86,18 @@ def _run(m, mode, snap, idx, acts, other=None):
 
 @pytest.mark.parametrize("mode", ["off", "rule", "all"])
 def test_fsim_step_bits_depend_on_the_env_alone(sawyer_lack, mode, monkeypatch):
-    # (the rule's threshold, 150 Newton iterations per step, lowered so that a leg held still between the fingers -- about two
-    #  iterations per substep -- already goes to the four-wave workgroups: development knob FSIM_MW_K, read by fsim_create)
-    monkeypatch.setenv("FSIM_MW_K", "60")
+    # (the rule's threshold, 150 Newton iterations per step, lowered so that any env whose solver took one extra iteration in a step
+    #  goes to the four-wave workgroups in the next one: development knob FSIM_MW_K, read by fsim_create.  Which envs do depends on
+    #  their states -- exactly what must not depend on the batch)
+    monkeypatch.setenv("FSIM_MW_K", "51")
     m = sawyer_lack
     n, steps = 48, 6
     snap = _start_states(m, n, mode)
     acts = _actions(n, steps, 9)
     whole = _run(m, mode, snap, np.arange(n), acts)
     mw_steps = whole[2]["env_block"][:, E_MW_STEPS].cpu().numpy()
-    if mode == "rule":  # the gripping envs did go through the four-wave workgroups, the others did not
-        assert mw_steps[0::3].sum() > 0 and mw_steps.max() < steps, mw_steps
+    if mode == "rule":  # some envs did go through the four-wave workgroups on some steps (never on the first: no history yet)
+        assert mw_steps.sum() > 0 and mw_steps.max() < steps and (mw_steps == 0).any(), mw_steps
     elif mode == "all":
         assert (mw_steps == steps).all()
     else:
