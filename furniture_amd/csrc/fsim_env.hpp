@@ -236,13 +236,24 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
 //   controller runs before every substep (_do_controller_step, furniture.py:3065-3093); pass -1 is the sim.forward() that
 //   precedes the loop, whose results the first _pre_action reads.
 template <bool CTRL, class Ctx> static __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
+#ifdef FSIM_OPAQUE_LANE
+  // (development: the lane index is re-read through an opaque copy at the top of every substep, so that the per-lane address
+  //  arithmetic of the pass cannot be hoisted out of the loop -- hoisted, those values live across the whole loop and some are spilled)
+  extern __shared__ float fs_lds_[];
+  Ctx c0_ = fs_rebuild(cv, fs_lds_);
+#define FS_LOOP_CTX() { int ln_ = c0_.lane; asm volatile("" : "+v"(ln_)); c0_.lane = ln_; }
+  const Ctx &c = c0_;
+#else
   FS_REBUILD_CTX(cv);
+#define FS_LOOP_CTX() do { } while (0)
+#endif
   const int n = __builtin_amdgcn_readfirstlane(n_), mode = __builtin_amdgcn_readfirstlane(mode_);
   // (ONE inlined copy of the forward pass: the forward-only mode leaves the loop after its first pass -- with a call site of its
   //  own the 18 k-instruction body sat in this function twice)
   const bool fwd_only = mode & 1;
 #pragma unroll 1
   for (int s = CTRL ? -1 : 0; fwd_only || s < n; s++) {
+    FS_LOOP_CTX();
     if (CTRL && s >= 0 && !fwd_only) fs_controller(c, s == 0);
     fs_forward_body(c);
     if (fwd_only) {

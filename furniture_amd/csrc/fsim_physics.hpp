@@ -147,8 +147,14 @@ template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { retur
 // `row_newbcast` DPP moves.  Larger islands (a robot holding two parts, Baxter's 19-dof tree) get a contiguous lane range
 // and are factored one after the other with v_readlane broadcasts.  (fs_chol_solve, fsim_solver.hpp)
 enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP = 6 };
+// (FSIM_BIG_MIN: the island of the robot's tree counts as "large" from this many dofs on.  17 = only when it does not fit a DPP row;
+//  12 with the matrix-core Hessian assembly, -DFSIM_MFMA_HESSIAN, whose tile then also takes the robot + one part islands)
 #ifndef FSIM_BIG_MIN
+#ifdef FSIM_MFMA_HESSIAN
 #define FSIM_BIG_MIN 12
+#else
+#define FSIM_BIG_MIN 17
+#endif
 #endif
 template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl, int hwords_slot) {
   const int nv = c.D.nv, ntree = c.D.ntree;

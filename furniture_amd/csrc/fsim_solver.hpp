@@ -1088,7 +1088,9 @@ template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, cons
       const int li = i0 + 4 * h - lock;
       const bool same = (unsigned)li < (unsigned)nk;
       const int lic = same ? li : 0; // (clamped: the index stays inside M whatever the row)
-      const int idx = lic >= lk ? hbk + lic * (lic + 1) / 2 + lk : rbk + lic;
+      int ia = hbk + lic * (lic + 1) / 2 + lk, ib = rbk + lic;
+      asm volatile("" : "+v"(ia), "+v"(ib)); // (both candidates computed, then ONE select: behind `?:` each entry became an exec-masked block of ~20 instructions)
+      const int idx = lic >= lk ? ia : ib;
       const float mv = L[c.ly.M + idx];
       eH[v] = same ? mv : 0.0f;
       eR[v] = rhs[i0 + 4 * h];
@@ -1280,7 +1282,8 @@ template <class Ctx> __device__ __noinline__ int fs_newton_mfma(Ctx cv, unsigned
 // path leaves out is fixed for the solve.  Welds couple rows the tile assembly does not know: the solve then takes the LDS path.
 // Returns the kinematic trees of those islands (bit mask).
 template <class Ctx> DEV int fs_asm_trees(const Ctx &c, const SolSlot &S) {
-#ifdef FSIM_NO_MFMA_HESSIAN
+#ifndef FSIM_MFMA_HESSIAN
+  // (opt-in build: round-4 measurement, DESIGN.md 12.3 -- the eligible slow envs get ~10 % faster, the 4096-env step 4-8 % slower)
   return 0;
 #endif
   if (Ctx::NS != 1 || S.anyweld) return 0;

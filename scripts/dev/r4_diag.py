@@ -59,3 +59,39 @@ if __name__ == "__main__":
         ik_case(int(sys.argv[2]), sys.argv[3])
     elif what == "grev":
         grev()
+    elif what == "grevsub":
+        grev_substeps(*(sys.argv[2:3]))
+
+
+def grev_substeps(name="bookcase_grevback_0484", nsub=60):
+    """device fsim_physics_step(1) vs OracleSim.step() from the laid-out start, substep by substep: which dofs part company first"""
+    import torch
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.sim import FSim
+    from oracle.oracle_sim import OracleSim
+    from tests.scenarios import spread_layout
+    m = load_compiled("Sawyer", name)
+    lay = spread_layout(m)
+    q = np.array(m.qpos0, dtype=float)
+    q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+    for p in range(m.nparts):
+        q[m.part_qposadr[p]:m.part_qposadr[p] + 7] = lay[p]
+    sim = FSim(m, 2)
+    sim.set_state(qpos=np.tile(q, (2, 1)), qvel=np.zeros((2, m.nv)), qacc_warmstart=np.zeros((2, m.nv)))
+    sim.physics_forward()
+    bias = sim.get_state("qfrc_bias")["qfrc_bias"].cpu().numpy()
+    rd = np.concatenate([m.arm_dofadr, m.grip_dofadr])
+    app = np.zeros((2, m.nv)); app[:, rd] = bias[:, rd]
+    sim.set_state(qfrc_applied=app)
+    o = OracleSim(m); o.set_solver(100, 1e-10, "newton"); o.reset()
+    o.data.qpos[:] = q; o.forward(); o.data.qfrc_applied[rd] = o.data.qfrc_bias[rd]
+    print(name, "kernel", sim.kernel_variant, "max_contacts", sim.max_contacts, "|bias dev - orc| robot %.2e" % np.abs(bias[0, rd] - o.data.qfrc_bias[rd]).max())
+    for k in range(nsub):
+        sim.physics_step(1); o.step()
+        st = {a: b[0].cpu().numpy() for a, b in sim.get_state("qpos", "qvel", "qacc", "ncon", "solver_iters").items()}
+        dq, dv, da = np.abs(st["qpos"] - o.data.qpos), np.abs(st["qvel"] - o.data.qvel), np.abs(st["qacc"] - o.data.qacc)
+        if k < 12 or k % 10 == 9:
+            print(" substep %2d: ncon dev %d orc %d iters %d | robot |dq| %.2e |dv| %.2e |da| %.2e | parts |dq| %.2e |dv| %.2e |da| %.2e (worst dof %d)" % (
+                k, int(st["ncon"][0]), len(o.contacts()), int(st["solver_iters"][0]), dq[m.arm_qposadr].max(), dv[rd].max(), da[rd].max(),
+                np.delete(dq, m.arm_qposadr).max(), np.delete(dv, rd).max(), np.delete(da, rd).max(), int(da.argmax())), flush=True)
+    sim.close()
