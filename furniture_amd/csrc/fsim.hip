@@ -700,6 +700,11 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (s->m.nu != 9 || ag.size() != 9 || ag[0] != 1.0f) { delete s; FAIL(FSIM_EINVAL, "arm controllers need the motor-actuated model (compiled with a torque-level control_type, robot_torque.xml)"); }
   }
   if (s->m.nr > 32) { int nr_ = s->m.nr; delete s; FAIL(FSIM_EINVAL, "model has %d moving bodies; this build supports <= 32 (body bitmasks)", nr_); }
+  { // (fs_body_spatial's packed chain words: 25 bits of dofs relative to the tree's first dof)
+    std::vector<int> tn_;
+    blob_i(s->blob, "tree_dofnum", tn_);
+    for (int n_ : tn_) if (n_ > 25) { delete s; FAIL(FSIM_EINVAL, "a kinematic tree of the model has %d dofs; this build supports <= 25 per tree", n_); }
+  }
   if (s->m.ntree > 16 || s->m.nv > 128) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 128 dofs", nt_, nv_); }
   const LayoutIn lin = layout_in(s, ncon_max);
   s->ly = make_layout(lin);

@@ -210,7 +210,7 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
     t0m = wave_or(t0m); t1m = wave_or(t1m);
     if (c.lane == 0) { int *ec = c.I(c.ly.env + E_GROUP + c.D.nparts); ec[EC_TOUCH] = t0m; ec[EC_TOUCH + 1] = t1m; }
   }
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
   long long tg0_ = clock64();
 #endif
   // instability guard (mj_checkPos / mj_checkVel / mj_checkAcc: NaN, Inf or a value beyond 1e10 in qpos, qvel or qacc -- the
@@ -221,7 +221,7 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
   bad = wave_or(bad);
   if (bad && c.lane == 0) c.I(c.ly.scal)[SC_BAD] |= 2;
   SYNC();
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
   { long long tg1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[18] += (int)((tg1_ - tg0_) >> 4); }
 #endif
 }
@@ -262,11 +262,11 @@ template <bool CTRL, class Ctx> static __device__ __noinline__ void fs_substeps_
     }
     if (CTRL && s < 0) continue;
     if ((mode & 2) && s == n - 1) fs_touch_flags(c);
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
     long long ti0_ = clock64();
 #endif
     fs_integrate_body(c);
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
     { long long ti1_ = clock64(); if (c.lane == 0) c.I(c.ly.scal)[16] += (int)((ti1_ - ti0_) >> 4); }
 #endif
   }
@@ -1234,13 +1234,13 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
     fs_substeps_t<true>(c, cfg.n_substeps, 2);
   } else {
     env_gravity_comp(c);
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
     long long tl0_ = clock64();
     if (c.lane == 0) scal[48] = (int)((tl0_ - io.t0) >> 4);
 #endif
     // _do_simulation: n_substeps x sim.step()
     fs_substeps(c, cfg.n_substeps, 2);
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
     { long long tl1_ = clock64(); if (c.lane == 0) { scal[51] = (int)((tl1_ - tl0_) >> 4); scal[52] = (int)(tl1_ >> 4); } }
 #endif
   }
@@ -1389,7 +1389,7 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
     const int nsub = max(1, cfg.n_substeps * (cfg_ik ? 3 : 1));
     env_post(c, cfg, io, nsub == 50 ? nit_step : (int)((float)nit_step * 50.0f / (float)nsub));
   }
-#ifdef FSIM_TIMELINE
+#if defined(FSIM_TIMELINE) && defined(FSIM_PROFILE)
   if (c.lane == 0) scal[52] = (int)(clock64() >> 4) - scal[52];
 #endif
   return 0;

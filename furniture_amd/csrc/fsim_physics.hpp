@@ -149,12 +149,13 @@ template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { retur
 enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP = 6 };
 // (FSIM_BIG_MIN: the island of the robot's tree counts as "large" from this many dofs on.  17 = only when it does not fit a DPP row;
 //  12 with the matrix-core Hessian assembly, -DFSIM_MFMA_HESSIAN, whose tile then also takes the robot + one part islands)
-#ifndef FSIM_BIG_MIN
-#ifdef FSIM_MFMA_HESSIAN
-#define FSIM_BIG_MIN 12
+//  -DFSIM_MFMA_HESSIAN=2: only in the multi-wave kernels, whose main wave is the critical path of the slowest envs)
+#ifndef FSIM_MFMA_HESSIAN
+#define FSIM_BIG_MIN_OF(Ctx) 17
+#elif FSIM_MFMA_HESSIAN == 2
+#define FSIM_BIG_MIN_OF(Ctx) (Ctx::NW > 1 ? 12 : 17)
 #else
-#define FSIM_BIG_MIN 17
-#endif
+#define FSIM_BIG_MIN_OF(Ctx) 12
 #endif
 template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl, int hwords_slot) {
   const int nv = c.D.nv, ntree = c.D.ntree;
@@ -186,8 +187,8 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
       int row = -1;
       // (round 4: an island of 12..16 dofs around the robot -- tree 0: the arm and the part it touches -- is a BIG island too: its
       //  Hessian is then assembled on the matrix cores, straight into the tile that is factored (fs_newton_mfma), instead of through
-      //  the body blocks in LDS and the row phase; FSIM_BIG_MIN = 17 restores the old split)
-      if (n <= 16 && !(u == 0 && n >= FSIM_BIG_MIN)) {
+      //  the body blocks in LDS and the row phase -- opt-in build, see FSIM_BIG_MIN_OF)
+      if (n <= 16 && !(u == 0 && n >= FSIM_BIG_MIN_OF(Ctx))) {
         for (int r = 0; r < 4; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
         if (row < 0) for (int r = 4; r < nrow; r++) if (fill[r] + n <= 16 && (row < 0 || fill[r] < fill[row])) row = r;
       }
@@ -234,14 +235,16 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
 #undef CPI
 #undef CPF
   // bit tables that replace index-list walks (an index load feeding a data load is two dependent LDS round trips per
-  // element): r_submask[b] = bodies in b's subtree; r_chain[b] = (first dof of b's tree) << 26 | bitmask of the dofs on
-  // the path root -> b, relative to that first dof (<= 26 dofs per tree, checked by the model compiler)
+  // element): r_submask[b] = bodies in b's subtree; r_chain[b] = (first dof of b's tree) << 25 | bitmask of the dofs on
+  // the path root -> b, relative to that first dof (<= 25 dofs per tree and <= 128 dofs in all, checked by fsim_create.  Round 4:
+  // the shift was 26, which left six bits for the first dof -- in a model with more than 64 dofs the parts whose dofs start at 64
+  // or later took their J v from other bodies' dofs: bookcase_grevback_0484's part 10, tests/test_all_furniture_gpu.py)
   for (int b = c.lane; b < nb; b += 64) {
     int sub = 0, ch = 0, base = b > 0 ? GP(m.tree_dofadr)[GP(m.r_tree)[b]] : 0;
     for (int d = b; d < nb; d++) if (b > 0 && ((GP(m.r_ancmask)[d] >> b) & 1)) sub |= 1 << d;
     if (b > 0) for (int k = 0; k < GP(m.r_chainlen)[b]; k++) ch |= 1 << (GP(m.chain_dofs)[GP(m.r_chainadr)[b] + k] - base);
     c.I(c.ly.k_r_submask)[b] = sub;
-    c.I(c.ly.k_r_chain)[b] = (base << 26) | ch;
+    c.I(c.ly.k_r_chain)[b] = (int)(((unsigned)base << 25) | (unsigned)ch);
   }
   SYNC();
   // static "tree map" of the block-diagonal-by-tree system M + h*D of fs_integrate (islands = trees): same format as the

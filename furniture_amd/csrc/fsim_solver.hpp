@@ -179,8 +179,8 @@ template <class Ctx> DEV void fs_body_spatial(const Ctx &c, int off_vec) {
   for (int b = c.lane; b < c.D.nr; b += 64) {
     S6 w = s6zero();
     {
-      const int ch = KI(r_chain, b), base = (unsigned)ch >> 26;
-      for (int mm = ch & 0x3ffffff; mm;) {
+      const int ch = KI(r_chain, b), base = (unsigned)ch >> 25;
+      for (int mm = ch & 0x1ffffff; mm;) {
         FS_BITS3(mm, e0, e1, e2, h1, h2);
         const int d0 = base + e0, d1 = base + e1, d2 = base + e2;
         const S6 s0 = lds6(L + c.ly.cdof + 6 * d0), s1 = lds6(L + c.ly.cdof + 6 * d1), s2 = lds6(L + c.ly.cdof + 6 * d2);
@@ -1285,6 +1285,8 @@ template <class Ctx> DEV int fs_asm_trees(const Ctx &c, const SolSlot &S) {
 #ifndef FSIM_MFMA_HESSIAN
   // (opt-in build: round-4 measurement, DESIGN.md 12.3 -- the eligible slow envs get ~10 % faster, the 4096-env step 4-8 % slower)
   return 0;
+#elif FSIM_MFMA_HESSIAN == 2
+  if (Ctx::NW == 1) return 0;
 #endif
   if (Ctx::NS != 1 || S.anyweld) return 0;
   const int nv = c.D.nv;

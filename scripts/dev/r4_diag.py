@@ -53,16 +53,6 @@ def grev():
         env.close()
 
 
-if __name__ == "__main__":
-    what = sys.argv[1]
-    if what == "ik":
-        ik_case(int(sys.argv[2]), sys.argv[3])
-    elif what == "grev":
-        grev()
-    elif what == "grevsub":
-        grev_substeps(*(sys.argv[2:3]))
-
-
 def grev_substeps(name="bookcase_grevback_0484", nsub=60):
     """device fsim_physics_step(1) vs OracleSim.step() from the laid-out start, substep by substep: which dofs part company first"""
     import torch
@@ -90,8 +80,26 @@ def grev_substeps(name="bookcase_grevback_0484", nsub=60):
         sim.physics_step(1); o.step()
         st = {a: b[0].cpu().numpy() for a, b in sim.get_state("qpos", "qvel", "qacc", "ncon", "solver_iters").items()}
         dq, dv, da = np.abs(st["qpos"] - o.data.qpos), np.abs(st["qvel"] - o.data.qvel), np.abs(st["qacc"] - o.data.qacc)
-        if k < 12 or k % 10 == 9:
-            print(" substep %2d: ncon dev %d orc %d iters %d | robot |dq| %.2e |dv| %.2e |da| %.2e | parts |dq| %.2e |dv| %.2e |da| %.2e (worst dof %d)" % (
+        if k in (0, 10, 11):
+            cg = sim.get_state("contact_geoms")["contact_geoms"][0].cpu().numpy().reshape(-1, 2)[:int(st["ncon"][0])]
+            dc, oc = sorted(map(tuple, np.sort(cg, axis=1).tolist())), sorted(tuple(sorted(x)) for x in o.contacts())
+            from collections import Counter
+            cd, co = Counter(dc), Counter(oc)
+            print("   contacts only on the device:", dict(cd - co), "only in the oracle:", dict(co - cd), "| oracle iterations", o.last_solver_iters, flush=True)
+            pt = [float(da[m.part_dofadr[p_]:m.part_dofadr[p_] + 6].max()) for p_ in range(m.nparts)]
+            print("   |da| per part:", " ".join("%.1e" % v for v in pt), flush=True)
+        if k < 14 or k % 10 == 9:
+            print(" substep %2d: ncon dev %d orc %d iters %d | robot |dq| %.2e |dv| %.2e |da| %.2e | parts |dq| %.2e |dv| %.2e |da| %.2e (worst dof %d) oracle iters %d" % (
                 k, int(st["ncon"][0]), len(o.contacts()), int(st["solver_iters"][0]), dq[m.arm_qposadr].max(), dv[rd].max(), da[rd].max(),
-                np.delete(dq, m.arm_qposadr).max(), np.delete(dv, rd).max(), np.delete(da, rd).max(), int(da.argmax())), flush=True)
+                np.delete(dq, m.arm_qposadr).max(), np.delete(dv, rd).max(), np.delete(da, rd).max(), int(da.argmax()), o.last_solver_iters), flush=True)
     sim.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    if what == "ik":
+        ik_case(int(sys.argv[2]), sys.argv[3])
+    elif what == "grev":
+        grev()
+    elif what == "grevsub":
+        grev_substeps(*(sys.argv[2:3]))
