@@ -672,5 +672,25 @@ void osim_full_M(osim_t *s, double *M) { memcpy(M, s->M, sizeof(double) * s->m.n
 void osim_set_solver(osim_t *s, int it, double tol) { s->solver_iters = it; s->solver_tol = tol; }
 void osim_set_solver_kind(osim_t *s, int kind) { s->solver_kind = kind; }
 int osim_last_solver_iters(osim_t *s) { return s->last_iters; }
+/* development / diagnostics (scripts/dev/release_diag.py): the constraint rows of the last forward pass and the solver's objective
+ * at a given acceleration -- which of two answers to one substep is the minimiser */
+int osim_contact_row(osim_t *s, int i) { return (i >= 0 && i < s->ncon) ? s->contact[i].efc_address : -1; }
+int osim_row_info(osim_t *s, int i, double *out8) {
+  if (i < 0 || i >= s->nefc) return -1;
+  const Row *r = &s->row[i];
+  out8[0] = r->type; out8[1] = r->dim; out8[2] = r->aref; out8[3] = r->R; out8[4] = r->D; out8[5] = r->mu; out8[6] = r->pos - r->margin; out8[7] = r->force;
+  return 0;
+}
+double osim_row_dot(osim_t *s, int i, const double *a) { return (i >= 0 && i < s->nefc) ? row_dot_a(&s->row[i], a) : 0.0; }
+double osim_cost_at(osim_t *s, const double *qacc) {
+  int nv = s->m.nv, ne = s->nefc;
+  double *Mx = (double *)malloc(sizeof(double) * nv), *jar = (double *)malloc(sizeof(double) * (ne > 0 ? ne : 1));
+  RowState *rs = (RowState *)malloc(sizeof(RowState) * (ne > 0 ? ne : 1));
+  mul_M(s, Mx, qacc);
+  for (int i = 0; i < ne; i++) jar[i] = row_dot_a(&s->row[i], qacc) - s->row[i].aref;
+  double c = total_cost(s, qacc, Mx, jar, rs);
+  free(Mx); free(jar); free(rs);
+  return c;
+}
 /* signed distance of listed contact i (< 0: penetration), as data.contact[i].dist */
 double osim_contact_dist(osim_t *s, int i) { return (i >= 0 && i < s->ncon) ? s->contact[i].dist : 0.0; }

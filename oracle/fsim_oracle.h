@@ -45,6 +45,11 @@ void osim_full_M(osim_t *, double *M_nvxnv);
 void osim_set_solver(osim_t *, int iterations, double tolerance);
 int osim_last_solver_iters(osim_t *);
 double osim_contact_dist(osim_t *, int i);
+/* diagnostics: efc row of contact i; (type, dim, aref, R, D, mu, pos - margin, force) of row i; J_i . a; the Newton objective at qacc */
+int osim_contact_row(osim_t *, int i);
+int osim_row_info(osim_t *, int i, double *out8);
+double osim_row_dot(osim_t *, int i, const double *a);
+double osim_cost_at(osim_t *, const double *qacc);
 void osim_set_solver_kind(osim_t *, int kind); /* 0 = PGS (dual), 1 = Newton (primal, MuJoCo default) */
 
 #ifdef __cplusplus

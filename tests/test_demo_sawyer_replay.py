@@ -12,6 +12,16 @@ Sawyer assembling swivel_chair_0700; scripts/make_golden_demo_sawyer7.py).  The 
   * frames 255-428  the gripper closes on the seat (finger penetration 0.3-1 mm, MuJoCo's 20 N grip), lifts it 35 cm and carries it
                   for 150 frames = 45 s = 22 500 substeps: the seat stays within 1.3 cm of the recording (slip grows 0.06 mm per
                   frame) and within 0.05 in orientation.
+  The RELEASE (frame 4), explained in round 4 (scripts/dev/release_diag.py): the recording holds one sample per
+  frame, so the replay opens the fingers at constant speed over the frame's 150 substeps.  The pads' two remaining contacts then have
+  -b v_n (opening speed) outweigh -k d r (penetration) from 1.5 mm of penetration on.  MuJoCo's default solver -- Newton on the primal
+  problem, which is what the device implements and what `OracleSim.set_solver(kind="newton")` runs -- keeps the elliptic cone's
+  middle-zone force there (normal residual satisfied, tangential not: the friction still carries 75-80 % of the column's weight)
+  until the geometric contact ends at substep 48; the PGS solver (the oracle's other kind, which rounds 2-3 replayed with) updates the
+  normal first and drops the friction with it at substep 37, so its column falls 11 substeps earlier and has landed when the frame
+  ends -- like the recording, whose real fingers opened faster than the interpolation.  Substep by substep from the same states the
+  device and the Newton oracle agree (column acceleration -1.751 vs -1.752, -2.071 vs -2.071, -3.027 vs -3.027 ...): the looser
+  frame-4 tolerance belongs to the solver KIND (primal vs dual), not to fp32, and the fp64 Newton oracle needs it too.
   Not replayable, and why: frames 47-150 -- the arm pushes the lying column, which rolls (neutral equilibrium: any difference grows),
   and today's column collider is ~1 cm wider across the recorded grasp than the recorded finger opening allows (asset revision: the
   kinematic fingers end up 5-9 mm inside it); the connects of frames 148 / 430 are env logic (covered by tests/golden/env_logic.npz).
@@ -59,8 +69,9 @@ def errors(parts_sim, t):
     return dp, dq
 
 
-def check_segment(name, traj, slip=6e-3, fp32=False):
-    """traj[k] = part poses [nparts, 7] at the end of frame f0 + k + 1"""
+def check_segment(name, traj, slip=6e-3, primal=False):
+    """traj[k] = part poses [nparts, 7] at the end of frame f0 + k + 1.  primal: the replay ran Newton on the primal problem (the device,
+    the Newton oracle) -- the column leaves the linearly opening fingers 11 substeps later than under PGS (module docstring)"""
     f0, f1 = SEGMENTS[name]
     E = [errors(p, f0 + k + 1) for k, p in enumerate(traj)]
     dp, dq = np.array([e[0] for e in E]), np.array([e[1] for e in E])
@@ -68,10 +79,10 @@ def check_segment(name, traj, slip=6e-3, fp32=False):
         BASE, COL, SEAT = 0, 1, 2
         assert dp[:4, COL].max() < 5e-4 and dq[:4, COL].max() < 0.01          # held in the closed gripper
         assert abs(D["parts"][4, COL, 2] - 0.0948) < 1e-3 and abs(D["parts"][5, COL, 2] - 0.0149) < 1e-4  # (the recording: released, landed one frame later)
-        # fell 8 cm and came to rest within the frame (fp32: the column slides out of the opening fingers ~40 substeps later and is still
+        # fell 8 cm and came to rest within the frame (primal: the pads' friction holds until the contact ends, the column is still
         # 1.5 cm up when the frame ends; it lies where the recording has it one frame later)
-        assert dp[4, COL] < (2.5e-2 if fp32 else 4e-3) and dq[4, COL] < (0.15 if fp32 else 0.04)  # (fp32: caught in mid-fall, tumbling)
-        assert dp[5:, COL].max() < (6e-3 if fp32 else 4e-3) and dq[5:, COL].max() < (0.06 if fp32 else 0.045)  # ... and stays there (a lying column is free to roll: 2.6 deg; fp32: where it comes to rest after the tumble moves by 1 mm with the summation order of the solver)
+        assert dp[4, COL] < (2.5e-2 if primal else 4e-3) and dq[4, COL] < (0.15 if primal else 0.04)  # (primal: caught in mid-fall, tumbling)
+        assert dp[5:, COL].max() < (6e-3 if primal else 4e-3) and dq[5:, COL].max() < (0.06 if primal else 0.045)  # ... and stays there (a lying column is free to roll: 2.6 deg; where it comes to rest after the later tumble differs by 1-4 mm)
         z = np.array([p[COL, 2] for p in traj[5:]])
         assert np.abs(z - 0.0149).max() < 1e-4                                 # MuJoCo's resting height of the lying column
         assert dp[:, BASE].max() < 5e-4 and dp[:, SEAT].max() < 1e-3           # nothing else moves (the arm brushes the seat: 0.5 mm)
@@ -84,11 +95,11 @@ def check_segment(name, traj, slip=6e-3, fp32=False):
         assert dp[:, 0].max() < 2e-3                                           # the base is not disturbed
 
 
-def replay_oracle(name):
+def replay_oracle(name, kind="newton"):
     from oracle.oracle_sim import OracleSim
     m = kinematic_robot_model()
     sim = OracleSim(m)
-    sim.set_solver(100, 1e-10)
+    sim.set_solver(100, 1e-10, kind)
     f0, f1 = SEGMENTS[name]
     sim.reset()
     sim.data.qpos[:] = start_state(m, f0)
@@ -108,8 +119,18 @@ def replay_oracle(name):
 
 
 @pytest.mark.parametrize("name", sorted(SEGMENTS))
-def test_oracle_parts_follow_the_mujoco_recording(name):
-    check_segment(name, replay_oracle(name))
+@pytest.mark.parametrize("kind", ["newton", "pgs"])
+def test_oracle_parts_follow_the_mujoco_recording(name, kind):
+    """both solver kinds of the fp64 oracle; Newton (MuJoCo's default, the device's algorithm) with the tolerances the device gets"""
+    check_segment(name, replay_oracle(name, kind), slip=8e-3 if kind == "newton" else 6e-3, primal=kind == "newton")
+
+
+def test_the_release_differs_by_solver_kind_not_by_precision():
+    """frame 4 in fp64 with both solvers: the primal solution still holds the column (friction of the two pad contacts) when PGS has
+    dropped it -- 1.5 cm of height at the end of the frame, the whole of what rounds 2-3 booked as an fp32 effect"""
+    zn = replay_oracle("hold_drop_rest", "newton")[4][1, 2]
+    zp = replay_oracle("hold_drop_rest", "pgs")[4][1, 2]
+    assert abs(zp - 0.0149) < 3e-3 and 0.025 < zn < 0.035, (zp, zn)
 
 
 @pytest.mark.gpu
@@ -140,11 +161,12 @@ def test_device_parts_follow_the_mujoco_recording(name):
         assert np.abs(qn[:9] - robot(t + 1)).max() < 5e-4
         traj.append(np.array([qn[int(a):int(a) + 7] for a in m.part_qposadr]))
     sim.close()
-    check_segment(name, traj, slip=8e-3, fp32=True)  # (fp32: the seat slips 0.6 mm further in the fingers while it is lifted)
-    # and against the fp64 oracle on the same protocol: frame by frame while the part is held / at rest
-    ora = replay_oracle(name)
+    check_segment(name, traj, slip=8e-3, primal=True)
+    # and against the fp64 NEWTON oracle on the same protocol, frame by frame: held, released (the same substep: both are 3 cm up, in
+    # mid-fall, when frame 4 ends), at rest
+    ora = replay_oracle(name, "newton")
     d = np.array([np.abs(a[:, :3] - b[:, :3]).max() for a, b in zip(traj, ora)])
     if name == "hold_drop_rest":
-        assert d[:4].max() < 2e-4 and d[5:].max() < 5e-3, (d[:4].max(), d[5:].max())  # held; (the fall: see above;) then at rest 3.5 mm apart
+        assert d[:4].max() < 2e-4 and d[4] < 4e-3 and d[5:].max() < 5e-3, (d[:4].max(), d[4], d[5:].max())
     else:
         assert d[:10].max() < 5e-4 and d.max() < 2e-2, (d[:10].max(), d.max())  # before the fingers touch; then two grips that settle and slip their own way
