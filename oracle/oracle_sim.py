@@ -89,6 +89,10 @@ class OracleSim:
         self._cg2 = self._iview("contact_geom2")
         self._ncon = self._iview("ncon")
         self._nefc = self._iview("nefc")
+        # MuJoCo's default solver (the reference sets none: base.xml:4 has impratio and cone only) is Newton on the primal problem; the C
+        # struct's zero-initialised kind is PGS.  Round 4: a replay that forgot to say "newton" compared the device with PGS for two
+        # rounds (tests/test_demo_sawyer_replay.py) -- the Python wrapper now starts where MuJoCo does; PGS is an explicit choice
+        L.osim_set_solver_kind(self._h, 1)
 
     def _dview(self, name, shape=None):
         n = ctypes.c_int()

@@ -1,6 +1,6 @@
 """development (round-3 verdict weak 2): Sawyer_7 frames 3-5 -- the gripper opens and the column leaves the fingers.  Device and fp64 oracle
 replayed substep by substep from the same frame start: column height / velocity, the finger-column contacts either side lists, Newton
-iterations.  usage: release_diag.py [first frame] [last frame]"""
+iterations.  usage: release_diag.py [first frame] [last frame] [pgs | newton: solver of the oracle that replays the whole path]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,8 +14,8 @@ COL = 1
 SAVE = {}
 f0, f1 = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 6)
 sim = FSim(m, 1, config=default_config())
-o = OracleSim(m); o.set_solver(100, 1e-10); o.reset()
-o2 = OracleSim(m); o2.set_solver(100, 1e-10); o2.reset()  # one substep from the DEVICE's state: is a difference the substep's or the path's?
+o = OracleSim(m); o.set_solver(100, 1e-10, sys.argv[3] if len(sys.argv) > 3 else "pgs"); o.reset()  # (pgs: what rounds 2-3 replayed with)
+o2 = OracleSim(m); o2.set_solver(100, 1e-10, "newton"); o2.reset()  # one substep from the DEVICE's state: is a difference the substep's or the path's?
 q = start_state(m, 0)
 zero = lambda k: np.zeros((1, k))
 sim.set_state(qpos=q[None], qvel=zero(m.nv), qacc_warmstart=zero(m.nv), ctrl=zero(m.nu), qfrc_applied=zero(m.nv), xfrc_applied=zero(6 * m.nparts))
