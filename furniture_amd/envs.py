@@ -555,8 +555,9 @@ class FurnitureBatchEnv:
         idx = np.nonzero(mask)[0]
         keep = [rngs[i].get_state() for i in idx]
         parts, noise = self._sampler._draw_python(mask)
+        no_draw = getattr(self, "_init_qpos", None) is not None  # (set_init_qpos: a reset takes nothing from the stream, furniture.py:1505-1519)
         for k, i in enumerate(idx):
-            self._attach_after_reset[i] = rngs[i].get_state()
+            self._attach_after_reset[i] = keep[k] if no_draw else rngs[i].get_state()
             rngs[i].set_state(keep[k])
         att = np.zeros((self.num_envs, max(narm, 1)), dtype=np.float32)
         for k, i in enumerate(idx):
@@ -568,7 +569,10 @@ class FurnitureBatchEnv:
 
     def _attach_reset(self, mask):
         """reset the envs in mask (numpy bool) from their committed streams; the observation rows of those envs are rewritten"""
-        parts, noise = self._sampler._draw_python(mask)  # advances the committed generators
+        keep = [(i, self._sampler.rngs[i].get_state()) for i in np.nonzero(mask)[0]] if getattr(self, "_init_qpos", None) is not None else []
+        parts, noise = self._sampler._draw_python(mask)  # advances the committed generators ...
+        for i, st in keep:  # ... unless the reset starts from a given state: the kernel wants a table present but takes nothing from it
+            self._sampler.rngs[i].set_state(st)
         self.sim.set_reset_tables(parts, noise, mask=mask)
         torch = self.sim.torch
         self.sim.reset(torch.as_tensor(mask.astype(np.uint8), device=self.sim.device), self._obs)
@@ -592,8 +596,6 @@ class FurnitureBatchEnv:
 
     def reset(self):
         if self._attach_mode:
-            if getattr(self, "_init_qpos", None) is not None:
-                raise NotImplementedError("config.reset_robot_after_attach with set_init_qpos is not built")
             self._sampler.rngs  # (the Python generators: the attach draws are taken from copies of them)
             if not hasattr(self, "_attach_after_reset"):
                 self._attach_after_reset, self._attach_after_attach = [None] * self.num_envs, [None] * self.num_envs

@@ -158,6 +158,83 @@ def test_reset_robot_after_attach_reposes_the_arm_and_keeps_the_rng_stream():
     env.close()
 
 
+def test_reset_robot_after_attach_with_set_init_qpos_takes_the_streams_first_draw():
+    """The combination round 3 refused: under set_init_qpos a reset takes NOTHING from the env's RandomState
+    (furniture.py:1505-1519, 1568-1569), so the joint noise of the first _connect (furniture.py:919-925) is the very first draw of the
+    stream, that of a connect in the next episode the second -- the host's bookkeeping must not advance the stream for the resets (nor for
+    a reset inside step()).  Device vs oracle env: reset observation, the arm after a scripted pinch + connect, the oracle's recorded
+    draws against a RandomState of the env's seed, the host-side reset at the episode end, and a second connect in the second episode."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions, pinch_attach_state
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n, T, seed = 2, 4, 47
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                           max_episode_steps=T, seed=seed, reset_robot_after_attach=True))
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=seed + i, solver_tolerance=1e-10, reset_robot_after_attach=True)) for i in range(n)]
+    start = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=1234, solver_tolerance=1e-10))
+    start.reset()
+    init = {"qpos": start.sim.data.qpos.copy(), "qvel": np.zeros(m.nv)}
+    env.set_init_qpos(init)
+    for o in orcs:
+        o.set_init_qpos(init)
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+    sim = env.sim
+
+    def pinch_and_connect(episode):
+        od = flat(env.reset()) if episode == 0 else None
+        if episode == 0:
+            for i in range(n):
+                assert np.abs(od[i] - orcs[i].flat_obs(orcs[i].reset())).max() < 5e-5
+        o0 = orcs[0]
+        q, xfrc, masks = pinch_attach_state(m, o0.sim.data.qpos.copy(), o0.sim.data.xpos.copy(), o0.sim.data.xquat.copy())
+        o0.sim.data.qpos[:], o0.sim.data.qvel[:], o0.sim.data.qacc_warmstart[:] = q, 0, 0
+        for i in range(m.nparts):
+            o0.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i]
+        st = sim.get_state("qpos", "qvel", "qacc_warmstart", "xfrc_applied", "geom_contype", "geom_conaffinity")
+        for g, (ct, ca) in masks.items():
+            o0.sim.model.geom_contype[g], o0.sim.model.geom_conaffinity[g] = ct, ca
+            st["geom_contype"][0, g], st["geom_conaffinity"][0, g] = ct, ca
+        st["qpos"][0] = torch.as_tensor(q, dtype=st["qpos"].dtype)
+        st["qvel"][0], st["qacc_warmstart"][0] = 0, 0
+        st["xfrc_applied"][0] = torch.as_tensor(xfrc.reshape(-1), dtype=st["xfrc_applied"].dtype)
+        sim.set_state(**st)
+        a = np.zeros((n, 9), dtype=np.float32)
+        a[:, 7] = a[:, 8] = 1.0
+        ob, rew, done, info = env.step(a)
+        res = [orcs[i].step(a[i]) for i in range(n)]
+        assert res[0][3]["connected_this_step"] == 1 and int(info["connected"][0]) == 1 and int(info["connected"][1]) == 0
+        qd = sim.get_state("qpos")["qpos"].cpu().numpy()
+        for i in range(n):
+            assert np.abs(qd[i][m.arm_qposadr] - orcs[i].sim.data.qpos[m.arm_qposadr]).max() < 2e-4, (episode, i)
+        return ob, done
+
+    pinch_and_connect(0)
+    # the oracle's first attach draw IS the stream's first draw: no reset took anything
+    first = np.random.RandomState(seed).uniform(-1e-3, 1e-3, 7)
+    assert len(orcs[0].attach_draws) == 1 and np.allclose(orcs[0].attach_draws[0], first, rtol=0, atol=0)
+    # to the end of the episode: the host resets from the given state again, the returned rows are the oracle's reset observation
+    done = None
+    for t in range(1, T):
+        a = np.stack([counter_actions(seed, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, _ = orcs[i].step(a[i])
+            assert bool(done[i]) == d
+            if d:
+                assert np.abs(flat(ob)[i] - orcs[i].flat_obs(orcs[i].reset())).max() < 2e-4, (t, i)
+    assert bool(done.all())
+    # second episode, second connect of env 0: the stream's SECOND draw (env 1, which never attached, is still at its first)
+    pinch_and_connect(1)
+    rs = np.random.RandomState(seed)
+    rs.uniform(-1e-3, 1e-3, 7)
+    assert len(orcs[0].attach_draws) == 2 and np.array_equal(orcs[0].attach_draws[1], rs.uniform(-1e-3, 1e-3, 7)) and len(orcs[1].attach_draws) == 0
+    env.close()
+
+
 def test_reset_robot_after_attach_resynchronises_the_ik_target():
     """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
     target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it
