@@ -113,7 +113,7 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   const int lane = c.lane;
   const EnvCfg &cfg = a.cfg;
   float *rec = a.state + (size_t)env * c.ly.stride;
-#if defined(FSIM_PROFILE) && defined(FSIM_TIMELINE)
+#ifdef FSIM_TIMELINE
   const long long tw0_ = wall_clock64(); // (100 MHz, one counter for the whole device: clock64() has an offset per XCD)
 #endif
   load_record(L, rec, c.ly.stride, lane);
@@ -163,6 +163,14 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
 #endif
   // (the debug row: words [0, nv) are read back as `qacc`, the ones behind that as `contact_geoms` -- the fields whose read-back is a plain copy)
   if (a.prof && lane < 48) a.prof[(size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max) + (lane < c.D.nv ? lane : 7 * c.D.nr + 4 + lane)] = reinterpret_cast<int *>(L + c.ly.scal)[16 + lane];
+#endif
+#if defined(FSIM_TIMELINE) && !defined(FSIM_PROFILE)
+  // development (scripts/dev/timeline_x.py): start / end tick only, into the same words of the debug row -- without the 48 profile words
+  // per env in LDS, with which two bundles of k_env_step_x no longer fit a CU
+  if (a.prof && lane == 0) {
+    int *row = a.prof + (size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max);
+    row[37] = (int)(tw0_ & 0x7fffffff); row[38] = (int)(wall_clock64() & 0x7fffffff);
+  }
 #endif
   store_record(rec, L, c.ly.stride, lane);
   return deferred;
