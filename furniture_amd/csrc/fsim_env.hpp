@@ -960,6 +960,9 @@ template <class Ctx0> static __device__ __noinline__ void env_reset_units(Ctx0 c
           if (c.lane == 0) env_project_connector_quat(c, k1, k2, ang == ang, ang);
           SYNC();
           env_connect(c, cfg, k1, k2, true);
+          // config.reset_robot_after_attach: this _connect, too, ends with _initialize_robot_pos() (furniture.py:919-925) -- its draw was taken
+          // between the placement's and the robot initialisation's and sits behind the latter's 101 rows of the noise table
+          if (cfg.reset_robot_after_attach && io.tab_noise && io.n_noise > 101 + i) env_init_robot(c, io, 101 + i, cfg.move_speed);
           if (c.lane == 0) { E[E_CONNECTED_THIS_STEP] = 0; E[E_CONNBODY1] = 0; }
           SYNC();
         }

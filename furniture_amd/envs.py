@@ -132,6 +132,11 @@ class ResetTableSampler:
         self._hist = [[] for _ in idx]  # RNG states before each of the last draws (rng_handover rolls unconsumed draws back)
         self._fixed = [None] * n_envs  # config.fix_init (furniture.py:1518-1525): the first placement of an env is kept for its later resets
         self.narm = len(model.arm_qposadr)
+        # config.reset_robot_after_attach with config.preassembled on a furniture with a recipe: every _connect of the reset re-poses the
+        # arm with one draw taken BETWEEN the placement and the 101 robot-initialisation draws (furniture.py:919-925 inside :1542-1557).
+        # They travel behind the 101 rows of the noise table (rows 101 ..: read by the kernel's in-reset connects, fsim_env.hpp)
+        self.n_attach_in_reset = (len(getattr(cfg, "preassembled", None) or []) if getattr(cfg, "reset_robot_after_attach", False)
+                                  and model.meta.get("has_recipe", False) and self.narm else 0)
         if self._native:
             self._mt = np.empty((n_envs, 625), dtype=np.uint32)
             sd = np.ascontiguousarray(self._seeds, dtype=np.uint32)
@@ -217,7 +222,7 @@ class ResetTableSampler:
 
     def draw(self, mask=None):
         """(part_qpos [n, nparts*7], robot_noise [n, 101*narm]) for the envs selected by mask (others zero)."""
-        return self._draw_native(mask) if self._native else self._draw_python(mask)
+        return self._draw_native(mask) if self._native and not self.n_attach_in_reset else self._draw_python(mask)
 
     def _draw_native(self, mask):
         m, cfg = self.m, self.cfg
@@ -263,7 +268,8 @@ class ResetTableSampler:
         self._to_python()
         n = len(self._rngs)
         parts = np.zeros((n, self.m.nparts * 7), dtype=np.float32)
-        noise = np.zeros((n, N_NOISE * max(self.narm, 1)), dtype=np.float32)
+        k = self.n_attach_in_reset
+        noise = np.zeros((n, (N_NOISE + k) * max(self.narm, 1)), dtype=np.float32)
         for i, rng in enumerate(self._rngs):
             if mask is not None and not mask[i]:
                 continue
@@ -277,8 +283,9 @@ class ResetTableSampler:
             parts[i] = np.asarray(self.m.part_initqpos, dtype=np.float64).reshape(-1) if getattr(self.cfg, "assembled", False) else placement
             if self.narm:
                 a = self.cfg.agent_xyz_rand
+                extra = rng.uniform(low=-a, high=a, size=(k, self.narm)).reshape(-1) if k else np.zeros(0)
                 # one (101, narm) draw consumes the Mersenne-Twister stream exactly like 101 successive size-narm draws
-                noise[i] = rng.uniform(low=-a, high=a, size=(N_NOISE, self.narm)).reshape(-1)
+                noise[i] = np.concatenate([rng.uniform(low=-a, high=a, size=(N_NOISE, self.narm)).reshape(-1), extra])
         return parts, noise
 
 
@@ -381,7 +388,7 @@ class FurnitureBatchEnv:
         # auto_reset off) once it knows whether the last step attached.  Combinations whose resets call _connect themselves are refused.
         self._attach_mode = bool(getattr(cfg, "reset_robot_after_attach", False)) and agent != "Cursor"
         if getattr(cfg, "reset_robot_after_attach", False):
-            for flag in ("preassembled", "assembled", "fix_init", "num_connects"):
+            for flag in ("assembled", "fix_init", "num_connects"):  # (config.preassembled: the reset's connects read their draws from rows 101.. of the noise table)
                 if getattr(cfg, flag, None):
                     raise NotImplementedError("config.reset_robot_after_attach with config.%s (pre-assembled resets call _connect -- and draw -- inside the reset, furniture.py:1542-1566) is not built" % flag)
             if dense:

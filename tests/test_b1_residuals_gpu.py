@@ -235,6 +235,65 @@ def test_reset_robot_after_attach_with_set_init_qpos_takes_the_streams_first_dra
     env.close()
 
 
+def test_reset_robot_after_attach_with_preassembled_draws_inside_the_reset():
+    """config.preassembled on a furniture with a recipe: the reset itself calls _connect (furniture.py:1542-1557), and with
+    reset_robot_after_attach every such _connect re-poses the arm with a draw taken between the placement's draws and the 101 of the
+    robot initialisation (furniture.py:919-925).  The host draws them in that order and hands them over behind the 101 rows of the noise
+    table; the kernel's in-reset connects read them.  Device vs oracle env over two resets and the steps between them: the placements
+    (the stream is where the oracle's is), the whole reset observation (the arm's velocity at the end of the settling depends on the
+    re-pose), and the oracle's recorded draw against the position in a RandomState of the env's seed."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions
+    m = load_compiled("Sawyer", "table_lack_0825")
+    assert m.meta["has_recipe"]
+    n, T, seed = 2, 3, 53
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                           max_episode_steps=T, seed=seed, reset_robot_after_attach=True, preassembled=[0]))
+    assert env._sampler.n_attach_in_reset == 1
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=seed + i, solver_tolerance=1e-10, reset_robot_after_attach=True, preassembled=[0])) for i in range(n)]
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+
+    def err(x, o, upto=None):
+        """each part's quaternion compared up to its sign (the recipe's 90 / 270 degree targets sit on a branch tie of lookat_to_quat that
+        fp32 and fp64 rounding break differently: q or -q, the same rotation -- tests/test_gpu_parity.py test_preassembled_starts...)"""
+        x = x.copy()
+        for p_ in range(m.nparts):
+            if np.dot(x[7 * p_ + 3:7 * p_ + 7], o[7 * p_ + 3:7 * p_ + 7]) < 0:
+                x[7 * p_ + 3:7 * p_ + 7] *= -1
+        return np.abs(x - o)[:upto].max()
+
+    od = flat(env.reset())
+    for i in range(n):
+        oo = orcs[i].flat_obs(orcs[i].reset())
+        assert err(od[i], oo, 7 * m.nparts) < 5e-5 and err(od[i], oo) < 2e-4, (i, err(od[i], oo, 7 * m.nparts), err(od[i], oo))
+        assert len(orcs[i].attach_draws) == 1
+    # where in the stream the in-reset draw sits: after the placement's draws, before the 101 x 7 of the robot initialisation
+    rs = np.random.RandomState(seed)
+    from furniture_amd.envs import ResetTableSampler
+    probe = ResetTableSampler(m, env.config, seed, 0, 1)
+    probe._to_python()
+    probe._placement(rs)
+    assert np.array_equal(orcs[0].attach_draws[0], rs.uniform(-1e-3, 1e-3, 7))
+    done = None
+    for t in range(T):
+        a = np.stack([counter_actions(seed, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, _ = orcs[i].step(a[i])
+            assert bool(done[i]) == d
+            if d:  # the host-side reset of the finished episode: second pass of the stream, in-reset draw included
+                oo = orcs[i].flat_obs(orcs[i].reset())
+                assert err(flat(ob)[i], oo, 7 * m.nparts) < 5e-5 and err(flat(ob)[i], oo) < 2e-4, (t, i)
+            else:
+                assert err(flat(ob)[i], orcs[i].flat_obs(o)) < 1e-3, (t, i)
+    assert bool(done.all()) and all(len(o.attach_draws) == 2 for o in orcs)
+    env.close()
+
+
 def test_reset_robot_after_attach_resynchronises_the_ik_target():
     """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
     target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it

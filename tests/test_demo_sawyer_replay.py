@@ -22,6 +22,9 @@ Sawyer assembling swivel_chair_0700; scripts/make_golden_demo_sawyer7.py).  The 
   ends -- like the recording, whose real fingers opened faster than the interpolation.  Substep by substep from the same states the
   device and the Newton oracle agree (column acceleration -1.751 vs -1.752, -2.071 vs -2.071, -3.027 vs -3.027 ...): the looser
   frame-4 tolerance belongs to the solver KIND (primal vs dual), not to fp32, and the fp64 Newton oracle needs it too.
+  * frames 150-255 (round 4)  after the first connect: base and column are one welded body (weld 0 active, the recorded poses are the
+                  aligned ones) standing on the floor while the arm travels to the seat and brushes it -- the welded pair stays within
+                  0.1 mm of the recording for 105 frames = 15 750 substeps, the seat within 1.1 mm / 0.004.
   Not replayable, and why: frames 47-150 -- the arm pushes the lying column, which rolls (neutral equilibrium: any difference grows),
   and today's column collider is ~1 cm wider across the recorded grasp than the recorded finger opening allows (asset revision: the
   kinematic fingers end up 5-9 mm inside it); the connects of frames 148 / 430 are env logic (covered by tests/golden/env_logic.npz).
@@ -35,7 +38,8 @@ from furniture_amd.mjcf.model import CompiledModel, load_compiled
 
 D = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_sawyer7.npz"))
 N_SUB, H = 150, 0.002
-SEGMENTS = {"hold_drop_rest": (0, 47), "grasp_lift_carry_seat": (255, 428)}
+SEGMENTS = {"hold_drop_rest": (0, 47), "grasp_lift_carry_seat": (255, 428), "welded_base_and_column_under_the_arm": (150, 255)}
+WELDS = {"welded_base_and_column_under_the_arm": [0]}  # equality constraints that are active in a segment (0: base - column, connected at frame 148)
 
 
 def kinematic_robot_model():
@@ -86,6 +90,9 @@ def check_segment(name, traj, slip=6e-3, primal=False):
         z = np.array([p[COL, 2] for p in traj[5:]])
         assert np.abs(z - 0.0149).max() < 1e-4                                 # MuJoCo's resting height of the lying column
         assert dp[:, BASE].max() < 5e-4 and dp[:, SEAT].max() < 1e-3           # nothing else moves (the arm brushes the seat: 0.5 mm)
+    elif name == "welded_base_and_column_under_the_arm":
+        assert dp[:, :2].max() < 5e-4 and dq[:, :2].max() < 2e-3   # the welded base + column do not move
+        assert dp[:, 2].max() < 2.5e-3 and dq[:, 2].max() < 0.01   # the arm brushes the seat on its way (1 mm)
     else:
         SEAT = 2
         assert dp[:60, SEAT].max() < 1.2e-2 and dp[25:60, SEAT].max() < slip   # closing, lift-off (the grip settles: 1 cm for three frames), lifting
@@ -104,6 +111,8 @@ def replay_oracle(name, kind="newton"):
     sim.reset()
     sim.data.qpos[:] = start_state(m, f0)
     sim.data.qvel[:] = 0
+    for e in WELDS.get(name, []):
+        sim.model.eq_active[e] = 1
     sim.forward()
     traj = []
     for t in range(f0, f1):
@@ -122,6 +131,8 @@ def replay_oracle(name, kind="newton"):
 @pytest.mark.parametrize("kind", ["newton", "pgs"])
 def test_oracle_parts_follow_the_mujoco_recording(name, kind):
     """both solver kinds of the fp64 oracle; Newton (MuJoCo's default, the device's algorithm) with the tolerances the device gets"""
+    if kind == "pgs" and name in WELDS:
+        pytest.skip("100 PGS sweeps do not converge on a weld row under load (the pair sags by millimetres); MuJoCo's default is Newton")
     check_segment(name, replay_oracle(name, kind), slip=8e-3 if kind == "newton" else 6e-3, primal=kind == "newton")
 
 
@@ -144,6 +155,10 @@ def test_device_parts_follow_the_mujoco_recording(name):
     q = start_state(m, f0)
     zero = lambda k: np.zeros((1, k))
     sim.set_state(qpos=q[None], qvel=zero(m.nv), qacc_warmstart=zero(m.nv), ctrl=zero(m.nu), qfrc_applied=zero(m.nv), xfrc_applied=zero(6 * m.nparts))
+    if WELDS.get(name):
+        act = np.zeros((1, m.neq), dtype=np.int32)
+        act[0, WELDS[name]] = 1
+        sim.set_state(eq_active=act)
     traj = []
     for t in range(f0, f1):
         v = (robot(t + 1) - robot(t)) / (N_SUB * H)
@@ -168,5 +183,7 @@ def test_device_parts_follow_the_mujoco_recording(name):
     d = np.array([np.abs(a[:, :3] - b[:, :3]).max() for a, b in zip(traj, ora)])
     if name == "hold_drop_rest":
         assert d[:4].max() < 2e-4 and d[4] < 4e-3 and d[5:].max() < 5e-3, (d[:4].max(), d[4], d[5:].max())
+    elif name in WELDS:
+        assert d.max() < 1.5e-3, d.max()
     else:
         assert d[:10].max() < 5e-4 and d.max() < 2e-2, (d[:10].max(), d.max())  # before the fingers touch; then two grips that settle and slip their own way
