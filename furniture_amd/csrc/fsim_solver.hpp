@@ -1861,11 +1861,18 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   // big islands whose Hessian is assembled on the matrix cores, straight into the tile the factorisation works on (fs_chol_mfma)
   // (kept in an LDS scalar and read back where it is used: one more value alive across the whole Newton loop cost the substep loop
   //  ten spill reloads per substep)
+#ifdef FSIM_MFMA_HESSIAN
   {
     const int asm_set = fs_asm_trees(c, S);
     if (c.lane == 0) { scal[SC_ASM] = asm_set; if constexpr (Ctx::NW > 1) { if (mw) c.I(c.ly.mwc)[MWC_ASM] = asm_set; } }
     SYNC();
   }
+#define FS_ASM_OK() __builtin_amdgcn_readfirstlane(scal[SC_ASM])
+#else
+  // (default build: no island is assembled on the matrix cores -- a compile-time zero, so that none of that path's code, nor the LDS
+  //  read per iteration, is in the substep loop)
+#define FS_ASM_OK() 0
+#endif
   for (; it < c.newton_maxit; it++) {
     SlotK sk, skT = {};
     bool ok;
@@ -1874,7 +1881,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       iterated = true;
       bool go;
       int am;
-      const int asm_ok = __builtin_amdgcn_readfirstlane(scal[SC_ASM]);
+      const int asm_ok = FS_ASM_OK();
       mw_iterate_main(c, S, sk, scale, &go, &am, asm_ok);
       FS_SPROF(24);
       if (!go) break;
@@ -1910,7 +1917,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       FS_SPROF(23);
       if (scale * gn < c.newton_tol) break;
       // (the LDS assembly serves the islands the matrix cores do not take: none at all when a robot island is all that still moves)
-      const int asm_ok = __builtin_amdgcn_readfirstlane(scal[SC_ASM]);
+      const int asm_ok = FS_ASM_OK();
       if (asm_ok) fs_stage_k(c, S, sk);
       if (!asm_ok || (am & ~asm_ok)) fs_hessian(c, sk, S, am & ~asm_ok);
       if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
