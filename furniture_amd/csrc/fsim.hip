@@ -462,6 +462,7 @@ struct fsim {
   int lds_bytes_mw = 0, lds_bytes_x = 0;
   int *d_mworder = nullptr, *d_mwn = nullptr; // q: [0] multi-wave envs of the launch, [1] the others, [2] / [3] heads of the bundle / multi-wave queues, [4] look-ahead jobs, [5] head of their queue
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
+  int x_grid = 0;                             // workgroups of a k_env_step_x launch
   DModel m{};
   Layout ly{};
   fsim_config_t cfg{};
@@ -748,6 +749,8 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
       s->mw_mode = (can_rule && n_envs <= 8 * pr.multiProcessorCount) ? MW_RULE : MW_OFF;
     }
     s->x_resident = 2 * pr.multiProcessorCount;
+    s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 8), s->x_resident);
+    if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
@@ -1123,7 +1126,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (mw_all)
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   else if (mw_rule) // persistent workgroups: as many as the one-wave envs need in bundles of four plus an eighth of the batch for multi-wave envs, at most what is resident at once
-    hipLaunchKernelGGL(s->ks.env_step_x, dim3(std::min((s->n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, s->n_envs / 8), s->x_resident)), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
+    hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->x_grid), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
                        s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mworder, s->d_mwn);
   else
     hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs + (jobs ? s->la_jobs : 0)), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
