@@ -48,13 +48,26 @@ def _cpu_worker(args):
     env = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=MAX_EPISODE_STEPS, seed=SEED + idx))
     rng = np.random.RandomState(SEED + idx)
     env.reset()
+    # how much of the baseline is the C physics (osim_step) and how much the Python env logic around it: timed on worker 0 only
+    # (two clock reads per substep would be 3 % of a worker's own time)
+    tc = [0.0]
+    if idx == 0:
+        raw = env.sim.step
+
+        def timed_step():
+            t = time.perf_counter()
+            r = raw()
+            tc[0] += time.perf_counter() - t
+            return r
+        env.sim.step = timed_step
     n, t0 = 0, time.time()
     while time.time() - t0 < seconds:
         _, _, done, _ = env.step(rng.uniform(-1, 1, 9))
         n += 1
         if done:
             env.reset()
-    return n, time.time() - t0
+    dt = time.time() - t0
+    return n, dt, (tc[0] / dt if idx == 0 else None)
 
 
 def cpu_baseline(seconds=10.0):
@@ -64,9 +77,13 @@ def cpu_baseline(seconds=10.0):
         res = pool.map(_cpu_worker, [(i, seconds) for i in range(cores)])
     steps = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
+    share = res[0][2]
     return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "c_physics_share": round(share, 3) if share is not None else None,
             "sample": "%d envs (one per core) x %.0f s of FurnitureSawyerEnv+table_lack_0825 random-action steps incl. resets; "
-                      "%.1f env-steps/s per core" % (cores, seconds, steps / wall / cores)}
+                      "%.1f env-steps/s per core; %.0f %% of worker 0's wall time inside the C physics (osim_step), the rest is the Python env "
+                      "logic of the oracle env -- a fully native stepper would be at most %.2fx this baseline"
+                      % (cores, seconds, steps / wall / cores, 100 * (share or 0), 1.0 / max(share or 1.0, 1e-6))}
 
 
 def _free_port():

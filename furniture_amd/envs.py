@@ -388,7 +388,9 @@ class FurnitureBatchEnv:
         # auto_reset off) once it knows whether the last step attached.  Combinations whose resets call _connect themselves are refused.
         self._attach_mode = bool(getattr(cfg, "reset_robot_after_attach", False)) and agent != "Cursor"
         if getattr(cfg, "reset_robot_after_attach", False):
-            for flag in ("assembled", "fix_init", "num_connects"):  # (config.preassembled: the reset's connects read their draws from rows 101.. of the noise table)
+            # (config.preassembled: the reset's connects read their draws from rows 101.. of the noise table; config.assembled switches the
+            #  welds on without calling _connect, config.fix_init only skips later placement draws: the sampler replays both as they are)
+            for flag in ("num_connects",):
                 if getattr(cfg, flag, None):
                     raise NotImplementedError("config.reset_robot_after_attach with config.%s (pre-assembled resets call _connect -- and draw -- inside the reset, furniture.py:1542-1566) is not built" % flag)
             if dense:

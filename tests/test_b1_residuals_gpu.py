@@ -294,6 +294,63 @@ def test_reset_robot_after_attach_with_preassembled_draws_inside_the_reset():
     env.close()
 
 
+@pytest.mark.parametrize("option", ["assembled", "fix_init"])
+def test_reset_robot_after_attach_with_assembled_and_fix_init(option):
+    """The two remaining start options under reset_robot_after_attach, neither of which calls _connect inside the reset: config.assembled
+    switches every weld on (furniture.py:1502-1503, 1526-1530: the placement draw is still taken, the parts stay at the XML's poses) and
+    config.fix_init keeps the first placement (furniture.py:1518-1525: later resets take no placement draw).  Device vs oracle env over
+    three episodes of host-side resets: every reset observation and the steps between them."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n, T, seed = 2, 2, 61
+    kw = {option: True}
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                           max_episode_steps=T, seed=seed, reset_robot_after_attach=True, **kw))
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=seed + i, solver_tolerance=1e-10, reset_robot_after_attach=True, **kw)) for i in range(n)]
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+    from furniture_amd import transform_utils as TU
+    npo = 7 * m.nparts
+
+    def same(x, o, tol):
+        if option == "fix_init":
+            return np.abs(x - o).max() < tol
+        # config.assembled: five parts yanked together over ~1 m by four welds inside the reset -- a violent transient in which the fp32
+        # and fp64 integrators part company (tests/test_gpu_parity.py test_fix_init_and_assembled...): what both reach is the assembled
+        # configuration (every weld's relative pose)
+        for v in (x, o):
+            parts = v[:npo].reshape(m.nparts, 7)
+            for e in range(m.neq):
+                rel = TU.rel_pose(parts[int(m.eq_part1[e])], parts[int(m.eq_part2[e])])
+                assert np.abs(rel[:3] - m.eq_data0[e][:3]).max() < 2e-2, ("weld", e, rel[:3], m.eq_data0[e][:3])
+        return np.isfinite(x).all()  # (the flung table knocks the arm about as well: the streams are compared directly, below)
+
+    def streams_agree():
+        """the host's committed generator of every env is where the oracle env's RandomState is (key array and position)"""
+        for i in range(n):
+            a_, b_ = env._sampler.rngs[i].get_state(), orcs[i]._rng.get_state()
+            assert a_[2] == b_[2] and np.array_equal(a_[1], b_[1]), i
+
+    od = flat(env.reset())
+    for i in range(n):
+        assert same(od[i], orcs[i].flat_obs(orcs[i].reset()), 2e-4), i
+    streams_agree()
+    for t in range(3 * T):
+        a = np.zeros((n, 9), dtype=np.float32) if option == "assembled" else np.stack([counter_actions(seed, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, _ = orcs[i].step(a[i])
+            assert bool(done[i]) == d
+            ref = orcs[i].flat_obs(orcs[i].reset()) if d else orcs[i].flat_obs(o)
+            assert same(flat(ob)[i], ref, 2e-4 if d else 1e-3), (t, i, d)
+        streams_agree()
+    env.close()
+
+
 def test_reset_robot_after_attach_resynchronises_the_ik_target():
     """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
     target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it
