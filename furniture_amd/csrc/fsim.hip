@@ -121,8 +121,14 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
   SYNC();
+#if defined(FSIM_TIMELINE) && !defined(FSIM_PROFILE)
+  const long long tlc0_ = wall_clock64();
+#endif
   if (load_cache) fs_load_cache(c);
   else { if (lane == 0) reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS] = twords; SYNC(); }
+#if defined(FSIM_TIMELINE) && !defined(FSIM_PROFILE)
+  const int tlc_ = (int)(wall_clock64() - tlc0_), tlr_ = (int)(tlc0_ - tw0_);
+#endif
   EnvIO io;
   io.action = a.action ? a.action + (size_t)env * cfg.dof_action : nullptr;
   io.obs = a.obs ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.obs) + (size_t)env * cfg.obs_dim * (cfg.obs_bf16 ? 2 : 4)) : nullptr;
@@ -170,6 +176,7 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   if (a.prof && lane == 0) {
     int *row = a.prof + (size_t)env * (c.D.nv + 7 * c.D.nr + 4 + 2 * c.ly.ncon_max);
     row[37] = (int)(tw0_ & 0x7fffffff); row[38] = (int)(wall_clock64() & 0x7fffffff);
+    row[35] = tlr_; row[36] = load_cache ? tlc_ : -1; // (10 ns ticks: record load, model-cache build -- -1: the wave had it already)
   }
 #endif
   store_record(rec, L, c.ly.stride, lane);

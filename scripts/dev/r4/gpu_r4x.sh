@@ -1,0 +1,6 @@
+#!/bin/bash
+# what the driver runs at round end: the GPU suite in ONE process, then smoke()
+O=gpurun_out/r4x; mkdir -p $O
+timeout 2400 python -m pytest tests/ -x -q -m gpu > $O/gpu_suite_one_process.txt 2>&1; echo "pytest rc=$?" >> $O/gpu_suite_one_process.txt
+tail -5 $O/gpu_suite_one_process.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt

@@ -41,6 +41,8 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     line = "step %2d: wall %.2f ms span %.0f us | one-wave envs %d: duration mean %.0f p99 %.0f max %.0f us, last end %.0f us" % (t, dt * 1e3, us(en.max()), one.sum(), us(d[one].mean()), us(np.percentile(d[one], 99)), us(d[one].max()), us(en[one].max()))
     if four.any():
         line += " | four-wave envs %d: duration mean %.0f max %.0f us, last start %.0f last end %.0f us; first one-wave start %.0f us" % (four.sum(), us(d[four].mean()), us(d[four].max()), us(st[four].max()), us(en[four].max()), us(st[one].min()))
+    lc = p[:, 36]
+    line += " | record load %.1f us, model-cache build %.1f us (built by %d of the waves)" % (p[:, 35].mean() / 100.0, lc[lc >= 0].mean() / 100.0 if (lc >= 0).any() else 0.0, int((lc >= 0).sum()))
     print(line)
     last = np.argsort(-en)[:8]
     print("     last to finish: " + "  ".join("[env %d %s start %.0f dur %.0f it %d]" % (e, "4w" if four[e] else "1w", us(st[e]), us(d[e]), nit[e]) for e in last))
