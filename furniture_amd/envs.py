@@ -393,8 +393,6 @@ class FurnitureBatchEnv:
             for flag in ("num_connects",):
                 if getattr(cfg, flag, None):
                     raise NotImplementedError("config.reset_robot_after_attach with config.%s (pre-assembled resets call _connect -- and draw -- inside the reset, furniture.py:1542-1566) is not built" % flag)
-            if dense:
-                raise NotImplementedError("config.reset_robot_after_attach with the dense-reward env is not built")
         names = furniture_names()
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg

@@ -351,6 +351,49 @@ def test_reset_robot_after_attach_with_assembled_and_fix_init(option):
     env.close()
 
 
+def test_reset_robot_after_attach_on_the_dense_reward_env():
+    """FurnitureSawyerDenseRewardEnv with config.reset_robot_after_attach (the flag is read by _connect, furniture.py:919-925, AND by the
+    dense reward's phase logic, furniture_sawyer_dense.py: both come from the one config).  The host-reset mode under the dense env:
+    reset observation, rewards and phases of the steps, the resets of finished episodes and the RNG stream against the oracle env."""
+    import torch
+    from furniture_amd.envs import DENSE_OVERRIDES, FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.dense_reward import DenseConfig
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import counter_actions
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n, T, seed = 2, 3, 71
+    over = dict(DENSE_OVERRIDES)
+    over.update(record_vid=False, max_episode_steps=T, seed=seed, reset_robot_after_attach=True)
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(**over), dense=True)
+    okw = {k: over[k] for k in ("auto_align", "alignment_pos_dist", "alignment_rot_dist_up", "alignment_rot_dist_forward", "alignment_project_dist")}
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=T, seed=seed + i, solver_tolerance=1e-10, reset_robot_after_attach=True,
+                                               dense=DenseConfig(reset_robot_after_attach=True), **okw)) for i in range(n)]
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+
+    def streams_agree():
+        for i in range(n):
+            a_, b_ = env._sampler.rngs[i].get_state(), orcs[i]._rng.get_state()
+            assert a_[2] == b_[2] and np.array_equal(a_[1], b_[1]), i
+
+    od = flat(env.reset())
+    for i in range(n):
+        assert np.abs(od[i] - orcs[i].flat_obs(orcs[i].reset())).max() < 5e-5, i
+    streams_agree()
+    for t in range(2 * T):
+        a = np.stack([counter_actions(seed, i, t, 9) for i in range(n)])
+        a[:, 8] = -1.0
+        ob, rew, done, info = env.step(a)
+        for i in range(n):
+            o, r, d, inf = orcs[i].step(a[i])
+            assert bool(done[i]) == d and abs(float(rew[i]) - r) < 2e-2 * (1 + abs(r)), (t, i, float(rew[i]), r)
+            assert int(info["phase_i"][i]) == inf["phase_i"], (t, i)
+            ref = orcs[i].flat_obs(orcs[i].reset()) if d else orcs[i].flat_obs(o)
+            assert np.abs(flat(ob)[i] - ref).max() < (2e-4 if d else 1e-3), (t, i, d)
+        streams_agree()
+    env.close()
+
+
 def test_reset_robot_after_attach_resynchronises_the_ik_target():
     """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
     target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it
