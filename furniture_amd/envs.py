@@ -385,14 +385,11 @@ class FurnitureBatchEnv:
         # config.reset_robot_after_attach (furniture.py:919-925): _connect re-poses the arm with ONE draw of the env's RandomState, taken
         # between the draws of two resets.  Built as a mode of its own (see _attach_*): the env's stream is kept on the host, the kernel is
         # handed the next attach draw and the next reset table ahead of time, resets of finished episodes are issued by the host (device
-        # auto_reset off) once it knows whether the last step attached.  Combinations whose resets call _connect themselves are refused.
+        # auto_reset off) once it knows whether the last step attached.
         self._attach_mode = bool(getattr(cfg, "reset_robot_after_attach", False)) and agent != "Cursor"
-        if getattr(cfg, "reset_robot_after_attach", False):
-            # (config.preassembled: the reset's connects read their draws from rows 101.. of the noise table; config.assembled switches the
-            #  welds on without calling _connect, config.fix_init only skips later placement draws: the sampler replays both as they are)
-            for flag in ("num_connects",):
-                if getattr(cfg, flag, None):
-                    raise NotImplementedError("config.reset_robot_after_attach with config.%s (pre-assembled resets call _connect -- and draw -- inside the reset, furniture.py:1542-1566) is not built" % flag)
+        # (config.preassembled / set_subtask: the reset's connects read their draws from rows 101.. of the noise table; config.assembled
+        #  switches the welds on without calling _connect, config.fix_init only skips later placement draws, num_connects only moves the
+        #  success count: the sampler replays all of them as they are)
         names = furniture_names()
         fname = cfg.furniture_name or names[cfg.furniture_id]
         self.agent, self.furniture_name, self.config = agent, fname, cfg
@@ -536,6 +533,12 @@ class FurnitureBatchEnv:
         self.config.preassembled = list(range(int(subtask)))
         self._num_connects = num_connects
         self.sim.set_preassembled(self.config.preassembled, num_connects)
+        if self._attach_mode:
+            # config.reset_robot_after_attach: the recipe connects of the following resets take one draw each (ResetTableSampler); the
+            # speculative reset table on the device (read by a reset inside step()) was drawn for the old count
+            self._sampler.n_attach_in_reset = len(self.config.preassembled) if self.model.meta.get("has_recipe", False) and self._sampler.narm else 0
+            if getattr(self, "_attach_after_reset", None) is not None and self._attach_after_reset[0] is not None:
+                self._attach_peek(np.ones(self.num_envs, dtype=bool))
 
     def num_subtask(self):
         """furniture.py:209-213"""

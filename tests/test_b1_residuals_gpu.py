@@ -394,6 +394,45 @@ def test_reset_robot_after_attach_on_the_dense_reward_env():
     env.close()
 
 
+def test_reset_robot_after_attach_with_set_subtask():
+    """set_subtask(k) (furniture.py:204-207) changes how many recipe steps the following resets connect -- and with
+    reset_robot_after_attach how many draws they take from the stream: 1, then 2, then none again.  Device vs oracle env: reset
+    observations (part quaternions up to sign: the recipe's branch tie), num_connected, and the stream after every reset."""
+    import torch
+    from furniture_amd.envs import FurnitureBatchEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Sawyer", "table_lack_0825")
+    n, seed = 2, 83
+    env = FurnitureBatchEnv("Sawyer", n, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
+                                                           max_episode_steps=20, seed=seed, reset_robot_after_attach=True))
+    orcs = [FurnitureEnvOracle(m, OracleConfig(max_episode_steps=20, seed=seed + i, solver_tolerance=1e-10, reset_robot_after_attach=True)) for i in range(n)]
+    flat = lambda d: torch.cat([d["object_ob"], d["robot_ob"]], dim=1).cpu().numpy()
+
+    def err(x, o):
+        x = x.copy()
+        for p_ in range(m.nparts):
+            if np.dot(x[7 * p_ + 3:7 * p_ + 7], o[7 * p_ + 3:7 * p_ + 7]) < 0:
+                x[7 * p_ + 3:7 * p_ + 7] *= -1
+        return np.abs(x - o).max()
+
+    for k, ndraw in ((0, 0), (1, 1), (2, 3), (0, 3)):
+        if k or ndraw:
+            env.set_subtask(k)
+            for o in orcs:
+                o.set_subtask(k)
+        od = flat(env.reset())
+        for i in range(n):
+            assert err(od[i], orcs[i].flat_obs(orcs[i].reset())) < 2e-4, (k, i)
+            assert len(orcs[i].attach_draws) == ndraw  # (the oracle's list grows by k per reset)
+            a_, b_ = env._sampler.rngs[i].get_state(), orcs[i]._rng.get_state()
+            assert a_[2] == b_[2] and np.array_equal(a_[1], b_[1]), (k, i)
+        ob, rew, done, info = env.step(np.zeros((n, 9), dtype=np.float32))
+        res = [orcs[i].step(np.zeros(9)) for i in range(n)]
+        assert [int(x) for x in info["num_connected"]] == [r[3]["num_connected"] for r in res] == [k] * n  # (the reset's own connects count)
+    env.close()
+
+
 def test_reset_robot_after_attach_resynchronises_the_ik_target():
     """The same option under control_type="ik": after the re-pose `_connect` calls `controller.sync_state()` (furniture.py:921-924) -- the IK
     target position becomes the chain's forward kinematics at the NEW joints; without it the next IK step would pull the arm back to where it
