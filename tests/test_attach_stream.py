@@ -127,3 +127,28 @@ def test_attach_mode_consumes_the_stream_like_the_reference():
             s1, s2 = env._sampler.rngs[i].get_state(), ref[i].get_state()
             assert s1[2] == s2[2] and np.array_equal(s1[1], s2[1]), i
 
+
+def test_in_reset_attach_draws_sit_between_placement_and_robot_initialisation():
+    """config.reset_robot_after_attach with config.preassembled on a furniture with a recipe (round 4): the reset's own _connect calls take
+    one draw each (furniture.py:919-925 inside :1542-1557) between the placement's draws and the 101 of the robot initialisation.  The
+    host sampler against the oracle env's recorded draws, two resets, one and two recipe steps: placement, the 101 noise rows, and the
+    in-reset rows behind them (rows 101..); the generators end in the same state."""
+    import numpy as np
+    from furniture_amd.envs import ResetTableSampler, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Sawyer", "table_lack_0825")
+    for pre in ([0], [0, 1]):
+        cfg = make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825", max_episode_steps=3, seed=53,
+                          reset_robot_after_attach=True, preassembled=pre)
+        s = ResetTableSampler(m, cfg, 53, 0, 1)
+        assert s.n_attach_in_reset == len(pre)
+        o = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=3, seed=53, solver_tolerance=1e-10, reset_robot_after_attach=True, preassembled=pre))
+        for rep in range(2):
+            parts, noise = s.draw()
+            o.reset()
+            assert np.abs(parts[0] - o.reset_draws["part_qpos"].reshape(-1)).max() < 1e-6
+            assert np.abs(noise[0][:707] - np.stack(o.reset_draws["noise"]).reshape(-1)).max() < 1e-9
+            assert np.abs(noise[0][707:] - np.concatenate(o.attach_draws[-len(pre):])).max() < 1e-9
+            a, b = s.rngs[0].get_state(), o._rng.get_state()
+            assert a[2] == b[2] and np.array_equal(a[1], b[1])

@@ -70,15 +70,6 @@ def test_unsupported_reference_options_fail_loudly(flag):
                                                           furniture_name="table_lack_0825", **{flag: True}))
 
 
-@pytest.mark.parametrize("other", [dict(preassembled=[0]), dict(assembled=True), dict(fix_init=True)])
-def test_reset_robot_after_attach_refuses_the_resets_that_connect_themselves(other):
-    """config.reset_robot_after_attach is built (tests/test_b1_residuals_gpu.py) -- except together with the options whose resets call
-    _connect, and therefore draw from the env's stream, inside the reset (furniture.py:1542-1566): refused before any device work."""
-    with pytest.raises(NotImplementedError, match="reset_robot_after_attach"):
-        FurnitureBatchEnv("Sawyer", 1, config=make_config(unity=False, record_vid=False, control_type="impedance", furniture_name="table_lack_0825",
-                                                          reset_robot_after_attach=True, **other))
-
-
 @pytest.mark.gpu
 def test_bf16_observation_slab_is_the_rounded_f32_one():
     """fsim_config_t.obs_bf16 (BASELINE config 2's narrow observation slab; SURVEY 8b `void* obs f32|bf16`): same state, same
