@@ -270,7 +270,11 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
       const int slot = __builtin_amdgcn_readfirstlane(*s_slot);
       __syncthreads(); // (everybody has read the slot before wave 0 goes on and overwrites it)
       if (slot >= nmw) break;
-      const CtxM c(L, m, *(CLayout *)lp_mw, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
+      // (the thread index through an opaque copy, here and in the loops below: per-lane address arithmetic of the env code then cannot be
+      //  hoisted out of the persistent loops to the kernel's entry, where it was spilled -- ~92 scratch stores per wave of every launch)
+      int tid_ = (int)threadIdx.x;
+      __asm__ volatile("" : "+v"(tid_));
+      const CtxM c(L, m, *(CLayout *)lp_mw, tid_, kp.newton_maxit, kp.newton_tol);
       if (c.wave > 0) { mw_helper_fn(c); continue; }
       const int env = mworder[slot];
       if (env_run<CtxM, true>(c, a, env, t_entry)) { defs = (defs << 16) | (unsigned)env; ndef++; }
@@ -278,10 +282,12 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
     }
   }
   {
-    const CtxB c(L, m, *(CLayout *)lp, (int)threadIdx.x, kp.newton_maxit, kp.newton_tol);
     const int nb = q[1];
     bool first = true;
     for (;; first = false) {
+      int tid_ = (int)threadIdx.x;
+      __asm__ volatile("" : "+v"(tid_));
+      const CtxB c(L, m, *(CLayout *)lp, tid_, kp.newton_maxit, kp.newton_tol);
       int env, job = JOB_AUTO;
       if (ndef > 0) { env = (int)(defs & 0xffffu); defs >>= 16; ndef--; job = JOB_RESET; } // (wave 0 only: ndef is 0 on the others)
       else {
@@ -298,6 +304,9 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
     if (a.sh_jobs) {
       const int nj = q[4];
       for (;; first = false) {
+        int tid_ = (int)threadIdx.x;
+        __asm__ volatile("" : "+v"(tid_));
+        const CtxB c(L, m, *(CLayout *)lp, tid_, kp.newton_maxit, kp.newton_tol);
         int j = 0;
         if (c.lane == 0) j = atomicAdd(q + 5, 1);
         j = __builtin_amdgcn_readfirstlane(j);
@@ -756,7 +765,11 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
       s->mw_mode = (can_rule && n_envs <= 8 * pr.multiProcessorCount) ? MW_RULE : MW_OFF;
     }
     s->x_resident = 2 * pr.multiProcessorCount;
-    s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 8), s->x_resident);
+    // workgroups of a launch: the one-wave envs in bundles of four plus a sixteenth of the batch for four-wave teams (2-4 % of the envs are
+    // multi-wave; more of them than teams are served in turn), at most what is resident at once.  Every wave of the launch pays ~92
+    // scratch stores at entry (the argument block does not fit the SGPRs of the persistent loop): n/4 + n/8 workgroups measured the same
+    // throughput with 20 % more HBM writes (round 4, FSIM_X_GRID sweep: 256 .. 512 flat)
+    s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 16), s->x_resident);
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
     if (s->mw_mode) {
