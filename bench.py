@@ -449,6 +449,9 @@ def main():
                        "lookahead_reset_units_in_timed_region": la["units"],  # reset substeps run by look-ahead jobs (waves of the step launches that had no env left)
                        "reset_substeps_in_timed_region": la["units"] + la["inline"] * reset_substeps,
                        "envs_that_dropped_contacts": dropped, "contact_slots": slabs[0].sim.max_contacts,
+                       # env-steps (warm-up included) the library repeated with a 64-slot layout because 48 slots did not hold their contacts
+                       # (fsim_overflow_resteps: done inside fsim_sync, i.e. inside the timed region)
+                       "overflow_resteps": int(sum(sl.sim.overflow_resteps() for sl in slabs)),
                        "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
             # `bound`: what the contract's two choices are priced against is HBM (BASELINE.json asks for the HBM fraction) and `frac` is

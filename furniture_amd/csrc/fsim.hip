@@ -102,6 +102,12 @@ struct StepArgs {
   const int *tab_serial; // [n] serial number of the reset table on the device (bumped by the host with every upload)
   const int *sh_jobs;    // look-ahead jobs of this launch (env indices, listed by k_schedule; q[4] of them), or null
   int la_chunk;          // reset units per look-ahead job
+  // Contact-overflow re-step (round 4): every step launch leaves the pre-step record of each env in `prev` and lists the envs whose step
+  // dropped contacts (ovf_list / *ovf_count, host-mapped); fsim_sync re-steps those from `prev` (state_in) with a layout of more slots.
+  float *prev;
+  const float *state_in;
+  int *ovf_list, *ovf_count;
+  int ovf_cap;
   int *stats; // host-mapped counters (fsim::h_nreset + 1): [0] resets taken from a shadow record, [1] resets executed in a step / reset launch, [2] reset units run by look-ahead jobs
 };
 enum { JOB_AUTO = 0 /* a.do_step decides */, JOB_RESET = 1 /* the deferred reset of a multi-wave workgroup's env */ };
@@ -116,7 +122,8 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
 #ifdef FSIM_TIMELINE
   const long long tw0_ = wall_clock64(); // (100 MHz, one counter for the whole device: clock64() has an offset per XCD)
 #endif
-  load_record(L, rec, c.ly.stride, lane);
+  load_record(L, a.state_in ? a.state_in + (size_t)env * c.ly.stride : rec, c.ly.stride, lane);
+  if (a.prev && job != JOB_RESET) store_record(a.prev + (size_t)env * c.ly.stride, L, c.ly.stride, lane); // (what a re-step starts from)
   const int twords = reinterpret_cast<int *>(L + c.ly.scal)[SC_TWORDS]; // (set by fs_load_cache: survives the per-env clearing)
   for (int i = lane; i < SC_WORDS; i += 64) reinterpret_cast<int *>(L + c.ly.scal)[i] = 0;
   if constexpr (Ctx::NW > 1) if (lane < FSIM_MWCW) c.I(c.ly.mwc)[lane] = 0;
@@ -156,6 +163,10 @@ template <class Ctx, bool DEFER = false> DEV int env_run(const Ctx &c, const Ste
   else if (!a.reset_mask || a.reset_mask[env]) env_reset_or_swap(c, cfg, io);
   if constexpr (Ctx::NW > 1) mw_post(c, MW_EXIT);
   SYNC();
+  if (a.ovf_count && lane == 0 && reinterpret_cast<const int *>(L + c.ly.scal)[SC_OVERFLOW] != 0) { // this launch dropped contacts of this env
+    const int k = __hip_atomic_fetch_add(a.ovf_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (k < a.ovf_cap) a.ovf_list[k] = env;
+  }
 #ifdef FSIM_PROFILE
 #ifdef FSIM_TIMELINE
   // development: when and where this workgroup ran (scripts/dev/timeline.py: how many are resident at a time)
@@ -459,6 +470,7 @@ typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, con
 typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
 #define FSIM_LA_MAXJOBS 512 // look-ahead jobs per launch, at most
+#define FSIM_OVF_CAP 1024    // envs of one step launch the overflow re-step lists, at most (the others keep their sticky report)
 struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 enum { MW_OFF = 0, MW_RULE = 1, MW_ALL = 2 }; // fsim::mw_mode
 
@@ -479,6 +491,16 @@ struct fsim {
   int *d_mworder = nullptr, *d_mwn = nullptr; // q: [0] multi-wave envs of the launch, [1] the others, [2] / [3] heads of the bundle / multi-wave queues, [4] look-ahead jobs, [5] head of their queue
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   int x_grid = 0;                             // workgroups of a k_env_step_x launch
+  // contact-overflow re-step (StepArgs::prev ...): an env whose step needed more contact slots than the step kernel's LDS image holds is
+  // stepped again from its pre-step record by a four-wave team with a 64-slot layout (the team has the LDS of four envs), at fsim_sync
+  bool redo_on = false, redo_armed = false;
+  float *d_prev = nullptr;
+  int *d_ovf_list = nullptr;
+  Layout ly_r{};
+  Layout *d_ly_r = nullptr;
+  int lds_bytes_r = 0;
+  int64_t n_redone = 0;
+  struct { const float *action; void *obs; float *reward; uint8_t *done; int32_t *info; } last{};
   DModel m{};
   Layout ly{};
   fsim_config_t cfg{};
@@ -771,6 +793,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     // throughput with 20 % more HBM writes (round 4, FSIM_X_GRID sweep: 256 .. 512 flat)
     s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 16), s->x_resident);
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
+    // overflow re-step: models on the default 48 slots (the benchmark's LDS budget), stepped again with 64 slots and longer broadphase lists
+    if (ncon_max == 48 && s->m.nv <= 64 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
+      LayoutIn lr = lin;
+      lr.ncon_max = 64; lr.maxsurv = std::max(lin.maxsurv, 128);
+      s->ly_r = make_layout(lr, FSIM_MW_NW);
+      s->lds_bytes_r = s->ly_r.lds_words * 4;
+      s->redo_on = s->lds_bytes_r <= 160 * 1024 && s->ly_r.stride == s->ly.stride;
+    }
     snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
     if (s->mw_mode) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics_mw), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_mw));
@@ -857,6 +887,13 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
+  if (s->redo_on) {
+    HIPCHK(hipMalloc(&s->d_ly_r, sizeof(Layout)));
+    HIPCHK(hipMemcpy(s->d_ly_r, &s->ly_r, sizeof(Layout), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&s->d_prev, (size_t)n_envs * s->ly.stride * 4));
+    HIPCHK(hipMalloc(&s->d_ovf_list, FSIM_OVF_CAP * 4));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_step<GenCtxT<FSIM_MW_NW>>), hipFuncAttributeMaxDynamicSharedMemorySize, std::max(s->lds_bytes_r, s->lds_bytes_mw)));
+  }
   *out = s;
   return FSIM_OK;
 }
@@ -867,6 +904,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_prog); hipFree(s->d_sh_serial); hipFree(s->d_tab_serial); hipFree(s->d_sh_jobs);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
+  hipFree(s->d_ly_r); hipFree(s->d_prev); hipFree(s->d_ovf_list);
   hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -889,7 +927,17 @@ extern "C" const char *fsim_kernel_variant(const fsim_t *s) { return s && s->ks.
 extern "C" const char *fsim_step_kernel(const fsim_t *s) { return s ? s->step_kernel : ""; }
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
-extern "C" int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); HIPCHK(hipSetDevice(s->device)); HIPCHK(hipStreamSynchronize(s->stream)); return FSIM_OK; }
+static int redo_overflowed(fsim *s);
+extern "C" int fsim_sync(fsim_t *s) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->redo_armed) { // (the last launch was a step: did any env of it drop contacts?)
+    s->redo_armed = false;
+    if (s->h_nreset[4] > 0) return redo_overflowed(s);
+  }
+  return FSIM_OK;
+}
 
 static KParams kparams(const fsim *s, int nsub, int mode) {
   KParams kp;
@@ -1102,6 +1150,7 @@ static int la_new_tables(fsim *s, const uint8_t *mask) {
   }
   return FSIM_OK;
 }
+extern "C" int64_t fsim_overflow_resteps(const fsim_t *s) { return s ? s->n_redone : 0; }
 extern "C" int fsim_lookahead_stats(fsim_t *s, int64_t *out) {
   if (!s || !out) FAIL(FSIM_EINVAL, "null");
   out[0] = s->la_on ? 1 : 0; out[1] = s->h_nreset[3]; out[2] = s->h_nreset[1]; out[3] = s->h_nreset[2]; out[4] = s->la_jobs; out[5] = s->la_chunk;
@@ -1132,6 +1181,13 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = do_step ? s->d_nreset : nullptr;
   a.stats = s->d_nreset + 1;
+  a.prev = nullptr; a.state_in = nullptr; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
+  if (do_step && s->redo_on) {
+    a.prev = s->d_prev; a.ovf_list = s->d_ovf_list; a.ovf_count = s->d_nreset + 4; a.ovf_cap = FSIM_OVF_CAP;
+    s->h_nreset[4] = 0;
+    s->last = {action, obs, reward, done, info};
+  }
+  s->redo_armed = do_step && s->redo_on;
   a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
   if (s->la_on) { a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_prog = s->d_sh_prog; a.sh_serial = s->d_sh_serial; a.tab_serial = s->d_tab_serial; }
   const bool jobs = sched && s->la_on && s->d_tab_parts && !mw_all; // (k_schedule has listed them)
@@ -1153,6 +1209,39 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   hipError_t e = hipGetLastError();
   if (s->timing) timing_end(s);
   if (e != hipSuccess) FAIL(FSIM_EHIP, "k_env_step launch: %s", hipGetErrorString(e));
+  return FSIM_OK;
+}
+// The envs the last step launch listed (StepArgs::ovf_list: their step needed more contact slots / longer broadphase lists than the
+// step kernel's LDS image holds, and dropped the rest) are stepped AGAIN from their pre-step records by the generic four-wave kernel
+// with a 64-slot layout -- one workgroup per env, the whole 25 KB image in the team's LDS -- before fsim_sync returns: record,
+// observation, reward, done and info rows of those envs are overwritten.  Rare (Sawyer + table_lack_0825: 1.6 per million env-steps),
+// so its cost is a second small launch on those steps.  A deterministic function of the env's own pre-step record and action; the
+// counters the first pass advanced (tables needed, reset statistics) are not advanced again; an env that overflows 64 slots too keeps
+// its sticky report.  Consumers that read the step's outputs in stream order WITHOUT fsim_sync (an RCCL gather enqueued behind the step
+// kernel) see the first pass's rows for such an env.
+static int redo_overflowed(fsim *s) {
+  int cnt = std::min(s->h_nreset[4], FSIM_OVF_CAP);
+  std::vector<int> list(cnt);
+  HIPCHK(hipMemcpy(list.data(), s->d_ovf_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  std::sort(list.begin(), list.end());
+  list.erase(std::unique(list.begin(), list.end()), list.end()); // (a deferred reset is a second pass over the same env)
+  cnt = (int)list.size();
+  HIPCHK(hipMemcpy(s->d_ovf_list, list.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+  KParams kp = kparams(s, s->cfg.n_substeps, 0);
+  kp.n_envs = cnt; // (workgroups beyond the list do nothing)
+  StepArgs a;
+  a.cfg = s->ecfg; a.state = s->d_state; a.action = s->last.action; a.obs = reinterpret_cast<float *>(s->last.obs); a.reward = s->last.reward; a.done = s->last.done; a.info = s->last.info;
+  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = nullptr; a.do_step = 1;
+  a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = s->d_cost; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
+  a.nreset = nullptr; a.stats = nullptr;
+  a.prev = nullptr; a.state_in = s->d_prev; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
+  a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
+  a.cfg_dev = s->d_ecfg;
+  hipLaunchKernelGGL(k_env_step<GenCtxT<FSIM_MW_NW>>, dim3(cnt), dim3(64 * FSIM_MW_NW), s->lds_bytes_r, s->stream, s->d_m, s->d_ly_r, kp, a, s->d_ovf_list, s->d_mwn);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(FSIM_EHIP, "overflow re-step launch: %s", hipGetErrorString(e));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->n_redone += cnt;
   return FSIM_OK;
 }
 // ---- dense-reward env

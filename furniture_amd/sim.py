@@ -130,6 +130,8 @@ def lib():
         L.fsim_step_kernel.argtypes = [ctypes.c_void_p]
         L.fsim_step_kernel.restype = ctypes.c_char_p
         L.fsim_lookahead_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_overflow_resteps.argtypes = [ctypes.c_void_p]
+        L.fsim_overflow_resteps.restype = ctypes.c_int64
         L.fsim_set_reset_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_set_attach_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -150,7 +152,7 @@ EXPORTED_SYMBOLS = [
     "fsim_physics_step", "fsim_physics_forward", "fsim_get_state", "fsim_set_state", "fsim_max_contacts",
     "fsim_set_reset_tables", "fsim_reset", "fsim_step", "fsim_kernel_time_ms", "fsim_set_dense_reward", "fsim_dense_replay",
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
-    "fsim_step_kernel", "fsim_lookahead_stats",
+    "fsim_step_kernel", "fsim_lookahead_stats", "fsim_overflow_resteps",
     "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
 ]
 
@@ -374,6 +376,10 @@ class FSim:
         out = (ctypes.c_int64 * 6)()
         self._chk(lib().fsim_lookahead_stats(self._h, out))
         return dict(zip(("enabled", "units", "swapped", "inline", "jobs_per_launch", "units_per_job"), [int(x) for x in out]))
+
+    def overflow_resteps(self):
+        """fsim_overflow_resteps: env-steps repeated with a 64-slot layout because the step kernel's 48 contact slots did not hold them"""
+        return int(lib().fsim_overflow_resteps(self._h))
 
     def set_max_episode_steps(self, n):
         self._chk(lib().fsim_set_max_episode_steps(self._h, int(n)))
