@@ -928,15 +928,20 @@ extern "C" const char *fsim_step_kernel(const fsim_t *s) { return s ? s->step_ke
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 static int redo_overflowed(fsim *s);
+// After a step launch and before anything else reads or advances the records: wait for it and re-step the envs that dropped contacts
+// (a caller that queues two steps without fsim_sync in between gets the wait here: the second step must start from corrected records).
+static int settle(fsim *s) {
+  if (!s->redo_armed) return FSIM_OK;
+  s->redo_armed = false;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->h_nreset[4] > 0) return redo_overflowed(s);
+  return FSIM_OK;
+}
 extern "C" int fsim_sync(fsim_t *s) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (s->redo_armed) { // (the last launch was a step: did any env of it drop contacts?)
-    s->redo_armed = false;
-    if (s->h_nreset[4] > 0) return redo_overflowed(s);
-  }
-  return FSIM_OK;
+  return settle(s);
 }
 
 static KParams kparams(const fsim *s, int nsub, int mode) {
@@ -957,6 +962,7 @@ static void timing_collect(fsim *s) {
 extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
   if (!s || nsub < 0) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, nsub, 0), s->d_state, s->d_aux);
   else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
@@ -965,6 +971,7 @@ extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
 extern "C" int fsim_physics_forward(fsim_t *s) {
   if (!s) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, 0, 1), s->d_state, s->d_aux);
   else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
@@ -981,6 +988,7 @@ static int copy_field(fsim *s, int off, int dim, void *ext, int to_state) {
 static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if (!s || !p) FAIL(FSIM_EINVAL, "null");
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   const DModel &m = s->m;
   const Layout &ly = s->ly;
   int rc;
@@ -1159,6 +1167,7 @@ extern "C" int fsim_lookahead_stats(fsim_t *s, int64_t *out) {
 
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   if (s->timing) timing_collect(s);
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
