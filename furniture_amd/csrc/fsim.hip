@@ -229,7 +229,10 @@ template <class Ctx> DEV void env_shadow_job(const Ctx &c, const StepArgs &a, in
   SYNC();
   store_record(rec, L, c.ly.stride, lane);
   if (lane == 0) {
-    a.sh_prog[env] = p1; a.sh_serial[env] = serial;
+    // (a shadow whose reset dropped contacts is never valid -- progress beyond "consumed": the terminal step then resets inside its
+    //  launch, where the overflow re-step can repeat it with more slots; the jobs stop being listed)
+    const bool dropped = reinterpret_cast<const int *>(L + c.ly.env)[E_OVERFLOW] != 0;
+    a.sh_prog[env] = dropped ? total + 1 : p1; a.sh_serial[env] = serial;
     if (a.stats) __hip_atomic_fetch_add(a.stats + 2, p1 - prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
