@@ -288,6 +288,7 @@ def main():
         sl.gen = torch.Generator(device=dev)
         sl.gen.manual_seed(SEED + rank * 64 + g)
         sl.inflight = False
+        sl.resteps = 0
         sl.pg = dist.new_group() if distributed else None  # one RCCL communicator (= one internal stream) per slab
         sl.sim.reset(None, sl.obs)
         sl.sim.sync()
@@ -300,6 +301,13 @@ def main():
             return
         sl.sim.sync()  # the handle's stream: step kernel + the gather chained behind it
         sl.inflight = False
+        r = sl.sim.overflow_resteps()
+        if r != sl.resteps:
+            # (rare -- 1.6 per million env-steps: fsim_sync has just re-stepped an env whose contacts did not fit 48 slots and rewritten
+            #  its rows; the gather that was chained behind the step kernel carried the first pass's rows: gather this slab again)
+            sl.resteps = r
+            sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
+            sl.sim.sync()
         if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
             t_h = time.perf_counter()
             # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave
