@@ -501,7 +501,9 @@ struct fsim {
   int *d_ovf_list = nullptr;
   Layout ly_r{};
   Layout *d_ly_r = nullptr;
-  int lds_bytes_r = 0;
+  int lds_bytes_r = 0, redo_block = 0, redo_slots = 0;
+  EnvStepFn redo_kernel = nullptr;            // 48 -> 64 slots: the generic four-wave kernel; 64 -> 128: the generic one-wave kernel with two slots per lane
+  int last_do_step = 0;
   int64_t n_redone = 0;
   struct { const float *action; void *obs; float *reward; uint8_t *done; int32_t *info; } last{};
   DModel m{};
@@ -797,11 +799,15 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 16), s->x_resident);
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     // overflow re-step: models on the default 48 slots (the benchmark's LDS budget), stepped again with 64 slots and longer broadphase lists
-    if (ncon_max == 48 && s->m.nv <= 64 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
+    if ((ncon_max == 48 || ncon_max == 64) && s->m.nv <= 64 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
       LayoutIn lr = lin;
-      lr.ncon_max = 64; lr.maxsurv = std::max(lin.maxsurv, 128);
-      s->ly_r = make_layout(lr, FSIM_MW_NW);
+      const bool big = ncon_max == 64; // (128 slots: two per lane, the one-wave kernel of the `generic2` set; the workgroup has the CU's LDS to itself)
+      lr.ncon_max = big ? 128 : 64; lr.maxsurv = std::max(lin.maxsurv, big ? 192 : 128);
+      s->ly_r = make_layout(lr, big ? 1 : FSIM_MW_NW);
       s->lds_bytes_r = s->ly_r.lds_words * 4;
+      s->redo_kernel = big ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 2>>) : static_cast<EnvStepFn>(k_env_step<GenCtxT<FSIM_MW_NW>>);
+      s->redo_block = big ? 64 : 64 * FSIM_MW_NW;
+      s->redo_slots = lr.ncon_max;
       s->redo_on = s->lds_bytes_r <= 160 * 1024 && s->ly_r.stride == s->ly.stride;
     }
     snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
@@ -895,7 +901,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     HIPCHK(hipMemcpy(s->d_ly_r, &s->ly_r, sizeof(Layout), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&s->d_prev, (size_t)n_envs * s->ly.stride * 4));
     HIPCHK(hipMalloc(&s->d_ovf_list, FSIM_OVF_CAP * 4));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_env_step<GenCtxT<FSIM_MW_NW>>), hipFuncAttributeMaxDynamicSharedMemorySize, std::max(s->lds_bytes_r, s->lds_bytes_mw)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->redo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, std::max(s->lds_bytes_r, std::max(s->lds_bytes_mw, s->lds_bytes))));
   }
   *out = s;
   return FSIM_OK;
@@ -1194,12 +1200,13 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   a.nreset = do_step ? s->d_nreset : nullptr;
   a.stats = s->d_nreset + 1;
   a.prev = nullptr; a.state_in = nullptr; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
-  if (do_step && s->redo_on) {
+  if (s->redo_on) { // (step AND reset launches: a reset that drops contacts is repeated the same way)
     a.prev = s->d_prev; a.ovf_list = s->d_ovf_list; a.ovf_count = s->d_nreset + 4; a.ovf_cap = FSIM_OVF_CAP;
     s->h_nreset[4] = 0;
     s->last = {action, obs, reward, done, info};
+    s->last_do_step = do_step;
   }
-  s->redo_armed = do_step && s->redo_on;
+  s->redo_armed = s->redo_on;
   a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
   if (s->la_on) { a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_prog = s->d_sh_prog; a.sh_serial = s->d_sh_serial; a.tab_serial = s->d_tab_serial; }
   const bool jobs = sched && s->la_on && s->d_tab_parts && !mw_all; // (k_schedule has listed them)
@@ -1225,7 +1232,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
 }
 // The envs the last step launch listed (StepArgs::ovf_list: their step needed more contact slots / longer broadphase lists than the
 // step kernel's LDS image holds, and dropped the rest) are stepped AGAIN from their pre-step records by the generic four-wave kernel
-// with a 64-slot layout -- one workgroup per env, the whole 25 KB image in the team's LDS -- before fsim_sync returns: record,
+// with a 64-slot layout -- one workgroup per env, the whole 25 KB image in the team's LDS; for models on 64 slots: the generic one-wave kernel with 128 -- before fsim_sync returns: record,
 // observation, reward, done and info rows of those envs are overwritten.  Rare (Sawyer + table_lack_0825: 1.6 per million env-steps),
 // so its cost is a second small launch on those steps.  A deterministic function of the env's own pre-step record and action; the
 // counters the first pass advanced (tables needed, reset statistics) are not advanced again; an env that overflows 64 slots too keeps
@@ -1243,13 +1250,13 @@ static int redo_overflowed(fsim *s) {
   kp.n_envs = cnt; // (workgroups beyond the list do nothing)
   StepArgs a;
   a.cfg = s->ecfg; a.state = s->d_state; a.action = s->last.action; a.obs = reinterpret_cast<float *>(s->last.obs); a.reward = s->last.reward; a.done = s->last.done; a.info = s->last.info;
-  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = nullptr; a.do_step = 1;
-  a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = s->d_cost; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
+  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = nullptr; a.do_step = s->last_do_step;
+  a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = s->last_do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
   a.nreset = nullptr; a.stats = nullptr;
   a.prev = nullptr; a.state_in = s->d_prev; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
   a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
   a.cfg_dev = s->d_ecfg;
-  hipLaunchKernelGGL(k_env_step<GenCtxT<FSIM_MW_NW>>, dim3(cnt), dim3(64 * FSIM_MW_NW), s->lds_bytes_r, s->stream, s->d_m, s->d_ly_r, kp, a, s->d_ovf_list, s->d_mwn);
+  hipLaunchKernelGGL(s->redo_kernel, dim3(cnt), dim3(s->redo_block), s->lds_bytes_r, s->stream, s->d_m, s->d_ly_r, kp, a, s->d_ovf_list, s->d_mwn);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) FAIL(FSIM_EHIP, "overflow re-step launch: %s", hipGetErrorString(e));
   HIPCHK(hipStreamSynchronize(s->stream));

@@ -181,7 +181,8 @@ int fsim_lookahead_stats(fsim_t *, int64_t *out);
  * the default 48 contact slots (what lets eight envs share a CU's LDS) occasionally need more: Sawyer + table_lack_0825 about 1.6 times
  * per million env-steps.  Every step launch keeps each env's pre-step record and lists the envs that dropped contacts; fsim_sync() steps
  * those again from the kept record with a 64-slot layout (one four-wave workgroup per env) and overwrites their record and output rows
- * before it returns.  Returns how many env-steps were repeated so far.  FSIM_NO_OVERFLOW_REDO=1 switches it off (the sticky report of
+ * before it returns.  Reset launches are covered the same way, and models that run on 64 slots are repeated with 128 (one-wave kernel, two
+ * slots per lane).  Returns how many env-steps were repeated so far.  FSIM_NO_OVERFLOW_REDO=1 switches it off (the sticky report of
  * FSIM_INFO_OVERFLOW is then all there is).  Outputs read in stream order without fsim_sync carry the first pass's rows. */
 int64_t fsim_overflow_resteps(const fsim_t *);
 

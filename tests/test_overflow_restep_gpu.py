@@ -70,3 +70,27 @@ def test_an_env_that_overflows_48_contact_slots_is_stepped_again_with_64(monkeyp
     err_off = [float(np.abs(off["trace"][t][e].cpu().numpy() - ref[t]).max()) for t in range(STEPS + 1)]
     print("env %d: obs error vs oracle per step, with the re-step %s, without %s" % (e, np.round(err_on, 5), np.round(err_off, 5)))
     assert max(err_on) < 2e-3, err_on
+
+
+def test_a_reset_that_overflows_64_slots_is_repeated_with_128(monkeypatch):
+    """The same mechanism for RESET launches and for models on 64 slots (re-step kernel: the generic one-wave kernel with two slots per
+    lane).  table_bjorkudden_0207 under config.assembled: the welds yank the parts together through more simultaneous contacts than 64
+    slots hold -- reset() used to raise."""
+    from furniture_amd.envs import ContactOverflowError, make_vec_env
+    kw = dict(furniture_name="table_bjorkudden_0207", max_episode_steps=5, seed=3, record_vid=False, unity=False, control_type="impedance", assembled=True)
+    monkeypatch.setenv("FSIM_NO_OVERFLOW_REDO", "1")
+    env = make_vec_env("Sawyer", 2, **kw)
+    assert env.sim.max_contacts == 64
+    with pytest.raises(ContactOverflowError):
+        env.reset()
+    env.close()
+    monkeypatch.delenv("FSIM_NO_OVERFLOW_REDO")
+    env = make_vec_env("Sawyer", 2, **kw)
+    ob = env.reset()
+    assert env.sim.overflow_resteps() >= 1
+    assert not bool((env.sim.get_state("env_block")["env_block"].view(torch.int32)[:, E_OVERFLOW] != 0).any())
+    assert bool(torch.isfinite(ob["object_ob"]).all())
+    for t in range(3):
+        ob, rew, done, info = env.step(torch.zeros((2, env.dof), device=env.sim.device))
+    assert bool(torch.isfinite(ob["object_ob"]).all()) and not bool((info["contact_overflow"] != 0).any())
+    env.close()
