@@ -587,7 +587,7 @@ extern "C" void fsim_default_config(fsim_config_t *c) {
   c->control_type = 0; c->n_substeps = 50; c->max_episode_steps = 2000; c->discrete_grip = 1; c->rescale_actions = 1;
   c->auto_align = 1; c->num_connect_steps = 0; c->auto_reset = 1; c->solver_iterations = 100; c->reset_robot_after_attach = 0;
   c->solver_tolerance = 1e-6f;
-  c->multi_wave = 0; c->lookahead_reset = 1;
+  c->multi_wave = 0; c->lookahead_reset = 1; c->overflow_restep = 1;
   c->alignment_pos_dist = 0.1f; c->alignment_rot_dist_up = 0.9f; c->alignment_rot_dist_forward = 0.9f; c->alignment_project_dist = 0.3f;
   c->ctrl_penalty_coef = 1e-3f; c->unstable_penalty_coef = 100.f; c->success_reward = 100.f; c->touch_reward = 10.f; c->pick_reward = 100.f;
   c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3.f; c->agent_xyz_rand = 0.001f;
@@ -799,7 +799,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 16), s->x_resident);
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     // overflow re-step: models on the default 48 slots (the benchmark's LDS budget), stepped again with 64 slots and longer broadphase lists
-    if ((ncon_max == 48 || ncon_max == 64) && s->m.nv <= 64 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
+    if ((ncon_max == 48 || ncon_max == 64) && s->m.nv <= 64 && s->cfg.overflow_restep != 0 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
       LayoutIn lr = lin;
       const bool big = ncon_max == 64; // (128 slots: two per lane, the one-wave kernel of the `generic2` set; the workgroup has the CU's LDS to itself)
       lr.ncon_max = big ? 128 : 64; lr.maxsurv = std::max(lin.maxsurv, big ? 192 : 128);

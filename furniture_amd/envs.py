@@ -419,6 +419,7 @@ class FurnitureBatchEnv:
         from .sim import MULTI_WAVE
         c.multi_wave = MULTI_WAVE[getattr(cfg, "multi_wave", None) or "auto"]
         c.lookahead_reset = 1 if getattr(cfg, "lookahead_reset", True) else 0
+        c.overflow_restep = 1 if getattr(cfg, "overflow_restep", True) else 0
         self.dense = bool(dense)
         self.sim = FSim(self.model, num_envs, device=device, config=c)
         if dense:

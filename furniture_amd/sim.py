@@ -42,7 +42,7 @@ class FsimConfig(ctypes.Structure):
         ("furn_xyz_rand", ctypes.c_float), ("furn_rot_rand", ctypes.c_float), ("agent_xyz_rand", ctypes.c_float),
         ("move_speed", ctypes.c_float), ("rotate_speed", ctypes.c_float), ("cursor_boundary", ctypes.c_float),
         ("dense_reward", ctypes.c_int32), ("obs_bf16", ctypes.c_int32),
-        ("multi_wave", ctypes.c_int32), ("lookahead_reset", ctypes.c_int32),
+        ("multi_wave", ctypes.c_int32), ("lookahead_reset", ctypes.c_int32), ("overflow_restep", ctypes.c_int32),
     ]
 
 

@@ -80,6 +80,9 @@ typedef struct fsim_config {
                                  301 / 401 reset substeps inside its launch.  Same loop on the same inputs: bit-identical to the in-launch reset,
                                  which remains the fallback whenever the shadow is not complete.  Not used with the arm controllers, ik /
                                  ik_quaternion, reset_robot_after_attach and multi_wave = all.  0: off. */
+  int32_t overflow_restep;    /* 1 (default): a step or reset that needs more contact slots than the kernel's LDS image holds (48 / 64) is repeated
+                                 with 64 / 128 before fsim_sync returns (fsim_overflow_resteps).  0: off -- the sticky report of FSIM_INFO_OVERFLOW
+                                 is then all there is. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
