@@ -31,6 +31,24 @@ def test_config_struct_matches_header_defaults():
     assert abs(c.alignment_pos_dist - 0.1) < 1e-7 and abs(c.pick_reward - 100) < 1e-7 and abs(c.agent_xyz_rand - 0.001) < 1e-9
 
 
+def test_python_config_struct_has_the_headers_fields_in_the_headers_order():
+    """fsim_config_t crosses the C-ABI by value: the ctypes mirror must list the header's fields, in its order, with its types -- a field
+    added on one side only would shift everything behind it silently.  The LAST fields' defaults, read through fsim_default_config, pin
+    the tail of the layout against the built library."""
+    import re
+    src = open(os.path.join(ROOT, "include", "fsim.h")).read()
+    body = src[src.index("typedef struct fsim_config"):src.index("} fsim_config_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in re.findall(r"\b(int32_t|float)\s+([^;]+);", body):
+        for name in decl[1].split(","):
+            fields.append((name.strip(), decl[0]))
+    py = [(n, {ctypes.c_int32: "int32_t", ctypes.c_float: "float"}[t]) for n, t in sim.FsimConfig._fields_]
+    assert py == fields, [x for x in zip(py, fields) if x[0] != x[1]][:3]
+    c = sim.default_config()
+    assert (c.multi_wave, c.lookahead_reset, c.overflow_restep) == (0, 1, 1)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="exercises the no-GPU failure path")
 def test_no_silent_cpu_fallback(sawyer_lack):
     # product classes refuse to construct without a device ...
