@@ -347,6 +347,9 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, 2) void k_en
 // The kernel is one latency chain (it sits between two step kernels of its stream): the keys are fetched once, eight loads in
 // flight per lane, and kept in LDS for the sorting passes (208 us -> ~20 us for 2048 envs).
 #define FSIM_SCHED_SELECTED ((int)0x80000000)
+#ifndef FSIM_SCHED_U
+#define FSIM_SCHED_U 8 // envs per lane whose keys are in flight at once (the unrolled fetch: code size against loads in flight)
+#endif
 // Look-ahead jobs (la.sh_prog != null): env i gets one this launch iff a reset table is on the device (serial > 0), its shadow record
 // does not yet hold that table's complete reset, and its episode is la.defer steps old -- the first la.maxjobs such envs in index
 // order (an env keeps its job from launch to launch until its shadow is complete) -> la.jobs / q[4].  Device state only.
@@ -358,11 +361,11 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
   const int tid = threadIdx.x;
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
   int base = 0, lm = 0, jbase = 0;
-  for (int i0 = 0; i0 < n; i0 += 512) {
-    int cv[8], v[8];
-    bool jb[8];
+  for (int i0 = 0; i0 < n; i0 += 64 * FSIM_SCHED_U) {
+    int cv[FSIM_SCHED_U], v[FSIM_SCHED_U];
+    bool jb[FSIM_SCHED_U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < FSIM_SCHED_U; u++) {
       const int i = i0 + 64 * u + tid;
       cv[u] = i < n ? cost[i] : -1;
       v[u] = (use_mw && i < n) ? state[(size_t)i * stride + niter_off] : -0x7fffffff;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < FSIM_SCHED_U; u++) {
       const int i = i0 + 64 * u + tid;
       const bool take = i < n && v[u] >= mw_k && cv[u] != -1;
       const unsigned long long mask = __ballot(take);
