@@ -31,11 +31,10 @@ for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         t, dt * 1e3, tot.mean() / 1e6, np.percentile(tot, 50) / 1e6, np.percentile(tot, 99) / 1e6, tot.max() / 1e6,
         " ".join("%s %.0f%%" % (n, 100 * cyc[:, i].sum() / tot.sum()) for i, n in enumerate(names)),
         nsub.mean(), nit.sum() / max(1, nsub.sum()), maxit.max(), ncoup.sum() / max(1, nsub.sum()), nsurv.sum() / max(1, nsub.sum()), nslot.sum() / max(1, nsub.sum())))
-    # which envs the scheduler gave four waves in THIS step (its rule, recomputed: last step's Newton iterations >= K, first cap envs)
-    K = int(os.environ.get("FSIM_MW_K", "150")); cap = int(os.environ.get("FSIM_MW_CAP", str(max(1, N // 8))))
+    # which envs the scheduler gave four waves in THIS step (its rule, recomputed: last step's Newton iterations >= K; no cap since round 4)
+    K = int(os.environ.get("FSIM_MW_K", "150"))
     if t > 0 and os.environ.get("FSIM_MW", "1") not in ("0", "all") and N <= 2048:
         selm = prev_nit >= K
-        idx = np.nonzero(selm)[0][:cap]; selm = np.zeros(N, bool); selm[idx] = True
         print("    multi-wave envs %d (%.1f%%): max %.2f mean %.2f Mcyc | one-wave envs: max %.2f Mcyc, %d above 5 Mcyc, %d above 7 Mcyc" % (
             selm.sum(), 100 * selm.mean(), tot[selm].max() / 1e6 if selm.any() else 0, tot[selm].mean() / 1e6 if selm.any() else 0,
             tot[~selm].max() / 1e6, (tot[~selm] > 5e6).sum(), (tot[~selm] > 7e6).sum()))
