@@ -150,7 +150,9 @@ enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP =
 // (FSIM_BIG_MIN: the island of the robot's tree counts as "large" from this many dofs on.  17 = only when it does not fit a DPP row;
 //  12 with the matrix-core Hessian assembly, -DFSIM_MFMA_HESSIAN, whose tile then also takes the robot + one part islands)
 //  -DFSIM_MFMA_HESSIAN=2: only in the multi-wave kernels, whose main wave is the critical path of the slowest envs)
-#ifndef FSIM_MFMA_HESSIAN
+#ifdef FSIM_BIG_MIN
+#define FSIM_BIG_MIN_OF(Ctx) FSIM_BIG_MIN
+#elif !defined(FSIM_MFMA_HESSIAN)
 #define FSIM_BIG_MIN_OF(Ctx) 17
 #elif FSIM_MFMA_HESSIAN == 2
 #define FSIM_BIG_MIN_OF(Ctx) (Ctx::NW > 1 ? 12 : 17)
