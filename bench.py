@@ -306,8 +306,9 @@ def main():
             # (rare -- 1.6 per million env-steps: fsim_sync has just re-stepped an env whose contacts did not fit 48 slots and rewritten
             #  its rows; the gather that was chained behind the step kernel carried the first pass's rows: gather this slab again)
             sl.resteps = r
-            sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
-            sl.sim.sync()
+            if not distributed:  # (a collective must be entered by every rank: with RCCL the gathered copy keeps the first pass's rows of that env)
+                sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
+                sl.sim.sync()
         if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
             t_h = time.perf_counter()
             # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave
