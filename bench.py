@@ -206,7 +206,11 @@ def main():
     ap.add_argument("--no-lookahead", action="store_true", help="(exploration only) resets run inside the terminal step's launch instead of ahead of time (fsim_config_t::lookahead_reset = 0)")
     ap.add_argument("--multi-wave", default="auto", choices=["auto", "off", "rule", "all"], help="(exploration only) fsim_config_t::multi_wave of every slab")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "4")),
-                    help="env groups per GPU, each on its own HIP stream, stepped software-pipelined (1 = one synchronous launch)")
+                    help="env groups (slabs) per GPU, each a handle of its own, stepped asynchronously (1 = one synchronous launch)")
+    ap.add_argument("--pool", type=int, default=int(os.environ.get("FSIM_BENCH_POOL", "0")), choices=[0, 1],
+                    help="1: the slabs share one work pool (include/fsim.h fsim_pool_*: steps are posted to a resident kernel, no launch per slab-step); 0: a scheduler + step launch per slab-step")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("FSIM_BENCH_THREADS", "0")), choices=[0, 1],
+                    help="1: one host thread per slab (each slab is re-stepped as soon as ITS step is done); 0: one thread, round robin")
     args = ap.parse_args()
     if "RANK" not in os.environ and args.gpus > 1:  # plain launch: become N ranks
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], selftest=args.launcher_selftest))
@@ -295,19 +299,30 @@ def main():
         sl.sim.set_reset_tables(*sl.tables.take())  # tables for the first auto-reset
         slabs.append(sl)
     dev = slabs[0].sim.device
+    pool = None
+    if args.pool:
+        from furniture_amd.sim import FSimPool
+        pool = FSimPool(local)
+        for sl in slabs:
+            pool.attach(sl.sim)
+
+    # When the all-gather of a slab-step is enqueued.  One process, no pool: right behind the step kernel on the handle's stream (no host
+    # round trip between the two).  Under RCCL and with the work pool: after fsim_sync -- under RCCL because fsim_sync may re-step an env
+    # whose contacts overflowed the slots (1.6 per million env-steps) and rewrite its rows, and a gather chained behind the FIRST pass
+    # would hand the learner that env's stale row on every rank (a second gather only on the rank that saw the re-step would not be entered
+    # by the others); with the pool because a posted step is not an operation of the handle's stream.  One collective per slab-step on
+    # every rank either way, entered in the same slab order.
+    GATHER_AFTER_SYNC = distributed or bool(args.pool)
 
     def wait(sl):
         if not sl.inflight:
             return
-        sl.sim.sync()  # the handle's stream: step kernel + the gather chained behind it
+        sl.sim.sync()  # the step (kernel or posted epoch), the overflow re-step if one was needed, and a gather chained behind the kernel
         sl.inflight = False
-        r = sl.sim.overflow_resteps()
-        if r != sl.resteps:
-            # (rare -- 1.6 per million env-steps: fsim_sync has just re-stepped an env whose contacts did not fit 48 slots and rewritten
-            #  its rows; the gather that was chained behind the step kernel carried the first pass's rows: gather this slab again)
-            sl.resteps = r
-            if not distributed:  # (a collective must be entered by every rank: with RCCL the gathered copy keeps the first pass's rows of that env)
-                sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
+        sl.resteps = sl.sim.overflow_resteps()
+        if GATHER_AFTER_SYNC:
+            sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
+            if distributed:
                 sl.sim.sync()
         if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
             t_h = time.perf_counter()
@@ -336,9 +351,8 @@ def main():
     def launch(sl):
         sl.sim.step(sl.actions[sl.t], sl.obs, sl.rew, sl.done, sl.info)
         sl.t += 1
-        # ONE RCCL all-gather per slab-step (obs | reward | done packed), enqueued on the handle's stream right behind the step
-        # kernel: no host synchronisation between the two
-        sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
+        if not GATHER_AFTER_SYNC:  # (single process: gather_observations hands the inputs back -- there is nobody to gather from)
+            sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
         sl.inflight = True
 
     def one_step():
@@ -358,7 +372,30 @@ def main():
 
     TRACE = os.environ.get("FSIM_BENCH_TRACE")  # development: wall time of every block of 50 batched steps, on stderr
 
+    THREADS = bool(args.threads) and not distributed
+    TRACE = os.environ.get("FSIM_BENCH_TRACE")  # development: wall time of every block of 50 batched steps, on stderr
+
     def run_steps(k):
+        if THREADS:  # one host thread per slab (ctypes releases the GIL inside fsim_sync): every slab cycles at its own pace
+            import threading
+
+            def loop(sl):
+                tw = tl = 0.0
+                for _ in range(k):
+                    t_a = time.perf_counter()
+                    wait(sl)
+                    t_b = time.perf_counter()
+                    launch(sl)
+                    tl += time.perf_counter() - t_b
+                    tw += t_b - t_a
+                if TRACE and sl.index in (0, len(slabs) - 1):
+                    sys.stderr.write("slab %d: %d steps, host blocked in wait %.3f ms/step, in launch %.3f ms/step\n" % (sl.index, k, tw / k * 1e3, tl / k * 1e3))
+            th = [threading.Thread(target=loop, args=(sl,)) for sl in slabs]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            return
         if not ASYNC:
             tb = time.perf_counter()
             for i in range(k):
@@ -379,6 +416,9 @@ def main():
 
     run_steps(args.warmup)
     drain()
+    if pool is not None:  # (a launch of the resident kernel of its own for the timed region: its HIP-event duration is the roofline's kernel time)
+        pool.retire()
+        pool_stats0 = pool.stats()
     la0 = [sl.sim.lookahead_stats() for sl in slabs]
     for sl in slabs:
         sl.sim.kernel_time_ms()  # reset the accumulators
@@ -392,8 +432,11 @@ def main():
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.retire()
     kt = [sl.sim.kernel_time_ms() for sl in slabs]
     la1 = [sl.sim.lookahead_stats() for sl in slabs]
+    pool_stats = pool.stats() if pool is not None else None  # (after the retire above: the timed region's launch is complete)
     # envs whose record carries the sticky contact-overflow word (fsim_model.hpp E_OVERFLOW): some launch since the handle was created
     # -- warm-up included -- needed more contact slots than the kernel's LDS image holds and dropped the rest for that substep
     from furniture_amd.sim import E_OVERFLOW
@@ -402,6 +445,14 @@ def main():
     reset_substeps = 401 if m.meta.get("has_recipe") else 301  # sim.step() calls of one _reset (tests/golden/reset_trace.npz)
     klaunches = sum(k[1] for k in kt)
     kms = sum(k[0] * k[1] for k in kt) / max(1, klaunches)
+    units_per_launch = ng  # env-steps one launch of the dominant kernel processes
+    if pool is not None:
+        # the dominant kernel is the resident k_pool: every env-step of the timed region ran inside its launch(es), timed with HIP events on
+        # the pool's stream; `step_latency_ms` keeps the host-clock post -> completion time of a slab-step
+        step_latency_ms = kms
+        klaunches = pool_stats["launches"] - pool_stats0["launches"]
+        kms = (pool_stats["resident_ms"] - pool_stats0["resident_ms"]) / max(1, klaunches)
+        units_per_launch = n * args.steps / max(1, klaunches)
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -412,16 +463,16 @@ def main():
     if rank == 0:
         total_env_steps = world * n * args.steps
         value = total_env_steps / dt
-        achieved = ALGO_BYTES_PER_ENV_STEP * ng / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        achieved = ALGO_BYTES_PER_ENV_STEP * units_per_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         # What the counters say about this kernel (rocprofv3 --pmc passes of the same workload, scripts/profile_round.sh; bench.py
         # cannot profile itself).  HBM traffic feeds the contract's roofline object; the rest says what actually binds.
         traffic, traffic_note, pmc = None, None, {}
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
-            traffic = pmc["bytes_per_env_step"] * ng
-            traffic_note = ("builder-lease PMC, not this run: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, %s), %d B per env-step x %d envs per launch"
-                            % (pmc.get("source", "profiles/"), pmc["bytes_per_env_step"], ng))
+            traffic = pmc["bytes_per_env_step"] * units_per_launch
+            traffic_note = ("builder-lease PMC, not this run: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, %s), %d B per env-step x %d env-steps per launch"
+                            % (pmc.get("source", "profiles/"), pmc["bytes_per_env_step"], units_per_launch))
         except Exception:
             pass
         # chip-wide utilisation of THIS run: instructions per env-step (PMC, a property of the workload) x the measured env-step rate
@@ -450,7 +501,10 @@ def main():
             "config": {"workload": "Furniture%sEnv + %s, %s control, %d envs/GPU, U(-1,1)^%d actions, "
                                    "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
-                       "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU pipelined on separate HIP streams" % (world, G, ng),
+                       "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU, %s, %s" % (
+                           world, G, ng, "stepped through one resident work-pool kernel (fsim_pool_*)" if pool is not None else "a scheduler + step launch per slab-step on the slab's own HIP stream",
+                           "one host thread per slab" if THREADS else "one host thread, round robin"),
+                       "work_pool": pool_stats,
                        "rccl_world": dist.get_world_size() if distributed else 1,  # ranks RCCL's communicator saw (1 without torch.distributed.run)
                        # every episode end costs its reset (the reference's _reset: 401 sim.step() calls here).  They are executed INSIDE the
                        # timed region: ahead of the step that needs them (look-ahead jobs) or inside that step's launch
@@ -471,7 +525,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": slabs[0].sim.step_kernel, "kernel_avg_ms": kms, "kernel_launches": klaunches,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * ng,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * units_per_launch,
+                         "env_steps_per_launch": units_per_launch, "slab_step_latency_ms": step_latency_ms if pool is not None else None,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
                          # wave issues at most one instruction per ~5 cycles (scripts/dev/micro: 5.0 cycles per dependent-distance-4
@@ -481,6 +536,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line))
+    if pool is not None:
+        pool.close()
     for sl in slabs:
         sl.tables.close()
         sl.sim.close()

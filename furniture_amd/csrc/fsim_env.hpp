@@ -54,6 +54,8 @@ struct EnvIO {
   const float *sh_state;
   const void *sh_obs;
   int *sh_prog;   // reset units of the shadow record done so far (env_reset_units); total + 1 = taken by a reset
+  int sh_prog0;   // *sh_prog when this env's launch took the env: "is the shadow ready" is decided on THIS value, never on what a look-ahead
+                  // job of the same launch writes later (no launch both produces and consumes a shadow; which path a reset takes is not timing)
   int sh_serial;  // serial number of the reset table the shadow record was (is being) computed from
   int tab_serial; // serial number of the table on the device (the host bumps it with every upload)
   int *stats;     // host-mapped counters: [0] resets taken from a shadow record, [1] resets executed inside a step / reset launch, [2] reset units run by look-ahead jobs
@@ -235,7 +237,7 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
 //   CTRL (separate instantiation, so the default path's code and register allocation are untouched): the torque-level arm
 //   controller runs before every substep (_do_controller_step, furniture.py:3065-3093); pass -1 is the sim.forward() that
 //   precedes the loop, whose results the first _pre_action reads.
-template <bool CTRL, class Ctx> static __device__ __noinline__ void fs_substeps_t(Ctx cv, int n_, int mode_) {
+template <bool CTRL, class Ctx> static FSIM_OUTLINE void fs_substeps_t(Ctx cv, int n_, int mode_) {
 #ifdef FSIM_OPAQUE_LANE
   // (development: the lane index is re-read through an opaque copy at the top of every substep, so that the per-lane address
   //  arithmetic of the pass cannot be hoisted out of the loop -- hoisted, those values live across the whole loop and some are spilled)
@@ -886,7 +888,7 @@ template <class Ctx> DEV void env_init_robot(const Ctx &c, const EnvResetIO &io,
 // The SAME loop serves both uses, so running it in pieces executes the same instructions on the same values (every derived quantity
 // is rebuilt by the forward pass of each step; what persists is the record): bit-identical, tests/test_lookahead_gpu.py.
 DEV int env_reset_total(const EnvCfg &cfg, bool init) { return init ? 100 : (100 + (cfg.has_recipe ? 100 : 0) + 201); }
-template <class Ctx0> static __device__ __noinline__ void env_reset_units(Ctx0 cv, const EnvCfg *cfgp, const EnvResetIO io, int p0_, int p1_) {
+template <class Ctx0> static FSIM_OUTLINE void env_reset_units(Ctx0 cv, const EnvCfg *cfgp, const EnvResetIO io, int p0_, int p1_) {
   extern __shared__ float fs_lds_[];
   typedef FsIn<Ctx0> Ctx; // (see FsIn: the physics routine called from here is not the one the step calls)
   const Ctx c(fs_rebuild(cv, fs_lds_));
@@ -1084,7 +1086,7 @@ template <class Ctx> DEV void env_post(const Ctx &c, const EnvCfg &cfg, const En
 // (serial numbers); everything happens on the handle's one stream, in launch order.
 DEV bool env_shadow_ready(const EnvCfg &cfg, const EnvIO &io) {
   if (!io.sh_prog) return false;
-  const int p = __builtin_amdgcn_readfirstlane(*io.sh_prog);
+  const int p = io.sh_prog0;
   return io.sh_serial == io.tab_serial && io.tab_serial > 0 && p == env_reset_total(cfg, io.init_state != nullptr);
 }
 template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {

@@ -152,7 +152,7 @@ template <class Ctx> DEV void env_ik_remember(const Ctx &c, int mode) {
 }
 
 // get_control(dpos, rotation) (sawyer_ik_controller.py:51-88): new target, solve, store commanded_joint_positions
-template <class Ctx> __device__ __noinline__ void env_ik(Ctx cv, float rotate_speed, int mode) {
+template <class Ctx> FSIM_OUTLINE void env_ik(Ctx cv, float rotate_speed, int mode) {
   FS_REBUILD_CTX(cv);
   CModel &m = c.m;
   const auto tail = GP(m.ik_tab) + IKT_ARM * c.D.narm;

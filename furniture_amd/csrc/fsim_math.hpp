@@ -4,6 +4,11 @@
 
 #define FS_MINVAL 1e-15f
 #define DEV __device__ __forceinline__
+// waves per SIMD the step kernels and their out-of-line callees are register-allocated for (2: 256 VGPRs, 3: 168, 4: 128)
+#ifndef FSIM_WPE
+#define FSIM_WPE 2
+#endif
+#define FSIM_OUTLINE __device__ __noinline__
 
 // Model tables live in global memory, but a pointer loaded from a struct that was itself reached through a pointer is
 // "flat" to the compiler: every such load becomes flat_load_dword, which also ticks the LDS counter (lgkmcnt), so LDS

@@ -1263,12 +1263,12 @@ template <class Ctx> DEV int fs_stage_big(const Ctx &c, const int trees, const i
 // register allocation of the substep loop, and only the env with a big island ever calls them.  The LDS base travels as a 32-bit LDS
 // address: naming the dynamic-LDS symbol inside a non-kernel function costs a table lookup -- s_getpc + s_load + wait, ~400 cycles --
 // at every use the compiler does not merge)
-template <class Ctx> __device__ __noinline__ int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_) {
+template <class Ctx> FSIM_OUTLINE int fs_chol_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_) {
   float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
   const Ctx c = fs_rebuild(cv, lds_);
   return fs_mfma_tile_solve(c, __builtin_amdgcn_readfirstlane(mp_), __builtin_amdgcn_readfirstlane(first_), __builtin_amdgcn_readfirstlane(n_), -1, 0);
 }
-template <class Ctx> __device__ __noinline__ int fs_newton_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int trees_) {
+template <class Ctx> FSIM_OUTLINE int fs_newton_mfma(Ctx cv, unsigned lds_addr_, int mp_, int first_, int n_, int trees_) {
   float *lds_ = (float *)(fs_lds_f *)(size_t)__builtin_amdgcn_readfirstlane(lds_addr_);
   const Ctx c = fs_rebuild(cv, lds_);
   const int stage = c.ly.hA;
@@ -1793,7 +1793,7 @@ template <class Ctx> DEV void mw_helper_loop(const Ctx &c) {
 // The helper waves' loop as a REAL function: inlined into k_env_step_x it shared one register allocation with the kernel's two env
 // loops and the look-ahead job (63 k instructions, 3 092 scratch instructions in the kernel body, against 1 008 in round 3), and what the
 // helpers run -- the collision pipeline, the Hessian blocks, the row factorisation -- is per-substep code.
-template <class Ctx> static __device__ __noinline__ void mw_helper_fn(Ctx cv) {
+template <class Ctx> static FSIM_OUTLINE void mw_helper_fn(Ctx cv) {
   FS_REBUILD_CTX(cv);
   mw_helper_loop(c);
 }
