@@ -224,7 +224,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from furniture_amd.dist import gather_observations, shard_range
+    from furniture_amd.dist import gather_observations, shard_range, step_wait_and_gather
     from furniture_amd.envs import ResetTableQueue, ResetTableSampler, make_config
     from furniture_amd.mjcf.model import load_compiled
     from furniture_amd.sim import FSim, INFO_DIM, INFO_NEEDS_TABLE, MULTI_WAVE, default_config
@@ -317,13 +317,12 @@ def main():
     def wait(sl):
         if not sl.inflight:
             return
-        sl.sim.sync()  # the step (kernel or posted epoch), the overflow re-step if one was needed, and a gather chained behind the kernel
+        if GATHER_AFTER_SYNC:  # (furniture_amd/dist.py: sync -- incl. the overflow re-step if one was needed --, then the collective)
+            sl.gathered = step_wait_and_gather(sl.sim, sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream if distributed else None, group=sl.pg)
+        else:
+            sl.sim.sync()  # the step kernel and the gather chained behind it
         sl.inflight = False
         sl.resteps = sl.sim.overflow_resteps()
-        if GATHER_AFTER_SYNC:
-            sl.gathered = gather_observations(sl.obs, sl.rew, sl.done, tag=sl.index, stream=sl.sim.torch_stream, group=sl.pg)
-            if distributed:
-                sl.sim.sync()
         if sl.sim.tables_needed():  # host-side reference RNG stream for the envs that just consumed their reset table
             t_h = time.perf_counter()
             # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave

@@ -1475,6 +1475,10 @@ extern "C" int fsim_set_state(fsim_t *s, const fsim_state_ptrs_t *src) { return 
 extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise) {
   if (!s || !part_qpos) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
+  // (a step of this handle still in flight reads the tables -- its terminal envs' resets, its look-ahead jobs: it completes first.
+  //  fsim.h says so since round 5; the repo's own callers always called between fsim_sync and the next step)
+  { int rc_ = settle(s); if (rc_) return rc_; }
+  HIPCHK(hipStreamSynchronize(s->stream));
   const DModel &m = s->m;
   size_t pw = (size_t)7 * m.nparts, nw = (size_t)n_noise * m.narmj;
   if (!s->d_tab_parts) HIPCHK(hipMalloc(&s->d_tab_parts, (size_t)s->n_envs * pw * 4 + 16));
@@ -1485,7 +1489,7 @@ extern "C" int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float
   }
   if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
   if (int rc = la_new_tables(s, mask)) return rc; // (new serial numbers: shadows computed from the old rows no longer count)
-  // rows of envs that are not in flight: safe to write while other envs' step kernels run (asynchronous stepping)
+  // (no launch of this handle is in flight here: see the settle above; other handles' kernels do not read these rows)
   if (!mask) {
     HIPCHK(hipMemcpyAsync(s->d_tab_parts, part_qpos, (size_t)s->n_envs * pw * 4, hipMemcpyHostToDevice, s->xfer));
     if (robot_noise) HIPCHK(hipMemcpyAsync(s->d_tab_noise, robot_noise, (size_t)s->n_envs * nw * 4, hipMemcpyHostToDevice, s->xfer));
@@ -1530,6 +1534,7 @@ extern "C" int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (s->ecfg.n_pre > 0 && qpos) FAIL(FSIM_EINVAL, "fsim_set_init_state: not combined with pre-assembled starts (fsim_set_preassembled)");
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; } // (a step still in flight -- and its overflow re-step -- run under the configuration they were launched with)
   HIPCHK(hipStreamSynchronize(s->stream));
   if (s->la_on && (s->d_init || qpos)) { // the resets of the masked envs start elsewhere from now on: their shadow records are void
     if (int rc = la_new_tables(s, mask)) return rc;
@@ -1901,6 +1906,7 @@ extern "C" int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, co
   if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "fsim_set_dense_reward: the handle was not created with dense_reward = 1");
   if (int rc = dense_check(coef, ncoef, sub, nsub, s->m.nsite, s->m.nparts, s->m.nconn)) return rc;
   HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   HIPCHK(hipStreamSynchronize(s->stream));
   if (s->la_on) { if (int rc = la_new_tables(s, nullptr)) return rc; HIPCHK(hipStreamSynchronize(s->xfer)); }
   if (s->d_dense) { hipFree(s->d_dense); s->d_dense = nullptr; }
@@ -2108,6 +2114,8 @@ extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, c
   if (n_pre > 0 && std::any_of(s->h_init_mask.begin(), s->h_init_mask.end(), [](uint8_t v) { return v != 0; }))
     FAIL(FSIM_EINVAL, "fsim_set_preassembled: not combined with fsim_set_init_state (an env still has an init state set; clear it with qpos = NULL)");
   if (n_pre > 0 && recipe && !angles) FAIL(FSIM_EINVAL, "fsim_set_preassembled: recipe steps need their angles next to the connector pairs");
+  HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   std::vector<int> tab(3 * (size_t)n_pre, 0);
   for (int i = 0; i < n_pre; i++) {
     if (recipe) {
@@ -2134,6 +2142,8 @@ extern "C" int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, c
 }
 extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   if (!s || n <= 0) FAIL(FSIM_EINVAL, "fsim_set_max_episode_steps: bad arguments");
+  HIPCHK(hipSetDevice(s->device));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   s->cfg.max_episode_steps = n; s->ecfg.max_episode_steps = n; // EnvCfg is passed by value with every launch
   if (s->la_on) la_policy(s);
   return FSIM_OK;

@@ -14,7 +14,7 @@
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2 = 10, C_G1 = 11, C_G2 = 12, C_AREF = 13,
        C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17 };
 
-__constant__ int FS_PAIR_MAXCON[9] = {1, 4, 4, 1, 1, 1, 8, 1, 1};
+__constant__ int FS_PAIR_MAXCON[11] = {1, 4, 4, 1, 1, 1, 8, 1, 1, 2, 1};
 
 template <class Ctx> struct Emit {
   const Ctx &c;
@@ -421,9 +421,10 @@ DEV V3 np_support(const Shape &s, V3 dir) {
     float rho = sqrtf(dl.x * dl.x + dl.y * dl.y);
     pl = rho > 1e-12f ? v3(dl.x / rho * s.size.x, dl.y / rho * s.size.x, 0) : v3(0, 0, 0);
     pl.z = dl.z >= 0 ? s.size.y : -s.size.y;
-  } else {
+  } else { // sphere; capsule = sphere swept along the local z axis
     float n = norm(dl);
     pl = n > 1e-12f ? dl * (s.size.x / n) : v3(0, 0, 0);
+    if (s.type == GT_CAPSULE) pl.z += dl.z >= 0 ? s.size.y : -s.size.y;
   }
   return mulv(s.R, pl) + s.pos;
 }
@@ -625,6 +626,12 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
       case PT_SPHERE_BOX: np_sphere_box(e, p1, s1.x, p2, R2, s2); break;
       case PT_SPHERE_CYL: np_sphere_cylinder(e, p1, s1.x, p2, R2, s2); break;
       case PT_BOX_BOX: np_box_box(e, p1, R1, s1, p2, R2, s2); break;
+      case PT_PLANE_CAP: { // the capsule's two end spheres against the plane (mjc_PlaneCapsule)
+        const V3 ax = colv(R2, 2);
+        np_plane_sphere(e, p1, R1, p2 + ax * s2.y, s2.x);
+        np_plane_sphere(e, p1, R1, p2 - ax * s2.y, s2.x);
+        break;
+      }
       default: {
         // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
         // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)
@@ -651,6 +658,12 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
       case PT_SPHERE_BOX: np_sphere_box(e, p1, s1.x, p2, R2, s2); break;
       case PT_SPHERE_CYL: np_sphere_cylinder(e, p1, s1.x, p2, R2, s2); break;
       case PT_BOX_BOX: np_box_box(e, p1, R1, s1, p2, R2, s2); break;
+      case PT_PLANE_CAP: { // the capsule's two end spheres against the plane (mjc_PlaneCapsule)
+        const V3 ax = colv(R2, 2);
+        np_plane_sphere(e, p1, R1, p2 + ax * s2.y, s2.x);
+        np_plane_sphere(e, p1, R1, p2 - ax * s2.y, s2.x);
+        break;
+      }
       default: {
         // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
         // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)

@@ -21,8 +21,9 @@
 #define FSIM_MAXSURV 48  // broadphase survivors per substep of models with <= 8 parts (22 is the most seen on Sawyer + table_lack); LayoutIn::maxsurv
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
-enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6 };
-enum { PT_PLANE_SPHERE = 0, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL };
+enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_CYLINDER = 5, GT_BOX = 6 };
+enum { PT_PLANE_SPHERE = 0, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL,
+       PT_PLANE_CAP, PT_CONVEX /* every other pair with a capsule in it: sphere / capsule / cylinder / box x capsule, through the portal routine */ };
 
 // Dimensions and scalar options of a model.  The generic kernels read them at run time (scalar loads from the DModel
 // in constant memory); the kernels specialised for one (agent, furniture, config) carry them as compile-time constants

@@ -68,3 +68,16 @@ def gather_observations(obs, reward, done, tag=0, stream=None, group=None):
     send[:, d + 1] = done
     dist.all_gather_into_tensor(recv, send, group=group)
     return recv[:, :d], recv[:, d], recv[:, d + 1].to(done.dtype)
+
+
+def step_wait_and_gather(sim, obs, reward, done, tag=0, stream=None, group=None):
+    """What a learner rank does at the end of a slab-step under RCCL: FIRST ``sim.sync()`` -- which, besides waiting for the step, may
+    re-step an env whose contacts did not fit the kernel's slots and rewrite its rows (include/fsim.h fsim_overflow_resteps) --, THEN the
+    all-gather, so that every rank receives the rows that are final.  A gather enqueued behind the step kernel instead would carry the
+    first pass's rows of such an env, and repeating it only on the rank that saw the re-step is not possible (a collective is entered by
+    every rank).  One collective per slab-step on every rank, whatever happened.  ``sim``: anything with ``sync()`` (furniture_amd.sim.FSim)."""
+    sim.sync()
+    out = gather_observations(obs, reward, done, tag=tag, stream=stream, group=group)
+    if stream is not None and obs.is_cuda:
+        stream.synchronize()
+    return out

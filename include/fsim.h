@@ -143,9 +143,10 @@ int fsim_env_block_words(const fsim_t *);
 /* Initial placements for the next reset of each env: part poses [n, nparts*7] (pos, quat wxyz) as drawn by
  * the reference's UniformRandomSampler (tasks/placement_sampler.py:138-190) and robot joint noise
  * [n, n_noise, narmjoints] as drawn by _initialize_robot_pos (furniture.py:1761-1779), n_noise = 101.
- * Host pointers; copied on a transfer stream of the handle and complete on return.  mask: host uint8 [n] or NULL = all.  The rows
- * written must not belong to envs with a reset / step in flight (the kernels read the tables); rows of idle envs may be
- * replaced while other envs are being stepped (asynchronous stepping). */
+ * Host pointers; copied on a transfer stream of the handle and complete on return.  mask: host uint8 [n] or NULL = all.  No launch of
+ * THIS handle may be in flight: besides the terminal envs' resets, the look-ahead jobs of a step launch read the tables of any env
+ * whose episode is old enough -- the call waits for a step still in flight itself (as fsim_sync would).  Other handles (the other
+ * slabs of an asynchronously stepped batch) keep running. */
 int fsim_set_reset_tables(fsim_t *, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise);
 
 /* config.reset_robot_after_attach (config/furniture.py:298-303; furniture.py:919-925: `_connect` ends with `_initialize_robot_pos()`):
@@ -186,7 +187,9 @@ int fsim_lookahead_stats(fsim_t *, int64_t *out);
  * those again from the kept record with a 64-slot layout (one four-wave workgroup per env) and overwrites their record and output rows
  * before it returns.  Reset launches are covered the same way, and models that run on 64 slots are repeated with 128 (one-wave kernel, two
  * slots per lane).  Returns how many env-steps were repeated so far.  FSIM_NO_OVERFLOW_REDO=1 switches it off (the sticky report of
- * FSIM_INFO_OVERFLOW is then all there is).  Outputs read in stream order without fsim_sync carry the first pass's rows. */
+ * FSIM_INFO_OVERFLOW is then all there is).  Outputs read in stream order without fsim_sync carry the first pass's rows.
+ * Buffer lifetime: the action and output buffers of a step must stay valid (and the action unchanged) until the next fsim_sync or
+ * launch of the handle -- the re-step reads and writes them again; every setter of the handle waits for it first. */
 int64_t fsim_overflow_resteps(const fsim_t *);
 
 /* Shared work pool (round 5; reference counterpart: the worker processes of furniture/env/base.py:55-80 and

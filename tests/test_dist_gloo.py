@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from furniture_amd.dist import shard_range, gather_observations
+from furniture_amd.dist import shard_range, gather_observations, step_wait_and_gather
 from furniture_amd.envs import ResetTableSampler
 from furniture_amd.mjcf.model import load_compiled
 
@@ -104,5 +104,54 @@ def test_one_rank_and_two_rank_batches_are_identical_per_env():
         p.start()
     for p in procs:
         p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def _restep_worker(rank, world, port, q):
+    """the handle's sync() rewrites one env's rows on rank 1 only (what fsim_sync does when it re-steps an env that dropped contacts);
+    the slab every rank receives must carry the rewritten rows"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per, d = 4, 5
+    obs = torch.full((per, d), float(rank))
+    rew = torch.full((per,), 10.0 + rank)
+    done = torch.zeros(per, dtype=torch.uint8)
+
+    class Handle:
+        synced = 0
+
+        def sync(self):  # (first pass's rows are in obs / rew / done when this is called)
+            self.synced += 1
+            if rank == 1:
+                obs[2] = 99.0
+                rew[2] = -1.0
+                done[2] = 1
+
+    h = Handle()
+    g_obs, g_rew, g_done = step_wait_and_gather(h, obs, rew, done)
+    assert h.synced == 1
+    want_obs = torch.cat([torch.full((per, d), 0.0), torch.full((per, d), 1.0)])
+    want_obs[per + 2] = 99.0
+    want_rew = torch.cat([torch.full((per,), 10.0), torch.full((per,), 11.0)])
+    want_rew[per + 2] = -1.0
+    assert torch.equal(g_obs, want_obs) and torch.equal(g_rew, want_rew), (rank, g_obs, g_rew)
+    assert g_done.tolist() == [0] * (per + 2) + [1, 0]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gathered_slab_carries_the_rows_of_an_overflow_restep():
+    """a re-step inside fsim_sync on ONE rank must not leave the learner a stale row.  bench.py's RCCL path enters
+    the all-gather after the sync on every rank (furniture_amd/dist.py step_wait_and_gather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_restep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(2)) == [0, 1]
