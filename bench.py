@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
     ap.add_argument("--control-type", default="impedance", help="(exploration only) a torque-level arm controller, e.g. position_orientation")
+    ap.add_argument("--episode-window", type=int, default=-1,
+                    help="steps of a SECOND, un-headlined timed window run after the contract's (reported as config.episode_window_*): -1 = one full "
+                         "episode + 10 steps when --steps is shorter than an episode, 0 = off")
     ap.add_argument("--obs-bf16", action="store_true", help="store the observation slab as bfloat16 (BASELINE config 2's narrow slab; state stays fp32)")
     ap.add_argument("--no-lookahead", action="store_true", help="(exploration only) resets run inside the terminal step's launch instead of ahead of time (fsim_config_t::lookahead_reset = 0)")
     ap.add_argument("--multi-wave", default="auto", choices=["auto", "off", "rule", "all"], help="(exploration only) fsim_config_t::multi_wave of every slab")
@@ -212,6 +215,12 @@ def main():
     ap.add_argument("--threads", type=int, default=int(os.environ.get("FSIM_BENCH_THREADS", "0")), choices=[0, 1],
                     help="1: one host thread per slab (each slab is re-stepped as soon as ITS step is done); 0: one thread, round robin")
     args = ap.parse_args()
+    # the host-side reset-table sampler (libfsim_host.so) is OpenMP code; with one host thread per slab, G of its parallel regions start at
+    # once when a batch-wide episode end reaches every slab: G x all-cores threads spinning on 64 cores took tens of seconds
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.groups * max(1, int(os.environ.get("WORLD_SIZE", "1")))))))
+    if os.environ.get("FSIM_BENCH_WATCHDOG"):  # development: where every thread is if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FSIM_BENCH_WATCHDOG"]), exit=True)
     if "RANK" not in os.environ and args.gpus > 1:  # plain launch: become N ranks
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], selftest=args.launcher_selftest))
     if args.launcher_selftest:
@@ -289,6 +298,7 @@ def main():
         sl.rew = torch.zeros(ng, device=dev)
         sl.done = torch.zeros(ng, dtype=torch.uint8, device=dev)
         sl.info = torch.zeros((ng, INFO_DIM), dtype=torch.int32, device=dev)
+        sl.info_host = torch.zeros((ng, INFO_DIM), dtype=torch.int32).pin_memory()
         sl.gen = torch.Generator(device=dev)
         sl.gen.manual_seed(SEED + rank * 64 + g)
         sl.inflight = False
@@ -327,7 +337,9 @@ def main():
             t_h = time.perf_counter()
             # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave
             #  slot -- behind the other slabs' reset-step kernels that was 55 ms of an idle host)
-            need = sl.info.cpu().numpy()[:, INFO_NEEDS_TABLE]
+            # into a pinned buffer allocated up front, on the slab's own stream: no allocation inside the loop (hipMalloc / hipFree -- also
+            # the ones behind torch's allocators -- wait until NO kernel is running, i.e. for the work pool's resident kernel to leave)
+            need = sl.sim.read_into(sl.info_host, sl.info).numpy()[:, INFO_NEEDS_TABLE]
             mask = need > 0
             if (need > 1).any():  # an unstable env: the reference draws twice (reset inside step() + the worker's reset)
                 sl.tables.take(need > 1)
@@ -341,7 +353,8 @@ def main():
     # U(-1,1) actions of every step, generated on the device BEFORE the timed region (the contract: inputs resident in HBM when
     # the clock starts) -- one slab-step's actions are a [ng, dof] slice; no torch kernel is launched inside the loop, where it
     # would queue behind the step kernels' waves for up to a millisecond
-    total_steps = args.warmup + args.steps
+    ew_steps = args.episode_window if args.episode_window >= 0 else (MAX_EPISODE_STEPS + 10 if args.steps < MAX_EPISODE_STEPS else 0)
+    total_steps = args.warmup + args.steps + ew_steps
     for sl in slabs:
         sl.actions = torch.empty((total_steps, ng, sl.sim.dof_action), device=dev).uniform_(-1, 1, generator=sl.gen)
         sl.t = 0
@@ -433,9 +446,36 @@ def main():
     dt = time.perf_counter() - t0
     if pool is not None:
         pool.retire()
-    kt = [sl.sim.kernel_time_ms() for sl in slabs]
-    la1 = [sl.sim.lookahead_stats() for sl in slabs]
+    la_mid = [sl.sim.lookahead_stats() for sl in slabs]
+    kt = [sl.sim.kernel_time_ms() for sl in slabs]  # (of the contract's timed region: read before the second window adds its launches)
     pool_stats = pool.stats() if pool is not None else None  # (after the retire above: the timed region's launch is complete)
+    # Second window, NOT the headline: the contract's K steps after a reset contain no episode end (150-step episodes), so no reset and no
+    # look-ahead reset work; this one spans a full episode right behind it -- every env resets once inside it -- on the same clock rules.
+    ew = None
+    if ew_steps > 0:
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run_steps(ew_steps)
+        drain()
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        dt_ew = time.perf_counter() - t1
+        if pool is not None:
+            pool.retire()
+        if distributed:
+            t = torch.tensor([dt_ew], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ew = float(t)
+        la_end = [sl.sim.lookahead_stats() for sl in slabs]
+        d_ = {k: sum(b[k] - a[k] for a, b in zip(la_mid, la_end)) for k in ("units", "swapped", "inline")}
+        reset_sub = 401 if m.meta.get("has_recipe") else 301
+        ew = {"steps": ew_steps, "env_steps_per_s": world * n * ew_steps / dt_ew, "ms_per_step": dt_ew / ew_steps * 1e3,
+              "resets": d_["swapped"] + d_["inline"], "resets_taken_from_lookahead": d_["swapped"], "reset_substeps": d_["units"] + d_["inline"] * reset_sub,
+              "note": "a second timed window right behind the contract's, spanning one full episode (every env resets once inside it); per-rank counts"}
+    la1 = la_mid
     # envs whose record carries the sticky contact-overflow word (fsim_model.hpp E_OVERFLOW): some launch since the handle was created
     # -- warm-up included -- needed more contact slots than the kernel's LDS image holds and dropped the rest for that substep
     from furniture_amd.sim import E_OVERFLOW
@@ -514,6 +554,7 @@ def main():
                        # env-steps (warm-up included) the library repeated with a 64-slot layout because 48 slots did not hold their contacts
                        # (fsim_overflow_resteps: done inside fsim_sync, i.e. inside the timed region)
                        "overflow_resteps": int(sum(sl.sim.overflow_resteps() for sl in slabs)),
+                       "episode_window": ew, "episode_window_env_steps_per_s": ew["env_steps_per_s"] if ew else None,
                        "physics_substeps_per_s": value * 50, "obs_finite": finite, "obs_dtype": "bf16" if args.obs_bf16 else "f32", "kernel_variant": slabs[0].sim.kernel_variant,
                        "reference_published_single_core_env_steps_per_s": 225},
             # `bound`: what the contract's two choices are priced against is HBM (BASELINE.json asks for the HBM fraction) and `frac` is
@@ -534,6 +575,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        else:  # (the contract times it on rank 0 at N = 1 only: the 1-GPU line of the same sweep carries it)
+            line["cpu_baseline"] = {"skipped": "--no-cpu-baseline" if args.no_cpu_baseline else "n_gpus > 1: timed at N = 1 only (see the 1-GPU line)"}
         print(json.dumps(line))
     if pool is not None:
         pool.close()

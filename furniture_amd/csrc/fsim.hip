@@ -716,9 +716,10 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) vo
         const int e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ph->posted[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
         const int pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&slots[k].epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (e != pub) { pool_publish(slots + k, ph, ctl, k, e, lds, ln); any = true; }
-        // (a step still in flight -- a batch-wide reset inside a step lasts tens of milliseconds -- is not idleness)
-        else if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ph->done[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != e) t_idle = (long long)wall_clock64();
       }
+      // (no new post for FSIM_POOL_IDLE_TICKS: leave, whatever is still in flight -- the workers finish what is published before they
+      //  follow, and the next post restarts the kernel.  Waiting for unfinished steps here instead turned anything that keeps a step from
+      //  finishing into a kernel that never leaves, with every hipMalloc / hipStreamCreate of the process queued behind it.)
       if (any) { t_idle = (long long)wall_clock64(); continue; }
       const int r = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ph->retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
       if (r) { if (ln == 0) __hip_atomic_store(&ctl->retire, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -1182,6 +1183,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking)); // (not lazily: creating a stream waits for a resident work-pool kernel to leave)
   { // multi-wave kernels
     s->ly_mw = make_layout(lin, FSIM_MW_NW);
     s->lds_bytes_mw = s->ly_mw.lds_words * 4;
@@ -2146,6 +2148,16 @@ extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   { int rc_ = settle(s); if (rc_) return rc_; }
   s->cfg.max_episode_steps = n; s->ecfg.max_episode_steps = n; // EnvCfg is passed by value with every launch
   if (s->la_on) la_policy(s);
+  return FSIM_OK;
+}
+// Device -> host copy of caller memory on the handle's transfer stream (pinned destination: a DMA transfer, no kernel, no allocation --
+// usable while the work pool's kernel is resident, where torch's .cpu() may wait for an allocation).  Complete on return.
+extern "C" int fsim_read(fsim_t *s, void *host_dst, const void *dev_src, size_t nbytes) {
+  if (!s || !host_dst || !dev_src) FAIL(FSIM_EINVAL, "null");
+  HIPCHK(hipSetDevice(s->device));
+  if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+  HIPCHK(hipMemcpyAsync(host_dst, dev_src, nbytes, hipMemcpyDeviceToHost, s->xfer));
+  HIPCHK(hipStreamSynchronize(s->xfer));
   return FSIM_OK;
 }
 extern "C" int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) {

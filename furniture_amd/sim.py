@@ -128,6 +128,7 @@ def lib():
         L.fsim_replay_touch_scan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_step_kernel.argtypes = [ctypes.c_void_p]
+        L.fsim_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.fsim_pool_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.fsim_pool_attach.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_pool_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
@@ -160,7 +161,7 @@ EXPORTED_SYMBOLS = [
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
     "fsim_step_kernel", "fsim_lookahead_stats", "fsim_overflow_resteps",
     "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
-    "fsim_pool_create", "fsim_pool_attach", "fsim_pool_stats", "fsim_pool_retire", "fsim_pool_destroy",
+    "fsim_read", "fsim_pool_create", "fsim_pool_attach", "fsim_pool_stats", "fsim_pool_retire", "fsim_pool_destroy",
 ]
 
 
@@ -419,6 +420,13 @@ class FSim:
         the counter tables_needed() reads lives in host memory and is cleared when a step is enqueued, so a second step enqueued
         without a sync in between loses the first one's reset notifications."""
         self._chk(lib().fsim_step(self._h, action.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), info.data_ptr()))
+
+    def read_into(self, host_tensor, dev_tensor):
+        """fsim_read: copy a device tensor into a (pinned) host tensor of the same size on the handle's transfer stream; complete on return"""
+        nbytes = dev_tensor.numel() * dev_tensor.element_size()
+        assert host_tensor.numel() * host_tensor.element_size() == nbytes and dev_tensor.is_contiguous() and host_tensor.is_contiguous()
+        self._chk(lib().fsim_read(self._h, host_tensor.data_ptr(), dev_tensor.data_ptr(), nbytes))
+        return host_tensor
 
     def tables_needed(self):
         """envs that consumed their reset table in the last step (valid after sync())"""

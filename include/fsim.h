@@ -171,6 +171,11 @@ int fsim_reset(fsim_t *, const uint8_t *mask_dev, void *obs_dev /* float32 | bfl
 int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bfloat16 with cfg.obs_bf16 */, float *reward_dev, uint8_t *done_dev,
               int32_t *info_dev);
 
+/* Device -> host copy of a caller buffer (e.g. the info block of the last step) on the handle's transfer stream; complete on return.
+ * With a pinned destination this is a plain DMA transfer: no kernel, no allocation -- which matters while a work pool's kernel is
+ * resident (hipMalloc / hipFree, also the ones behind a framework's allocator, wait for it to leave). */
+int fsim_read(fsim_t *, void *host_dst, const void *dev_src, size_t nbytes);
+
 /* Number of envs whose FSIM_INFO_NEEDS_TABLE is set by the last fsim_step, valid once that step has completed (fsim_sync): lets the
  * host skip the scan of the info block on the (many) steps in which no episode ended. */
 int fsim_tables_needed(const fsim_t *);

@@ -3,7 +3,7 @@ export PYTHONPATH=$PWD
 O=gpurun_out/$1; mkdir -p $O; ST=${2:-60}; WU=${3:-5}
 run() { # tag "args" env...
   tag=$1; a=$2; shift; shift
-  env "$@" timeout 300 python bench.py --steps $ST --warmup $WU --no-cpu-baseline $a > $O/$tag.json 2> $O/$tag.err
+  env "$@" timeout 60 python bench.py --steps $ST --warmup $WU --no-cpu-baseline $a > $O/$tag.json 2> $O/$tag.err
   python - $O/$tag.json $tag <<'PY'
 import json,sys
 try:

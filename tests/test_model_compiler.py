@@ -91,13 +91,16 @@ def test_shipped_tables_match_fresh_compile(have_reference):
 
 
 def test_unsupported_collider_pairs_fail_the_compilation(have_reference, monkeypatch):
-    """A primitive pair without a narrow-phase routine (Baxter's pedestal capsule, robots/baxter/robot.xml:61) is either waived BY
-    NAME with a stated reason (reduce.WAIVED_COLLIDERS) or fails the model compilation -- never dropped silently."""
+    """A primitive pair without a narrow-phase routine fails the model compilation -- never dropped silently, and since round 5 nothing is
+    waived by name any more (Baxter's pedestal capsule, robots/baxter/robot.xml:61, collides: tests/test_capsule.py).  What is left
+    without a routine: convex-mesh colliders (three furniture) and ellipsoids (none in the assets)."""
     if not have_reference:
         pytest.skip("needs the reference's MJCF assets")
     from furniture_amd.mjcf import reduce
     from furniture_amd.mjcf.model import build_model
-    build_model("Baxter", "desk_mikael_1064")  # waived by name: compiles
-    monkeypatch.setattr(reduce, "WAIVED_COLLIDERS", set())
+    assert not reduce.WAIVED_COLLIDERS
+    m = build_model("Baxter", "desk_mikael_1064")
+    assert (m.arrays["cp"].reshape(-1, 3)[:, 2] == reduce.PT_CONVEX).sum() >= 16  # the capsule's pairs are in the candidate list
+    monkeypatch.delitem(reduce._PAIR_CODE, (reduce.GEOM_CAPSULE, reduce.GEOM_BOX))
     with pytest.raises(NotImplementedError, match="pedestal_2_collision"):
         build_model("Baxter", "desk_mikael_1064")
