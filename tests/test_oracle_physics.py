@@ -216,3 +216,30 @@ def test_sliding_friction_primal_dual_agree(sawyer_lack):
     a_p = solve("pgs", 200000, 0.0)
     assert np.abs(a_n).max() > 100  # genuinely dynamic
     assert np.abs(a_n - a_p).max() < 1e-6 * np.abs(a_n).max()
+
+
+def test_oracle_sim_solves_with_newton_unless_told_otherwise(sawyer_lack):
+    """Round 4: the C struct's zero-initialised solver kind is PGS, and a replay that forgot to say "newton" compared the device with PGS for
+    a round.  OracleSim selects Newton in its constructor; this pins it through behaviour: on a state with resting contacts a fresh
+    OracleSim must land on the Newton answer (1e-10 from an explicit Newton solve), which 100 PGS sweeps do not reach."""
+    from oracle.oracle_sim import OracleSim
+    m = sawyer_lack
+    q = m.qpos0.copy()
+    q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+    for i in range(m.nparts):
+        a = m.part_qposadr[i]
+        q[a:a + 7] = m.part_initqpos[i]
+        q[a + 2] -= 0.0005  # half a millimetre into the floor: active contacts
+    acc = {}
+    for tag, kind in (("default", None), ("newton", "newton"), ("pgs", "pgs")):
+        o = OracleSim(m)
+        if kind is not None:
+            o.set_solver(100, 1e-10, kind)
+        o.reset()
+        o.data.qpos[:] = q
+        o.forward()
+        acc[tag] = np.array(o.data.qacc)
+        o.close()
+    scale = np.abs(acc["newton"]).max()
+    assert np.abs(acc["default"] - acc["newton"]).max() < 1e-6 * scale
+    assert np.abs(acc["pgs"] - acc["newton"]).max() > 1e-4 * scale  # (the two kinds ARE told apart by this state)
