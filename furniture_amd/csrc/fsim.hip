@@ -1054,6 +1054,13 @@ static int build_model(fsim *s) {
     std::vector<float> mg_, gp_, rb_, sz_;
     blob_i(s->blob, "cp", cp_); blob_i(s->blob, "cg_type", ty_); blob_f(s->blob, "cg_margin", mg_); blob_f(s->blob, "cg_gap", gp_);
     blob_f(s->blob, "cg_rbound", rb_); blob_f(s->blob, "cg_size", sz_);
+    // convex-mesh colliders (tables compiled since round 5; absent = none)
+    std::vector<int> ma_, mn_;
+    std::vector<float> mv_;
+    blob_i(s->blob, "cg_meshadr", ma_); blob_i(s->blob, "cg_meshnum", mn_); blob_f(s->blob, "mesh_vert", mv_);
+    if (mv_.empty()) mv_.assign(4, 0.0f);
+    if (mv_.size() / 3 > 65535) FAIL(FSIM_ENOMEM, "more than 65535 hull vertices of mesh colliders");
+    ar.add(&s->m.mesh_vert, mv_);
     std::vector<float> rec((size_t)16 * std::max(m.ncp, 1), 0.0f);
     for (int p = 0; p < m.ncp; p++) {
       int g1 = cp_[3 * p], g2 = cp_[3 * p + 1], w[4] = {g1, g2, cp_[3 * p + 2], ty_[g1] | (ty_[g2] << 8)};
@@ -1061,6 +1068,16 @@ static int build_model(fsim *s) {
       memcpy(r, w, 16);
       r[4] = std::max(mg_[g1], mg_[g2]); r[5] = std::max(gp_[g1], gp_[g2]); r[6] = rb_[g1]; r[7] = rb_[g2];
       for (int k = 0; k < 3; k++) { r[8 + k] = sz_[3 * g1 + k]; r[12 + k] = sz_[3 * g2 + k]; }
+      const int gs[2] = {g1, g2};
+      for (int q = 0; q < 2; q++) {
+        const int g = gs[q];
+        int packed = 0;
+        if (ty_[g] == GT_MESH) {
+          if ((size_t)g >= ma_.size() || ma_[g] < 0 || mn_[g] <= 0) FAIL(FSIM_EINVAL, "mesh collider without hull vertices (model compiled before round 5?)");
+          packed = ma_[g] | (mn_[g] << 16);
+        }
+        memcpy(r + 11 + 4 * q, &packed, 4);
+      }
     }
     ar.add(&s->m.pair_rec, rec);
     std::vector<int> bp((size_t)2 * std::max(m.ncp, 1), 0);

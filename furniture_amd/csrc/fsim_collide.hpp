@@ -14,7 +14,7 @@
 enum { C_ACTIVE = 0, C_POS = 1, C_FRAME = 4, C_MU = 7, C_DIM = 8, C_B1 = 9, C_B2 = 10, C_G1 = 11, C_G2 = 12, C_AREF = 13,
        C_DIST = 14, C_INCM = 15, C_DN = 16, C_DT = 17 };
 
-__constant__ int FS_PAIR_MAXCON[11] = {1, 4, 4, 1, 1, 1, 8, 1, 1, 2, 1};
+__constant__ int FS_PAIR_MAXCON[12] = {1, 4, 4, 1, 1, 1, 8, 1, 1, 2, 1, 4};
 
 template <class Ctx> struct Emit {
   const Ctx &c;
@@ -412,11 +412,48 @@ DEV bool np_cyl_box_separated(V3 pc, const M3 &Rc, V3 sc, V3 pb, const M3 &Rb, V
   return sep;
 }
 
-// ---- Minkowski portal refinement for cylinder-box / cylinder-cylinder --------------------------
-struct Shape { int type; V3 pos; M3 R; V3 size; };
-DEV V3 np_support(const Shape &s, V3 dir) {
+// the hull vertex furthest along the local direction dl (arg max; first one on ties: a function of the inputs alone)
+typedef const __attribute__((address_space(1))) float *MeshVerts; // (global memory: the model's hull-vertex table)
+DEV V3 np_mesh_support(MeshVerts verts, int n, V3 dl) {
+  float best = -3.0e38f;
+  V3 bv = v3(0, 0, 0);
+  for (int i = 0; i < n; i++) {
+    const V3 v = v3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    const float d = dot(v, dl);
+    if (d > best) { best = d; bv = v; }
+  }
+  return bv;
+}
+// plane - convex mesh: the hull's lowest vertex, then the vertices a slightly tilted "down" picks in three directions 120 degrees
+// apart (for a hull resting on a face these are spread over that face: a stable support polygon instead of three neighbours of the
+// lowest corner) -- the scheme of MuJoCo's mjc_PlaneConvex; every distinct vertex within the margin is a contact, at most four.
+template <class Emit> DEV void np_plane_mesh(const Emit &e, V3 pp, const M3 &pR, V3 mp, const M3 &mR, MeshVerts verts, int n) {
+  const V3 nw = colv(pR, 2), t1 = colv(pR, 0), t2 = colv(pR, 1);
+  V3 prev[4];
+  int cnt = 0;
+  for (int k = 0; k < 4; k++) {
+    V3 dw = -nw;
+    if (k > 0) { const float a = 2.0943951f * (float)(k - 1); dw = dw + (t1 * cosf(a) + t2 * sinf(a)) * 1e-3f; }
+    const V3 vl = np_mesh_support(verts, n, multv(mR, dw));
+    bool dup = false;
+    for (int j = 0; j < cnt; j++) if (prev[j].x == vl.x && prev[j].y == vl.y && prev[j].z == vl.z) dup = true;
+    if (dup) continue;
+    prev[cnt++] = vl;
+    const V3 vw = mulv(mR, vl) + mp;
+    const float dist = dot(vw - pp, nw);
+    if (dist > e.margin) continue;
+    e(k, dist, vw - nw * (0.5f * dist), nw);
+  }
+}
+
+// ---- Minkowski portal refinement for cylinder-box / cylinder-cylinder; every pair with a capsule or a convex mesh in it ---------
+struct Shape { int type; V3 pos; M3 R; V3 size; MeshVerts verts; int nvert; }; // verts / nvert: hull of a convex mesh (geom frame)
+// MESH: the kernel serves models with convex-mesh colliders (the generic kernels; the kernels specialised for one model -- the
+// benchmark's -- are compiled without that branch: nothing that is not the benchmark's work belongs in its substep loop)
+template <bool MESH> DEV V3 np_support(const Shape &s, V3 dir) {
   V3 dl = multv(s.R, dir), pl;
-  if (s.type == GT_BOX) pl = v3(dl.x >= 0 ? s.size.x : -s.size.x, dl.y >= 0 ? s.size.y : -s.size.y, dl.z >= 0 ? s.size.z : -s.size.z);
+  if (MESH && s.type == GT_MESH) pl = np_mesh_support(s.verts, s.nvert, dl);
+  else if (s.type == GT_BOX) pl = v3(dl.x >= 0 ? s.size.x : -s.size.x, dl.y >= 0 ? s.size.y : -s.size.y, dl.z >= 0 ? s.size.z : -s.size.z);
   else if (s.type == GT_CYLINDER) {
     float rho = sqrtf(dl.x * dl.x + dl.y * dl.y);
     pl = rho > 1e-12f ? v3(dl.x / rho * s.size.x, dl.y / rho * s.size.x, 0) : v3(0, 0, 0);
@@ -429,8 +466,9 @@ DEV V3 np_support(const Shape &s, V3 dir) {
   return mulv(s.R, pl) + s.pos;
 }
 struct Sup { V3 v, a, b; };
-DEV Sup np_msup(const Shape &A, const Shape &B, V3 dir) { Sup s; s.a = np_support(A, -dir); s.b = np_support(B, dir); s.v = s.b - s.a; return s; }
-template <class Emit> DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
+template <bool MESH> DEV Sup np_msup_t(const Shape &A, const Shape &B, V3 dir) { Sup s; s.a = np_support<MESH>(A, -dir); s.b = np_support<MESH>(B, dir); s.v = s.b - s.a; return s; }
+template <class Emit, bool MESH = false> DEV void np_mpr(const Emit &e, const Shape &A, const Shape &B) {
+  auto np_msup = [](const Shape &A_, const Shape &B_, V3 d_) { return np_msup_t<MESH>(A_, B_, d_); };
   Sup v0, v1, v2, v3_, v4;
   v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
   if (dot(v0.v, v0.v) < 1e-20f) v0.v.x = 1e-5f;
@@ -632,6 +670,7 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
         np_plane_sphere(e, p1, R1, p2 - ax * s2.y, s2.x);
         break;
       }
+      case PT_PLANE_MESH: { if constexpr (!Ctx::PLAIN) { const int mk = __float_as_int(q3.w); np_plane_mesh(e, p1, R1, p2, R2, GP(m.mesh_vert) + 3 * (mk & 0xffff), mk >> 16); } break; }
       default: {
         // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
         // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)
@@ -641,7 +680,10 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
         Shape A, B;
         A.type = q0.w & 255; A.pos = p1; A.R = R1; A.size = s1;
         B.type = q0.w >> 8; B.pos = p2; B.R = R2; B.size = s2;
-        np_mpr(e, A, B);
+        A.verts = nullptr; A.nvert = 0; B.verts = nullptr; B.nvert = 0;
+        if constexpr (!Ctx::PLAIN) { const int ma = __float_as_int(q2.w), mb = __float_as_int(q3.w); // (0 unless the geom is a convex mesh)
+          A.verts = GP(m.mesh_vert) + 3 * (ma & 0xffff); A.nvert = ma >> 16; B.verts = GP(m.mesh_vert) + 3 * (mb & 0xffff); B.nvert = mb >> 16; }
+        np_mpr<Emit<Ctx>, !Ctx::PLAIN>(e, A, B);
       }
     }
       }
@@ -664,6 +706,7 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
         np_plane_sphere(e, p1, R1, p2 - ax * s2.y, s2.x);
         break;
       }
+      case PT_PLANE_MESH: { if constexpr (!Ctx::PLAIN) { const int mk = __float_as_int(q3.w); np_plane_mesh(e, p1, R1, p2, R2, GP(m.mesh_vert) + 3 * (mk & 0xffff), mk >> 16); } break; }
       default: {
         // cylinder c capsule of the same radius and half length: if the two capsules are farther apart than the
         // margin the cylinders cannot touch (robot link pairs that sit next to each other but never collide)
@@ -673,7 +716,10 @@ template <class Ctx> DEV void fs_collide(const Ctx &c) {
         Shape A, B;
         A.type = q0.w & 255; A.pos = p1; A.R = R1; A.size = s1;
         B.type = q0.w >> 8; B.pos = p2; B.R = R2; B.size = s2;
-        np_mpr(e, A, B);
+        A.verts = nullptr; A.nvert = 0; B.verts = nullptr; B.nvert = 0;
+        if constexpr (!Ctx::PLAIN) { const int ma = __float_as_int(q2.w), mb = __float_as_int(q3.w); // (0 unless the geom is a convex mesh)
+          A.verts = GP(m.mesh_vert) + 3 * (ma & 0xffff); A.nvert = ma >> 16; B.verts = GP(m.mesh_vert) + 3 * (mb & 0xffff); B.nvert = mb >> 16; }
+        np_mpr<Emit<Ctx>, !Ctx::PLAIN>(e, A, B);
       }
     }
 #endif

@@ -21,9 +21,10 @@
 #define FSIM_MAXSURV 48  // broadphase survivors per substep of models with <= 8 parts (22 is the most seen on Sawyer + table_lack); LayoutIn::maxsurv
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
-enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_CYLINDER = 5, GT_BOX = 6 };
+enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_CYLINDER = 5, GT_BOX = 6, GT_MESH = 7 };
 enum { PT_PLANE_SPHERE = 0, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL,
-       PT_PLANE_CAP, PT_CONVEX /* every other pair with a capsule in it: sphere / capsule / cylinder / box x capsule, through the portal routine */ };
+       PT_PLANE_CAP, PT_CONVEX /* every other pair with a capsule or a convex mesh in it, through the portal routine */,
+       PT_PLANE_MESH /* a convex mesh (its hull vertices: DModel::mesh_vert) against a plane */ };
 
 // Dimensions and scalar options of a model.  The generic kernels read them at run time (scalar loads from the DModel
 // in constant memory); the kernels specialised for one (agent, furniture, config) carry them as compile-time constants
@@ -53,8 +54,10 @@ struct DModel : Dims {
   const float *cg_pos, *cg_mat, *cg_size, *cg_rbound, *cg_friction, *cg_solref, *cg_solimp, *cg_margin, *cg_gap, *cg_solmix, *cg_invweight;
   const int *cp; // [ncp][3] = cg1, cg2, pair type
   // [ncp][16] one 64-byte record per candidate pair with everything the broad/narrow phase needs from the two geoms:
-  // g1 g2 pairtype (type1 | type2 << 8) | margin gap rbound1 rbound2 | size1 xyz - | size2 xyz -   (built by fsim_create)
+  // g1 g2 pairtype (type1 | type2 << 8) | margin gap rbound1 rbound2 | size1 xyz mesh1 | size2 xyz mesh2   (built by fsim_create;
+  // mesh = first hull vertex | vertex count << 16 for a convex-mesh geom, as int bits)
   const float *pair_rec;
+  const float *mesh_vert; // [nvert][3] convex-hull vertices of the colliding mesh geoms, geom frame (three furniture: SURVEY C.1)
   // [ncp][2] broadphase stage-1 record: g1 | g2 << 8 | (geom 1 is a plane) << 16, then the float bound the centre distance (plane:
   // the signed distance of geom 2's centre) is tested against: r1 + r2 + margin (plane: r2 + margin)
   const int *pair_bp;

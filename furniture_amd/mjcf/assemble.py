@@ -259,6 +259,11 @@ def assemble_scene(assets_root, agent, furniture_name, control_type="impedance",
     # FloorTask.__init__ order: arena, robot, objects, equality (floor_task.py:33-36)
     world.merge(arena)
     world.merge(robot)
+    # (ref tasks/floor_task.py merge_objects -> merge_asset: the furniture's meshes travel with its bodies; three furniture collide them)
+    have = {a_.get("name") for a_ in world.asset}
+    for a_ in list(furn.asset):
+        if a_.get("name") not in have:
+            world.asset.append(copy.deepcopy(a_))
     for p in part_names:
         world.worldbody.append(_part_collision_body(furn, p))
     for eq in list(furn.equality):

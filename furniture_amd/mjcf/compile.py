@@ -12,6 +12,7 @@ Everything is float64 numpy here; the device library down-converts to fp32.
 """
 
 import math
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -135,6 +136,44 @@ class _Defaults:
         return base
 
 
+def load_stl(path):
+    """Triangles [n, 3, 3] of a binary (or ASCII) STL file."""
+    raw = open(path, "rb").read()
+    if len(raw) >= 84:
+        n = int(np.frombuffer(raw, dtype="<u4", count=1, offset=80)[0])
+        if len(raw) == 84 + 50 * n:
+            rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+            return np.array(rec["v"], dtype=np.float64)
+    tri = [[float(x) for x in ln.split()[1:4]] for ln in raw.decode("ascii", "ignore").splitlines() if ln.strip().startswith("vertex")]
+    return np.array(tri, dtype=np.float64).reshape(-1, 3, 3)
+
+
+def mesh_properties(tri):
+    """(volume, centre of mass, inertia tensor about the centre of mass per unit density) of the closed surface `tri` [n, 3, 3], by
+    signed tetrahedra from the origin -- what MuJoCo's compiler does with a mesh geom's triangles (the surface is taken as closed and
+    consistently oriented; a surface wound inside out gives a negative volume and is flipped)."""
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    det = np.einsum("ij,ij->i", a, np.cross(b, c))  # 6 x signed volume of (0, a, b, c)
+    vol = det.sum() / 6.0
+    if vol < 0:
+        det, vol = -det, -vol
+    com = (det[:, None] * (a + b + c)).sum(0) / (24.0 * vol)
+    # second moments of a tetrahedron (0, a, b, c): integral x_i x_j dV = det / 120 * (sum over vertex pairs ...)
+    s = a + b + c
+    C = (np.einsum("n,ni,nj->ij", det, a, a) + np.einsum("n,ni,nj->ij", det, b, b) + np.einsum("n,ni,nj->ij", det, c, c) + np.einsum("n,ni,nj->ij", det, s, s)) / 120.0
+    C -= vol * np.outer(com, com)  # about the centre of mass
+    I = np.trace(C) * np.eye(3) - C
+    return vol, com, I
+
+
+def mesh_hull(tri):
+    """vertices [k, 3] of the convex hull of the mesh: what MuJoCo collides a mesh geom with"""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(tri.reshape(-1, 3), axis=0)
+    h = ConvexHull(pts)
+    return pts[np.sort(h.vertices)]
+
+
 def _geom_mass_inertia(gtype, size, density):
     """mass and diagonal inertia (geom frame, about geom centre) of a primitive."""
     if gtype == GEOM_BOX:
@@ -167,9 +206,8 @@ def _geom_mass_inertia(gtype, size, density):
     elif gtype == GEOM_MESH:
         # Visual meshes carry density 0 everywhere except toy_table's part1 (density="01",
         # SURVEY C.1): 1 kg/m^3 x ~1e-4 m^3 of STL volume ~ 0.1 g next to the part's primitive
-        # colliders.  The STL is not parsed; that mass is dropped (documented in DESIGN.md).
-        if density > 1.0:
-            raise NotImplementedError("mesh geoms with density > 1 need mesh volume (out of scope)")
+        # colliders; that mass is dropped (documented in DESIGN.md).  Meshes that collide or weigh more are handled by the caller
+        # (compile_mjcf: volume and inertia from the triangles).
         return 0.0, np.zeros(3)
     else:
         raise ValueError(gtype)
@@ -195,9 +233,26 @@ class Flat:
         return {k: v for k, v in self.__dict__.items()}
 
 
-def compile_mjcf(root):
-    """Flatten an assembled MJCF tree.  Returns a ``Flat``."""
+def compile_mjcf(root, mesh_root=None):
+    """Flatten an assembled MJCF tree.  Returns a ``Flat``.  mesh_root: directory the <mesh file=...> paths are relative to (only
+    needed by models whose mesh geoms collide or carry mass: three furniture)."""
     dfl = _Defaults(root)
+    mesh_assets = {}
+    for a_ in root.iter("asset"):
+        for me in a_.findall("mesh"):
+            mesh_assets[me.get("name")] = (me.get("file"), _floats(me.get("scale"), 3, (1, 1, 1)))
+    mesh_cache = {}
+
+    def mesh_of(name):
+        """(hull vertices, volume, centre of mass, inertia about it per unit density) of mesh asset `name`, in the mesh geom's frame"""
+        if name not in mesh_cache:
+            if mesh_root is None or name not in mesh_assets:
+                raise NotImplementedError("mesh geom %r collides / carries mass, but its STL file cannot be found (mesh_root)" % name)
+            f, sc = mesh_assets[name]
+            tri = load_stl(os.path.join(mesh_root, f)) * sc
+            vol, com, I = mesh_properties(tri)
+            mesh_cache[name] = (mesh_hull(tri), vol, com, I)
+        return mesh_cache[name]
     opt = root.find("option")
     optattr = dict(opt.attrib) if opt is not None else {}
     if optattr.get("cone", "pyramidal") != "elliptic":
@@ -314,7 +369,7 @@ def compile_mjcf(root):
 
     # ---- geoms -----------------------------------------------------------
     G = dict(name=[], type=[], bodyid=[], contype=[], conaffinity=[], condim=[], size=[], pos=[], quat=[],
-             friction=[], solref=[], solimp=[], margin=[], gap=[], rbound=[], solmix=[], priority=[], density=[])
+             friction=[], solref=[], solimp=[], margin=[], gap=[], rbound=[], solmix=[], priority=[], density=[], mesh=[])
     for b in bodies:
         for ga in b["geoms"]:
             gt = _GEOM_TYPES[ga.get("type", "sphere")]
@@ -335,11 +390,23 @@ def compile_mjcf(root):
             G["solimp"].append(_floats(ga.get("solimp"), 5, _DEF_SOLIMP))
             G["margin"].append(float(ga.get("margin", 0)))
             G["gap"].append(float(ga.get("gap", 0)))
+            G["mesh"].append(ga.get("mesh") if gt == GEOM_MESH else None)
             G["rbound"].append(_rbound(gt, size))
             G["solmix"].append(float(ga.get("solmix", 1)))
             G["priority"].append(int(ga.get("priority", 0)))
             G["density"].append(float(ga.get("density", 1000)))
     ngeom = len(G["type"])
+    # mesh geoms that collide or carry mass: convex hull (what they collide with), bounding radius about the geom origin.  Visual meshes
+    # (contype = conaffinity = 0, density <= 1) stay what they were: massless and absent from the tables.
+    mesh_adr, mesh_num, mesh_vert = [-1] * ngeom, [0] * ngeom, []
+    for g in range(ngeom):
+        if G["type"][g] != GEOM_MESH or not (G["contype"][g] or G["conaffinity"][g]):
+            continue
+        hull = mesh_of(G["mesh"][g])[0]
+        mesh_adr[g], mesh_num[g] = sum(len(v) for v in mesh_vert), len(hull)
+        mesh_vert.append(hull)
+        G["rbound"][g] = float(np.linalg.norm(hull, axis=1).max())
+        G["size"][g] = np.abs(hull).max(axis=0)
     if any(c not in (1, 3) for c, t, ct, ca in zip(G["condim"], G["type"], G["contype"], G["conaffinity"]) if ct or ca):
         raise NotImplementedError("only condim 1/3 contacts are implemented")
 
@@ -378,6 +445,20 @@ def compile_mjcf(root):
         tot, com = 0.0, np.zeros(3)
         parts = []
         for g in geom_index_of_body[i]:
+            if G["type"][g] == GEOM_MESH and (mesh_adr[g] >= 0 or G["density"][g] > 1.0) and G["density"][g] > 0:
+                # the mesh's own volume, centre of mass and inertia tensor (signed tetrahedra of its triangles), entered as a primitive
+                # sitting at that centre of mass with its principal axes
+                _, vol, cm, It = mesh_of(G["mesh"][g])
+                mg = G["density"][g] * vol
+                wI, VI = np.linalg.eigh(It * G["density"][g])
+                if np.linalg.det(VI) < 0:
+                    VI[:, 2] = -VI[:, 2]
+                Rg = q2m(G["quat"][g])
+                pg = G["pos"][g] + Rg @ cm
+                parts.append((mg, wI, pg, Rg @ VI))
+                tot += mg
+                com += mg * pg
+                continue
             mg, Ig = _geom_mass_inertia(G["type"][g], G["size"][g], G["density"][g])
             if mg <= 0:
                 continue
@@ -510,6 +591,9 @@ def compile_mjcf(root):
     m.geom_margin = np.array(G["margin"])
     m.geom_gap = np.array(G["gap"])
     m.geom_rbound = np.array(G["rbound"])
+    m.geom_meshadr = np.array(mesh_adr, dtype=np.int32)  # first hull vertex of a colliding mesh geom in mesh_vert, -1 = none
+    m.geom_meshnum = np.array(mesh_num, dtype=np.int32)
+    m.mesh_vert = np.concatenate(mesh_vert).reshape(-1, 3) if mesh_vert else np.zeros((0, 3))  # hull vertices, geom frame
     m.geom_solmix = np.array(G["solmix"])
     m.geom_priority = np.array(G["priority"], dtype=np.int32)
     m.site_bodyid = np.array(S["bodyid"], dtype=np.int32)
@@ -581,11 +665,8 @@ def compile_mjcf(root):
                 e2 = (1, 1) if (part_like(G["name"][g2]) and b2 in _part_body_ids(m)) else (ct2, ca2)
                 if not ((e1[0] & e2[1]) or (e2[0] & e1[1])):
                     continue
-            if G["type"][g1] == GEOM_MESH or G["type"][g2] == GEOM_MESH:
-                # mesh colliders exist only in 3 out-of-scope furniture models
-                if static_ok:
-                    raise NotImplementedError("mesh collider %s / %s" % (G["name"][g1], G["name"][g2]))
-                continue
+            if (G["type"][g1] == GEOM_MESH and mesh_adr[g1] < 0) or (G["type"][g2] == GEOM_MESH and mesh_adr[g2] < 0):
+                continue  # a visual mesh (contype = conaffinity = 0): never collides
             pairs.append((g1, g2))
     m.pair_geom = np.array(pairs, dtype=np.int32).reshape(-1, 2)
     m.npair = len(pairs)

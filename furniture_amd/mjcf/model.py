@@ -149,7 +149,7 @@ def load_compiled(agent, furniture_name, control_type="impedance"):
 def build_model(agent, furniture_name, control_type="impedance", assets_root=None, move_speed=0.1):
     assets_root = assets_root or _asm.default_assets_root()
     root, info = _asm.assemble_scene(assets_root, agent, furniture_name, control_type, move_speed)
-    m = _cmp.compile_mjcf(root)
+    m = _cmp.compile_mjcf(root, mesh_root=os.path.join(assets_root, "objects"))
     A = {}
     for k, v in m.__dict__.items():
         if isinstance(v, np.ndarray) and not k.startswith("_"):

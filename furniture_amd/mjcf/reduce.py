@@ -14,10 +14,10 @@ CompiledModel's array table.
 
 import numpy as np
 
-from .compile import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, q2m, qmul)
+from .compile import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, q2m, qmul)
 
 # pair-type codes consumed by the narrow phase kernel
-PT_PLANE_SPHERE, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL, PT_PLANE_CAP, PT_CONVEX = range(11)
+PT_PLANE_SPHERE, PT_PLANE_BOX, PT_PLANE_CYL, PT_SPHERE_SPHERE, PT_SPHERE_BOX, PT_SPHERE_CYL, PT_BOX_BOX, PT_CYL_BOX, PT_CYL_CYL, PT_PLANE_CAP, PT_CONVEX, PT_PLANE_MESH = range(12)
 _PAIR_CODE = {
     (GEOM_PLANE, GEOM_SPHERE): PT_PLANE_SPHERE, (GEOM_PLANE, GEOM_BOX): PT_PLANE_BOX, (GEOM_PLANE, GEOM_CYLINDER): PT_PLANE_CYL,
     (GEOM_SPHERE, GEOM_SPHERE): PT_SPHERE_SPHERE, (GEOM_SPHERE, GEOM_BOX): PT_SPHERE_BOX, (GEOM_SPHERE, GEOM_CYLINDER): PT_SPHERE_CYL,
@@ -26,8 +26,13 @@ _PAIR_CODE = {
     # every other pair through the Minkowski-portal routine with the capsule's support function (a sphere swept along a segment)
     (GEOM_PLANE, GEOM_CAPSULE): PT_PLANE_CAP, (GEOM_SPHERE, GEOM_CAPSULE): PT_CONVEX, (GEOM_CAPSULE, GEOM_CAPSULE): PT_CONVEX,
     (GEOM_CAPSULE, GEOM_CYLINDER): PT_CONVEX, (GEOM_CAPSULE, GEOM_BOX): PT_CONVEX,
+    # convex meshes (round 5; three furniture collide mesh geoms: chair_agne_0010, chair_bertil_0148, shelf_liden_0922): the mesh's convex
+    # hull -- vertices in the geom frame, tables mesh_vert / cg_meshadr / cg_meshnum -- against a plane (its lowest vertices), every other
+    # pair through the portal routine with the hull's support function (arg max over its vertices)
+    (GEOM_PLANE, GEOM_MESH): PT_PLANE_MESH, (GEOM_SPHERE, GEOM_MESH): PT_CONVEX, (GEOM_CAPSULE, GEOM_MESH): PT_CONVEX,
+    (GEOM_CYLINDER, GEOM_MESH): PT_CONVEX, (GEOM_BOX, GEOM_MESH): PT_CONVEX, (GEOM_MESH, GEOM_MESH): PT_CONVEX,
 }
-PAIR_MAXCON = [1, 4, 4, 1, 1, 1, 8, 1, 1, 2, 1]
+PAIR_MAXCON = [1, 4, 4, 1, 1, 1, 8, 1, 1, 2, 1, 4]
 
 
 # Colliders whose pairs are waived (not collided) instead of failing the compilation: none since round 5 (Baxter's pedestal capsule,
@@ -175,6 +180,13 @@ def reduce_model(A):
             cpos[i] = rel_pos[b] + R @ A["geom_pos"][g]
             cquat[i] = qmul(rel_quat[b], A["geom_quat"][g])
     cg["pos"], cg["quat"] = cpos, cquat
+    # convex-mesh colliders: where each colliding geom's hull vertices sit in mesh_vert (geom frame: unchanged by the body reduction)
+    if "geom_meshadr" in A:
+        cg["meshadr"] = A["geom_meshadr"][used].astype(np.int32)
+        cg["meshnum"] = A["geom_meshnum"][used].astype(np.int32)
+    else:  # (tables compiled before round 5)
+        cg["meshadr"] = -np.ones(ncg, dtype=np.int32)
+        cg["meshnum"] = np.zeros(ncg, dtype=np.int32)
     for nm in ("type", "condim"):
         cg[nm] = A["geom_" + nm][used].astype(np.int32)
     for nm in ("size", "rbound", "friction", "solref", "solimp", "margin", "gap", "solmix"):

@@ -56,6 +56,8 @@ typedef struct {
   double *eq_data;    /* mutable (furniture.py:2772) */
   const double *eq_solref, *eq_solimp;
   const int32_t *pair_geom;
+  const int32_t *geom_meshadr, *geom_meshnum; /* convex-mesh colliders: hull vertices in mesh_vert (geom frame); NULL in tables compiled before round 5 */
+  const double *mesh_vert;
   int ntree;
   int *tree_dofadr, *tree_dofnum, *dof_treeid;
 } Model;
@@ -137,6 +139,10 @@ static int load_model(osim_t *s, size_t nbytes) {
   GETD(actuator_gain); GETD(actuator_bias); GETD(actuator_ctrlrange); GETD(actuator_forcerange); GETD(actuator_gear);
   GETI(eq_obj1id); GETI(eq_obj2id); GETD(eq_solref); GETD(eq_solimp);
   GETI(pair_geom);
+  m->geom_meshadr = (const int32_t *)blob_find(s->blob, nbytes, "geom_meshadr", 1, NULL); /* optional */
+  m->geom_meshnum = (const int32_t *)blob_find(s->blob, nbytes, "geom_meshnum", 1, NULL);
+  m->mesh_vert = (const double *)blob_find(s->blob, nbytes, "mesh_vert", 0, NULL);
+  g_err[0] = 0;
   /* mutable copies seeded from the *0 arrays */
   {
     int64_t c;

@@ -29,4 +29,4 @@ K(isa_constraints, { fs_make_constraints(c); })
 KE(isa_boxbox, { np_box_box(e, p1, R1, s1, p2, R2, s2); })
 KE(isa_planebox, { np_plane_box(e, p1, R1, p2, R2, s2); })
 KE(isa_cylboxsep, { out[c.lane] = np_cyl_box_separated(p1, R1, s1, p2, R2, s2, out[5]); })
-KE(isa_mpr, { Shape A, B; A.type = a; A.pos = p1; A.R = R1; A.size = s1; B.type = b; B.pos = p2; B.R = R2; B.size = s2; np_mpr(e, A, B); })
+KE(isa_mpr, { Shape A, B; A.type = a; A.pos = p1; A.R = R1; A.size = s1; B.type = b; B.pos = p2; B.R = R2; B.size = s2; A.verts = nullptr; A.nvert = 0; B.verts = nullptr; B.nvert = 0; np_mpr(e, A, B); })

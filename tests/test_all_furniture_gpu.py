@@ -77,6 +77,9 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
     assert refused == [] and sorted(x[0] for x in troubled) == ["bookcase_billy_0191", "table_liden_0921"], (refused, troubled)
     assert sorted(unplaceable) == ["bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"], unplaceable
     assert len(ran) == len(names) - 5
+    # since round 5 all 64 furniture of the reference compile (furniture/tests/test_furniture_init.py:14-55 resets them all): the three
+    # that collide mesh geoms run like the others (their hulls: tests/test_mesh.py)
+    assert len(names) == 64 and {"chair_agne_0010", "chair_bertil_0148", "shelf_liden_0922"} <= set(ran)
 
 
 def test_a_model_with_more_than_64_dofs_matches_the_oracle_env():
