@@ -3,7 +3,7 @@
 #   usage: scripts/pmc_traffic.sh <tag>   -> gpurun_out/<tag>/pmc.json
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-traffic}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-PB="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline"
+PB="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --episode-window 0"
 i=2
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
