@@ -70,20 +70,94 @@ def _cpu_worker(args):
     return n, dt, (tc[0] / dt if idx == 0 else None)
 
 
-def cpu_baseline(seconds=10.0):
+def _cpu_native_worker(q, seconds, n):
+    """(spawned with OMP_NUM_THREADS set): oracle/libfsim_cpu.so -- the SAME C-ABI as the product's (include/fsim.h) on host memory, env
+    logic and physics in C, one env per OpenMP thread -- driven with the benchmark's own protocol: auto-reset at 150 steps, reset
+    tables from the reference's RNG stream uploaded for the envs that consumed theirs."""
+    import ctypes
+    from furniture_amd.envs import ResetTableQueue, ResetTableSampler, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from furniture_amd.sim import FsimConfig, INFO_DIM, INFO_NEEDS_TABLE
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libfsim_cpu.so"))
+    L.fsim_last_error.restype = ctypes.c_char_p
+    m = load_compiled(AGENT, FURNITURE)
+    ecfg = make_config(unity=False, record_vid=False, furniture_name=FURNITURE, max_episode_steps=MAX_EPISODE_STEPS, seed=SEED)
+    cfg = FsimConfig()
+    L.fsim_default_config(ctypes.byref(cfg))
+    cfg.max_episode_steps, cfg.auto_reset = MAX_EPISODE_STEPS, 1
+    h = ctypes.c_void_p()
+    blob = m.to_blob()
+    vp = ctypes.c_void_p
+
+    def ck(rc):
+        if rc != 0:
+            raise RuntimeError(L.fsim_last_error().decode())
+    ck(L.fsim_create(blob, ctypes.c_size_t(len(blob)), n, 0, ctypes.byref(cfg), ctypes.byref(h)))
+    tables = ResetTableQueue(ResetTableSampler(m, ecfg, SEED, 0, n))
+
+    def upload(mask=None):
+        parts, noise = tables.take(mask)
+        parts, noise = np.ascontiguousarray(parts, dtype=np.float32), np.ascontiguousarray(noise, dtype=np.float32)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        ck(L.fsim_set_reset_tables(h, None if mk is None else vp(mk.ctypes.data), vp(parts.ctypes.data), vp(noise.ctypes.data), 101))
+    upload()
+    obs = np.zeros((n, 64), dtype=np.float32)
+    rew, done, info = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.uint8), np.zeros((n, INFO_DIM), dtype=np.int32)
+    ck(L.fsim_reset(h, None, vp(obs.ctypes.data)))
+    upload()
+    rng = np.random.RandomState(SEED)
+    k, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        a = rng.uniform(-1, 1, (n, 9)).astype(np.float32)
+        ck(L.fsim_step(h, vp(a.ctypes.data), vp(obs.ctypes.data), vp(rew.ctypes.data), vp(done.ctypes.data), vp(info.ctypes.data)))
+        k += 1
+        if L.fsim_tables_needed(h):
+            upload(info[:, INFO_NEEDS_TABLE] > 0)
+    dt = time.time() - t0
+    tables.close()
+    L.fsim_destroy(h)
+    q.put((k * n, dt))
+
+
+def cpu_baseline(seconds=10.0, kind="native"):
     cores = max(1, min(os.cpu_count() or 1, 64))
     ctx = mp.get_context("spawn")
+    if kind == "native":
+        n = 16 * cores  # (sixteen envs per thread, dynamically scheduled: an env inside its 301-substep auto-reset or a slow contact step does not hold the batch)
+        q = ctx.Queue()
+        old = os.environ.get("OMP_NUM_THREADS")
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        try:
+            p = ctx.Process(target=_cpu_native_worker, args=(q, seconds, n))
+            p.start()
+            import queue
+            while True:  # (a worker that died -- library not built, ... -- must not leave the bench waiting)
+                try:
+                    steps, wall = q.get(timeout=1.0)
+                    break
+                except queue.Empty:
+                    if not p.is_alive():
+                        raise RuntimeError("cpu_baseline: the native worker exited with code %s" % p.exitcode)
+            p.join()
+        finally:
+            if old is None:
+                os.environ.pop("OMP_NUM_THREADS", None)
+            else:
+                os.environ["OMP_NUM_THREADS"] = old
+        return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port", "impl": "native C, same C-ABI (oracle/libfsim_cpu.so)",
+                "sample": "%d envs on %d OpenMP threads x %.0f s of FurnitureSawyerEnv+table_lack_0825 random-action steps incl. the auto-resets at 150 steps, "
+                          "env logic and fp64 physics in C behind include/fsim.h's entry points on host memory; %.1f env-steps/s per core"
+                          % (n, cores, wall, steps / wall / cores)}
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(i, seconds) for i in range(cores)])
     steps = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
     share = res[0][2]
-    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port", "impl": "Python env logic over the C physics (oracle/oracle_env.py)",
             "c_physics_share": round(share, 3) if share is not None else None,
             "sample": "%d envs (one per core) x %.0f s of FurnitureSawyerEnv+table_lack_0825 random-action steps incl. resets; "
                       "%.1f env-steps/s per core; %.0f %% of worker 0's wall time inside the C physics (osim_step), the rest is the Python env "
-                      "logic of the oracle env -- a fully native stepper would be at most %.2fx this baseline"
-                      % (cores, seconds, steps / wall / cores, 100 * (share or 0), 1.0 / max(share or 1.0, 1e-6))}
+                      "logic of the oracle env" % (cores, seconds, steps / wall / cores, 100 * (share or 0))}
 
 
 def _free_port():
@@ -198,6 +272,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["native", "python"], default="native", help="native: oracle/libfsim_cpu.so (C env logic + physics behind the same C-ABI, OpenMP); python: oracle/oracle_env.py, one process per core")
     ap.add_argument("--agent", default=AGENT, help="(exploration only; the benchmark workload is the default)")
     ap.add_argument("--furniture", default=FURNITURE, help="(exploration only)")
     ap.add_argument("--dense", action="store_true", help="(exploration only) FurnitureSawyerDenseRewardEnv: 8-phase dense reward + its config overrides")
@@ -574,7 +649,7 @@ def main():
                          "binding": binding},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_baseline)
         else:  # (the contract times it on rank 0 at N = 1 only: the 1-GPU line of the same sweep carries it)
             line["cpu_baseline"] = {"skipped": "--no-cpu-baseline" if args.no_cpu_baseline else "n_gpus > 1: timed at N = 1 only (see the 1-GPU line)"}
         print(json.dumps(line))

@@ -1,0 +1,700 @@
+/* fsim_cpu.c -- libfsim_cpu.so: the C-ABI of include/fsim.h on HOST memory, for the CPU checker ("liboracle.so
+ * exports the same symbols on host memory").
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in furniture_amd/ may load this library; it exists so that (1) tests/test_capi_cpu.py can make the
+ * SAME ctypes calls against libfsim.so (device pointers) and against this library (host pointers) and compare what comes back, and
+ * (2) bench.py's cpu_baseline leg times a NATIVE stepper (env logic + physics in C, one env per OpenMP thread) instead of the Python
+ * oracle env.  PARITY UNPINNED for the physics, exactly as fsim_oracle.h says: the physics underneath is oracle/fsim_oracle.c (fp64
+ * restatement of MuJoCo's published pipeline); the env logic here restates furniture/env/furniture.py the way oracle/oracle_env.py does
+ * (which is pinned to the reference's own methods by tests/golden/env_logic.npz, step_scan.npz, reset_trace.npz) and is checked against
+ * that Python restatement on the same inputs.
+ *
+ * Scope: the arm agents (Sawyer, Baxter) under control_type impedance with the sparse reward -- BASELINE configs 2, 3, 4 --, both
+ * auto_reset modes.  Dense reward, ik / arm controllers, the Cursor agent, pre-assembled starts, init states and
+ * reset_robot_after_attach are refused at fsim_create (FSIM_EINVAL): the Python oracle env remains their checker.
+ *
+ * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
+ * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
+ * furniture_sawyer.py:103-155 / furniture_baxter.py:98-165; _compute_reward :482-541; _after_step :451-480.
+ */
+#define _GNU_SOURCE /* M_PI */
+#include "../include/fsim.h"
+#include "fsim_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static _Thread_local char g_err[512];
+const char *fsim_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
+
+/* ---- blob access (furniture_amd/mjcf/model.py to_blob: magic, version, n, n x {name[48], code, pad, count, off}, data) */
+typedef struct { char name[48]; int32_t code, pad; int64_t count, off; } BlobEnt;
+static const void *blob_get(const char *blob, size_t nbytes, const char *name, int code, int64_t *count) {
+  int32_t n;
+  memcpy(&n, blob + 12, 4);
+  const BlobEnt *e = (const BlobEnt *)(blob + 16);
+  for (int i = 0; i < n; i++)
+    if (strncmp(e[i].name, name, 48) == 0 && e[i].code == code && (size_t)e[i].off + (size_t)e[i].count * (code == 0 ? 8 : 4) <= nbytes) {
+      if (count) *count = e[i].count;
+      return blob + e[i].off;
+    }
+  return NULL;
+}
+
+typedef struct {
+  int nq, nv, nu, nbody, ngeom, nsite, neq, nparts, narm, nconn, agent, narmj, ngripj, has_recipe, maxang;
+  double timestep, gravz;
+  const int32_t *part_bodyid, *part_qposadr, *part_dofadr, *body_partid, *geom_bodyid, *geom_fingerrole, *geom_is_robot, *geom_is_partcol,
+      *geom_contype0, *geom_conaffinity0, *floor_geomid, *eq_part1, *eq_part2, *arm_qposadr, *arm_dofadr, *grip_qposadr, *grip_dofadr,
+      *eef_siteid, *hand_bodyid, *conn_siteid, *conn_partid, *conn_keya, *conn_keyb, *conn_nangle, *part_site_adr, *part_site_num, *part_sites,
+      *site_bodyid;
+  const double *body_mass, *eq_data0, *arm_initqpos, *grip_initqpos, *ctrl_bias, *ctrl_weight, *conn_angles, *site_quat;
+} EnvModel;
+
+typedef struct {
+  osim_t *sim;
+  double *qpos, *qvel, *ctrl, *qfrc_applied, *xfrc_applied, *qacc, *qacc_warmstart, *qfrc_bias, *xpos, *xquat, *xmat, *site_xpos, *site_xmat, *time_, *eq_data;
+  int32_t *contype, *conaff, *eq_active, *cg1, *cg2, *ncon;
+  int group[32];
+  unsigned long long connected_sites;
+  int connect_step, connected, connected_body1, num_connected, prev_num_connected, site1, site2, success_num_conn, subtask1, subtask2;
+  int touched[32], picked[32];
+  double cb1_pos[3], cb1_quat[4], target_quat[4]; /* _connected_body1_pos / quat, _target_connector_xquat (wxyz) */
+  double episode_reward;
+  int episode_length, success, fail;
+} Env;
+
+struct fsim {
+  int n;
+  char *blob;
+  size_t nbytes;
+  fsim_config_t cfg;
+  EnvModel m;
+  Env *env;
+  float *tab_parts, *tab_noise; /* [n][nparts*7], [n][n_noise][narmj] */
+  int n_noise, n_substeps, dof, obs_dim, tables_needed;
+};
+
+/* ---- small vector / quaternion helpers (furniture_amd/transform_utils.py; quaternions wxyz unless said otherwise) */
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double norm3(const double *a) { return sqrt(dot3(a, a)); }
+static void cross3(double *c, const double *a, const double *b) { double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0]; c[0] = x; c[1] = y; c[2] = z; }
+static void qmul(double *o, const double *a, const double *b) {
+  double r[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(o, r, sizeof r);
+}
+static void qinv(double *o, const double *q) { double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2; }
+/* Quaternion.rotate: the quaternion is normalised first */
+static void qrot(double *o, const double *q, const double *v) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n}, uc[4] = {u[0], -u[1], -u[2], -u[3]};
+  double p[4] = {0, v[0], v[1], v[2]}, t[4];
+  qmul(t, u, p); qmul(t, t, uc);
+  o[0] = t[1]; o[1] = t[2]; o[2] = t[3];
+}
+static double cos_siml(const double *a, const double *b) { return dot3(a, b) / norm3(a) / norm3(b); }
+/* unit_vector: float32 normalisation (transform_utils.py:53-97 down-casts) */
+static void unit_f32(double *o, const double *v) {
+  float d[3] = {(float)v[0], (float)v[1], (float)v[2]};
+  float s = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  float n = (float)sqrt((double)s);
+  for (int k = 0; k < 3; k++) o[k] = (double)(float)(d[k] / n);
+}
+/* rotate_vector: cos(a) v + sin(a) k x v (no (1 - cos)(k.v)k term, as in the reference) */
+static void rotate_vector(double *o, const double *v, const double *axis, double deg) {
+  double k[3], c[3], a = deg / 180.0 * M_PI;
+  unit_f32(k, axis); cross3(c, k, v);
+  for (int i = 0; i < 3; i++) o[i] = cos(a) * v[i] + sin(a) * c[i];
+}
+static void rotate_vector_cos(double *o, const double *v, const double *axis, double cs, int dir) {
+  double k[3], c[3];
+  unit_f32(k, axis); cross3(c, k, v);
+  for (int i = 0; i < 3; i++) o[i] = cs * v[i] + dir * sqrt(1 - cs * cs) * c[i];
+}
+/* lookat_to_quat(forward, up) -> xyzw, then convert_quat(.., "wxyz"): returned wxyz here */
+static void lookat_wxyz(double *o, const double *forward, const double *up) {
+  double f[3], un[3], s[3], u[3], n;
+  n = norm3(forward); for (int i = 0; i < 3; i++) f[i] = forward[i] / n;
+  n = norm3(up); for (int i = 0; i < 3; i++) un[i] = up[i] / n;
+  cross3(s, un, f); n = norm3(s); for (int i = 0; i < 3; i++) s[i] /= n;
+  cross3(u, f, s);
+  double m00 = s[0], m01 = s[1], m02 = s[2], m10 = u[0], m11 = u[1], m12 = u[2], m20 = f[0], m21 = f[1], m22 = f[2];
+  double tr = (m00 + m11) + m22, q[4]; /* xyzw */
+  if (tr > 0) { double k = sqrt(tr + 1); q[3] = k * 0.5; k = 0.5 / k; q[0] = (m12 - m21) * k; q[1] = (m20 - m02) * k; q[2] = (m01 - m10) * k; }
+  else if (m00 >= m11 && m00 >= m22) { double k0 = sqrt(((1 + m00) - m11) - m22), k = 0.5 / k0; q[0] = 0.5 * k0; q[1] = (m01 + m10) * k; q[2] = (m02 + m20) * k; q[3] = (m12 - m21) * k; }
+  else if (m11 > m22) { double k0 = sqrt(((1 + m11) - m00) - m22), k = 0.5 / k0; q[0] = (m10 + m01) * k; q[1] = 0.5 * k0; q[2] = (m21 + m12) * k; q[3] = (m20 - m02) * k; }
+  else { double k0 = sqrt(((1 + m22) - m00) - m11), k = 0.5 / k0; q[0] = (m20 + m02) * k; q[1] = (m21 + m12) * k; q[2] = 0.5 * k0; q[3] = (m01 - m10) * k; }
+  o[0] = q[3]; o[1] = q[0]; o[2] = q[1]; o[3] = q[2];
+}
+/* transform_to_target_quat(qpos_base, qpos, target): pose of qpos after rigidly rotating qpos_base to target about the base position */
+static void ttq(const double *base, const double *qp, const double *target, double *np_, double *nq) {
+  double bi[4], rel[4], d[3] = {qp[0] - base[0], qp[1] - base[1], qp[2] - base[2]}, r[3];
+  qinv(bi, base + 3); qmul(rel, target, bi);
+  qrot(r, rel, d);
+  for (int i = 0; i < 3; i++) np_[i] = r[i] + base[i];
+  qmul(nq, rel, qp + 3);
+}
+
+/* ---- env helpers */
+static int find_group(Env *e, int i) { int r = i; while (e->group[r] != r) r = e->group[r]; while (e->group[i] != r) { int n = e->group[i]; e->group[i] = r; i = n; } return r; }
+static void merge_groups(Env *e, int i, int j) { e->group[find_group(e, i)] = find_group(e, j); }
+static void part_qpos(const struct fsim *s, Env *e, int i, double *q) { memcpy(q, e->qpos + s->m.part_qposadr[i], 7 * sizeof(double)); }
+static void set_part_qpos(const struct fsim *s, Env *e, int i, const double *pos, const double *rot) { double *q = e->qpos + s->m.part_qposadr[i]; memcpy(q, pos, 24); memcpy(q + 3, rot, 32); }
+static void stop_object(const struct fsim *s, Env *e, int i, double gravity) {
+  const EnvModel *m = &s->m;
+  int b = m->part_bodyid[i], d = m->part_dofadr[i];
+  double *x = e->xfrc_applied + 6 * b;
+  x[0] = 0; x[1] = 0; x[2] = -gravity * m->gravz * m->body_mass[b]; x[3] = 0; x[4] = 0; x[5] = 0;
+  for (int k = 0; k < 6; k++) { e->qvel[d + k] = 0; e->qfrc_applied[d + k] = 0; }
+}
+static void slow_object(const struct fsim *s, Env *e, int i) {
+  const EnvModel *m = &s->m;
+  int b = m->part_bodyid[i], d = m->part_dofadr[i];
+  double *x = e->xfrc_applied + 6 * b;
+  x[0] = 0; x[1] = 0; x[2] = -m->gravz * m->body_mass[b]; x[3] = 0; x[4] = 0; x[5] = 0;
+  for (int k = 0; k < 6; k++) { double v = e->qvel[d + k]; e->qvel[d + k] = v < -0.2 ? -0.2 : (v > 0.2 ? 0.2 : v); e->qfrc_applied[d + k] = 0; }
+}
+static void gravity_comp(const struct fsim *s, Env *e) {
+  const EnvModel *m = &s->m;
+  for (int k = 0; k < m->narmj; k++) e->qfrc_applied[m->arm_dofadr[k]] = e->qfrc_bias[m->arm_dofadr[k]];
+  for (int k = 0; k < m->ngripj; k++) e->qfrc_applied[m->grip_dofadr[k]] = e->qfrc_bias[m->grip_dofadr[k]];
+}
+static int fs(Env *e) { osim_forward(e->sim); return osim_step(e->sim); }
+static void site_pose(const struct fsim *s, Env *e, int site, double *pq) { /* _site_xpos_xquat: [site_xpos, body xquat * site_quat] */
+  memcpy(pq, e->site_xpos + 3 * site, 24);
+  qmul(pq + 3, e->xquat + 4 * s->m.site_bodyid[site], s->m.site_quat + 4 * site);
+}
+static void site_axes(Env *e, int site, double *up, double *fwd) { const double *R = e->site_xmat + 9 * site; for (int k = 0; k < 3; k++) { up[k] = R[3 * k + 2]; fwd[k] = R[3 * k + 1]; } }
+static void init_robot(const struct fsim *s, Env *e, const float *noise) {
+  const EnvModel *m = &s->m;
+  for (int k = 0; k < m->narmj; k++) e->qpos[m->arm_qposadr[k]] = m->arm_initqpos[k] + (noise ? (double)noise[k] : 0.0);
+  for (int k = 0; k < m->ngripj; k++) e->qpos[m->grip_qposadr[k]] = m->grip_initqpos[k];
+}
+static void settle(const struct fsim *s, Env *e) {
+  for (int a = 0; a < 10; a++) {
+    for (int i = 0; i < s->m.nparts; i++) stop_object(s, e, i, 0);
+    for (int b = 0; b < 10; b++) { fs(e); for (int i = 0; i < s->m.nparts; i++) slow_object(s, e, i); }
+  }
+}
+static void next_subtask(const struct fsim *s, Env *e) {
+  for (int k = 0; k < s->m.neq; k++) {
+    int p1 = s->m.eq_part1[k], p2 = s->m.eq_part2[k];
+    if (find_group(e, p1) != find_group(e, p2)) { e->subtask1 = p1; e->subtask2 = p2; return; }
+  }
+  e->subtask1 = e->subtask2 = -1;
+}
+
+static void env_reset(const struct fsim *s, int idx) {
+  const EnvModel *m = &s->m;
+  Env *e = &s->env[idx];
+  osim_reset_data(e->sim);
+  for (int g = 0; g < m->ngeom; g++) {
+    e->contype[g] = m->geom_contype0[g]; e->conaff[g] = m->geom_conaffinity0[g];
+    if (m->geom_is_robot[g]) { e->contype[g] = 0; e->conaff[g] = 0; }
+    if (m->geom_is_partcol[g]) { e->contype[g] = 1; e->conaff[g] = 1; }
+  }
+  for (int i = 0; i < m->nparts; i++) { e->group[i] = i; e->touched[i] = 0; e->picked[i] = 0; }
+  e->connect_step = 0; e->connected = 0; e->connected_sites = 0; e->connected_body1 = -1; e->num_connected = 0; e->prev_num_connected = 0;
+  e->site1 = e->site2 = -1;
+  e->success_num_conn = m->nparts - 1;
+  for (int k = 0; k < m->neq; k++) e->eq_active[k] = 0;
+  memcpy(e->eq_data, m->eq_data0, sizeof(double) * 7 * m->neq);
+  const float *tp = s->tab_parts + (size_t)idx * 7 * m->nparts;
+  for (int i = 0; i < m->nparts; i++) { double q[7]; for (int k = 0; k < 7; k++) q[k] = (double)tp[7 * i + k]; set_part_qpos(s, e, i, q, q + 3); }
+  settle(s, e);
+  if (m->has_recipe) settle(s, e);
+  const float *tn = s->tab_noise ? s->tab_noise + (size_t)idx * s->n_noise * m->narmj : NULL;
+  gravity_comp(s, e);
+  init_robot(s, e, tn);
+  fs(e);
+  for (int g = 0; g < m->ngeom; g++) if (m->geom_is_robot[g]) { e->contype[g] = m->geom_contype0[g]; e->conaff[g] = m->geom_conaffinity0[g]; }
+  gravity_comp(s, e);
+  for (int k = 1; k <= 100; k++) { init_robot(s, e, tn ? tn + (size_t)(k < s->n_noise ? k : s->n_noise - 1) * m->narmj : NULL); fs(e); }
+  for (int k = 0; k < m->nu; k++) e->ctrl[k] = 0;
+  for (int k = 0; k < m->nv; k++) { e->qfrc_applied[k] = 0; e->qacc[k] = 0; e->qacc_warmstart[k] = 0; }
+  for (int k = 0; k < 6 * m->nbody; k++) e->xfrc_applied[k] = 0;
+  e->time_[0] = 0;
+  osim_forward(e->sim);
+  gravity_comp(s, e);
+  for (int k = 0; k < 100; k++) fs(e);
+  next_subtask(s, e);
+  e->episode_reward = 0; e->episode_length = 0; e->success = 0; e->fail = 0;
+}
+
+static void write_obs(const struct fsim *s, Env *e, float *ob) {
+  const EnvModel *m = &s->m;
+  int o = 0;
+  for (int i = 0; i < m->nparts; i++) {
+    int b = m->part_bodyid[i];
+    for (int k = 0; k < 3; k++) ob[o++] = (float)e->xpos[3 * b + k];
+    for (int k = 0; k < 4; k++) ob[o++] = (float)e->xquat[4 * b + k];
+  }
+  int nj = m->narmj / m->narm;
+  for (int a = 0; a < m->narm; a++) {
+    int site = m->eef_siteid[a];
+    /* data.site_xvelp / site_xvelr as mujoco_py computes them: the site's Jacobian of the last forward pass times the current qvel
+       (oracle/oracle_sim.py site_vel) */
+    double vp[3] = {0, 0, 0}, vr[3] = {0, 0, 0}, *jp = (double *)malloc(sizeof(double) * 6 * m->nv), *jr = jp + 3 * m->nv;
+    osim_body_jac(e->sim, m->site_bodyid[site], e->site_xpos + 3 * site, jp, jr);
+    for (int r = 0; r < 3; r++) for (int k = 0; k < m->nv; k++) { vp[r] += jp[r * m->nv + k] * e->qvel[k]; vr[r] += jr[r * m->nv + k] * e->qvel[k]; }
+    free(jp);
+    for (int k = 0; k < nj; k++) ob[o++] = (float)e->qpos[m->arm_qposadr[a * nj + k]];
+    for (int k = 0; k < nj; k++) ob[o++] = (float)e->qvel[m->arm_dofadr[a * nj + k]];
+    for (int k = 0; k < 2; k++) ob[o++] = (float)e->qpos[m->grip_qposadr[2 * a + k]];
+    for (int k = 0; k < 3; k++) ob[o++] = (float)e->site_xpos[3 * site + k];
+    const double *hq = e->xquat + 4 * m->hand_bodyid[a]; /* wxyz -> xyzw (furniture_sawyer.py:141-143) */
+    ob[o++] = (float)hq[1]; ob[o++] = (float)hq[2]; ob[o++] = (float)hq[3]; ob[o++] = (float)hq[0];
+    for (int k = 0; k < 3; k++) ob[o++] = (float)vp[k];
+    for (int k = 0; k < 3; k++) ob[o++] = (float)vr[k];
+  }
+}
+
+/* _is_aligned(k1, k2): verdict; sets e->target_quat when the forward test passes (as the reference's side effect) */
+static int is_aligned(const struct fsim *s, Env *e, int k1, int k2) {
+  const EnvModel *m = &s->m;
+  const fsim_config_t *c = &s->cfg;
+  int s1 = m->conn_siteid[k1], s2 = m->conn_siteid[k2];
+  const double *p1 = e->site_xpos + 3 * s1, *p2 = e->site_xpos + 3 * s2;
+  double up1[3], up2[3], f1[3], f2[3], d12[3], d21[3], u[3];
+  site_axes(e, s1, up1, f1); site_axes(e, s2, up2, f2);
+  for (int k = 0; k < 3; k++) { d12[k] = p2[k] - p1[k]; d21[k] = p1[k] - p2[k]; }
+  double pos_dist = norm3(d12), rot_up = cos_siml(up1, up2);
+  unit_f32(u, d12); double proj12 = dot3(up1, u);
+  unit_f32(u, d21); double proj21 = dot3(up2, u);
+  int na = m->conn_nangle[k1], fwd_ok = 0;
+  double fr[3];
+  if (na == 0) {
+    double cs = cos_siml(f1, f2), rp[3], rn[3];
+    fwd_ok = 1;
+    rotate_vector_cos(rp, f1, up1, cs, 1); rotate_vector_cos(rn, f1, up1, cs, -1);
+    memcpy(fr, cos_siml(rp, f2) > cos_siml(rn, f2) ? rp : rn, sizeof fr);
+    lookat_wxyz(e->target_quat, up1, fr);
+  } else
+    for (int a = 0; a < na; a++) {
+      rotate_vector(fr, f1, up1, m->conn_angles[(size_t)k1 * m->maxang + a]);
+      if (cos_siml(fr, f2) > c->alignment_rot_dist_forward) { fwd_ok = 1; lookat_wxyz(e->target_quat, up1, fr); break; }
+    }
+  if (pos_dist < c->alignment_pos_dist && rot_up > c->alignment_rot_dist_up && fwd_ok && fabs(proj12) > c->alignment_project_dist && fabs(proj21) > c->alignment_project_dist) return 1;
+  if (pos_dist < c->alignment_pos_dist / 2 && rot_up > c->alignment_rot_dist_up && fwd_ok) return 1;
+  return 0;
+}
+static void move_group_tq(const struct fsim *s, Env *e, int part, const double *translation, const double *target_quat, double gravity) {
+  double base[7];
+  part_qpos(s, e, part, base);
+  int g = find_group(e, part);
+  for (int i = 0; i < s->m.nparts; i++)
+    if (find_group(e, i) == g) {
+      double q[7], np_[3], nq[4];
+      part_qpos(s, e, i, q);
+      ttq(base, q, target_quat, np_, nq);
+      for (int k = 0; k < 3; k++) np_[k] += translation[k];
+      set_part_qpos(s, e, i, np_, nq);
+      stop_object(s, e, i, gravity);
+    }
+}
+static void bounding_box(const struct fsim *s, Env *e, int part, double *mn, double *mx) {
+  const EnvModel *m = &s->m;
+  int g = find_group(e, part);
+  for (int k = 0; k < 3; k++) { mn[k] = 0; mx[k] = 0; } /* quirk Q1: the box always contains the world origin */
+  for (int i = 0; i < m->nparts; i++) {
+    if (find_group(e, i) != g) continue;
+    for (int j = 0; j < m->part_site_num[i]; j++) {
+      const double *p = e->site_xpos + 3 * m->part_sites[m->part_site_adr[i] + j];
+      for (int k = 0; k < 3; k++) { if (p[k] < mn[k]) mn[k] = p[k]; if (p[k] > mx[k]) mx[k] = p[k]; }
+    }
+  }
+}
+/* _move_rotate_object(part, offset, [0, 0, 0]): the group moves by `offset`; kept if the bounding box stays inside the workspace */
+static void move_rotate_object(const struct fsim *s, Env *e, int part, const double *off) {
+  const EnvModel *m = &s->m;
+  double base[7], old[32][7];
+  int in[32], g = find_group(e, part);
+  part_qpos(s, e, part, base);
+  /* euler_to_quat([0, 0, 0], base quat) = base quat * identity */
+  for (int i = 0; i < m->nparts; i++) {
+    in[i] = find_group(e, i) == g;
+    if (!in[i]) continue;
+    double np_[3], nq[4];
+    part_qpos(s, e, i, old[i]);
+    ttq(base, old[i], base + 3, np_, nq);
+    for (int k = 0; k < 3; k++) np_[k] += off[k];
+    set_part_qpos(s, e, i, np_, nq);
+  }
+  fs(e); /* _is_inside */
+  double mn[3], mx[3], b = s->cfg.cursor_boundary;
+  bounding_box(s, e, part, mn, mx);
+  int inside = !(mn[0] < -b || mn[1] < -b || mn[2] < -0.05 || mx[0] > b || mx[1] > b || mx[2] > b);
+  if (!inside) for (int i = 0; i < m->nparts; i++) if (in[i]) set_part_qpos(s, e, i, old[i], old[i] + 3);
+}
+static void do_connect(const struct fsim *s, Env *e, int k1, int k2) {
+  const EnvModel *m = &s->m;
+  e->connected_sites |= (1ull << k1) | (1ull << k2);
+  e->site1 = m->conn_siteid[k1]; e->site2 = m->conn_siteid[k2];
+  int pA = m->conn_partid[k1], pB = m->conn_partid[k2], gA = find_group(e, pA), gB = find_group(e, pB);
+  for (int g = 0; g < m->ngeom; g++) {
+    int p = m->body_partid[m->geom_bodyid[g]];
+    if (p < 0) continue;
+    int gp = find_group(e, p);
+    if ((gp == gA || gp == gB) && e->contype[g] != 0) { e->contype[g] = (1 << 30) - 1 - (1 << (gA + 1)); e->conaff[g] = 1 << (gA + 1); }
+  }
+  if (s->cfg.auto_align) { /* _move_site_to_target(k2, [site1 pos, target quat]) */
+    double tq[7], base[7], body[7], np_[3], nq[4], nsp[3], nsq[4], tr[3];
+    site_pose(s, e, m->conn_siteid[k1], tq);
+    memcpy(tq + 3, e->target_quat, 32);
+    site_pose(s, e, m->conn_siteid[k2], base);
+    int part = m->conn_partid[k2];
+    part_qpos(s, e, part, body);
+    ttq(base, body, tq + 3, np_, nq);
+    double body2[7]; memcpy(body2, body, sizeof body2);
+    ttq(body2, base, nq, nsp, nsq);
+    for (int k = 0; k < 3; k++) tr[k] = tq[k] - nsp[k];
+    move_group_tq(s, e, part, tr, nq, 0.0 /* _gravity_compensation of the arm agents */);
+  }
+  fs(e);
+  double mn1[3], mn2[3], mx[3];
+  bounding_box(s, e, pA, mn1, mx); bounding_box(s, e, pB, mn2, mx);
+  double mz = mn1[2] < mn2[2] ? mn1[2] : mn2[2];
+  if (mz < 0) { double off[3] = {0, 0, -mz}; move_rotate_object(s, e, pA, off); move_rotate_object(s, e, pB, off); }
+  fs(e);
+  for (int i = 0; i < m->neq; i++) { /* _activate_weld */
+    int p1 = m->eq_part1[i], p2 = m->eq_part2[i];
+    if ((p1 == pA || p1 == pB) && (p2 == pA || p2 == pB)) {
+      double q1[7], q2[7], qi[4], d[3];
+      part_qpos(s, e, p1, q1); part_qpos(s, e, p2, q2);
+      qinv(qi, q1 + 3);
+      for (int k = 0; k < 3; k++) d[k] = q2[k] - q1[k];
+      qrot(e->eq_data + 7 * i, qi, d);
+      qmul(e->eq_data + 7 * i + 3, qi, q2 + 3);
+      e->eq_active[i] = 1;
+      merge_groups(e, pA, pB);
+    }
+  }
+  e->num_connected += 1; e->connected = 1; e->connected_body1 = pA;
+  double q[7]; part_qpos(s, e, pA, q);
+  memcpy(e->cb1_pos, q, 24); memcpy(e->cb1_quat, q + 3, 32);
+  next_subtask(s, e);
+}
+static int try_connect(const struct fsim *s, Env *e, int part1) {
+  const EnvModel *m = &s->m;
+  int g1 = find_group(e, part1), any1 = 0;
+  for (int k = 0; k < m->nconn; k++) if (find_group(e, m->conn_partid[k]) == g1) any1 = 1;
+  if (!any1 || m->nconn == 0) return 0;
+  /* (part2 = None: ids2 = every part, so "a weld between the two id sets" is "any weld at all") */
+  if (m->neq == 0) return 0;
+  for (int k1 = 0; k1 < m->nconn; k1++) {
+    if (find_group(e, m->conn_partid[k1]) != g1) continue;
+    for (int k2 = 0; k2 < m->nconn; k2++) {
+      if (((e->connected_sites >> k1) & 1) || ((e->connected_sites >> k2) & 1)) continue;
+      int a1 = m->conn_keya[k1], b1 = m->conn_keyb[k1], a2 = m->conn_keya[k2], b2 = m->conn_keyb[k2];
+      int match = (b1 < 0 || b2 < 0) ? (b1 < 0 && b2 < 0 && a1 == a2) : (a1 == b2 && b1 == a2);
+      if (!match) continue;
+      if (is_aligned(s, e, k1, k2)) { /* (_num_connect_steps = 0 for the arm agents: connect at once) */
+        do_connect(s, e, k1, k2);
+        e->connect_step = 0;
+        return 1;
+      }
+    }
+  }
+  e->connect_step = 0;
+  return 0;
+}
+/* per arm: parts touched by the left / right finger set, parts touching the floor (bit masks) */
+static void touch_sets(const struct fsim *s, Env *e, int arm, unsigned *L, unsigned *R, unsigned *F) {
+  const EnvModel *m = &s->m;
+  *L = *R = *F = 0;
+  for (int c = 0; c < e->ncon[0]; c++) {
+    int gg[2] = {e->cg1[c], e->cg2[c]};
+    for (int o = 0; o < 2; o++) {
+      int ga = gg[o], gb = gg[1 - o], p = m->body_partid[m->geom_bodyid[gb]];
+      if (p < 0) continue;
+      int role = m->geom_fingerrole[ga];
+      if (role & (1 << (2 * arm))) *L |= 1u << p;
+      if (role & (1 << (2 * arm + 1))) *R |= 1u << p;
+      if (ga == m->floor_geomid[0]) *F |= 1u << p;
+    }
+  }
+}
+
+static void env_step(struct fsim *s, int idx, const float *action, float *ob, float *reward, uint8_t *done, int32_t *info) {
+  const EnvModel *m = &s->m;
+  const fsim_config_t *c = &s->cfg;
+  Env *e = &s->env[idx];
+  double a[64];
+  const int dof = s->dof;
+  for (int k = 0; k < dof; k++) a[k] = (double)action[k];
+  e->connected = 0;
+  if (m->agent == 0 && c->discrete_grip) a[dof - 2] = action[dof - 2] < 0 ? -1 : 1;
+  const double connect = a[dof - 1];
+  { /* _setup_action + _do_simulation */
+    double act[64];
+    int na = m->narmj, n = 0;
+    for (int k = 0; k < na; k++) act[n++] = a[k];
+    for (int arm = 0; arm < m->narm; arm++) { act[n++] = a[na + arm]; act[n++] = -a[na + arm]; }
+    if (c->rescale_actions) { /* (the clip precedes the gripper mirroring: symmetric bounds, same result) */
+      for (int k = 0; k < n; k++) { double v = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); act[k] = m->ctrl_bias[k] + m->ctrl_weight[k] * v; }
+    }
+    gravity_comp(s, e);
+    for (int k = 0; k < m->nu; k++) e->ctrl[k] = act[k];
+    osim_forward(e->sim);
+    int bad = 0;
+    for (int k = 0; k < s->n_substeps && !bad; k++) bad = osim_step(e->sim);
+    if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
+  }
+  if (connect > 0 && !e->fail)
+    for (int arm = 0; arm < m->narm; arm++) { /* _connect_scan */
+      unsigned L, R, F;
+      int stop = 0;
+      touch_sets(s, e, arm, &L, &R, &F);
+      for (int i = 0; i < m->nparts; i++)
+        if (((L >> i) & 1) && ((R >> i) & 1)) { stop = try_connect(s, e, i); break; }
+      if (stop) break;
+    }
+  if (e->connected_body1 >= 0) {
+    osim_forward(e->sim);
+    double base[7], tr[3];
+    part_qpos(s, e, e->connected_body1, base);
+    for (int k = 0; k < 3; k++) tr[k] = e->cb1_pos[k] - base[k];
+    move_group_tq(s, e, e->connected_body1, tr, e->cb1_quat, 0.0);
+    e->connected_body1 = -1;
+    fs(e);
+  }
+  int terminal = 0;
+  if (e->num_connected == e->success_num_conn && m->nparts > 1) { e->success = 1; terminal = 1; }
+  /* _compute_reward on the RAW action */
+  double touch = 0, pick = 0;
+  for (int arm = 0; arm < m->narm; arm++) {
+    unsigned L, R, F;
+    touch_sets(s, e, arm, &L, &R, &F);
+    for (int i = 0; i < m->nparts; i++)
+      if (((L >> i) & 1) && ((R >> i) & 1)) {
+        if (!e->touched[i]) { e->touched[i] = 1; touch += c->touch_reward; }
+        if (!((F >> i) & 1) && !e->picked[i]) { e->picked[i] = 1; pick += c->pick_reward; }
+      }
+  }
+  double succ = c->success_reward * (e->num_connected - e->prev_num_connected), s2 = 0;
+  e->prev_num_connected = e->num_connected;
+  for (int k = 0; k < dof; k++) s2 += (double)action[k] * (double)action[k];
+  double ctrl_pen = -c->ctrl_penalty_coef * s2, rew = succ + touch + pick + ctrl_pen, penalty = 0;
+  /* _after_step */
+  e->episode_reward += rew;
+  e->episode_length += 1;
+  const int fail = e->fail;
+  if (e->episode_length == c->max_episode_steps || fail) { terminal = 1; if (fail) { e->fail = 0; penalty = -c->unstable_penalty_coef; } }
+  rew += penalty;
+  if (reward) *reward = (float)rew;
+  if (done) *done = (uint8_t)terminal;
+  if (info) {
+    float f;
+    memset(info, 0, sizeof(int32_t) * FSIM_INFO_DIM);
+    info[FSIM_INFO_NUM_CONNECTED] = e->num_connected; info[FSIM_INFO_SUCCESS] = e->success; info[FSIM_INFO_FAIL] = fail ? 1 : 0;
+    info[FSIM_INFO_LAST_SITE1] = e->site1; info[FSIM_INFO_LAST_SITE2] = e->site2; info[FSIM_INFO_EPISODE_LENGTH] = e->episode_length;
+    info[FSIM_INFO_CONNECTED_THIS_STEP] = e->connected;
+    info[FSIM_INFO_NEEDS_TABLE] = (terminal && c->auto_reset) ? (fail == 2 ? 2 : 1) : 0;
+    f = (float)succ; memcpy(&info[FSIM_INFO_SUCCESS_REWARD_F], &f, 4); f = (float)touch; memcpy(&info[FSIM_INFO_TOUCH_REWARD_F], &f, 4);
+    f = (float)pick; memcpy(&info[FSIM_INFO_PICK_REWARD_F], &f, 4); f = (float)ctrl_pen; memcpy(&info[FSIM_INFO_CTRL_PENALTY_F], &f, 4);
+    f = (float)(e->episode_reward + penalty); memcpy(&info[FSIM_INFO_EPISODE_REWARD_F], &f, 4);
+  }
+  if (terminal && c->auto_reset) {
+#pragma omp atomic
+    s->tables_needed += 1;
+    env_reset(s, idx);
+  }
+  if (info) { info[FSIM_INFO_SUBTASK1] = e->subtask1; info[FSIM_INFO_SUBTASK2] = e->subtask2; }
+  if (ob) write_obs(s, e, ob);
+}
+
+/* ---- the C-ABI */
+void fsim_default_config(fsim_config_t *c) {
+  memset(c, 0, sizeof *c);
+  c->n_substeps = 50; c->max_episode_steps = 2000; c->discrete_grip = 1; c->rescale_actions = 1; c->auto_align = 1; c->auto_reset = 1;
+  c->solver_iterations = 100; c->solver_tolerance = 1e-8f;
+  c->alignment_pos_dist = 0.1f; c->alignment_rot_dist_up = 0.9f; c->alignment_rot_dist_forward = 0.9f; c->alignment_project_dist = 0.3f;
+  c->ctrl_penalty_coef = 1e-3f; c->unstable_penalty_coef = 100; c->success_reward = 100; c->touch_reward = 10; c->pick_reward = 100;
+  c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3; c->agent_xyz_rand = 0.001f; c->move_speed = 0.1f; c->rotate_speed = 22.5f; c->cursor_boundary = 1.5f;
+  c->lookahead_reset = 1; c->overflow_restep = 1;
+}
+#define GI(field, name) do { m->field = (const int32_t *)blob_get(s->blob, s->nbytes, name, 1, NULL); if (!m->field) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry %s missing", name); } } while (0)
+#define GD(field, name) do { m->field = (const double *)blob_get(s->blob, s->nbytes, name, 0, NULL); if (!m->field) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry %s missing", name); } } while (0)
+int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
+  (void)device;
+  if (!model_blob || nbytes < 64 || n_envs <= 0 || !out || memcmp(model_blob, "FSIMBLOB", 8) != 0) FAIL(FSIM_EINVAL, "fsim_create: bad arguments");
+  struct fsim *s = (struct fsim *)calloc(1, sizeof *s);
+  s->n = n_envs; s->nbytes = nbytes;
+  s->blob = (char *)malloc(nbytes); memcpy(s->blob, model_blob, nbytes);
+  if (cfg) s->cfg = *cfg; else fsim_default_config(&s->cfg);
+  EnvModel *m = &s->m;
+  const int32_t *dims = (const int32_t *)blob_get(s->blob, nbytes, "dims", 1, NULL);
+  const double *opt = (const double *)blob_get(s->blob, nbytes, "opt", 0, NULL);
+  if (!dims || !opt) { fsim_destroy(s); FAIL(FSIM_EINVAL, "not a model blob"); }
+  m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->ngeom = dims[5]; m->nsite = dims[6]; m->neq = dims[7];
+  m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
+  m->timestep = opt[0]; m->gravz = opt[3];
+  if (m->agent == 2 || s->cfg.control_type != 0 || s->cfg.dense_reward || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
+    fsim_destroy(s);
+    FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control with the sparse reward and fp32 observations (oracle/oracle_env.py checks the rest)");
+  }
+  int64_t cnt;
+  GI(part_bodyid, "part_bodyid"); GI(part_qposadr, "part_qposadr"); GI(part_dofadr, "part_dofadr"); GI(body_partid, "body_partid"); GI(geom_bodyid, "geom_bodyid");
+  GI(geom_fingerrole, "geom_fingerrole"); GI(geom_is_robot, "geom_is_robot"); GI(geom_is_partcol, "geom_is_partcol"); GI(geom_contype0, "geom_contype");
+  GI(geom_conaffinity0, "geom_conaffinity"); GI(floor_geomid, "floor_geomid"); GI(eq_part1, "eq_part1"); GI(eq_part2, "eq_part2");
+  GI(arm_qposadr, "arm_qposadr"); GI(arm_dofadr, "arm_dofadr"); GI(grip_qposadr, "grip_qposadr"); GI(grip_dofadr, "grip_dofadr"); GI(eef_siteid, "eef_siteid");
+  GI(hand_bodyid, "hand_bodyid"); GI(conn_siteid, "conn_siteid"); GI(conn_partid, "conn_partid"); GI(conn_keya, "conn_keya"); GI(conn_keyb, "conn_keyb");
+  GI(conn_nangle, "conn_nangle"); GI(part_site_adr, "part_site_adr"); GI(part_site_num, "part_site_num"); GI(part_sites, "part_sites"); GI(site_bodyid, "site_bodyid");
+  GD(body_mass, "body_mass"); GD(eq_data0, "eq_data0"); GD(arm_initqpos, "arm_initqpos"); GD(grip_initqpos, "grip_initqpos"); GD(ctrl_bias, "ctrl_bias");
+  GD(ctrl_weight, "ctrl_weight"); GD(site_quat, "site_quat");
+  m->conn_angles = (const double *)blob_get(s->blob, nbytes, "conn_angles", 0, &cnt);
+  if (!m->conn_angles) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry conn_angles missing"); }
+  m->maxang = m->nconn > 0 ? (int)(cnt / m->nconn) : 1;
+  blob_get(s->blob, nbytes, "arm_qposadr", 1, &cnt); m->narmj = (int)cnt;
+  blob_get(s->blob, nbytes, "grip_qposadr", 1, &cnt); m->ngripj = (int)cnt;
+  { const int32_t *fl = (const int32_t *)blob_get(s->blob, nbytes, "flags", 1, &cnt); m->has_recipe = fl && cnt > 0 ? fl[0] : 0; }
+  s->n_substeps = s->cfg.n_substeps > 0 ? s->cfg.n_substeps : 50;
+  s->dof = m->narmj + m->narm + 1;
+  s->obs_dim = 7 * m->nparts + 29 * m->narm;
+  s->env = (Env *)calloc((size_t)n_envs, sizeof(Env));
+  for (int i = 0; i < n_envs; i++) {
+    Env *e = &s->env[i];
+    e->sim = osim_create(s->blob, nbytes);
+    if (!e->sim) { fsim_destroy(s); FAIL(FSIM_EINVAL, "osim_create: %s", osim_last_error()); }
+    osim_set_solver(e->sim, s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : 100, s->cfg.solver_tolerance > 0 ? (double)s->cfg.solver_tolerance : 1e-8);
+    osim_set_solver_kind(e->sim, 1); /* Newton: MuJoCo's default, what the reference runs (base.xml:4) */
+#define DP(f, name) e->f = osim_dptr(e->sim, name, NULL)
+    DP(qpos, "qpos"); DP(qvel, "qvel"); DP(ctrl, "ctrl"); DP(qfrc_applied, "qfrc_applied"); DP(xfrc_applied, "xfrc_applied"); DP(qacc, "qacc");
+    DP(qacc_warmstart, "qacc_warmstart"); DP(qfrc_bias, "qfrc_bias"); DP(xpos, "xpos"); DP(xquat, "xquat"); DP(xmat, "xmat"); DP(site_xpos, "site_xpos");
+    DP(site_xmat, "site_xmat"); DP(time_, "time"); DP(eq_data, "eq_data");
+    e->contype = osim_iptr(e->sim, "geom_contype", NULL); e->conaff = osim_iptr(e->sim, "geom_conaffinity", NULL); e->eq_active = osim_iptr(e->sim, "eq_active", NULL);
+    e->cg1 = osim_iptr(e->sim, "contact_geom1", NULL); e->cg2 = osim_iptr(e->sim, "contact_geom2", NULL); e->ncon = osim_iptr(e->sim, "ncon", NULL);
+    e->connected_body1 = -1;
+    for (int p = 0; p < m->nparts; p++) e->group[p] = p;
+  }
+  *out = s;
+  return FSIM_OK;
+}
+void fsim_destroy(fsim_t *s) {
+  if (!s) return;
+  if (s->env) for (int i = 0; i < s->n; i++) if (s->env[i].sim) osim_destroy(s->env[i].sim);
+  free(s->env); free(s->blob); free(s->tab_parts); free(s->tab_noise); free(s);
+}
+int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim, int32_t *info_dim, int32_t *stride) {
+  if (!s) FAIL(FSIM_EINVAL, "null handle");
+  int32_t *dst[7] = {nq, nv, nu, dof_action, obs_dim, info_dim, stride};
+  const int32_t val[7] = {s->m.nq, s->m.nv, s->m.nu, s->dof, s->obs_dim, FSIM_INFO_DIM, 0};
+  for (int k = 0; k < 7; k++) if (dst[k]) *dst[k] = val[k];
+  return FSIM_OK;
+}
+int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = NULL; return FSIM_OK; }
+int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); return FSIM_OK; } /* every call of this library is complete on return */
+int fsim_tables_needed(const fsim_t *s) { return s ? s->tables_needed : 0; }
+int fsim_max_contacts(const fsim_t *s) { (void)s; return 5000; } /* nconmax of the reference's models (base.xml:5): nothing is dropped here */
+const char *fsim_kernel_variant(const fsim_t *s) { (void)s; return "cpu-fp64"; }
+const char *fsim_step_kernel(const fsim_t *s) { (void)s; return "libfsim_cpu (fp64 checker: one env per OpenMP thread)"; }
+int64_t fsim_overflow_resteps(const fsim_t *s) { (void)s; return 0; }
+int fsim_set_max_episode_steps(fsim_t *s, int n) { if (!s || n <= 0) FAIL(FSIM_EINVAL, "bad arguments"); s->cfg.max_episode_steps = n; return FSIM_OK; }
+int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float *part_qpos, const float *robot_noise, int n_noise) {
+  if (!s || !part_qpos) FAIL(FSIM_EINVAL, "bad args");
+  const size_t pw = (size_t)7 * s->m.nparts, nw = (size_t)n_noise * s->m.narmj;
+  if (!s->tab_parts) s->tab_parts = (float *)calloc((size_t)s->n * pw, 4);
+  if (robot_noise && (!s->tab_noise || s->n_noise != n_noise)) { free(s->tab_noise); s->tab_noise = (float *)calloc((size_t)s->n * nw, 4); s->n_noise = n_noise; }
+  for (int e = 0; e < s->n; e++) {
+    if (mask && !mask[e]) continue;
+    memcpy(s->tab_parts + e * pw, part_qpos + e * pw, pw * 4);
+    if (robot_noise) memcpy(s->tab_noise + e * nw, robot_noise + e * nw, nw * 4);
+  }
+  return FSIM_OK;
+}
+int fsim_reset(fsim_t *s, const uint8_t *mask, void *obs) {
+  if (!s) FAIL(FSIM_EINVAL, "null");
+  if (!s->tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: no reset tables (fsim_set_reset_tables)");
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < s->n; e++) {
+    if (mask && !mask[e]) continue;
+    env_reset(s, e);
+    if (obs) write_obs(s, &s->env[e], (float *)obs + (size_t)e * s->obs_dim);
+  }
+  return FSIM_OK;
+}
+int fsim_step(fsim_t *s, const float *action, void *obs, float *reward, uint8_t *done, int32_t *info) {
+  if (!s || !action) FAIL(FSIM_EINVAL, "null");
+  s->tables_needed = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < s->n; e++)
+    env_step(s, e, action + (size_t)e * s->dof, obs ? (float *)obs + (size_t)e * s->obs_dim : NULL, reward ? reward + e : NULL, done ? done + e : NULL,
+             info ? info + (size_t)e * FSIM_INFO_DIM : NULL);
+  return FSIM_OK;
+}
+static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
+  if (!s || !p) FAIL(FSIM_EINVAL, "null");
+  if (p->cursor || p->dense || p->env_block || p->contact_geoms || p->solver_iters) FAIL(FSIM_EINVAL, "libfsim_cpu: cursor / dense / env_block / contact_geoms / solver_iters are not served by the CPU checker");
+  const EnvModel *m = &s->m;
+  for (int i = 0; i < s->n; i++) {
+    Env *e = &s->env[i];
+#define FLD(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = (double)p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (float)(src)[k]; }
+    FLD(qpos, e->qpos, m->nq) FLD(qvel, e->qvel, m->nv) FLD(qacc_warmstart, e->qacc_warmstart, m->nv) FLD(qfrc_bias, e->qfrc_bias, m->nv) FLD(ctrl, e->ctrl, m->nu)
+    FLD(qfrc_applied, e->qfrc_applied, m->nv) FLD(eq_data, e->eq_data, 7 * m->neq)
+    if (p->xfrc_applied) for (int q = 0; q < m->nparts; q++) for (int k = 0; k < 6; k++) { double *x = e->xfrc_applied + 6 * m->part_bodyid[q] + k; float *y = p->xfrc_applied + ((size_t)i * m->nparts + q) * 6 + k; if (to_state) *x = *y; else *y = (float)*x; }
+#define FLI(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (src)[k]; }
+    FLI(eq_active, e->eq_active, m->neq) FLI(geom_contype, e->contype, m->ngeom) FLI(geom_conaffinity, e->conaff, m->ngeom) FLI(group, e->group, m->nparts)
+    if (!to_state) {
+      if (p->qacc) for (int k = 0; k < m->nv; k++) p->qacc[(size_t)i * m->nv + k] = (float)e->qacc[k];
+      if (p->xpos) for (int k = 0; k < 3 * m->nbody; k++) p->xpos[(size_t)i * 3 * m->nbody + k] = (float)e->xpos[k];
+      if (p->xquat) for (int k = 0; k < 4 * m->nbody; k++) p->xquat[(size_t)i * 4 * m->nbody + k] = (float)e->xquat[k];
+      if (p->ncon) p->ncon[i] = e->ncon[0];
+    }
+  }
+  return FSIM_OK;
+}
+int fsim_get_state(fsim_t *s, const fsim_state_ptrs_t *dst) { return xfer(s, dst, 0); }
+int fsim_set_state(fsim_t *s, const fsim_state_ptrs_t *src) { return xfer(s, src, 1); }
+int fsim_physics_step(fsim_t *s, int n) {
+  if (!s || n < 0) FAIL(FSIM_EINVAL, "bad args");
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < s->n; e++) for (int k = 0; k < n; k++) osim_step(s->env[e].sim);
+  return FSIM_OK;
+}
+int fsim_physics_forward(fsim_t *s) {
+  if (!s) FAIL(FSIM_EINVAL, "bad args");
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < s->n; e++) osim_forward(s->env[e].sim);
+  return FSIM_OK;
+}
+
+/* ---- the rest of include/fsim.h: served where it means something on the host, refused by name otherwise (never silently) */
+int fsim_read(fsim_t *s, void *host_dst, const void *dev_src, size_t nbytes) { if (!s || !host_dst || !dev_src) FAIL(FSIM_EINVAL, "null"); memcpy(host_dst, dev_src, nbytes); return FSIM_OK; }
+int fsim_env_block_words(const fsim_t *s) { (void)s; return 0; }
+int fsim_lookahead_stats(fsim_t *s, int64_t *out) { if (!s || !out) FAIL(FSIM_EINVAL, "null"); memset(out, 0, 6 * sizeof(int64_t)); return FSIM_OK; }
+int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) { if (!s) FAIL(FSIM_EINVAL, "null"); if (avg_ms) *avg_ms = 0; if (n) *n = 0; return FSIM_OK; }
+#define NOT_SERVED(what) FAIL(FSIM_EINVAL, "libfsim_cpu: " what " is not served by the native CPU checker (oracle/oracle_env.py is the checker for it)")
+int fsim_set_attach_noise(fsim_t *s, const uint8_t *mask, const float *noise) { (void)s; (void)mask; (void)noise; NOT_SERVED("reset_robot_after_attach"); }
+int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) { (void)s; (void)mask; (void)qpos; (void)qvel; NOT_SERVED("set_init_qpos"); }
+int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *subtasks, int nsub) { (void)s; (void)coef; (void)ncoef; (void)subtasks; (void)nsub; NOT_SERVED("the dense reward"); }
+int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
+  (void)s; (void)ids; (void)conn_pairs; (void)angles;
+  if (n_pre == 0 && num_connects < 0) return FSIM_OK;
+  NOT_SERVED("a pre-assembled start");
+}
+int fsim_dense_replay(int device, const float *coef, int ncoef, const float *subtasks, int nsub, int n_pre, const float *obs0, const float *obs, const float *ac, int dof,
+                      const uint8_t *connected, int T, float *out_reward, int32_t *out_flags) {
+  (void)device; (void)coef; (void)ncoef; (void)subtasks; (void)nsub; (void)n_pre; (void)obs0; (void)obs; (void)ac; (void)dof; (void)connected; (void)T; (void)out_reward; (void)out_flags;
+  NOT_SERVED("fsim_dense_replay");
+}
+int fsim_replay_is_aligned(int device, float pos_dist, float rot_up, float rot_fwd, float proj_dist, int n, const float *p1, const float *R1, const float *p2, const float *R2,
+                           const int32_t *nang, const float *angles, int32_t *out_ok, float *out_tq) {
+  (void)device; (void)pos_dist; (void)rot_up; (void)rot_fwd; (void)proj_dist; (void)n; (void)p1; (void)R1; (void)p2; (void)R2; (void)nang; (void)angles; (void)out_ok; (void)out_tq;
+  NOT_SERVED("fsim_replay_is_aligned");
+}
+int fsim_replay_try_connect(fsim_t *s, int n, int num_connect_steps, const int32_t *part12, const int32_t *group, const int32_t *used, const uint8_t *aligned, const int32_t *step_in, int32_t *out) {
+  (void)s; (void)n; (void)num_connect_steps; (void)part12; (void)group; (void)used; (void)aligned; (void)step_in; (void)out;
+  NOT_SERVED("fsim_replay_try_connect");
+}
+int fsim_replay_touch_scan(fsim_t *s, int n, int maxc, const int32_t *ncon, const int32_t *geoms, const uint8_t *script, int32_t *out_masks, int32_t *out_tried) {
+  (void)s; (void)n; (void)maxc; (void)ncon; (void)geoms; (void)script; (void)out_masks; (void)out_tried;
+  NOT_SERVED("fsim_replay_touch_scan");
+}
+int fsim_pool_create(int device, fsim_pool_t **out) { (void)device; (void)out; NOT_SERVED("the work pool (a device scheduling construct)"); }
+int fsim_pool_attach(fsim_pool_t *p, fsim_t *s) { (void)p; (void)s; NOT_SERVED("the work pool"); }
+int fsim_pool_stats(fsim_pool_t *p, int64_t *out) { (void)p; (void)out; NOT_SERVED("the work pool"); }
+int fsim_pool_retire(fsim_pool_t *p) { (void)p; NOT_SERVED("the work pool"); }
+void fsim_pool_destroy(fsim_pool_t *p) { (void)p; }
