@@ -271,21 +271,22 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, FSIM_WPE) void k
 // on its neighbours), and a launch with more of them than workgroups just serves them in turn.
 // q: [0] multi-wave envs of the launch, [1] the others, [2] head of the bundle queue, [3] head of the multi-wave queue (k_schedule)
 template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) void k_env_step_x(const DModel *mp, const Layout *lp, const Layout *lp_mw, KParams kp, StepArgs a,
-                                                                                           const int *order, const int *mworder, int *q) {
+                                                                                           const int *order, const int *mworder, int *q, int *defer) {
   extern __shared__ float L[];
   CModel &m = *(CModel *)mp;
   long long t_entry = clock64();
   const int nmw = q[0];
   // Envs of this workgroup's multi-wave phase whose step ended the episode with no shadow record ready: their reset is ONE-wave work
   // (env_step DEFER) and runs in the bundle phase below, on wave 0, before it takes anything from the queue -- the same instantiation
-  // a bundled env's reset runs, so a reset's bits do not depend on who stepped the env.  Up to four 16-bit env indices in a register
-  // pair (wave 0's); a workgroup whose list is full leaves the multi-wave phase (the other workgroups serve the queue).
-  unsigned long long defs = 0;
+  // a bundled env's reset runs, so a reset's bits do not depend on who stepped the env.  The list is the workgroup's row of `defer`
+  // ([gridDim.x][n_envs] in device memory, written and read by wave 0 alone): it holds whatever number of deferrals the launch produces
+  // (until round 5 it was four 16-bit indices in a register pair, and a workgroup whose list was full left the queue for good).
+  int *const dlist = defer + (size_t)blockIdx.x * kp.n_envs;
   int ndef = 0;
   if (nmw > 0) {
     int *s_slot = reinterpret_cast<int *>(L); // (between two envs nothing in the workgroup's LDS is live)
     for (;;) {
-      if (threadIdx.x == 0) *s_slot = ndef == 4 ? 0x7fffffff : atomicAdd(q + 3, 1);
+      if (threadIdx.x == 0) *s_slot = atomicAdd(q + 3, 1);
       __syncthreads();
       const int slot = __builtin_amdgcn_readfirstlane(*s_slot);
       __syncthreads(); // (everybody has read the slot before wave 0 goes on and overwrites it)
@@ -297,7 +298,7 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) vo
       const CtxM c(L, m, *(CLayout *)lp_mw, tid_, kp.newton_maxit, kp.newton_tol);
       if (c.wave > 0) { mw_helper_fn(c); continue; }
       const int env = mworder[slot];
-      if (env_run<CtxM, true>(c, a.cfg, a, env, t_entry)) { defs = (defs << 16) | (unsigned)env; ndef++; }
+      if (env_run<CtxM, true>(c, a.cfg, a, env, t_entry)) { if (c.lane == 0) dlist[ndef] = env; ndef++; }
       t_entry = clock64();
     }
   }
@@ -309,7 +310,7 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) vo
       __asm__ volatile("" : "+v"(tid_));
       const CtxB c(L, m, *(CLayout *)lp, tid_, kp.newton_maxit, kp.newton_tol);
       int env, job = JOB_AUTO;
-      if (ndef > 0) { env = (int)(defs & 0xffffu); defs >>= 16; ndef--; job = JOB_RESET; } // (wave 0 only: ndef is 0 on the others)
+      if (ndef > 0) { ndef--; env = __builtin_amdgcn_readfirstlane(dlist[ndef]); job = JOB_RESET; } // (wave 0 only: ndef is 0 on the others)
       else {
         int slot = 0;
         if (c.lane == 0) slot = atomicAdd(q + 2, 1);
@@ -862,7 +863,7 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 // ---- kernel variants: the generic kernels (run-time layout, any model) and the specialised ones of fsim_spec.hpp
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *, const int *);
-typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *);
+typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *, int *);
 typedef void (*PoolFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, PoolSlot *, PoolHost *, PoolCtl *, int, int, long long);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
 #define FSIM_LA_MAXJOBS 512 // look-ahead jobs per launch, at most
@@ -884,6 +885,7 @@ struct fsim {
   Layout ly_mw{};
   Layout *d_ly_mw = nullptr;
   int lds_bytes_mw = 0, lds_bytes_x = 0;
+  int *d_defer = nullptr; // k_env_step_x: [x_grid][n_envs] deferred resets of each workgroup's multi-wave phase
   int *d_mworder = nullptr, *d_mwn = nullptr; // q: [0] multi-wave envs of the launch, [1] the others, [2] / [3] heads of the bundle / multi-wave queues, [4] look-ahead jobs, [5] head of their queue
   int x_resident = 0;                         // bundle workgroups that can be resident at once (2 per CU)
   int x_grid = 0;                             // workgroups of a k_env_step_x launch
@@ -1214,7 +1216,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     HIPCHK(hipGetDeviceProperties(&pr, device));
     const bool can_all = s->ks.env_step_mw && s->lds_bytes_mw <= 160 * 1024;
     // bundles of four keep the one-wave kernel's occupancy only while two of them fit a CU's LDS; bigger models stay on the one-wave kernel
-    const bool can_rule = can_all && s->ks.env_step_x && 2 * s->lds_bytes_x <= 160 * 1024 && !getenv("FSIM_NO_LPT") && n_envs <= 32768; // (the scheduler keeps one key per env in LDS; deferred resets travel as 16-bit env indices)
+    const bool can_rule = can_all && s->ks.env_step_x && 2 * s->lds_bytes_x <= 160 * 1024 && !getenv("FSIM_NO_LPT") && n_envs <= 32768; // (the scheduler keeps one key per env in LDS)
     if (want == 3) { if (!can_all) { delete s; FAIL(FSIM_EINVAL, "multi_wave = all: this model has no multi-wave kernel (more than 64 contact slots, or its LDS image does not fit)"); } s->mw_mode = MW_ALL; }
     else if (want == 2) { if (!can_rule) { delete s; FAIL(FSIM_EINVAL, "multi_wave = rule: this model / batch cannot run k_env_step_x (LDS image, contact slots or batch size)"); } s->mw_mode = MW_RULE; }
     else if (want == 1) s->mw_mode = MW_OFF;
@@ -1268,6 +1270,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   s->lpt = !getenv("FSIM_NO_LPT");
   HIPCHK(hipMalloc(&s->d_mworder, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&s->d_mwn, 32));
   HIPCHK(hipMemset(s->d_mwn, 0, 32));
+  if (s->mw_mode == MW_RULE) HIPCHK(hipMalloc(&s->d_defer, (size_t)std::max(1, s->x_grid) * n_envs * 4));
   if ((size_t)n_envs * 4 > 150 * 1024) s->lpt = false; // (the scheduler keeps one key per env in LDS)
   else if ((size_t)n_envs * 4 > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_schedule), hipFuncAttributeMaxDynamicSharedMemorySize, n_envs * 4));
   // look-ahead reset: off for what carries state across a reset or draws inside it (arm controllers keep their ramps, the IK controller
@@ -1349,7 +1352,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_prog); hipFree(s->d_sh_serial); hipFree(s->d_tab_serial); hipFree(s->d_sh_jobs);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
   hipFree(s->d_ly_r); hipFree(s->d_prev); hipFree(s->d_ovf_list);
-  hipFree(s->d_ly_mw); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
+  hipFree(s->d_ly_mw); hipFree(s->d_defer); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -1863,7 +1866,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   else if (mw_rule) // persistent workgroups: as many as the one-wave envs need in bundles of four plus an eighth of the batch for multi-wave envs, at most what is resident at once
     hipLaunchKernelGGL(s->ks.env_step_x, dim3(s->x_grid), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, s->stream,
-                       s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mworder, s->d_mwn);
+                       s->d_m, s->d_ly, s->d_ly_mw, kp, a, s->d_order, s->d_mworder, s->d_mwn, s->d_defer);
   else
     hipLaunchKernelGGL(s->ks.env_step, dim3(s->n_envs + (jobs ? s->la_jobs : 0)), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   hipError_t e = hipGetLastError();

@@ -1131,7 +1131,10 @@ template <class Ctx> DEV void env_reset_or_swap(const Ctx &c, const EnvCfg &cfg,
 // ---------------------------------------------------------------------------------------------------- step
 // DEFER (the multi-wave workgroups of k_env_step_x): a terminal env without a ready shadow record is NOT reset here -- env_step returns 1
 // and the workgroup's wave 0 runs the reset as a one-wave job right afterwards (fsim.hip), so that a reset's bits never depend on
-// whether the env happened to be stepped by four waves (a reset is one-wave arithmetic wherever it runs).  Returns 0 otherwise.
+// whether the env happened to be stepped by four waves (a reset is one-wave arithmetic wherever a STEP launch runs it).  Returns 0 otherwise.
+// The one exception is the overflow re-step (fsim.hip redo_overflowed: the generic four-wave kernel, non-DEFER, on the larger slot layout): an env
+// whose terminal step or reset dropped contacts is repeated there WITH its reset inline -- four-wave arithmetic with more contact slots, i.e. a
+// different (more complete) computation than the first pass by construction, not a bit-copy of it.
 template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const EnvCfg &cfg, const EnvIO &io) {
   const int cfg_ik = Ctx::PLAIN ? 0 : cfg.ik, cfg_controller = Ctx::PLAIN ? 0 : cfg.controller, cfg_dense = Ctx::PLAIN ? 0 : cfg.dense; // (SpecCtx::PLAIN)
   CModel &m = c.m;

@@ -79,12 +79,27 @@ def build(force=False, verbose=False):
     #  -fno-optimize-sibling-calls: ONE tail call of an out-of-line device function is enough for the compiler to give up treating
     #  that function as "all callers known" -- it then saves its 113 callee-saved VGPRs to scratch on every call, 29 KB per wave.
     #  Without tail calls every local function drops its callee-saved area: 55 -> 33 KB of HBM traffic per env-step)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-optimize-sibling-calls", "-o", _LIBPATH, os.path.join(_CSRC, "fsim.hip")]
+    cmd = hipcc_command(_LIBPATH)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return _LIBPATH
+
+
+def hipcc_command(out, defines=()):
+    """The one hipcc line that builds the library (``defines``: -D options of an opt-in variant, e.g. FSIM_MFMA_HESSIAN -- __graft_entry__.build()
+    builds that one beside the default library so that the GPU suite can run it through the same C-ABI session)."""
+    return ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+            "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-optimize-sibling-calls"] + ["-D" + d for d in defines] + ["-o", out, os.path.join(_CSRC, "fsim.hip")]
+
+
+def build_variant(name, defines, force=False):
+    """libfsim_<name>.so: the library with opt-in compile-time paths switched on (never loaded by the package itself)."""
+    out = os.path.join(_CSRC, "libfsim_%s.so" % name)
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp"))]
+    if force or not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        subprocess.check_call(hipcc_command(out, defines))
+    return out
 
 
 def build_host(verbose=False):

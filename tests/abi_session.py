@@ -40,6 +40,7 @@ class Abi:
         L.fsim_get_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_set_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.fsim_physics_forward.argtypes = [ctypes.c_void_p]
 
     def check(self, rc):
         if rc != 0:
@@ -108,6 +109,10 @@ class Session:
         a.check(a.L.fsim_step(self.h, a.ptr(self.act), a.ptr(self.obs), a.ptr(self.rew), a.ptr(self.done), a.ptr(self.info)))
         a.check(a.L.fsim_sync(self.h))
         return a.get(self.obs), a.get(self.rew), a.get(self.done), a.get(self.info)
+
+    def forward(self):
+        self.abi.check(self.abi.L.fsim_physics_forward(self.h))
+        self.abi.check(self.abi.L.fsim_sync(self.h))
 
     def tables_needed(self):
         return self.abi.L.fsim_tables_needed(self.h)

@@ -113,14 +113,20 @@ def test_native_checker_refuses_what_it_does_not_cover(cpu_abi, sawyer_lack):
 
 
 @pytest.mark.gpu
-def test_same_session_against_both_libraries(cpu_abi, sawyer_lack):
-    """The same ctypes calls with the same arguments against libfsim.so (device pointers) and libfsim_cpu.so (host pointers): reset,
+@pytest.mark.parametrize("gpu_lib", ["libfsim.so", "libfsim_mfmah.so"])
+def test_same_session_against_both_libraries(cpu_abi, sawyer_lack, gpu_lib):
+    """(libfsim_mfmah.so: the opt-in build -DFSIM_MFMA_HESSIAN, the island Hessian of the robot + part islands assembled on the matrix
+    cores -- the pinch of the scripted attach is such an island; built by __graft_entry__.build() beside the default library.)
+    The same ctypes calls with the same arguments against libfsim.so (device pointers) and libfsim_cpu.so (host pointers): reset,
     steps, state transfer, the scripted attach -- fp32 device results within the usual tolerances of the fp64 checker's, integers equal."""
     import torch
     m = sawyer_lack
     n = 4
     envs, _, parts, noise = _oracles(m, n, max_episode_steps=150)  # (only for the draws and the pinch geometry)
-    gpu_abi = Abi(GPU_LIB, torch.device("cuda:0"))
+    path = os.path.join(os.path.dirname(GPU_LIB), gpu_lib)
+    if not os.path.exists(path):
+        pytest.skip("%s is not built (python -c 'import __graft_entry__ as g; g.build()')" % gpu_lib)
+    gpu_abi = Abi(path, torch.device("cuda:0"))
     pair = [Session(gpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0), Session(cpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0)]
     assert pair[0].variant() != "cpu-fp64"
     assert (pair[0].nq, pair[0].nv, pair[0].nu, pair[0].dof, pair[0].obs_dim) == (pair[1].nq, pair[1].nv, pair[1].nu, pair[1].dof, pair[1].obs_dim)
@@ -133,6 +139,8 @@ def test_same_session_against_both_libraries(cpu_abi, sawyer_lack):
         (og, rg, dg, ig), (oc, rc, dc, ic) = [s.step(a) for s in pair]
         assert np.abs(og - oc).max() < 2e-4 and np.abs(rg - rc).max() < 1e-5 and np.array_equal(dg, dc)
         assert np.array_equal(ig[:, [0, 1, 2, 3, 4, 5, 6, 7, 15, 16]], ic[:, [0, 1, 2, 3, 4, 5, 6, 7, 15, 16]])
+    for s in pair:
+        s.forward()  # (xpos / xquat / qacc / ncon are outputs of the physics entry points: include/fsim.h)
     sg = pair[0].get_state(m, "qpos", "qvel", "xpos")
     sc = pair[1].get_state(m, "qpos", "qvel", "xpos")
     assert np.abs(sg["qpos"] - sc["qpos"]).max() < 2e-4 and np.abs(sg["xpos"] - sc["xpos"]).max() < 2e-4
