@@ -173,11 +173,6 @@ template <class Ctx> DEV void fs_forward_body(const Ctx &c) {
   }
   int coupled = fs_make_constraints(c);
   FS_PROF(3);
-#ifdef FSIM_PRIO
-  // an env whose robot island is joined to a part is the long job of the launch (5-6 Newton iterations per substep): it
-  // wins issue arbitration over the wave it shares the SIMD with for the rest of the launch
-  if (coupled) __builtin_amdgcn_s_setprio(FSIM_PRIO);
-#endif
 #ifdef FSIM_PROFILE
   {
     int bad_ = 0;
