@@ -588,7 +588,7 @@ int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *d
 int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = NULL; return FSIM_OK; }
 int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); return FSIM_OK; } /* every call of this library is complete on return */
 int fsim_tables_needed(const fsim_t *s) { return s ? s->tables_needed : 0; }
-int fsim_max_contacts(const fsim_t *s) { (void)s; return 5000; } /* nconmax of the reference's models (base.xml:5): nothing is dropped here */
+int fsim_max_contacts(const fsim_t *s) { (void)s; return 256; } /* the checker's contact capacity (fsim_oracle.c MAXCON): rows of contact_geoms */
 const char *fsim_kernel_variant(const fsim_t *s) { (void)s; return "cpu-fp64"; }
 const char *fsim_step_kernel(const fsim_t *s) { (void)s; return "libfsim_cpu (fp64 checker: one env per OpenMP thread)"; }
 int64_t fsim_overflow_resteps(const fsim_t *s) { (void)s; return 0; }
@@ -627,7 +627,7 @@ int fsim_step(fsim_t *s, const float *action, void *obs, float *reward, uint8_t 
 }
 static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
   if (!s || !p) FAIL(FSIM_EINVAL, "null");
-  if (p->cursor || p->dense || p->env_block || p->contact_geoms || p->solver_iters) FAIL(FSIM_EINVAL, "libfsim_cpu: cursor / dense / env_block / contact_geoms / solver_iters are not served by the CPU checker");
+  if (p->cursor || p->dense || p->env_block || p->solver_iters) FAIL(FSIM_EINVAL, "libfsim_cpu: cursor / dense / env_block / solver_iters are not served by the CPU checker");
   const EnvModel *m = &s->m;
   for (int i = 0; i < s->n; i++) {
     Env *e = &s->env[i];
@@ -642,6 +642,10 @@ static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
       if (p->xpos) for (int k = 0; k < 3 * m->nbody; k++) p->xpos[(size_t)i * 3 * m->nbody + k] = (float)e->xpos[k];
       if (p->xquat) for (int k = 0; k < 4 * m->nbody; k++) p->xquat[(size_t)i * 4 * m->nbody + k] = (float)e->xquat[k];
       if (p->ncon) p->ncon[i] = e->ncon[0];
+      if (p->contact_geoms) for (int k = 0; k < 256; k++) { /* [n, max_contacts * 2], -1 padded */
+        p->contact_geoms[((size_t)i * 256 + k) * 2] = k < e->ncon[0] ? e->cg1[k] : -1;
+        p->contact_geoms[((size_t)i * 256 + k) * 2 + 1] = k < e->ncon[0] ? e->cg2[k] : -1;
+      }
     }
   }
   return FSIM_OK;

@@ -84,6 +84,8 @@ class Session:
         abi.check(L.fsim_dims(self.h, *[ctypes.byref(x) for x in d]))
         self.nq, self.nv, self.nu, self.dof, self.obs_dim, self.info_dim, _ = [x.value for x in d]
         assert self.info_dim == INFO_DIM
+        L.fsim_max_contacts.argtypes = [ctypes.c_void_p]
+        self.max_contacts = L.fsim_max_contacts(self.h)
         self.obs = abi.zeros((n, self.obs_dim), np.float32)
         self.act = abi.zeros((n, self.dof), np.float32)
         self.rew = abi.zeros((n,), np.float32)
@@ -123,7 +125,8 @@ class Session:
                 "qfrc_bias": ((n, self.nv), np.float32), "ctrl": ((n, self.nu), np.float32), "qfrc_applied": ((n, self.nv), np.float32),
                 "xfrc_applied": ((n, m.nparts * 6), np.float32), "eq_data": ((n, m.neq * 7), np.float32), "eq_active": ((n, m.neq), np.int32),
                 "geom_contype": ((n, m.ngeom), np.int32), "geom_conaffinity": ((n, m.ngeom), np.int32), "group": ((n, m.nparts), np.int32),
-                "xpos": ((n, m.nbody * 3), np.float32), "xquat": ((n, m.nbody * 4), np.float32), "ncon": ((n,), np.int32)}[name]
+                "xpos": ((n, m.nbody * 3), np.float32), "xquat": ((n, m.nbody * 4), np.float32), "ncon": ((n,), np.int32),
+                "contact_geoms": ((n, self.max_contacts * 2), np.int32)}[name]
 
     def get_state(self, m, *names):
         a, sp, bufs = self.abi, StatePtrs(), {}
