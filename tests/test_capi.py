@@ -70,3 +70,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "fsim_oracle" not in txt, f
+
+
+def test_header_and_c_host_compile_as_plain_c(tmp_path):
+    """include/fsim.h is a C header (no C++, no torch types): the plain-C host example compiles against it with gcc -std=c11 (object
+    only here; the GPU suite links and runs it: tests/test_c_host_gpu.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no ROCm headers on this machine")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-c", os.path.join(root, "examples", "c_host.c"), "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", "-o", str(tmp_path / "c_host.o")])
