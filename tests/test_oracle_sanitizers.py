@@ -43,3 +43,64 @@ def test_oracle_runs_clean_under_asan_and_ubsan():
     p = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0 and "SANITIZED-OK" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
     assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-3000:]
+
+
+CPU_ABI_SCRIPT = r"""
+import numpy as np
+from furniture_amd.mjcf.model import load_compiled
+from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+from tests.abi_session import Abi, Session
+from tests.scenarios import counter_actions, pinch_attach_state
+import os
+m = load_compiled("Sawyer", "table_lack_0825")
+n = 3
+envs = [FurnitureEnvOracle(m, OracleConfig(seed=40 + i, max_episode_steps=4)) for i in range(n)]
+for e in envs:
+    e.reset()
+parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+noise = np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs])
+ses = Session(Abi(os.environ["FSIM_CPU_SAN"]), m.to_blob(), n, max_episode_steps=4, auto_reset=1)
+ses.set_reset_tables(parts, noise)
+ses.reset()
+for t in range(6):  # crosses the auto-reset at the time limit
+    obs, rew, done, info = ses.step(np.stack([counter_actions(1, i, t, 9) for i in range(n)]))
+    if ses.tables_needed():
+        ses.set_reset_tables(parts, noise, mask=info[:, 7] > 0)
+assert np.isfinite(obs).all()
+ses.forward()
+st = ses.get_state(m, "qpos", "xpos", "xquat", "geom_contype", "geom_conaffinity", "contact_geoms", "ncon")
+q, xfrc, masks = pinch_attach_state(m, st["qpos"][0].astype(float), st["xpos"][0].reshape(-1, 3).astype(float), st["xquat"][0].reshape(-1, 4).astype(float))
+for g, (ct, ca) in masks.items():
+    st["geom_contype"][:, g], st["geom_conaffinity"][:, g] = ct, ca
+ses.set_state(m, qpos=np.tile(q, (n, 1)), qvel=np.zeros((n, m.nv)), xfrc_applied=np.tile(xfrc, (n, 1)), geom_contype=st["geom_contype"], geom_conaffinity=st["geom_conaffinity"])
+a = np.zeros((n, 9), dtype=np.float32)
+a[:, 7] = a[:, 8] = 1
+obs, rew, done, info = ses.step(a)
+assert info[0, 0] == 1, info[0]
+b = load_compiled("Baxter", "desk_mikael_1064")
+sb = Session(Abi(os.environ["FSIM_CPU_SAN"]), b.to_blob(), 1, max_episode_steps=10, auto_reset=0)
+eb = FurnitureEnvOracle(b, OracleConfig(seed=7, max_episode_steps=10))
+eb.reset()
+sb.set_reset_tables(eb.reset_draws["part_qpos"].reshape(1, -1), np.stack(eb.reset_draws["noise"]).reshape(1, -1))
+sb.reset()
+sb.step(counter_actions(1, 0, 0, 17)[None])
+sb.close(); ses.close()
+print("SANITIZED-OK")
+"""
+
+
+def test_native_checker_runs_clean_under_asan_and_ubsan():
+    """oracle/libfsim_cpu.so (the C-ABI on host memory: env logic in C) under ASan + UBSan: resets, steps across an auto-reset, state
+    transfer in both directions, the scripted attach, a Baxter step."""
+    so = os.path.join(ROOT, "oracle", "libfsim_cpu_san.so")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libfsim_cpu_san.so"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer build not available: " + r.stderr[-200:])
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    env = dict(os.environ, FSIM_CPU_SAN=so, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-c", CPU_ABI_SCRIPT], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert p.returncode == 0 and "SANITIZED-OK" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-3000:]
