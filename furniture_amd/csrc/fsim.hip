@@ -34,6 +34,11 @@ struct KParams {
   float newton_tol;
 };
 
+#ifdef FSIM_DBG_FILL
+// development (scripts/dev/r5/lds_uninit.sh): LDS words [lo, hi) of every env image are set to a pattern before the env runs -- with the rest
+// of the LDS poisoned by another kernel, the range whose filling changes the results contains a word that is read before it is written
+__device__ int g_dbg_fill[3];
+#endif
 __device__ __forceinline__ void load_record(float *L, const float *rec, int n, int lane) {
   for (int i = lane; i < n; i += 64) L[i] = rec[i];
 }
@@ -126,6 +131,10 @@ template <class Ctx, bool DEFER = false, class A> DEV int env_run(const Ctx &c, 
   float *rec = a.state + (size_t)env * c.ly.stride;
 #ifdef FSIM_TIMELINE
   const long long tw0_ = wall_clock64(); // (100 MHz, one counter for the whole device: clock64() has an offset per XCD)
+#endif
+#ifdef FSIM_DBG_FILL
+  for (int i = g_dbg_fill[0] + lane; i < g_dbg_fill[1]; i += 64) reinterpret_cast<int *>(L)[i] = g_dbg_fill[2];
+  SYNC();
 #endif
   load_record(L, a.state_in ? a.state_in + (size_t)env * c.ly.stride : rec, c.ly.stride, lane);
   if (a.prev && job != JOB_RESET) store_record(a.prev + (size_t)env * c.ly.stride, L, c.ly.stride, lane); // (what a re-step starts from)
@@ -1299,6 +1308,16 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     for (int e = 0; e < n_envs; e++) memcpy(all.data() + (size_t)e * s->ly.stride, rec.data(), s->ly.stride * 4);
     HIPCHK(hipMemcpy(s->d_state, all.data(), sbytes, hipMemcpyHostToDevice));
   }
+#ifdef FSIM_DBG_FILL
+  {
+    int v[3] = {0, 0, 0};
+    if (const char *e = getenv("FSIM_DBG_FILL")) sscanf(e, "%d,%d,%x", &v[0], &v[1], (unsigned *)&v[2]);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_fill), v, sizeof v));
+    const Layout &y = s->ly;
+    fprintf(stderr, "[fsim dbg] stride %d xpos %d cvel %d cinert(H) %d cdof %d M %d LD %d smooth %d x %d grad %d gpos %d surv %d con %d weld %d lim %d W %d G %d scal %d hmap %d hA %d hP %d pitem %d k_begin %d k_end %d lds_words %d\n",
+            y.stride, y.xpos, y.cvel, y.cinert, y.cdof, y.M, y.LD, y.smooth, y.x, y.grad, y.gpos, y.surv, y.con, y.weld, y.lim, y.W, y.G, y.scal, y.hmap, y.hA, y.hP, y.pitem, y.k_begin, y.k_end, y.lds_words);
+  }
+#endif
   if (getenv("FSIM_VERBOSE")) {
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(s->ks.env_step), 64, s->lds_bytes);

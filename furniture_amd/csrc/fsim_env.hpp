@@ -1190,6 +1190,14 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
   if (c.D.agent == 2) {
     // FurnitureCursorEnv._step: _step_discrete(a) then _do_simulation(None) (furniture_cursor.py:59-70, furniture.py:2857-2897)
     connect = 0; // the arm agents' finger scan below does not apply
+    // _step_discrete reads data.site_xpos / site_xmat (_try_connect -> _is_aligned, the approach target) BEFORE this step's first forward
+    // pass: in the reference they are what the last forward pass of the previous step left; here the pose arrays live in LDS and do not
+    // survive the launch, so they are rebuilt from the record's qpos -- the poses AFTER the previous step's last integration, one
+    // substep (2 ms x velocity) newer than the reference's; identical for a group that is held (selected groups are stopped, qvel = 0).
+    // Until round 5 a step in which neither cursor moved a selected part (a move rejected at the boundary) read these arrays as
+    // whatever the LDS held (scripts/dev/r5/lds_uninit.py found word xpos + 6: results depended on the CU's previous tenant).
+    fs_kinematics(c);
+    SYNC();
     env_cursor_discrete(c, cfg, io.action);
     if (cfg.reset_robot_after_attach && E[E_CONNECTED_THIS_STEP]) env_init_robot(c, EnvResetIO{nullptr, nullptr, nullptr, 0}, 0, cfg.move_speed); // (furniture.py:919-925: the cursors go back to their start positions)
     if (c.lane == 0) { // parts in a selected group float (gravity compensated), the others are only stopped

@@ -1,0 +1,78 @@
+"""No result may depend on what the LDS held before the kernel started.  Work arrays live in LDS and do not survive a launch; a code path
+that reads one before this launch wrote it (round 5: the Cursor agent's _try_connect read the part poses of "the last forward pass" in a step
+in which no forward pass had run yet) returns whatever the CU's previous tenant left -- run-to-run nondeterminism that a fresh process on an
+idle GPU never shows.  Here every CU's LDS is filled with NaNs, then with zeros, before each launch (tests/lds_poison.hip): the two runs
+must be bit-identical."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from furniture_amd.envs import ResetTableSampler, make_config
+from furniture_amd.mjcf.model import load_compiled
+from furniture_amd.sim import FSim, INFO_DIM, default_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(agent, furniture, n, steps, pattern, tool):
+    m = load_compiled(agent, furniture)
+    ecfg = make_config(unity=False, record_vid=False, furniture_name=furniture, max_episode_steps=4, seed=200)
+    tabs = ResetTableSampler(m, ecfg, 200, 0, n)
+    cfg = default_config()
+    cfg.max_episode_steps, cfg.auto_reset = 4, 1  # in-kernel resets and look-ahead jobs inside the run
+
+    def poison():
+        for _ in range(3):  # (more workgroups than one pass places on every CU)
+            assert tool.lds_poison(ctypes.c_uint(pattern)) == 0
+    sim = FSim(m, n, config=cfg)
+    p, nz = tabs.draw()
+    sim.set_reset_tables(p, nz if agent != "Cursor" else None)
+    dev = sim.device
+    obs = torch.zeros((n, sim.obs_dim), device=dev)
+    poison()
+    sim.reset(None, obs)
+    sim.sync()
+    p, nz = tabs.draw()
+    sim.set_reset_tables(p, nz if agent != "Cursor" else None)
+    dof = sim.dof_action
+    act, rew = torch.zeros((n, dof), device=dev), torch.zeros(n, device=dev)
+    done, info = torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
+    rng = np.random.RandomState(1)
+    out = [obs.cpu().numpy().copy()]
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
+        if agent == "Cursor":  # select mostly on: parts get picked up, carried against the boundary, connected
+            a[:, 6] = np.abs(a[:, 6]) * np.where(rng.rand(n) < 0.8, 1, -1)
+            a[:, 13] = np.abs(a[:, 13]) * np.where(rng.rand(n) < 0.8, 1, -1)
+        act.copy_(torch.as_tensor(a))
+        torch.cuda.synchronize()
+        poison()
+        sim.step(act, obs, rew, done, info)
+        sim.sync()
+        out.append(np.concatenate([obs.cpu().numpy().view(np.uint32), rew.cpu().numpy().view(np.uint32)[:, None], info.cpu().numpy()[:, :12].astype(np.uint32)], axis=1))
+        need = info[:, 7].cpu().numpy() > 0
+        if need.any():
+            p, nz = tabs.draw(need)
+            sim.set_reset_tables(p, nz if agent != "Cursor" else None, mask=need)
+    kernel = sim.step_kernel
+    sim.close()
+    return out, kernel
+
+
+@pytest.mark.parametrize("agent,furniture,mw", [("Cursor", "toy_table", None), ("Cursor", "toy_table", "0"), ("Cursor", "table_lack_0825", None), ("Sawyer", "table_lack_0825", None),
+                                                ("Sawyer", "table_lack_0825", "all"), ("Baxter", "desk_mikael_1064", None), ("Sawyer", "toy_table", None)])
+def test_results_do_not_depend_on_what_the_lds_held(agent, furniture, mw, monkeypatch):
+    so = os.path.join(ROOT, "tests", "liblds_poison.so")
+    assert os.path.exists(so), "tests/liblds_poison.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    tool = ctypes.CDLL(so)
+    if mw is not None:
+        monkeypatch.setenv("FSIM_MW", mw)
+    a, kernel = _run(agent, furniture, 32, 9, 0x7FC00000, tool)
+    b, _ = _run(agent, furniture, 32, 9, 0, tool)
+    for t, (x, y) in enumerate(zip(a, b)):
+        bad = np.nonzero((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0]
+        assert len(bad) == 0, "%s: step %d, envs %s differ between an LDS full of NaNs and an LDS full of zeros" % (kernel, t - 1, bad[:8].tolist())
