@@ -18,17 +18,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(agent, furniture, n, steps, pattern, tool):
-    m = load_compiled(agent, furniture)
+def _run(agent, furniture, n, steps, pattern, tool, control="impedance", dense=False):
+    from furniture_amd.envs import CONTROLLER_CODES
+    m = load_compiled(agent, furniture, control)
     ecfg = make_config(unity=False, record_vid=False, furniture_name=furniture, max_episode_steps=4, seed=200)
     tabs = ResetTableSampler(m, ecfg, 200, 0, n)
     cfg = default_config()
     cfg.max_episode_steps, cfg.auto_reset = 4, 1  # in-kernel resets and look-ahead jobs inside the run
+    cfg.control_type, cfg.dense_reward = CONTROLLER_CODES.get(control, 0), 1 if dense else 0
 
     def poison():
         for _ in range(3):  # (more workgroups than one pass places on every CU)
             assert tool.lds_poison(ctypes.c_uint(pattern)) == 0
     sim = FSim(m, n, config=cfg)
+    if dense:
+        from furniture_amd.dense import pack_dense
+        sim.set_dense_reward(*pack_dense(m))
     p, nz = tabs.draw()
     sim.set_reset_tables(p, nz if agent != "Cursor" else None)
     dev = sim.device
@@ -76,3 +81,19 @@ def test_results_do_not_depend_on_what_the_lds_held(agent, furniture, mw, monkey
     for t, (x, y) in enumerate(zip(a, b)):
         bad = np.nonzero((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0]
         assert len(bad) == 0, "%s: step %d, envs %s differ between an LDS full of NaNs and an LDS full of zeros" % (kernel, t - 1, bad[:8].tolist())
+
+
+@pytest.mark.parametrize("control,dense,mw_k", [("impedance", False, "0"), ("impedance", True, None), ("ik", False, None), ("ik_quaternion", True, None), ("position_orientation", False, None),
+                                                ("joint_torque", False, None)])
+def test_other_control_paths_do_not_depend_on_what_the_lds_held(control, dense, mw_k, monkeypatch):
+    """(Sawyer + table_lack_0825: every env on a four-wave team -- the rule at 0 iterations --, the dense-reward env, IK control, two of the
+    torque-level controllers)"""
+    tool = ctypes.CDLL(os.path.join(ROOT, "tests", "liblds_poison.so"))
+    if mw_k is not None:
+        monkeypatch.setenv("FSIM_MW", "1")
+        monkeypatch.setenv("FSIM_MW_K", mw_k)
+    a, kernel = _run("Sawyer", "table_lack_0825", 32, 9, 0x7FC00000, tool, control, dense)
+    b, _ = _run("Sawyer", "table_lack_0825", 32, 9, 0, tool, control, dense)
+    for t, (x, y) in enumerate(zip(a, b)):
+        bad = np.nonzero((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0]
+        assert len(bad) == 0, "%s / %s: step %d, envs %s differ between an LDS full of NaNs and an LDS full of zeros" % (kernel, control, t - 1, bad[:8].tolist())
