@@ -13,6 +13,7 @@ import torch
 from furniture_amd.envs import ResetTableSampler, make_config
 from furniture_amd.mjcf.model import load_compiled
 from furniture_amd.sim import FSim, INFO_DIM, default_config
+from tests.scenarios import counter_actions
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,13 +47,12 @@ def _run(agent, furniture, n, steps, pattern, tool, control="impedance", dense=F
     dof = sim.dof_action
     act, rew = torch.zeros((n, dof), device=dev), torch.zeros(n, device=dev)
     done, info = torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros((n, INFO_DIM), dtype=torch.int32, device=dev)
-    rng = np.random.RandomState(1)
     out = [obs.cpu().numpy().copy()]
     for t in range(steps):
-        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
+        a = np.stack([counter_actions(1, i, t, dof) for i in range(n)])  # (keyed by (env, t): the same rows whatever the batch size)
         if agent == "Cursor":  # select mostly on: parts get picked up, carried against the boundary, connected
-            a[:, 6] = np.abs(a[:, 6]) * np.where(rng.rand(n) < 0.8, 1, -1)
-            a[:, 13] = np.abs(a[:, 13]) * np.where(rng.rand(n) < 0.8, 1, -1)
+            for k in (6, 13):
+                a[:, k] = np.abs(a[:, k]) * np.where(np.abs(a[:, k - 1]) < 0.8, 1, -1)
         act.copy_(torch.as_tensor(a))
         torch.cuda.synchronize()
         poison()
@@ -97,3 +97,15 @@ def test_other_control_paths_do_not_depend_on_what_the_lds_held(control, dense, 
     for t, (x, y) in enumerate(zip(a, b)):
         bad = np.nonzero((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0]
         assert len(bad) == 0, "%s / %s: step %d, envs %s differ between an LDS full of NaNs and an LDS full of zeros" % (kernel, control, t - 1, bad[:8].tolist())
+
+
+@pytest.mark.parametrize("agent,furniture", [("Cursor", "toy_table"), ("Baxter", "desk_mikael_1064"), ("Sawyer", "chair_bertil_0148")])
+def test_an_envs_bits_do_not_depend_on_the_batch_it_is_stepped_in(agent, furniture):
+    """(tests/test_determinism_gpu.py holds this for the benchmark model; here the Cursor agent, Baxter and a mesh furniture on the generic kernels, with
+    auto-resets inside the run and a differently filled LDS on the two sides)  Env i is seeded seed + i and its actions are keyed by (i, t): the first
+    eight envs of a batch of 40 and a batch of 8 are bit-identical."""
+    tool = ctypes.CDLL(os.path.join(ROOT, "tests", "liblds_poison.so"))
+    a, _ = _run(agent, furniture, 40, 9, 0, tool)
+    b, _ = _run(agent, furniture, 8, 9, 0x7FC00000, tool)
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x[:8].view(np.uint32), y.view(np.uint32)), (t - 1, np.nonzero((x[:8].view(np.uint32) != y.view(np.uint32)).any(axis=1))[0].tolist())
