@@ -33,3 +33,35 @@ def fsim_mw(request, monkeypatch):
     if mode is not None:
         monkeypatch.setenv("FSIM_MW", mode)
     return mode
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poisoned_lds():
+    """FSIM_TEST_POISON=<hex pattern> (e.g. 7fc00000): every fsim_step / fsim_reset / fsim_physics_* call of the session is preceded by a kernel that
+    fills every CU's LDS with the pattern (tests/lds_poison.hip).  A test that passes without it and fails with it has found a code path that
+    reads LDS before writing it.  Off by default (tests/test_lds_clean_gpu.py runs the comparison itself); the whole GPU suite is run this way
+    by hand at the end of a round."""
+    pat = os.environ.get("FSIM_TEST_POISON")
+    if not pat:
+        yield
+        return
+    import ctypes
+    from furniture_amd import sim as S
+    tool = ctypes.CDLL(os.path.join(ROOT, "tests", "liblds_poison.so"))
+    saved = {}
+
+    def wrap(name):
+        orig = getattr(S.FSim, name)
+
+        def f(self, *a, **k):
+            for _ in range(2):
+                tool.lds_poison(ctypes.c_uint(int(pat, 16)))
+            return orig(self, *a, **k)
+        saved[name] = orig
+        setattr(S.FSim, name, f)
+    for name in ("step", "reset", "physics_step", "physics_forward"):
+        if hasattr(S.FSim, name):
+            wrap(name)
+    yield
+    for name, orig in saved.items():
+        setattr(S.FSim, name, orig)
