@@ -83,6 +83,7 @@ template <class Ctx> __global__ __launch_bounds__(64 * Ctx::NW, 2) void k_physic
     }
   }
   SYNC();
+  env_cursor_keep_poses(c);
   store_record(rec, L, c.ly.stride, lane);
 }
 
@@ -206,6 +207,7 @@ template <class Ctx, bool DEFER = false, class A> DEV int env_run(const Ctx &c, 
     row[35] = tlr_; row[36] = load_cache ? tlc_ : -1; // (10 ns ticks: record load, model-cache build -- -1: the wave had it already)
   }
 #endif
+  env_cursor_keep_poses(c);
   store_record(rec, L, c.ly.stride, lane);
   return deferred;
 }
@@ -242,6 +244,7 @@ template <class Ctx, class A> DEV void env_shadow_job(const Ctx &c, const EnvCfg
   env_reset_units(c, a.cfg_dev, env_reset_io(io), prog, p1);
   if (p1 == total) env_post(c, cfg, io, 0);
   SYNC();
+  env_cursor_keep_poses(c);
   store_record(rec, L, c.ly.stride, lane);
   if (lane == 0) {
     // (a shadow whose reset dropped contacts is never valid -- progress beyond "consumed": the terminal step then resets inside its

@@ -72,7 +72,7 @@ DEV EnvResetIO env_reset_io(const EnvIO &io) { return EnvResetIO{io.tab_parts, i
 static inline int env_controller_kind(const fsim_config_t &c) { return c.control_type >= 2 && c.control_type <= 6 ? c.control_type - 1 : 0; }
 static inline int env_extra_words(const DModel &m, const fsim_config_t &c) {
   const int ik = (c.control_type == 7 || c.control_type == 8) ? EI_WORDS * m.narm : 0;  // the dense-reward env may run under IK control: [dense | ik]
-  return m.agent == 2 ? EC_WORDS : (c.dense_reward ? ED_WORDS + ik : (env_controller_kind(c) ? EK_WORDS : ik));
+  return m.agent == 2 ? EC_WORDS + 7 * m.nr /* + env_cursor_keep_poses */ : (c.dense_reward ? ED_WORDS + ik : (env_controller_kind(c) ? EK_WORDS : ik));
 }
 
 static inline void env_fill_cfg(EnvCfg &e, const fsim_config_t &c, const DModel &m) {
@@ -441,6 +441,25 @@ template <class Ctx> DEV float *env_edense(const Ctx &c) { return c.L + c.ly.env
 
 // ---------------------------------------------------------------------------------------------------- connect
 template <class Ctx> DEV int env_ecur(const Ctx &c) { return c.ly.env + E_GROUP + c.D.nparts; }
+// Cursor agent: data.xpos / data.xquat as the last forward pass left them, kept in the record behind the EC_* block.  _step_discrete runs BEFORE the
+// step's first forward pass and reads site poses there (_try_connect -> _is_aligned, the approach target: furniture.py:926-1042) -- in the reference what the
+// previous step's last forward pass computed, one integration older than qpos.  The pose arrays live in LDS and do not survive the launch, so every launch
+// that ends with the record stored keeps them (env_run, env_shadow_job, k_physics) and the Cursor step restores them before _step_discrete.
+template <class Ctx> DEV void env_cursor_keep_poses(const Ctx &c) {
+  if (c.D.agent != 2) return;
+  float *st = c.L + env_ecur(c) + EC_WORDS;
+  for (int i = c.lane; i < 3 * c.D.nr; i += 64) st[i] = c.L[c.ly.xpos + i];
+  for (int i = c.lane; i < 4 * c.D.nr; i += 64) st[3 * c.D.nr + i] = c.L[c.ly.xquat + i];
+  SYNC();
+}
+template <class Ctx> DEV void env_cursor_restore_poses(const Ctx &c) {
+  const float *st = c.L + env_ecur(c) + EC_WORDS;
+  for (int i = c.lane; i < 3 * c.D.nr; i += 64) c.L[c.ly.xpos + i] = st[i];
+  for (int i = c.lane; i < 4 * c.D.nr; i += 64) c.L[c.ly.xquat + i] = st[3 * c.D.nr + i];
+  SYNC();
+  for (int b = c.lane; b < c.D.nr; b += 64) stm3(c.L + c.ly.xmat + 9 * b, q2m(qnormalized(ldq(c.L + c.ly.xquat + 4 * b))));
+  SYNC();
+}
 
 // euler_to_quat(rotation_deg, quat) = quat * (qz * qy * qx)   (transform_utils.py:617-630)
 DEV Q4 env_euler_quat(V3 deg, Q4 q) {
@@ -1092,6 +1111,7 @@ template <class Ctx> DEV void env_swap_in(const Ctx &c, const EnvCfg &cfg, const
   SYNC();
   for (int i = c.lane; i < c.ly.stride; i += 64) L[i] = io.sh_state[i];
   SYNC();
+  if (c.D.agent == 2) env_cursor_restore_poses(c); // (the pose arrays follow the record: the launch's closing env_cursor_keep_poses then writes the reset's poses back, not this step's)
   if (c.lane == 0) {
     // (the two words of the record that belong to the env, not to the reset: how many episodes it has seen, whether it ever dropped contacts)
     E[E_EPISODE_COUNT] = episodes + 1; E[E_OVERFLOW] |= sticky;
@@ -1191,13 +1211,10 @@ template <class Ctx, bool DEFER = false> DEV int env_step(const Ctx &c, const En
     // FurnitureCursorEnv._step: _step_discrete(a) then _do_simulation(None) (furniture_cursor.py:59-70, furniture.py:2857-2897)
     connect = 0; // the arm agents' finger scan below does not apply
     // _step_discrete reads data.site_xpos / site_xmat (_try_connect -> _is_aligned, the approach target) BEFORE this step's first forward
-    // pass: in the reference they are what the last forward pass of the previous step left; here the pose arrays live in LDS and do not
-    // survive the launch, so they are rebuilt from the record's qpos -- the poses AFTER the previous step's last integration, one
-    // substep (2 ms x velocity) newer than the reference's; identical for a group that is held (selected groups are stopped, qvel = 0).
-    // Until round 5 a step in which neither cursor moved a selected part (a move rejected at the boundary) read these arrays as
-    // whatever the LDS held (scripts/dev/r5/lds_uninit.py found word xpos + 6: results depended on the CU's previous tenant).
-    fs_kinematics(c);
-    SYNC();
+    // pass: the poses the previous launch kept in the record (env_cursor_keep_poses).  Until round 5 a step in which neither cursor moved a
+    // selected part (a move rejected at the boundary) read these arrays as whatever the LDS held (scripts/dev/r5/lds_uninit.py found word
+    // xpos + 6: results depended on the CU's previous tenant).
+    env_cursor_restore_poses(c);
     env_cursor_discrete(c, cfg, io.action);
     if (cfg.reset_robot_after_attach && E[E_CONNECTED_THIS_STEP]) env_init_robot(c, EnvResetIO{nullptr, nullptr, nullptr, 0}, 0, cfg.move_speed); // (furniture.py:919-925: the cursors go back to their start positions)
     if (c.lane == 0) { // parts in a selected group float (gravity compensated), the others are only stopped
