@@ -123,6 +123,13 @@ def cpu_baseline(seconds=10.0, kind="native"):
     cores = max(1, min(os.cpu_count() or 1, 64))
     ctx = mp.get_context("spawn")
     if kind == "native":
+        # (the checker is built by __graft_entry__.build(); a tree without it -- or without a compiler -- falls back to the Python env logic, and says so)
+        import subprocess
+        so = os.path.join(ROOT, "oracle", "libfsim_cpu.so")
+        if subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libfsim_cpu.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0 and not os.path.exists(so):
+            out = cpu_baseline(seconds, "python")
+            out["note"] = "oracle/libfsim_cpu.so could not be built here: the Python env logic over the C physics was timed instead"
+            return out
         n = 16 * cores  # (sixteen envs per thread, dynamically scheduled: an env inside its 301-substep auto-reset or a slow contact step does not hold the batch)
         q = ctx.Queue()
         old = os.environ.get("OMP_NUM_THREADS")
@@ -137,7 +144,9 @@ def cpu_baseline(seconds=10.0, kind="native"):
                     break
                 except queue.Empty:
                     if not p.is_alive():
-                        raise RuntimeError("cpu_baseline: the native worker exited with code %s" % p.exitcode)
+                        out = cpu_baseline(seconds, "python")
+                        out["note"] = "the native worker (oracle/libfsim_cpu.so) exited with code %s: the Python env logic over the C physics was timed instead" % p.exitcode
+                        return out
             p.join()
         finally:
             if old is None:
