@@ -19,6 +19,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _tool():
+    """tests/liblds_poison.so: built by __graft_entry__.build(); compiled on the spot (hipcc, a few seconds) in a tree that does not have it"""
+    so = os.path.join(ROOT, "tests", "liblds_poison.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "lds_poison.hip")])
+    return ctypes.CDLL(so)
+
+
 def _run(agent, furniture, n, steps, pattern, tool, control="impedance", dense=False):
     from furniture_amd.envs import CONTROLLER_CODES
     m = load_compiled(agent, furniture, control)
@@ -71,9 +80,7 @@ def _run(agent, furniture, n, steps, pattern, tool, control="impedance", dense=F
 @pytest.mark.parametrize("agent,furniture,mw", [("Cursor", "toy_table", None), ("Cursor", "toy_table", "0"), ("Cursor", "table_lack_0825", None), ("Sawyer", "table_lack_0825", None),
                                                 ("Sawyer", "table_lack_0825", "all"), ("Baxter", "desk_mikael_1064", None), ("Sawyer", "toy_table", None)])
 def test_results_do_not_depend_on_what_the_lds_held(agent, furniture, mw, monkeypatch):
-    so = os.path.join(ROOT, "tests", "liblds_poison.so")
-    assert os.path.exists(so), "tests/liblds_poison.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
-    tool = ctypes.CDLL(so)
+    tool = _tool()
     if mw is not None:
         monkeypatch.setenv("FSIM_MW", mw)
     a, kernel = _run(agent, furniture, 32, 9, 0x7FC00000, tool)
@@ -88,7 +95,7 @@ def test_results_do_not_depend_on_what_the_lds_held(agent, furniture, mw, monkey
 def test_other_control_paths_do_not_depend_on_what_the_lds_held(control, dense, mw_k, monkeypatch):
     """(Sawyer + table_lack_0825: every env on a four-wave team -- the rule at 0 iterations --, the dense-reward env, IK control, two of the
     torque-level controllers)"""
-    tool = ctypes.CDLL(os.path.join(ROOT, "tests", "liblds_poison.so"))
+    tool = _tool()
     if mw_k is not None:
         monkeypatch.setenv("FSIM_MW", "1")
         monkeypatch.setenv("FSIM_MW_K", mw_k)
@@ -104,7 +111,7 @@ def test_an_envs_bits_do_not_depend_on_the_batch_it_is_stepped_in(agent, furnitu
     """(tests/test_determinism_gpu.py holds this for the benchmark model; here the Cursor agent, Baxter and a mesh furniture on the generic kernels, with
     auto-resets inside the run and a differently filled LDS on the two sides)  Env i is seeded seed + i and its actions are keyed by (i, t): the first
     eight envs of a batch of 40 and a batch of 8 are bit-identical."""
-    tool = ctypes.CDLL(os.path.join(ROOT, "tests", "liblds_poison.so"))
+    tool = _tool()
     a, _ = _run(agent, furniture, 40, 9, 0, tool)
     b, _ = _run(agent, furniture, 8, 9, 0x7FC00000, tool)
     for t, (x, y) in enumerate(zip(a, b)):
