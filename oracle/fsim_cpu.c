@@ -21,7 +21,8 @@
 #include "../include/fsim.h"
 #include "fsim_oracle.h"
 
-#include <math.h>
+#include <tgmath.h>
+#undef I
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -46,24 +47,24 @@ static const void *blob_get(const char *blob, size_t nbytes, const char *name, i
 
 typedef struct {
   int nq, nv, nu, nbody, ngeom, nsite, neq, nparts, narm, nconn, agent, narmj, ngripj, has_recipe, maxang;
-  double timestep, gravz;
+  real timestep, gravz;
   const int32_t *part_bodyid, *part_qposadr, *part_dofadr, *body_partid, *geom_bodyid, *geom_fingerrole, *geom_is_robot, *geom_is_partcol,
       *geom_contype0, *geom_conaffinity0, *floor_geomid, *eq_part1, *eq_part2, *arm_qposadr, *arm_dofadr, *grip_qposadr, *grip_dofadr,
       *eef_siteid, *hand_bodyid, *conn_siteid, *conn_partid, *conn_keya, *conn_keyb, *conn_nangle, *part_site_adr, *part_site_num, *part_sites,
       *site_bodyid;
-  const double *body_mass, *eq_data0, *arm_initqpos, *grip_initqpos, *ctrl_bias, *ctrl_weight, *conn_angles, *site_quat;
+  const real *body_mass, *eq_data0, *arm_initqpos, *grip_initqpos, *ctrl_bias, *ctrl_weight, *conn_angles, *site_quat;
 } EnvModel;
 
 typedef struct {
   osim_t *sim;
-  double *qpos, *qvel, *ctrl, *qfrc_applied, *xfrc_applied, *qacc, *qacc_warmstart, *qfrc_bias, *xpos, *xquat, *xmat, *site_xpos, *site_xmat, *time_, *eq_data;
+  real *qpos, *qvel, *ctrl, *qfrc_applied, *xfrc_applied, *qacc, *qacc_warmstart, *qfrc_bias, *xpos, *xquat, *xmat, *site_xpos, *site_xmat, *time_, *eq_data;
   int32_t *contype, *conaff, *eq_active, *cg1, *cg2, *ncon;
   int group[32];
   unsigned long long connected_sites;
   int connect_step, connected, connected_body1, num_connected, prev_num_connected, site1, site2, success_num_conn, subtask1, subtask2;
   int touched[32], picked[32];
-  double cb1_pos[3], cb1_quat[4], target_quat[4]; /* _connected_body1_pos / quat, _target_connector_xquat (wxyz) */
-  double episode_reward;
+  real cb1_pos[3], cb1_quat[4], target_quat[4]; /* _connected_body1_pos / quat, _target_connector_xquat (wxyz) */
+  real episode_reward;
   int episode_length, success, fail;
 } Env;
 
@@ -76,62 +77,66 @@ struct fsim {
   Env *env;
   float *tab_parts, *tab_noise; /* [n][nparts*7], [n][n_noise][narmj] */
   int n_noise, n_substeps, dof, obs_dim, tables_needed;
+  real perturb;      /* FSIM_CPU_PERTURB (read at fsim_create): added to every arm-joint angle and part position at the end of each reset -- the
+                        `perturbed twin` of scripts/divergence_control.py; 0 in every test */
+  real *conv[16];    /* float64 blob entries converted to `real` (fp32 control build only) */
+  int nconv;
 };
 
 /* ---- small vector / quaternion helpers (furniture_amd/transform_utils.py; quaternions wxyz unless said otherwise) */
-static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-static double norm3(const double *a) { return sqrt(dot3(a, a)); }
-static void cross3(double *c, const double *a, const double *b) { double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0]; c[0] = x; c[1] = y; c[2] = z; }
-static void qmul(double *o, const double *a, const double *b) {
-  double r[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+static real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static real norm3(const real *a) { return sqrt(dot3(a, a)); }
+static void cross3(real *c, const real *a, const real *b) { real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0]; c[0] = x; c[1] = y; c[2] = z; }
+static void qmul(real *o, const real *a, const real *b) {
+  real r[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
                  a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
   memcpy(o, r, sizeof r);
 }
-static void qinv(double *o, const double *q) { double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2; }
+static void qinv(real *o, const real *q) { real n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2; }
 /* Quaternion.rotate: the quaternion is normalised first */
-static void qrot(double *o, const double *q, const double *v) {
-  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n}, uc[4] = {u[0], -u[1], -u[2], -u[3]};
-  double p[4] = {0, v[0], v[1], v[2]}, t[4];
+static void qrot(real *o, const real *q, const real *v) {
+  real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n}, uc[4] = {u[0], -u[1], -u[2], -u[3]};
+  real p[4] = {0, v[0], v[1], v[2]}, t[4];
   qmul(t, u, p); qmul(t, t, uc);
   o[0] = t[1]; o[1] = t[2]; o[2] = t[3];
 }
-static double cos_siml(const double *a, const double *b) { return dot3(a, b) / norm3(a) / norm3(b); }
+static real cos_siml(const real *a, const real *b) { return dot3(a, b) / norm3(a) / norm3(b); }
 /* unit_vector: float32 normalisation (transform_utils.py:53-97 down-casts) */
-static void unit_f32(double *o, const double *v) {
+static void unit_f32(real *o, const real *v) {
   float d[3] = {(float)v[0], (float)v[1], (float)v[2]};
   float s = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  float n = (float)sqrt((double)s);
-  for (int k = 0; k < 3; k++) o[k] = (double)(float)(d[k] / n);
+  float n = (float)sqrt((real)s);
+  for (int k = 0; k < 3; k++) o[k] = (real)(float)(d[k] / n);
 }
 /* rotate_vector: cos(a) v + sin(a) k x v (no (1 - cos)(k.v)k term, as in the reference) */
-static void rotate_vector(double *o, const double *v, const double *axis, double deg) {
-  double k[3], c[3], a = deg / 180.0 * M_PI;
+static void rotate_vector(real *o, const real *v, const real *axis, real deg) {
+  real k[3], c[3], a = deg / 180.0 * M_PI;
   unit_f32(k, axis); cross3(c, k, v);
   for (int i = 0; i < 3; i++) o[i] = cos(a) * v[i] + sin(a) * c[i];
 }
-static void rotate_vector_cos(double *o, const double *v, const double *axis, double cs, int dir) {
-  double k[3], c[3];
+static void rotate_vector_cos(real *o, const real *v, const real *axis, real cs, int dir) {
+  real k[3], c[3];
   unit_f32(k, axis); cross3(c, k, v);
   for (int i = 0; i < 3; i++) o[i] = cs * v[i] + dir * sqrt(1 - cs * cs) * c[i];
 }
 /* lookat_to_quat(forward, up) -> xyzw, then convert_quat(.., "wxyz"): returned wxyz here */
-static void lookat_wxyz(double *o, const double *forward, const double *up) {
-  double f[3], un[3], s[3], u[3], n;
+static void lookat_wxyz(real *o, const real *forward, const real *up) {
+  real f[3], un[3], s[3], u[3], n;
   n = norm3(forward); for (int i = 0; i < 3; i++) f[i] = forward[i] / n;
   n = norm3(up); for (int i = 0; i < 3; i++) un[i] = up[i] / n;
   cross3(s, un, f); n = norm3(s); for (int i = 0; i < 3; i++) s[i] /= n;
   cross3(u, f, s);
-  double m00 = s[0], m01 = s[1], m02 = s[2], m10 = u[0], m11 = u[1], m12 = u[2], m20 = f[0], m21 = f[1], m22 = f[2];
-  double tr = (m00 + m11) + m22, q[4]; /* xyzw */
-  if (tr > 0) { double k = sqrt(tr + 1); q[3] = k * 0.5; k = 0.5 / k; q[0] = (m12 - m21) * k; q[1] = (m20 - m02) * k; q[2] = (m01 - m10) * k; }
-  else if (m00 >= m11 && m00 >= m22) { double k0 = sqrt(((1 + m00) - m11) - m22), k = 0.5 / k0; q[0] = 0.5 * k0; q[1] = (m01 + m10) * k; q[2] = (m02 + m20) * k; q[3] = (m12 - m21) * k; }
-  else if (m11 > m22) { double k0 = sqrt(((1 + m11) - m00) - m22), k = 0.5 / k0; q[0] = (m10 + m01) * k; q[1] = 0.5 * k0; q[2] = (m21 + m12) * k; q[3] = (m20 - m02) * k; }
-  else { double k0 = sqrt(((1 + m22) - m00) - m11), k = 0.5 / k0; q[0] = (m20 + m02) * k; q[1] = (m21 + m12) * k; q[2] = 0.5 * k0; q[3] = (m01 - m10) * k; }
+  real m00 = s[0], m01 = s[1], m02 = s[2], m10 = u[0], m11 = u[1], m12 = u[2], m20 = f[0], m21 = f[1], m22 = f[2];
+  real tr = (m00 + m11) + m22, q[4]; /* xyzw */
+  if (tr > 0) { real k = sqrt(tr + 1); q[3] = k * 0.5; k = 0.5 / k; q[0] = (m12 - m21) * k; q[1] = (m20 - m02) * k; q[2] = (m01 - m10) * k; }
+  else if (m00 >= m11 && m00 >= m22) { real k0 = sqrt(((1 + m00) - m11) - m22), k = 0.5 / k0; q[0] = 0.5 * k0; q[1] = (m01 + m10) * k; q[2] = (m02 + m20) * k; q[3] = (m12 - m21) * k; }
+  else if (m11 > m22) { real k0 = sqrt(((1 + m11) - m00) - m22), k = 0.5 / k0; q[0] = (m10 + m01) * k; q[1] = 0.5 * k0; q[2] = (m21 + m12) * k; q[3] = (m20 - m02) * k; }
+  else { real k0 = sqrt(((1 + m22) - m00) - m11), k = 0.5 / k0; q[0] = (m20 + m02) * k; q[1] = (m21 + m12) * k; q[2] = 0.5 * k0; q[3] = (m01 - m10) * k; }
   o[0] = q[3]; o[1] = q[0]; o[2] = q[1]; o[3] = q[2];
 }
 /* transform_to_target_quat(qpos_base, qpos, target): pose of qpos after rigidly rotating qpos_base to target about the base position */
-static void ttq(const double *base, const double *qp, const double *target, double *np_, double *nq) {
-  double bi[4], rel[4], d[3] = {qp[0] - base[0], qp[1] - base[1], qp[2] - base[2]}, r[3];
+static void ttq(const real *base, const real *qp, const real *target, real *np_, real *nq) {
+  real bi[4], rel[4], d[3] = {qp[0] - base[0], qp[1] - base[1], qp[2] - base[2]}, r[3];
   qinv(bi, base + 3); qmul(rel, target, bi);
   qrot(r, rel, d);
   for (int i = 0; i < 3; i++) np_[i] = r[i] + base[i];
@@ -141,21 +146,21 @@ static void ttq(const double *base, const double *qp, const double *target, doub
 /* ---- env helpers */
 static int find_group(Env *e, int i) { int r = i; while (e->group[r] != r) r = e->group[r]; while (e->group[i] != r) { int n = e->group[i]; e->group[i] = r; i = n; } return r; }
 static void merge_groups(Env *e, int i, int j) { e->group[find_group(e, i)] = find_group(e, j); }
-static void part_qpos(const struct fsim *s, Env *e, int i, double *q) { memcpy(q, e->qpos + s->m.part_qposadr[i], 7 * sizeof(double)); }
-static void set_part_qpos(const struct fsim *s, Env *e, int i, const double *pos, const double *rot) { double *q = e->qpos + s->m.part_qposadr[i]; memcpy(q, pos, 24); memcpy(q + 3, rot, 32); }
-static void stop_object(const struct fsim *s, Env *e, int i, double gravity) {
+static void part_qpos(const struct fsim *s, Env *e, int i, real *q) { memcpy(q, e->qpos + s->m.part_qposadr[i], 7 * sizeof(real)); }
+static void set_part_qpos(const struct fsim *s, Env *e, int i, const real *pos, const real *rot) { real *q = e->qpos + s->m.part_qposadr[i]; memcpy(q, pos, 3 * sizeof(real)); memcpy(q + 3, rot, 4 * sizeof(real)); }
+static void stop_object(const struct fsim *s, Env *e, int i, real gravity) {
   const EnvModel *m = &s->m;
   int b = m->part_bodyid[i], d = m->part_dofadr[i];
-  double *x = e->xfrc_applied + 6 * b;
+  real *x = e->xfrc_applied + 6 * b;
   x[0] = 0; x[1] = 0; x[2] = -gravity * m->gravz * m->body_mass[b]; x[3] = 0; x[4] = 0; x[5] = 0;
   for (int k = 0; k < 6; k++) { e->qvel[d + k] = 0; e->qfrc_applied[d + k] = 0; }
 }
 static void slow_object(const struct fsim *s, Env *e, int i) {
   const EnvModel *m = &s->m;
   int b = m->part_bodyid[i], d = m->part_dofadr[i];
-  double *x = e->xfrc_applied + 6 * b;
+  real *x = e->xfrc_applied + 6 * b;
   x[0] = 0; x[1] = 0; x[2] = -m->gravz * m->body_mass[b]; x[3] = 0; x[4] = 0; x[5] = 0;
-  for (int k = 0; k < 6; k++) { double v = e->qvel[d + k]; e->qvel[d + k] = v < -0.2 ? -0.2 : (v > 0.2 ? 0.2 : v); e->qfrc_applied[d + k] = 0; }
+  for (int k = 0; k < 6; k++) { real v = e->qvel[d + k]; e->qvel[d + k] = v < -0.2 ? -0.2 : (v > 0.2 ? 0.2 : v); e->qfrc_applied[d + k] = 0; }
 }
 static void gravity_comp(const struct fsim *s, Env *e) {
   const EnvModel *m = &s->m;
@@ -163,14 +168,14 @@ static void gravity_comp(const struct fsim *s, Env *e) {
   for (int k = 0; k < m->ngripj; k++) e->qfrc_applied[m->grip_dofadr[k]] = e->qfrc_bias[m->grip_dofadr[k]];
 }
 static int fs(Env *e) { osim_forward(e->sim); return osim_step(e->sim); }
-static void site_pose(const struct fsim *s, Env *e, int site, double *pq) { /* _site_xpos_xquat: [site_xpos, body xquat * site_quat] */
-  memcpy(pq, e->site_xpos + 3 * site, 24);
+static void site_pose(const struct fsim *s, Env *e, int site, real *pq) { /* _site_xpos_xquat: [site_xpos, body xquat * site_quat] */
+  memcpy(pq, e->site_xpos + 3 * site, 3 * sizeof(real));
   qmul(pq + 3, e->xquat + 4 * s->m.site_bodyid[site], s->m.site_quat + 4 * site);
 }
-static void site_axes(Env *e, int site, double *up, double *fwd) { const double *R = e->site_xmat + 9 * site; for (int k = 0; k < 3; k++) { up[k] = R[3 * k + 2]; fwd[k] = R[3 * k + 1]; } }
+static void site_axes(Env *e, int site, real *up, real *fwd) { const real *R = e->site_xmat + 9 * site; for (int k = 0; k < 3; k++) { up[k] = R[3 * k + 2]; fwd[k] = R[3 * k + 1]; } }
 static void init_robot(const struct fsim *s, Env *e, const float *noise) {
   const EnvModel *m = &s->m;
-  for (int k = 0; k < m->narmj; k++) e->qpos[m->arm_qposadr[k]] = m->arm_initqpos[k] + (noise ? (double)noise[k] : 0.0);
+  for (int k = 0; k < m->narmj; k++) e->qpos[m->arm_qposadr[k]] = m->arm_initqpos[k] + (noise ? (real)noise[k] : 0.0);
   for (int k = 0; k < m->ngripj; k++) e->qpos[m->grip_qposadr[k]] = m->grip_initqpos[k];
 }
 static void settle(const struct fsim *s, Env *e) {
@@ -201,9 +206,9 @@ static void env_reset(const struct fsim *s, int idx) {
   e->site1 = e->site2 = -1;
   e->success_num_conn = m->nparts - 1;
   for (int k = 0; k < m->neq; k++) e->eq_active[k] = 0;
-  memcpy(e->eq_data, m->eq_data0, sizeof(double) * 7 * m->neq);
+  memcpy(e->eq_data, m->eq_data0, sizeof(real) * 7 * m->neq);
   const float *tp = s->tab_parts + (size_t)idx * 7 * m->nparts;
-  for (int i = 0; i < m->nparts; i++) { double q[7]; for (int k = 0; k < 7; k++) q[k] = (double)tp[7 * i + k]; set_part_qpos(s, e, i, q, q + 3); }
+  for (int i = 0; i < m->nparts; i++) { real q[7]; for (int k = 0; k < 7; k++) q[k] = (real)tp[7 * i + k]; set_part_qpos(s, e, i, q, q + 3); }
   settle(s, e);
   if (m->has_recipe) settle(s, e);
   const float *tn = s->tab_noise ? s->tab_noise + (size_t)idx * s->n_noise * m->narmj : NULL;
@@ -222,6 +227,10 @@ static void env_reset(const struct fsim *s, int idx) {
   for (int k = 0; k < 100; k++) fs(e);
   next_subtask(s, e);
   e->episode_reward = 0; e->episode_length = 0; e->success = 0; e->fail = 0;
+  if (s->perturb != 0) { /* the perturbed twin: same reset, state moved by `perturb` (the poses of this reset's observation are the unperturbed ones) */
+    for (int k = 0; k < m->narmj; k++) e->qpos[m->arm_qposadr[k]] += s->perturb;
+    for (int i = 0; i < m->nparts; i++) for (int k = 0; k < 3; k++) e->qpos[m->part_qposadr[i] + k] += s->perturb;
+  }
 }
 
 static void write_obs(const struct fsim *s, Env *e, float *ob) {
@@ -237,7 +246,7 @@ static void write_obs(const struct fsim *s, Env *e, float *ob) {
     int site = m->eef_siteid[a];
     /* data.site_xvelp / site_xvelr as mujoco_py computes them: the site's Jacobian of the last forward pass times the current qvel
        (oracle/oracle_sim.py site_vel) */
-    double vp[3] = {0, 0, 0}, vr[3] = {0, 0, 0}, *jp = (double *)malloc(sizeof(double) * 6 * m->nv), *jr = jp + 3 * m->nv;
+    real vp[3] = {0, 0, 0}, vr[3] = {0, 0, 0}, *jp = (real *)malloc(sizeof(real) * 6 * m->nv), *jr = jp + 3 * m->nv;
     osim_body_jac(e->sim, m->site_bodyid[site], e->site_xpos + 3 * site, jp, jr);
     for (int r = 0; r < 3; r++) for (int k = 0; k < m->nv; k++) { vp[r] += jp[r * m->nv + k] * e->qvel[k]; vr[r] += jr[r * m->nv + k] * e->qvel[k]; }
     free(jp);
@@ -245,7 +254,7 @@ static void write_obs(const struct fsim *s, Env *e, float *ob) {
     for (int k = 0; k < nj; k++) ob[o++] = (float)e->qvel[m->arm_dofadr[a * nj + k]];
     for (int k = 0; k < 2; k++) ob[o++] = (float)e->qpos[m->grip_qposadr[2 * a + k]];
     for (int k = 0; k < 3; k++) ob[o++] = (float)e->site_xpos[3 * site + k];
-    const double *hq = e->xquat + 4 * m->hand_bodyid[a]; /* wxyz -> xyzw (furniture_sawyer.py:141-143) */
+    const real *hq = e->xquat + 4 * m->hand_bodyid[a]; /* wxyz -> xyzw (furniture_sawyer.py:141-143) */
     ob[o++] = (float)hq[1]; ob[o++] = (float)hq[2]; ob[o++] = (float)hq[3]; ob[o++] = (float)hq[0];
     for (int k = 0; k < 3; k++) ob[o++] = (float)vp[k];
     for (int k = 0; k < 3; k++) ob[o++] = (float)vr[k];
@@ -257,17 +266,17 @@ static int is_aligned(const struct fsim *s, Env *e, int k1, int k2) {
   const EnvModel *m = &s->m;
   const fsim_config_t *c = &s->cfg;
   int s1 = m->conn_siteid[k1], s2 = m->conn_siteid[k2];
-  const double *p1 = e->site_xpos + 3 * s1, *p2 = e->site_xpos + 3 * s2;
-  double up1[3], up2[3], f1[3], f2[3], d12[3], d21[3], u[3];
+  const real *p1 = e->site_xpos + 3 * s1, *p2 = e->site_xpos + 3 * s2;
+  real up1[3], up2[3], f1[3], f2[3], d12[3], d21[3], u[3];
   site_axes(e, s1, up1, f1); site_axes(e, s2, up2, f2);
   for (int k = 0; k < 3; k++) { d12[k] = p2[k] - p1[k]; d21[k] = p1[k] - p2[k]; }
-  double pos_dist = norm3(d12), rot_up = cos_siml(up1, up2);
-  unit_f32(u, d12); double proj12 = dot3(up1, u);
-  unit_f32(u, d21); double proj21 = dot3(up2, u);
+  real pos_dist = norm3(d12), rot_up = cos_siml(up1, up2);
+  unit_f32(u, d12); real proj12 = dot3(up1, u);
+  unit_f32(u, d21); real proj21 = dot3(up2, u);
   int na = m->conn_nangle[k1], fwd_ok = 0;
-  double fr[3];
+  real fr[3];
   if (na == 0) {
-    double cs = cos_siml(f1, f2), rp[3], rn[3];
+    real cs = cos_siml(f1, f2), rp[3], rn[3];
     fwd_ok = 1;
     rotate_vector_cos(rp, f1, up1, cs, 1); rotate_vector_cos(rn, f1, up1, cs, -1);
     memcpy(fr, cos_siml(rp, f2) > cos_siml(rn, f2) ? rp : rn, sizeof fr);
@@ -281,13 +290,13 @@ static int is_aligned(const struct fsim *s, Env *e, int k1, int k2) {
   if (pos_dist < c->alignment_pos_dist / 2 && rot_up > c->alignment_rot_dist_up && fwd_ok) return 1;
   return 0;
 }
-static void move_group_tq(const struct fsim *s, Env *e, int part, const double *translation, const double *target_quat, double gravity) {
-  double base[7];
+static void move_group_tq(const struct fsim *s, Env *e, int part, const real *translation, const real *target_quat, real gravity) {
+  real base[7];
   part_qpos(s, e, part, base);
   int g = find_group(e, part);
   for (int i = 0; i < s->m.nparts; i++)
     if (find_group(e, i) == g) {
-      double q[7], np_[3], nq[4];
+      real q[7], np_[3], nq[4];
       part_qpos(s, e, i, q);
       ttq(base, q, target_quat, np_, nq);
       for (int k = 0; k < 3; k++) np_[k] += translation[k];
@@ -295,36 +304,36 @@ static void move_group_tq(const struct fsim *s, Env *e, int part, const double *
       stop_object(s, e, i, gravity);
     }
 }
-static void bounding_box(const struct fsim *s, Env *e, int part, double *mn, double *mx) {
+static void bounding_box(const struct fsim *s, Env *e, int part, real *mn, real *mx) {
   const EnvModel *m = &s->m;
   int g = find_group(e, part);
   for (int k = 0; k < 3; k++) { mn[k] = 0; mx[k] = 0; } /* quirk Q1: the box always contains the world origin */
   for (int i = 0; i < m->nparts; i++) {
     if (find_group(e, i) != g) continue;
     for (int j = 0; j < m->part_site_num[i]; j++) {
-      const double *p = e->site_xpos + 3 * m->part_sites[m->part_site_adr[i] + j];
+      const real *p = e->site_xpos + 3 * m->part_sites[m->part_site_adr[i] + j];
       for (int k = 0; k < 3; k++) { if (p[k] < mn[k]) mn[k] = p[k]; if (p[k] > mx[k]) mx[k] = p[k]; }
     }
   }
 }
 /* _move_rotate_object(part, offset, [0, 0, 0]): the group moves by `offset`; kept if the bounding box stays inside the workspace */
-static void move_rotate_object(const struct fsim *s, Env *e, int part, const double *off) {
+static void move_rotate_object(const struct fsim *s, Env *e, int part, const real *off) {
   const EnvModel *m = &s->m;
-  double base[7], old[32][7];
+  real base[7], old[32][7];
   int in[32], g = find_group(e, part);
   part_qpos(s, e, part, base);
   /* euler_to_quat([0, 0, 0], base quat) = base quat * identity */
   for (int i = 0; i < m->nparts; i++) {
     in[i] = find_group(e, i) == g;
     if (!in[i]) continue;
-    double np_[3], nq[4];
+    real np_[3], nq[4];
     part_qpos(s, e, i, old[i]);
     ttq(base, old[i], base + 3, np_, nq);
     for (int k = 0; k < 3; k++) np_[k] += off[k];
     set_part_qpos(s, e, i, np_, nq);
   }
   fs(e); /* _is_inside */
-  double mn[3], mx[3], b = s->cfg.cursor_boundary;
+  real mn[3], mx[3], b = s->cfg.cursor_boundary;
   bounding_box(s, e, part, mn, mx);
   int inside = !(mn[0] < -b || mn[1] < -b || mn[2] < -0.05 || mx[0] > b || mx[1] > b || mx[2] > b);
   if (!inside) for (int i = 0; i < m->nparts; i++) if (in[i]) set_part_qpos(s, e, i, old[i], old[i] + 3);
@@ -341,28 +350,28 @@ static void do_connect(const struct fsim *s, Env *e, int k1, int k2) {
     if ((gp == gA || gp == gB) && e->contype[g] != 0) { e->contype[g] = (1 << 30) - 1 - (1 << (gA + 1)); e->conaff[g] = 1 << (gA + 1); }
   }
   if (s->cfg.auto_align) { /* _move_site_to_target(k2, [site1 pos, target quat]) */
-    double tq[7], base[7], body[7], np_[3], nq[4], nsp[3], nsq[4], tr[3];
+    real tq[7], base[7], body[7], np_[3], nq[4], nsp[3], nsq[4], tr[3];
     site_pose(s, e, m->conn_siteid[k1], tq);
-    memcpy(tq + 3, e->target_quat, 32);
+    memcpy(tq + 3, e->target_quat, 4 * sizeof(real));
     site_pose(s, e, m->conn_siteid[k2], base);
     int part = m->conn_partid[k2];
     part_qpos(s, e, part, body);
     ttq(base, body, tq + 3, np_, nq);
-    double body2[7]; memcpy(body2, body, sizeof body2);
+    real body2[7]; memcpy(body2, body, sizeof body2);
     ttq(body2, base, nq, nsp, nsq);
     for (int k = 0; k < 3; k++) tr[k] = tq[k] - nsp[k];
     move_group_tq(s, e, part, tr, nq, 0.0 /* _gravity_compensation of the arm agents */);
   }
   fs(e);
-  double mn1[3], mn2[3], mx[3];
+  real mn1[3], mn2[3], mx[3];
   bounding_box(s, e, pA, mn1, mx); bounding_box(s, e, pB, mn2, mx);
-  double mz = mn1[2] < mn2[2] ? mn1[2] : mn2[2];
-  if (mz < 0) { double off[3] = {0, 0, -mz}; move_rotate_object(s, e, pA, off); move_rotate_object(s, e, pB, off); }
+  real mz = mn1[2] < mn2[2] ? mn1[2] : mn2[2];
+  if (mz < 0) { real off[3] = {0, 0, -mz}; move_rotate_object(s, e, pA, off); move_rotate_object(s, e, pB, off); }
   fs(e);
   for (int i = 0; i < m->neq; i++) { /* _activate_weld */
     int p1 = m->eq_part1[i], p2 = m->eq_part2[i];
     if ((p1 == pA || p1 == pB) && (p2 == pA || p2 == pB)) {
-      double q1[7], q2[7], qi[4], d[3];
+      real q1[7], q2[7], qi[4], d[3];
       part_qpos(s, e, p1, q1); part_qpos(s, e, p2, q2);
       qinv(qi, q1 + 3);
       for (int k = 0; k < 3; k++) d[k] = q2[k] - q1[k];
@@ -373,8 +382,8 @@ static void do_connect(const struct fsim *s, Env *e, int k1, int k2) {
     }
   }
   e->num_connected += 1; e->connected = 1; e->connected_body1 = pA;
-  double q[7]; part_qpos(s, e, pA, q);
-  memcpy(e->cb1_pos, q, 24); memcpy(e->cb1_quat, q + 3, 32);
+  real q[7]; part_qpos(s, e, pA, q);
+  memcpy(e->cb1_pos, q, 3 * sizeof(real)); memcpy(e->cb1_quat, q + 3, 4 * sizeof(real));
   next_subtask(s, e);
 }
 static int try_connect(const struct fsim *s, Env *e, int part1) {
@@ -422,19 +431,19 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
   const EnvModel *m = &s->m;
   const fsim_config_t *c = &s->cfg;
   Env *e = &s->env[idx];
-  double a[64];
+  real a[64];
   const int dof = s->dof;
-  for (int k = 0; k < dof; k++) a[k] = (double)action[k];
+  for (int k = 0; k < dof; k++) a[k] = (real)action[k];
   e->connected = 0;
   if (m->agent == 0 && c->discrete_grip) a[dof - 2] = action[dof - 2] < 0 ? -1 : 1;
-  const double connect = a[dof - 1];
+  const real connect = a[dof - 1];
   { /* _setup_action + _do_simulation */
-    double act[64];
+    real act[64];
     int na = m->narmj, n = 0;
     for (int k = 0; k < na; k++) act[n++] = a[k];
     for (int arm = 0; arm < m->narm; arm++) { act[n++] = a[na + arm]; act[n++] = -a[na + arm]; }
     if (c->rescale_actions) { /* (the clip precedes the gripper mirroring: symmetric bounds, same result) */
-      for (int k = 0; k < n; k++) { double v = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); act[k] = m->ctrl_bias[k] + m->ctrl_weight[k] * v; }
+      for (int k = 0; k < n; k++) { real v = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); act[k] = m->ctrl_bias[k] + m->ctrl_weight[k] * v; }
     }
     gravity_comp(s, e);
     for (int k = 0; k < m->nu; k++) e->ctrl[k] = act[k];
@@ -454,7 +463,7 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
     }
   if (e->connected_body1 >= 0) {
     osim_forward(e->sim);
-    double base[7], tr[3];
+    real base[7], tr[3];
     part_qpos(s, e, e->connected_body1, base);
     for (int k = 0; k < 3; k++) tr[k] = e->cb1_pos[k] - base[k];
     move_group_tq(s, e, e->connected_body1, tr, e->cb1_quat, 0.0);
@@ -464,7 +473,7 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
   int terminal = 0;
   if (e->num_connected == e->success_num_conn && m->nparts > 1) { e->success = 1; terminal = 1; }
   /* _compute_reward on the RAW action */
-  double touch = 0, pick = 0;
+  real touch = 0, pick = 0;
   for (int arm = 0; arm < m->narm; arm++) {
     unsigned L, R, F;
     touch_sets(s, e, arm, &L, &R, &F);
@@ -474,10 +483,10 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
         if (!((F >> i) & 1) && !e->picked[i]) { e->picked[i] = 1; pick += c->pick_reward; }
       }
   }
-  double succ = c->success_reward * (e->num_connected - e->prev_num_connected), s2 = 0;
+  real succ = c->success_reward * (e->num_connected - e->prev_num_connected), s2 = 0;
   e->prev_num_connected = e->num_connected;
-  for (int k = 0; k < dof; k++) s2 += (double)action[k] * (double)action[k];
-  double ctrl_pen = -c->ctrl_penalty_coef * s2, rew = succ + touch + pick + ctrl_pen, penalty = 0;
+  for (int k = 0; k < dof; k++) s2 += (real)action[k] * (real)action[k];
+  real ctrl_pen = -c->ctrl_penalty_coef * s2, rew = succ + touch + pick + ctrl_pen, penalty = 0;
   /* _after_step */
   e->episode_reward += rew;
   e->episode_length += 1;
@@ -516,8 +525,20 @@ void fsim_default_config(fsim_config_t *c) {
   c->furn_xyz_rand = 0.02f; c->furn_rot_rand = 3; c->agent_xyz_rand = 0.001f; c->move_speed = 0.1f; c->rotate_speed = 22.5f; c->cursor_boundary = 1.5f;
   c->lookahead_reset = 1; c->overflow_restep = 1;
 }
+/* a float64 entry of the blob as `real` (in place when real is double; a converted copy the handle owns in the fp32 control build) */
+static const real *cpu_reals(struct fsim *s, const char *name, int64_t *count) {
+  int64_t cnt = 0;
+  const void *p = blob_get(s->blob, s->nbytes, name, 0, &cnt);
+  if (count) *count = cnt;
+  if (!p || sizeof(real) == 8) return (const real *)p;
+  if (s->nconv >= 16) return NULL;
+  real *r = (real *)malloc(sizeof(real) * (size_t)(cnt + 1));
+  for (int64_t i = 0; i < cnt; i++) { double v; memcpy(&v, (const char *)p + 8 * i, 8); r[i] = (real)v; }
+  s->conv[s->nconv++] = r;
+  return r;
+}
 #define GI(field, name) do { m->field = (const int32_t *)blob_get(s->blob, s->nbytes, name, 1, NULL); if (!m->field) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry %s missing", name); } } while (0)
-#define GD(field, name) do { m->field = (const double *)blob_get(s->blob, s->nbytes, name, 0, NULL); if (!m->field) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry %s missing", name); } } while (0)
+#define GD(field, name) do { m->field = cpu_reals(s, name, NULL); if (!m->field) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry %s missing", name); } } while (0)
 int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
   (void)device;
   if (!model_blob || nbytes < 64 || n_envs <= 0 || !out || memcmp(model_blob, "FSIMBLOB", 8) != 0) FAIL(FSIM_EINVAL, "fsim_create: bad arguments");
@@ -527,7 +548,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   if (cfg) s->cfg = *cfg; else fsim_default_config(&s->cfg);
   EnvModel *m = &s->m;
   const int32_t *dims = (const int32_t *)blob_get(s->blob, nbytes, "dims", 1, NULL);
-  const double *opt = (const double *)blob_get(s->blob, nbytes, "opt", 0, NULL);
+  const real *opt = cpu_reals(s, "opt", NULL);
   if (!dims || !opt) { fsim_destroy(s); FAIL(FSIM_EINVAL, "not a model blob"); }
   m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->ngeom = dims[5]; m->nsite = dims[6]; m->neq = dims[7];
   m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
@@ -545,13 +566,14 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   GI(conn_nangle, "conn_nangle"); GI(part_site_adr, "part_site_adr"); GI(part_site_num, "part_site_num"); GI(part_sites, "part_sites"); GI(site_bodyid, "site_bodyid");
   GD(body_mass, "body_mass"); GD(eq_data0, "eq_data0"); GD(arm_initqpos, "arm_initqpos"); GD(grip_initqpos, "grip_initqpos"); GD(ctrl_bias, "ctrl_bias");
   GD(ctrl_weight, "ctrl_weight"); GD(site_quat, "site_quat");
-  m->conn_angles = (const double *)blob_get(s->blob, nbytes, "conn_angles", 0, &cnt);
+  m->conn_angles = cpu_reals(s, "conn_angles", &cnt);
   if (!m->conn_angles) { fsim_destroy(s); FAIL(FSIM_EINVAL, "blob entry conn_angles missing"); }
   m->maxang = m->nconn > 0 ? (int)(cnt / m->nconn) : 1;
   blob_get(s->blob, nbytes, "arm_qposadr", 1, &cnt); m->narmj = (int)cnt;
   blob_get(s->blob, nbytes, "grip_qposadr", 1, &cnt); m->ngripj = (int)cnt;
   { const int32_t *fl = (const int32_t *)blob_get(s->blob, nbytes, "flags", 1, &cnt); m->has_recipe = fl && cnt > 0 ? fl[0] : 0; }
   s->n_substeps = s->cfg.n_substeps > 0 ? s->cfg.n_substeps : 50;
+  { const char *pv = getenv("FSIM_CPU_PERTURB"); s->perturb = pv ? (real)atof(pv) : 0; }
   s->dof = m->narmj + m->narm + 1;
   s->obs_dim = 7 * m->nparts + 29 * m->narm;
   s->env = (Env *)calloc((size_t)n_envs, sizeof(Env));
@@ -559,7 +581,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
     Env *e = &s->env[i];
     e->sim = osim_create(s->blob, nbytes);
     if (!e->sim) { fsim_destroy(s); FAIL(FSIM_EINVAL, "osim_create: %s", osim_last_error()); }
-    osim_set_solver(e->sim, s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : 100, s->cfg.solver_tolerance > 0 ? (double)s->cfg.solver_tolerance : 1e-8);
+    osim_set_solver(e->sim, s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : 100, s->cfg.solver_tolerance > 0 ? (sizeof(real) == 8 ? (real)s->cfg.solver_tolerance : (real)fmax(s->cfg.solver_tolerance, 1e-6f)) : (real)(sizeof(real) == 8 ? 1e-8 : 1e-6)); /* (fp32 control build: the device's tolerance) */
     osim_set_solver_kind(e->sim, 1); /* Newton: MuJoCo's default, what the reference runs (base.xml:4) */
 #define DP(f, name) e->f = osim_dptr(e->sim, name, NULL)
     DP(qpos, "qpos"); DP(qvel, "qvel"); DP(ctrl, "ctrl"); DP(qfrc_applied, "qfrc_applied"); DP(xfrc_applied, "xfrc_applied"); DP(qacc, "qacc");
@@ -576,6 +598,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
 void fsim_destroy(fsim_t *s) {
   if (!s) return;
   if (s->env) for (int i = 0; i < s->n; i++) if (s->env[i].sim) osim_destroy(s->env[i].sim);
+  for (int i = 0; i < s->nconv; i++) free(s->conv[i]);
   free(s->env); free(s->blob); free(s->tab_parts); free(s->tab_noise); free(s);
 }
 int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim, int32_t *info_dim, int32_t *stride) {
@@ -589,7 +612,7 @@ int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null")
 int fsim_sync(fsim_t *s) { if (!s) FAIL(FSIM_EINVAL, "null"); return FSIM_OK; } /* every call of this library is complete on return */
 int fsim_tables_needed(const fsim_t *s) { return s ? s->tables_needed : 0; }
 int fsim_max_contacts(const fsim_t *s) { (void)s; return 256; } /* the checker's contact capacity (fsim_oracle.c MAXCON): rows of contact_geoms */
-const char *fsim_kernel_variant(const fsim_t *s) { (void)s; return "cpu-fp64"; }
+const char *fsim_kernel_variant(const fsim_t *s) { (void)s; return sizeof(real) == 8 ? "cpu-fp64" : "cpu-fp32"; }
 const char *fsim_step_kernel(const fsim_t *s) { (void)s; return "libfsim_cpu (fp64 checker: one env per OpenMP thread)"; }
 int64_t fsim_overflow_resteps(const fsim_t *s) { (void)s; return 0; }
 int fsim_set_max_episode_steps(fsim_t *s, int n) { if (!s || n <= 0) FAIL(FSIM_EINVAL, "bad arguments"); s->cfg.max_episode_steps = n; return FSIM_OK; }
@@ -631,10 +654,10 @@ static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
   const EnvModel *m = &s->m;
   for (int i = 0; i < s->n; i++) {
     Env *e = &s->env[i];
-#define FLD(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = (double)p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (float)(src)[k]; }
+#define FLD(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = (real)p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (float)(src)[k]; }
     FLD(qpos, e->qpos, m->nq) FLD(qvel, e->qvel, m->nv) FLD(qacc_warmstart, e->qacc_warmstart, m->nv) FLD(qfrc_bias, e->qfrc_bias, m->nv) FLD(ctrl, e->ctrl, m->nu)
     FLD(qfrc_applied, e->qfrc_applied, m->nv) FLD(eq_data, e->eq_data, 7 * m->neq)
-    if (p->xfrc_applied) for (int q = 0; q < m->nparts; q++) for (int k = 0; k < 6; k++) { double *x = e->xfrc_applied + 6 * m->part_bodyid[q] + k; float *y = p->xfrc_applied + ((size_t)i * m->nparts + q) * 6 + k; if (to_state) *x = *y; else *y = (float)*x; }
+    if (p->xfrc_applied) for (int q = 0; q < m->nparts; q++) for (int k = 0; k < 6; k++) { real *x = e->xfrc_applied + 6 * m->part_bodyid[q] + k; float *y = p->xfrc_applied + ((size_t)i * m->nparts + q) * 6 + k; if (to_state) *x = *y; else *y = (float)*x; }
 #define FLI(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (src)[k]; }
     FLI(eq_active, e->eq_active, m->neq) FLI(geom_contype, e->contype, m->ngeom) FLI(geom_conaffinity, e->conaff, m->ngeom) FLI(group, e->group, m->nparts)
     if (!to_state) {

@@ -24,6 +24,14 @@
 extern "C" {
 #endif
 
+/* `real` is the arithmetic type of the whole checker: double in libfsim_oracle.so / libfsim_cpu.so (THE checker), float in the
+ * control build libfsim_cpu32.so (-DOSIM_REAL=float -fsingle-precision-constant, <tgmath.h>: the same source in fp32 throughout --
+ * what `fp32 alone` does to a trajectory, scripts/divergence_control.py).  The Python binding (oracle/oracle_sim.py) is fp64 only. */
+#ifndef OSIM_REAL
+#define OSIM_REAL double
+#endif
+typedef OSIM_REAL real;
+
 typedef struct osim osim_t;
 
 osim_t *osim_create(const void *model_blob, size_t nbytes);
@@ -31,25 +39,25 @@ void osim_destroy(osim_t *);
 const char *osim_last_error(void);
 
 /* named views into the simulator's own memory (mujoco_py-style in-place access) */
-double *osim_dptr(osim_t *, const char *name, int *count);
+real *osim_dptr(osim_t *, const char *name, int *count);
 int32_t *osim_iptr(osim_t *, const char *name, int *count);
 
 void osim_reset_data(osim_t *);          /* sim.reset(): qpos=qpos0, everything else 0 */
 void osim_forward(osim_t *);             /* sim.forward() */
 int osim_step(osim_t *);                 /* sim.step(); !=0 -> unstable (MujocoException analogue) */
-void osim_site_vel(osim_t *, int site, double *velp3, double *velr3); /* data.site_xvelp/xvelr */
-void osim_body_jac(osim_t *, int body, const double *point3, double *jacp_3xnv, double *jacr_3xnv);
-void osim_full_M(osim_t *, double *M_nvxnv);
+void osim_site_vel(osim_t *, int site, real *velp3, real *velr3); /* data.site_xvelp/xvelr */
+void osim_body_jac(osim_t *, int body, const real *point3, real *jacp_3xnv, real *jacr_3xnv);
+void osim_full_M(osim_t *, real *M_nvxnv);
 
 /* solver knobs: iterations, tolerance (<=0: fixed iterations), order (0 canonical) */
-void osim_set_solver(osim_t *, int iterations, double tolerance);
+void osim_set_solver(osim_t *, int iterations, real tolerance);
 int osim_last_solver_iters(osim_t *);
-double osim_contact_dist(osim_t *, int i);
+real osim_contact_dist(osim_t *, int i);
 /* diagnostics: efc row of contact i; (type, dim, aref, R, D, mu, pos - margin, force) of row i; J_i . a; the Newton objective at qacc */
 int osim_contact_row(osim_t *, int i);
-int osim_row_info(osim_t *, int i, double *out8);
-double osim_row_dot(osim_t *, int i, const double *a);
-double osim_cost_at(osim_t *, const double *qacc);
+int osim_row_info(osim_t *, int i, real *out8);
+real osim_row_dot(osim_t *, int i, const real *a);
+real osim_cost_at(osim_t *, const real *qacc);
 void osim_set_solver_kind(osim_t *, int kind); /* 0 = PGS (dual), 1 = Newton (primal, MuJoCo default) */
 
 #ifdef __cplusplus
