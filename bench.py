@@ -294,10 +294,9 @@ def main():
     ap.add_argument("--multi-wave", default="auto", choices=["auto", "off", "rule", "all"], help="(exploration only) fsim_config_t::multi_wave of every slab")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("FSIM_BENCH_GROUPS", "4")),
                     help="env groups (slabs) per GPU, each a handle of its own, stepped asynchronously (1 = one synchronous launch)")
-    ap.add_argument("--pool", type=int, default=int(os.environ.get("FSIM_BENCH_POOL", "0")), choices=[0, 1],
-                    help="1: the slabs share one work pool (include/fsim.h fsim_pool_*: steps are posted to a resident kernel, no launch per slab-step); 0: a scheduler + step launch per slab-step")
-    ap.add_argument("--threads", type=int, default=int(os.environ.get("FSIM_BENCH_THREADS", "0")), choices=[0, 1],
-                    help="1: one host thread per slab (each slab is re-stepped as soon as ITS step is done); 0: one thread, round robin")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("FSIM_BENCH_THREADS", "1")), choices=[0, 1],
+                    help="1 (default since round 6; single-process runs only): one host thread per slab -- each slab is re-stepped as soon as ITS step is "
+                         "done (+1 %: 836 / 834 k against 826 / 828 k on one box, profiles/r06_b_*); 0: one thread, round robin (what a rank under torch.distributed.run does)")
     args = ap.parse_args()
     # the host-side reset-table sampler (libfsim_host.so) is OpenMP code; with one host thread per slab, G of its parallel regions start at
     # once when a batch-wide episode end reaches every slab: G x all-cores threads spinning on 64 cores took tens of seconds
@@ -393,20 +392,14 @@ def main():
         sl.sim.set_reset_tables(*sl.tables.take())  # tables for the first auto-reset
         slabs.append(sl)
     dev = slabs[0].sim.device
-    pool = None
-    if args.pool:
-        from furniture_amd.sim import FSimPool
-        pool = FSimPool(local)
-        for sl in slabs:
-            pool.attach(sl.sim)
 
-    # When the all-gather of a slab-step is enqueued.  One process, no pool: right behind the step kernel on the handle's stream (no host
-    # round trip between the two).  Under RCCL and with the work pool: after fsim_sync -- under RCCL because fsim_sync may re-step an env
+    # When the all-gather of a slab-step is enqueued.  One process: right behind the step kernel on the handle's stream (no host
+    # round trip between the two).  Under RCCL: after fsim_sync -- because fsim_sync may re-step an env
     # whose contacts overflowed the slots (1.6 per million env-steps) and rewrite its rows, and a gather chained behind the FIRST pass
     # would hand the learner that env's stale row on every rank (a second gather only on the rank that saw the re-step would not be entered
-    # by the others); with the pool because a posted step is not an operation of the handle's stream.  One collective per slab-step on
+    # by the others).  One collective per slab-step on
     # every rank either way, entered in the same slab order.
-    GATHER_AFTER_SYNC = distributed or bool(args.pool)
+    GATHER_AFTER_SYNC = distributed
 
     def wait(sl):
         if not sl.inflight:
@@ -422,7 +415,7 @@ def main():
             # (the WHOLE contiguous info block: a plain DMA copy.  A column slice is a strided gather KERNEL first, which waits for a wave
             #  slot -- behind the other slabs' reset-step kernels that was 55 ms of an idle host)
             # into a pinned buffer allocated up front, on the slab's own stream: no allocation inside the loop (hipMalloc / hipFree -- also
-            # the ones behind torch's allocators -- wait until NO kernel is running, i.e. for the work pool's resident kernel to leave)
+            # the ones behind torch's allocators -- wait until NO kernel is running)
             need = sl.sim.read_into(sl.info_host, sl.info).numpy()[:, INFO_NEEDS_TABLE]
             mask = need > 0
             if (need > 1).any():  # an unstable env: the reference draws twice (reset inside step() + the worker's reset)
@@ -512,9 +505,6 @@ def main():
 
     run_steps(args.warmup)
     drain()
-    if pool is not None:  # (a launch of the resident kernel of its own for the timed region: its HIP-event duration is the roofline's kernel time)
-        pool.retire()
-        pool_stats0 = pool.stats()
     la0 = [sl.sim.lookahead_stats() for sl in slabs]
     for sl in slabs:
         sl.sim.kernel_time_ms()  # reset the accumulators
@@ -528,11 +518,8 @@ def main():
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if pool is not None:
-        pool.retire()
     la_mid = [sl.sim.lookahead_stats() for sl in slabs]
     kt = [sl.sim.kernel_time_ms() for sl in slabs]  # (of the contract's timed region: read before the second window adds its launches)
-    pool_stats = pool.stats() if pool is not None else None  # (after the retire above: the timed region's launch is complete)
     # Second window, NOT the headline: the contract's K steps after a reset contain no episode end (150-step episodes), so no reset and no
     # look-ahead reset work; this one spans a full episode right behind it -- every env resets once inside it -- on the same clock rules.
     ew = None
@@ -547,8 +534,6 @@ def main():
         if distributed:
             dist.barrier()
         dt_ew = time.perf_counter() - t1
-        if pool is not None:
-            pool.retire()
         if distributed:
             t = torch.tensor([dt_ew], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -569,13 +554,6 @@ def main():
     klaunches = sum(k[1] for k in kt)
     kms = sum(k[0] * k[1] for k in kt) / max(1, klaunches)
     units_per_launch = ng  # env-steps one launch of the dominant kernel processes
-    if pool is not None:
-        # the dominant kernel is the resident k_pool: every env-step of the timed region ran inside its launch(es), timed with HIP events on
-        # the pool's stream; `step_latency_ms` keeps the host-clock post -> completion time of a slab-step
-        step_latency_ms = kms
-        klaunches = pool_stats["launches"] - pool_stats0["launches"]
-        kms = (pool_stats["resident_ms"] - pool_stats0["resident_ms"]) / max(1, klaunches)
-        units_per_launch = n * args.steps / max(1, klaunches)
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -625,9 +603,8 @@ def main():
                                    "50 substeps/step, max_episode_steps=150 with in-kernel auto-reset" % (args.agent, args.furniture, args.control_type, n, slabs[0].sim.dof_action),
                        "envs_per_gpu": n, "global_envs": world * n,
                        "parallelism": "env-sharded x%d, RCCL obs all-gather; %d slab(s) of %d envs per GPU, %s, %s" % (
-                           world, G, ng, "stepped through one resident work-pool kernel (fsim_pool_*)" if pool is not None else "a scheduler + step launch per slab-step on the slab's own HIP stream",
+                           world, G, ng, "a scheduler + step launch per slab-step on the slab's own HIP stream",
                            "one host thread per slab" if THREADS else "one host thread, round robin"),
-                       "work_pool": pool_stats,
                        "rccl_world": dist.get_world_size() if distributed else 1,  # ranks RCCL's communicator saw (1 without torch.distributed.run)
                        # every episode end costs its reset (the reference's _reset: 401 sim.step() calls here).  They are executed INSIDE the
                        # timed region: ahead of the step that needs them (look-ahead jobs) or inside that step's launch
@@ -650,7 +627,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": slabs[0].sim.step_kernel, "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * units_per_launch,
-                         "env_steps_per_launch": units_per_launch, "slab_step_latency_ms": step_latency_ms if pool is not None else None,
+                         "env_steps_per_launch": units_per_launch,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
                          # wave issues at most one instruction per ~5 cycles (scripts/dev/micro: 5.0 cycles per dependent-distance-4
@@ -662,8 +639,6 @@ def main():
         else:  # (the contract times it on rank 0 at N = 1 only: the 1-GPU line of the same sweep carries it)
             line["cpu_baseline"] = {"skipped": "--no-cpu-baseline" if args.no_cpu_baseline else "n_gpus > 1: timed at N = 1 only (see the 1-GPU line)"}
         print(json.dumps(line))
-    if pool is not None:
-        pool.close()
     for sl in slabs:
         sl.tables.close()
         sl.sim.close()

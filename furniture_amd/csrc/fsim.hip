@@ -124,8 +124,7 @@ enum { JOB_AUTO = 0 /* a.do_step decides */, JOB_RESET = 1 /* the deferred reset
 // load_cache: the wave's LDS copy of the model tables is not there yet (a bundled wave steps several envs one after the other
 // and loads it once)
 // returns 1 if the env's reset was deferred (DEFER, see env_step): the caller runs it as a JOB_RESET
-// a: the kernel's own argument block, or (k_pool) a register copy of the block of the pool member the env belongs to; cfg: the kernel's
-// own EnvCfg (the members of a pool have identical configurations)
+// a: the kernel's own argument block; cfg: the kernel's own EnvCfg
 template <class Ctx, bool DEFER = false, class A> DEV int env_run(const Ctx &c, const EnvCfg &cfg, A &a, int env, long long t_entry, bool load_cache = true, int job = JOB_AUTO) {
   float *L = c.L;
   const int lane = c.lane;
@@ -375,7 +374,7 @@ template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) vo
 struct LaSched { const int *sh_prog, *sh_serial, *tab_serial; const uint8_t *init_mask; int *jobs; int maxjobs, defer, total, total_init, eplen_off; };
 // The scheduler proper, run by ONE wave (tid = lane): keys[n] and hist[257] are LDS scratch of the caller; counts[0..2] receive the
 // number of multi-wave envs, of the others, and of look-ahead jobs.  WSYNC orders the wave's LDS phases (a one-wave workgroup's
-// __syncthreads in k_schedule; a compiler barrier when a wave of a bigger workgroup runs it: pool_schedule).
+// __syncthreads in k_schedule; a compiler barrier when a wave of a bigger workgroup runs it).
 template <class WS> __device__ __forceinline__ void sched_run(const int tid, int *keys, int *hist, const int *cost, int *order, int n, const int *state, int stride, int niter_off, int mw_k,
                                                               int use_mw, int *mworder, int *counts, const LaSched &la, WS wsync) {
   for (int b = tid; b < 257; b += 64) hist[b] = 0;
@@ -448,379 +447,6 @@ __global__ __launch_bounds__(64) void k_schedule(const int *cost, int *order, in
   if (threadIdx.x == 0) { q[0] = counts[0]; q[1] = counts[1]; q[2] = 0; q[3] = 0; q[4] = counts[2]; q[5] = 0; }
 }
 
-// ------------------------------------------------------------------------------------------ shared work pool (round 5)
-// Several handles of ONE model and configuration on one device (the slabs of a learner's batch: bench.py, reference: the workers of
-// furniture/env/base.py:55-80) step through ONE resident kernel instead of a k_schedule + k_env_step_x launch each.  Why: a slab's
-// step lasts as long as its slowest env, so the way to more env-steps/s is more, smaller slabs in flight -- and with a launch pair per
-// slab-step the scheduler kernel waits for a wave slot (0.4 ms at 16 slabs), the new launch's workgroups -- its LONGEST jobs first
-// among them -- wait for the other slabs' persistent workgroups to leave (0.6 ms), and 16 slabs ran slower than 4 (round 5,
-// scripts/dev/r5).  Here nothing is launched per step: the host POSTS a step (argument block + epoch number in host-mapped
-// memory), a dispatcher wave of the resident kernel builds that step's queues (the k_schedule code, sched_run), and every resident
-// wave takes the next env of ANY published step.  Which envs get four waves, and what every env computes, is exactly what
-// k_env_step_x does (same rule on the env's own record, same env_run instantiations): results are bit-identical to the launch-per-
-// step path (tests/test_pool_gpu.py) and never depend on which wave ran an env or when.
-//   workgroup 0          dispatcher: wave w polls the posts of members k = w mod 4 and schedules them (its LDS quarter holds the keys)
-//   workgroups 1 .. T    team servers: four waves step one multi-wave env at a time (thead queues of all members)
-//   the others           four independent one-wave workers each: bhead queues of all members, then look-ahead reset jobs (jhead)
-// Memory model.  The kernel outlives a step, so nothing may rely on launch boundaries: a wave that finishes an env (or a job)
-// releases at SYSTEM scope before it counts the env done, the wave that takes an env acquires at system scope after its claim (L2 is
-// per XCD: another XCD's writes and the host's uploads are only visible after that), and the argument block of the other handle is
-// read through the scalar cache only after an explicit invalidate.  Completion: the last env of an epoch (and the last look-ahead
-// job in flight -- jobs count, so that no job outlives the step that listed it) stores the epoch to host-mapped memory; fsim_sync
-// polls that word.
-#define FSIM_POOL_MAX 32 // member handles of a pool (one wave load reads every member's post)
-typedef unsigned long long u64_t;
-// queue word: [63:40] epoch, [39:20] length, [19:0] next index -- ONE atomic add hands out (epoch, length, index) together, so a claim
-// can never pair an index of one epoch with the length (or the arguments) of another
-#define PQ_PACK(ep, n) ((((u64_t)(unsigned)(ep) & 0xffffffull) << 40) | (((u64_t)(unsigned)(n) & 0xfffffull) << 20))
-#define PQ_EPOCH(w) ((int)(((w) >> 40) & 0xffffffull))
-#define PQ_N(w) ((int)(((w) >> 20) & 0xfffffull))
-#define PQ_IDX(w) ((int)((w) & 0xfffffull))
-// the one-wave queue is taken from BOTH ends -- the persistent one-wave workers from the front (longest predicted job first), the
-// team servers' fill-in rounds from the back (the cheapest jobs: four of them end within microseconds of each other) -- so its word
-// carries two counters: [63:48] epoch (16 bits), [47:32] length, [31:16] taken from the back, [15:0] taken from the front
-#define BQ_PACK(ep, n) ((((u64_t)(unsigned)(ep) & 0xffffull) << 48) | (((u64_t)(unsigned)(n) & 0xffffull) << 32))
-#define BQ_EPOCH(w) ((int)(((w) >> 48) & 0xffffull))
-#define BQ_N(w) ((int)(((w) >> 32) & 0xffffull))
-#define BQ_BACK(w) ((int)(((w) >> 16) & 0xffffull))
-#define BQ_FRONT(w) ((int)((w) & 0xffffull))
-#define BQ_LEFT(w) (BQ_N(w) - BQ_BACK(w) - BQ_FRONT(w))
-// completion word: [63:41] epoch, [40] closed (every env done: no new look-ahead job), [39:20] look-ahead jobs in flight, [19:0] envs done
-#define PST_PACK(ep) (((u64_t)(unsigned)(ep) & 0x7fffffull) << 41)
-#define PST_EPOCH(w) ((int)(((w) >> 41) & 0x7fffffull))
-#define PST_CLOSED (1ull << 40)
-#define PST_JOB (1ull << 20)
-#define PST_JOBS(w) ((int)(((w) >> 20) & 0xfffffull))
-#define PST_DONE(w) ((int)((w) & 0xfffffull))
-struct PoolSched { const int *cost; int *order; int n; const int *state; int stride, niter_off, mw_k, use_mw; int *mworder; LaSched la; };
-struct alignas(256) PoolSlot {
-  u64_t thead, bhead, jhead; // queues of the published epoch: multi-wave envs, one-wave envs (longest job first), look-ahead jobs
-  u64_t st;                  // completion word of the published epoch
-  int epoch;                 // the published epoch, all 32 bits (what the completion flag receives)
-  int n_total;               // its envs
-  long long t_pub;           // device-wide clock (100 MHz) when it was published: look-ahead jobs are only started on a young epoch
-  int dalloc, dhead;         // deferred resets of the epoch (multi-wave envs whose step ended the episode with no shadow record ready: the reset is
-  int *dlist;                // ONE-wave work, as in k_env_step_x): entries allocated / taken, the env indices (-1 = not written yet / consumed)
-  PoolSched si;              // scheduler inputs of the published epoch (a copy of the host's: the workers read the order lists through it)
-  StepArgs args;             // of the published epoch: copied from the host's post by the dispatcher
-};
-struct PoolHost {            // host-mapped pinned memory
-  int posted[FSIM_POOL_MAX]; // host -> device: newest epoch posted per member (one 128-byte line)
-  int retire, pad_[31];      // host -> device: leave when idle
-  int done[FSIM_POOL_MAX];   // device -> host: newest epoch completed per member
-  int err[32];               // device -> host: [0] the dispatcher left on its own (nothing posted for FSIM_POOL_IDLE_TICKS): the next post relaunches
-  StepArgs args[FSIM_POOL_MAX]; // host -> device: the argument block of the posted epoch
-  PoolSched si[FSIM_POOL_MAX];  // host -> device: scheduler inputs of the member (they follow its configuration: read at every publication)
-};
-struct PoolCtl { // device memory
-  int retire;      // the dispatcher tells the other waves to leave when idle
-  int pubs;        // publications so far (pool_publish)
-  int pad_[30];
-  int seen[16];    // per XCD: its L2 was invalidated after publication number seen[x] (pool_acquire)
-  int pad2_[16];
-};
-
-DEV u64_t pq_load(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// (lane 0 of a wave) the next item of queue *p, or -1
-DEV int pq_claim(u64_t *p) {
-  u64_t w = pq_load(p);
-  if (PQ_IDX(w) >= PQ_N(w)) return -1;
-  w = __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return PQ_IDX(w) < PQ_N(w) ? PQ_IDX(w) : -1;
-}
-// Every lane of the wave, after a successful claim and before it reads anything the claim hands out.  What an env of epoch E reads
-// -- its record, its action, its reset table, its shadow record -- was written (by waves on other XCDs, whose L2 this one does not
-// snoop, or by the host) and released BEFORE epoch E was published.  So ONE L2 invalidate per XCD after each publication covers every
-// wave of that XCD: the dispatcher numbers the publications (PoolCtl::pubs), each XCD keeps the number its last invalidate is known to be
-// newer than (PoolCtl::seen), and a wave only invalidates when its XCD is behind.  (An invalidate per claim -- one every 7 us per XCD
-// at benchmark load -- threw the model tables out of L2 all the time: 587 k env-steps/s against 799 k for the launch-per-step path.)
-// The argument block of member sl's published epoch, into registers (every lane calls; the result is wave-uniform).  Vector loads that
-// bypass this XCD's L2 and readlanes -- NOT scalar loads: the scalar cache is shared by neighbouring CUs, and invalidating it at every
-// claim (which scalar loads of a block that changes with every epoch would need) made every wave nearby re-fetch its model-table
-// words a few thousand times per second: the long envs, which set a slab's step time, ran 10-25 % slower than on launches of their own.
-DEV StepArgs pool_args(const PoolSlot *sl, int lane) {
-  constexpr int W = (int)(sizeof(StepArgs) / 4);
-  static_assert(W <= 192 && sizeof(StepArgs) % 4 == 0, "StepArgs is read with three loads per lane");
-  const int *src = reinterpret_cast<const int *>(&sl->args);
-  int v[3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) v[j] = (64 * j + lane < W) ? __hip_atomic_load(src + 64 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  StepArgs a;
-  int *dst = reinterpret_cast<int *>(&a);
-#pragma unroll
-  for (int i = 0; i < W; i++) dst[i] = __builtin_amdgcn_readlane(v[i / 64], i % 64);
-  return a;
-}
-// (lane 0) the next one-wave env of queue *p from its front (back = false) or its back: position in the order list, or -1
-DEV int bq_claim(u64_t *p, bool back) {
-  u64_t w = pq_load(p);
-  if (BQ_LEFT(w) <= 0) return -1;
-  w = __hip_atomic_fetch_add(p, back ? (1ull << 16) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (BQ_LEFT(w) <= 0) return -1; // (the item was gone: the counters overshoot by the number of racing claims, which is what BQ_LEFT <= 0 means from now on)
-  return back ? BQ_N(w) - 1 - BQ_BACK(w) : BQ_FRONT(w);
-}
-DEV int pool_xcc() { int x; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 15; }
-DEV void pool_acquire(PoolCtl *ctl, int lane) {
-#ifndef FSIM_POOL_NOFENCE
-  const int x = pool_xcc();
-  int need = 0, have = 0;
-  if (lane == 0) { need = __hip_atomic_load(&ctl->pubs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); have = __hip_atomic_load(&ctl->seen[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  need = __builtin_amdgcn_readfirstlane(need); have = __builtin_amdgcn_readfirstlane(have);
-  if (have - need < 0) { // (pubs was read BEFORE the invalidate: everything released up to publication `need` is visible after it)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    if (lane == 0) __hip_atomic_fetch_max(&ctl->seen[x], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#endif
-  __asm__ volatile("" ::: "memory");
-}
-DEV void pool_signal(PoolHost *ph, int k, int epoch) { __hip_atomic_store(&ph->done[k], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-// an env of member k is finished (every lane calls; the record and the output rows are stored)
-DEV void pool_env_done(PoolSlot *sl, PoolHost *ph, int k, int lane) {
-#if !defined(FSIM_POOL_NOFENCE) && !defined(FSIM_POOL_NOREL)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-#endif
-  if (lane == 0) {
-    const u64_t o = __hip_atomic_fetch_add(&sl->st, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (PST_DONE(o) + 1 == sl->n_total) { // the epoch's last env: no new look-ahead job; whoever sees "closed, none in flight" signals
-      const u64_t o2 = __hip_atomic_fetch_or(&sl->st, PST_CLOSED, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (PST_JOBS(o2) == 0) pool_signal(ph, k, sl->epoch);
-    }
-  }
-}
-// (lane 0) take a look-ahead job of member k's published epoch: job index or -1
-DEV int pool_job_claim(PoolSlot *sl, long long job_age) {
-  const u64_t j = pq_load(&sl->jhead);
-  if (PQ_IDX(j) >= PQ_N(j)) return -1;
-  const u64_t t = pq_load(&sl->thead), b = pq_load(&sl->bhead);
-  // (jobs of an epoch start after every env of it has been TAKEN: what a terminal step decides about its shadow it decided before)
-  if (PQ_EPOCH(t) != PQ_EPOCH(j) || BQ_EPOCH(b) != (PQ_EPOCH(j) & 0xffff) || PQ_IDX(t) < PQ_N(t) || BQ_LEFT(b) > 0) return -1;
-  if ((long long)wall_clock64() - __hip_atomic_load(&sl->t_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > job_age) return -1;
-  // in flight + 1, unless the epoch is closed or no longer the one the queue word showed (CAS: never a blind add on a foreign epoch)
-  u64_t s0 = pq_load(&sl->st);
-  for (;;) {
-    if (PST_EPOCH(s0) != (PQ_EPOCH(j) & 0x7fffff) || (s0 & PST_CLOSED)) return -1;
-    if (__hip_atomic_compare_exchange_strong(&sl->st, &s0, s0 + PST_JOB, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-  }
-  const u64_t w = __hip_atomic_fetch_add(&sl->jhead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (PQ_EPOCH(w) == PQ_EPOCH(j) && PQ_IDX(w) < PQ_N(w)) return PQ_IDX(w);
-  return -2; // (somebody else took the last one: the caller undoes the in-flight count through pool_job_done)
-}
-DEV void pool_job_done(PoolSlot *sl, PoolHost *ph, int k, int lane) {
-#if !defined(FSIM_POOL_NOFENCE) && !defined(FSIM_POOL_NOREL)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-#endif
-  if (lane == 0) {
-    const u64_t o = __hip_atomic_fetch_sub(&sl->st, PST_JOB, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if ((o & PST_CLOSED) && PST_JOBS(o) == 1) pool_signal(ph, k, sl->epoch);
-  }
-}
-// The dispatcher's part for member k, run by ONE wave (lds: >= n + 257 + 8 ints of scratch): copy the posted argument block, build the
-// queues (k_schedule's code), publish.
-DEV void pool_publish(PoolSlot *sl, const PoolHost *ph, PoolCtl *ctl, int k, int epoch, int *lds, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  {
-    const int *src = reinterpret_cast<const int *>(&ph->args[k]);
-    int *dst = reinterpret_cast<int *>(&sl->args);
-    for (int i = lane; i < (int)(sizeof(StepArgs) / 4); i += 64) dst[i] = src[i];
-  }
-  const PoolSched si = ph->si[k]; // (a local copy: the scheduler's loops read these words many times)
-  if (lane == 0) sl->si = si;
-  const int n = si.n;
-  int *counts = lds, *keys = lds + 8, *hist = lds + 8 + n;
-  if (lane < 8) counts[lane] = 0;
-  sched_run(lane, keys, hist, si.cost, si.order, n, si.state, si.stride, si.niter_off, si.mw_k, si.use_mw, si.mworder, counts, si.la, [] { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); });
-  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int nt = __builtin_amdgcn_readfirstlane(counts[0]), nb = __builtin_amdgcn_readfirstlane(counts[1]);
-  const int nj = si.la.sh_prog ? __builtin_amdgcn_readfirstlane(counts[2]) : 0;
-  if (lane == 0) {
-    __hip_atomic_store(&sl->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sl->n_total = nt + nb; sl->dalloc = 0; sl->dhead = 0;
-    __hip_atomic_store(&sl->t_pub, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sl->st, PST_PACK(epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (order, mworder, jobs, the argument block and the words above before the queue words)
-  if (lane == 0) {
-    __hip_atomic_fetch_add(&ctl->pubs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sl->jhead, PQ_PACK(epoch, nj), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sl->thead, PQ_PACK(epoch, nt), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sl->bhead, BQ_PACK(epoch, nb), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-#ifndef FSIM_POOL_IDLE_TICKS
-#define FSIM_POOL_IDLE_TICKS 2000000LL // 20 ms without a post (100 MHz ticks): the kernel leaves the chip to whatever else the process runs; the next post relaunches it
-#endif
-// One unit of ONE-wave work for this wave (every lane calls): a deferred reset (they hold their epoch open), else the next env of
-// some member's one-wave queue -- from its front (the persistent workers: longest predicted job first) or its back (a team server's
-// fill-in round: the cheapest jobs) --, else a look-ahead job.  k0: where the scan over the members starts (advanced).  Returns
-// whether there was anything to do.
-template <class CtxB> DEV bool pool_one(const CtxB &c, const EnvCfg &cfg, PoolSlot *slots, PoolHost *ph, PoolCtl *ctl, int ns, int &k0, bool back, bool load_cache, long long job_age) {
-  const int ln = c.lane;
-  int kind = 0, gk = 0, got = -1; // kind 1 deferred reset, 2 env, 3 look-ahead job
-  {
-    const int k = ln < ns ? (k0 + ln) % ns : 0;
-    PoolSlot *sk = slots + k;
-    u64_t wb = 0, wj = 0;
-    int dn = 0, dh = 0;
-    if (ln < ns) {
-      wb = pq_load(&sk->bhead); wj = pq_load(&sk->jhead);
-      dn = __hip_atomic_load(&sk->dalloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dh = __hip_atomic_load(&sk->dhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // (a fill-in round takes envs only: a deferred reset is 401 substeps, and the team must be back soon)
-    u64_t hd = __ballot(!back && ln < ns && dh < dn), hb = __ballot(ln < ns && BQ_LEFT(wb) > 0), hj = __ballot(!back && ln < ns && PQ_IDX(wj) < PQ_N(wj));
-    while (hd && got < 0) { // (lane order = members from k0 on)
-      const int f = __ffsll((long long)hd) - 1; hd &= hd - 1; gk = (k0 + f) % ns;
-      if (ln == 0) { // (compare-and-swap: the head never passes what has been allocated)
-        PoolSlot *sg = slots + gk;
-        int h_ = __hip_atomic_load(&sg->dhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
-          if (h_ >= __hip_atomic_load(&sg->dalloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { h_ = -1; break; }
-          if (__hip_atomic_compare_exchange_strong(&sg->dhead, &h_, h_ + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-        got = h_;
-      }
-      got = __builtin_amdgcn_readfirstlane(got);
-      if (got >= 0) kind = 1;
-    }
-    while (hb && got < 0) {
-      const int f = __ffsll((long long)hb) - 1; hb &= hb - 1; gk = (k0 + f) % ns;
-      if (ln == 0) got = bq_claim(&slots[gk].bhead, back);
-      got = __builtin_amdgcn_readfirstlane(got);
-      if (got >= 0) kind = 2;
-    }
-    while (hj && got < 0) {
-      const int f = __ffsll((long long)hj) - 1; hj &= hj - 1; gk = (k0 + f) % ns;
-      if (ln == 0) got = pool_job_claim(slots + gk, job_age);
-      got = __builtin_amdgcn_readfirstlane(got);
-      if (got == -2) { pool_job_done(slots + gk, ph, gk, ln); got = -1; }
-      if (got >= 0) kind = 3;
-    }
-  }
-  if (kind == 0) return false;
-  pool_acquire(ctl, ln);
-  int kk = __builtin_amdgcn_readfirstlane(gk);
-  __asm__ volatile("" : "+s"(kk));
-  PoolSlot *sl = slots + kk;
-  const StepArgs a = pool_args(sl, ln);
-  if (kind == 1) {
-    int env = -1; // (the entry is written right after its allocation: a short wait at most)
-    while (env < 0) env = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sl->dlist[got], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (ln == 0) __hip_atomic_store(&sl->dlist[got], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (the record the team server left: on another XCD's L2, released at agent scope -- this wave's L2 may hold the pre-step lines)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    env_run(c, cfg, a, env, clock64(), load_cache, JOB_RESET); pool_env_done(sl, ph, kk, ln);
-  } else if (kind == 2) { env_run(c, cfg, a, sl->si.order[got], clock64(), load_cache); pool_env_done(sl, ph, kk, ln); }
-  else { env_shadow_job(c, cfg, a, a.sh_jobs[got], load_cache); pool_job_done(sl, ph, kk, ln); }
-  k0 = (k0 + 1) % ns;
-  return true;
-}
-// ka: the argument block of the member that launched the kernel -- its EnvCfg serves every member (pool_attach checks they are equal)
-template <class CtxM, class CtxB> __global__ __launch_bounds__(256, FSIM_WPE) void k_pool(const DModel *mp, const Layout *lp, const Layout *lp_mw, KParams kp, StepArgs ka, PoolSlot *slots,
-                                                                                         PoolHost *ph, PoolCtl *ctl, int ns, int nteam, long long job_age) {
-  extern __shared__ float L[];
-  CModel &m = *(CModel *)mp;
-  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), ln = (int)threadIdx.x & 63;
-  if (blockIdx.x == 0) {
-    // ---- dispatcher: wave w serves members w, w + 4, ...; scratch = its quarter of the workgroup's LDS
-    int *lds = reinterpret_cast<int *>(L) + wv * FSIM_BUNDLE_STRIDE(((CLayout *)lp)->lds_words);
-    long long t_idle = (long long)wall_clock64();
-    for (;;) {
-      bool any = false;
-      for (int i = 0; 4 * i + wv < ns; i++) {
-        const int k = 4 * i + wv;
-        const int e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ph->posted[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-        const int pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&slots[k].epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (e != pub) { pool_publish(slots + k, ph, ctl, k, e, lds, ln); any = true; }
-      }
-      // (no new post for FSIM_POOL_IDLE_TICKS: leave, whatever is still in flight -- the workers finish what is published before they
-      //  follow, and the next post restarts the kernel.  Waiting for unfinished steps here instead turned anything that keeps a step from
-      //  finishing into a kernel that never leaves, with every hipMalloc / hipStreamCreate of the process queued behind it.)
-      if (any) { t_idle = (long long)wall_clock64(); continue; }
-      const int r = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ph->retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      if (r) { if (ln == 0) __hip_atomic_store(&ctl->retire, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); break; }
-      if ((long long)wall_clock64() - t_idle > FSIM_POOL_IDLE_TICKS) {
-        if (ln == 0) { __hip_atomic_store(&ctl->retire, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ph->err[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        break;
-      }
-      __builtin_amdgcn_s_sleep(20);
-    }
-    return;
-  }
-  if ((int)blockIdx.x <= nteam) {
-    // ---- team server: while some member has multi-wave envs waiting, the four waves step them, one at a time; in between -- no
-    // workgroup sits idle waiting for the next one -- a FILL-IN ROUND: each wave steps one env from the BACK of a one-wave queue (the
-    // cheapest jobs: the four end within microseconds of each other) and the workgroup meets again.  A multi-wave env thus waits for
-    // a team for as long as it takes ANY of the team-capable workgroups to finish its round, not for a reserved team to come free.
-    int *xw = reinterpret_cast<int *>(L); // (between two envs nothing in the workgroup's LDS is live)
-    int k0 = (int)blockIdx.x % ns, kb = ((int)blockIdx.x * 4 + wv) % ns;
-    for (;;) {
-      if (threadIdx.x < 64) {
-        int got = -1, gk = 0;
-        const int k = ln < ns ? (k0 + ln) % ns : 0;
-        const u64_t w = ln < ns ? pq_load(&slots[k].thead) : 0;
-        u64_t have = __ballot(ln < ns && PQ_IDX(w) < PQ_N(w));
-        while (have && got < 0) { // (lane order = members from k0 on)
-          const int f = __ffsll((long long)have) - 1;
-          have &= have - 1;
-          gk = (k0 + f) % ns;
-          if (ln == 0) got = pq_claim(&slots[gk].thead);
-          got = __builtin_amdgcn_readfirstlane(got);
-        }
-        int quit = 0;
-        if (got < 0) quit = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->retire, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-        if (ln == 0) { xw[0] = got; xw[1] = gk; xw[2] = quit; }
-      }
-      __syncthreads();
-      const int idx = __builtin_amdgcn_readfirstlane(xw[0]), k = __builtin_amdgcn_readfirstlane(xw[1]), quit = __builtin_amdgcn_readfirstlane(xw[2]);
-      __syncthreads(); // (everybody has read the words before anybody goes on and overwrites them)
-      if (idx >= 0) {
-        pool_acquire(ctl, ln);
-        int tid_ = (int)threadIdx.x, kk = __builtin_amdgcn_readfirstlane(k);
-        __asm__ volatile("" : "+v"(tid_), "+s"(kk));
-        const CtxM c(L, m, *(CLayout *)lp_mw, tid_, kp.newton_maxit, kp.newton_tol);
-        if (c.wave > 0) { mw_helper_fn(c); continue; }
-        PoolSlot *sl = slots + kk;
-        const StepArgs a = pool_args(sl, ln);
-        const int env = sl->si.mworder[idx];
-        // (a terminal env without a ready shadow record: its reset is one-wave work -- the member's deferred-reset list, served by
-        //  the one-wave workers like any env; the env counts as done when THAT has run)
-        if (env_run<CtxM, true>(c, ka.cfg, a, env, clock64())) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (the record the reset starts from)
-          if (c.lane == 0) {
-            const int s_ = __hip_atomic_fetch_add(&sl->dalloc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sl->dlist[s_], env, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        } else pool_env_done(sl, ph, kk, c.lane);
-        k0 = (k0 + 1) % ns;
-        continue;
-      }
-      if (quit) break;
-      {
-        int tid_ = (int)threadIdx.x;
-        __asm__ volatile("" : "+v"(tid_));
-        const CtxB c(L, m, *(CLayout *)lp, tid_, kp.newton_maxit, kp.newton_tol);
-        // (load_cache: the team phase's image overlays this wave's copy of the model tables)
-        if (!pool_one(c, ka.cfg, slots, ph, ctl, ns, kb, true, true, job_age)) __builtin_amdgcn_s_sleep(100);
-      }
-    }
-    return;
-  }
-  // ---- one-wave workers: four independent waves, each with its own LDS image, for as long as the kernel is resident
-  {
-    bool first = true;
-    int k0 = ((int)blockIdx.x * 4 + wv) % ns, nidle = 0;
-    for (;;) {
-      int tid_ = (int)threadIdx.x;
-      __asm__ volatile("" : "+v"(tid_));
-      const CtxB c(L, m, *(CLayout *)lp, tid_, kp.newton_maxit, kp.newton_tol);
-      if (pool_one(c, ka.cfg, slots, ph, ctl, ns, k0, false, first, job_age)) { first = false; nidle = 0; continue; }
-      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->retire, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))) break;
-      // (nothing to take: look again in ~3 us, ~12 us once that has failed a few times -- a thousand idle waves polling flat out are
-      //  memory traffic the busy ones pay for)
-      nidle = min(nidle + 1, 8);
-      for (int z = 0; z < (nidle > 4 ? 4 : 1); z++) __builtin_amdgcn_s_sleep(100);
-    }
-  }
-}
-
 // strided gather/scatter between the AoS env records and caller [n, dim] arrays
 __global__ void k_copy_field(float *state, int stride, int off, int dim, float *ext, int n_envs, int to_state) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -876,16 +502,16 @@ struct BlobEnt { char name[48]; int32_t code; int32_t pad; int64_t count; int64_
 typedef void (*PhysicsFn)(const DModel *, const Layout *, KParams, float *, float *);
 typedef void (*EnvStepFn)(const DModel *, const Layout *, KParams, StepArgs, const int *, const int *);
 typedef void (*EnvStepXFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, const int *, const int *, int *, int *);
-typedef void (*PoolFn)(const DModel *, const Layout *, const Layout *, KParams, StepArgs, PoolSlot *, PoolHost *, PoolCtl *, int, int, long long);
 #define FSIM_MW_NW 4 // waves per env of the multi-wave kernels = one-wave envs per bundle
 #define FSIM_LA_MAXJOBS 512 // look-ahead jobs per launch, at most
 #define FSIM_OVF_CAP 1024    // envs of one step launch the overflow re-step lists, at most (the others keep their sticky report)
-struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; PoolFn pool; };
+struct KernelSet { const char *name; PhysicsFn physics; EnvStepFn env_step; PhysicsFn physics_mw; EnvStepFn env_step_mw; EnvStepXFn env_step_x; };
 enum { MW_OFF = 0, MW_RULE = 1, MW_ALL = 2 }; // fsim::mw_mode
 
 struct fsim {
   int device = 0, n_envs = 0;
   bool has_ik = false; // the model carries the IK chain table (Sawyer)
+  bool has_mesh = false; // some colliding geom is a convex mesh (the PLAIN specialisations are compiled without those branches)
   hipStream_t xfer = nullptr; // host -> device table uploads (must not queue behind a running step kernel)
   hipStream_t stream = nullptr;
   // multi-wave kernels (fsim_solver.hpp): MW_OFF one-wave kernel only, MW_RULE = a step is ONE launch of k_env_step_x -- the envs
@@ -906,10 +532,14 @@ struct fsim {
   bool redo_on = false, redo_armed = false;
   float *d_prev = nullptr;
   int *d_ovf_list = nullptr;
-  Layout ly_r{};
-  Layout *d_ly_r = nullptr;
-  int lds_bytes_r = 0, redo_block = 0, redo_slots = 0;
-  EnvStepFn redo_kernel = nullptr;            // 48 -> 64 slots: the generic four-wave kernel; 64 -> 128: the generic one-wave kernel with two slots per lane
+  // the re-step LADDER: rung 0 for models on 48 slots = 64 slots on the generic four-wave kernel, then (round 6) 128 slots on the generic
+  // one-wave kernel with two slots per lane for the envs that overflow 64 as well; models on 64 slots have the one rung 64 -> 128
+  int redo_rungs = 0;
+  Layout ly_r[2]{};
+  Layout *d_ly_r[2] = {nullptr, nullptr};
+  int lds_bytes_r[2] = {0, 0}, redo_block[2] = {0, 0}, redo_slots[2] = {0, 0};
+  EnvStepFn redo_kernel[2] = {nullptr, nullptr};
+  int *d_ovf_list2 = nullptr;                 // envs a re-step rung lists for the next one
   int last_do_step = 0;
   int64_t n_redone = 0;
   struct { const float *action; void *obs; float *reward; uint8_t *done; int32_t *info; } last{};
@@ -949,30 +579,7 @@ struct fsim {
   int *d_sh_prog = nullptr, *d_sh_serial = nullptr, *d_tab_serial = nullptr, *d_sh_jobs = nullptr;
   std::vector<int> h_tab_serial;       // serial number of each env's reset table (bumped with every upload / change of what a reset starts from)
   int la_jobs = 0, la_defer = 0, la_chunk = 0; // jobs per launch, steps into the episode before an env's shadow is started, reset units per job
-  // ---- shared work pool (fsim_pool_attach): the handle's steps are posted to the pool's resident kernel instead of launched
-  struct fsim_pool *pool = nullptr;
-  int pool_k = -1;            // member index
-  int pool_epoch = 0;         // steps posted so far
-  bool pool_pending = false;  // the last post has not been waited for yet
-  int *d_dlist = nullptr;     // deferred resets of the published epoch (PoolSlot::dlist)
-  std::chrono::steady_clock::time_point pool_t0{};
 };
-struct fsim_pool {
-  int device = 0;
-  std::mutex mu;              // launch / retire of the resident kernel (members may be stepped from several host threads)
-  std::vector<fsim *> members;
-  PoolSlot *d_slots = nullptr;
-  PoolCtl *d_ctl = nullptr;
-  PoolHost *h = nullptr, *d_h = nullptr; // host-mapped
-  hipStream_t wstream = nullptr;
-  bool running = false;
-  int grid = 0, nteam = 0;
-  long long job_age = 0;
-  int64_t launches = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr; // lifetime of the resident kernel (fsim_pool_stats)
-  double run_ms = 0;                       // HIP-event time of its completed launches
-};
-static void pool_dissolve(fsim_pool_t *p);
 
 static void la_policy(fsim *s);
 static int la_new_tables(fsim *s, const uint8_t *mask);
@@ -1074,6 +681,10 @@ static int build_model(fsim *s) {
     blob_i(s->blob, "cg_meshadr", ma_); blob_i(s->blob, "cg_meshnum", mn_); blob_f(s->blob, "mesh_vert", mv_);
     if (mv_.empty()) mv_.assign(4, 0.0f);
     if (mv_.size() / 3 > 65535) FAIL(FSIM_ENOMEM, "more than 65535 hull vertices of mesh colliders");
+    for (int v : mn_) {
+      if (v > 32767) FAIL(FSIM_ENOMEM, "a mesh collider's hull has %d vertices (the packed geom word holds 15 bits)", v);
+      if (v > 0) s->has_mesh = true;
+    }
     ar.add(&s->m.mesh_vert, mv_);
     std::vector<float> rec((size_t)16 * std::max(m.ncp, 1), 0.0f);
     for (int p = 0; p < m.ncp; p++) {
@@ -1159,15 +770,15 @@ static LayoutIn layout_in(const fsim *s, int ncon_max) {
 
 static bool same_dims(const Dims &a, const Dims &b) { return memcmp(&a, &b, sizeof(Dims)) == 0; }
 static bool same_in(const LayoutIn &a, const LayoutIn &b) { return memcmp(&a, &b, sizeof(LayoutIn)) == 0; }
-static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg) { // plain_cfg: no controller / IK / dense reward (SpecCtx::PLAIN)
+static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg) { // plain_cfg: no controller / IK / dense reward, no convex-mesh collider (SpecCtx::PLAIN compiles those branches out)
   if (!getenv("FSIM_GENERIC")) { // (development / tests: force the generic kernels)
-#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>, k_pool<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
+#define FS_TRY(S) { const Dims sd = S::D; const LayoutIn si = S::in; if (same_dims(d, sd) && same_in(in, si) && (plain_cfg || !S::plain)) return KernelSet{S::name, k_physics<SpecCtx<S>>, k_env_step<SpecCtx<S>>, k_physics<SpecCtx<S, FSIM_MW_NW>>, k_env_step<SpecCtx<S, FSIM_MW_NW>>, k_env_step_x<SpecCtx<S, FSIM_MW_NW>, SpecCtx<S, 1, true>>}; }
     FSIM_SPEC_LIST(FS_TRY)
 #undef FS_TRY
   }
   // (more than 64 contact slots: two slot sets per lane in the Newton solve -- one-wave kernels only)
-  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr, nullptr};
-  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>, k_pool<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
+  if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr};
+  return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
 }
 
 extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, const fsim_config_t *cfg, fsim_t **out) {
@@ -1207,14 +818,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (s->m.ntree > 16 || s->m.nv > 128) { int nt_ = s->m.ntree, nv_ = s->m.nv; delete s; FAIL(FSIM_EINVAL, "model has %d trees / %d dofs; this build supports <= 16 trees and <= 128 dofs", nt_, nv_); }
   const LayoutIn lin = layout_in(s, ncon_max);
   s->ly = make_layout(lin);
-  s->ks = pick_kernels(s->m, lin, !s->cfg.dense_reward && !env_controller_kind(s->cfg) && s->cfg.control_type != 7 && s->cfg.control_type != 8);
+  s->ks = pick_kernels(s->m, lin, !s->cfg.dense_reward && !env_controller_kind(s->cfg) && s->cfg.control_type != 7 && s->cfg.control_type != 8 && !s->has_mesh);
   s->lds_bytes = s->ly.lds_words * 4;
   if (const char *e = getenv("FSIM_LDS_PAD")) s->lds_bytes += atoi(e); // development: lower the occupancy on purpose
   if (s->lds_bytes > 160 * 1024) { int w = s->ly.lds_words; delete s; FAIL(FSIM_ENOMEM, "per-env LDS image %d words exceeds 160 KiB", w); }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.physics), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.env_step), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking)); // (not lazily: creating a stream waits for a resident work-pool kernel to leave)
+  HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
   { // multi-wave kernels
     s->ly_mw = make_layout(lin, FSIM_MW_NW);
     s->lds_bytes_mw = s->ly_mw.lds_words * 4;
@@ -1248,15 +859,20 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     // overflow re-step: models on the default 48 slots (the benchmark's LDS budget), stepped again with 64 slots and longer broadphase lists
     if ((ncon_max == 48 || ncon_max == 64) && s->m.nv <= 64 && s->cfg.overflow_restep != 0 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
-      LayoutIn lr = lin;
-      const bool big = ncon_max == 64; // (128 slots: two per lane, the one-wave kernel of the `generic2` set; the workgroup has the CU's LDS to itself)
-      lr.ncon_max = big ? 128 : 64; lr.maxsurv = std::max(lin.maxsurv, big ? 192 : 128);
-      s->ly_r = make_layout(lr, big ? 1 : FSIM_MW_NW);
-      s->lds_bytes_r = s->ly_r.lds_words * 4;
-      s->redo_kernel = big ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 2>>) : static_cast<EnvStepFn>(k_env_step<GenCtxT<FSIM_MW_NW>>);
-      s->redo_block = big ? 64 : 64 * FSIM_MW_NW;
-      s->redo_slots = lr.ncon_max;
-      s->redo_on = s->lds_bytes_r <= 160 * 1024 && s->ly_r.stride == s->ly.stride;
+      for (int slots = ncon_max == 48 ? 64 : 128; slots <= 128 && s->redo_rungs < 2; slots *= 2) {
+        LayoutIn lr = lin;
+        const bool big = slots == 128; // (128 slots: two per lane, the one-wave kernel of the `generic2` set; the workgroup has the CU's LDS to itself)
+        lr.ncon_max = slots; lr.maxsurv = std::max(lin.maxsurv, big ? 192 : 128);
+        const Layout ly = make_layout(lr, big ? 1 : FSIM_MW_NW);
+        if (ly.lds_words * 4 > 160 * 1024 || ly.stride != s->ly.stride) break;
+        const int r = s->redo_rungs++;
+        s->ly_r[r] = ly;
+        s->lds_bytes_r[r] = ly.lds_words * 4;
+        s->redo_kernel[r] = big ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 2>>) : static_cast<EnvStepFn>(k_env_step<GenCtxT<FSIM_MW_NW>>);
+        s->redo_block[r] = big ? 64 : 64 * FSIM_MW_NW;
+        s->redo_slots[r] = slots;
+      }
+      s->redo_on = s->redo_rungs > 0;
     }
     snprintf(s->step_kernel, sizeof s->step_kernel, "%s", s->mw_mode == MW_RULE ? "k_env_step_x (multi-wave rule + bundles)" : (s->mw_mode == MW_ALL ? "k_env_step (four waves per env)" : "k_env_step (one wave per env)"));
     if (s->mw_mode) {
@@ -1356,11 +972,14 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
   if (s->redo_on) {
-    HIPCHK(hipMalloc(&s->d_ly_r, sizeof(Layout)));
-    HIPCHK(hipMemcpy(s->d_ly_r, &s->ly_r, sizeof(Layout), hipMemcpyHostToDevice));
+    for (int r = 0; r < s->redo_rungs; r++) {
+      HIPCHK(hipMalloc(&s->d_ly_r[r], sizeof(Layout)));
+      HIPCHK(hipMemcpy(s->d_ly_r[r], &s->ly_r[r], sizeof(Layout), hipMemcpyHostToDevice));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->redo_kernel[r]), hipFuncAttributeMaxDynamicSharedMemorySize, std::max(s->lds_bytes_r[r], std::max(s->lds_bytes_mw, s->lds_bytes))));
+    }
     HIPCHK(hipMalloc(&s->d_prev, (size_t)n_envs * s->ly.stride * 4));
     HIPCHK(hipMalloc(&s->d_ovf_list, FSIM_OVF_CAP * 4));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->redo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, std::max(s->lds_bytes_r, std::max(s->lds_bytes_mw, s->lds_bytes))));
+    HIPCHK(hipMalloc(&s->d_ovf_list2, FSIM_OVF_CAP * 4));
   }
   *out = s;
   return FSIM_OK;
@@ -1369,11 +988,10 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
 extern "C" void fsim_destroy(fsim_t *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  if (s->pool) pool_dissolve(s->pool); // (a pool does not outlive any of its members: the others step on their own launches again)
   if (s->stream) hipStreamSynchronize(s->stream);
   hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_prog); hipFree(s->d_sh_serial); hipFree(s->d_tab_serial); hipFree(s->d_sh_jobs);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_ly_r); hipFree(s->d_prev); hipFree(s->d_ovf_list);
+  hipFree(s->d_ly_r[0]); hipFree(s->d_ly_r[1]); hipFree(s->d_prev); hipFree(s->d_ovf_list); hipFree(s->d_ovf_list2);
   hipFree(s->d_ly_mw); hipFree(s->d_defer); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -1393,16 +1011,13 @@ extern "C" int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu,
 extern "C" int fsim_tables_needed(const fsim_t *s) { return s && s->h_nreset ? *s->h_nreset : 0; }
 extern "C" int fsim_max_contacts(const fsim_t *s) { return s ? s->ly.ncon_max : 0; }
 extern "C" const char *fsim_kernel_variant(const fsim_t *s) { return s && s->ks.name ? s->ks.name : ""; }
-extern "C" const char *fsim_step_kernel(const fsim_t *s) { return s ? (s->pool ? "k_pool (resident work pool: team servers + one-wave workers, multi-wave rule)" : s->step_kernel) : ""; }
+extern "C" const char *fsim_step_kernel(const fsim_t *s) { return s ? s->step_kernel : ""; }
 extern "C" int fsim_env_block_words(const fsim_t *s) { return s ? E_FIXED_WORDS + s->m.nparts + env_extra_words(s->m, s->cfg) : 0; }
 extern "C" int fsim_stream(fsim_t *s, void **st) { if (!s || !st) FAIL(FSIM_EINVAL, "null"); *st = s->stream; return FSIM_OK; }
 static int redo_overflowed(fsim *s);
-static int pool_wait(fsim *s);
-static int pool_quiesce(fsim *s);
 // After a step launch and before anything else reads or advances the records: wait for it and re-step the envs that dropped contacts
 // (a caller that queues two steps without fsim_sync in between gets the wait here: the second step must start from corrected records).
 static int settle(fsim *s) {
-  if (s->pool_pending) { int rc_ = pool_wait(s); if (rc_) return rc_; } // (a step posted to the shared work pool)
   if (!s->redo_armed) return FSIM_OK;
   s->redo_armed = false;
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1435,7 +1050,6 @@ extern "C" int fsim_physics_step(fsim_t *s, int nsub) {
   if (!s || nsub < 0) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
   { int rc_ = settle(s); if (rc_) return rc_; }
-  { int rc_ = pool_quiesce(s); if (rc_) return rc_; }
   if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, nsub, 0), s->d_state, s->d_aux);
   else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, nsub, 0), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
@@ -1445,7 +1059,6 @@ extern "C" int fsim_physics_forward(fsim_t *s) {
   if (!s) FAIL(FSIM_EINVAL, "bad args");
   HIPCHK(hipSetDevice(s->device));
   { int rc_ = settle(s); if (rc_) return rc_; }
-  { int rc_ = pool_quiesce(s); if (rc_) return rc_; }
   if (s->mw_mode == 2) hipLaunchKernelGGL(s->ks.physics_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kparams(s, 0, 1), s->d_state, s->d_aux);
   else hipLaunchKernelGGL(s->ks.physics, dim3(s->n_envs), dim3(64), s->lds_bytes, s->stream, s->d_m, s->d_ly, kparams(s, 0, 1), s->d_state, s->d_aux);
   HIPCHK(hipGetLastError());
@@ -1463,7 +1076,6 @@ static int xfer_state(fsim *s, const fsim_state_ptrs_t *p, int to_state) {
   if (!s || !p) FAIL(FSIM_EINVAL, "null");
   HIPCHK(hipSetDevice(s->device));
   { int rc_ = settle(s); if (rc_) return rc_; }
-  { int rc_ = pool_quiesce(s); if (rc_) return rc_; } // (the copy kernels need wave slots)
   const DModel &m = s->m;
   const Layout &ly = s->ly;
   int rc;
@@ -1646,193 +1258,6 @@ extern "C" int fsim_lookahead_stats(fsim_t *s, int64_t *out) {
 }
 
 
-// ---- shared work pool, host side (device side: k_pool).  A member's fsim_step writes its argument block and epoch number to
-// host-mapped memory (the POST); the resident kernel does the rest; fsim_sync polls the completion word.  The kernel is started by
-// the first post and leaves by itself when nothing has been posted for 20 ms (or at once before a member launches anything of its
-// own: resets, state copies -- those need the wave slots the resident kernel holds).
-static int pool_start(fsim_pool *p) { // (caller holds p->mu)
-  fsim *s = p->members[0];
-  HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipMemsetAsync(p->d_ctl, 0, sizeof(PoolCtl), p->wstream));
-  __atomic_store_n(&p->h->retire, 0, __ATOMIC_RELEASE);
-  __atomic_store_n(&p->h->err[0], 0, __ATOMIC_RELEASE);
-  StepArgs a{};
-  a.cfg = s->ecfg;
-  hipEventRecord(p->ev0, p->wstream);
-  hipLaunchKernelGGL(s->ks.pool, dim3(p->grid), dim3(64 * FSIM_MW_NW), s->lds_bytes_x, p->wstream, s->d_m, s->d_ly, s->d_ly_mw, kparams(s, s->cfg.n_substeps, 0), a,
-                     p->d_slots, p->d_h, p->d_ctl, (int)p->members.size(), p->nteam, p->job_age);
-  hipError_t e = hipGetLastError();
-  hipEventRecord(p->ev1, p->wstream);
-  if (e != hipSuccess) FAIL(FSIM_EHIP, "k_pool launch: %s", hipGetErrorString(e));
-  p->running = true;
-  p->launches++;
-  return FSIM_OK;
-}
-// the resident kernel leaves (after finishing what is in flight); posts it has not served restart it
-static int pool_retire(fsim_pool *p) {
-  std::lock_guard<std::mutex> g(p->mu);
-  if (!p->running) return FSIM_OK;
-  HIPCHK(hipSetDevice(p->device));
-  __atomic_store_n(&p->h->retire, 1, __ATOMIC_RELEASE);
-  HIPCHK(hipStreamSynchronize(p->wstream));
-  p->running = false;
-  { float ms = 0; if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->run_ms += ms; }
-  for (size_t k = 0; k < p->members.size(); k++)
-    if (__atomic_load_n(&p->h->posted[k], __ATOMIC_ACQUIRE) != __atomic_load_n(&p->h->done[k], __ATOMIC_ACQUIRE)) return pool_start(p);
-  return FSIM_OK;
-}
-static int pool_kick(fsim_pool *p) { // after a post: make sure somebody will see it
-  std::lock_guard<std::mutex> g(p->mu);
-  if (p->running && !__atomic_load_n(&p->h->err[0], __ATOMIC_ACQUIRE)) return FSIM_OK;
-  if (p->running) { // (it left on its own)
-    HIPCHK(hipSetDevice(p->device)); HIPCHK(hipStreamSynchronize(p->wstream)); p->running = false;
-    float ms = 0; if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->run_ms += ms;
-  }
-  return pool_start(p);
-}
-static int pool_post(fsim *s, const StepArgs &a) {
-  fsim_pool *p = s->pool;
-  const int k = s->pool_k;
-  if (memcmp(&s->ecfg, &p->members[0]->ecfg, sizeof(EnvCfg)) != 0) FAIL(FSIM_EINVAL, "the members of a work pool must keep one configuration (max_episode_steps, ...): set it on every member");
-  { // scheduler inputs that follow the configuration
-    PoolSched si{};
-    si.cost = s->d_cost; si.order = s->d_order; si.n = s->n_envs; si.state = reinterpret_cast<const int *>(s->d_state); si.stride = s->ly.stride;
-    si.niter_off = s->ly.env + E_NITER; si.mw_k = s->mw_k; si.use_mw = 1; si.mworder = s->d_mworder;
-    if (s->la_on && s->d_tab_parts) {
-      LaSched &la = si.la;
-      la.sh_prog = s->d_sh_prog; la.sh_serial = s->d_sh_serial; la.tab_serial = s->d_tab_serial; la.init_mask = s->d_init_mask; la.jobs = s->d_sh_jobs;
-      la.maxjobs = s->la_jobs; la.defer = std::min(s->la_defer, std::max(0, s->cfg.max_episode_steps - 1)); la.eplen_off = s->ly.env + E_EPISODE_LENGTH;
-      la.total = 100 + (s->ecfg.has_recipe ? 100 : 0) + 201; la.total_init = 100; // (env_reset_total)
-    }
-    memcpy(&p->h->si[k], &si, sizeof si); // (host-mapped: nothing of this member is posted, the dispatcher reads it at the next publication)
-  }
-  memcpy(&p->h->args[k], &a, sizeof a);
-  const int e = ++s->pool_epoch;
-  s->pool_t0 = std::chrono::steady_clock::now();
-  __atomic_store_n(&p->h->posted[k], e, __ATOMIC_SEQ_CST);
-  s->pool_pending = true;
-  return pool_kick(p);
-}
-// wait for the member's posted epoch (fsim_sync / settle)
-static int pool_wait(fsim *s) {
-  if (!s->pool_pending) return FSIM_OK;
-  fsim_pool *p = s->pool;
-  const int k = s->pool_k, e = s->pool_epoch;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (long long spin = 0;; spin++) {
-    if (__atomic_load_n(&p->h->done[k], __ATOMIC_ACQUIRE) == e) break;
-    if ((spin & 0x3ff) == 0x3ff) {
-      if (__atomic_load_n(&p->h->err[0], __ATOMIC_ACQUIRE)) { int rc_ = pool_kick(p); if (rc_) return rc_; }
-      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (sec > 20.0) FAIL(FSIM_EHIP, "work pool: member %d's step %d did not complete within 20 s (resident kernel lost?)", k, e);
-      if (sec > 0.002) std::this_thread::yield();
-    }
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-  }
-  s->pool_pending = false;
-  if (s->timing) { s->acc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->pool_t0).count(); s->acc_n++; }
-  return FSIM_OK;
-}
-// before the member launches anything of its own (reset, physics_step, state copies, the overflow re-step): its step is complete and
-// the resident kernel is off the chip
-static int pool_quiesce(fsim *s) {
-  if (!s->pool) return FSIM_OK;
-  { int rc_ = pool_wait(s); if (rc_) return rc_; }
-  return pool_retire(s->pool);
-}
-extern "C" int fsim_pool_create(int device, fsim_pool_t **out) {
-  if (!out) FAIL(FSIM_EINVAL, "null");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(FSIM_ENODEV, "fsim_pool_create: no HIP device");
-  if (device < 0 || device >= ndev) FAIL(FSIM_EINVAL, "fsim_pool_create: device %d out of range", device);
-  HIPCHK(hipSetDevice(device));
-  fsim_pool *p = new fsim_pool();
-  p->device = device;
-  HIPCHK(hipMalloc(&p->d_slots, sizeof(PoolSlot) * FSIM_POOL_MAX));
-  HIPCHK(hipMemset(p->d_slots, 0, sizeof(PoolSlot) * FSIM_POOL_MAX));
-  HIPCHK(hipMalloc(&p->d_ctl, sizeof(PoolCtl)));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&p->h), sizeof(PoolHost), hipHostMallocMapped));
-  memset(p->h, 0, sizeof(PoolHost));
-  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_h), p->h, 0));
-  HIPCHK(hipStreamCreateWithFlags(&p->wstream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1));
-  hipDeviceProp_t pr;
-  HIPCHK(hipGetDeviceProperties(&pr, device));
-  // workgroups: what the chip holds at once (two per CU: LDS and registers) less a few CUs' worth for whatever else the process runs
-  int spare = 16, teams = 128;
-  if (const char *e = getenv("FSIM_POOL_SPARE")) spare = std::max(0, atoi(e));
-  if (const char *e = getenv("FSIM_POOL_TEAMS")) teams = std::max(1, atoi(e));
-  p->grid = std::max(8, 2 * pr.multiProcessorCount - spare);
-  p->nteam = std::min(teams, p->grid / 2);
-  // look-ahead jobs are started on an epoch younger than this (a job lasts about as long as a cheap env-step and counts towards the epoch)
-  double age_ms = 2.3;
-  if (const char *e = getenv("FSIM_POOL_JOB_AGE_MS")) age_ms = atof(e);
-  p->job_age = (long long)(age_ms * 1e5);
-  *out = p;
-  return FSIM_OK;
-}
-extern "C" int fsim_pool_attach(fsim_pool_t *p, fsim_t *s) {
-  if (!p || !s) FAIL(FSIM_EINVAL, "null");
-  if (s->pool) FAIL(FSIM_EINVAL, "fsim_pool_attach: the handle is in a pool already");
-  if (s->device != p->device) FAIL(FSIM_EINVAL, "fsim_pool_attach: handle and pool are on different devices");
-  if ((int)p->members.size() >= FSIM_POOL_MAX) FAIL(FSIM_EINVAL, "fsim_pool_attach: a pool holds at most %d handles", FSIM_POOL_MAX);
-  if (s->mw_mode != MW_RULE || !s->ks.pool || !s->lpt) FAIL(FSIM_EINVAL, "fsim_pool_attach: the handle must step with k_env_step_x (multi_wave = rule / auto on a batch that fits the chip)");
-  if (s->n_envs > 4096) FAIL(FSIM_EINVAL, "fsim_pool_attach: at most 4096 envs per member (the dispatcher sorts a member's keys in a quarter of a workgroup's LDS)");
-  if (s->ecfg.dense || s->ecfg.n_pre || s->ecfg.dense_coef || s->ecfg.pre_tab || s->cfg.reset_robot_after_attach)
-    FAIL(FSIM_EINVAL, "fsim_pool_attach: dense-reward, pre-assembled and reset_robot_after_attach handles carry per-handle tables in their configuration and step on their own launches");
-  { int rc_ = settle(s); if (rc_) return rc_; }
-  HIPCHK(hipSetDevice(s->device));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  if (!p->members.empty()) {
-    fsim *m0 = p->members[0];
-    if (m0->blob.size() != s->blob.size() || memcmp(m0->blob.data(), s->blob.data(), s->blob.size()) != 0 || memcmp(&m0->cfg, &s->cfg, sizeof(fsim_config_t)) != 0 ||
-        memcmp(&m0->ly, &s->ly, sizeof(Layout)) != 0 || memcmp(&m0->ecfg, &s->ecfg, sizeof(EnvCfg)) != 0 || m0->ks.pool != s->ks.pool || m0->redo_on != s->redo_on)
-      FAIL(FSIM_EINVAL, "fsim_pool_attach: the members of a pool are handles of ONE model and ONE configuration (they may differ in their number of envs only)");
-  }
-  { int rc_ = pool_retire(p); if (rc_) return rc_; } // (the member count is a launch argument)
-  std::lock_guard<std::mutex> g(p->mu);
-  const int k = (int)p->members.size();
-  HIPCHK(hipMalloc(&s->d_dlist, (size_t)s->n_envs * 4));
-  HIPCHK(hipMemset(s->d_dlist, 0xff, (size_t)s->n_envs * 4));
-  PoolSlot sl{};
-  sl.dlist = s->d_dlist;
-  HIPCHK(hipMemcpy(&p->d_slots[k], &sl, sizeof sl, hipMemcpyHostToDevice));
-  p->h->posted[k] = 0; p->h->done[k] = 0;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(s->ks.pool), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes_x));
-  p->members.push_back(s);
-  s->pool = p; s->pool_k = k; s->pool_epoch = 0; s->pool_pending = false;
-  return FSIM_OK;
-}
-// out[0] launches of the resident kernel, [1] its workgroups, [2] team servers among them, [3] members, [4] milliseconds it has been resident (completed launches)
-extern "C" int fsim_pool_stats(fsim_pool_t *p, int64_t *out) {
-  if (!p || !out) FAIL(FSIM_EINVAL, "null");
-  out[0] = p->launches; out[1] = p->grid; out[2] = p->nteam; out[3] = (int64_t)p->members.size(); out[4] = (int64_t)(p->run_ms * 1000.0); // (microseconds)
-  return FSIM_OK;
-}
-extern "C" int fsim_pool_retire(fsim_pool_t *p) {
-  if (!p) FAIL(FSIM_EINVAL, "null");
-  for (fsim *s : p->members) { int rc_ = pool_wait(s); if (rc_) return rc_; }
-  return pool_retire(p);
-}
-// every member leaves the pool (their next steps are launches of their own again); the pool object stays valid, empty
-static void pool_dissolve(fsim_pool *p) {
-  hipSetDevice(p->device);
-  for (fsim *s : p->members) pool_wait(s);
-  pool_retire(p);
-  for (fsim *s : p->members) { s->pool = nullptr; s->pool_k = -1; hipFree(s->d_dlist); s->d_dlist = nullptr; }
-  p->members.clear();
-}
-extern "C" void fsim_pool_destroy(fsim_pool_t *p) {
-  if (!p) return;
-  pool_dissolve(p);
-  hipStreamSynchronize(p->wstream);
-  hipFree(p->d_slots); hipFree(p->d_ctl); hipHostFree(p->h);
-  hipEventDestroy(p->ev0); hipEventDestroy(p->ev1);
-  hipStreamDestroy(p->wstream);
-  delete p;
-}
 
 static int launch_env(fsim *s, const float *action, float *obs, float *reward, uint8_t *done, int32_t *info, const uint8_t *mask, int do_step) {
   HIPCHK(hipSetDevice(s->device));
@@ -1841,12 +1266,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   bool sched = do_step && s->lpt;
   if (do_step) *s->h_nreset = 0; // (host-resident counter: no launch of this handle is in flight once the caller has synchronised)
   const bool mw_rule = sched && s->mw_mode == MW_RULE, mw_all = s->mw_mode == MW_ALL;
-  // member of a shared work pool: a step is POSTED to the pool's resident kernel (which also does the scheduling); anything else the
-  // handle launches itself, with the resident kernel off the chip
-  const bool pooled = s->pool && mw_rule;
-  if (s->pool && !pooled) { int rc_ = pool_quiesce(s); if (rc_) return rc_; }
-  if (pooled && hipStreamQuery(s->stream) != hipSuccess) HIPCHK(hipStreamSynchronize(s->stream)); // (what the caller enqueued on the handle's stream comes first, as with a launch)
-  if (sched && !pooled) {
+  if (sched) {
     LaSched la{};
     if (s->la_on && s->d_tab_parts) {
       la.sh_prog = s->d_sh_prog; la.sh_serial = s->d_sh_serial; la.tab_serial = s->d_tab_serial; la.init_mask = s->d_init_mask; la.jobs = s->d_sh_jobs;
@@ -1856,7 +1276,7 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
     hipLaunchKernelGGL(k_schedule, dim3(1), dim3(64), (size_t)s->n_envs * 4, s->stream, s->d_cost, s->d_order, s->n_envs, reinterpret_cast<const int *>(s->d_state), s->ly.stride,
                        s->ly.env + E_NITER, s->mw_k, mw_rule ? 1 : 0, s->d_mworder, s->d_mwn, la);
   }
-  if (s->timing && !pooled) timing_begin(s);
+  if (s->timing) timing_begin(s);
   const KParams kp = kparams(s, s->cfg.n_substeps, 0);
   StepArgs a;
   a.cfg = s->ecfg; a.state = s->d_state; a.action = action; a.obs = obs; a.reward = reward; a.done = done; a.info = info;
@@ -1883,7 +1303,6 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
     memcpy(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg));
   }
   a.cfg_dev = s->d_ecfg;
-  if (pooled) return pool_post(s, a);
   if (mw_all)
     hipLaunchKernelGGL(s->ks.env_step_mw, dim3(s->n_envs), dim3(64 * FSIM_MW_NW), s->lds_bytes_mw, s->stream, s->d_m, s->d_ly_mw, kp, a, sched ? s->d_order : nullptr, s->d_mwn);
   else if (mw_rule) // persistent workgroups: as many as the one-wave envs need in bundles of four plus an eighth of the batch for multi-wave envs, at most what is resident at once
@@ -1908,25 +1327,32 @@ static int redo_overflowed(fsim *s) {
   int cnt = std::min(s->h_nreset[4], FSIM_OVF_CAP);
   std::vector<int> list(cnt);
   HIPCHK(hipMemcpy(list.data(), s->d_ovf_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-  std::sort(list.begin(), list.end());
-  list.erase(std::unique(list.begin(), list.end()), list.end()); // (a deferred reset is a second pass over the same env)
-  cnt = (int)list.size();
-  HIPCHK(hipMemcpy(s->d_ovf_list, list.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
-  KParams kp = kparams(s, s->cfg.n_substeps, 0);
-  kp.n_envs = cnt; // (workgroups beyond the list do nothing)
-  StepArgs a;
-  a.cfg = s->ecfg; a.state = s->d_state; a.action = s->last.action; a.obs = reinterpret_cast<float *>(s->last.obs); a.reward = s->last.reward; a.done = s->last.done; a.info = s->last.info;
-  a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = nullptr; a.do_step = s->last_do_step;
-  a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = s->last_do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
-  a.nreset = nullptr; a.stats = nullptr;
-  a.prev = nullptr; a.state_in = s->d_prev; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
-  a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
-  a.cfg_dev = s->d_ecfg;
-  hipLaunchKernelGGL(s->redo_kernel, dim3(cnt), dim3(s->redo_block), s->lds_bytes_r, s->stream, s->d_m, s->d_ly_r, kp, a, s->d_ovf_list, s->d_mwn);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) FAIL(FSIM_EHIP, "overflow re-step launch: %s", hipGetErrorString(e));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  s->n_redone += cnt;
+  int *cur = s->d_ovf_list, *nxt = s->d_ovf_list2;
+  for (int r = 0; r < s->redo_rungs && cnt > 0; r++) {
+    std::sort(list.begin(), list.end());
+    list.erase(std::unique(list.begin(), list.end()), list.end()); // (a deferred reset is a second pass over the same env)
+    cnt = (int)list.size();
+    HIPCHK(hipMemcpy(cur, list.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+    KParams kp = kparams(s, s->cfg.n_substeps, 0);
+    kp.n_envs = cnt; // (workgroups beyond the list do nothing)
+    StepArgs a;
+    a.cfg = s->ecfg; a.state = s->d_state; a.action = s->last.action; a.obs = reinterpret_cast<float *>(s->last.obs); a.reward = s->last.reward; a.done = s->last.done; a.info = s->last.info;
+    a.tab_parts = s->d_tab_parts; a.tab_noise = s->d_tab_noise; a.tab_attach = s->d_tab_attach; a.n_noise = s->n_noise; a.reset_mask = nullptr; a.do_step = s->last_do_step;
+    a.prof = reinterpret_cast<int *>(s->d_aux); a.cost = s->last_do_step ? s->d_cost : nullptr; a.init_state = s->d_init; a.init_mask = s->d_init_mask;
+    a.nreset = nullptr; a.stats = nullptr;
+    a.prev = nullptr; a.state_in = s->d_prev; a.ovf_list = nullptr; a.ovf_count = nullptr; a.ovf_cap = 0;
+    const bool more = r + 1 < s->redo_rungs; // the envs that drop contacts on this rung's layout too are listed for the next one
+    if (more) { a.ovf_list = nxt; a.ovf_count = s->d_nreset + 5; a.ovf_cap = FSIM_OVF_CAP; s->h_nreset[5] = 0; }
+    a.sh_state = nullptr; a.sh_obs = nullptr; a.sh_prog = nullptr; a.sh_serial = nullptr; a.tab_serial = nullptr; a.sh_jobs = nullptr; a.la_chunk = s->la_chunk;
+    a.cfg_dev = s->d_ecfg;
+    hipLaunchKernelGGL(s->redo_kernel[r], dim3(cnt), dim3(s->redo_block[r]), s->lds_bytes_r[r], s->stream, s->d_m, s->d_ly_r[r], kp, a, cur, s->d_mwn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(FSIM_EHIP, "overflow re-step launch: %s", hipGetErrorString(e));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->n_redone += cnt;
+    cnt = more ? std::min(s->h_nreset[5], FSIM_OVF_CAP) : 0;
+    if (cnt > 0) { list.resize(cnt); HIPCHK(hipMemcpy(list.data(), nxt, (size_t)cnt * 4, hipMemcpyDeviceToHost)); std::swap(cur, nxt); }
+  }
   return FSIM_OK;
 }
 // ---- dense-reward env
@@ -2070,7 +1496,6 @@ extern "C" int fsim_replay_try_connect(fsim_t *s, int n, int num_connect_steps, 
                                        const uint8_t *aligned, const int32_t *step_in, int32_t *out) {
   if (!s || n < 1 || !part12 || !group || !used || !aligned || !step_in || !out) FAIL(FSIM_EINVAL, "fsim_replay_try_connect: bad args");
   HIPCHK(hipSetDevice(s->device));
-  { int rc_ = pool_quiesce(s); if (rc_) return rc_; }
   const int np = s->m.nparts, nc = s->m.nconn;
   int *d = nullptr; unsigned char *da = nullptr;
   HIPCHK(hipMalloc(&d, (size_t)n * (2 + np + nc + 1 + 5) * 4)); HIPCHK(hipMalloc(&da, (size_t)n * nc * nc + 4));
@@ -2120,7 +1545,6 @@ extern "C" int fsim_replay_touch_scan(fsim_t *s, int n, int maxc, const int32_t 
                                       int32_t *out_tried) {
   if (!s || n < 1 || maxc < 1 || !ncon || !geoms || !script || !out_masks || !out_tried) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: bad args");
   HIPCHK(hipSetDevice(s->device));
-  { int rc_ = pool_quiesce(s); if (rc_) return rc_; }
   for (int t = 0; t < n; t++) {
     if (ncon[t] < 0 || ncon[t] > maxc) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: ncon[%d] out of range", t);
     for (int k = 0; k < 2 * ncon[t]; k++) if (geoms[(size_t)t * maxc * 2 + k] < 0 || geoms[(size_t)t * maxc * 2 + k] >= s->m.ncg) FAIL(FSIM_EINVAL, "fsim_replay_touch_scan: geom index out of range (colliding-geom indices expected)");
@@ -2192,11 +1616,13 @@ extern "C" int fsim_set_max_episode_steps(fsim_t *s, int n) {
   if (s->la_on) la_policy(s);
   return FSIM_OK;
 }
-// Device -> host copy of caller memory on the handle's transfer stream (pinned destination: a DMA transfer, no kernel, no allocation --
-// usable while the work pool's kernel is resident, where torch's .cpu() may wait for an allocation).  Complete on return.
+// Device -> host copy of caller memory on the handle's transfer stream (pinned destination: a DMA transfer, no kernel, no allocation).
+// Complete on return.  The handle's in-flight step is waited for first (its overflow re-step included): the rows read are final.
 extern "C" int fsim_read(fsim_t *s, void *host_dst, const void *dev_src, size_t nbytes) {
   if (!s || !host_dst || !dev_src) FAIL(FSIM_EINVAL, "null");
   HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  { int rc_ = settle(s); if (rc_) return rc_; }
   if (!s->xfer) HIPCHK(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
   HIPCHK(hipMemcpyAsync(host_dst, dev_src, nbytes, hipMemcpyDeviceToHost, s->xfer));
   HIPCHK(hipStreamSynchronize(s->xfer));

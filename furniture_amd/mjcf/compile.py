@@ -403,6 +403,14 @@ def compile_mjcf(root, mesh_root=None):
         if G["type"][g] != GEOM_MESH or not (G["contype"][g] or G["conaffinity"][g]):
             continue
         hull = mesh_of(G["mesh"][g])[0]
+        # the portal routine takes the geom ORIGIN as the interior point of the hull (csrc/fsim_collide.hpp np_mpr; MuJoCo re-centres a
+        # mesh on its centre of mass, here the vertices stay where the file puts them): the origin must lie strictly inside
+        from scipy.spatial import ConvexHull
+        eq = ConvexHull(hull).equations  # rows [n, d]: n . x + d <= 0 inside
+        if not (eq[:, 3] < -1e-6).all():
+            raise NotImplementedError("mesh %s: the geom origin is not strictly inside the convex hull (needs re-centring)" % G["mesh"][g])
+        if len(hull) > 32767:
+            raise NotImplementedError("mesh %s: more than 32767 hull vertices" % G["mesh"][g])
         mesh_adr[g], mesh_num[g] = sum(len(v) for v in mesh_vert), len(hull)
         mesh_vert.append(hull)
         G["rbound"][g] = float(np.linalg.norm(hull, axis=1).max())

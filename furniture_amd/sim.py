@@ -144,12 +144,6 @@ def lib():
         L.fsim_kernel_variant.restype = ctypes.c_char_p
         L.fsim_step_kernel.argtypes = [ctypes.c_void_p]
         L.fsim_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-        L.fsim_pool_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
-        L.fsim_pool_attach.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        L.fsim_pool_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
-        L.fsim_pool_destroy.argtypes = [ctypes.c_void_p]
-        L.fsim_pool_retire.argtypes = [ctypes.c_void_p]
-        L.fsim_pool_destroy.restype = None
         L.fsim_step_kernel.restype = ctypes.c_char_p
         L.fsim_lookahead_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.fsim_overflow_resteps.argtypes = [ctypes.c_void_p]
@@ -176,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "fsim_env_block_words", "fsim_set_max_episode_steps", "fsim_kernel_variant",
     "fsim_step_kernel", "fsim_lookahead_stats", "fsim_overflow_resteps",
     "fsim_replay_is_aligned", "fsim_replay_try_connect", "fsim_replay_touch_scan", "fsim_set_init_state", "fsim_tables_needed", "fsim_set_preassembled", "fsim_set_attach_noise",
-    "fsim_read", "fsim_pool_create", "fsim_pool_attach", "fsim_pool_stats", "fsim_pool_retire", "fsim_pool_destroy",
+    "fsim_read",
 ]
 
 
@@ -237,52 +231,6 @@ def replay_is_aligned(p1, R1, p2, R2, nang, angles, pos_dist=0.1, rot_up=0.9, ro
     if rc != 0:
         raise FsimError("fsim_replay_is_aligned rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
     return ok.astype(bool), tq
-
-
-class FSimPool:
-    """Shared work pool (include/fsim.h, fsim_pool_*): handles of ONE model and configuration -- the slabs a learner steps asynchronously
-    -- post their steps to one resident kernel instead of launching a scheduler + step kernel each.  Bit-identical results; what changes
-    is when an env starts.  Close the pool before (or together with) its members."""
-
-    def __init__(self, device=0):
-        h = ctypes.c_void_p()
-        rc = lib().fsim_pool_create(int(device), ctypes.byref(h))
-        if rc:
-            raise FsimError("fsim_pool_create rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
-        self._h = h
-        self.members = []
-
-    def attach(self, sim):
-        rc = lib().fsim_pool_attach(self._h, sim._h)
-        if rc:
-            raise FsimError("fsim_pool_attach rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
-        self.members.append(sim)
-        return sim
-
-    def stats(self):
-        out = (ctypes.c_int64 * 8)()
-        rc = lib().fsim_pool_stats(self._h, out)
-        if rc:
-            raise FsimError("fsim_pool_stats rc=%d" % rc)
-        return dict(launches=int(out[0]), workgroups=int(out[1]), team_workgroups=int(out[2]), members=int(out[3]), resident_ms=out[4] / 1000.0)
-
-    def retire(self):
-        """Wait for every member's posted step and take the resident kernel off the chip (the next post restarts it)."""
-        rc = lib().fsim_pool_retire(self._h)
-        if rc:
-            raise FsimError("fsim_pool_retire rc=%d: %s" % (rc, lib().fsim_last_error().decode()))
-
-    def close(self):
-        if self._h:
-            lib().fsim_pool_destroy(self._h)
-            self._h = None
-            self.members = []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 class FSim:

@@ -172,8 +172,8 @@ int fsim_step(fsim_t *, const float *action_dev, void *obs_dev /* float32, or bf
               int32_t *info_dev);
 
 /* Device -> host copy of a caller buffer (e.g. the info block of the last step) on the handle's transfer stream; complete on return.
- * With a pinned destination this is a plain DMA transfer: no kernel, no allocation -- which matters while a work pool's kernel is
- * resident (hipMalloc / hipFree, also the ones behind a framework's allocator, wait for it to leave). */
+ * With a pinned destination this is a plain DMA transfer: no kernel, no allocation.  The handle's in-flight step is waited for first
+ * (as by fsim_sync, overflow re-step included), so the rows read are the step's final ones. */
 int fsim_read(fsim_t *, void *host_dst, const void *dev_src, size_t nbytes);
 
 /* Number of envs whose FSIM_INFO_NEEDS_TABLE is set by the last fsim_step, valid once that step has completed (fsim_sync): lets the
@@ -197,32 +197,9 @@ int fsim_lookahead_stats(fsim_t *, int64_t *out);
  * launch of the handle -- the re-step reads and writes them again; every setter of the handle waits for it first. */
 int64_t fsim_overflow_resteps(const fsim_t *);
 
-/* Shared work pool (round 5; reference counterpart: the worker processes of furniture/env/base.py:55-80 and
- * furniture/util/subproc_vec_env.py:100-121, which step their envs independently of one another).  A learner that splits its batch
- * into several handles (slabs) and steps them asynchronously -- bench.py -- attaches them to ONE pool: their fsim_step calls then
- * launch nothing; each POSTS its step (argument block + epoch number in host-mapped memory) to a kernel that stays resident while steps
- * keep coming, whose waves take the next env of ANY posted step, longest predicted job first, and whose dispatcher waves do what the
- * per-step scheduler kernel does.  A slab's step lasts as long as its slowest env; smaller slabs have a less extreme slowest env, and
- * without a launch pair per slab-step (scheduler kernel waiting for a wave slot, the new launch's workgroups waiting for the other
- * slabs' persistent ones) sixteen slabs of 256 envs cost no more to drive than four of 1024.  Results are bit-identical to the
- * unpooled handle (same multi-wave rule on the env's own record, same kernels' device code); what changes is when an env starts.
- *   - members: handles of ONE model blob and ONE configuration on the pool's device, multi_wave = rule (or auto resolving to it),
- *     <= 4096 envs each, no dense-reward / pre-assembled / reset_robot_after_attach tables; at most 32 per pool.
- *   - a member's fsim_step returns once the step is posted; fsim_sync (and anything that needs the step's results) waits for ITS
- *     completion word only.  fsim_step first waits for whatever the caller enqueued on the handle's stream (an action copy), as a
- *     launch on that stream would; work enqueued on the stream AFTER fsim_step is NOT ordered behind the step -- fsim_sync first.
- *   - anything else a member does on the device (fsim_reset, fsim_get_state ...) makes the resident kernel finish what is in flight
- *     and leave first; it also leaves on its own when nothing has been posted for 20 ms, and the next post brings it back.
- *   - one member is stepped by one host thread at a time; different members may be stepped from different threads.
- *   - destroying a member (or the pool) dissolves the pool: the other members step on launches of their own again.
- * fsim_pool_stats: out[5] = { launches of the resident kernel, its workgroups, team-server workgroups among them, members,
- * microseconds it was resident over its completed launches (HIP events on its stream) }. */
-typedef struct fsim_pool fsim_pool_t;
-int fsim_pool_create(int device, fsim_pool_t **out);
-int fsim_pool_attach(fsim_pool_t *, fsim_t *);
-int fsim_pool_stats(fsim_pool_t *, int64_t *out);
-int fsim_pool_retire(fsim_pool_t *); /* wait for every member's posted step, then make the resident kernel leave (the next post restarts it) */
-void fsim_pool_destroy(fsim_pool_t *);
+/* (Round 5's shared work pool -- fsim_pool_*: a resident kernel that several handles posted their steps to -- measured 20 % slower
+ * than a launch per slab-step (663 / 634 k against 828 k env-steps/s, profiles/r05_b_bench_pool_*) and left the library in round 6;
+ * the code is in the history at commit 71a76b7.) */
 
 /* FurnitureEnv.set_max_episode_steps (furniture.py:312-313, forwarded by FurnitureGym :46-48): takes effect from the next step. */
 int fsim_set_max_episode_steps(fsim_t *, int max_episode_steps);

@@ -720,8 +720,3 @@ int fsim_replay_touch_scan(fsim_t *s, int n, int maxc, const int32_t *ncon, cons
   (void)s; (void)n; (void)maxc; (void)ncon; (void)geoms; (void)script; (void)out_masks; (void)out_tried;
   NOT_SERVED("fsim_replay_touch_scan");
 }
-int fsim_pool_create(int device, fsim_pool_t **out) { (void)device; (void)out; NOT_SERVED("the work pool (a device scheduling construct)"); }
-int fsim_pool_attach(fsim_pool_t *p, fsim_t *s) { (void)p; (void)s; NOT_SERVED("the work pool"); }
-int fsim_pool_stats(fsim_pool_t *p, int64_t *out) { (void)p; (void)out; NOT_SERVED("the work pool"); }
-int fsim_pool_retire(fsim_pool_t *p) { (void)p; NOT_SERVED("the work pool"); }
-void fsim_pool_destroy(fsim_pool_t *p) { (void)p; }

@@ -4,6 +4,7 @@ Run in the build container (needs /root/reference or FURNITURE_ASSETS_ROOT); the
 reference tree, so the hot path loads these .npz files.  Usage:
     python scripts/compile_assets.py            # the BASELINE configs + stress models
     python scripts/compile_assets.py --all      # every furniture id for Sawyer
+    python scripts/compile_assets.py --all --agents Sawyer,Baxter,Cursor   # ... for every agent (furniture/tests/test_furniture_init.py:14-55 is Baxter x 64)
 """
 import argparse
 import os
@@ -26,6 +27,7 @@ DEFAULT = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--all", action="store_true")
+    ap.add_argument("--agents", default="Sawyer", help="comma-separated agents that --all compiles every furniture for")
     args = ap.parse_args()
     root = assemble.default_assets_root()
     if root is None:
@@ -33,7 +35,8 @@ def main():
     todo = list(DEFAULT)
     if args.all:
         _, names, _ = assemble.furniture_table(root)
-        todo += [("Sawyer", n) for n in names if ("Sawyer", n) not in todo]
+        for agent in args.agents.split(","):
+            todo += [(agent, n) for n in names if (agent, n) not in todo]
     out = model._COMPILED_DIR
     os.makedirs(out, exist_ok=True)
     for item in todo:

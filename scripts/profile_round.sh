@@ -12,11 +12,6 @@ DB=$(find $O/kt -name "*.db" | head -1)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt1 -o kt1 -- $BENCH --groups 1 > $O/kt1.log 2>&1
 DB=$(find $O/kt1 -name "*.db" | head -1)
 [ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_single_stream.txt "bench.py --steps 30 --warmup 5 --groups 1 (one 4096-env launch per step)" | tail -4
-# (round 5) the same workload through the shared work pool: one resident k_pool launch instead of a k_schedule + k_env_step_x pair per slab-step
-echo "rocprofv3 --kernel-trace --stats -- $BENCH --groups 8 --pool 1 --threads 1" >> $O/commands.txt
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktp -o ktp -- $BENCH --groups 8 --pool 1 --threads 1 > $O/ktp.log 2>&1
-DB=$(find $O/ktp -name "*.db" | head -1)
-[ -n "$DB" ] && python $R/scripts/rocprof_summary.py $DB $O/kt_work_pool_8_slabs.txt "bench.py --steps 30 --warmup 5 --groups 8 --pool 1 --threads 1 (eight slabs of 512 envs posting to one resident kernel)" | tail -4
 PB="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --episode-window 0"
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -25,5 +20,5 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCL
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc$i -o pmc -- $PB > $O/pmc$i.log 2>&1
 done
 python $R/scripts/pmc_summary.py $O $O/pmc_sq_counters.txt $O/pmc.json
-rm -rf $O/kt $O/kt1 $O/ktp $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4
+rm -rf $O/kt $O/kt1 $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4
 ls $O
