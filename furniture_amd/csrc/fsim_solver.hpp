@@ -1283,7 +1283,7 @@ template <class Ctx> FSIM_OUTLINE int fs_newton_mfma(Ctx cv, unsigned lds_addr_,
 // Returns the kinematic trees of those islands (bit mask).
 template <class Ctx> DEV int fs_asm_trees(const Ctx &c, const SolSlot &S) {
 #ifndef FSIM_MFMA_HESSIAN
-  // (opt-in build: round-4 measurement, DESIGN.md 12.3 -- the eligible slow envs get ~10 % faster, the 4096-env step 4-8 % slower)
+  // (opt-in build: round-4 measurement, DESIGN_HISTORY.md 12 item 1 -- the eligible slow envs get ~10 % faster, the 4096-env step 4-8 % slower)
   return 0;
 #elif FSIM_MFMA_HESSIAN == 2
   if (Ctx::NW == 1) return 0;

@@ -10,7 +10,7 @@ observation slab is padded: rows are ``max_obs_dim`` wide, ``object_ob`` padded 
 the RCCL all-gather to the learner moves (``furniture_amd/dist.py``).
 
 With four or more furniture models set ``GPU_MAX_HW_QUEUES`` >= 2 x models in the environment BEFORE the first HIP call: with the
-runtime's default of 4 hardware queues four handles' step kernels ran two at a time (measured); three models
+runtime's default of 4 hardware queues four handles' step kernels ran two at a time (measured, DESIGN_HISTORY.md section 6); three models
 overlap fine with the default.
 """
 

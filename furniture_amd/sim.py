@@ -78,7 +78,7 @@ def build(force=False, verbose=False):
     #  independent chains rather than to minimise register pressure; +1.5 % on the benchmark, same register / scratch budget.
     #  -fno-optimize-sibling-calls: ONE tail call of an out-of-line device function is enough for the compiler to give up treating
     #  that function as "all callers known" -- it then saves its 113 callee-saved VGPRs to scratch on every call, 29 KB per wave.
-    #  Without tail calls every local function drops its callee-saved area: 55 -> 33 KB of HBM traffic per env-step)
+    #  Without tail calls every local function drops its callee-saved area: 55 -> 33 KB of HBM traffic per env-step, DESIGN_HISTORY.md 6c)
     cmd = hipcc_command(_LIBPATH)
     if verbose:
         print(" ".join(cmd))
