@@ -126,7 +126,7 @@ class Session:
                 "xfrc_applied": ((n, m.nparts * 6), np.float32), "eq_data": ((n, m.neq * 7), np.float32), "eq_active": ((n, m.neq), np.int32),
                 "geom_contype": ((n, m.ngeom), np.int32), "geom_conaffinity": ((n, m.ngeom), np.int32), "group": ((n, m.nparts), np.int32),
                 "xpos": ((n, m.nbody * 3), np.float32), "xquat": ((n, m.nbody * 4), np.float32), "ncon": ((n,), np.int32),
-                "contact_geoms": ((n, self.max_contacts * 2), np.int32)}[name]
+                "contact_geoms": ((n, self.max_contacts * 2), np.int32), "cursor": ((n, 8), np.float32)}[name]
 
     def get_state(self, m, *names):
         a, sp, bufs = self.abi, StatePtrs(), {}
