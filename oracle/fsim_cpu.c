@@ -10,8 +10,9 @@
  * that Python restatement on the same inputs.
  *
  * Scope: the arm agents (Sawyer, Baxter) under control_type impedance and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
- * reward, both auto_reset modes.  Dense reward, ik / arm controllers, pre-assembled starts, init states and reset_robot_after_attach are
- * refused at fsim_create (FSIM_EINVAL): the Python oracle env remains their checker.
+ * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
+ * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes.  ik / arm controllers, pre-assembled starts, init
+ * states, phase_ob and reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
  * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
@@ -69,6 +70,12 @@ typedef struct {
   real cb1_pos[3], cb1_quat[4], target_quat[4]; /* _connected_body1_pos / quat, _target_connector_xquat (wxyz) */
   real episode_reward;
   int episode_length, success, fail;
+  /* dense reward (furniture_sawyer_dense.py:128-216): subtask, phase, flags, the anchors and the previous distances of the difference rewards */
+  struct {
+    int subtask, phase, leg_dropped, table_moved, leg_lift, fine_aligned;
+    real init_table_site[3], init_lift_leg[3], lift_leg[3], init_eef[3];
+    real prev_init_eef, prev_above, prev_eef_leg, prev_grasp, prev_lift_z, prev_lift_xy, prev_move_pos, prev_up, prev_fwd, prev_proj_t, prev_proj_l;
+  } dn;
   /* Cursor agent */
   real *body_pos;              /* model.body_pos (mutable: the cursor bodies, furniture.py:3139) */
   int cursor_sel[2];           /* _cursor_selected: part index or -1 */
@@ -84,6 +91,8 @@ struct fsim {
   Env *env;
   float *tab_parts, *tab_noise; /* [n][nparts*7], [n][n_noise][narmj] */
   int n_noise, n_substeps, dof, obs_dim, tables_needed;
+  float *dcoef, *dsub; /* fsim_set_dense_reward: the coefficient table and [dnsub][FSIM_DENSE_SUBW] subtask rows (furniture_amd/dense.py pack_dense) */
+  int dnsub;
   real perturb;      /* FSIM_CPU_PERTURB (read at fsim_create): added to every arm-joint angle and part position at the end of each reset -- the
                         `perturbed twin` of scripts/divergence_control.py; 0 in every test */
   real *conv[16];    /* float64 blob entries converted to `real` (fp32 control build only) */
@@ -229,6 +238,7 @@ static void next_subtask(const struct fsim *s, Env *e) {
   e->subtask1 = e->subtask2 = -1;
 }
 
+static void dense_reset(const struct fsim *s, Env *e);
 static void env_reset(const struct fsim *s, int idx) {
   const EnvModel *m = &s->m;
   Env *e = &s->env[idx];
@@ -265,6 +275,7 @@ static void env_reset(const struct fsim *s, int idx) {
   for (int k = 0; k < 100; k++) fs(e);
   next_subtask(s, e);
   e->episode_reward = 0; e->episode_length = 0; e->success = 0; e->fail = 0;
+  if (s->cfg.dense_reward) dense_reset(s, e); /* _reset_reward_variables (furniture_sawyer_dense.py:218-220) */
   if (s->perturb != 0) { /* the perturbed twin: same reset, state moved by `perturb` (the poses of this reset's observation are the unperturbed ones) */
     for (int k = 0; k < m->narmj; k++) e->qpos[m->arm_qposadr[k]] += s->perturb;
     for (int i = 0; i < m->nparts; i++) for (int k = 0; k < 3; k++) e->qpos[m->part_qposadr[i] + k] += s->perturb;
@@ -560,6 +571,189 @@ static void touch_sets(const struct fsim *s, Env *e, int arm, unsigned *L, unsig
   }
 }
 
+
+/* ---- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577), restated from oracle/dense_reward.py (which
+ * tests/golden/dense_reward.npz pins to the reference's own _compute_reward / _update_reward_variables).  Tables: fsim_set_dense_reward, in the
+ * order of furniture_amd/dense.py (DENSE_COEF_DEFAULTS, DS_*).  diff_rew = True (the reference's dense config; it is not in the table). */
+enum { DC_PHASE_BONUS = 0, DC_EEF_FWD, DC_EEF_UP, DC_EEF_ROT_THR, DC_GRIPPER_PEN, DC_MOVE_OTHER, DC_DROP_PEN, DC_EARLY_TERM, DC_INIT_EEF, DC_MOVE_EEF, DC_LOWER_EEF,
+       DC_GRASP, DC_LIFT_Z, DC_LIFT_XY, DC_LIFT_Z_THR, DC_LIFT_XY_THR, DC_ALIGN_POS, DC_ALIGN_ROT, DC_ALIGN_POS_THR, DC_ALIGN_ROT_THR, DC_MOVE_POS, DC_MOVE_ROT,
+       DC_MOVE_POS_THR, DC_MOVE_ROT_THR, DC_FINE_EXP, DC_FINE_POS, DC_FINE_ROT, DC_ALIGNED_BONUS, DC_CTRL_PEN, DC_RESET_ROBOT, DC_Z_FINEDIST, DC_GRIPTIP_SITE,
+       DC_GRIP_SITE, DC_PHASE_OB, DC_WORDS };
+enum { DS_LEG_PART = 0, DS_TABLE_PART, DS_LEG_SITE, DS_TABLE_SITE, DS_GL_SITE, DS_GR_SITE, DS_ANGLE, DS_HAS_ANGLES, DS_WAYPOINT_Z, DS_GRIP_INIT_N, DS_GRIP_INIT0,
+       DS_K_LEG = 14, DS_K_TABLE, DS_WORDS };
+typedef struct { real eef[3], gl[3], gr[3], leg[3], legsite[3], tablesite[3], legup[3], tableup[3], legfwd[3], tablefwd[3], gripup[3], gripfwd[3]; int touch_l, touch_r; } DObs;
+static void touch_sets(const struct fsim *s, Env *e, int arm, unsigned *L, unsigned *R, unsigned *F);
+static int is_aligned(const struct fsim *s, Env *e, int k1, int k2);
+static real dist3(const real *a, const real *b) { real d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; return norm3(d); }
+static void dense_obs(const struct fsim *s, Env *e, int st, DObs *o) { /* FurnitureEnvOracle._dense_obs */
+  const EnvModel *m = &s->m;
+  const float *T = s->dsub + DS_WORDS * st;
+  const int griptip = (int)s->dcoef[DC_GRIPTIP_SITE], grip = (int)s->dcoef[DC_GRIP_SITE], ls = (int)T[DS_LEG_SITE], ts = (int)T[DS_TABLE_SITE], leg = (int)T[DS_LEG_PART];
+  memcpy(o->eef, e->site_xpos + 3 * griptip, 3 * sizeof(real));
+  memcpy(o->gl, e->site_xpos + 3 * (int)T[DS_GL_SITE], 3 * sizeof(real)); memcpy(o->gr, e->site_xpos + 3 * (int)T[DS_GR_SITE], 3 * sizeof(real));
+  memcpy(o->leg, e->xpos + 3 * m->part_bodyid[leg], 3 * sizeof(real));
+  memcpy(o->legsite, e->site_xpos + 3 * ls, 3 * sizeof(real)); memcpy(o->tablesite, e->site_xpos + 3 * ts, 3 * sizeof(real));
+  site_axes(e, ls, o->legup, o->legfwd); site_axes(e, ts, o->tableup, o->tablefwd); site_axes(e, grip, o->gripup, o->gripfwd);
+  unsigned L, R, F;
+  touch_sets(s, e, 0, &L, &R, &F);
+  o->touch_l = (L >> leg) & 1; o->touch_r = (R >> leg) & 1;
+}
+static void dense_update(const struct fsim *s, Env *e) { /* _update_reward_variables (:149-216) */
+  const float *C = s->dcoef, *T = s->dsub + DS_WORDS * e->dn.subtask;
+  DObs o;
+  dense_obs(s, e, e->dn.subtask, &o);
+  e->dn.leg_dropped = e->dn.table_moved = e->dn.leg_lift = 0; e->dn.fine_aligned = 0;
+  for (int k = 0; k < 3; k++) { e->dn.init_table_site[k] = o.tablesite[k]; e->dn.init_lift_leg[k] = o.leg[k]; e->dn.lift_leg[k] = o.leg[k]; }
+  e->dn.lift_leg[2] += (real)T[DS_WAYPOINT_Z];
+  e->dn.phase = C[DC_RESET_ROBOT] != 0.0f ? 1 : 0;
+  const int ngi = (int)T[DS_GRIP_INIT_N];
+  if (ngi > 0) {
+    for (int k = 0; k < 3; k++) e->dn.init_eef[k] = o.eef[k] + (real)T[DS_GRIP_INIT0 + k];
+    if (ngi == 4) e->dn.init_eef[2] = (real)T[DS_GRIP_INIT0 + 3] - 0.085;
+  } else e->dn.phase = 1;
+  if (e->dn.phase == 1) { real g[3]; for (int k = 0; k < 3; k++) g[k] = 0.5 * (o.gl[k] + o.gr[k]); g[2] += 0.05; e->dn.prev_above = dist3(o.eef, g); }
+  else e->dn.prev_init_eef = dist3(o.eef, e->dn.init_eef);
+  e->dn.prev_grasp = -1; e->dn.prev_lift_z = (real)T[DS_WAYPOINT_Z]; e->dn.prev_lift_xy = 0;
+}
+static void dense_reset(const struct fsim *s, Env *e) { memset(&e->dn, 0, sizeof e->dn); e->dn.subtask = 0 /* n_pre */; dense_update(s, e); }
+static int dense_next_subtask(const struct fsim *s, Env *e) { e->dn.subtask += 1; if (e->dn.subtask == e->success_num_conn) return 1; dense_update(s, e); return 0; }
+static real rmin(real a, real b) { return a < b ? a : b; }
+static real rmax(real a, real b) { return a > b ? a : b; }
+/* _compute_reward (:273-577): -> reward; *done, *success, *phase_bonus, *phase_info (phase_i + 8 * subtask, taken where the reference fills info["phase_i"]) */
+static real dense_compute(const struct fsim *s, Env *e, const float *ac, int dof, int connected, int *done, int *success, real *phase_bonus_out, int *phase_info) {
+  const float *C = s->dcoef, *T = s->dsub + DS_WORDS * e->dn.subtask;
+  const int st_now = e->dn.subtask, k_leg = (int)T[DS_K_LEG], k_table = (int)T[DS_K_TABLE];
+  const int early = C[DC_EARLY_TERM] != 0.0f;
+  const real bonus = C[DC_PHASE_BONUS];
+  DObs o;
+  dense_obs(s, e, st_now, &o);
+  real phase_bonus = 0, reward = 0, phase_reward = 0;
+  *done = 0; *success = 0;
+  /* _collect_values */
+  const int leg_touched = o.touch_l && o.touch_r;
+  real fr[3];
+  if (T[DS_HAS_ANGLES] != 0.0f) { /* project_forward (furniture.py:1178-1199) */
+    if (T[DS_ANGLE] != T[DS_ANGLE]) { /* None */
+      real cs = cos_siml(o.legfwd, o.tablefwd), rp[3], rn[3];
+      rotate_vector_cos(rp, o.legfwd, o.legup, cs, 1); rotate_vector_cos(rn, o.legfwd, o.legup, cs, -1);
+      memcpy(fr, cos_siml(rp, o.tablefwd) > cos_siml(rn, o.tablefwd) ? rp : rn, 3 * sizeof(real));
+    } else rotate_vector(fr, o.legfwd, o.legup, (real)T[DS_ANGLE]);
+  } else memcpy(fr, o.legfwd, 3 * sizeof(real));
+  real above[3] = {o.tablesite[0], o.tablesite[1], o.tablesite[2] + (real)C[DC_Z_FINEDIST]}, grasp[3];
+  for (int k = 0; k < 3; k++) grasp[k] = (o.gl[k] + o.gr[k]) / 2;
+  const int safe_grasp = leg_touched && (o.eef[2] < grasp[2] - 0.000);
+  const real move_pos_dist = dist3(o.tablesite, o.legsite), move_above = dist3(above, o.legsite), up_ang = cos_siml(o.legup, o.tableup), fwd_ang = cos_siml(fr, o.tablefwd);
+  real ntu[3] = {-o.tableup[0], -o.tableup[1], -o.tableup[2]}, dlt[3], dtl[3];
+  for (int k = 0; k < 3; k++) { dlt[k] = o.legsite[k] - o.tablesite[k]; dtl[k] = o.tablesite[k] - o.legsite[k]; }
+  const real proj_t = cos_siml(ntu, dlt), proj_l = cos_siml(o.legup, dtl), table_disp = dist3(o.tablesite, e->dn.init_table_site);
+  real s2 = 0; for (int k = 0; k < dof - 2; k++) s2 += (real)ac[k] * (real)ac[k];
+  const real ctrl_pen = sqrt(s2) * -(real)C[DC_CTRL_PEN];
+  /* _stable_grip_rew: the two cosines */
+  real down[3] = {0, 0, -1}, gv[3], nf[3];
+  const real up_d = cos_siml(o.gripup, down);
+  for (int k = 0; k < 3; k++) { gv[k] = o.gr[k] - o.gl[k]; nf[k] = -o.gripfwd[k]; }
+  const real fd = rmax(cos_siml(o.gripfwd, gv), cos_siml(nf, gv));
+#define SG_SUCC(ph) ((!((ph) <= 4) || up_d > (real)C[DC_EEF_ROT_THR]) && (!((ph) >= 1 && (ph) <= 4) || fd > (real)C[DC_EEF_ROT_THR]))
+  const real move_pen = -(real)C[DC_MOVE_OTHER] * table_disp;
+  const int table_moved = table_disp > 0.1;
+  if (C[DC_PHASE_OB] == 0.0f) { /* phase skips */
+    if (safe_grasp && SG_SUCC(e->dn.phase) && e->dn.phase < 3) e->dn.phase = 4;
+    if (leg_touched && (e->dn.phase == 4 || e->dn.phase == 5))
+      if ((move_pos_dist < C[DC_MOVE_POS_THR] || move_above < C[DC_MOVE_POS_THR]) && up_ang > C[DC_MOVE_ROT_THR] && fwd_ang > C[DC_MOVE_ROT_THR]) {
+        e->dn.phase = 7; e->dn.prev_move_pos = move_pos_dist; e->dn.prev_up = up_ang; e->dn.prev_fwd = fwd_ang; e->dn.prev_proj_t = proj_t; e->dn.prev_proj_l = proj_l;
+      }
+  }
+  const int ph = e->dn.phase;
+  *phase_info = ph + 8 * e->dn.subtask;
+  real sg_rew = 0;
+  if (ph <= 4) sg_rew += (real)C[DC_EEF_UP] * (up_d - 1);
+  if (ph >= 1 && ph <= 4) sg_rew += (fabs(fd) - 1) * (real)C[DC_EEF_FWD];
+  const int sg_succ = SG_SUCC(ph);
+  const real ga = ac[dof - 2];
+  const int open_phase = ph <= 2, grip_succ = open_phase ? ga < 0 : ga > 0;
+  const real grip_pen = (open_phase ? -ga : ga) * (real)C[DC_GRIPPER_PEN];
+#define DROP_OR_MOVED(half) do { if (!leg_touched) e->dn.leg_dropped = 1; else e->dn.table_moved = 1; *done = early; if (early) phase_bonus -= (half) ? bonus / 2 : bonus; } while (0)
+#define LOWER(rew_, succ_) do { real lg[3] = {grasp[0], grasp[1], grasp[2] - 0.015}, dxy[2] = {o.eef[0] - lg[0], o.eef[1] - lg[1]};                   \
+    const real xy_ = sqrt(dxy[0] * dxy[0] + dxy[1] * dxy[1]), z_ = fabs(o.eef[2] - lg[2]), d_ = dist3(o.eef, lg);                               \
+    (rew_) = (rmin(e->dn.prev_eef_leg, 0.2) - rmin(d_, 0.2)) * (real)C[DC_LOWER_EEF] * 10; e->dn.prev_eef_leg = d_; (succ_) = xy_ < 0.02 && z_ < 0.015; } while (0)
+  if (ph != 7 && connected) {
+    const int correct = is_aligned(s, e, k_leg, k_table);
+    if (table_moved) { e->dn.table_moved = 1; *done = early; if (early) phase_bonus -= bonus; }
+    else if (correct) { phase_bonus += bonus * 2; phase_bonus -= e->dn.fine_aligned * (real)C[DC_ALIGNED_BONUS]; e->dn.phase = 0; *done = *success = dense_next_subtask(s, e); }
+    else { *success = 0; *done = 1; }
+  } else if (ph == 0) {
+    const real d = dist3(o.eef, e->dn.init_eef);
+    phase_reward = (exp(-10 * rmin(d, 0.5)) - exp(-10 * rmin(e->dn.prev_init_eef, 0.5))) * (real)C[DC_INIT_EEF] * 10; e->dn.prev_init_eef = d;
+    if (d < 0.03 && sg_succ && grip_succ) { e->dn.phase += 1; phase_bonus += bonus; real g[3] = {grasp[0], grasp[1], grasp[2] + 0.05}; e->dn.prev_above = dist3(o.eef, g); }
+  } else if (ph == 1) {
+    real g[3] = {grasp[0], grasp[1], grasp[2] + 0.05};
+    const real d = dist3(o.eef, g);
+    phase_reward = (rmin(e->dn.prev_above, 1.0) - rmin(d, 1.0)) * (real)C[DC_MOVE_EEF] * 10; e->dn.prev_above = d;
+    if (d < 0.03 && sg_succ && grip_succ) { e->dn.phase += 1; phase_bonus += bonus; real g2[3] = {grasp[0], grasp[1], grasp[2] - 0.015}; e->dn.prev_eef_leg = dist3(o.eef, g2); }
+  } else if (ph == 2) {
+    int succ; LOWER(phase_reward, succ);
+    if (succ && sg_succ && grip_succ) { phase_bonus += bonus; e->dn.phase += 1; }
+  } else if (ph == 3) {
+    int dummy; LOWER(phase_reward, dummy); (void)dummy;
+    const int succ = leg_touched && safe_grasp;
+    phase_reward += (ga - e->dn.prev_grasp) * (real)C[DC_GRASP]; e->dn.prev_grasp = ga;
+    if (succ && sg_succ) { e->dn.phase += 1; phase_bonus += bonus; }
+  } else if (ph == 4) {
+    real dxy[2] = {e->dn.lift_leg[0] - o.leg[0], e->dn.lift_leg[1] - o.leg[1]};
+    const real xy = sqrt(dxy[0] * dxy[0] + dxy[1] * dxy[1]), z = fabs(e->dn.lift_leg[2] - o.leg[2]);
+    const real zr = (rmin(e->dn.prev_lift_z, 0.5) - rmin(z, 0.5)) * (real)C[DC_LIFT_Z] * 10, xr = (rmin(e->dn.prev_lift_xy, 0.8) - rmin(xy, 0.8)) * (real)C[DC_LIFT_XY] * 10;
+    e->dn.prev_lift_z = z; e->dn.prev_lift_xy = xy;
+    real r = xr + zr;
+    const int lift = o.leg[2] > e->dn.init_lift_leg[2] + 0.01;
+    if (leg_touched && lift && safe_grasp && !e->dn.leg_lift) { e->dn.leg_lift = 1; r += bonus / 2; }
+    if (!leg_touched) r = rmin(r, 0);
+    phase_reward = r;
+    const int succ = xy < C[DC_LIFT_XY_THR] && z < C[DC_LIFT_Z_THR];
+    if (!leg_touched || table_moved) DROP_OR_MOVED(1);
+    else if (succ) { e->dn.phase += 1; phase_bonus += bonus; e->dn.prev_move_pos = 0; e->dn.prev_up = up_ang; e->dn.prev_fwd = fwd_ang; }
+  } else if (ph == 5) {
+    const real d = dist3(e->dn.lift_leg, o.leg);
+    real pr = (rmin(e->dn.prev_move_pos, 0.4) - rmin(d, 0.4)) * (real)C[DC_ALIGN_POS] * 10, ur = (up_ang - e->dn.prev_up) * (real)C[DC_ALIGN_ROT] * 10, frr = (fwd_ang - e->dn.prev_fwd) * (real)C[DC_ALIGN_ROT] * 10;
+    e->dn.prev_move_pos = d; e->dn.prev_up = up_ang; e->dn.prev_fwd = fwd_ang;
+    if (!leg_touched) { pr = rmin(pr, 0); ur = rmin(ur, 0); frr = rmin(frr, 0); }
+    phase_reward = pr + ur + frr;
+    const int succ = d < C[DC_ALIGN_POS_THR] && up_ang > C[DC_ALIGN_ROT_THR] && fwd_ang > C[DC_ALIGN_ROT_THR] && leg_touched;
+    if (!leg_touched || table_moved) DROP_OR_MOVED(1);
+    else if (succ) { e->dn.phase += 1; phase_bonus += bonus * 2; e->dn.prev_move_pos = move_above; }
+  } else if (ph == 6) {
+    real pr = (rmin(e->dn.prev_move_pos, 0.5) - rmin(move_above, 0.5)) * (real)C[DC_MOVE_POS] * 10, ur = (rmax(up_ang, 0) - rmax(e->dn.prev_up, 0)) * (real)C[DC_MOVE_ROT] * 10,
+         frr = (rmax(fwd_ang, 0) - rmax(e->dn.prev_fwd, 0)) * (real)C[DC_MOVE_ROT] * 10;
+    e->dn.prev_move_pos = move_above; e->dn.prev_up = up_ang; e->dn.prev_fwd = fwd_ang;
+    if (!leg_touched) { pr = rmin(pr, 0); ur = rmin(ur, 0); frr = rmin(frr, 0); }
+    phase_reward = pr + ur + frr;
+    const int succ = (move_above < C[DC_MOVE_POS_THR] || move_pos_dist < C[DC_MOVE_POS_THR]) && up_ang > C[DC_MOVE_ROT_THR] && fwd_ang > C[DC_MOVE_ROT_THR] && leg_touched;
+    if (!leg_touched || table_moved) DROP_OR_MOVED(1);
+    else if (succ) { e->dn.phase += 1; phase_bonus += bonus * 2; e->dn.prev_move_pos = move_pos_dist; e->dn.prev_proj_t = proj_t; e->dn.prev_proj_l = proj_l; }
+  } else if (ph == 7) {
+    const real ke = C[DC_FINE_EXP], thr = (real)C[DC_MOVE_ROT_THR] - 0.1;
+#define FROT(x) exp(-2 * (1 - rmax((x), thr)))
+#define GPROJ(x) exp(-3 * (1 - rmax(fabs(x), 0.5)))
+    real pr = (exp(ke * move_pos_dist) - exp(ke * e->dn.prev_move_pos)) * (real)C[DC_FINE_POS] * 10, ur = (FROT(up_ang) - FROT(e->dn.prev_up)) * (real)C[DC_FINE_ROT] * 10,
+         frr = (FROT(fwd_ang) - FROT(e->dn.prev_fwd)) * (real)C[DC_FINE_ROT] * 10, tr = (GPROJ(proj_t) - GPROJ(e->dn.prev_proj_t)) * (real)C[DC_FINE_ROT] * 5,
+         lr = (GPROJ(proj_l) - GPROJ(e->dn.prev_proj_l)) * (real)C[DC_FINE_ROT] * 5;
+    e->dn.prev_move_pos = move_pos_dist; e->dn.prev_up = up_ang; e->dn.prev_fwd = fwd_ang; e->dn.prev_proj_t = proj_t; e->dn.prev_proj_l = proj_l;
+    const int fine_succ = is_aligned(s, e, k_leg, k_table), connect_succ = connected && fine_succ;
+    if (!leg_touched) { pr = rmin(pr, 0); ur = rmin(ur, 0); frr = rmin(frr, 0); tr = rmin(tr, 0); lr = rmin(lr, 0); }
+    real r = pr + ur + frr + tr + lr;
+    if (fine_succ) { e->dn.fine_aligned += 1; r += ((real)ac[dof - 1] + 1) * (real)C[DC_ALIGNED_BONUS]; }
+    phase_reward = connected ? 0 : r;
+    if (table_moved) { e->dn.table_moved = 1; *done = early; if (early) phase_bonus -= bonus; }
+    else if (connected && fine_succ) { phase_bonus += bonus * 2; phase_bonus -= e->dn.fine_aligned * (real)C[DC_ALIGNED_BONUS]; e->dn.phase = 0; *done = *success = dense_next_subtask(s, e); }
+    else if (connected) { *done = 1; *success = 0; }
+    if (!leg_touched && !connect_succ) { e->dn.leg_dropped = 1; *done = early; if (early) phase_bonus -= bonus; }
+  } else *done = 1;
+  reward += ctrl_pen + phase_reward + sg_rew;
+  reward += grip_pen + phase_bonus + move_pen;
+  if (e->dn.leg_dropped && !early) reward -= (real)C[DC_DROP_PEN];
+  *phase_bonus_out = phase_bonus;
+  return reward;
+}
+
 static void env_step(struct fsim *s, int idx, const float *action, float *ob, float *reward, uint8_t *done, int32_t *info) {
   const EnvModel *m = &s->m;
   const fsim_config_t *c = &s->cfg;
@@ -617,10 +811,16 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
     e->connected_body1 = -1;
     fs(e);
   }
-  int terminal = 0;
+  int terminal = 0, dense_phase = 0;
   if (e->num_connected == e->success_num_conn && m->nparts > 1) { e->success = 1; terminal = 1; }
   /* _compute_reward on the RAW action */
-  real touch = 0, pick = 0;
+  real touch = 0, pick = 0, dense_rew = 0, dense_bonus = 0;
+  if (c->dense_reward) { /* FurnitureSawyerEnv._step: done = done or the dense _compute_reward's _done, which also owns _success (furniture_sawyer.py:78-79) */
+    int d2 = 0, succ2 = 0;
+    dense_rew = dense_compute(s, e, action, dof, e->connected, &d2, &succ2, &dense_bonus, &dense_phase);
+    e->success = succ2;
+    terminal = terminal || d2;
+  } else
   for (int arm = 0; arm < m->narm; arm++) {
     unsigned L, R, F;
     touch_sets(s, e, arm, &L, &R, &F);
@@ -634,6 +834,7 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
   e->prev_num_connected = e->num_connected;
   for (int k = 0; k < dof; k++) s2 += (real)action[k] * (real)action[k];
   real ctrl_pen = m->agent == 2 ? 0 : -c->ctrl_penalty_coef * s2, rew = succ + touch + pick + ctrl_pen, penalty = 0; /* (no control penalty for the Cursor agent) */
+  if (c->dense_reward) { rew = dense_rew; succ = dense_bonus; touch = pick = ctrl_pen = 0; } /* (FSIM_INFO_SUCCESS_REWARD_F carries info["phase_bonus"], the other *_F are 0) */
   /* _after_step */
   e->episode_reward += rew;
   e->episode_length += 1;
@@ -648,6 +849,7 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
     info[FSIM_INFO_NUM_CONNECTED] = e->num_connected; info[FSIM_INFO_SUCCESS] = e->success; info[FSIM_INFO_FAIL] = fail ? 1 : 0;
     info[FSIM_INFO_LAST_SITE1] = e->site1; info[FSIM_INFO_LAST_SITE2] = e->site2; info[FSIM_INFO_EPISODE_LENGTH] = e->episode_length;
     info[FSIM_INFO_CONNECTED_THIS_STEP] = e->connected;
+    if (c->dense_reward) info[FSIM_INFO_DENSE_PHASE] = dense_phase;
     info[FSIM_INFO_NEEDS_TABLE] = (terminal && c->auto_reset) ? (fail == 2 ? 2 : 1) : 0;
     f = (float)succ; memcpy(&info[FSIM_INFO_SUCCESS_REWARD_F], &f, 4); f = (float)touch; memcpy(&info[FSIM_INFO_TOUCH_REWARD_F], &f, 4);
     f = (float)pick; memcpy(&info[FSIM_INFO_PICK_REWARD_F], &f, 4); f = (float)ctrl_pen; memcpy(&info[FSIM_INFO_CTRL_PENALTY_F], &f, 4);
@@ -700,9 +902,9 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->ngeom = dims[5]; m->nsite = dims[6]; m->neq = dims[7];
   m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
   m->timestep = opt[0]; m->gravz = opt[3];
-  if (s->cfg.control_type != 0 || s->cfg.dense_reward || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
+  if (s->cfg.control_type != 0 || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
     fsim_destroy(s);
-    FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control and the Cursor agent, with the sparse reward and fp32 observations (oracle/oracle_env.py checks the rest)");
+    FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control and the Cursor agent, with the sparse reward (Sawyer: also the dense reward) and fp32 observations (oracle/oracle_env.py checks the rest)");
   }
   int64_t cnt;
   GI(part_bodyid, "part_bodyid"); GI(part_qposadr, "part_qposadr"); GI(part_dofadr, "part_dofadr"); GI(body_partid, "body_partid"); GI(geom_bodyid, "geom_bodyid");
@@ -755,7 +957,7 @@ void fsim_destroy(fsim_t *s) {
   if (!s) return;
   if (s->env) for (int i = 0; i < s->n; i++) if (s->env[i].sim) osim_destroy(s->env[i].sim);
   for (int i = 0; i < s->nconv; i++) free(s->conv[i]);
-  free(s->m.geom_cursor); free(s->m.geom_namepart);
+  free(s->m.geom_cursor); free(s->m.geom_namepart); free(s->dcoef); free(s->dsub);
   free(s->env); free(s->blob); free(s->tab_parts); free(s->tab_noise); free(s);
 }
 int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim, int32_t *info_dim, int32_t *stride) {
@@ -788,6 +990,7 @@ int fsim_set_reset_tables(fsim_t *s, const uint8_t *mask, const float *part_qpos
 int fsim_reset(fsim_t *s, const uint8_t *mask, void *obs) {
   if (!s) FAIL(FSIM_EINVAL, "null");
   if (!s->tab_parts) FAIL(FSIM_EINVAL, "fsim_reset: no reset tables (fsim_set_reset_tables)");
+  if (s->cfg.dense_reward && !s->dcoef) FAIL(FSIM_EINVAL, "fsim_reset: dense_reward handle without tables (fsim_set_dense_reward)");
 #pragma omp parallel for schedule(dynamic, 1)
   for (int e = 0; e < s->n; e++) {
     if (mask && !mask[e]) continue;
@@ -807,7 +1010,8 @@ int fsim_step(fsim_t *s, const float *action, void *obs, float *reward, uint8_t 
 }
 static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
   if (!s || !p) FAIL(FSIM_EINVAL, "null");
-  if (p->dense || p->env_block || p->solver_iters) FAIL(FSIM_EINVAL, "libfsim_cpu: dense / env_block / solver_iters are not served by the CPU checker");
+  if (p->env_block || p->solver_iters) FAIL(FSIM_EINVAL, "libfsim_cpu: env_block / solver_iters are not served by the CPU checker");
+  if (p->dense && !s->cfg.dense_reward) FAIL(FSIM_EINVAL, "libfsim_cpu: the dense field belongs to a dense_reward handle");
   if (p->cursor && s->m.agent != 2) FAIL(FSIM_EINVAL, "libfsim_cpu: the cursor field belongs to the Cursor agent");
   const EnvModel *m = &s->m;
   for (int i = 0; i < s->n; i++) {
@@ -817,6 +1021,21 @@ static int xfer(fsim_t *s, const fsim_state_ptrs_t *p, int to_state) {
     FLD(qfrc_applied, e->qfrc_applied, m->nv) FLD(eq_data, e->eq_data, 7 * m->neq)
     if (p->xfrc_applied) for (int q = 0; q < m->nparts; q++) for (int k = 0; k < 6; k++) { real *x = e->xfrc_applied + 6 * m->part_bodyid[q] + k; float *y = p->xfrc_applied + ((size_t)i * m->nparts + q) * 6 + k; if (to_state) *x = *y; else *y = (float)*x; }
 #define FLI(ptr, src, cnt) if (p->ptr) for (int k = 0; k < (cnt); k++) { if (to_state) (src)[k] = p->ptr[(size_t)i * (cnt) + k]; else p->ptr[(size_t)i * (cnt) + k] = (src)[k]; }
+    if (p->dense) { /* FSIM_DENSE_STATEW floats, the device's layout (csrc/fsim_dense.hpp ED_*) */
+      float *x = p->dense + (size_t)i * FSIM_DENSE_STATEW;
+      real *v[11] = {&e->dn.prev_init_eef, &e->dn.prev_above, &e->dn.prev_eef_leg, &e->dn.prev_grasp, &e->dn.prev_lift_z, &e->dn.prev_lift_xy, &e->dn.prev_move_pos, &e->dn.prev_up,
+                     &e->dn.prev_fwd, &e->dn.prev_proj_t, &e->dn.prev_proj_l};
+      real *v3s[4] = {e->dn.init_table_site, e->dn.init_lift_leg, e->dn.lift_leg, e->dn.init_eef};
+      if (to_state) {
+        e->dn.subtask = (int)x[0]; e->dn.phase = (int)x[1]; { int f = (int)x[2]; e->dn.leg_dropped = f & 1; e->dn.table_moved = (f >> 1) & 1; e->dn.leg_lift = (f >> 2) & 1; } e->dn.fine_aligned = (int)x[3];
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) v3s[q][k] = x[4 + 3 * q + k];
+        for (int q = 0; q < 11; q++) *v[q] = x[16 + q];
+      } else {
+        x[0] = (float)e->dn.subtask; x[1] = (float)e->dn.phase; x[2] = (float)(e->dn.leg_dropped | (e->dn.table_moved << 1) | (e->dn.leg_lift << 2)); x[3] = (float)e->dn.fine_aligned;
+        for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) x[4 + 3 * q + k] = (float)v3s[q][k];
+        for (int q = 0; q < 11; q++) x[16 + q] = (float)*v[q];
+      }
+    }
     if (p->cursor) { /* [pos0 pos1 (model.body_pos of the cursor bodies), selection as part + 1] */
       float *x = p->cursor + (size_t)i * 8;
       for (int k = 0; k < 2; k++) for (int q = 0; q < 3; q++) { real *bp = e->body_pos + 3 * m->cursor_bodyid[k] + q; if (to_state) *bp = x[3 * k + q]; else x[3 * k + q] = (float)*bp; }
@@ -859,7 +1078,17 @@ int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) { if (!s) FAIL(FS
 #define NOT_SERVED(what) FAIL(FSIM_EINVAL, "libfsim_cpu: " what " is not served by the native CPU checker (oracle/oracle_env.py is the checker for it)")
 int fsim_set_attach_noise(fsim_t *s, const uint8_t *mask, const float *noise) { (void)s; (void)mask; (void)noise; NOT_SERVED("reset_robot_after_attach"); }
 int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) { (void)s; (void)mask; (void)qpos; (void)qvel; NOT_SERVED("set_init_qpos"); }
-int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *subtasks, int nsub) { (void)s; (void)coef; (void)ncoef; (void)subtasks; (void)nsub; NOT_SERVED("the dense reward"); }
+int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *subtasks, int nsub) {
+  if (!s || !coef || !subtasks) FAIL(FSIM_EINVAL, "null");
+  if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "fsim_set_dense_reward: the handle was not created with dense_reward = 1");
+  if (ncoef != FSIM_DENSE_NCOEF || nsub < 1 || nsub > 16) FAIL(FSIM_EINVAL, "dense reward: need %d coefficients and 1..16 subtasks", FSIM_DENSE_NCOEF);
+  if (coef[DC_PHASE_OB] != 0.0f || coef[DC_RESET_ROBOT] != 0.0f) NOT_SERVED("phase_ob / reset_robot_after_attach of the dense reward");
+  free(s->dcoef); free(s->dsub);
+  s->dcoef = (float *)malloc(sizeof(float) * ncoef); s->dsub = (float *)malloc(sizeof(float) * DS_WORDS * nsub);
+  memcpy(s->dcoef, coef, sizeof(float) * ncoef); memcpy(s->dsub, subtasks, sizeof(float) * DS_WORDS * nsub);
+  s->dnsub = nsub;
+  return FSIM_OK;
+}
 int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
   (void)s; (void)ids; (void)conn_pairs; (void)angles;
   if (n_pre == 0 && num_connects < 0) return FSIM_OK;

@@ -41,6 +41,7 @@ class Abi:
         L.fsim_set_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(StatePtrs)]
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_physics_forward.argtypes = [ctypes.c_void_p]
+        L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
 
     def check(self, rc):
         if rc != 0:
@@ -100,6 +101,11 @@ class Session:
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self.abi.check(self.abi.L.fsim_set_reset_tables(self.h, None if m is None else m.ctypes.data, parts.ctypes.data, noise.ctypes.data, n_noise))
 
+    def set_dense_reward(self, coef, subtasks):
+        """furniture_amd.dense.pack_dense(model) -> the tables of a dense_reward = 1 handle (host pointers on both libraries)"""
+        coef, subtasks = np.ascontiguousarray(coef, dtype=np.float32), np.ascontiguousarray(subtasks, dtype=np.float32)
+        self.abi.check(self.abi.L.fsim_set_dense_reward(self.h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
     def reset(self):
         self.abi.check(self.abi.L.fsim_reset(self.h, None, self.abi.ptr(self.obs)))
         self.abi.check(self.abi.L.fsim_sync(self.h))
@@ -126,7 +132,7 @@ class Session:
                 "xfrc_applied": ((n, m.nparts * 6), np.float32), "eq_data": ((n, m.neq * 7), np.float32), "eq_active": ((n, m.neq), np.int32),
                 "geom_contype": ((n, m.ngeom), np.int32), "geom_conaffinity": ((n, m.ngeom), np.int32), "group": ((n, m.nparts), np.int32),
                 "xpos": ((n, m.nbody * 3), np.float32), "xquat": ((n, m.nbody * 4), np.float32), "ncon": ((n,), np.int32),
-                "contact_geoms": ((n, self.max_contacts * 2), np.int32), "cursor": ((n, 8), np.float32)}[name]
+                "contact_geoms": ((n, self.max_contacts * 2), np.int32), "cursor": ((n, 8), np.float32), "dense": ((n, 27), np.float32)}[name]
 
     def get_state(self, m, *names):
         a, sp, bufs = self.abi, StatePtrs(), {}

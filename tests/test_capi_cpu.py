@@ -498,6 +498,94 @@ def test_scripted_attach_in_64_different_envs_device_vs_native(cpu_abi, sawyer_l
         s.close()
 
 
+def _dense_setup(abi, m, n, T, **dkw):
+    from furniture_amd.dense import pack_dense
+    from oracle.dense_reward import DenseConfig
+    envs = [FurnitureEnvOracle(m, OracleConfig(seed=123 + i, solver_tolerance=1e-8, max_episode_steps=T, auto_align=False, dense=DenseConfig(**dkw))) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+    noise = np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs])
+    ses = Session(abi, m.to_blob(), n, max_episode_steps=T, auto_reset=0, auto_align=0, dense_reward=1)
+    ses.set_dense_reward(*pack_dense(m, dkw))
+    ses.set_reset_tables(parts, noise)
+    obs = ses.reset()
+    return envs, obs_o, ses, obs
+
+
+def _dense_state_of(o):
+    D = o._dense
+    return np.concatenate([[D.subtask_step, D.phase_i, int(D.leg_dropped) | (int(D.table_moved) << 1) | (int(D.leg_lift) << 2), D.leg_fine_aligned],
+                           D.init_table_site_pos, D.init_lift_leg_pos, D.lift_leg_pos])
+
+
+def _dense_pinch(m, envs, ses, n):
+    """tests/test_dense_gpu.py's scenario: the gripper pinches the leg of recipe step 0 (part 1, connector 1) next to its table connector (5); the
+    reward's "table must not move" anchor is re-set on both sides (the scenario teleports the table)"""
+    gm = ses.get_state(m, "qpos", "qvel", "qacc_warmstart", "xfrc_applied", "geom_contype", "geom_conaffinity", "dense")
+    for e in range(n):
+        o = envs[e]
+        q, xfrc, masks = pinch_attach_state(m, o.sim.data.qpos.copy(), o.sim.data.xpos.copy(), o.sim.data.xquat.copy(), leg=1, table_conn=5, leg_conn=1, gap=0.02)
+        q = q.astype(np.float32).astype(np.float64)
+        o.sim.data.qpos[:], o.sim.data.qvel[:], o.sim.data.qacc_warmstart[:] = q, 0, 0
+        for i in range(m.nparts):
+            o.sim.data.xfrc_applied[m.part_bodyid[i]] = xfrc.reshape(-1, 6)[i].astype(np.float32)
+        for g, (ct, ca) in masks.items():
+            o.sim.model.geom_contype[g], o.sim.model.geom_conaffinity[g] = ct, ca
+            gm["geom_contype"][e, g], gm["geom_conaffinity"][e, g] = ct, ca
+        gm["qpos"][e], gm["qvel"][e], gm["qacc_warmstart"][e], gm["xfrc_applied"][e] = q, 0, 0, xfrc
+        o.sim.forward()
+        tsite = o.sim.data.site_xpos[o._dsub[0]["table_site"]].astype(np.float32)
+        o._dense.init_table_site_pos = tsite.astype(np.float64)
+        gm["dense"][e, 4:7] = tsite
+    ses.set_state(m, **gm)
+
+
+def _dense_both(m, envs, ses, a, n, seen, rel=1e-4):
+    obs, rew, done, info = ses.step(a)
+    st = ses.get_state(m, "dense")["dense"]
+    out = []
+    for e in range(n):
+        o = envs[e]
+        ob, r, d, inf = o.step(a[e])
+        # (fp32 at the boundary, bonuses of 5000; the difference rewards multiply a DISTANCE change by up to 1e4, so where the two trajectories have
+        #  parted by dobs -- the finger-pad amplification of DESIGN.md section 5 -- the rewards may differ by 2e4 dobs)
+        dobs = float(np.abs(obs[e] - o.flat_obs(ob)).max())
+        assert bool(done[e]) == d, e
+        assert abs(float(rew[e]) - r) < rel * max(1.0, abs(r)) + 2e4 * dobs, (e, float(rew[e]), r, dobs)
+        assert info[e, 13] == inf["phase_i"] and info[e, 1] == inf["success"] and info[e, 0] == inf["num_connected"], (e, info[e, :14], inf)
+        assert abs(float(np.asarray(info[e, 8:9]).view(np.float32)[0]) - inf["phase_bonus"]) < 1e-3, e
+        so = _dense_state_of(o)
+        assert np.array_equal(st[e, :4], so[:4]) and np.abs(st[e, 4:13] - so[4:]).max() < 1e-4 + 10 * dobs, (e, st[e, :13], so)
+        seen.add(int(inf["phase_i"]) % 8)
+        out.append(inf)
+    return out
+
+
+def test_native_checker_dense_reward_matches_the_python_restatement(cpu_abi, sawyer_lack):
+    """Round 6: the dense 8-phase reward (FurnitureSawyerDenseRewardEnv, row f1) in the native checker against oracle/dense_reward.py (pinned to the
+    reference's _compute_reward by tests/golden/dense_reward.npz): 8 envs, random actions, then the scripted pinch of the recipe's first leg next to
+    its table connector -- early pick -> lift_leg -- and the connect -> next subtask: reward, done, success, info["phase_i"], info["phase_bonus"]
+    and the reward state (subtask, phase, flags, anchors) at every step."""
+    m, n, T = sawyer_lack, 8, 150
+    envs, obs_o, ses, obs = _dense_setup(cpu_abi, m, n, T, eef_rot_threshold=0.8)
+    assert max(np.abs(obs[e] - envs[e].flat_obs(obs_o[e])).max() for e in range(n)) < 2e-6
+    seen = set()
+    for t in range(6):
+        _dense_both(m, envs, ses, np.stack([counter_actions(321, i, t, 9) for i in range(n)]), n, seen)
+    _dense_pinch(m, envs, ses, n)
+    a = np.zeros((n, 9), dtype=np.float32)
+    a[:, 7], a[:, 8] = 1.0, -1.0  # close the gripper, do not connect yet
+    for t in range(3):
+        _dense_both(m, envs, ses, a, n, seen)
+    a[:, 8] = 1.0                  # connect
+    res = _dense_both(m, envs, ses, a, n, seen)
+    assert sum(r["num_connected"] == 1 and r["subtask"] == 1 for r in res) >= n - 1, [(r["num_connected"], r["subtask"]) for r in res]
+    assert {1, 4} <= seen, seen
+    for t in range(2):
+        _dense_both(m, envs, ses, a, n, seen)
+    ses.close()
+
+
 @pytest.mark.gpu
 def test_cursor_whole_episodes_against_the_native_checker(cpu_abi):
     """BASELINE config 1's agent, device against the native checker through the one session (round 6: the checker serves the Cursor agent):
@@ -583,3 +671,74 @@ def test_cursor_demo_replayed_through_both_libraries(cpu_abi):
     k = 7 * m.nparts
     assert np.abs(Og[:, k:k + 6] - Oc[:, k:k + 6]).max() < 1e-6 and np.array_equal(Og[:, k + 6:], Oc[:, k + 6:])
     assert np.abs(Og[:, :k] - Oc[:, :k]).max() < 3e-3
+
+
+@pytest.mark.gpu
+def test_dense_reward_device_against_the_native_checker(cpu_abi, sawyer_lack):
+    """Row f1 over many envs and steps (round 6: the native checker serves the dense reward): 64 Sawyer + table_lack dense-reward envs, 6 random-action
+    steps, the scripted pinch (early pick -> lift_leg), the connect (-> next subtask), 2 more steps -- device against native through the one session:
+    done, success, num_connected and info["phase_i"] equal in every env at every step; the reward within fp32 of the native one given how far the
+    two states are apart (the difference rewards multiply a distance change by up to 1e4)."""
+    import torch
+    from furniture_amd.dense import pack_dense
+    m, n, T = sawyer_lack, 64, 150
+    envs, obs_o, sc, oc = _dense_setup(cpu_abi, m, n, T, eef_rot_threshold=0.8)  # (the Python envs only place the pinch)
+    sg = Session(Abi(GPU_LIB, torch.device("cuda:0")), m.to_blob(), n, max_episode_steps=T, auto_reset=0, auto_align=0, dense_reward=1)
+    sg.set_dense_reward(*pack_dense(m, dict(eef_rot_threshold=0.8)))
+    sg.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]), np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    og = sg.reset()
+    assert np.abs(og - oc).max() < 5e-5
+    seen, checked = set(), 0
+
+    def both(a):
+        nonlocal checked
+        (o1, r1, d1, i1), (o2, r2, d2, i2) = sg.step(a), sc.step(a)
+        dobs = np.abs(o1 - o2).max(axis=1)
+        close = dobs < 1e-4
+        assert np.array_equal(d1[close], d2[close]) and np.array_equal(i1[close][:, [0, 1, 2, 5, 13]], i2[close][:, [0, 1, 2, 5, 13]])
+        assert (np.abs(r1 - r2)[close] < 1e-3 * np.maximum(1.0, np.abs(r2[close])) + 2e4 * dobs[close] + 0.05).all(), float(np.abs(r1 - r2)[close].max())
+        checked += int(close.sum())
+        seen.update(int(x) % 8 for x in i2[:, 13])
+        return i2
+
+    for t in range(6):
+        both(np.stack([counter_actions(321, i, t, 9) for i in range(n)]))
+    # the pinch, placed from the native side's poses, on both libraries (and the reward's table anchor with it)
+    for ses in (sc, sg):
+        gm = ses.get_state(m, "qpos", "qvel", "qacc_warmstart", "xfrc_applied", "geom_contype", "geom_conaffinity", "dense")
+        if ses is sc:
+            src = ses.get_state(m, "qpos", "xpos", "xquat")
+            Q, X, MK = [], [], []
+            for e in range(n):
+                q, xfrc, masks = pinch_attach_state(m, src["qpos"][e].astype(np.float64), src["xpos"][e].reshape(-1, 3).astype(np.float64), src["xquat"][e].reshape(-1, 4).astype(np.float64),
+                                                    leg=1, table_conn=5, leg_conn=1, gap=0.02)
+                Q.append(q), X.append(xfrc), MK.append(masks)
+        for e in range(n):
+            for g, (ct, ca) in MK[e].items():
+                gm["geom_contype"][e, g], gm["geom_conaffinity"][e, g] = ct, ca
+        gm["qpos"], gm["qvel"], gm["qacc_warmstart"], gm["xfrc_applied"] = np.stack(Q), np.zeros((n, m.nv)), np.zeros((n, m.nv)), np.stack(X)
+        ses.set_state(m, **{k: v for k, v in gm.items() if k != "dense"})
+        ses.forward()
+    from furniture_amd.dense import dense_subtasks
+    tsid = dense_subtasks(m)[0][0]["table_site"]
+    # (site poses are not a state field: the anchor is the table connector's position of the teleported table, computed by the Python env of env e)
+    for e in range(n):
+        o = envs[e]
+        o.sim.data.qpos[:] = Q[e]
+        o.sim.forward()
+    anchors = np.stack([envs[e].sim.data.site_xpos[tsid] for e in range(n)]).astype(np.float32)
+    for ses in (sc, sg):
+        ds = ses.get_state(m, "dense")["dense"]
+        ds[:, 4:7] = anchors
+        ses.set_state(m, dense=ds)
+    a = np.zeros((n, 9), dtype=np.float32)
+    a[:, 7], a[:, 8] = 1.0, -1.0
+    for t in range(3):
+        both(a)
+    a[:, 8] = 1.0
+    i2 = both(a)
+    assert (i2[:, 0] == 1).sum() >= 0.9 * n
+    for t in range(2):
+        both(a)
+    assert {1, 4} <= seen and checked >= 0.7 * n * 12, (seen, checked)
+    sg.close(), sc.close()

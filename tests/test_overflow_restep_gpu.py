@@ -94,3 +94,34 @@ def test_a_reset_that_overflows_64_slots_is_repeated_with_128(monkeypatch):
         ob, rew, done, info = env.step(torch.zeros((2, env.dof), device=env.sim.device))
     assert bool(torch.isfinite(ob["object_ob"]).all()) and not bool((info["contact_overflow"] != 0).any())
     env.close()
+
+
+@pytest.mark.parametrize("furniture", ["three_blocks_peg", "table_torsby_1549"])
+def test_a_reset_beyond_64_slots_takes_the_second_rung_to_128(furniture):
+    """Round 6: the re-step is a ladder.  Cursor + three_blocks_peg / table_torsby_1549 run on 48 contact slots and pass through 80 / 72
+    simultaneous contacts while their reset settles (counted with the oracle): the 64-slot rung overflows too, the env is repeated once more on
+    the generic one-wave kernel with 128 slots, and the reset that comes out is the fp64 oracle env's (which holds 256 contacts) -- no sticky
+    report, both rungs counted."""
+    from furniture_amd.envs import FurnitureCursorEnv
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Cursor", furniture)
+    kw = dict(unity=False, record_vid=False, furniture_name=furniture, max_episode_steps=50, seed=11)
+    env = FurnitureCursorEnv(make_config(**kw))
+    assert env._b.sim.max_contacts == 48
+    orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=11, solver_tolerance=1e-10))
+    peak = [0]
+    step0 = orc.sim.step
+
+    def counted():
+        step0()
+        peak[0] = max(peak[0], orc.sim.ncon)
+    orc.sim.step = counted
+    o = orc.flat_obs(orc.reset())
+    assert peak[0] > 64, peak[0]
+    d = env.reset()  # (raises ContactOverflowError if a sticky report is left)
+    assert env._b.sim.overflow_resteps() >= 2  # the 64-slot rung and the 128-slot rung
+    got = np.concatenate([d["object_ob"], d["robot_ob"]])
+    assert np.abs(got - o).max() < 2e-3, float(np.abs(got - o).max())
+    sticky = env._b.sim.get_state("env_block")["env_block"].view(torch.int32)[:, E_OVERFLOW].cpu().numpy()
+    assert not sticky.any()
+    env.close()
