@@ -212,9 +212,16 @@ def _root(g, i):
 
 def test_native_checker_refuses_what_it_does_not_cover(cpu_abi, sawyer_lack):
     with pytest.raises(RuntimeError, match="native CPU checker covers"):
-        Session(cpu_abi, sawyer_lack.to_blob(), 1, dense_reward=1)
+        Session(cpu_abi, sawyer_lack.to_blob(), 1, control_type=7)  # ik
+    with pytest.raises(RuntimeError, match="native CPU checker covers"):
+        Session(cpu_abi, load_compiled("Baxter", "desk_mikael_1064").to_blob(), 1, dense_reward=1)  # (the dense reward is Sawyer's)
     with pytest.raises(RuntimeError, match="native CPU checker covers"):
         Session(cpu_abi, load_compiled("Cursor", "toy_table").to_blob(), 1, control_type=5)
+    ses = Session(cpu_abi, sawyer_lack.to_blob(), 1, dense_reward=1)
+    with pytest.raises(RuntimeError, match="without tables"):  # a dense handle says so when its tables are missing
+        ses.set_reset_tables(np.zeros((1, 7 * sawyer_lack.nparts), dtype=np.float32), np.zeros((1, 101 * 7), dtype=np.float32))
+        ses.reset()
+    ses.close()
 
 
 def _cursor_oracles(m, n, T, **kw):
