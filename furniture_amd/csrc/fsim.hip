@@ -968,6 +968,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   if (s->ecfg.obs_dim > 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4) { int od = s->ecfg.obs_dim; delete s; FAIL(FSIM_ENOMEM, "obs_dim %d exceeds the LDS staging area of the observation (%d words)", od, 36 * FSIM_NPAIR + 3 * FSIM_NPAIR + 4); }
   { std::vector<int> fl; if (blob_i(s->blob, "flags", fl) && !fl.empty()) s->ecfg.has_recipe = fl[0]; }
   HIPCHK(hipMalloc(&s->d_m, sizeof(DModel))); HIPCHK(hipMalloc(&s->d_ly, sizeof(Layout))); HIPCHK(hipMalloc(&s->d_ly_mw, sizeof(Layout)));
+  HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); // (allocated here, not at the first launch: no allocation on the step path)
   HIPCHK(hipMemcpy(s->d_m, &s->m, sizeof(DModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly, &s->ly, sizeof(Layout), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_ly_mw, &s->ly_mw, sizeof(Layout), hipMemcpyHostToDevice));
@@ -1296,7 +1297,6 @@ static int launch_env(fsim *s, const float *action, float *obs, float *reward, u
   if (s->la_on) { a.sh_state = s->d_sh_state; a.sh_obs = s->d_sh_obs; a.sh_prog = s->d_sh_prog; a.sh_serial = s->d_sh_serial; a.tab_serial = s->d_tab_serial; }
   const bool jobs = sched && s->la_on && s->d_tab_parts && !mw_all; // (k_schedule has listed them)
   if (jobs) a.sh_jobs = s->d_sh_jobs;
-  if (!s->d_ecfg) { HIPCHK(hipMalloc(&s->d_ecfg, sizeof(EnvCfg))); memset(&s->ecfg_sent, 0xff, sizeof(EnvCfg)); }
   if (memcmp(&s->ecfg_sent, &s->ecfg, sizeof(EnvCfg)) != 0) { // (rare: max_episode_steps, dense tables, pre-assembled starts)
     HIPCHK(hipMemcpyAsync(s->d_ecfg, &s->ecfg, sizeof(EnvCfg), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream)); // (pageable source: the copy must have left the host struct before it can change again)
