@@ -749,3 +749,21 @@ def test_dense_reward_device_against_the_native_checker(cpu_abi, sawyer_lack):
         both(a)
     assert {1, 4} <= seen and checked >= 0.7 * n * 12, (seen, checked)
     sg.close(), sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agent,furniture,reset_tol", [("Baxter", "table_lack_0825", 5e-5), ("Baxter", "bench_bjoderna_0208", 1e-4), ("Baxter", "chair_agne_0007", 1e-4),
+                                                       ("Cursor", "toy_table", 5e-5), ("Cursor", "swivel_chair_0700", 5e-5), ("Cursor", "bed_dalselv_0270", 2e-4)])
+def test_the_other_agents_whole_episodes_against_the_native_checker(cpu_abi, agent, furniture, reset_tol):
+    """Round 6: the two agents the catalogue sweeps added, over whole episodes against the native checker -- Baxter on three
+    furniture that are not desk_mikael (IKEABaxter-v0's default bench_bjoderna among them), Cursor on its three shipped defaults (bed_dalselv_0270 is
+    IKEACursor-v0's furniture id 0: ten parts, 64 contact slots).  48 envs x 34 random-action steps, one auto-reset of every env: done and the integer
+    words equal at every step (asserted inside _episodes), every env within reset_tol of the checker after the reset and after the auto-reset."""
+    n, T = 48, 30
+    m, out = _episodes(cpu_abi, agent, furniture, n, T, 34)
+    assert out[0][0].max() < reset_tol, float(out[0][0].max())
+    d, fresh, _ = out[T]
+    assert fresh.all() and d.max() < reset_tol, float(d.max())
+    for t in (1, T + 1):
+        assert (out[t][0].max(axis=1) < 1e-3).sum() >= n - 3, (t, int((out[t][0].max(axis=1) < 1e-3).sum()))
+    print(agent, furniture, "envs within 1e-3 at the end of the episode: %d of %d; reset %.1e, auto-reset %.1e" % ((out[T - 1][0].max(axis=1) < 1e-3).sum(), n, out[0][0].max(), d.max()))
