@@ -628,6 +628,10 @@ def main():
                          "kernel": slabs[0].sim.step_kernel, "kernel_avg_ms": kms, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * units_per_launch,
                          "env_steps_per_launch": units_per_launch,
+                         # `achieved` / `frac` price ONE launch (the contract's definition) -- but G launches of G slabs overlap on the chip, so the
+                         # chip-wide algorithmic rate over the timed region is the whole batch's bytes / the batched step's wall time
+                         "concurrent_launches": G, "chip_wide_achieved": ALGO_BYTES_PER_ENV_STEP * n / (dt / args.steps) / 1e9,
+                         "chip_wide_frac": ALGO_BYTES_PER_ENV_STEP * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "note": "fused 50-substep step keeps state in LDS: HBM fraction is ~0 by design; see `binding`",
                          # what binds instead (SURVEY 8d asked for VALU utilisation and occupancy): one wavefront = one env, and a
                          # wave issues at most one instruction per ~5 cycles (scripts/dev/micro: 5.0 cycles per dependent-distance-4
