@@ -85,13 +85,46 @@ sb.set_reset_tables(eb.reset_draws["part_qpos"].reshape(1, -1), np.stack(eb.rese
 sb.reset()
 sb.step(counter_actions(1, 0, 0, 17)[None])
 sb.close(); ses.close()
+# round 6: the Cursor agent -- the MuJoCo-recorded demo's first 64 frames (selection by contact, carried groups, the ten approach steps, the connect)
+from tests.test_demo_replay import D
+c = load_compiled("Cursor", "swivel_chair_0700")
+ec = FurnitureEnvOracle(c, OracleConfig(seed=123, max_episode_steps=10000, move_speed=0.025, rotate_speed=22.5))
+ec.reset()
+sc = Session(Abi(os.environ["FSIM_CPU_SAN"]), c.to_blob(), 1, max_episode_steps=10000, auto_reset=0, move_speed=0.025, rotate_speed=22.5)
+sc.set_reset_tables(ec.reset_draws["part_qpos"].reshape(1, -1), np.zeros((1, 0), dtype=np.float32))
+sc.reset()
+q = sc.get_state(c, "qpos")["qpos"]
+for i in range(c.nparts):
+    q[0, c.part_qposadr[i]:c.part_qposadr[i] + 7] = D["parts"][0, i]
+sc.set_state(c, qpos=q, qvel=np.zeros((1, c.nv)), cursor=np.concatenate([D["cursor0"][0], D["cursor1"][0], [0, 0]])[None])
+sc.forward()
+conn = None
+for t, a in enumerate(D["actions_ext"][:64]):
+    obs, rew, done, info = sc.step(np.asarray(a, dtype=np.float32)[None])
+    if info[0, 6] and conn is None:
+        conn = t
+assert conn == 60, conn
+assert sc.get_state(c, "cursor")["cursor"].shape == (1, 8)
+sc.close()
+# ... and the dense reward: reset, steps, state transfer of the reward block
+from furniture_amd.dense import pack_dense
+sd = Session(Abi(os.environ["FSIM_CPU_SAN"]), m.to_blob(), 2, max_episode_steps=20, auto_reset=1, dense_reward=1)
+sd.set_dense_reward(*pack_dense(m))
+sd.set_reset_tables(parts[:2], noise[:2])
+sd.reset()
+for t in range(3):
+    obs, rew, done, info = sd.step(np.stack([counter_actions(2, i, t, 9) for i in range(2)]))
+ds = sd.get_state(m, "dense")["dense"]
+sd.set_state(m, dense=ds)
+assert np.isfinite(rew).all() and ds.shape == (2, 27)
+sd.close()
 print("SANITIZED-OK")
 """
 
 
 def test_native_checker_runs_clean_under_asan_and_ubsan():
     """oracle/libfsim_cpu.so (the C-ABI on host memory: env logic in C) under ASan + UBSan: resets, steps across an auto-reset, state
-    transfer in both directions, the scripted attach, a Baxter step."""
+    transfer in both directions, the scripted attach, a Baxter step; round 6: the Cursor agent through the recorded demo's connect, the dense reward."""
     so = os.path.join(ROOT, "oracle", "libfsim_cpu_san.so")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libfsim_cpu_san.so"], capture_output=True, text=True)
     if r.returncode != 0:
