@@ -534,11 +534,14 @@ struct fsim {
   int *d_ovf_list = nullptr;
   // the re-step LADDER: rung 0 for models on 48 slots = 64 slots on the generic four-wave kernel, then (round 6) 128 slots on the generic
   // one-wave kernel with two slots per lane for the envs that overflow 64 as well; models on 64 slots have the one rung 64 -> 128
+  // (round 6, last rung: 512 slots -- eight per lane -- on the generic one-wave kernel `generic8`, which also takes islands of more than 64 dofs through
+  //  the LDS-resident factorisation fs_chol_all_lds: the furniture whose reset starts with the planks inside each other -- 250 to 370 contacts in the
+  //  first substeps, every part in one island)
   int redo_rungs = 0;
-  Layout ly_r[2]{};
-  Layout *d_ly_r[2] = {nullptr, nullptr};
-  int lds_bytes_r[2] = {0, 0}, redo_block[2] = {0, 0}, redo_slots[2] = {0, 0};
-  EnvStepFn redo_kernel[2] = {nullptr, nullptr};
+  Layout ly_r[3]{};
+  Layout *d_ly_r[3] = {nullptr, nullptr, nullptr};
+  int lds_bytes_r[3] = {0, 0, 0}, redo_block[3] = {0, 0, 0}, redo_slots[3] = {0, 0, 0};
+  EnvStepFn redo_kernel[3] = {nullptr, nullptr, nullptr};
   int *d_ovf_list2 = nullptr;                 // envs a re-step rung lists for the next one
   int last_do_step = 0;
   int64_t n_redone = 0;
@@ -764,7 +767,7 @@ static LayoutIn layout_in(const fsim *s, int ncon_max) {
   in.eik_rel = s->cfg.dense_reward ? ED_WORDS : 0;
   in.ncon_max = ncon_max;
   // furniture with many long parts (bookcase planks lying side by side): more part-part pairs survive the broadphase
-  in.maxsurv = ncon_max > 64 ? 192 : (m.nparts > 8 ? 128 : FSIM_MAXSURV);
+  in.maxsurv = ncon_max > 128 ? 1024 : (ncon_max > 64 ? 192 : (m.nparts > 8 ? 128 : FSIM_MAXSURV));
   return in;
 }
 
@@ -777,6 +780,7 @@ static KernelSet pick_kernels(const Dims &d, const LayoutIn &in, bool plain_cfg)
 #undef FS_TRY
   }
   // (more than 64 contact slots: two slot sets per lane in the Newton solve -- one-wave kernels only)
+  if (in.ncon_max > 128) return KernelSet{"generic8", k_physics<GenCtxT<1, false, 8>>, k_env_step<GenCtxT<1, false, 8>>, nullptr, nullptr, nullptr};
   if (in.ncon_max > 64) return KernelSet{"generic2", k_physics<GenCtxT<1, false, 2>>, k_env_step<GenCtxT<1, false, 2>>, nullptr, nullptr, nullptr};
   return KernelSet{"generic", k_physics<GenCtx>, k_env_step<GenCtx>, k_physics<GenCtxT<FSIM_MW_NW>>, k_env_step<GenCtxT<FSIM_MW_NW>>, k_env_step_x<GenCtxT<FSIM_MW_NW>, GenCtxT<1, true>>};
 }
@@ -800,7 +804,7 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
   // Ctx::NS == 2 -- for ten parts and more (4 part-floor contacts per part at rest plus the part-part ones)
   int ncon_max = s->m.nparts >= 10 ? 128 : ((s->m.nparts >= 8 || s->m.ncg >= 34 || (s->m.nparts >= 5 && s->m.ncg >= 31)) ? 64 : 48);
   if (const char *e = getenv("FSIM_NCON_MAX")) ncon_max = atoi(e);
-  if (ncon_max < 8 || ncon_max > 128) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 128] (the Newton solve keeps one or two contact slots per lane)"); }
+  if (ncon_max < 8 || ncon_max > 512) { delete s; FAIL(FSIM_EINVAL, "FSIM_NCON_MAX must be in [8, 512] (the Newton solve keeps one, two or eight contact slots per lane)"); }
   if (s->cfg.dense_reward && s->m.agent != 0) { delete s; FAIL(FSIM_EINVAL, "dense_reward exists for the Sawyer agent only (FurnitureSawyerDenseRewardEnv)"); }
   if ((s->cfg.control_type == 7 || s->cfg.control_type == 8) && (s->m.agent == 2 || !s->has_ik)) { delete s; FAIL(FSIM_EINVAL, "control_type 7 / 8 (ik / ik_quaternion) is built for the Sawyer and Baxter agents, on a model compiled with the IK chain table"); }
   if (s->cfg.control_type == 1 || s->cfg.control_type < 0 || s->cfg.control_type > 8) { delete s; FAIL(FSIM_EINVAL, "control_type %d: 0 (impedance; also the reference's 'torque', which is the impedance flow on the motor-actuated model), 2..6 (arm controllers), 7 (ik) and 8 (ik_quaternion) are built", cfg ? cfg->control_type : 0); }
@@ -858,17 +862,19 @@ extern "C" int fsim_create(const void *model_blob, size_t nbytes, int n_envs, in
     s->x_grid = std::min((n_envs + FSIM_MW_NW - 1) / FSIM_MW_NW + std::max(1, n_envs / 16), s->x_resident);
     if (const char *e = getenv("FSIM_X_GRID")) s->x_grid = std::max(1, std::min(atoi(e), s->x_resident)); // development: workgroups of a k_env_step_x launch
     // overflow re-step: models on the default 48 slots (the benchmark's LDS budget), stepped again with 64 slots and longer broadphase lists
-    if ((ncon_max == 48 || ncon_max == 64) && s->m.nv <= 64 && s->cfg.overflow_restep != 0 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
-      for (int slots = ncon_max == 48 ? 64 : 128; slots <= 128 && s->redo_rungs < 2; slots *= 2) {
+    if ((ncon_max == 48 || ncon_max == 64 || ncon_max == 128) && s->cfg.overflow_restep != 0 && !getenv("FSIM_NO_OVERFLOW_REDO") && !env_controller_kind(s->cfg)) {
+      for (int slots = ncon_max == 48 ? 64 : (ncon_max == 64 ? 128 : 512); slots <= 512 && s->redo_rungs < 3; slots = slots == 64 ? 128 : (slots == 128 ? 512 : 1024)) {
+        if (slots == 64 && s->m.nv > 64) continue; // (the four-wave kernel's solve knows one row pass)
         LayoutIn lr = lin;
-        const bool big = slots == 128; // (128 slots: two per lane, the one-wave kernel of the `generic2` set; the workgroup has the CU's LDS to itself)
-        lr.ncon_max = slots; lr.maxsurv = std::max(lin.maxsurv, big ? 192 : 128);
+        const bool big = slots >= 128; // (128 / 512 slots: two / eight per lane, the one-wave kernels of the `generic2` / `generic8` sets; the workgroup has the CU's LDS to itself)
+        lr.ncon_max = slots; lr.maxsurv = std::max(lin.maxsurv, slots == 512 ? 1024 : (big ? 192 : 128));
         const Layout ly = make_layout(lr, big ? 1 : FSIM_MW_NW);
         if (ly.lds_words * 4 > 160 * 1024 || ly.stride != s->ly.stride) break;
         const int r = s->redo_rungs++;
         s->ly_r[r] = ly;
         s->lds_bytes_r[r] = ly.lds_words * 4;
-        s->redo_kernel[r] = big ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 2>>) : static_cast<EnvStepFn>(k_env_step<GenCtxT<FSIM_MW_NW>>);
+        s->redo_kernel[r] = slots == 512 ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 8>>)
+                                         : (big ? static_cast<EnvStepFn>(k_env_step<GenCtxT<1, false, 2>>) : static_cast<EnvStepFn>(k_env_step<GenCtxT<FSIM_MW_NW>>));
         s->redo_block[r] = big ? 64 : 64 * FSIM_MW_NW;
         s->redo_slots[r] = slots;
       }
@@ -992,7 +998,7 @@ extern "C" void fsim_destroy(fsim_t *s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   hipFree(s->d_sh_state); hipFree(s->d_sh_obs); hipFree(s->d_sh_prog); hipFree(s->d_sh_serial); hipFree(s->d_tab_serial); hipFree(s->d_sh_jobs);
   if (s->xfer) { hipStreamSynchronize(s->xfer); hipStreamDestroy(s->xfer); }
-  hipFree(s->d_ly_r[0]); hipFree(s->d_ly_r[1]); hipFree(s->d_prev); hipFree(s->d_ovf_list); hipFree(s->d_ovf_list2);
+  hipFree(s->d_ly_r[0]); hipFree(s->d_ly_r[1]); hipFree(s->d_ly_r[2]); hipFree(s->d_prev); hipFree(s->d_ovf_list); hipFree(s->d_ovf_list2);
   hipFree(s->d_ly_mw); hipFree(s->d_defer); hipFree(s->d_mworder); hipFree(s->d_mwn); hipFree(s->d_ecfg);
   hipFree(s->d_m); hipFree(s->d_ly); hipFree(s->d_model); hipFree(s->d_state); hipFree(s->d_aux); hipFree(s->d_tab_parts); hipFree(s->d_tab_noise); hipFree(s->d_tab_attach); hipFree(s->d_cost); hipFree(s->d_order); hipFree(s->d_dense); hipFree(s->d_pre); hipFree(s->d_init); hipFree(s->d_init_mask); if (s->h_nreset) hipHostFree(s->h_nreset);
   if (s->ev0) hipEventDestroy(s->ev0);

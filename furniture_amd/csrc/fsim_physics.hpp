@@ -135,8 +135,9 @@ template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { retur
 // ---- map of a block-diagonal SPD system over "islands" (sets of kinematic trees): Layout::hmap (Newton Hessian, islands
 // = trees joined by an active constraint, rebuilt when the adjacency changes) and Layout::k_tmap (M + h D of the
 // integrator, islands = trees, built once per launch).  Words, relative to `mp`:
-//   [0, nv)        per dof:  row base in the packed triangles (12 bits) | local index l in its island (6) << 12 |
-//                            island size nI (7) << 18 | solver lane (6) << 25
+//   [0, nv)        per dof:  row base in the packed triangles (13 bits) | local index l in its island (7) << 13 |
+//                            island size nI (7) << 20            (MAP_ROWB / MAP_L / MAP_NI; round 6: l had six bits -- an island of
+//                            more than 64 dofs, which only the 512-slot re-step kernels accept, needs seven -- and the row base twelve)
 //   [nv, nv + 64)  per lane: byte 0 = dof this lane owns in the ROW phase (0xff none), byte 1 = dof it owns in the BIG phase,
 //                            byte 2 = dof it owns in the SECOND row pass (models with more than 64 dofs: the four 16-lane rows are
 //                            filled twice)
@@ -147,6 +148,11 @@ template <class B> DEV FsIn<B> fs_rebuild(const FsIn<B> &cv, float *lds) { retur
 // `row_newbcast` DPP moves.  Larger islands (a robot holding two parts, Baxter's 19-dof tree) get a contiguous lane range
 // and are factored one after the other with v_readlane broadcasts.  (fs_chol_solve, fsim_solver.hpp)
 enum { MAP_RSTEPS = 0, MAP_NBIG = 1, MAP_BIG0 = 2, MAP_MAXBIG = 14, MAP_BIGCAP = 6 };
+#define MAP_ROWB(w) ((w) & 0x1fff) // (13 bits: the packed triangle of 93 dofs -- Sawyer + bookcase_grevback_0484 -- has 4371 words)
+#define MAP_L(w) (((w) >> 13) & 127)
+#define MAP_NI(w) (((w) >> 20) & 127)
+#define MAP_HUGE 200 // tail[MAP_MAXBIG] of a system with an island of more than 64 dofs (or big islands beyond the 64 big-phase lanes): no lane tables --
+                     // fs_chol_all_lds factors every island from the dof words alone (contexts with Ctx::NS >= 4 only: the last rung of the re-step ladder)
 // (FSIM_BIG_MIN: the island of the robot's tree counts as "large" from this many dofs on.  17 = only when it does not fit a DPP row;
 //  12 with the matrix-core Hessian assembly, -DFSIM_MFMA_HESSIAN, whose tile then also takes the robot + one part islands)
 //  -DFSIM_MFMA_HESSIAN=2: only in the multi-wave kernels, whose main wave is the critical path of the slowest envs)
@@ -181,6 +187,7 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
     // (a model with more than 64 dofs fills the four rows a second time: second row pass of fs_chol_solve)
     const int nrow = nv > 64 ? 8 : 4;
     int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hb = 0, sb = 0, nbig = 0, maxbig = 0;
+    bool huge = false;
     for (int u = 0; u < ntree; u++) {
       if (__ffs(isl[u]) - 1 != u) continue;
       const int n = (tmp[u] >> 8) & 255;
@@ -198,13 +205,14 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
       if (row >= 0) { lane0 = 16 * (row & 3) + fill[row]; fill[row] += n; }
       else { lane0 = sb; if (nbig < MAP_BIGCAP) { tail[MAP_BIG0 + 2 * nbig] = sb; tail[MAP_BIG0 + 2 * nbig + 1] = n; } nbig++; sb += n; maxbig = max(maxbig, n); }
       tmp[u] |= (lane0 << 16) | ((row < 0 ? 1 : 0) << 24) | ((row >= 4 ? 1 : 0) << 25);
-      // an island of more than 64 dofs (or big islands that overflow the 64 big-phase lanes) cannot be mapped: the solve is
-      // flagged bad, which the env treats like an unstable simulation -- a robot holding ten mutually coupled parts
-      if (n > 64 || sb > 64) scal_[SC_BAD] |= 3;
+      // an island of more than 64 dofs (or big islands that overflow the 64 big-phase lanes) cannot be mapped onto lanes: the solve is
+      // flagged bad, which the env treats like an unstable simulation -- a robot holding ten mutually coupled parts.  (The 256-slot
+      // kernels of the re-step ladder, Ctx::NS >= 4, take such a system through the LDS-resident factorisation instead: `huge`.)
+      if (n > 64 || sb > 64) { if (Ctx::NS >= 4 && n <= 127) huge = true; else scal_[SC_BAD] |= 3; }
     }
     tail[MAP_RSTEPS] = max(max(fill[0], fill[1]), max(fill[2], fill[3])) | (max(max(fill[4], fill[5]), max(fill[6], fill[7])) << 8);
     tail[MAP_NBIG] = nbig;
-    tail[MAP_MAXBIG] = nbig > MAP_BIGCAP ? 99 : maxbig; // (more big islands than the table holds: LDS fallback handles them all)
+    tail[MAP_MAXBIG] = huge ? MAP_HUGE : (nbig > MAP_BIGCAP ? 99 : maxbig); // (more big islands than the table holds: LDS fallback handles them all)
     scal_[hwords_slot] = hb;
   }
   SYNC();
@@ -212,12 +220,26 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
   SYNC();
   for (int i = c.lane; i < nv; i += 64) {
     const int t = KI(r_tree, KI(dof_rbody, i)), rep = __ffs(isl[t]) - 1;
-    const int nI = (tmp[rep] >> 8) & 255, l = (tmp[t] & 255) + i - KI(tree_dofadr, t), lane = ((tmp[rep] >> 16) & 63) + l;
-    hm[i] = (tmp[16 + rep] + l * (l + 1) / 2) | (l << 12) | (nI << 18) | (lane << 25);
+    const int nI = (tmp[rep] >> 8) & 255, l = (tmp[t] & 255) + i - KI(tree_dofadr, t), lane = ((tmp[rep] >> 16) & 255) + l;
+    hm[i] = (tmp[16 + rep] + l * (l + 1) / 2) | (l << 13) | (nI << 20);
     const bool big = (tmp[rep] >> 24) & 1, second = (tmp[rep] >> 25) & 1;
     if (lane < 64) reinterpret_cast<unsigned char *>(hm + nv)[4 * lane + (big ? 1 : (second ? 2 : 0))] = (unsigned char)i;
   }
   SYNC();
+  if constexpr (Ctx::NS >= 4) {
+    // huge system (fs_chol_all_lds): the lane tables mean nothing; [nv + t] = COMPACT offset of tree t's island -- the islands' dofs numbered
+    // island by island in the order of their lowest tree, so that (offset + local index) addresses a vector by island position
+    if (tail[MAP_MAXBIG] == MAP_HUGE) {
+      SYNC();
+      if (c.lane < ntree) {
+        const int rep = __ffs(isl[c.lane]) - 1;
+        int off = 0;
+        for (int u = 0; u < rep; u++) if (__ffs(isl[u]) - 1 == u) off += (tmp[u] >> 8) & 255;
+        hm[nv + c.lane] = off;
+      }
+      SYNC();
+    }
+  }
 }
 
 // copy the hot model tables HBM -> LDS (once per kernel launch; the 50 substeps then never leave the CU for them)
@@ -258,7 +280,7 @@ template <class Ctx> DEV void fs_load_cache(const Ctx &c) {
   // (two branches of one tree) are zeroed once here and never written again
   for (int e = c.lane; e < c.D.nM; e += 64) {
     int i = GP(m.M_i)[e], j = GP(m.M_j)[e];
-    int pidx = (c.I(c.ly.k_tmap)[i] & 0xfff) + ((c.I(c.ly.k_tmap)[j] >> 12) & 63);
+    int pidx = MAP_ROWB(c.I(c.ly.k_tmap)[i]) + MAP_L(c.I(c.ly.k_tmap)[j]);
     c.I(c.ly.k_M_ij)[e] = (pidx << 16) | (i << 8) | j;
   }
   {
@@ -422,8 +444,8 @@ template <class Ctx> DEV void fs_mulM(const Ctx &c, int off_y, int off_v) {
   float *L = c.L;
   for (int i = c.lane; i < c.D.nv; i += 64) {
     const int w = c.I(c.ly.k_tmap)[i];
-    const int li = (w >> 12) & 63, n = (w >> 18) & 127, a = i - li; // local index, tree size, first dof
-    const int rowi = w & 0xfff, tb = rowi - li * (li + 1) / 2;
+    const int li = MAP_L(w), n = MAP_NI(w), a = i - li; // local index, tree size, first dof
+    const int rowi = MAP_ROWB(w), tb = rowi - li * (li + 1) / 2;
     const float *Mt = L + c.ly.M;
     float acc = 0;
     // one walk over the row (left of the diagonal: the packed row itself, right of it: column li of the later rows), three

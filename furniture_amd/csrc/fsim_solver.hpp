@@ -212,6 +212,8 @@ struct SolSlot {
   bool anyweld;            // (wave-uniform) some weld is active
   int pid, npc, ptot, nye; // body-pair cache (fs_pair_cache): this slot's pair block (-1 none), pairs (wave-uniform; -1 = not cached), items, column items
 };
+// (what the gradient pass knows about a lane's contact slot and later passes need again: fs_grad_slot)
+struct SlotK { bool on; int zone; float K[6]; }; // zone: see fs_line_eval
 // base: first contact slot of the set (0; 64 for the second set of a model with more than 64 contact slots -- Ctx::NS == 2: the
 // solve then carries two SolSlot per lane; joint limits and welds belong to the first set)
 template <class Ctx> DEV SolSlot fs_load_slots(const Ctx &c, const int base = 0) {
@@ -412,17 +414,20 @@ DEV int fs_line_slot(const SolSlot &S, float alpha, float &a1, float &a2) {
   }
   return zc;
 }
-// (T / zoneT: the second slot set of a model with more than 64 contact slots, Ctx::NS == 2)
+// (T / skT: the further slot sets of a model with more than 64 contact slots, Ctx::NS - 1 of them)
 template <class Ctx> DEV void fs_line_eval(const Ctx &c, const SolSlot &S, float alpha, float *d1, float *d2, int zone, bool *nonquad, const SolSlot *T = nullptr,
-                                          int zoneT = 0) {
+                                          const SlotK *skT = nullptr) {
   float *L = c.L;
   float a1 = 0, a2 = 0;
   int zl = 0; // this lane's limit activity at alpha
   const int zc = fs_line_slot(S, alpha, a1, a2); // this lane's contact zone at alpha
   bool moved = zc == 2 || zc != (zone & 3);
   if constexpr (Ctx::NS > 1) {
-    const int zt = fs_line_slot(*T, alpha, a1, a2);
-    moved = moved || zt == 2 || zt != (zoneT & 3);
+#pragma unroll
+    for (int k = 0; k < Ctx::NS - 1; k++) {
+      const int zt = fs_line_slot(T[k], alpha, a1, a2);
+      moved = moved || zt == 2 || zt != (skT[k].zone & 3);
+    }
   }
   if (S.lact) {
     float j = S.ljar + alpha * S.ljp;
@@ -462,7 +467,6 @@ template <class Ctx> DEV void fs_add_wrench_r(const Ctx &c, int bt, V3 r, V3 F, 
 // grad = Mx - qfrc_smooth - J' f(jar)
 // What the gradient pass already knows about this lane's contact slot and the Hessian pass needs again: whether the
 // cone is active and its world-frame stiffness K = F' * Hcone * F (one slot per lane: ncon_max <= 64).
-struct SlotK { bool on; int zone; float K[6]; }; // zone: see fs_line_eval
 
 // this lane's contact slot: cone force -> wrenches on its two bodies; returns the cone state and world stiffness
 template <class Ctx> DEV SlotK fs_grad_slot(const Ctx &c, const SolSlot &S) {
@@ -504,7 +508,10 @@ template <class Ctx> DEV SlotK fs_gradient(const Ctx &c, const SolSlot &S, const
   SYNC();
   SlotK sk = fs_grad_slot(c, S);
   int tb = S.tb;
-  if constexpr (Ctx::NS > 1) { *skT = fs_grad_slot(c, *T); tb |= T->tb; }
+  if constexpr (Ctx::NS > 1) {
+#pragma unroll
+    for (int k = 0; k < Ctx::NS - 1; k++) { skT[k] = fs_grad_slot(c, T[k]); tb |= T[k].tb; }
+  }
   if (S.lact && S.ljar < 0) {
     sk.zone |= 4;
     atomicAdd(L + c.ly.grad + S.ldof, S.lsign * S.ld * S.ljar); // -sign*f, f = -D*jar
@@ -575,8 +582,8 @@ template <class Ctx> DEV float fs_active_islands(const Ctx &c, float scale, bool
 
 DEV int fs_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of entry (i, j), i >= j, both in the same island, under the map at word offset mp (Layout::hmap or k_tmap)
-// map word of dof i: packed row base (12 bits) | local index (6) | island size (7) | first solver lane (6); [nv + lane] = dof of a solver lane
-template <class Ctx> DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return (A[i] & 0xfff) + ((A[j] >> 12) & 63); }
+// map word of dof i: packed row base (12 bits) | local index (7) | island size (7) (MAP_ROWB / MAP_L / MAP_NI); [nv + lane] = dof of a solver lane
+template <class Ctx> DEV int fs_hidx(const Ctx &c, int mp, int i, int j) { const int *A = c.I(mp); return MAP_ROWB(A[i]) + MAP_L(A[j]); }
 
 // column of J for chain entry: value of row-space functional on dof d.  For a contact the three rows are
 // frame_a . (cdof_lin + cdof_ang x (pos - com)); sign folded in by the caller.
@@ -925,7 +932,7 @@ template <int NLOC, class BC, class Ctx> DEV int fs_chol_phase(const Ctx &c, int
   const float *H = L + c.ly.H;
   const bool row = dof >= 0;
   const int B = row ? c.I(mp)[dof] : 0;
-  const int l = (B >> 12) & 63, nI = (B >> 18) & 127, rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
+  const int l = MAP_L(B), nI = MAP_NI(B), rowb = MAP_ROWB(B), hI = rowb - l * (l + 1) / 2;
   const int p0 = pos - l; // first position of the lane's island inside its group
   fs_f2 A[NLOC / 2];
   {
@@ -1059,7 +1066,7 @@ template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, cons
   const int lw = c.I(mp)[nv + first + min(k, n - 1)];
   const int dofk = (lw >> 8) & 255;
   const float gk = L[c.ly.grad + dofk];
-  const int hI = __builtin_amdgcn_readfirstlane(c.I(mp)[__builtin_amdgcn_readfirstlane(dofk)] & 0xfff); // packed base of the island (its first dof -- lane 0's -- has l = 0)
+  const int hI = MAP_ROWB(__builtin_amdgcn_readfirstlane(c.I(mp)[__builtin_amdgcn_readfirstlane(dofk)])); // packed base of the island (its first dof -- lane 0's -- has l = 0)
   if (c.lane < 32) rhs[k] = k < n ? -gk : 0.0f;
   SYNC();
   fs_f16v D;
@@ -1081,7 +1088,7 @@ template <class Ctx> DEV int fs_mfma_tile_solve(const Ctx &c, const int mp, cons
     // (lk: index of dof k inside its tree, nk: the tree's size -- both in the dof's word of the tree map), and row i = i0 + 4 h with
     // i0 a compile-time constant: no cross-lane traffic, a handful of integer instructions per entry
     const int Tk = c.I(c.ly.k_tmap)[dofk];
-    const int rbk = Tk & 0xfff, lk = (Tk >> 12) & 63, nk = (Tk >> 18) & 127, lock = k - lk, hbk = rbk - lk * (lk + 1) / 2;
+    const int rbk = MAP_ROWB(Tk), lk = MAP_L(Tk), nk = MAP_NI(Tk), lock = k - lk, hbk = rbk - lk * (lk + 1) / 2;
 #pragma unroll
     for (int v = 0; v < 16; v++) {
       const int i0 = 8 * (v >> 2) + (v & 3);
@@ -1253,7 +1260,7 @@ template <class Ctx> DEV int fs_stage_big(const Ctx &c, const int trees, const i
   if (c.lane < 2 * c.D.nlim) {
     const float *q = L + c.ly.lim + FSIM_LIMW * c.lane;
     const int *qi = reinterpret_cast<const int *>(q);
-    if (qi[LM_ACTIVE] != 0 && q[LM_JAR] < 0 && ((trees >> KI(dof_tree, qi[LM_DOF])) & 1)) atomicAdd(L + stage + 32 + ((c.I(c.ly.hmap)[qi[LM_DOF]] >> 12) & 63), q[LM_D]);
+    if (qi[LM_ACTIVE] != 0 && q[LM_JAR] < 0 && ((trees >> KI(dof_tree, qi[LM_DOF])) & 1)) atomicAdd(L + stage + 32 + MAP_L(c.I(c.ly.hmap)[qi[LM_DOF]]), q[LM_D]);
   }
   SYNC();
   return nst;
@@ -1317,8 +1324,8 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
   const bool row = dofb != 255;
   const int i = row ? dofb : 0;
   const int B = row ? c.I(mp)[i] : 0;
-  const int l = (B >> 12) & 63, nI = row ? (B >> 18) & 127 : 0, ib = c.lane - l;
-  const int rowb = B & 0xfff, hI = rowb - l * (l + 1) / 2;
+  const int l = MAP_L(B), nI = row ? MAP_NI(B) : 0, ib = c.lane - l;
+  const int rowb = MAP_ROWB(B), hI = rowb - l * (l + 1) / 2;
   const int steps = (int)wave_max((float)nI);
   int bad = 0;
   float mydinv = 0.0f;
@@ -1356,6 +1363,74 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
   return bad;
 }
 
+// A system with an island of more than 64 dofs (MAP_HUGE; the 256-slot kernels of the re-step ladder only: furniture whose reset starts with the
+// planks inside each other -- an 81-dof island for table_liden_0921, 84 for bookcase_grevback_0484): every island, small ones included, is factored
+// in LDS from the dof words alone -- lane = rows d = lane and lane + 64, left-looking, one column of every island per trip (two barriers), the
+// substitutions column-oriented through a vector indexed by island position (Layout::Mp, dead until M p is formed).  ~150 kcycles per solve of an
+// 81-dof island against ~9 k for the register paths: this path serves resets and re-steps of models nothing else can hold, not throughput.
+template <class Ctx> DEV int fs_chol_all_lds(const Ctx &c, int mp) {
+  float *L = c.L;
+  float *H = L + c.ly.H, *Y = L + c.ly.Mp;
+  const int nv = c.D.nv;
+  const int *hm = c.I(mp);
+  int l[2], nI[2], rowb[2], hI[2], co[2];
+  bool row[2];
+  float b[2];
+  int steps = 0, bad = 0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int d = c.lane + 64 * k;
+    row[k] = d < nv;
+    const int w = hm[row[k] ? d : 0];
+    l[k] = MAP_L(w); nI[k] = row[k] ? MAP_NI(w) : 0; rowb[k] = MAP_ROWB(w); hI[k] = rowb[k] - l[k] * (l[k] + 1) / 2;
+    co[k] = hm[nv + KI(dof_tree, row[k] ? d : 0)];
+    b[k] = row[k] ? -L[c.ly.grad + d] : 0.0f;
+    steps = max(steps, nI[k]);
+  }
+  steps = (int)wave_max((float)steps);
+#pragma unroll 1
+  for (int jj = 0; jj < steps; jj++) {
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (row[k] && l[k] == jj) { // the pivot of column jj of this row's island
+        float dd = H[rowb[k] + jj];
+        for (int q = 0; q < jj; q++) dd -= H[rowb[k] + q] * H[rowb[k] + q];
+        if (!(dd > 1e-30f)) { bad = 1; dd = 1e-30f; }
+        H[rowb[k] + jj] = sqrtf(dd);
+      }
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (row[k] && l[k] > jj && jj < nI[k]) {
+        const int rj = hI[k] + jj * (jj + 1) / 2;
+        float s = H[rowb[k] + jj];
+        for (int q = 0; q < jj; q++) s -= H[rowb[k] + q] * H[rj + q];
+        H[rowb[k] + jj] = s / H[rj + jj];
+      }
+    SYNC();
+  }
+#pragma unroll 1
+  for (int jj = 0; jj < steps; jj++) { // L y = b
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (row[k] && l[k] == jj) { b[k] = b[k] / H[rowb[k] + jj]; Y[co[k] + jj] = b[k]; }
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (row[k] && l[k] > jj && jj < nI[k]) b[k] -= H[rowb[k] + jj] * Y[co[k] + jj];
+  }
+  SYNC();
+#pragma unroll 1
+  for (int jj = steps - 1; jj >= 0; jj--) { // L' p = y
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (row[k] && l[k] == jj && jj < nI[k]) { b[k] = b[k] / H[rowb[k] + jj]; Y[co[k] + jj] = b[k]; }
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < 2; k++) if (row[k] && l[k] < jj && jj < nI[k]) b[k] -= H[hI[k] + jj * (jj + 1) / 2 + l[k]] * Y[co[k] + jj];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) if (row[k]) L[c.ly.p + c.lane + 64 * k] = b[k];
+  return bad;
+}
+
 // (inlined at its two call sites -- the Newton step and the damped integrator -- both inside fs_substeps)
 // am (-1: every island): trees of the islands that take a step (fs_active_islands).  Lanes of the others act as empty lanes (unit
 // diagonal) and set p = 0, the row phase only runs as many pivots as the last moving lane needs, a big island that does not move is skipped.
@@ -1370,6 +1445,9 @@ template <class Ctx> DEV bool fs_chol_solve(const Ctx &c, int mp, const int am =
   if (c.lane == 0 && mp == c.ly.hmap) { int *ps_ = c.I(c.ly.scal); ps_[51] += nbig > 0 ? tail[MAP_MAXBIG] : 0; ps_[52] += (nbig > 0) + ((nbig > 0 && tail[MAP_MAXBIG] > 31) << 10); } // (bits 10..15: solves with an island beyond the MFMA tile)
 #endif
   int bad = 0;
+  if constexpr (Ctx::NS >= 4) {
+    if (__builtin_amdgcn_readfirstlane(tail[MAP_MAXBIG]) == MAP_HUGE) { bad = fs_chol_all_lds(c, mp); SYNC(); return !wave_or(bad); }
+  }
 #ifdef FSIM_CHOLPROF
   long long tc_ = clock64();
 #define FS_CHPROF(slot) do { long long t1c_ = clock64(); if (c.lane == 0 && mp == c.ly.hmap) c.I(c.ly.scal)[slot] += (int)((t1c_ - tc_) >> 4); tc_ = t1c_; } while (0)
@@ -1827,14 +1905,18 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     mw_post(c, MW_MULM);
   }
   SolSlot S = fs_load_slots(c);
-  SolSlot T = {};  // (second slot set: models with more than 64 contact slots, Ctx::NS == 2; dead code otherwise)
+  SolSlot T[Ctx::NS > 1 ? Ctx::NS - 1 : 1] = {};  // (further slot sets: models with more than 64 contact slots -- Ctx::NS == 2: 128, == 4: 256; dead code otherwise)
   if constexpr (Ctx::NS > 1) {
-    // two sets: the body-pair cache is not used (its election runs over one set of lanes); every set takes fs_hessian's multi-pass path
-    T = fs_load_slots(c, 64);
+    // several sets: the body-pair cache is not used (its election runs over one set of lanes); every set takes fs_hessian's multi-pass path
     {
-      const int b1 = S.bt1 & 255, b2 = S.bt2 & 255, u1 = T.bt1 & 255, u2 = T.bt2 & 255;
+      const int b1 = S.bt1 & 255, b2 = S.bt2 & 255;
       S.npc = __ballot(S.act && min(b1, b2) != 0 && b1 != b2) ? -1 : 0;
-      T.npc = __ballot(T.act && min(u1, u2) != 0 && u1 != u2) ? -1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < Ctx::NS - 1; k++) {
+      T[k] = fs_load_slots(c, 64 * (k + 1));
+      const int u1 = T[k].bt1 & 255, u2 = T[k].bt2 & 255;
+      T[k].npc = __ballot(T[k].act && min(u1, u2) != 0 && u1 != u2) ? -1 : 0;
     }
   } else
   fs_pair_cache(c, S);
@@ -1844,7 +1926,10 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
   if constexpr (Ctx::NW == 1) fs_mulM(c, c.ly.Mx, c.ly.x);
   fs_body_spatial(c, c.ly.x);
   fs_jdot(c, S, c.ly.x, true);
-  if constexpr (Ctx::NS > 1) fs_jdot(c, T, c.ly.x, true, false);
+  if constexpr (Ctx::NS > 1) {
+#pragma unroll
+    for (int k = 0; k < Ctx::NS - 1; k++) fs_jdot(c, T[k], c.ly.x, true, false);
+  }
   if constexpr (Ctx::NW > 1) mw_post(c, MW_IDLE);
   float scale = c.D.meaninertia_scale;
   int it = 0;
@@ -1874,7 +1959,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
 #define FS_ASM_OK() 0
 #endif
   for (; it < c.newton_maxit; it++) {
-    SlotK sk, skT = {};
+    SlotK sk, skT[Ctx::NS > 1 ? Ctx::NS - 1 : 1] = {};
     bool ok;
     bool iterated = false;
     if constexpr (Ctx::NW > 1) if (mw) {
@@ -1908,7 +1993,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       mw_post(c, MW_IDLE);
     }
     if (!iterated) {
-      sk = fs_gradient(c, S, &T, &skT);
+      sk = fs_gradient(c, S, T, skT);
       int am;
       // (welds and the LDS-resident factorisation of islands beyond the MFMA tile keep every island in the iteration)
       const int *tailh = c.I(c.ly.hmap) + c.D.nv + 64;
@@ -1920,7 +2005,10 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       const int asm_ok = FS_ASM_OK();
       if (asm_ok) fs_stage_k(c, S, sk);
       if (!asm_ok || (am & ~asm_ok)) fs_hessian(c, sk, S, am & ~asm_ok);
-      if constexpr (Ctx::NS > 1) fs_hessian<Ctx, true>(c, skT, T, am);
+      if constexpr (Ctx::NS > 1) {
+#pragma unroll
+        for (int k = 0; k < Ctx::NS - 1; k++) fs_hessian<Ctx, true>(c, skT[k], T[k], am);
+      }
       FS_SPROF(24);
       ok = fs_chol_solve(c, c.ly.hmap, am, asm_ok);
       FS_SPROF(25);
@@ -1928,7 +2016,10 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
       fs_mulM(c, c.ly.Mp, c.ly.p);
       fs_body_spatial(c, c.ly.p);
       fs_jdot(c, S, c.ly.p, false);
-      if constexpr (Ctx::NS > 1) fs_jdot(c, T, c.ly.p, false, false);
+      if constexpr (Ctx::NS > 1) {
+#pragma unroll
+        for (int k = 0; k < Ctx::NS - 1; k++) fs_jdot(c, T[k], c.ly.p, false, false);
+      }
     }
     // phi'(0) along the Newton direction (= -g' H^-1 g < 0), p'Mp and p'(Mx - smooth) in one pass over the dofs
     float dphi0 = 0, pMp = 0, pg0 = 0;
@@ -1945,7 +2036,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     for (int ls = 0; ls < 20; ls++) {
       float d1, d2;
       bool nq;
-      fs_line_eval(c, S, alpha, &d1, &d2, sk.zone, &nq, &T, skT.zone);
+      fs_line_eval(c, S, alpha, &d1, &d2, sk.zone, &nq, T, skT);
       if (ls == 0) nonquad = nq;
 #ifdef FSIM_PROFILE
       if (c.lane == 0) { scal[16 + 13] += 1; }
@@ -1969,7 +2060,10 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     FS_SPROF(27);
     for (int d = c.lane; d < c.D.nv; d += 64) { L[c.ly.x + d] += alpha * L[c.ly.p + d]; L[c.ly.Mx + d] += alpha * L[c.ly.Mp + d]; }
     for (int a = 0; a < 3; a++) S.jar[a] += alpha * S.jp[a];
-    if constexpr (Ctx::NS > 1) for (int a = 0; a < 3; a++) T.jar[a] += alpha * T.jp[a];
+    if constexpr (Ctx::NS > 1) {
+#pragma unroll
+      for (int k = 0; k < Ctx::NS - 1; k++) for (int a = 0; a < 3; a++) T[k].jar[a] += alpha * T[k].jp[a];
+    }
     S.ljar += alpha * S.ljp;
     if (S.anyweld)
       for (int e = c.lane; e < c.D.neq; e += 64) {

@@ -80,9 +80,9 @@ typedef struct fsim_config {
                                  301 / 401 reset substeps inside its launch.  Same loop on the same inputs: bit-identical to the in-launch reset,
                                  which remains the fallback whenever the shadow is not complete.  Not used with the arm controllers, ik /
                                  ik_quaternion, reset_robot_after_attach and multi_wave = all.  0: off. */
-  int32_t overflow_restep;    /* 1 (default): a step or reset that needs more contact slots than the kernel's LDS image holds (48 / 64) is repeated
-                                 with 64 / 128 before fsim_sync returns (fsim_overflow_resteps).  0: off -- the sticky report of FSIM_INFO_OVERFLOW
-                                 is then all there is. */
+  int32_t overflow_restep;    /* 1 (default): a step or reset that needs more contact slots than the kernel's LDS image holds (48 / 64 / 128) is repeated
+                                 up a ladder of layouts -- 64, 128, 512 slots -- before fsim_sync returns (fsim_overflow_resteps).  0: off -- the sticky
+                                 report of FSIM_INFO_OVERFLOW is then all there is. */
 } fsim_config_t;
 
 void fsim_default_config(fsim_config_t *cfg);
@@ -190,8 +190,11 @@ int fsim_lookahead_stats(fsim_t *, int64_t *out);
  * the default 48 contact slots (what lets eight envs share a CU's LDS) occasionally need more: Sawyer + table_lack_0825 about 1.6 times
  * per million env-steps.  Every step launch keeps each env's pre-step record and lists the envs that dropped contacts; fsim_sync() steps
  * those again from the kept record with a 64-slot layout (one four-wave workgroup per env) and overwrites their record and output rows
- * before it returns.  Reset launches are covered the same way, and models that run on 64 slots are repeated with 128 (one-wave kernel, two
- * slots per lane).  Returns how many env-steps were repeated so far.  FSIM_NO_OVERFLOW_REDO=1 switches it off (the sticky report of
+ * before it returns.  Reset launches are covered the same way, and the re-step is a LADDER: an env that overflows 64 slots too is repeated with
+ * 128 (one-wave kernel, two slots per lane), and one that overflows 128 -- the furniture with eleven and more planks, which the reference's
+ * sampler places inside each other: 240 - 370 simultaneous contacts and every part in one island of up to 84 dofs while the reset throws them
+ * apart -- with 512 (eight slots per lane; islands of more than 64 dofs factored in LDS).  Models start on the rung their size gives them (48,
+ * 64 or 128 slots).  Returns how many env-steps were repeated so far (one count per rung taken).  FSIM_NO_OVERFLOW_REDO=1 switches it off (the sticky report of
  * FSIM_INFO_OVERFLOW is then all there is).  Outputs read in stream order without fsim_sync carry the first pass's rows.
  * Buffer lifetime: the action and output buffers of a step must stay valid (and the action unchanged) until the next fsim_sync or
  * launch of the handle -- the re-step reads and writes them again; every setter of the handle waits for it first. */

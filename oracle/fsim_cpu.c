@@ -62,7 +62,7 @@ typedef struct {
 typedef struct {
   osim_t *sim;
   real *qpos, *qvel, *ctrl, *qfrc_applied, *xfrc_applied, *qacc, *qacc_warmstart, *qfrc_bias, *xpos, *xquat, *xmat, *site_xpos, *site_xmat, *time_, *eq_data;
-  int32_t *contype, *conaff, *eq_active, *cg1, *cg2, *ncon;
+  int32_t *contype, *conaff, *eq_active, *cg1, *cg2, *ncon, *ndropped;
   int group[32];
   unsigned long long connected_sites;
   int connect_step, connected, connected_body1, num_connected, prev_num_connected, site1, site2, success_num_conn, subtask1, subtask2;
@@ -849,6 +849,7 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
     info[FSIM_INFO_NUM_CONNECTED] = e->num_connected; info[FSIM_INFO_SUCCESS] = e->success; info[FSIM_INFO_FAIL] = fail ? 1 : 0;
     info[FSIM_INFO_LAST_SITE1] = e->site1; info[FSIM_INFO_LAST_SITE2] = e->site2; info[FSIM_INFO_EPISODE_LENGTH] = e->episode_length;
     info[FSIM_INFO_CONNECTED_THIS_STEP] = e->connected;
+    if (e->ndropped[0]) info[FSIM_INFO_OVERFLOW] = 2 | (2 << 8); /* the checker itself ran out of contacts / rows (fsim_oracle.c MAXCON / MAXEFC): sticky until the next reset */
     if (c->dense_reward) info[FSIM_INFO_DENSE_PHASE] = dense_phase;
     info[FSIM_INFO_NEEDS_TABLE] = (terminal && c->auto_reset) ? (fail == 2 ? 2 : 1) : 0;
     f = (float)succ; memcpy(&info[FSIM_INFO_SUCCESS_REWARD_F], &f, 4); f = (float)touch; memcpy(&info[FSIM_INFO_TOUCH_REWARD_F], &f, 4);
@@ -946,7 +947,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
     DP(site_xmat, "site_xmat"); DP(time_, "time"); DP(eq_data, "eq_data"); DP(body_pos, "body_pos");
     e->cursor_sel[0] = e->cursor_sel[1] = -1;
     e->contype = osim_iptr(e->sim, "geom_contype", NULL); e->conaff = osim_iptr(e->sim, "geom_conaffinity", NULL); e->eq_active = osim_iptr(e->sim, "eq_active", NULL);
-    e->cg1 = osim_iptr(e->sim, "contact_geom1", NULL); e->cg2 = osim_iptr(e->sim, "contact_geom2", NULL); e->ncon = osim_iptr(e->sim, "ncon", NULL);
+    e->cg1 = osim_iptr(e->sim, "contact_geom1", NULL); e->cg2 = osim_iptr(e->sim, "contact_geom2", NULL); e->ncon = osim_iptr(e->sim, "ncon", NULL); e->ndropped = osim_iptr(e->sim, "ndropped", NULL);
     e->connected_body1 = -1;
     for (int p = 0; p < m->nparts; p++) e->group[p] = p;
   }

@@ -21,8 +21,8 @@
 #define MINVAL 1e-15
 /* a constant of the fp64 checker | of the fp32 control build (tolerances below fp32 resolution would never be met) */
 #define RSEL(d, f) (sizeof(real) == 8 ? (real)(d) : (real)(f))
-#define MAXCON 256
-#define MAXEFC 1024
+#define MAXCON 1024 /* contacts of one substep; more are DROPPED and counted in `ndropped` (never silently: the callers raise on it) */
+#define MAXEFC 4096 /* constraint rows, likewise */
 #define MAXNNZ 128
 #define MAXCONV 64
 
@@ -93,6 +93,7 @@ struct osim {
   int32_t ncon, *contact_geom1, *contact_geom2;
   Row *row;
   int nefc;
+  int32_t ndropped; /* contacts / rows that did not fit MAXCON / MAXEFC since the last osim_reset (sticky) */
   real *conv[MAXCONV]; /* blob entries converted to `real` (fp32 control build only) */
   int nconv;
   int solver_iters, solver_kind; /* kind: 0 PGS, 1 Newton */
@@ -641,7 +642,7 @@ void osim_reset_data(osim_t *s) {
   memset(s->qfrc_applied, 0, sizeof(real) * m->nv); memset(s->xfrc_applied, 0, sizeof(real) * 6 * m->nbody);
   memset(s->qacc, 0, sizeof(real) * m->nv); memset(s->qacc_warmstart, 0, sizeof(real) * m->nv);
   memset(s->qfrc_bias, 0, sizeof(real) * m->nv);
-  s->time_ = 0; s->ncon = 0; s->nefc = 0;
+  s->time_ = 0; s->ncon = 0; s->nefc = 0; s->ndropped = 0;
 }
 
 real *osim_dptr(osim_t *s, const char *name, int *count) {
@@ -664,7 +665,7 @@ int32_t *osim_iptr(osim_t *s, const char *name, int *count) {
   Model *m = &s->m;
   struct { const char *n; int32_t *p; int c; } tab[] = {
       {"geom_contype", m->geom_contype, m->ngeom}, {"geom_conaffinity", m->geom_conaffinity, m->ngeom}, {"eq_active", m->eq_active, m->neq},
-      {"contact_geom1", s->contact_geom1, MAXCON}, {"contact_geom2", s->contact_geom2, MAXCON}, {"ncon", &s->ncon, 1}, {"nefc", &s->nefc, 1}};
+      {"contact_geom1", s->contact_geom1, MAXCON}, {"contact_geom2", s->contact_geom2, MAXCON}, {"ncon", &s->ncon, 1}, {"nefc", &s->nefc, 1}, {"ndropped", &s->ndropped, 1}};
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (strcmp(tab[i].n, name) == 0) { if (count) *count = tab[i].c; return tab[i].p; }
   snprintf(g_err, sizeof g_err, "no int field %s", name);

@@ -54,6 +54,10 @@ def lib():
     return _LIB
 
 
+class OracleCapacity(RuntimeError):
+    """a substep had more contacts / constraint rows than the checker holds"""
+
+
 class SimUnstable(Exception):
     """Analogue of mujoco_py.MujocoException raised from sim.step()."""
 
@@ -89,6 +93,7 @@ class OracleSim:
         self._cg2 = self._iview("contact_geom2")
         self._ncon = self._iview("ncon")
         self._nefc = self._iview("nefc")
+        self._ndropped = self._iview("ndropped")
         # MuJoCo's default solver (the reference sets none: base.xml:4 has impratio and cone only) is Newton on the primal problem; the C
         # struct's zero-initialised kind is PGS.  Round 4: a replay that forgot to say "newton" compared the device with PGS for two
         # rounds (tests/test_demo_sawyer_replay.py) -- the Python wrapper now starts where MuJoCo does; PGS is an explicit choice
@@ -120,6 +125,8 @@ class OracleSim:
         rc = lib().osim_step(self._h)
         if rc:
             raise SimUnstable("oracle step rc=%d" % rc)
+        if self._ndropped[0]:  # the checker never clips silently (fsim_oracle.c MAXCON / MAXEFC)
+            raise OracleCapacity("the oracle dropped %d contacts / rows: raise MAXCON / MAXEFC in oracle/fsim_oracle.c" % int(self._ndropped[0]))
 
     @property
     def ncon(self):

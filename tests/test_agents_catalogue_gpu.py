@@ -12,12 +12,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 # Baxter: two furniture do not compile -- 18 moving robot bodies + 14 / 12 parts exceed the 31 moving bodies a 32-bit ancestor mask holds
-# (furniture_amd/mjcf/compile.py); both are also beyond the device's contact capacity under Sawyer (tests/test_all_furniture_gpu.py)
+# (furniture_amd/mjcf/compile.py)
 NOT_COMPILED = {"Baxter": {"bookcase_grevback_0484", "table_liden_0921"}, "Cursor": set()}
 # the reference's own UniformRandomSampler raises RandomizationError for these with the default jitter (checked by running it in round 4)
 UNPLACEABLE = {"bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"}
-# resets that pass through more simultaneous contacts than 128 slots while the parts settle (230-250, counted with the oracle): reset() raises
-OVERFLOWS = {"Baxter": {"bookcase_billy_0191"}, "Cursor": {"bookcase_billy_0191", "table_liden_0921"}}
+# resets that drop contacts: none since round 6 (bookcase_billy_0191 and table_liden_0921 pass through 240-270 simultaneous contacts while the planks
+# are thrown apart -- beyond 128 slots; the re-step ladder's last rung, 512 slots, takes them: tests/test_overflow_restep_gpu.py)
+OVERFLOWS = {"Baxter": set(), "Cursor": set()}
 
 
 def sweep(agent):

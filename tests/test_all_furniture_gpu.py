@@ -72,11 +72,12 @@ def test_every_compiled_sawyer_furniture_resets_and_steps():
     print("ran %d furniture models (%d of them with more than 64 dofs), refused %d: %s; placement sampler gives up (as the reference's does) on %s" % (
         len(ran), sum(load_compiled("Sawyer", x).nv > 64 for x in ran), len(refused), refused, unplaceable))
     print("overflowed or failed (name, parts, fail | overflow << 1):", troubled)
-    # two models do not fit even 128 slots: bookcase_billy_0191 (11 planks) and table_liden_0921 (12 parts) pass through 230-250
-    # simultaneous contacts while the reset settles them (counted with the oracle); their resets raise ContactOverflowError
-    assert refused == [] and sorted(x[0] for x in troubled) == ["bookcase_billy_0191", "table_liden_0921"], (refused, troubled)
+    # (through round 5 two models raised here: bookcase_billy_0191 (11 planks) and table_liden_0921 (12 parts) pass through 240-270 simultaneous
+    #  contacts, all parts in one island, while the reset throws the planks apart; round 6: the re-step ladder's last rung takes them --
+    #  512 slots, islands of more than 64 dofs: tests/test_overflow_restep_gpu.py)
+    assert refused == [] and troubled == [], (refused, troubled)
     assert sorted(unplaceable) == ["bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"], unplaceable
-    assert len(ran) == len(names) - 5
+    assert len(ran) == len(names) - 3
     # since round 5 all 64 furniture of the reference compile (furniture/tests/test_furniture_init.py:14-55 resets them all): the three
     # that collide mesh geoms run like the others (their hulls: tests/test_mesh.py)
     assert len(names) == 64 and {"chair_agne_0010", "chair_bertil_0148", "shelf_liden_0922"} <= set(ran)
@@ -122,24 +123,6 @@ def test_config_assembled_constructs_for_furniture_with_more_welds_than_recipe_s
         act = env.sim.get_state("eq_active")["eq_active"]
         assert int(act.sum()) == 2 * m.neq, name
         env.close()
-
-
-def test_the_fourteen_part_bookcase_says_when_it_drops_contacts():
-    """Sawyer + bookcase_grevback_0484 (SURVEY section 8's size table: 14 parts, 93 dofs) as the reference places it: the XML stacks the
-    fourteen planks at the origin with placement radii of 5 mm and the jitter is 2 cm, so -- for the seeds the sampler places at all --
-    the episode starts with the planks INSIDE each other: 256 contacts and one 84-dof island at the first substep of the reset (measured
-    with the oracle), which MuJoCo resolves by throwing the planks apart.  That is beyond the 128 slots / 64-dof islands of the device
-    path, and reset() says so (the overflow flag is sticky in the env record) instead of integrating wrong physics."""
-    from furniture_amd.envs import ContactOverflowError, FurnitureSawyerEnv, make_config
-    from furniture_amd.mjcf.model import load_compiled
-    m = load_compiled("Sawyer", "bookcase_grevback_0484")
-    assert m.nparts == 14 and m.nv == 93 and float(np.max(m.part_hradius)) < 0.01
-    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="bookcase_grevback_0484", max_episode_steps=50, seed=3)
-    env = FurnitureSawyerEnv(make_config(**kw))
-    assert env._b.sim.max_contacts == 128 and env._b.sim.kernel_variant == "generic2"
-    with pytest.raises(ContactOverflowError):
-        env.reset()
-    env.close()
 
 
 def test_the_fourteen_part_bookcase_matches_the_oracle_env_from_a_laid_out_start():

@@ -125,3 +125,102 @@ def test_a_reset_beyond_64_slots_takes_the_second_rung_to_128(furniture):
     sticky = env._b.sim.get_state("env_block")["env_block"].view(torch.int32)[:, E_OVERFLOW].cpu().numpy()
     assert not sticky.any()
     env.close()
+
+
+def _sampler_start(m, name, seed):
+    """the state the reset's first substep sees: robot at its initial pose, the parts where the reference's sampler puts them"""
+    parts, _ = ResetTableSampler(m, make_config(furniture_name=name), seed, 0, 1).draw()
+    q = np.array(m.qpos0, dtype=np.float64)
+    q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+    pq = np.asarray(parts).reshape(-1, 7)
+    for i in range(m.nparts):
+        q[m.part_qposadr[i]:m.part_qposadr[i] + 7] = pq[i]
+    return q
+
+
+@pytest.mark.parametrize("furniture,tol", [("table_liden_0921", 1e-6), ("bookcase_grevback_0484", 5e-4)])
+def test_the_512_slot_kernel_against_the_oracle_on_planks_inside_each_other(furniture, tol, monkeypatch):
+    """The last rung's kernel by itself (`generic8`: eight contact slots per lane in the Newton solve; every island factored in LDS by
+    fs_chol_all_lds because one island holds more than 64 dofs), as the base kernel of a one-env batch (FSIM_NCON_MAX=512), over the first
+    substeps of the start the reference's sampler gives these furniture: the planks INSIDE each other -- table_liden_0921 268 contacts and
+    bookcase_grevback_0484 370 (the fourteen planks stacked at one point: coincident boxes), all parts in ONE island of 72 / 84 dofs, thrown
+    apart at 80 - 480 m/s.  Against OracleSim (fp64; its capacity is 1024 contacts and it raises when that is short): the same contact count
+    (+ 1: the robot's l0 / base pair at exactly zero distance, which fp32 lists), qpos within 1e-6 for table_liden's first two substeps (measured
+    1e-7) and 5e-4 for the coincident planks of grevback (measured 6e-5 / 1.1e-4: which face pair a box-box contact of two coincident boxes
+    picks is a tie that fp32 breaks differently)."""
+    from oracle.oracle_sim import OracleSim
+    monkeypatch.setenv("FSIM_NCON_MAX", "512")
+    m = load_compiled("Sawyer", furniture)
+    q = _sampler_start(m, furniture, 3)
+    sim = FSim(m, 1)
+    assert sim.kernel_variant == "generic8" and sim.max_contacts == 512
+    sim.set_state(qpos=q[None], qvel=np.zeros((1, m.nv)), qacc_warmstart=np.zeros((1, m.nv)))
+    o = OracleSim(m)
+    o.set_solver(100, 1e-10, "newton")
+    o.reset()
+    o.data.qpos[:] = q
+    o.forward()
+    peak = 0
+    for t in range(2):
+        sim.physics_step(1)
+        o.step()
+        st = sim.get_state("qpos", "qvel", "ncon", "solver_iters")
+        peak = max(peak, o.ncon)
+        assert int(st["ncon"][0]) in (o.ncon, o.ncon + 1), (t, int(st["ncon"][0]), o.ncon)
+        assert abs(int(st["solver_iters"][0]) - o.last_solver_iters) <= 3
+        assert np.abs(st["qpos"][0].cpu().numpy() - o.data.qpos).max() < tol, t
+        assert np.abs(st["qvel"][0].cpu().numpy() - o.data.qvel).max() < 1e-3 * np.abs(o.data.qvel).max(), t
+    assert peak > 256 and np.abs(o.data.qvel).max() > 30.0
+    sim.close()
+
+
+@pytest.mark.parametrize("furniture,tol", [("table_liden_0921", 2e-3), ("bookcase_billy_0191", None), ("bookcase_grevback_0484", None)])
+def test_a_reset_with_the_planks_inside_each_other_takes_the_last_rung_to_512(furniture, tol, monkeypatch):
+    """the three Sawyer furniture whose reset() raised.  They run on 128 slots (two per lane); the reset the reference's
+    sampler gives them starts with the planks inside each other -- 240 to 370 contacts and every part in one island of 66 to 84 dofs for the
+    first substeps -- and is repeated on the ladder's last rung: 512 slots on the one-wave kernel `generic8`, islands of more than 64 dofs
+    through the LDS-resident factorisation.  reset() returns (no sticky report), the rung is counted, and the observation is the fp64 oracle env's:
+    within 2e-3 for table_liden (measured 3e-4) and, for the two bookcases, in the median (the planks start COINCIDENT, fly apart at up to
+    480 m/s and are still tumbling at 10 - 16 m/s when the reset's 401 substeps end: a part's pose is then sensitive to the last bit, in the
+    oracle's own fp32 build too)."""
+    from furniture_amd.envs import ContactOverflowError, FurnitureSawyerEnv
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Sawyer", furniture)
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name=furniture, max_episode_steps=50, seed=3)
+    monkeypatch.setenv("FSIM_NO_OVERFLOW_REDO", "1")
+    env = FurnitureSawyerEnv(make_config(**kw))
+    assert env._b.sim.max_contacts == 128 and env._b.sim.kernel_variant == "generic2"
+    with pytest.raises(ContactOverflowError):  # without the ladder the reset says that it dropped contacts (sticky report), as in round 5
+        env.reset()
+    env.close()
+    monkeypatch.delenv("FSIM_NO_OVERFLOW_REDO")
+    env = FurnitureSawyerEnv(make_config(**kw))
+    orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=3, solver_tolerance=1e-10))
+    peak = [0]
+    step0 = orc.sim.step
+
+    def counted():
+        step0()
+        peak[0] = max(peak[0], orc.sim.ncon)
+    orc.sim.step = counted
+    o = orc.flat_obs(orc.reset())
+    assert peak[0] > 128, peak[0]
+    d = env.reset()
+    assert env._b.sim.overflow_resteps() >= 1
+    got = np.concatenate([d["object_ob"], d["robot_ob"]])
+    dd = np.abs(got - o)
+    assert np.isfinite(got).all() and np.median(dd) < 5e-4, float(np.median(dd))
+    if tol is not None:
+        assert dd.max() < tol, float(dd.max())
+    assert np.abs(d["robot_ob"] - o[7 * m.nparts:]).max() < 5e-4  # the robot is not part of the pile
+    sticky = env._b.sim.get_state("env_block")["env_block"].view(torch.int32)[:, E_OVERFLOW].cpu().numpy()
+    assert not sticky.any()
+    rng = np.random.RandomState(2)
+    for t in range(3):  # the steps that follow (parts still settling: some overflow 128 slots again and are re-stepped)
+        a = rng.uniform(-1, 1, 9)
+        ob, r, done, info = env.step(a)
+        ob_o, r_o, done_o, _ = orc.step(a)
+        g = np.concatenate([ob["object_ob"], ob["robot_ob"]])
+        assert np.isfinite(g).all() and int(info["contact_overflow"]) == 0 and done == done_o
+        assert np.median(np.abs(g - orc.flat_obs(ob_o))) < 1e-3, t
+    env.close()
