@@ -651,7 +651,7 @@ static int build_model(fsim *s) {
   m.timestep = opt[0]; m.gravity[0] = opt[1]; m.gravity[1] = opt[2]; m.gravity[2] = opt[3]; m.impratio = opt[4];
   m.meaninertia_scale = 1.0f / fmaxf(trace[0], 1e-15f);
   if (m.nv > 128) FAIL(FSIM_ENOMEM, "nv=%d > 128: the Newton factorisation maps the dofs on two passes of 64 solver lanes", m.nv);
-  if (m.nr > 31) FAIL(FSIM_ENOMEM, "more than 31 moving bodies");
+  if (m.nr > 32) FAIL(FSIM_ENOMEM, "more than 31 moving bodies (the world body + 31: subtree masks are one 32-bit word)");
   if (m.ncp > 65535) FAIL(FSIM_ENOMEM, "too many candidate pairs");
   if (m.ncg > 255) FAIL(FSIM_ENOMEM, "more than 255 colliding geoms (broadphase records hold 8-bit geom indices)");
   LI(r_parent, "r_parent"); LI(r_jtype, "r_jtype"); LI(r_qposadr, "r_qposadr"); LI(r_dofadr, "r_dofadr"); LI(r_dofnum, "r_dofnum");

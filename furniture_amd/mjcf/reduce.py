@@ -237,7 +237,7 @@ def reduce_model(A):
     dof_parent = A["dof_parentid"]
     chain_adr, chain_len, chain = np.zeros(nr, np.int32), np.zeros(nr, np.int32), []
     ancmask = np.zeros(nr, dtype=np.int64)
-    if nr > 31:
+    if nr > 32:  # (the world body is one of them: bit 0 is never set, bit 31 is the last body's)
         raise NotImplementedError("more than 31 moving bodies (ancestor bitmask is 32 bits)")
     for k in range(1, nr):
         lst = []
@@ -275,7 +275,7 @@ def reduce_model(A):
         part_sites += ss
     extra = dict(
         r_chainadr=chain_adr, r_chainlen=chain_len, chain_dofs=np.array(chain, dtype=np.int32),
-        r_ancmask=ancmask.astype(np.int32), tree_bodyadr=tree_bodyadr, tree_bodynum=tree_bodynum,
+        r_ancmask=ancmask.astype(np.uint32).view(np.int32), tree_bodyadr=tree_bodyadr, tree_bodynum=tree_bodynum,
         M_i=np.array(M_i, dtype=np.int32), M_j=np.array(M_j, dtype=np.int32),
         lim_dof=np.array(lim, dtype=np.int32), lim_range=dof_range[lim].reshape(-1, 2), lim_margin=dof_lmargin[lim],
         lim_solref=dof_lsolref[lim].reshape(-1, 2), lim_solimp=dof_lsolimp[lim].reshape(-1, 5),

@@ -11,9 +11,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-# Baxter: two furniture do not compile -- 18 moving robot bodies + 14 / 12 parts exceed the 31 moving bodies a 32-bit ancestor mask holds
-# (furniture_amd/mjcf/compile.py)
-NOT_COMPILED = {"Baxter": {"bookcase_grevback_0484", "table_liden_0921"}, "Cursor": set()}
+# Baxter: one furniture does not compile -- 19 moving robot bodies + 14 parts exceed the 31 moving bodies (+ the world body) that a 32-bit subtree
+# mask holds (furniture_amd/mjcf/reduce.py).  table_liden_0921 (12 parts: 32 bodies with the world, bit 31 in use) compiles since round 6.
+NOT_COMPILED = {"Baxter": {"bookcase_grevback_0484"}, "Cursor": set()}
 # the reference's own UniformRandomSampler raises RandomizationError for these with the default jitter (checked by running it in round 4)
 UNPLACEABLE = {"bookcase_grevback_0484", "cabinet_akurum_0021", "table_hemnes_0539"}
 # resets that drop contacts: none since round 6 (bookcase_billy_0191 and table_liden_0921 pass through 240-270 simultaneous contacts while the planks
@@ -109,4 +109,35 @@ def test_baxter_reset_matches_the_oracle_env(furniture):
         ob_o, r_o, done_o, _ = orc.step(a)
         assert np.abs(np.concatenate([ob["object_ob"], ob["robot_ob"]]) - orc.flat_obs(ob_o)).max() < 2e-3, t
         assert abs(r - r_o) < 1e-4 and done == done_o
+    env.close()
+
+
+def test_baxter_with_the_last_body_on_bit_31_resets_like_the_oracle_env():
+    """Baxter + table_liden_0921: 19 robot bodies + 12 parts + the world = 32 reduced bodies, the most a 32-bit subtree mask holds (the last
+    part sits on bit 31: every mask loop of the kernels is sign-agnostic -- `mm &= mm - 1`, `__ffs`).  91 dofs, 128 contact slots; the reset
+    starts with the parts inside each other (268 contacts, counted with the oracle) and takes the re-step ladder's last rung; against the fp64
+    oracle env: the robot within 5e-4, the observation in the median (parts still moving when the reset ends: tests/test_overflow_restep_gpu.py)."""
+    from furniture_amd.envs import FurnitureBaxterEnv, make_config
+    from furniture_amd.mjcf.model import load_compiled
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    m = load_compiled("Baxter", "table_liden_0921")
+    assert len(m.r_ancmask) == 32 and int(m.r_ancmask[-1]) < 0 and m.nv == 91
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name="table_liden_0921", max_episode_steps=50, seed=3)
+    env = FurnitureBaxterEnv(make_config(**kw))
+    orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=3, solver_tolerance=1e-10))
+    o = orc.flat_obs(orc.reset())
+    d = env.reset()
+    assert env._b.sim.overflow_resteps() >= 1
+    got = np.concatenate([d["object_ob"], d["robot_ob"]])
+    dd = np.abs(got - o)
+    assert np.isfinite(got).all() and np.median(dd) < 5e-4 and dd[7 * m.nparts:].max() < 5e-4, (float(np.median(dd)), float(dd.max()))
+    print("Baxter + table_liden_0921 reset vs oracle env: max %.2e median %.1e" % (dd.max(), np.median(dd)))
+    rng = np.random.RandomState(2)
+    for t in range(2):
+        a = rng.uniform(-1, 1, env.dof)
+        ob, r, done, info = env.step(a)
+        ob_o, r_o, done_o, _ = orc.step(a)
+        g = np.concatenate([ob["object_ob"], ob["robot_ob"]])
+        assert np.isfinite(g).all() and int(info["contact_overflow"]) == 0 and done == done_o
+        assert np.median(np.abs(g - orc.flat_obs(ob_o))) < 1e-3, t
     env.close()
