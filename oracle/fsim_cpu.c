@@ -11,7 +11,7 @@
  *
  * Scope: the arm agents (Sawyer, Baxter) under control_type impedance and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
  * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
- * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes.  ik / arm controllers, pre-assembled starts, init
+ * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557).  ik / arm controllers, init
  * states, phase_ob and reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
@@ -97,6 +97,10 @@ struct fsim {
                         `perturbed twin` of scripts/divergence_control.py; 0 in every test */
   real *conv[16];    /* float64 blob entries converted to `real` (fp32 control build only) */
   int nconv;
+  /* fsim_set_preassembled: recipe steps (pre_recipe: rows = connector indices of the recipe's site2 and site1 + the angle, NaN none) or weld ids */
+  int n_pre, pre_recipe, success_num_conn;
+  int32_t pre_tab[16][2];
+  float pre_angle[16];
 };
 
 /* ---- small vector / quaternion helpers (furniture_amd/transform_utils.py; quaternions wxyz unless said otherwise) */
@@ -239,6 +243,8 @@ static void next_subtask(const struct fsim *s, Env *e) {
 }
 
 static void dense_reset(const struct fsim *s, Env *e);
+static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align);
+static void project_connector_quat(const struct fsim *s, Env *e, int k1, int k2, int has_angle, real angle);
 static void env_reset(const struct fsim *s, int idx) {
   const EnvModel *m = &s->m;
   Env *e = &s->env[idx];
@@ -252,13 +258,24 @@ static void env_reset(const struct fsim *s, int idx) {
   e->connect_step = 0; e->connected = 0; e->connected_sites = 0; e->connected_body1 = -1; e->num_connected = 0; e->prev_num_connected = 0;
   e->site1 = e->site2 = -1;
   e->cursor_sel[0] = e->cursor_sel[1] = -1;
-  e->success_num_conn = m->nparts - 1;
+  e->success_num_conn = s->success_num_conn; /* _success_num_conn (furniture.py:1476-1481) */
   for (int k = 0; k < m->neq; k++) e->eq_active[k] = 0;
   memcpy(e->eq_data, m->eq_data0, sizeof(real) * 7 * m->neq);
+  if (s->n_pre > 0 && !s->pre_recipe) /* no recipe (or config.assembled): the listed welds are on from the start, their groups merged (furniture.py:1493-1503) */
+    for (int i = 0; i < s->n_pre; i++) { int k = s->pre_tab[i][0]; e->eq_active[k] = 1; merge_groups(e, m->eq_part1[k], m->eq_part2[k]); }
   const float *tp = s->tab_parts + (size_t)idx * 7 * m->nparts;
   for (int i = 0; i < m->nparts; i++) { real q[7]; for (int k = 0; k < 7; k++) q[k] = (real)tp[7 * i + k]; set_part_qpos(s, e, i, q, q + 3); }
   settle(s, e);
-  if (m->has_recipe) settle(s, e);
+  if (m->has_recipe) {
+    /* _preassemble (furniture.py:1542-1557): the listed recipe steps are connected during the reset -- _connect(site2, site1), always auto-aligned, at the
+       recipe's angle (_project_connector_quat) -- and the latches of a connect cleared */
+    for (int i = 0; s->pre_recipe && i < s->n_pre; i++) {
+      project_connector_quat(s, e, s->pre_tab[i][0], s->pre_tab[i][1], s->pre_angle[i] == s->pre_angle[i], (real)s->pre_angle[i]);
+      do_connect(s, e, s->pre_tab[i][0], s->pre_tab[i][1], 1);
+      e->connected = 0; e->connected_body1 = -1;
+    }
+    settle(s, e);
+  }
   const float *tn = s->tab_noise ? s->tab_noise + (size_t)idx * s->n_noise * m->narmj : NULL;
   gravity_comp(s, e);
   init_robot(s, e, tn);
@@ -399,7 +416,20 @@ static void stop_selected(const struct fsim *s, Env *e) {
   for (int i = 0; i < s->m.nparts; i++)
     for (int q = 0; q < 2; q++) if (e->cursor_sel[q] >= 0 && find_group(e, i) == find_group(e, e->cursor_sel[q])) { stop_object(s, e, i, 1); break; }
 }
-static void do_connect(const struct fsim *s, Env *e, int k1, int k2) {
+/* _project_connector_quat(k1, k2, angle) (furniture.py:1201-1222) -> e->target_quat: connector k2's orientation when aligned with connector k1, at `angle` degrees
+   about k1's up axis or (no angle) at the nearer of the two rotations that bring the forward axes together */
+static void project_connector_quat(const struct fsim *s, Env *e, int k1, int k2, int has_angle, real angle) {
+  const EnvModel *m = &s->m;
+  real up1[3], up2[3], f1[3], f2[3], fr[3];
+  site_axes(e, m->conn_siteid[k1], up1, f1); site_axes(e, m->conn_siteid[k2], up2, f2);
+  if (!has_angle) {
+    real cs = cos_siml(f1, f2), rp[3], rn[3];
+    rotate_vector_cos(rp, f1, up1, cs, 1); rotate_vector_cos(rn, f1, up1, cs, -1);
+    memcpy(fr, cos_siml(rp, f2) > cos_siml(rn, f2) ? rp : rn, sizeof fr);
+  } else rotate_vector(fr, f1, up1, angle);
+  lookat_wxyz(e->target_quat, up1, fr);
+}
+static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align) {
   const EnvModel *m = &s->m;
   e->connected_sites |= (1ull << k1) | (1ull << k2);
   e->site1 = m->conn_siteid[k1]; e->site2 = m->conn_siteid[k2];
@@ -410,7 +440,7 @@ static void do_connect(const struct fsim *s, Env *e, int k1, int k2) {
     int gp = find_group(e, p);
     if ((gp == gA || gp == gB) && e->contype[g] != 0) { e->contype[g] = (1 << 30) - 1 - (1 << (gA + 1)); e->conaff[g] = 1 << (gA + 1); }
   }
-  if (s->cfg.auto_align) { /* _move_site_to_target(k2, [site1 pos, target quat]) */
+  if (align) { /* _move_site_to_target(k2, [site1 pos, target quat]) */
     real tq[7], base[7], body[7], np_[3], nq[4], nsp[3], nsq[4], tr[3];
     site_pose(s, e, m->conn_siteid[k1], tq);
     memcpy(tq + 3, e->target_quat, 4 * sizeof(real));
@@ -500,7 +530,7 @@ static int try_connect(const struct fsim *s, Env *e, int part1, int part2) {
           e->connect_step += 1;
           return 0;
         }
-        do_connect(s, e, k1, k2);
+        do_connect(s, e, k1, k2, s->cfg.auto_align);
         e->connect_step = 0;
         return 1;
       }
@@ -615,7 +645,7 @@ static void dense_update(const struct fsim *s, Env *e) { /* _update_reward_varia
   else e->dn.prev_init_eef = dist3(o.eef, e->dn.init_eef);
   e->dn.prev_grasp = -1; e->dn.prev_lift_z = (real)T[DS_WAYPOINT_Z]; e->dn.prev_lift_xy = 0;
 }
-static void dense_reset(const struct fsim *s, Env *e) { memset(&e->dn, 0, sizeof e->dn); e->dn.subtask = 0 /* n_pre */; dense_update(s, e); }
+static void dense_reset(const struct fsim *s, Env *e) { memset(&e->dn, 0, sizeof e->dn); e->dn.subtask = s->n_pre < s->dnsub ? s->n_pre : 0; /* _reset_reward_variables (:128-139): the first subtask is len(preassembled) */ dense_update(s, e); }
 static int dense_next_subtask(const struct fsim *s, Env *e) { e->dn.subtask += 1; if (e->dn.subtask == e->success_num_conn) return 1; dense_update(s, e); return 0; }
 static real rmin(real a, real b) { return a < b ? a : b; }
 static real rmax(real a, real b) { return a > b ? a : b; }
@@ -931,6 +961,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   blob_get(s->blob, nbytes, "grip_qposadr", 1, &cnt); m->ngripj = (int)cnt;
   { const int32_t *fl = (const int32_t *)blob_get(s->blob, nbytes, "flags", 1, &cnt); m->has_recipe = fl && cnt > 0 ? fl[0] : 0; }
   s->n_substeps = s->cfg.n_substeps > 0 ? s->cfg.n_substeps : 50;
+  s->success_num_conn = m->nparts - 1;
   { const char *pv = getenv("FSIM_CPU_PERTURB"); s->perturb = pv ? (real)atof(pv) : 0; }
   s->dof = m->agent == 2 ? 15 : m->narmj + m->narm + 1;            /* (move, rotate, select) x 2 + connect, furniture_cursor.py:56 */
   s->obs_dim = 7 * m->nparts + (m->agent == 2 ? 8 : 29 * m->narm);
@@ -1091,9 +1122,22 @@ int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *
   return FSIM_OK;
 }
 int fsim_set_preassembled(fsim_t *s, int n_pre, const int32_t *ids, const int32_t *conn_pairs, const float *angles, int num_connects) {
-  (void)s; (void)ids; (void)conn_pairs; (void)angles;
-  if (n_pre == 0 && num_connects < 0) return FSIM_OK;
-  NOT_SERVED("a pre-assembled start");
+  if (!s || n_pre < 0 || n_pre > 16 || (n_pre > 0 && !ids)) FAIL(FSIM_EINVAL, "fsim_set_preassembled: bad arguments");
+  const int recipe = s->m.has_recipe && conn_pairs != NULL; /* (no connector pairs: the list holds weld ids -- config.assembled) */
+  if (n_pre > 0 && recipe && !angles) FAIL(FSIM_EINVAL, "fsim_set_preassembled: recipe steps need their angles next to the connector pairs");
+  for (int i = 0; i < n_pre; i++) {
+    if (recipe) {
+      int k1 = conn_pairs[2 * i], k2 = conn_pairs[2 * i + 1];
+      if (k1 < 0 || k1 >= s->m.nconn || k2 < 0 || k2 >= s->m.nconn) FAIL(FSIM_EINVAL, "fsim_set_preassembled: connector index out of range in row %d", i);
+      s->pre_tab[i][0] = k1; s->pre_tab[i][1] = k2; s->pre_angle[i] = angles[i];
+    } else {
+      if (ids[i] < 0 || ids[i] >= s->m.neq) FAIL(FSIM_EINVAL, "fsim_set_preassembled: weld id %d out of range (%d welds)", ids[i], s->m.neq);
+      s->pre_tab[i][0] = ids[i]; s->pre_tab[i][1] = 0;
+    }
+  }
+  s->n_pre = n_pre; s->pre_recipe = recipe;
+  s->success_num_conn = num_connects >= 0 ? num_connects + n_pre : s->m.nparts - 1; /* furniture.py:1476-1481 */
+  return FSIM_OK;
 }
 int fsim_dense_replay(int device, const float *coef, int ncoef, const float *subtasks, int nsub, int n_pre, const float *obs0, const float *obs, const float *ac, int dof,
                       const uint8_t *connected, int T, float *out_reward, int32_t *out_flags) {

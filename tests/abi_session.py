@@ -42,6 +42,7 @@ class Abi:
         L.fsim_set_max_episode_steps.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.fsim_physics_forward.argtypes = [ctypes.c_void_p]
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.fsim_set_preassembled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 
     def check(self, rc):
         if rc != 0:
@@ -105,6 +106,17 @@ class Session:
         """furniture_amd.dense.pack_dense(model) -> the tables of a dense_reward = 1 handle (host pointers on both libraries)"""
         coef, subtasks = np.ascontiguousarray(coef, dtype=np.float32), np.ascontiguousarray(subtasks, dtype=np.float32)
         self.abi.check(self.abi.L.fsim_set_dense_reward(self.h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
+    def set_preassembled(self, model, preassembled, num_connects=None, welds=False):
+        """config.preassembled / set_subtask / config.assembled (welds=True: the list holds weld ids whatever the furniture) -- fsim_set_preassembled, host
+        pointers on both libraries; rows as furniture_amd.sim.FSim.set_preassembled builds them"""
+        from furniture_amd.sim import preassembled_rows
+        if welds:  # weld ids as they are: no recipe lookup
+            ids, pairs, angles = np.ascontiguousarray(list(preassembled), dtype=np.int32), None, None
+        else:
+            ids, pairs, angles = preassembled_rows(model, preassembled)
+        self.abi.check(self.abi.L.fsim_set_preassembled(self.h, len(ids), ids.ctypes.data if len(ids) else None, None if pairs is None else pairs.ctypes.data,
+                                                        None if angles is None else angles.ctypes.data, -1 if num_connects is None else int(num_connects)))
 
     def reset(self):
         self.abi.check(self.abi.L.fsim_reset(self.h, None, self.abi.ptr(self.obs)))

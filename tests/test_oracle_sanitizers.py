@@ -85,6 +85,23 @@ sb.set_reset_tables(eb.reset_draws["part_qpos"].reshape(1, -1), np.stack(eb.rese
 sb.reset()
 sb.step(counter_actions(1, 0, 0, 17)[None])
 sb.close(); ses.close()
+# end of round 6: a pre-assembled start (two recipe steps connected inside the reset) and one with weld ids (no recipe file)
+sp = Session(Abi(os.environ["FSIM_CPU_SAN"]), m.to_blob(), 1, max_episode_steps=4, auto_reset=0)
+sp.set_preassembled(m, [0, 1])
+sp.set_reset_tables(parts[:1], noise[:1])
+sp.reset()
+o_, r_, d_, i_ = sp.step(counter_actions(1, 0, 0, 9)[None])
+assert i_[0, 0] == 2, i_[0]
+sp.close()
+w = load_compiled("Sawyer", "swivel_chair_0700")
+ew = FurnitureEnvOracle(w, OracleConfig(seed=9, max_episode_steps=4, preassembled=[1]))
+ew.reset()
+sw = Session(Abi(os.environ["FSIM_CPU_SAN"]), w.to_blob(), 1, max_episode_steps=4, auto_reset=0)
+sw.set_preassembled(w, [1])
+sw.set_reset_tables(ew.reset_draws["part_qpos"].reshape(1, -1), np.stack(ew.reset_draws["noise"]).reshape(1, -1))
+sw.reset()
+sw.step(counter_actions(1, 0, 0, 9)[None])
+sw.close()
 # round 6: the Cursor agent -- the MuJoCo-recorded demo's first 64 frames (selection by contact, carried groups, the ten approach steps, the connect)
 from tests.test_demo_replay import D
 c = load_compiled("Cursor", "swivel_chair_0700")
