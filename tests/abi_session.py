@@ -43,6 +43,7 @@ class Abi:
         L.fsim_physics_forward.argtypes = [ctypes.c_void_p]
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.fsim_set_preassembled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.fsim_set_init_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 
     def check(self, rc):
         if rc != 0:
@@ -106,6 +107,15 @@ class Session:
         """furniture_amd.dense.pack_dense(model) -> the tables of a dense_reward = 1 handle (host pointers on both libraries)"""
         coef, subtasks = np.ascontiguousarray(coef, dtype=np.float32), np.ascontiguousarray(subtasks, dtype=np.float32)
         self.abi.check(self.abi.L.fsim_set_dense_reward(self.h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
+    def set_init_state(self, qpos, qvel, mask=None):
+        """FurnitureEnv.set_init_qpos for the masked envs (qpos = None: back to sampled resets) -- fsim_set_init_state, host pointers on both libraries"""
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if qpos is None:
+            self.abi.check(self.abi.L.fsim_set_init_state(self.h, None if mk is None else mk.ctypes.data, None, None))
+            return
+        q, v = np.ascontiguousarray(qpos, dtype=np.float32), np.ascontiguousarray(qvel, dtype=np.float32)
+        self.abi.check(self.abi.L.fsim_set_init_state(self.h, None if mk is None else mk.ctypes.data, q.ctypes.data, v.ctypes.data))
 
     def set_preassembled(self, model, preassembled, num_connects=None, welds=False):
         """config.preassembled / set_subtask / config.assembled (welds=True: the list holds weld ids whatever the furniture) -- fsim_set_preassembled, host

@@ -241,6 +241,47 @@ def test_native_checker_preassembled_starts_match_the_python_restatement(cpu_abi
     ses.close()
 
 
+def test_native_checker_set_init_qpos_matches_the_python_restatement(cpu_abi, sawyer_lack):
+    """fsim_set_init_state in the checker (round 6; it refused): the masked envs' resets start from a given state -- no placement, no settling, no robot
+    initialisation, no reset table consumed (furniture.py:1505-1519) -- the others from their tables; against the Python env, then the sampled reset again
+    after set_init_qpos(None)."""
+    m = sawyer_lack
+    n = 3
+    envs, obs_o, parts, noise = _oracles(m, n, max_episode_steps=150)
+    q0 = np.stack([e.sim.data.qpos.copy() for e in envs]).astype(np.float32)  # (a settled state of each env, float32 as the boundary carries it)
+    q0[:, m.arm_qposadr[0]] += 0.2
+    mask = np.array([1, 0, 1], dtype=np.uint8)
+    for e in (0, 2):
+        envs[e].set_init_qpos({"qpos": q0[e].astype(np.float64), "qvel": np.zeros(m.nv)})
+    obs_o = [e.reset() for e in envs]
+    parts2 = np.stack([e.reset_draws["part_qpos"].reshape(-1) if "part_qpos" in e.reset_draws else parts[i] for i, e in enumerate(envs)])
+    noise2 = np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) if e.reset_draws["noise"] else noise[i] for i, e in enumerate(envs)])
+    ses = Session(cpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0)
+    ses.set_init_state(q0, np.zeros((n, m.nv)), mask=mask)
+    ses.set_reset_tables(parts2, noise2)
+    obs = ses.reset()
+    for e in range(n):
+        assert np.abs(obs[e] - envs[e].flat_obs(obs_o[e])).max() < 2e-6, e
+    assert not envs[0].reset_draws["noise"] and envs[1].reset_draws["noise"]  # the init-state envs drew nothing
+    for t in range(2):
+        a = np.stack([counter_actions(9, i, t, ses.dof) for i in range(n)])
+        obs, rew, done, info = ses.step(a)
+        for e in range(n):
+            ob, r, d, inf = envs[e].step(a[e])
+            assert np.abs(obs[e] - envs[e].flat_obs(ob)).max() < 5e-6 and abs(float(rew[e]) - r) < 1e-6
+    with pytest.raises(RuntimeError, match="not combined"):
+        ses.set_preassembled(m, [0])
+    ses.set_init_state(None, None)
+    for e in (0, 2):
+        envs[e].set_init_qpos(None)
+    obs_o = [e.reset() for e in envs]
+    ses.set_reset_tables(np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs]), np.stack([np.stack(e.reset_draws["noise"]).reshape(-1) for e in envs]))
+    obs = ses.reset()
+    for e in range(n):
+        assert np.abs(obs[e] - envs[e].flat_obs(obs_o[e])).max() < 2e-6, e
+    ses.close()
+
+
 def _root(g, i):
     while g[i] != i:
         i = g[i]
@@ -398,7 +439,7 @@ def test_same_session_against_both_libraries(cpu_abi, sawyer_lack, gpu_lib):
         s.close()
 
 
-def _episodes(cpu_abi, agent, furniture, n, T, steps, seed=77, pre=None, num_connects=None, quat_sign=False):
+def _episodes(cpu_abi, agent, furniture, n, T, steps, seed=77, pre=None, num_connects=None, quat_sign=False, init_state=False):
     """(device, native checker) stepped side by side through the one session with auto-reset; returns per step the observation
     differences [n, obs_dim], the mask of envs that ended an episode, and the count of rewards equal to 1e-4.  Asserted inside: done and
     the success / fail / episode-length / needs-table words equal at EVERY step."""
@@ -414,6 +455,14 @@ def _episodes(cpu_abi, agent, furniture, n, T, steps, seed=77, pre=None, num_con
         if pre is not None:
             s.set_preassembled(m, pre, num_connects)
         s.set_reset_tables(*t0)
+    if init_state:  # set_init_qpos on every other env: a settled state (the checker's own first reset) with the arm moved, for every reset that follows
+        pair[1].reset()
+        q = pair[1].get_state(m, "qpos")["qpos"].astype(np.float32)
+        q[:, m.arm_qposadr[1]] += 0.3
+        msk = (np.arange(n) % 2 == 0).astype(np.uint8)
+        for s in pair:
+            s.set_init_state(q, np.zeros((n, m.nv), dtype=np.float32), mask=msk)
+
     def same_sign(x, ref):
         """(quat_sign) each part's quaternion compared up to its sign: a recipe's 90 / 270 degree targets put lookat_to_quat exactly on a branch tie that
         fp32 and fp64 rounding break differently -- q or -q, the same rotation (tests/test_gpu_parity.py test_preassembled_starts_match_the_oracle_env)"""
@@ -844,3 +893,21 @@ def test_preassembled_starts_whole_episodes_against_the_native_checker(cpu_abi, 
         assert rs.max() < 5e-5
     else:
         assert np.median(rs) < 1e-4 and np.percentile(rs, 90) < 1e-3
+
+
+@pytest.mark.gpu
+def test_set_init_qpos_whole_episodes_against_the_native_checker(cpu_abi):
+    """fsim_set_init_state at scale: every other env of 64 restarts each episode from a given state (no placement, no settling, no table read:
+    furniture.py:1505-1519), the others from their reset tables, 32 steps with episodes of 15 -- integer words exact at every step, all 192 resets within
+    5e-5 of the fp64 checker."""
+    n, T = 64, 15
+    m, out = _episodes(cpu_abi, "Sawyer", "table_lack_0825", n, T, 32, init_state=True)
+    rs = [out[0][0].max(axis=1)]
+    for t, (d, fresh, _) in enumerate(out[1:]):
+        if fresh.any():
+            assert fresh.all() and t % T == T - 1
+            rs.append(d.max(axis=1))
+    rs = np.concatenate(rs)
+    print("set_init_qpos: resets %d, reset distance median %.1e max %.1e (init-state envs %.1e, table envs %.1e)" % (
+        len(rs), np.median(rs), rs.max(), rs.reshape(3, n)[:, 0::2].max(), rs.reshape(3, n)[:, 1::2].max()))
+    assert len(rs) == 3 * n and rs.max() < 5e-5 and sum(o[2] for o in out[1:]) >= 0.99 * 32 * n
