@@ -9,10 +9,10 @@
  * (which is pinned to the reference's own methods by tests/golden/env_logic.npz, step_scan.npz, reset_trace.npz) and is checked against
  * that Python restatement on the same inputs.
  *
- * Scope: the arm agents (Sawyer, Baxter) under control_type impedance and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
+ * Scope: the arm agents (Sawyer, Baxter) under control_type impedance (Sawyer: also the five torque-level arm controllers, control_type 2..6, end of round 6) and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
  * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
- * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519).  ik / arm
- * controllers, phase_ob and reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
+ * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519).  ik, phase_ob and
+ * reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
  * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
@@ -76,6 +76,13 @@ typedef struct {
     real init_table_site[3], init_lift_leg[3], lift_leg[3], init_eef[3];
     real prev_init_eef, prev_above, prev_eef_leg, prev_grasp, prev_lift_z, prev_lift_xy, prev_move_pos, prev_up, prev_fwd, prev_proj_t, prev_proj_l;
   } dn;
+  /* torque-level arm controller (control_type 2..6; oracle/controllers.py new_state): created with the env, NOT cleared by a reset (controller.reset() runs only
+     in _reset_internal, furniture.py:1885-1887) */
+  struct {
+    int step, ori_init_live, goal_orientation_set;
+    real last_goal_position[3], last_goal_orientation[9], lin_base[3], lin_delta[3], ori_delta[3], ori_init[9], goal_orientation[9];
+    real last_goal[7], base[7], delta[7];
+  } ck;
   /* Cursor agent */
   real *body_pos;              /* model.body_pos (mutable: the cursor bodies, furniture.py:3139) */
   int cursor_sel[2];           /* _cursor_selected: part index or -1 */
@@ -335,8 +342,10 @@ static void write_obs(const struct fsim *s, Env *e, float *ob) {
     osim_body_jac(e->sim, m->site_bodyid[site], e->site_xpos + 3 * site, jp, jr);
     for (int r = 0; r < 3; r++) for (int k = 0; k < m->nv; k++) { vp[r] += jp[r * m->nv + k] * e->qvel[k]; vr[r] += jr[r * m->nv + k] * e->qvel[k]; }
     free(jp);
-    for (int k = 0; k < nj; k++) ob[o++] = (float)e->qpos[m->arm_qposadr[a * nj + k]];
-    for (int k = 0; k < nj; k++) ob[o++] = (float)e->qvel[m->arm_dofadr[a * nj + k]];
+    if (s->cfg.control_type == 0) { /* robot_ob: joint_pos / joint_vel only under impedance control (furniture_sawyer.py:112-123: `if self._control_type in ["impedance", "torque"]`) */
+      for (int k = 0; k < nj; k++) ob[o++] = (float)e->qpos[m->arm_qposadr[a * nj + k]];
+      for (int k = 0; k < nj; k++) ob[o++] = (float)e->qvel[m->arm_dofadr[a * nj + k]];
+    }
     for (int k = 0; k < 2; k++) ob[o++] = (float)e->qpos[m->grip_qposadr[2 * a + k]];
     for (int k = 0; k < 3; k++) ob[o++] = (float)e->site_xpos[3 * site + k];
     const real *hq = e->xquat + 4 * m->hand_bodyid[a]; /* wxyz -> xyzw (furniture_sawyer.py:141-143) */
@@ -798,6 +807,158 @@ static real dense_compute(const struct fsim *s, Env *e, const float *ac, int dof
   return reward;
 }
 
+/* ---- torque-level arm controllers (furniture/env/controllers/arm_controller.py as the env can construct them: controller_config.hjson without overrides --
+ * linear interpolation, impedance_flag false, no nullspace posture, no limits), restated from oracle/controllers.py, which tests/golden/controllers.npz pins to the
+ * reference's own classes.  kind = control_type: 2 position_orientation, 3 position, 4 joint_impedance, 5 joint_velocity, 6 joint_torque. */
+static int ck_dim(int kind) { return kind == 2 ? 6 : (kind == 3 ? 3 : 7); }
+static void ck_euler2mat(real *R, const real *e) { /* transform_utils.py:360-380 */
+  real ai = -e[2], aj = -e[1], ak = -e[0], si = sin(ai), sj = sin(aj), sk = sin(ak), ci = cos(ai), cj = cos(aj), ck = cos(ak);
+  real cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  R[0] = cj * ci; R[1] = cj * si; R[2] = -sj; R[3] = sj * cs - sc; R[4] = sj * ss + cc; R[5] = cj * sk; R[6] = sj * cc + ss; R[7] = sj * sc - cs; R[8] = cj * ck;
+}
+static void ck_ori_error(real *o, const real *desired, const real *current) { /* arm_controller.py:180-201: half the sum of the column cross products */
+  o[0] = o[1] = o[2] = 0;
+  for (int k = 0; k < 3; k++) {
+    real c_[3] = {current[k], current[3 + k], current[6 + k]}, d_[3] = {desired[k], desired[3 + k], desired[6 + k]}, x[3];
+    cross3(x, c_, d_);
+    for (int q = 0; q < 3; q++) o[q] += (real)0.5 * x[q];
+  }
+}
+static void ck_mat3T_mul(real *o, const real *A, const real *B) { /* A' B */
+  real r[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { r[3 * i + j] = 0; for (int k = 0; k < 3; k++) r[3 * i + j] += A[3 * k + i] * B[3 * k + j]; }
+  memcpy(o, r, sizeof r);
+}
+/* arm_controller.py:781-790: the SVD inverse with singular values below 0.00025 zeroed.  The argument is J M^-1 J' -- symmetric positive semi-definite, so its
+   singular values are its eigenvalues: cyclic Jacobi on the symmetrised matrix */
+static void ck_pinv3(real *out, const real *Ain) {
+  real A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[3 * i + j] = (real)0.5 * (Ain[3 * i + j] + Ain[3 * j + i]);
+  for (int sweep = 0; sweep < 60; sweep++) {
+    real off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+    if (off < (real)1e-300) break;
+    for (int p_ = 0; p_ < 2; p_++) for (int q = p_ + 1; q < 3; q++) {
+      real apq = A[3 * p_ + q];
+      if (apq == 0) continue;
+      real th = (A[3 * q + q] - A[3 * p_ + p_]) / (2 * apq), t = (th >= 0 ? 1 : -1) / (fabs(th) + sqrt(th * th + 1)), cs = 1 / sqrt(t * t + 1), sn = t * cs;
+      for (int k = 0; k < 3; k++) { real akp = A[3 * k + p_], akq = A[3 * k + q]; A[3 * k + p_] = cs * akp - sn * akq; A[3 * k + q] = sn * akp + cs * akq; }
+      for (int k = 0; k < 3; k++) { real apk = A[3 * p_ + k], aqk = A[3 * q + k]; A[3 * p_ + k] = cs * apk - sn * aqk; A[3 * q + k] = sn * apk + cs * aqk; }
+      for (int k = 0; k < 3; k++) { real vkp = V[3 * k + p_], vkq = V[3 * k + q]; V[3 * k + p_] = cs * vkp - sn * vkq; V[3 * k + q] = sn * vkp + cs * vkq; }
+    }
+  }
+  for (int i = 0; i < 9; i++) out[i] = 0;
+  for (int e_ = 0; e_ < 3; e_++) {
+    real lam = A[4 * e_];
+    if (fabs(lam) < (real)0.00025) continue; /* (singular value = |eigenvalue|) */
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[3 * i + j] += V[3 * i + e_] * V[3 * j + e_] / lam;
+  }
+}
+/* X = M^-1 B for the 7 x 7 arm block (Cholesky), B [7][nb] */
+static void ck_solve7(const real *M, const real *B, int nb, real *X) {
+  real Lc[49];
+  for (int i = 0; i < 7; i++) for (int j = 0; j <= i; j++) {
+    real v = M[7 * i + j];
+    for (int k = 0; k < j; k++) v -= Lc[7 * i + k] * Lc[7 * j + k];
+    Lc[7 * i + j] = i == j ? sqrt(v) : v / Lc[7 * j + j];
+  }
+  for (int c_ = 0; c_ < nb; c_++) {
+    real y[7];
+    for (int i = 0; i < 7; i++) { real v = B[nb * i + c_]; for (int k = 0; k < i; k++) v -= Lc[7 * i + k] * y[k]; y[i] = v / Lc[7 * i + i]; }
+    for (int i = 6; i >= 0; i--) { real v = y[i]; for (int k = i + 1; k < 7; k++) v -= Lc[7 * k + i] * X[nb * k + c_]; X[nb * i + c_] = v / Lc[7 * i + i]; }
+  }
+}
+/* update_model + action_to_torques for one physics substep (oracle/controllers.py torques) -> tq[7] (before `+ qfrc_bias`, furniture.py:1756-1758).
+   update_model (arm_controller.py:109-136) reads MuJoCo's memory as sim.step() left it: poses / Jacobian / mass matrix of the forward pass BEFORE the last
+   integration, qpos and qvel after it */
+static void ck_torques(const struct fsim *s, Env *e, int kind, const real *action, int policy_step, real *tq) {
+  const EnvModel *m = &s->m;
+  const int n = ck_dim(kind), nv = m->nv;
+  const real N = floor((real)0.2 * 20 / m->timestep); /* interpolation_steps: ramp_ratio 0.2 x the constructor's control_freq 20 / timestep (arm_controller.py:114) */
+  static const real range_jimp[7] = {0.2, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2}, range_jvel[7] = {1, 1, 1, 1, 1, 1, 1}, range_jtq[7] = {0.5, 0.5, 0.5, 0.2, 0.2, 0.1, 0.1};
+  static const real kv_jvel[7] = {8.0, 7.0, 6.0, 4.0, 2.0, 0.5, 0.1}, kpmax[7] = {100, 100, 100, 100, 50, 30, 10}, kpmin[7] = {10, 10, 10, 10, 10, 1, 1};
+  real a[7], q[7], qd[7];
+  for (int k = 0; k < n; k++) {
+    real r = kind == 2 ? (k < 3 ? 0.05 : 0.2) : (kind == 3 ? 0.05 : (kind == 4 ? range_jimp[k] : (kind == 5 ? range_jvel[k] : range_jtq[k])));
+    real v = action[k] < -1 ? -1 : (action[k] > 1 ? 1 : action[k]);
+    a[k] = v * r; /* transform_action (:99-107); the ranges are symmetric */
+  }
+  for (int k = 0; k < 7; k++) { q[k] = e->qpos[m->arm_qposadr[k]]; qd[k] = e->qvel[m->arm_dofadr[k]]; }
+  if (kind == 6 || kind == 5) {
+    if (policy_step) { e->ck.step = 0; for (int k = 0; k < 7; k++) { e->ck.base[k] = e->ck.last_goal[k]; e->ck.delta[k] = (a[k] - e->ck.last_goal[k]) / N; } }
+    for (int k = 0; k < 7; k++) e->ck.last_goal[k] = e->ck.base[k] + (e->ck.step + 1) * e->ck.delta[k];
+    if (e->ck.step < N - 1) e->ck.step += 1;
+    for (int k = 0; k < 7; k++) tq[k] = kind == 6 ? e->ck.last_goal[k] : kv_jvel[k] * (e->ck.last_goal[k] - qd[k]);
+    return;
+  }
+  real *Mfull = (real *)malloc(sizeof(real) * nv * nv), Ma[49];
+  osim_full_M(e->sim, Mfull);
+  for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) Ma[7 * i + j] = Mfull[(size_t)m->arm_dofadr[i] * nv + m->arm_dofadr[j]];
+  free(Mfull);
+  if (kind == 4) {
+    if (policy_step) {
+      e->ck.step = 0;
+      real nrm = 0;
+      for (int k = 0; k < 7; k++) nrm += e->ck.last_goal[k] * e->ck.last_goal[k];
+      if (nrm == 0) for (int k = 0; k < 7; k++) e->ck.last_goal[k] = q[k]; /* :446-447 */
+      for (int k = 0; k < 7; k++) { e->ck.base[k] = e->ck.last_goal[k]; e->ck.delta[k] = (q[k] + a[k] - e->ck.last_goal[k]) / N; }
+    }
+    for (int k = 0; k < 7; k++) e->ck.last_goal[k] = e->ck.base[k] + (e->ck.step + 1) * e->ck.delta[k];
+    if (e->ck.step < N - 1) e->ck.step += 1;
+    real nrm = 0, u[7];
+    for (int k = 0; k < 7; k++) nrm += qd[k] * qd[k];
+    nrm = sqrt(nrm);
+    if (nrm > 7.0) for (int k = 0; k < 7; k++) qd[k] /= nrm * (real)7.0; /* :485-487 (divides by norm * 7) */
+    for (int k = 0; k < 7; k++) { real kp = (kpmax[k] + kpmin[k]) * (real)0.5, damping = (real)(2 + 0) * (real)0.5, kv = 2 * sqrt(kp) * damping; u[k] = kp * (e->ck.last_goal[k] - q[k]) - kv * qd[k]; }
+    for (int i = 0; i < 7; i++) { tq[i] = 0; for (int j = 0; j < 7; j++) tq[i] += Ma[7 * i + j] * u[j]; }
+    return;
+  }
+  /* position / position_orientation */
+  const int hb = m->hand_bodyid[0];
+  const real *pos = e->xpos + 3 * hb, *R = e->xmat + 9 * hb;
+  real *jp = (real *)malloc(sizeof(real) * 6 * nv), *jr = jp + 3 * nv, Jx[21], Jr[21], velp[3] = {0, 0, 0}, velr[3] = {0, 0, 0};
+  osim_body_jac(e->sim, hb, pos, jp, jr);
+  for (int r = 0; r < 3; r++) {
+    for (int k = 0; k < nv; k++) { velp[r] += jp[r * nv + k] * e->qvel[k]; velr[r] += jr[r * nv + k] * e->qvel[k]; }
+    for (int k = 0; k < 7; k++) { Jx[7 * r + k] = jp[r * nv + m->arm_dofadr[k]]; Jr[7 * r + k] = jr[r * nv + m->arm_dofadr[k]]; }
+  }
+  free(jp);
+  if (policy_step) {
+    e->ck.step = 0;
+    real goal_pos[3] = {pos[0] + a[0], pos[1] + a[1], pos[2] + a[2]};
+    if (kind == 2) { real ne[3] = {-a[3], -a[4], -a[5]}, E[9]; ck_euler2mat(E, ne); ck_mat3T_mul(e->ck.goal_orientation, E, R); } /* set_goal_orientation (:808-810) */
+    else if (!e->ck.goal_orientation_set) { memcpy(e->ck.goal_orientation, R, 9 * sizeof(real)); e->ck.goal_orientation_set = 1; } /* PositionController (:934-939) */
+    if (norm3(e->ck.last_goal_position) == 0) memcpy(e->ck.last_goal_position, pos, 3 * sizeof(real));
+    /* Quirk (arm_controller.py:679-680, :635): on the first policy step after the controller's reset `last_goal_orientation` becomes a VIEW of the hand's
+       orientation in MuJoCo's memory and the ramp's "initial" orientation follows it until the next policy step */
+    static const real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    e->ck.ori_init_live = memcmp(e->ck.last_goal_orientation, I3, sizeof I3) == 0;
+    if (e->ck.ori_init_live) memcpy(e->ck.last_goal_orientation, R, 9 * sizeof(real));
+    for (int k = 0; k < 3; k++) { e->ck.lin_base[k] = e->ck.last_goal_position[k]; e->ck.lin_delta[k] = (goal_pos[k] - e->ck.last_goal_position[k]) / N; }
+    real oe[3];
+    ck_ori_error(oe, e->ck.goal_orientation, e->ck.last_goal_orientation);
+    for (int k = 0; k < 3; k++) e->ck.ori_delta[k] = oe[k] / N;
+    memcpy(e->ck.ori_init, e->ck.last_goal_orientation, 9 * sizeof(real));
+  }
+  for (int k = 0; k < 3; k++) e->ck.last_goal_position[k] = e->ck.lin_base[k] + (e->ck.step + 1) * e->ck.lin_delta[k];
+  real ngod[3], E[9];
+  for (int k = 0; k < 3; k++) ngod[k] = -((e->ck.step + 1) * e->ck.ori_delta[k]);
+  if (e->ck.ori_init_live) memcpy(e->ck.ori_init, R, 9 * sizeof(real));
+  ck_euler2mat(E, ngod);
+  ck_mat3T_mul(e->ck.last_goal_orientation, E, e->ck.ori_init);
+  if (e->ck.step < N - 1) e->ck.step += 1;
+  const real kp = 150.0, kv = 2 * sqrt(kp) * (real)1.0;
+  real f[3], t[3], oe[3];
+  ck_ori_error(oe, e->ck.last_goal_orientation, R);
+  for (int k = 0; k < 3; k++) { f[k] = (e->ck.last_goal_position[k] - pos[k]) * kp - velp[k] * kv; t[k] = oe[k] * kp - velr[k] * kv; }
+  real JxT[21], JrT[21], MiJx[21], MiJr[21], Ax[9], Ar[9], Px[9], Pr[9], wx[3], wr[3];
+  for (int r = 0; r < 3; r++) for (int k = 0; k < 7; k++) { JxT[3 * k + r] = Jx[7 * r + k]; JrT[3 * k + r] = Jr[7 * r + k]; }
+  ck_solve7(Ma, JxT, 3, MiJx); ck_solve7(Ma, JrT, 3, MiJr); /* M^-1 J' : [7][3] */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Ax[3 * i + j] = 0; Ar[3 * i + j] = 0; for (int k = 0; k < 7; k++) { Ax[3 * i + j] += Jx[7 * i + k] * MiJx[3 * k + j]; Ar[3 * i + j] += Jr[7 * i + k] * MiJr[3 * k + j]; } }
+  ck_pinv3(Px, Ax); ck_pinv3(Pr, Ar);
+  for (int i = 0; i < 3; i++) { wx[i] = 0; wr[i] = 0; for (int j = 0; j < 3; j++) { wx[i] += Px[3 * i + j] * f[j]; wr[i] += Pr[3 * i + j] * t[j]; } }
+  for (int k = 0; k < 7; k++) { tq[k] = 0; for (int r = 0; r < 3; r++) tq[k] += Jx[7 * r + k] * wx[r] + Jr[7 * r + k] * wr[r]; }
+}
+
 static void env_step(struct fsim *s, int idx, const float *action, float *ob, float *reward, uint8_t *done, int32_t *info) {
   const EnvModel *m = &s->m;
   const fsim_config_t *c = &s->cfg;
@@ -821,6 +982,26 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
     for (int k = 0; k < s->n_substeps && !bad; k++) bad = osim_step(e->sim);
     if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
     else for (int i = 0; i < m->nparts; i++) if (sel[i]) stop_object(s, e, i, 1);
+  } else if (c->control_type >= 2 && c->control_type <= 6) {
+    /* _do_controller_step (furniture.py:3065-3093) + _pre_action (:1706-1759): sim.forward(), then n_substeps x (one torque update, sim.step()); no
+       _setup_action, so qfrc_applied keeps the gravity compensation the reset left.  The first three action entries are scaled by move_speed and permuted
+       [-a1, a0, a2] for EVERY controller kind (:3069-3071) */
+    const int cd = ck_dim(c->control_type);
+    real act[16];
+    for (int k = 0; k < dof; k++) act[k] = a[k];
+    { real a0 = a[0] * (real)c->move_speed, a1 = a[1] * (real)c->move_speed, a2 = a[2] * (real)c->move_speed; act[0] = -a1; act[1] = a0; act[2] = a2; }
+    osim_forward(e->sim);
+    int bad = 0;
+    for (int k = 0; k < s->n_substeps && !bad; k++) {
+      real tq[7];
+      ck_torques(s, e, c->control_type, act, k == 0, tq);
+      for (int j = 0; j < 7; j++) e->ctrl[m->arm_dofadr[j]] = e->qfrc_bias[m->arm_dofadr[j]] + tq[j]; /* (the reference indexes ctrl with the joint-velocity indices, :1756) */
+      const real g = act[cd]; /* gripper: format_action 1 -> 2 (two_finger_gripper.py:66-72), then bias + weight * a, unclipped (:1722-1727) */
+      e->ctrl[m->grip_dofadr[0]] = m->ctrl_bias[m->grip_dofadr[0]] + m->ctrl_weight[m->grip_dofadr[0]] * g;
+      e->ctrl[m->grip_dofadr[1]] = m->ctrl_bias[m->grip_dofadr[1]] + m->ctrl_weight[m->grip_dofadr[1]] * -g;
+      bad = osim_step(e->sim);
+    }
+    if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
   } else
   { /* _setup_action + _do_simulation */
     real act[64];
@@ -947,11 +1128,16 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->ngeom = dims[5]; m->nsite = dims[6]; m->neq = dims[7];
   m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
   m->timestep = opt[0]; m->gravz = opt[3];
-  if (s->cfg.control_type != 0 || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
+  const int ctrl_kind = s->cfg.control_type >= 2 && s->cfg.control_type <= 6;
+  if ((s->cfg.control_type != 0 && !(ctrl_kind && m->agent == 0 && !s->cfg.dense_reward)) || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
     fsim_destroy(s);
     FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control and the Cursor agent, with the sparse reward (Sawyer: also the dense reward) and fp32 observations (oracle/oracle_env.py checks the rest)");
   }
   int64_t cnt;
+  if (ctrl_kind) { /* as the device: the controllers write joint torques, which only the motor-actuated model (robot_torque.xml, furniture.py:1893) applies as such */
+    const real *ag = cpu_reals(s, "actuator_gain", &cnt);
+    if (m->nu != 9 || !ag || cnt != 9 || ag[0] != (real)1.0) { fsim_destroy(s); FAIL(FSIM_EINVAL, "arm controllers need the motor-actuated model (compiled with a torque-level control_type, robot_torque.xml)"); }
+  }
   GI(part_bodyid, "part_bodyid"); GI(part_qposadr, "part_qposadr"); GI(part_dofadr, "part_dofadr"); GI(body_partid, "body_partid"); GI(geom_bodyid, "geom_bodyid");
   GI(geom_fingerrole, "geom_fingerrole"); GI(geom_is_robot, "geom_is_robot"); GI(geom_is_partcol, "geom_is_partcol"); GI(geom_contype0, "geom_contype");
   GI(geom_conaffinity0, "geom_conaffinity"); GI(floor_geomid, "floor_geomid"); GI(eq_part1, "eq_part1"); GI(eq_part2, "eq_part2");
@@ -978,7 +1164,8 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   s->success_num_conn = m->nparts - 1;
   { const char *pv = getenv("FSIM_CPU_PERTURB"); s->perturb = pv ? (real)atof(pv) : 0; }
   s->dof = m->agent == 2 ? 15 : m->narmj + m->narm + 1;            /* (move, rotate, select) x 2 + connect, furniture_cursor.py:56 */
-  s->obs_dim = 7 * m->nparts + (m->agent == 2 ? 8 : 29 * m->narm);
+  if (s->cfg.control_type >= 2 && s->cfg.control_type <= 6) s->dof = ck_dim(s->cfg.control_type) + 2; /* [arm command, grip, connect] */
+  s->obs_dim = 7 * m->nparts + (m->agent == 2 ? 8 : (s->cfg.control_type == 0 ? 29 : 15) * m->narm); /* (joint_pos / joint_vel belong to the impedance robot_ob) */
   s->env = (Env *)calloc((size_t)n_envs, sizeof(Env));
   for (int i = 0; i < n_envs; i++) {
     Env *e = &s->env[i];
@@ -986,6 +1173,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
     if (!e->sim) { fsim_destroy(s); FAIL(FSIM_EINVAL, "osim_create: %s", osim_last_error()); }
     osim_set_solver(e->sim, s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : 100, s->cfg.solver_tolerance > 0 ? (sizeof(real) == 8 ? (real)s->cfg.solver_tolerance : (real)fmax(s->cfg.solver_tolerance, 1e-6f)) : (real)(sizeof(real) == 8 ? 1e-8 : 1e-6)); /* (fp32 control build: the device's tolerance) */
     osim_set_solver_kind(e->sim, 1); /* Newton: MuJoCo's default, what the reference runs (base.xml:4) */
+    for (int k = 0; k < 3; k++) e->ck.last_goal_orientation[4 * k] = e->ck.ori_init[4 * k] = e->ck.goal_orientation[4 * k] = 1; /* Controller.reset(): identities (arm_controller.py:93-97) */
 #define DP(f, name) e->f = osim_dptr(e->sim, name, NULL)
     DP(qpos, "qpos"); DP(qvel, "qvel"); DP(ctrl, "ctrl"); DP(qfrc_applied, "qfrc_applied"); DP(xfrc_applied, "xfrc_applied"); DP(qacc, "qacc");
     DP(qacc_warmstart, "qacc_warmstart"); DP(qfrc_bias, "qfrc_bias"); DP(xpos, "xpos"); DP(xquat, "xquat"); DP(xmat, "xmat"); DP(site_xpos, "site_xpos");

@@ -102,6 +102,18 @@ sw.set_reset_tables(ew.reset_draws["part_qpos"].reshape(1, -1), np.stack(ew.rese
 sw.reset()
 sw.step(counter_actions(1, 0, 0, 9)[None])
 sw.close()
+# ... and the torque-level arm controllers (the cartesian kind: Jacobians, the 7 x 7 solve, the thresholded 3 x 3 inverses; a joint-space kind)
+for kind, code in (("position_orientation", 2), ("joint_impedance", 4)):
+    mk = load_compiled("Sawyer", "table_lack_0825", kind)
+    ek = FurnitureEnvOracle(mk, OracleConfig(seed=11, max_episode_steps=4, control_type=kind))
+    ek.reset()
+    sk = Session(Abi(os.environ["FSIM_CPU_SAN"]), mk.to_blob(), 1, max_episode_steps=4, auto_reset=0, control_type=code)
+    sk.set_reset_tables(ek.reset_draws["part_qpos"].reshape(1, -1), np.stack(ek.reset_draws["noise"]).reshape(1, -1))
+    sk.reset()
+    for t in range(2):
+        o_, r_, d_, i_ = sk.step(counter_actions(1, 0, t, sk.dof)[None])
+    assert np.isfinite(o_).all()
+    sk.close()
 # round 6: the Cursor agent -- the MuJoCo-recorded demo's first 64 frames (selection by contact, carried groups, the ten approach steps, the connect)
 from tests.test_demo_replay import D
 c = load_compiled("Cursor", "swivel_chair_0700")
