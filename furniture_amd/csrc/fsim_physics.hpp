@@ -206,9 +206,11 @@ template <class Ctx> DEV void fs_build_map(const Ctx &c, int mp, const int *isl,
       else { lane0 = sb; if (nbig < MAP_BIGCAP) { tail[MAP_BIG0 + 2 * nbig] = sb; tail[MAP_BIG0 + 2 * nbig + 1] = n; } nbig++; sb += n; maxbig = max(maxbig, n); }
       tmp[u] |= (lane0 << 16) | ((row < 0 ? 1 : 0) << 24) | ((row >= 4 ? 1 : 0) << 25);
       // an island of more than 64 dofs (or big islands that overflow the 64 big-phase lanes) cannot be mapped onto lanes: the solve is
-      // flagged bad, which the env treats like an unstable simulation -- a robot holding ten mutually coupled parts.  (The 256-slot
-      // kernels of the re-step ladder, Ctx::NS >= 4, take such a system through the LDS-resident factorisation instead: `huge`.)
-      if (n > 64 || sb > 64) { if (Ctx::NS >= 4 && n <= 127) huge = true; else scal_[SC_BAD] |= 3; }
+      // flagged bad, which the env treats like an unstable simulation -- a robot holding ten mutually coupled parts, eleven planks in one pile.
+      // The 512-slot kernels of the re-step ladder, Ctx::NS >= 4, take such a system through the LDS-resident factorisation instead (`huge`), and
+      // every other kernel ALSO raises the capacity report (SC_OVERFLOW bit 1: "this kernel's layout does not hold this step"), which lists the
+      // env for the ladder: its step or reset is repeated from the kept record, rung by rung, and the last rung solves it.
+      if (n > 64 || sb > 64) { if (Ctx::NS >= 4 && n <= 127) huge = true; else { scal_[SC_BAD] |= 3; if (Ctx::NS < 4) scal_[SC_OVERFLOW] |= 2; } }
     }
     tail[MAP_RSTEPS] = max(max(fill[0], fill[1]), max(fill[2], fill[3])) | (max(max(fill[4], fill[5]), max(fill[6], fill[7])) << 8);
     tail[MAP_NBIG] = nbig;

@@ -215,7 +215,7 @@ enum {
                               * step() (furniture.py:2889-2897) and the vec-env worker resets again; only the second reset is run */
   FSIM_INFO_SUCCESS_REWARD_F = 8, FSIM_INFO_TOUCH_REWARD_F = 9, FSIM_INFO_PICK_REWARD_F = 10,
   FSIM_INFO_CTRL_PENALTY_F = 11, /* float bits */
-  FSIM_INFO_OVERFLOW = 12, /* bits 0-1: this launch -- bit 0 broadphase survivor list truncated, bit 1 contact slots exhausted (contacts dropped);
+  FSIM_INFO_OVERFLOW = 12, /* bits 0-1: this launch -- bit 0 broadphase survivor list truncated, bit 1 contact slots exhausted (contacts dropped) or an island of more than 64 dofs met on a kernel without the LDS-resident factorisation;
                               bits 8-9: the same two flags, STICKY: raised by any launch of this env so far (a step, a reset, the look-ahead
                               reset that was copied in) and kept in its record across resets, so a host that reads the block every k-th step
                               misses nothing */

@@ -124,3 +124,19 @@ def spread_layout(m, x0=0.9, gap=0.03):
         y += 2 * rad + gap
         row_h = max(row_h, 2 * rad)
     return out
+
+
+def stacked_layout(m, x=1.0, y=0.0, gap=0.001):
+    """Part poses [nparts, 7] that put every part flat ON TOP of the previous one, one pile a metre in front of the robot: every part touches its
+    neighbours, so the whole furniture is ONE constraint island (6 x nparts dofs) with a few contacts per part -- for bookcase_billy_0191 66 dofs and
+    about 45 contacts: a system that fits the contact slots of its kernel but not the 64 lanes of its island map (orientation as in spread_layout)."""
+    lay = spread_layout(m)
+    cg_body, cg_size = np.asarray(m.cg_body), np.asarray(m.cg_size).reshape(-1, 3)
+    out, z = lay.copy(), 0.0
+    for p in range(m.nparts):
+        g0 = [g for g in range(len(cg_body)) if cg_body[g] == m.part_rbody[p]][0]
+        h = cg_size[g0][int(np.argmin(cg_size[g0]))]
+        out[p, 0], out[p, 1] = x, y
+        out[p, 2] = lay[p, 2] - (h + 0.002) + z + h + gap  # (spread_layout put the first box's centre at height h + 0.002)
+        z += 2 * h + gap
+    return out

@@ -224,3 +224,53 @@ def test_a_reset_with_the_planks_inside_each_other_takes_the_last_rung_to_512(fu
         assert np.isfinite(g).all() and int(info["contact_overflow"]) == 0 and done == done_o
         assert np.median(np.abs(g - orc.flat_obs(ob_o))) < 1e-3, t
     env.close()
+
+
+def test_a_pile_of_eleven_planks_is_one_island_of_66_dofs_and_goes_to_the_last_rung(monkeypatch):
+    """The other capacity of a kernel: its island map holds islands of up to 64 dofs (one lane per dof).  bookcase_billy_0191's eleven planks
+    stacked in ONE pile (set_init_qpos, tests/scenarios.py stacked_layout) are one island of 66 dofs with about 45 contacts -- the 128 slots hold
+    them, the lane map does not.  Through round 5 (and here with the ladder off) such a step failed like an unstable simulation; now the kernel
+    raises the capacity report as well, the env is listed for the re-step ladder and its last rung (LDS-resident factorisation) solves it:
+    reset and steps against the fp64 oracle env."""
+    from furniture_amd.envs import ContactOverflowError, FurnitureSawyerEnv
+    from oracle.oracle_env import FurnitureEnvOracle, OracleConfig
+    from tests.scenarios import stacked_layout
+    name = "bookcase_billy_0191"
+    m = load_compiled("Sawyer", name)
+    lay = stacked_layout(m)
+    q = np.array(m.qpos0, dtype=float)
+    q[m.arm_qposadr], q[m.grip_qposadr] = m.arm_initqpos, m.grip_initqpos
+    for p in range(m.nparts):
+        q[m.part_qposadr[p]:m.part_qposadr[p] + 7] = lay[p]
+    init = {"qpos": q, "qvel": np.zeros(m.nv)}
+    kw = dict(unity=False, record_vid=False, control_type="impedance", furniture_name=name, max_episode_steps=50, seed=3)
+    orc = FurnitureEnvOracle(m, OracleConfig(max_episode_steps=50, seed=3, solver_tolerance=1e-10))
+    orc.set_init_qpos(init)
+    o = orc.flat_obs(orc.reset())
+    pairs = {tuple(sorted((int(m.body_partid[m.geom_bodyid[a]]), int(m.body_partid[m.geom_bodyid[b]])))) for a, b in orc.sim.contacts()}
+    linked = {p for pr in pairs for p in pr if pr[0] >= 0 and pr[1] >= 0}
+    assert len(linked) == m.nparts and orc.sim.ncon <= 100, (sorted(linked), orc.sim.ncon)  # every plank touches another one: one island; the slots suffice
+    monkeypatch.setenv("FSIM_NO_OVERFLOW_REDO", "1")
+    env = FurnitureSawyerEnv(make_config(**kw))
+    env.set_init_qpos(init)
+    with pytest.raises((ContactOverflowError, RuntimeError)):  # without the ladder: reported, not integrated wrongly
+        env.reset()
+    env.close()
+    monkeypatch.delenv("FSIM_NO_OVERFLOW_REDO")
+    env = FurnitureSawyerEnv(make_config(**kw))
+    env.set_init_qpos(init)
+    d = env.reset()
+    assert env._b.sim.overflow_resteps() >= 1
+    got = np.concatenate([d["object_ob"], d["robot_ob"]])
+    dd = np.abs(got - o)
+    # (measured: median 1e-7, one plank of the pile 1.5e-3 -- eleven planks held on each other by friction alone over 401 substeps)
+    assert np.median(dd) < 1e-5 and dd.max() < 5e-3, (float(np.median(dd)), float(dd.max()))
+    rng = np.random.RandomState(2)
+    for t in range(3):
+        a = rng.uniform(-1, 1, 9)
+        ob, r, done, info = env.step(a)
+        ob_o, r_o, done_o, _ = orc.step(a)
+        dd = np.abs(np.concatenate([ob["object_ob"], ob["robot_ob"]]) - orc.flat_obs(ob_o))
+        assert np.median(dd) < 1e-4 and dd.max() < 1e-2 and int(info["contact_overflow"]) == 0 and int(info["fail"]) == 0 and done == done_o, (t, float(dd.max()))
+    assert env._b.sim.overflow_resteps() >= 4  # the reset and each of the three steps
+    env.close()
