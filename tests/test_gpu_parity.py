@@ -793,3 +793,44 @@ def test_specialised_and_generic_kernels_agree(sawyer_lack, fsim_mw):
         assert float((r1 - r2).abs().max()) < 1e-5 and torch.equal(d1, d2)
     for k in ("eq_active", "geom_contype"):
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("slots,variant", [(128, "generic2"), (512, "generic8")])
+def test_the_kernels_with_several_slot_sets_agree_with_the_specialised_one(slots, variant, monkeypatch):
+    """The kernels that carry two / eight contact-slot sets per lane in the Newton solve (`generic2`: furniture with ten parts and more; `generic8`: the
+    re-step ladder's last rung) as the BASE kernel of the benchmark model (FSIM_NCON_MAX), where the specialised 48-slot kernel is the yardstick: the
+    further sets are empty here, every loop over them runs, and the result must be the specialised kernel's -- compared like two correct fp32
+    implementations (test_specialised_and_generic_kernels_agree): 1e-5 over the reset, 2e-4 over 300 substeps of random actions; integer state exact."""
+    import torch
+    from furniture_amd.envs import make_vec_env
+
+    def run(n_slots):
+        if n_slots:
+            monkeypatch.setenv("FSIM_NCON_MAX", str(n_slots))
+        try:
+            env = make_vec_env("Sawyer", 32, furniture_name="table_lack_0825", max_episode_steps=4, seed=5, record_vid=False, unity=False, control_type="impedance")
+        finally:
+            monkeypatch.delenv("FSIM_NCON_MAX", raising=False)
+        assert env.sim.kernel_variant == (variant if n_slots else "sawyer_table_lack_0825") and env.sim.max_contacts == (n_slots or 48)
+        out = [env.reset()]
+        g = torch.Generator(device=env.sim.device)
+        g.manual_seed(3)
+        rews = []
+        for t in range(6):
+            ob, rew, done, info = env.step(torch.empty((32, 9), device=env.sim.device).uniform_(-1, 1, generator=g))
+            out.append({k: v.clone() for k, v in ob.items()})
+            rews.append((rew.clone(), done.clone()))
+        st = {k: v.clone() for k, v in env.sim.get_state("eq_active", "geom_contype").items()}
+        env.close()
+        return out, rews, st
+
+    a, ra, sa = run(0)
+    b, rb, sb = run(slots)
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in x:
+            err = float((x[k] - y[k]).abs().max())
+            assert err < (1e-5 if t == 0 else 2e-4), (t, k, err)
+    for (r1, d1), (r2, d2) in zip(ra, rb):
+        assert float((r1 - r2).abs().max()) < 1e-5 and torch.equal(d1, d2)
+    for k in ("eq_active", "geom_contype"):
+        assert torch.equal(sa[k], sb[k]), k
