@@ -764,12 +764,16 @@ def test_specialised_and_generic_kernels_agree(sawyer_lack, fsim_mw):
     from furniture_amd.envs import make_vec_env
 
     def run(generic):
+        before = os.environ.get("FSIM_GENERIC")  # (restored afterwards: the suite's FSIM_GENERIC=1 variant run must stay generic for the tests that follow)
         if generic:
             os.environ["FSIM_GENERIC"] = "1"
         try:
             env = make_vec_env("Sawyer", 96, furniture_name="table_lack_0825", max_episode_steps=4, seed=5, record_vid=False, unity=False, control_type="impedance")
         finally:
-            os.environ.pop("FSIM_GENERIC", None)
+            if before is None:
+                os.environ.pop("FSIM_GENERIC", None)
+            else:
+                os.environ["FSIM_GENERIC"] = before
         assert env.sim.kernel_variant == ("generic" if generic else "sawyer_table_lack_0825")
         out = [env.reset()]
         g = torch.Generator(device=env.sim.device)
