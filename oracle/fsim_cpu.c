@@ -11,8 +11,8 @@
  *
  * Scope: the arm agents (Sawyer, Baxter) under control_type impedance (Sawyer: also the five torque-level arm controllers, control_type 2..6, end of round 6) and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
  * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
- * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519).  ik, phase_ob and
- * reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
+ * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519), control_type ik / ik_quaternion (:2899-3063 over the
+ * solver of oracle/ik.py).  phase_ob and reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
  * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
@@ -57,6 +57,8 @@ typedef struct {
       *site_bodyid, *cursor_bodyid, *cg_orig, *cg_cursor, *cg_namepart;
   int32_t *geom_cursor, *geom_namepart; /* [ngeom] by ORIGINAL geom id: bit k = the geom's name contains 'cursor<k>' / bit i = ... part i's name (model.py _cursor_tables) */
   const real *body_mass, *eq_data0, *arm_initqpos, *grip_initqpos, *ctrl_bias, *ctrl_weight, *conn_angles, *site_quat;
+  /* control_type ik / ik_quaternion: the IK chain tables of the compiled model (furniture_amd/mjcf/urdf_chain.py) */
+  const real *ik_joint_pos, *ik_joint_quat, *ik_eef_pos, *ik_eef_quat, *ik_rest, *ik_lower, *ik_upper, *ik_params, *ik_base_quat;
 } EnvModel;
 
 typedef struct {
@@ -83,6 +85,9 @@ typedef struct {
     real last_goal_position[3], last_goal_orientation[9], lin_base[3], lin_delta[3], ori_delta[3], ori_init[9], goal_orientation[9];
     real last_goal[7], base[7], delta[7];
   } ck;
+  /* control_type ik / ik_quaternion (furniture.py:2899-3063): the IK target position per arm (base frame), the accumulated commanded orientation
+     `_initial_<arm>_hand_quat` (xyzw), the commanded joints of the last solve */
+  struct { real tp[2][3], init_quat[2][4], q_cmd[14]; } ik;
   /* Cursor agent */
   real *body_pos;              /* model.body_pos (mutable: the cursor bodies, furniture.py:3139) */
   int cursor_sel[2];           /* _cursor_selected: part index or -1 */
@@ -102,7 +107,7 @@ struct fsim {
   int dnsub;
   real perturb;      /* FSIM_CPU_PERTURB (read at fsim_create): added to every arm-joint angle and part position at the end of each reset -- the
                         `perturbed twin` of scripts/divergence_control.py; 0 in every test */
-  real *conv[16];    /* float64 blob entries converted to `real` (fp32 control build only) */
+  real *conv[32];    /* float64 blob entries converted to `real` (fp32 control build only) */
   int nconv;
   /* fsim_set_preassembled: recipe steps (pre_recipe: rows = connector indices of the recipe's site2 and site1 + the angle, NaN none) or weld ids */
   int n_pre, pre_recipe, success_num_conn;
@@ -253,6 +258,7 @@ static void next_subtask(const struct fsim *s, Env *e) {
 }
 
 static void dense_reset(const struct fsim *s, Env *e);
+static void ik_sync(const struct fsim *s, Env *e);
 static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align);
 static void project_connector_quat(const struct fsim *s, Env *e, int k1, int k2, int has_angle, real angle);
 static void env_reset(const struct fsim *s, int idx) {
@@ -311,6 +317,7 @@ tail:
   osim_forward(e->sim);
   gravity_comp(s, e);
   for (int k = 0; k < 100; k++) fs(e);
+  if (s->cfg.control_type == 7 || s->cfg.control_type == 8) ik_sync(s, e);
   next_subtask(s, e);
   e->episode_reward = 0; e->episode_length = 0; e->success = 0; e->fail = 0;
   if (s->cfg.dense_reward) dense_reset(s, e); /* _reset_reward_variables (furniture_sawyer_dense.py:218-220) */
@@ -959,6 +966,215 @@ static void ck_torques(const struct fsim *s, Env *e, int kind, const real *actio
   for (int k = 0; k < 7; k++) { tq[k] = 0; for (int r = 0; r < 3; r++) tq[k] += Jx[7 * r + k] * wx[r] + Jr[7 * r + k] * wr[r]; }
 }
 
+/* ---- control_type ik / ik_quaternion: the batched damped-least-squares solver that stands in for pybullet (oracle/ik.py: PARITY UNPINNED by construction, the
+ * bookkeeping around it restated from sawyer_ik_controller.py / baxter_ik_controller.py and furniture.py:2899-3063) */
+static void ik_q2m(real *R, const real *q) { /* wxyz -> 3x3, normalised */
+  real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void m3mul(real *o, const real *A, const real *B) { real r[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { r[3 * i + j] = 0; for (int k = 0; k < 3; k++) r[3 * i + j] += A[3 * i + k] * B[3 * k + j]; } memcpy(o, r, sizeof r); }
+static void m3vec(real *o, const real *A, const real *v) { real r[3]; for (int i = 0; i < 3; i++) r[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2]; memcpy(o, r, sizeof r); }
+/* pose of the end-effector frame in the robot base frame + joint origins and axes (ik.fk): child = parent . Trans(xyz) . Rot . Rz(q_i) */
+static void ik_fk(const EnvModel *m, const real *q, int arm, real *p, real *R, real (*org)[3], real (*axs)[3]) {
+  real Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};
+  for (int i = 0; i < 7; i++) {
+    real t[3], Rj[9];
+    m3vec(t, Rc, m->ik_joint_pos + 3 * (7 * arm + i));
+    for (int k = 0; k < 3; k++) pc[k] += t[k];
+    ik_q2m(Rj, m->ik_joint_quat + 4 * (7 * arm + i));
+    m3mul(Rc, Rc, Rj);
+    if (org) { memcpy(org[i], pc, sizeof pc); axs[i][0] = Rc[2]; axs[i][1] = Rc[5]; axs[i][2] = Rc[8]; }
+    real c_ = cos(q[i]), s_ = sin(q[i]), Rz[9] = {c_, -s_, 0, s_, c_, 0, 0, 0, 1};
+    m3mul(Rc, Rc, Rz);
+  }
+  real t[3], Re[9];
+  m3vec(t, Rc, m->ik_eef_pos + 3 * arm);
+  for (int k = 0; k < 3; k++) p[k] = pc[k] + t[k];
+  ik_q2m(Re, m->ik_eef_quat + 4 * arm);
+  if (R) m3mul(R, Rc, Re);
+}
+static void ik_rotvec(real *v, const real *R) { /* axis * angle (small-angle safe) */
+  v[0] = (real)0.5 * (R[7] - R[5]); v[1] = (real)0.5 * (R[2] - R[6]); v[2] = (real)0.5 * (R[3] - R[1]);
+  real s_ = norm3(v), c_ = (real)0.5 * (R[0] + R[4] + R[8] - 1);
+  if (s_ < (real)1e-12) return;
+  real f = atan2(s_, c_) / s_;
+  for (int k = 0; k < 3; k++) v[k] *= f;
+}
+static void ik_solve6(const real *A, const real *b, real *x) { /* numpy.linalg.solve: LU with partial pivoting */
+  real M[6][7];
+  for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) M[i][j] = A[6 * i + j]; M[i][6] = b[i]; }
+  for (int c_ = 0; c_ < 6; c_++) {
+    int pv = c_;
+    for (int r = c_ + 1; r < 6; r++) if (fabs(M[r][c_]) > fabs(M[pv][c_])) pv = r;
+    if (pv != c_) for (int j = 0; j < 7; j++) { real t = M[c_][j]; M[c_][j] = M[pv][j]; M[pv][j] = t; }
+    for (int r = c_ + 1; r < 6; r++) { real f = M[r][c_] / M[c_][c_]; for (int j = c_; j < 7; j++) M[r][j] -= f * M[c_][j]; }
+  }
+  for (int i = 5; i >= 0; i--) { real v = M[i][6]; for (int j = i + 1; j < 6; j++) v -= M[i][j] * x[j]; x[i] = v / M[i][i]; }
+}
+/* ik.solve: 12 damped-least-squares iterations with a null-space pull towards the rest pose (none in the last 4), joint-limit clamping */
+static void ik_solve(const EnvModel *m, const real *q0, const real *tp, const real *tR, int arm, const real *rest_in, real *q) {
+  const real *rest = rest_in ? rest_in : m->ik_rest + 7 * arm, *lower = m->ik_lower + 7 * arm, *upper = m->ik_upper + 7 * arm;
+  memcpy(q, q0, 7 * sizeof(real));
+  for (int k = 0; k < 12; k++) {
+    real p[3], R[9], org[7][3], axs[7][3], e_[6], J[42], A[36], y[6], dq[7], Rt[9], RR[9];
+    ik_fk(m, q, arm, p, R, org, axs);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+    m3mul(RR, tR, Rt);
+    for (int i = 0; i < 3; i++) e_[i] = tp[i] - p[i];
+    ik_rotvec(e_ + 3, RR);
+    for (int i = 0; i < 7; i++) {
+      real d[3] = {p[0] - org[i][0], p[1] - org[i][1], p[2] - org[i][2]}, cx[3];
+      cross3(cx, axs[i], d);
+      for (int r = 0; r < 3; r++) { J[7 * r + i] = cx[r]; J[7 * (3 + r) + i] = axs[i][r]; }
+    }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { real v = 0; for (int c_ = 0; c_ < 7; c_++) v += J[7 * i + c_] * J[7 * j + c_]; A[6 * i + j] = v + (i == j ? (real)(0.05 * 0.05) : 0); }
+    ik_solve6(A, e_, y);
+    for (int i = 0; i < 7; i++) { dq[i] = 0; for (int r = 0; r < 6; r++) dq[i] += J[7 * r + i] * y[r]; }
+    if (k < 12 - 4) {
+      real n_[7], Jn[6], z[6];
+      for (int i = 0; i < 7; i++) n_[i] = (real)0.01 * (rest[i] - q[i]);
+      for (int r = 0; r < 6; r++) { Jn[r] = 0; for (int i = 0; i < 7; i++) Jn[r] += J[7 * r + i] * n_[i]; }
+      ik_solve6(A, Jn, z);
+      for (int i = 0; i < 7; i++) { real v = 0; for (int r = 0; r < 6; r++) v += J[7 * r + i] * z[r]; dq[i] += n_[i] - v; }
+    }
+    for (int i = 0; i < 7; i++) { real v = q[i] + dq[i]; q[i] = v < lower[i] ? lower[i] : (v > upper[i] ? upper[i] : v); }
+  }
+}
+/* transform_utils.mat2quat (:298-352, non-precise branch): the eigenvector of the largest eigenvalue of the symmetric 4 x 4 matrix K built from the float32 copy
+   of the rotation matrix -> xyzw, w >= 0.  numpy's eigh by LAPACK; cyclic Jacobi here */
+static void tu_mat2quat(real *q_xyzw, const real *Rin) {
+  real M[9];
+  for (int k = 0; k < 9; k++) M[k] = (real)(float)Rin[k];
+  real K[16] = {M[0] - M[4] - M[8], 0, 0, 0, M[1] + M[3], M[4] - M[0] - M[8], 0, 0, M[2] + M[6], M[5] + M[7], M[8] - M[0] - M[4], 0, M[7] - M[5], M[2] - M[6], M[3] - M[1], M[0] + M[4] + M[8]};
+  real A[16], V[16];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { A[4 * i + j] = (j <= i ? K[4 * i + j] : K[4 * j + i]) / 3; V[4 * i + j] = i == j; } /* (eigh reads the lower triangle) */
+  for (int sweep = 0; sweep < 80; sweep++) {
+    real off = 0;
+    for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) off += fabs(A[4 * i + j]);
+    if (off < (real)1e-300) break;
+    for (int p_ = 0; p_ < 3; p_++) for (int q = p_ + 1; q < 4; q++) {
+      real apq = A[4 * p_ + q];
+      if (apq == 0) continue;
+      real th = (A[4 * q + q] - A[4 * p_ + p_]) / (2 * apq), t = (th >= 0 ? 1 : -1) / (fabs(th) + sqrt(th * th + 1)), cs = 1 / sqrt(t * t + 1), sn = t * cs;
+      for (int k = 0; k < 4; k++) { real akp = A[4 * k + p_], akq = A[4 * k + q]; A[4 * k + p_] = cs * akp - sn * akq; A[4 * k + q] = sn * akp + cs * akq; }
+      for (int k = 0; k < 4; k++) { real apk = A[4 * p_ + k], aqk = A[4 * q + k]; A[4 * p_ + k] = cs * apk - sn * aqk; A[4 * q + k] = sn * apk + cs * aqk; }
+      for (int k = 0; k < 4; k++) { real vkp = V[4 * k + p_], vkq = V[4 * k + q]; V[4 * k + p_] = cs * vkp - sn * vkq; V[4 * k + q] = sn * vkp + cs * vkq; }
+    }
+  }
+  int best = 0;
+  for (int e_ = 1; e_ < 4; e_++) if (A[5 * e_] > A[5 * best]) best = e_;
+  real w = V[4 * 3 + best], x = V[best], y = V[4 + best], z = V[8 + best]; /* q = V[[3, 0, 1, 2], argmax] = (w, x, y, z) */
+  if (w < 0) { w = -w; x = -x; y = -y; z = -z; }
+  q_xyzw[0] = x; q_xyzw[1] = y; q_xyzw[2] = z; q_xyzw[3] = w;
+}
+/* transform_utils (xyzw): quat_multiply and quat_inverse return float32 (:33-50, :99-119), quat2mat works on a float32 copy (:207-229) */
+static void tu_quat_multiply(real *o, const real *q1, const real *q0) {
+  real x0 = q0[0], y0 = q0[1], z0 = q0[2], w0 = q0[3], x1 = q1[0], y1 = q1[1], z1 = q1[2], w1 = q1[3];
+  real r[4] = {x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0, -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0, x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0, -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0};
+  for (int k = 0; k < 4; k++) o[k] = (real)(float)r[k];
+}
+static void tu_quat_inverse(real *o, const real *q) {
+  real d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  real c_[4] = {(real)(float)-q[0], (real)(float)-q[1], (real)(float)-q[2], (real)(float)q[3]};
+  for (int k = 0; k < 4; k++) o[k] = c_[k] / d;
+}
+static void tu_quat2mat(real *R, const real *q_xyzw) {
+  float q[4] = {(float)q_xyzw[3], (float)q_xyzw[0], (float)q_xyzw[1], (float)q_xyzw[2]}; /* wxyz, float32 */
+  float n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n < 2.220446049250313e-16 * 4.0) { for (int k = 0; k < 9; k++) R[k] = (k % 4) == 0; return; }
+  /* numpy >= 2 promotion: `2.0 / n` with n a float32 scalar is a float32; math.sqrt of it a Python float, which the in-place product with the float32 array
+     rounds to float32 again; `1.0 - q[2, 2] - q[3, 3]` stays float32 */
+  const float scf = (float)sqrt((double)(2.0f / n));
+  for (int k = 0; k < 4; k++) q[k] = q[k] * scf;
+  float o[4][4];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) o[i][j] = q[i] * q[j];
+  R[0] = (1.0f - o[2][2]) - o[3][3]; R[1] = o[1][2] - o[3][0]; R[2] = o[1][3] + o[2][0];
+  R[3] = o[1][2] + o[3][0]; R[4] = (1.0f - o[1][1]) - o[3][3]; R[5] = o[2][3] - o[1][0];
+  R[6] = o[1][3] - o[2][0]; R[7] = o[2][3] + o[1][0]; R[8] = (1.0f - o[1][1]) - o[2][2];
+}
+/* _<arm>_hand_quat (furniture.py:3380-3457): mat2quat of the hand's orientation in the frame of the body 'base' (poses of the last forward pass) -> xyzw */
+static void hand_quat(const struct fsim *s, Env *e, int arm, real *q_xyzw) {
+  real Rb[9], Rbt[9], M[9];
+  ik_q2m(Rb, s->m.ik_base_quat);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rbt[3 * i + j] = Rb[3 * j + i];
+  m3mul(M, Rbt, e->xmat + 9 * s->m.hand_bodyid[arm]);
+  tu_mat2quat(q_xyzw, M);
+}
+/* controller.sync_state() + _initial_<arm>_hand_quat at the end of a reset (furniture.py:1643-1650) */
+static void ik_sync(const struct fsim *s, Env *e) {
+  const EnvModel *m = &s->m;
+  for (int a = 0; a < m->narm; a++) {
+    real q[7];
+    for (int k = 0; k < 7; k++) q[k] = e->qpos[m->arm_qposadr[7 * a + k]];
+    hand_quat(s, e, a, e->ik.init_quat[a]);
+    ik_fk(m, q, a, e->ik.tp[a], NULL, NULL, NULL);
+  }
+}
+static int do_simulation(struct fsim *s, Env *e, const real *arm_and_grips);
+/* _do_ik_step (furniture.py:2899-3063) up to the three closed-loop repeats of _do_simulation; returns the unstable flag */
+static int ik_step(struct fsim *s, Env *e, const real *a, int dof) {
+  const EnvModel *m = &s->m;
+  const fsim_config_t *c = &s->cfg;
+  const int quat = c->control_type == 8, nrot = quat ? 4 : 3, na = m->narm;
+  const real sens = m->ik_params[0], gain = m->ik_params[1];
+  const int rest_current = m->ik_params[2] != 0, rz = m->ik_params[3] != 0;
+  real grips[2];
+  for (int arm = 0; arm < na; arm++) {
+    const int o = arm * (3 + nrot);
+    const real *hp = e->xpos + 3 * m->hand_bodyid[arm];
+    real dp[3] = {-a[o + 1] * (real)c->move_speed, a[o] * (real)c->move_speed, a[o + 2] * (real)c->move_speed}, d_pos[3];
+    const real lo[3] = {(real)-1.5 - hp[0], (real)-1.5 - hp[1], (real)0.0 - hp[2]}, hi[3] = {(real)1.5 - hp[0], (real)1.5 - hp[1], (real)1.5 - hp[2]};
+    for (int k = 0; k < 3; k++) d_pos[k] = dp[k] < lo[k] ? lo[k] : (dp[k] > hi[k] ? hi[k] : dp[k]); /* _bounded_d_pos (:170-171, 1252-1258) */
+    real hq[4], d_quat[4], newi[4], t4[4], rot[9];
+    hand_quat(s, e, arm, hq);
+    if (quat) { d_quat[0] = a[o + 4]; d_quat[1] = a[o + 5]; d_quat[2] = a[o + 6]; d_quat[3] = a[o + 3]; memcpy(newi, e->ik.init_quat[arm], sizeof newi); } /* convert_quat(wxyz -> xyzw) */
+    else {
+      /* the reference hands the xyzw quaternion to euler_to_quat, whose pyquaternion reads it as wxyz (:2917-2919): garbled identically here */
+      real deg[3] = {a[o + 3] * (real)c->rotate_speed, a[o + 4] * (real)c->rotate_speed, a[o + 5] * (real)c->rotate_speed}, inv[4];
+      euler_to_quat(newi, deg, e->ik.init_quat[arm]);
+      tu_quat_inverse(inv, hq);
+      tu_quat_multiply(d_quat, inv, newi);
+    }
+    memcpy(e->ik.init_quat[arm], newi, sizeof newi);
+    tu_quat_multiply(t4, hq, d_quat);
+    tu_quat2mat(rot, t4);
+    grips[arm] = a[dof - (1 + na) + arm];
+    for (int k = 0; k < 3; k++) e->ik.tp[arm][k] += d_pos[k] * sens;
+    real tR[9], qa[7];
+    if (rz) { const real Rz[9] = {cos(-M_PI / 2), -sin(-M_PI / 2), 0, sin(-M_PI / 2), cos(-M_PI / 2), 0, 0, 0, 1}; m3mul(tR, rot, Rz); } else memcpy(tR, rot, sizeof tR);
+    for (int k = 0; k < 7; k++) qa[k] = e->qpos[m->arm_qposadr[7 * arm + k]];
+    ik_solve(m, qa, e->ik.tp[arm], tR, arm, rest_current ? qa : NULL, e->ik.q_cmd + 7 * arm);
+  }
+  int bad = 0;
+  for (int rep = 0; rep < 3 && !bad; rep++) { /* _action_repeat = 3 (furniture.py:172): joint P controller, clipped to +-1 (sawyer_ik_controller.py:75-84) */
+    real act[16];
+    for (int k = 0; k < m->narmj; k++) { real v = -gain * (e->qpos[m->arm_qposadr[k]] - e->ik.q_cmd[k]); act[k] = v < -1 ? -1 : (v > 1 ? 1 : v); }
+    for (int arm = 0; arm < na; arm++) act[m->narmj + arm] = grips[arm];
+    bad = do_simulation(s, e, act);
+  }
+  return bad;
+}
+
+/* _setup_action + _do_simulation (furniture.py:3332-3379, 2857-2897) on [arm joints, one gripper command per arm]; returns the unstable flag */
+static int do_simulation(struct fsim *s, Env *e, const real *a) {
+  const EnvModel *m = &s->m;
+  real act[64];
+  int na = m->narmj, n = 0;
+  for (int k = 0; k < na; k++) act[n++] = a[k];
+  for (int arm = 0; arm < m->narm; arm++) { act[n++] = a[na + arm]; act[n++] = -a[na + arm]; }
+  if (s->cfg.rescale_actions) { /* (the clip precedes the gripper mirroring: symmetric bounds, same result) */
+    for (int k = 0; k < n; k++) { real v = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); act[k] = m->ctrl_bias[k] + m->ctrl_weight[k] * v; }
+  }
+  gravity_comp(s, e);
+  for (int k = 0; k < m->nu; k++) e->ctrl[k] = act[k];
+  osim_forward(e->sim);
+  int bad = 0;
+  for (int k = 0; k < s->n_substeps && !bad; k++) bad = osim_step(e->sim);
+  return bad;
+}
+
 static void env_step(struct fsim *s, int idx, const float *action, float *ob, float *reward, uint8_t *done, int32_t *info) {
   const EnvModel *m = &s->m;
   const fsim_config_t *c = &s->cfg;
@@ -1002,20 +1218,12 @@ static void env_step(struct fsim *s, int idx, const float *action, float *ob, fl
       bad = osim_step(e->sim);
     }
     if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
+  } else if (c->control_type == 7 || c->control_type == 8) {
+    const int bad = ik_step(s, e, a, dof);
+    if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
   } else
-  { /* _setup_action + _do_simulation */
-    real act[64];
-    int na = m->narmj, n = 0;
-    for (int k = 0; k < na; k++) act[n++] = a[k];
-    for (int arm = 0; arm < m->narm; arm++) { act[n++] = a[na + arm]; act[n++] = -a[na + arm]; }
-    if (c->rescale_actions) { /* (the clip precedes the gripper mirroring: symmetric bounds, same result) */
-      for (int k = 0; k < n; k++) { real v = act[k] < -1 ? -1 : (act[k] > 1 ? 1 : act[k]); act[k] = m->ctrl_bias[k] + m->ctrl_weight[k] * v; }
-    }
-    gravity_comp(s, e);
-    for (int k = 0; k < m->nu; k++) e->ctrl[k] = act[k];
-    osim_forward(e->sim);
-    int bad = 0;
-    for (int k = 0; k < s->n_substeps && !bad; k++) bad = osim_step(e->sim);
+  {
+    const int bad = do_simulation(s, e, a);
     if (bad) { if (!c->auto_reset) env_reset(s, idx); e->fail = c->auto_reset ? 2 : 1; }
   }
   if (connect > 0 && !e->fail)
@@ -1106,7 +1314,7 @@ static const real *cpu_reals(struct fsim *s, const char *name, int64_t *count) {
   const void *p = blob_get(s->blob, s->nbytes, name, 0, &cnt);
   if (count) *count = cnt;
   if (!p || sizeof(real) == 8) return (const real *)p;
-  if (s->nconv >= 16) return NULL;
+  if (s->nconv >= 32) return NULL;
   real *r = (real *)malloc(sizeof(real) * (size_t)(cnt + 1));
   for (int64_t i = 0; i < cnt; i++) { double v; memcpy(&v, (const char *)p + 8 * i, 8); r[i] = (real)v; }
   s->conv[s->nconv++] = r;
@@ -1128,10 +1336,10 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->ngeom = dims[5]; m->nsite = dims[6]; m->neq = dims[7];
   m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
   m->timestep = opt[0]; m->gravz = opt[3];
-  const int ctrl_kind = s->cfg.control_type >= 2 && s->cfg.control_type <= 6;
-  if ((s->cfg.control_type != 0 && !(ctrl_kind && m->agent == 0 && !s->cfg.dense_reward)) || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
+  const int ctrl_kind = s->cfg.control_type >= 2 && s->cfg.control_type <= 6, ik_kind = s->cfg.control_type == 7 || s->cfg.control_type == 8;
+  if ((s->cfg.control_type != 0 && !(ctrl_kind && m->agent == 0 && !s->cfg.dense_reward) && !(ik_kind && m->agent != 2 && !s->cfg.dense_reward)) || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
     fsim_destroy(s);
-    FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control and the Cursor agent, with the sparse reward (Sawyer: also the dense reward) and fp32 observations (oracle/oracle_env.py checks the rest)");
+    FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control, ik / ik_quaternion and (Sawyer) the torque-level arm controllers, and the Cursor agent, with the sparse reward (Sawyer under impedance control: also the dense reward) and fp32 observations (oracle/oracle_env.py checks the rest)");
   }
   int64_t cnt;
   if (ctrl_kind) { /* as the device: the controllers write joint torques, which only the motor-actuated model (robot_torque.xml, furniture.py:1893) applies as such */
@@ -1165,6 +1373,15 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   { const char *pv = getenv("FSIM_CPU_PERTURB"); s->perturb = pv ? (real)atof(pv) : 0; }
   s->dof = m->agent == 2 ? 15 : m->narmj + m->narm + 1;            /* (move, rotate, select) x 2 + connect, furniture_cursor.py:56 */
   if (s->cfg.control_type >= 2 && s->cfg.control_type <= 6) s->dof = ck_dim(s->cfg.control_type) + 2; /* [arm command, grip, connect] */
+  if (ik_kind) { /* per arm [dpos 3, rotation 3 | quaternion 4], then one gripper command per arm, connect (furniture.py:2911-2958, 2994-3018) */
+    s->dof = m->narm * (3 + (s->cfg.control_type == 8 ? 4 : 3)) + m->narm + 1;
+    int64_t c1 = 0, c2 = 0;
+    m->ik_joint_pos = cpu_reals(s, "ik_joint_pos", &c1); m->ik_joint_quat = cpu_reals(s, "ik_joint_quat", &c2); m->ik_eef_pos = cpu_reals(s, "ik_eef_pos", NULL);
+    m->ik_eef_quat = cpu_reals(s, "ik_eef_quat", NULL); m->ik_rest = cpu_reals(s, "ik_rest", NULL); m->ik_lower = cpu_reals(s, "ik_lower", NULL);
+    m->ik_upper = cpu_reals(s, "ik_upper", NULL); m->ik_params = cpu_reals(s, "ik_params", NULL); m->ik_base_quat = cpu_reals(s, "ik_base_quat", NULL);
+    if (!m->ik_joint_pos || !m->ik_joint_quat || !m->ik_eef_pos || !m->ik_eef_quat || !m->ik_rest || !m->ik_lower || !m->ik_upper || !m->ik_params || !m->ik_base_quat ||
+        c1 != 21 * m->narm || c2 != 28 * m->narm || m->narmj != 7 * m->narm) { fsim_destroy(s); FAIL(FSIM_EINVAL, "control_type ik / ik_quaternion needs a model compiled with the IK chain table"); }
+  }
   s->obs_dim = 7 * m->nparts + (m->agent == 2 ? 8 : (s->cfg.control_type == 0 ? 29 : 15) * m->narm); /* (joint_pos / joint_vel belong to the impedance robot_ob) */
   s->env = (Env *)calloc((size_t)n_envs, sizeof(Env));
   for (int i = 0; i < n_envs; i++) {

@@ -114,6 +114,16 @@ for kind, code in (("position_orientation", 2), ("joint_impedance", 4)):
         o_, r_, d_, i_ = sk.step(counter_actions(1, 0, t, sk.dof)[None])
     assert np.isfinite(o_).all()
     sk.close()
+# ... and control_type ik (Baxter: two arms -- the chain kinematics, the 6 x 6 solves, the 4 x 4 Jacobi of mat2quat)
+bi = load_compiled("Baxter", "table_lack_0825")
+ei = FurnitureEnvOracle(bi, OracleConfig(seed=13, max_episode_steps=4, control_type="ik"))
+ei.reset()
+si = Session(Abi(os.environ["FSIM_CPU_SAN"]), bi.to_blob(), 1, max_episode_steps=4, auto_reset=0, control_type=7)
+si.set_reset_tables(ei.reset_draws["part_qpos"].reshape(1, -1), np.stack(ei.reset_draws["noise"]).reshape(1, -1))
+si.reset()
+o_, r_, d_, i_ = si.step(counter_actions(1, 0, 0, si.dof)[None])
+assert np.isfinite(o_).all()
+si.close()
 # round 6: the Cursor agent -- the MuJoCo-recorded demo's first 64 frames (selection by contact, carried groups, the ten approach steps, the connect)
 from tests.test_demo_replay import D
 c = load_compiled("Cursor", "swivel_chair_0700")
