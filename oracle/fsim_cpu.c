@@ -12,7 +12,7 @@
  * Scope: the arm agents (Sawyer, Baxter) under control_type impedance (Sawyer: also the five torque-level arm controllers, control_type 2..6, end of round 6) and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
  * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
  * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519), control_type ik / ik_quaternion (:2899-3063 over the
- * solver of oracle/ik.py).  phase_ob and reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
+ * solver of oracle/ik.py), config.reset_robot_after_attach (:919-925; fsim_set_attach_noise).  The dense reward's phase_ob / reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
  * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
@@ -116,6 +116,7 @@ struct fsim {
   /* fsim_set_init_state (set_init_qpos): per env, the state its resets start from */
   uint8_t *init_mask;
   float *init_q, *init_v; /* [n][nq], [n][nv] */
+  float *attach_noise;    /* fsim_set_attach_noise: [n][narmj], the joint noise the NEXT attach of each env adds to the arm's initial pose (reset_robot_after_attach) */
 };
 
 /* ---- small vector / quaternion helpers (furniture_amd/transform_utils.py; quaternions wxyz unless said otherwise) */
@@ -259,7 +260,8 @@ static void next_subtask(const struct fsim *s, Env *e) {
 
 static void dense_reset(const struct fsim *s, Env *e);
 static void ik_sync(const struct fsim *s, Env *e);
-static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align);
+static void ik_fk(const EnvModel *m, const real *q, int arm, real *p, real *R, real (*org)[3], real (*axs)[3]);
+static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align, const float *robot_noise);
 static void project_connector_quat(const struct fsim *s, Env *e, int k1, int k2, int has_angle, real angle);
 static void env_reset(const struct fsim *s, int idx) {
   const EnvModel *m = &s->m;
@@ -297,7 +299,9 @@ static void env_reset(const struct fsim *s, int idx) {
        recipe's angle (_project_connector_quat) -- and the latches of a connect cleared */
     for (int i = 0; s->pre_recipe && i < s->n_pre; i++) {
       project_connector_quat(s, e, s->pre_tab[i][0], s->pre_tab[i][1], s->pre_angle[i] == s->pre_angle[i], (real)s->pre_angle[i]);
-      do_connect(s, e, s->pre_tab[i][0], s->pre_tab[i][1], 1);
+      /* (reset_robot_after_attach: this _connect, too, ends with _initialize_robot_pos(); its draw was taken between the placement's and the robot
+         initialisation's and sits behind the latter's 101 rows of the noise table -- as on the device) */
+      do_connect(s, e, s->pre_tab[i][0], s->pre_tab[i][1], 1, (s->tab_noise && s->n_noise > 101 + i) ? s->tab_noise + ((size_t)idx * s->n_noise + 101 + i) * m->narmj : NULL);
       e->connected = 0; e->connected_body1 = -1;
     }
     settle(s, e);
@@ -459,7 +463,7 @@ static void project_connector_quat(const struct fsim *s, Env *e, int k1, int k2,
   } else rotate_vector(fr, f1, up1, angle);
   lookat_wxyz(e->target_quat, up1, fr);
 }
-static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align) {
+static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align, const float *robot_noise) {
   const EnvModel *m = &s->m;
   e->connected_sites |= (1ull << k1) | (1ull << k2);
   e->site1 = m->conn_siteid[k1]; e->site2 = m->conn_siteid[k2];
@@ -509,6 +513,11 @@ static void do_connect(const struct fsim *s, Env *e, int k1, int k2, int align) 
   real q[7]; part_qpos(s, e, pA, q);
   memcpy(e->cb1_pos, q, 3 * sizeof(real)); memcpy(e->cb1_quat, q + 3, 4 * sizeof(real));
   next_subtask(s, e);
+  if (s->cfg.reset_robot_after_attach) { /* furniture.py:919-925: reset robot arm -- one more draw of the env's ONE RandomState (the Cursor agent: no draw, both cursors back at their start) */
+    init_robot(s, e, robot_noise);
+    if (s->cfg.control_type == 7 || s->cfg.control_type == 8) /* controller.sync_state(): the IK target position := the chain's forward kinematics at the new joints */
+      for (int a = 0; a < m->narm; a++) { real qa[7]; for (int k = 0; k < 7; k++) qa[k] = e->qpos[m->arm_qposadr[7 * a + k]]; ik_fk(m, qa, a, e->ik.tp[a], NULL, NULL, NULL); }
+  }
 }
 /* _try_connect(part1, part2) (furniture.py:926-1042; part2 < 0 = None).  With _num_connect_steps > 0 (the Cursor agent: 10) an aligned pair is first
  * APPROACHED over that many calls -- part2's group is moved along a path fixed at the first call (positions on a line to 90 % of the way, slerped
@@ -560,7 +569,7 @@ static int try_connect(const struct fsim *s, Env *e, int part1, int part2) {
           e->connect_step += 1;
           return 0;
         }
-        do_connect(s, e, k1, k2, s->cfg.auto_align);
+        do_connect(s, e, k1, k2, s->cfg.auto_align, s->attach_noise ? s->attach_noise + (size_t)(e - s->env) * m->narmj : NULL);
         e->connect_step = 0;
         return 1;
       }
@@ -1337,7 +1346,7 @@ int fsim_create(const void *model_blob, size_t nbytes, int n_envs, int device, c
   m->nparts = dims[10]; m->narm = dims[12]; m->nconn = dims[13]; m->agent = dims[15];
   m->timestep = opt[0]; m->gravz = opt[3];
   const int ctrl_kind = s->cfg.control_type >= 2 && s->cfg.control_type <= 6, ik_kind = s->cfg.control_type == 7 || s->cfg.control_type == 8;
-  if ((s->cfg.control_type != 0 && !(ctrl_kind && m->agent == 0 && !s->cfg.dense_reward) && !(ik_kind && m->agent != 2 && !s->cfg.dense_reward)) || (s->cfg.dense_reward && m->agent != 0) || s->cfg.reset_robot_after_attach || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
+  if ((s->cfg.control_type != 0 && !(ctrl_kind && m->agent == 0 && !s->cfg.dense_reward) && !(ik_kind && m->agent != 2 && !s->cfg.dense_reward)) || (s->cfg.dense_reward && m->agent != 0) || (s->cfg.reset_robot_after_attach && s->cfg.dense_reward) || s->cfg.obs_bf16 || m->nparts > 32 || m->nconn > 64) {
     fsim_destroy(s);
     FAIL(FSIM_EINVAL, "libfsim_cpu: the native CPU checker covers the arm agents under impedance control, ik / ik_quaternion and (Sawyer) the torque-level arm controllers, and the Cursor agent, with the sparse reward (Sawyer under impedance control: also the dense reward) and fp32 observations (oracle/oracle_env.py checks the rest)");
   }
@@ -1408,7 +1417,7 @@ void fsim_destroy(fsim_t *s) {
   if (!s) return;
   if (s->env) for (int i = 0; i < s->n; i++) if (s->env[i].sim) osim_destroy(s->env[i].sim);
   for (int i = 0; i < s->nconv; i++) free(s->conv[i]);
-  free(s->m.geom_cursor); free(s->m.geom_namepart); free(s->dcoef); free(s->dsub); free(s->init_mask); free(s->init_q); free(s->init_v);
+  free(s->m.geom_cursor); free(s->m.geom_namepart); free(s->dcoef); free(s->dsub); free(s->init_mask); free(s->init_q); free(s->init_v); free(s->attach_noise);
   free(s->env); free(s->blob); free(s->tab_parts); free(s->tab_noise); free(s);
 }
 int fsim_dims(const fsim_t *s, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *dof_action, int32_t *obs_dim, int32_t *info_dim, int32_t *stride) {
@@ -1527,7 +1536,14 @@ int fsim_env_block_words(const fsim_t *s) { (void)s; return 0; }
 int fsim_lookahead_stats(fsim_t *s, int64_t *out) { if (!s || !out) FAIL(FSIM_EINVAL, "null"); memset(out, 0, 6 * sizeof(int64_t)); return FSIM_OK; }
 int fsim_kernel_time_ms(fsim_t *s, double *avg_ms, int32_t *n) { if (!s) FAIL(FSIM_EINVAL, "null"); if (avg_ms) *avg_ms = 0; if (n) *n = 0; return FSIM_OK; }
 #define NOT_SERVED(what) FAIL(FSIM_EINVAL, "libfsim_cpu: " what " is not served by the native CPU checker (oracle/oracle_env.py is the checker for it)")
-int fsim_set_attach_noise(fsim_t *s, const uint8_t *mask, const float *noise) { (void)s; (void)mask; (void)noise; NOT_SERVED("reset_robot_after_attach"); }
+int fsim_set_attach_noise(fsim_t *s, const uint8_t *mask, const float *noise) {
+  if (!s || !noise) FAIL(FSIM_EINVAL, "fsim_set_attach_noise: bad arguments");
+  if (!s->cfg.reset_robot_after_attach) FAIL(FSIM_EINVAL, "fsim_set_attach_noise: only for handles created with reset_robot_after_attach = 1");
+  const int nj = s->m.narmj;
+  if (!s->attach_noise) s->attach_noise = (float *)calloc((size_t)s->n * (nj > 0 ? nj : 1), sizeof(float));
+  for (int i = 0; i < s->n; i++) if (!mask || mask[i]) memcpy(s->attach_noise + (size_t)i * nj, noise + (size_t)i * nj, sizeof(float) * nj);
+  return FSIM_OK;
+}
 int fsim_set_init_state(fsim_t *s, const uint8_t *mask, const float *qpos, const float *qvel) {
   if (!s || (qpos && !qvel)) FAIL(FSIM_EINVAL, "fsim_set_init_state: bad arguments");
   if (qpos && s->n_pre > 0) FAIL(FSIM_EINVAL, "fsim_set_init_state: not combined with pre-assembled starts (fsim_set_preassembled)");

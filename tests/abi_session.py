@@ -44,6 +44,7 @@ class Abi:
         L.fsim_set_dense_reward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.fsim_set_preassembled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.fsim_set_init_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.fsim_set_attach_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 
     def check(self, rc):
         if rc != 0:
@@ -107,6 +108,12 @@ class Session:
         """furniture_amd.dense.pack_dense(model) -> the tables of a dense_reward = 1 handle (host pointers on both libraries)"""
         coef, subtasks = np.ascontiguousarray(coef, dtype=np.float32), np.ascontiguousarray(subtasks, dtype=np.float32)
         self.abi.check(self.abi.L.fsim_set_dense_reward(self.h, coef.ctypes.data, len(coef), subtasks.ctypes.data, len(subtasks)))
+
+    def set_attach_noise(self, noise, mask=None):
+        """config.reset_robot_after_attach: the joint noise [n, narmjoints] the NEXT attach of each env adds to the arm's initial pose (fsim_set_attach_noise)"""
+        nz = np.ascontiguousarray(noise, dtype=np.float32)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.abi.check(self.abi.L.fsim_set_attach_noise(self.h, None if mk is None else mk.ctypes.data, nz.ctypes.data))
 
     def set_init_state(self, qpos, qvel, mask=None):
         """FurnitureEnv.set_init_qpos for the masked envs (qpos = None: back to sampled resets) -- fsim_set_init_state, host pointers on both libraries"""

@@ -373,6 +373,49 @@ def test_native_checker_ik_control_matches_the_python_restatement(cpu_abi, agent
     ses.close()
 
 
+@pytest.mark.parametrize("pre", [None, [0, 2]])
+def test_native_checker_reset_robot_after_attach_matches_the_python_restatement(cpu_abi, sawyer_lack, pre):
+    """config.reset_robot_after_attach in the checker (end of round 6; it refused it): `_connect` ends with `_initialize_robot_pos()` -- one draw of the env's
+    ONE RandomState, which the host hands over ahead of time (fsim_set_attach_noise; here: the draw the Python env took) -- also for the connects of a
+    pre-assembled start, whose draws sit behind the robot initialisation's 101 rows of the reset's noise table.  Scripted pinch + connect: the arm is back at its
+    initial pose (+ noise) after the step, on both sides; integer words, weld data and the observation against the Python env."""
+    m = sawyer_lack
+    n = 2
+    kw = dict(reset_robot_after_attach=True) if pre is None else dict(reset_robot_after_attach=True, preassembled=list(pre))
+    envs = [FurnitureEnvOracle(m, OracleConfig(seed=123 + i, solver_tolerance=1e-8, max_episode_steps=150, **kw)) for i in range(n)]
+    obs_o = [e.reset() for e in envs]
+    parts = np.stack([e.reset_draws["part_qpos"].reshape(-1) for e in envs])
+    # the reset's noise table: its 101 robot-initialisation rows, then the draws of the pre-assembled connects (taken BEFORE them in the stream, stored behind)
+    noise = np.stack([np.concatenate([np.stack(e.reset_draws["noise"]).reshape(-1)] + [np.asarray(d, dtype=np.float64).reshape(-1) for d in e.attach_draws]) for e in envs])
+    npre = 0 if pre is None else len(pre)
+    ses = Session(cpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0, reset_robot_after_attach=1)
+    if pre is not None:
+        ses.set_preassembled(m, pre)
+    ses.set_reset_tables(parts, noise, n_noise=101 + npre)
+    obs = ses.reset()
+    for e in range(n):
+        assert np.abs(obs[e] - envs[e].flat_obs(obs_o[e])).max() < 2e-6, e
+        assert len(envs[e].attach_draws) == npre
+    if pre is not None:  # (the pre-assembled variant is about the reset: the connect inside it re-posed the arm with the table's row 101; the pinch scenario assumes free parts)
+        st = ses.get_state(m, "eq_active", "qpos")
+        assert int(st["eq_active"][0].sum()) == npre and np.abs(st["qpos"][0] - envs[0].sim.data.qpos).max() < 1e-5
+        ses.close()
+        return
+    o = envs[0]
+    a = _scripted_attach(m, o, ses, n)
+    ob, r, d, inf = o.step(a)
+    assert inf["num_connected"] == npre + 1 and len(o.attach_draws) == npre + 1
+    ses.set_attach_noise(np.tile(np.asarray(o.attach_draws[-1], dtype=np.float64), (n, 1)))
+    obs, rew, done, info = ses.step(np.tile(a, (n, 1)))
+    assert (info[0, 0], info[0, 3], info[0, 4], info[0, 6]) == (npre + 1, inf["site1"], inf["site2"], 1)
+    assert abs(float(rew[0]) - r) < 1e-5 * max(1.0, abs(r)) and np.abs(obs[0] - o.flat_obs(ob)).max() < 1e-4
+    st = ses.get_state(m, "qpos", "eq_active", "eq_data")
+    assert np.abs(st["qpos"][0][m.arm_qposadr] - (m.arm_initqpos + o.attach_draws[-1])).max() < 1e-3  # the arm is back at its start (+ the one physics step that follows the connect)
+    assert np.abs(st["qpos"][0] - o.sim.data.qpos).max() < 1e-5
+    assert np.array_equal(st["eq_active"][0], o.sim.model.eq_active) and np.abs(st["eq_data"][0].reshape(-1, 7) - o.sim.model.eq_data).max() < 1e-5
+    ses.close()
+
+
 def _root(g, i):
     while g[i] != i:
         i = g[i]
@@ -644,22 +687,29 @@ def test_other_models_whole_episodes_against_the_native_checker(cpu_abi, agent, 
 
 
 @pytest.mark.gpu
-def test_scripted_attach_in_64_different_envs_device_vs_native(cpu_abi, sawyer_lack):
+@pytest.mark.parametrize("attach_reset", [False, True])
+def test_scripted_attach_in_64_different_envs_device_vs_native(cpu_abi, sawyer_lack, attach_reset):
     """The connect path at scale: 64 envs, each reset from its own table and advanced by three random steps, each then given the pinch
     of tests/scenarios.py built from ITS OWN gripper pose, then the connect action -- _try_connect, _is_aligned, _connect with auto-align,
     the floor lift, _activate_weld, the union-find merge, the reward latches -- and five more steps with the welded pair in the gripper.
     Device against the native checker: attach words, weld state and collision masks equal in every env, weld data to 5e-5 (median), the welded
-    assembly's poses afterwards together in the median (2e-3)."""
+    assembly's poses afterwards together in the median (2e-3).
+    attach_reset: config.reset_robot_after_attach on both sides (the checker serves it since the end of round 6) -- `_connect` ends with the arm back at its
+    initial pose + the joint noise handed over ahead of time (fsim_set_attach_noise, a different draw per env): same integer words, and the re-posed arm."""
     import torch
     from furniture_amd.envs import ResetTableSampler, make_config
     m, n = sawyer_lack, 64
+    akw = dict(reset_robot_after_attach=1) if attach_reset else {}
     ecfg = make_config(unity=False, record_vid=False, furniture_name="table_lack_0825", max_episode_steps=150, seed=31)
     tabs = ResetTableSampler(m, ecfg, 31, 0, n)
-    pair = [Session(Abi(GPU_LIB, torch.device("cuda:0")), m.to_blob(), n, max_episode_steps=150, auto_reset=0),
-            Session(cpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0)]
+    pair = [Session(Abi(GPU_LIB, torch.device("cuda:0")), m.to_blob(), n, max_episode_steps=150, auto_reset=0, **akw),
+            Session(cpu_abi, m.to_blob(), n, max_episode_steps=150, auto_reset=0, **akw)]
     t0 = tabs.draw()
+    attach_noise = np.random.RandomState(4).uniform(-0.001, 0.001, (n, len(m.arm_qposadr))).astype(np.float32)
     for s in pair:
         s.set_reset_tables(*t0)
+        if attach_reset:
+            s.set_attach_noise(attach_noise)
         s.reset()
     for t in range(3):
         a = np.stack([counter_actions(9, i, t, 9) for i in range(n)])
@@ -694,6 +744,16 @@ def test_scripted_attach_in_64_different_envs_device_vs_native(cpu_abi, sawyer_l
     # (the weld data are the parts' relative pose after the 50 pinched substeps that precede the connect: contact dynamics, not arithmetic alone)
     de = np.abs(sg["eq_data"] - sc["eq_data"]).max(axis=1)
     assert np.median(de) < 5e-5 and de.max() < 2e-3, (float(np.median(de)), float(de.max()))
+    if attach_reset:  # the arm of every env that connected is back at its initial pose + ITS noise (one physics step later), on both sides
+        qg, qc = [s.get_state(m, "qpos")["qpos"][:, m.arm_qposadr] for s in pair]
+        hit = ic[:, 0] == 1
+        dq = np.abs(qc[hit] - (m.arm_initqpos + attach_noise[hit])).max(axis=1)  # (the joints keep their velocity through the re-pose: one substep of it on top)
+        print("attach_reset: %d envs connected; arm vs initial pose + noise: median %.1e max %.1e; device vs checker arm joints: max %.1e" % (
+            int(hit.sum()), np.median(dq), dq.max(), np.abs(qg[hit] - qc[hit]).max()))
+        assert np.median(dq) < 2e-3 and dq.max() < 5e-2 and np.abs(qg[hit] - qc[hit]).max() < 1e-3
+        for s in pair:
+            s.close()
+        return
     # five more steps with the welded pair in the gripper (nothing floats any more: the 307 g table top hangs on a 1.2 g leg between the pads).  The
     # velocities of that contact are chatter on both sides; the POSES stay together: medians over the envs
     for t in range(5):
