@@ -424,7 +424,7 @@ def _root(g, i):
 
 def test_native_checker_refuses_what_it_does_not_cover(cpu_abi, sawyer_lack):
     with pytest.raises(RuntimeError, match="native CPU checker covers"):
-        Session(cpu_abi, sawyer_lack.to_blob(), 1, reset_robot_after_attach=1)
+        Session(cpu_abi, sawyer_lack.to_blob(), 1, reset_robot_after_attach=1, dense_reward=1)  # (served with the sparse reward)
     with pytest.raises(RuntimeError, match="native CPU checker covers"):
         Session(cpu_abi, sawyer_lack.to_blob(), 1, control_type=7, dense_reward=1)  # (ik is served with the sparse reward)
     with pytest.raises(RuntimeError, match="native CPU checker covers"):
