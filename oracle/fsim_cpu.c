@@ -12,7 +12,7 @@
  * Scope: the arm agents (Sawyer, Baxter) under control_type impedance (Sawyer: also the five torque-level arm controllers, control_type 2..6, end of round 6) and -- round 6 -- the Cursor agent (BASELINE config 1's), with the sparse
  * reward and -- round 6 -- the dense 8-phase reward of FurnitureSawyerDenseRewardEnv (furniture_sawyer_dense.py:128-577, restated from
  * oracle/dense_reward.py, which the golden vectors pin to the reference), both auto_reset modes, and -- end of round 6 -- pre-assembled starts (fsim_set_preassembled: furniture.py:1476-1503, 1542-1557) and set_init_qpos (fsim_set_init_state: :1505-1519), control_type ik / ik_quaternion (:2899-3063 over the
- * solver of oracle/ik.py), config.reset_robot_after_attach (:919-925; fsim_set_attach_noise).  The dense reward's phase_ob / reset_robot_after_attach are refused (FSIM_EINVAL): the Python oracle env remains their checker.
+ * solver of oracle/ik.py), config.reset_robot_after_attach (:919-925; fsim_set_attach_noise).  The dense reward with reset_robot_after_attach is refused (FSIM_EINVAL): the Python oracle env remains their checker.
  *
  * Reference lines: reset furniture.py:1406-1663; step :364-449; _setup_action :3332-3379; _do_simulation :2857-2897; finger scan
  * :1290-1330; _try_connect :926-1042; _is_aligned :1044-1153; _connect :847-924; _activate_weld :2761-2776; _get_obs :1344-1387 +
@@ -1562,7 +1562,7 @@ int fsim_set_dense_reward(fsim_t *s, const float *coef, int ncoef, const float *
   if (!s || !coef || !subtasks) FAIL(FSIM_EINVAL, "null");
   if (!s->cfg.dense_reward) FAIL(FSIM_EINVAL, "fsim_set_dense_reward: the handle was not created with dense_reward = 1");
   if (ncoef != FSIM_DENSE_NCOEF || nsub < 1 || nsub > 16) FAIL(FSIM_EINVAL, "dense reward: need %d coefficients and 1..16 subtasks", FSIM_DENSE_NCOEF);
-  if (coef[DC_PHASE_OB] != 0.0f || coef[DC_RESET_ROBOT] != 0.0f) NOT_SERVED("phase_ob / reset_robot_after_attach of the dense reward");
+  if (coef[DC_RESET_ROBOT] != 0.0f) NOT_SERVED("reset_robot_after_attach of the dense reward"); /* (phase_ob: the early-pick / early-alignment shortcuts are off, dense_compute; the one-hot observation is the env layer's) */
   free(s->dcoef); free(s->dsub);
   s->dcoef = (float *)malloc(sizeof(float) * ncoef); s->dsub = (float *)malloc(sizeof(float) * DS_WORDS * nsub);
   memcpy(s->dcoef, coef, sizeof(float) * ncoef); memcpy(s->dsub, subtasks, sizeof(float) * DS_WORDS * nsub);
