@@ -1363,11 +1363,11 @@ template <class Ctx> DEV int fs_chol_lds(const Ctx &c, int mp) {
   return bad;
 }
 
-// A system with an island of more than 64 dofs (MAP_HUGE; the 256-slot kernels of the re-step ladder only: furniture whose reset starts with the
-// planks inside each other -- an 81-dof island for table_liden_0921, 84 for bookcase_grevback_0484): every island, small ones included, is factored
+// A system with an island of more than 64 dofs (MAP_HUGE; the 512-slot kernels of the re-step ladder only: furniture whose reset starts with the
+// planks inside each other -- a 72-dof island for table_liden_0921, 84 for bookcase_grevback_0484 -- or eleven planks in one pile): every island, small ones included, is factored
 // in LDS from the dof words alone -- lane = rows d = lane and lane + 64, left-looking, one column of every island per trip (two barriers), the
-// substitutions column-oriented through a vector indexed by island position (Layout::Mp, dead until M p is formed).  ~150 kcycles per solve of an
-// 81-dof island against ~9 k for the register paths: this path serves resets and re-steps of models nothing else can hold, not throughput.
+// substitutions column-oriented through a vector indexed by island position (Layout::Mp, dead until M p is formed).  ~150 kcycles per solve of such an
+// island against ~9 k for the register paths: this path serves resets and re-steps of models nothing else can hold, not throughput.
 template <class Ctx> DEV int fs_chol_all_lds(const Ctx &c, int mp) {
   float *L = c.L;
   float *H = L + c.ly.H, *Y = L + c.ly.Mp;
@@ -1905,7 +1905,7 @@ template <class Ctx> DEV void fs_solve(const Ctx &c, int coupled) {
     mw_post(c, MW_MULM);
   }
   SolSlot S = fs_load_slots(c);
-  SolSlot T[Ctx::NS > 1 ? Ctx::NS - 1 : 1] = {};  // (further slot sets: models with more than 64 contact slots -- Ctx::NS == 2: 128, == 4: 256; dead code otherwise)
+  SolSlot T[Ctx::NS > 1 ? Ctx::NS - 1 : 1] = {};  // (further slot sets: models with more than 64 contact slots -- Ctx::NS == 2: 128, == 8: 512; dead code otherwise)
   if constexpr (Ctx::NS > 1) {
     // several sets: the body-pair cache is not used (its election runs over one set of lanes); every set takes fs_hessian's multi-pass path
     {
