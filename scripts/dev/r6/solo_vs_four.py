@@ -93,3 +93,17 @@ print("mean over steps 4..%d: kernel span alone %.3f ms, shared %.3f ms | slowes
     T - 1, a[:, 0].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(), a[:, 3].mean() / a[:, 2].mean(), a[:, 4].mean(), np.nanmean(a[:, 5]), a[:, 6].mean()))
 print("host time of fsim_step + fsim_sync (k_schedule + step kernel + launch and wake-up latencies): alone %.3f ms, shared %.3f ms; minus the span of the envs: alone %.3f ms, shared %.3f ms" % (
     a[:, 7].mean(), a[:, 8].mean(), (a[:, 7] - a[:, 0]).mean(), (a[:, 8] - a[:, 1]).mean()))
+# who ends the launch when the chip is shared: a four-wave team (the env's previous step took >= K iterations) or a one-wave env, and when it started
+K = int(os.environ.get("FSIM_MW_K", "150"))
+n_team = n_one = 0; off_last = []; off_team = []; off_one = []; late_top = []
+for t in range(5, T):
+    s1, e1, n1, _ = many[t]; prev = many[t - 1][2]
+    team = prev >= K
+    last = int(np.argmax(e1)); k0 = s1.min()
+    n_team += bool(team[last]); n_one += not bool(team[last])
+    off_last.append((s1[last] - k0) / MS)
+    d1 = (e1 - s1) / MS
+    top = np.argsort(-d1)[:16]
+    off_team += list((s1[top][team[top]] - k0) / MS); off_one += list((s1[top][~team[top]] - k0) / MS)
+print("shared layout, steps 5..%d: the env that ends the launch is a team %d times, a one-wave env %d times; it started %.3f ms after the slab's first env on average (max %.2f); of the 16 longest envs of a step the teams start at +%.3f ms, the one-wave envs at +%.3f ms" % (
+    T - 1, n_team, n_one, float(np.mean(off_last)), float(np.max(off_last)), float(np.mean(off_team)) if off_team else float("nan"), float(np.mean(off_one)) if off_one else float("nan")))
