@@ -593,7 +593,11 @@ def main():
                    "wave_cycles_per_env_step": pmc.get("wave_cycles_per_env_step"),
                    "algorithmic_flops_per_env_step": [1.5e6, 5.5e6], "fp32_vector_peak_tflops": 157.3,
                    "achieved_tflops_algorithmic": [1.5e6 * per_gpu_rate / 1e12, 5.5e6 * per_gpu_rate / 1e12],
-                   "pmc_source": "builder-lease PMC passes (per-env-step counts), not this run: %s" % pmc.get("source")}
+                   "pmc_source": "builder-lease PMC passes (per-env-step counts), not this run: %s" % pmc.get("source"),
+                   # (builder-lease measurement of the benchmark's own slab 0, not this run: DESIGN.md section 6 item 6)
+                   "slab_of_1024_alone_vs_one_of_four": {"ms_per_step_alone": 4.15, "ms_per_step_one_of_four": 4.90, "env_slowdown_when_shared": 1.08,
+                                                         "launch_ends_with": "a second-round one-wave env that started ~1 ms late (31 of 35 steps)",
+                                                         "source": "profiles/r06_w_slab_alone_against_one_of_four.txt, profiles/r06_w_same_envs_alone_and_shared_timeline.txt"}}
         line = {
             "metric": "env-steps/sec (whole node), Sawyer+table_lack 4096 envs/GPU" if (args.agent, args.furniture, n, args.dense, args.control_type) == (AGENT, FURNITURE, ENVS_PER_GPU, False, "impedance")
             else "env-steps/sec (whole node), EXPLORATION %s+%s%s %d envs/GPU" % (args.agent, args.furniture, (" dense-reward" if args.dense else "") + ("" if args.control_type == "impedance" else " control_type=" + args.control_type), n), "value": value, "unit": "env-steps/s",
